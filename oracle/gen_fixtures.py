@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE - golden-vector generator (build container only).
+
+Runs the reference's OWN compiled shaders (oracle/ref_runner.py: the prebuilt
+bundle under /root/reference/docs/js, executed unmodified by headless Chromium +
+SwiftShader) on seeded synthetic textures and writes the inputs, the exact
+uniform values and the reference outputs as .npz fixtures under tests/golden/.
+Only numbers are written; no reference text reaches the repository.
+
+    python oracle/gen_fixtures.py [--only NAME_SUBSTRING]
+
+Every fixture holds:  kind, the inputs (state/flow/targets/...), `uniforms`
+(json), `out` (reference output, [K,N,N,4] for logic cases) and `valid`
+(boolean mask of texels whose reference value is defined; see QUAD NOTE).
+
+QUAD NOTE.  logic.frag samples `flow` inside the non-uniform `if(pos != inert)`
+branch, which GLSL ES 1.0 leaves undefined (implicit derivatives in divergent
+control flow).  SwiftShader's behaviour there: in the left-most 2x2 pixel quads
+(x in {0,1}) whose lane 0 (x = 0, even y) is inert, the other three lanes read a
+zero flow texel.  Those (at most 3 per quad) texels are masked out of `valid`;
+everything else is compared bit-for-bit.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_runner import RefRunner  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+INERT = np.float32(-1e6)
+
+
+def rand_state(rng, n, inert_frac=0.0, pos_range=1.0, vel_range=0.01):
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-pos_range, pos_range, (n, n, 2))
+    st[..., 2:] = rng.uniform(-vel_range, vel_range, (n, n, 2))
+    if inert_frac > 0:
+        st[rng.random((n, n)) < inert_frac] = [INERT, INERT, 0, 0]
+    return st
+
+
+def rand_flow(rng, w, h, time, mag=0.01, age=120.0):
+    fl = np.zeros((h, w, 4), np.float32)
+    fl[..., :2] = rng.uniform(-mag, mag, (h, w, 2))
+    fl[..., 2] = time - rng.uniform(0, age, (h, w))     # deposit time (ms), some fully decayed
+    fl[..., 3] = rng.uniform(0, 1, (h, w))
+    return fl
+
+
+def valid_mask(state):
+    """See QUAD NOTE."""
+    n = state.shape[0]
+    inert = (state[..., 0] == INERT) & (state[..., 1] == INERT)
+    valid = np.ones((n, n), bool)
+    for y in range(0, n - 1, 2):
+        if inert[y, 0]:
+            for (yy, xx) in ((y, 1), (y + 1, 0), (y + 1, 1)):
+                if not inert[yy, xx]:
+                    valid[yy, xx] = False
+    return valid
+
+
+def save(name, **arrs):
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-34s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def logic_case(r, name, n, seed, uniforms=None, time0=5000.0, steps=1, view=(48, 48),
+               flow_shape=None, inert_frac=0.09, pos_range=1.0, vel_range=0.01, flow_mag=0.01,
+               with_targets=False, zero_flow=False, state=None, view_size=None):
+    rng = np.random.default_rng(seed)
+    st = rand_state(rng, n, inert_frac, pos_range, vel_range) if state is None else state
+    fw, fh = flow_shape if flow_shape else view
+    t_first = time0 + 1000.0 / 60.0
+    fl = np.zeros((fh, fw, 4), np.float32) if zero_flow else rand_flow(rng, fw, fh, t_first, flow_mag)
+    tg = None
+    if with_targets:
+        tg = np.zeros((n, n, 4), np.float32)
+        tg[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    outs, res = r.logic(st, flow=fl, targets=tg, uniforms=uniforms or {}, time0=time0, steps=steps,
+                        view=view, flow_shape=(fw, fh), view_size=view_size, return_each=True)
+    # chain the validity mask through the trajectory: an undefined texel stays undefined
+    valid = np.ones((steps, n, n), bool)
+    cur, v = st, np.ones((n, n), bool)
+    for k in range(steps):
+        v = v & valid_mask(cur)
+        valid[k] = v
+        cur = outs[k]
+    meta = dict(kind="logic", N=n, steps=steps, times=res["times"], dts=res["dts"],
+                viewSize=res["viewSize"], viewRes=res["viewRes"], flowShape=res["flowShape"],
+                state={k: v for k, v in res["state"].items() if isinstance(v, (int, float))},
+                overrides=uniforms or {}, seed=seed, ref_ms=res["ms"])
+    arrs = dict(state=st, flow=fl, out=np.stack(outs), valid=valid, uniforms=json.dumps(meta))
+    if tg is not None:
+        arrs["targets"] = tg
+    save(name, **arrs)
+
+
+def gen_logic(r, only):
+    cases = [
+        # name, kwargs
+        ("logic_default_64", dict(n=64, seed=101)),
+        ("logic_flow_only_64", dict(n=64, seed=102, uniforms={"noiseWeight": 0})),
+        # preset 'Flow Only' src/demo.main.js:1865-1870
+        ("logic_flow_only_preset_64", dict(n=64, seed=103, uniforms={
+            "flowDecay": 0.001, "forceWeight": 0.014, "noiseWeight": 0})),
+        # preset 'Noise Only' src/demo.main.js:1828-1838
+        ("logic_noise_only_preset_64", dict(n=64, seed=104, uniforms={
+            "flowWeight": 0, "noiseWeight": 0.003, "noiseScale": 1.5, "varyNoiseScale": -30,
+            "noiseSpeed": 0.00025, "varyNoiseSpeed": -0.3})),
+        # tracksStart.tendrils3 target pull (src/demo.main.js:905-909), exaggerated too
+        ("logic_target_64", dict(n=64, seed=105, uniforms={"target": 0.000005, "varyTarget": 1},
+                                 with_targets=True)),
+        ("logic_target_strong_64", dict(n=64, seed=106, uniforms={"target": 0.003, "varyTarget": -0.5},
+                                        with_targets=True)),
+        # speed cap active: large flow forces
+        ("logic_speedcap_64", dict(n=64, seed=107, uniforms={"forceWeight": 0.2}, flow_mag=0.05,
+                                   vel_range=0.05)),
+        ("logic_all_inert_64", dict(n=64, seed=108, inert_frac=1.1)),
+        # non-square view: viewSize = coverAspect([96,54]) = [1, 1.7778]; particles beyond the view
+        ("logic_viewsize_64", dict(n=64, seed=109, view=(96, 54), pos_range=1.5)),
+        # trajectories: K = 8 steps, flow held fixed
+        ("logic_multistep_64", dict(n=64, seed=110, steps=8, time0=1000.0)),
+        # non power-of-two state texture (pins `/dataRes`)
+        ("logic_npot_48", dict(n=48, seed=111, view=(40, 30))),
+        # C1: 256x256, fresh (zero) flow, default state, first tick from t=0
+        ("logic_c1_256", dict(n=256, seed=12345, time0=0.0, view=(256, 256), zero_flow=True,
+                              inert_frac=0.0)),
+        # late time (time*noiseSpeed large) + long-decayed flow
+        ("logic_latetime_64", dict(n=64, seed=112, time0=3.6e6)),
+    ]
+    for name, kw in cases:
+        if only and only not in name:
+            continue
+        logic_case(r, name, **kw)
+
+    # zero speed -> 0/0 = NaN (src/logic.frag:92-94): zero velocity, no forces
+    if not only or "zero_speed" in only:
+        rng = np.random.default_rng(113)
+        st = rand_state(rng, 32, 0.0)
+        st[::2, :, 2:] = 0.0
+        logic_case(r, "logic_zero_speed_32", n=32, seed=113, uniforms={"noiseWeight": 0},
+                   zero_flow=True, state=st, view=(32, 32))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    r = RefRunner()
+    print("oracle:", r.probe())
+    gen_logic(r, args.only)
+
+
+if __name__ == "__main__":
+    main()

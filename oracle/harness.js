@@ -1,0 +1,203 @@
+/*
+ * TEST INFRASTRUCTURE - oracle harness (runs ONLY in the build container).
+ *
+ * Appended (at fixture-generation time, in /tmp) after the reference's own
+ * prebuilt UMD bundle /root/reference/docs/js/index.js and loaded by kaleido's
+ * headless Chromium (SwiftShader software WebGL 1) in place of plotly.js.
+ * It drives the reference's *own* Tendrils/Particles objects and compiled
+ * shaders on caller-supplied textures and returns readPixels(FLOAT) output.
+ * Nothing in here restates the reference's arithmetic: it is pure plumbing.
+ *
+ * Job kinds (fig.layout.job):
+ *   {kind:'probe'}                       -> renderer / extension info
+ *   {kind:'logic', ...}                  -> reference Tendrils.step() K times
+ *   {kind:'shader', ...}                 -> one full-screen pass of a compiled
+ *                                           reference shader string (spawners,
+ *                                           optical flow) handed in by python
+ */
+(function () {
+  function b64ToBytes(s) {
+    var bin = atob(s), n = bin.length, out = new Uint8Array(n);
+    for (var i = 0; i < n; ++i) out[i] = bin.charCodeAt(i);
+    return out;
+  }
+  function bytesToB64(u8) {
+    var parts = [], CH = 0x8000;
+    for (var i = 0; i < u8.length; i += CH)
+      parts.push(String.fromCharCode.apply(null, u8.subarray(i, Math.min(i + CH, u8.length))));
+    return btoa(parts.join(''));
+  }
+  function f32FromB64(s) { return new Float32Array(b64ToBytes(s).buffer); }
+  function f32ToB64(f) { return bytesToB64(new Uint8Array(f.buffer, f.byteOffset, f.byteLength)); }
+
+  function getGL(w, h, T) {
+    var c = document.createElement('canvas');
+    c.width = w; c.height = h;
+    var gl = c.getContext('webgl', T ? T.glSettings : {preserveDrawingBuffer: true});
+    if (!gl) throw new Error('no webgl');
+    if (!gl.getExtension('OES_texture_float')) throw new Error('no OES_texture_float');
+    gl.getExtension('WEBGL_color_buffer_float');
+    gl.getExtension('EXT_float_blend');
+    return gl;
+  }
+
+  function uploadF32(gl, handle, w, h, f32) {
+    gl.bindTexture(gl.TEXTURE_2D, handle);
+    gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGBA, w, h, 0, gl.RGBA, gl.FLOAT, f32);
+  }
+
+  function readFBO(gl, w, h) {
+    var px = new Float32Array(4 * w * h);
+    gl.readPixels(0, 0, w, h, gl.RGBA, gl.FLOAT, px);
+    return px;
+  }
+
+  // ---- reference Tendrils.step() driven on supplied textures ---------------
+  function runLogic(job) {
+    var T = window.Tendrils, N = job.N;
+    var gl = getGL(job.viewW, job.viewH, T);
+    var t = new T.Tendrils(gl, {});
+    t.resize();              // viewRes <- canvas; viewSize <- coverAspect; flow.shape <- viewRes
+    t.setup(N);              // reference default: 2 state buffers, inert spawn
+    if (job.flowW) t.flow.shape = [job.flowW, job.flowH];
+    if (job.viewSize) { t.viewSize[0] = job.viewSize[0]; t.viewSize[1] = job.viewSize[1]; }
+    var k;
+    for (k in (job.state || {})) t.state[k] = job.state[k];
+
+    var st = f32FromB64(job.inputs.state);
+    for (var b = 0; b < t.particles.buffers.length; ++b)
+      uploadF32(gl, t.particles.buffers[b].color[0].handle, N, N, st);
+    if (job.inputs.flow)
+      uploadF32(gl, t.flow.color[0].handle, t.flow.shape[0], t.flow.shape[1], f32FromB64(job.inputs.flow));
+    if (job.inputs.targets)
+      uploadF32(gl, t.targets.color[0].handle, N, N, f32FromB64(job.inputs.targets));
+
+    t.timer.time = job.time0;
+    if (job.rate != null) t.timer.rate = job.rate;
+    var outs = [], times = [], dts = [];
+    var rows = job.rows || null;   // optional [y0, y1) bands to return instead of everything
+    var t0 = performance.now();
+    for (var s = 0; s < job.steps; ++s) {
+      t.timer.tick();
+      t.step();
+      times.push(t.timer.time); dts.push(t.timer.dt);
+      if (job.returnEach || s === job.steps - 1) {
+        t.particles.buffers[0].bind();
+        if (rows) {
+          var bands = [];
+          for (var r = 0; r < rows.length; ++r) {
+            var px = new Float32Array(4 * N * (rows[r][1] - rows[r][0]));
+            gl.readPixels(0, rows[r][0], N, rows[r][1] - rows[r][0], gl.RGBA, gl.FLOAT, px);
+            bands.push(f32ToB64(px));
+          }
+          outs.push(bands);
+        } else {
+          outs.push(f32ToB64(readFBO(gl, N, N)));
+        }
+      }
+    }
+    var ms = performance.now() - t0;
+    return {out: outs, times: times, dts: dts, ms: ms,
+            viewSize: [t.viewSize[0], t.viewSize[1]], viewRes: [t.viewRes[0], t.viewRes[1]],
+            flowShape: [t.flow.shape[0], t.flow.shape[1]],
+            state: t.state, err: gl.getError()};
+  }
+
+  // ---- one full-screen pass of a compiled reference shader -----------------
+  function compile(gl, type, src) {
+    var sh = gl.createShader(type);
+    gl.shaderSource(sh, src); gl.compileShader(sh);
+    if (!gl.getShaderParameter(sh, gl.COMPILE_STATUS)) throw new Error(gl.getShaderInfoLog(sh));
+    return sh;
+  }
+  function makeTex(gl, spec) {
+    var tex = gl.createTexture();
+    gl.bindTexture(gl.TEXTURE_2D, tex);
+    gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MIN_FILTER, gl.NEAREST);
+    gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MAG_FILTER, gl.NEAREST);
+    gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_S, gl.CLAMP_TO_EDGE);
+    gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_WRAP_T, gl.CLAMP_TO_EDGE);
+    if (spec.type === 'u8') {
+      gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGBA, spec.w, spec.h, 0, gl.RGBA, gl.UNSIGNED_BYTE,
+                    spec.data ? b64ToBytes(spec.data) : null);
+    } else {
+      gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGBA, spec.w, spec.h, 0, gl.RGBA, gl.FLOAT,
+                    spec.data ? f32FromB64(spec.data) : null);
+    }
+    return tex;
+  }
+  function runShader(job) {
+    var gl = getGL(job.outW, job.outH, null);
+    var prog = gl.createProgram();
+    gl.attachShader(prog, compile(gl, gl.VERTEX_SHADER, job.vert));
+    gl.attachShader(prog, compile(gl, gl.FRAGMENT_SHADER, job.frag));
+    gl.bindAttribLocation(prog, 0, 'position');
+    gl.linkProgram(prog);
+    if (!gl.getProgramParameter(prog, gl.LINK_STATUS)) throw new Error(gl.getProgramInfoLog(prog));
+    gl.useProgram(prog);
+
+    // render target: RGBA32F, optionally pre-filled (for the blended optical-flow pass)
+    var dst = makeTex(gl, {type: 'f32', w: job.outW, h: job.outH, data: job.dst || null});
+    var fbo = gl.createFramebuffer();
+    gl.bindFramebuffer(gl.FRAMEBUFFER, fbo);
+    gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT0, gl.TEXTURE_2D, dst, 0);
+    if (gl.checkFramebufferStatus(gl.FRAMEBUFFER) !== gl.FRAMEBUFFER_COMPLETE) throw new Error('fbo incomplete');
+    if (!job.dst) { gl.clearColor(0, 0, 0, 0); gl.clear(gl.COLOR_BUFFER_BIT); }
+
+    var unit = 0, name;
+    for (name in (job.textures || {})) {
+      var tex = makeTex(gl, job.textures[name]);
+      gl.activeTexture(gl.TEXTURE0 + unit);
+      gl.bindTexture(gl.TEXTURE_2D, tex);
+      gl.uniform1i(gl.getUniformLocation(prog, name), unit);
+      ++unit;
+    }
+    for (name in (job.uniforms || {})) {
+      var v = job.uniforms[name], loc = gl.getUniformLocation(prog, name);
+      if (loc === null) continue;
+      if (typeof v === 'number') gl.uniform1f(loc, v);
+      else if (v.length === 2) gl.uniform2f(loc, v[0], v[1]);
+      else if (v.length === 3) gl.uniform3f(loc, v[0], v[1], v[2]);
+      else if (v.length === 4) gl.uniform4f(loc, v[0], v[1], v[2], v[3]);
+      else if (v.length === 9) gl.uniformMatrix3fv(loc, false, new Float32Array(v));
+    }
+
+    if (job.blend) { gl.enable(gl.BLEND); gl.blendFunc(gl.SRC_ALPHA, gl.ONE_MINUS_SRC_ALPHA); }
+    else gl.disable(gl.BLEND);
+
+    // gl-big-triangle geometry
+    var vb = gl.createBuffer();
+    gl.bindBuffer(gl.ARRAY_BUFFER, vb);
+    gl.bufferData(gl.ARRAY_BUFFER, new Float32Array([-1, -1, -1, 4, 4, -1]), gl.STATIC_DRAW);
+    gl.enableVertexAttribArray(0);
+    gl.vertexAttribPointer(0, 2, gl.FLOAT, false, 0, 0);
+    gl.viewport(0, 0, job.outW, job.outH);
+    gl.drawArrays(gl.TRIANGLES, 0, 3);
+    return {out: f32ToB64(readFBO(gl, job.outW, job.outH)), err: gl.getError()};
+  }
+
+  window.Plotly = {
+    version: '2.0.0',
+    toImage: function (fig) {
+      var res;
+      try {
+        var job = fig.layout.job;
+        if (job.kind === 'probe') {
+          var gl = getGL(4, 4, window.Tendrils);
+          var dbg = gl.getExtension('WEBGL_debug_renderer_info');
+          var pf = gl.getShaderPrecisionFormat(gl.FRAGMENT_SHADER, gl.HIGH_FLOAT);
+          res = {keys: Object.keys(window.Tendrils),
+                 renderer: dbg ? gl.getParameter(dbg.UNMASKED_RENDERER_WEBGL) : gl.getParameter(gl.RENDERER),
+                 highp: [pf.rangeMin, pf.rangeMax, pf.precision],
+                 maxTex: gl.getParameter(gl.MAX_TEXTURE_SIZE),
+                 threads: navigator.hardwareConcurrency};
+        } else if (job.kind === 'logic') res = runLogic(job);
+        else if (job.kind === 'shader') res = runShader(job);
+        else res = {error: 'unknown job kind'};
+      } catch (e) {
+        res = {error: String(e), stack: e && e.stack};
+      }
+      return Promise.resolve(JSON.stringify(res));
+    }
+  };
+})();

@@ -1,0 +1,135 @@
+"""TEST INFRASTRUCTURE - ctypes binding of oracle/libtendrils_oracle.so.
+
+CPU restatement of the reference's particle path (see tendrils_oracle.c).  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module; the product package (tendrils_amd/) must never do so.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtendrils_oracle.so")
+
+INERT = np.float32(-1000000.0)
+
+# reference defaults: /root/reference/src/index.js:28-66 (state) and timer step 1000/60 (:67)
+DEFAULT_STATE = dict(
+    damping=0.043, speedLimit=0.01,
+    forceWeight=0.016, varyForce=-0.1,
+    flowWeight=1.0, varyFlow=0.2,
+    noiseWeight=0.002, varyNoise=0.3,
+    flowDecay=0.005,
+    noiseScale=2.125, varyNoiseScale=0.5,
+    noiseSpeed=0.00025, varyNoiseSpeed=0.1,
+    target=0.0, varyTarget=1.0,
+)
+
+
+class LogicUniforms(C.Structure):
+    _fields_ = [("data_w", C.c_int32), ("data_h", C.c_int32),
+                ("viewSize", C.c_float * 2),
+                ("time", C.c_float), ("dt", C.c_float),
+                ("speedLimit", C.c_float), ("damping", C.c_float),
+                ("forceWeight", C.c_float), ("flowWeight", C.c_float), ("noiseWeight", C.c_float),
+                ("flowDecay", C.c_float),
+                ("noiseSpeed", C.c_float), ("noiseScale", C.c_float),
+                ("target", C.c_float),
+                ("varyForce", C.c_float), ("varyFlow", C.c_float), ("varyNoise", C.c_float),
+                ("varyNoiseScale", C.c_float), ("varyNoiseSpeed", C.c_float), ("varyTarget", C.c_float)]
+
+
+class OpticalFlowUniforms(C.Structure):
+    _fields_ = [("viewSize", C.c_float * 2), ("scaleUV", C.c_float * 2),
+                ("offset", C.c_float), ("lambda_", C.c_float),
+                ("time", C.c_float), ("speed", C.c_float), ("speedLimit", C.c_float)]
+
+
+class SpawnBallUniforms(C.Structure):
+    _fields_ = [("radius", C.c_float), ("speed", C.c_float)]
+
+
+class SpawnSampleUniforms(C.Structure):
+    _fields_ = [("data_w", C.c_int32), ("data_h", C.c_int32),
+                ("spawnSize", C.c_float * 2), ("jitter", C.c_float * 2),
+                ("time", C.c_float), ("speed", C.c_float), ("bias", C.c_float),
+                ("flowDecay", C.c_float),
+                ("spawnMatrix", C.c_float * 9),
+                ("samples", C.c_int32), ("apply", C.c_int32)]
+
+
+def build(force=False):
+    src = [os.path.join(HERE, f) for f in ("tendrils_oracle.c", "tendrils_oracle.h", "Makefile")]
+    if force or not os.path.exists(LIB_PATH) or \
+            any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-C", HERE, "-B", "libtendrils_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.to_snoise3.restype = C.c_float
+        L.to_snoise3.argtypes = [C.c_float] * 3
+        L.to_logic_step.restype = None
+        L.to_logic_step.argtypes = [C.POINTER(LogicUniforms), fp, fp, C.c_int, C.c_int,
+                                    fp, C.c_int, C.c_int, fp]
+        L.to_spawn_init.restype = None
+        L.to_spawn_init.argtypes = [fp, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def logic_uniforms(data_w, data_h, time, dt, view_size=(1.0, 1.0), **state):
+    s = dict(DEFAULT_STATE)
+    for k, v in state.items():
+        if k in s:
+            s[k] = v
+    u = LogicUniforms()
+    u.data_w, u.data_h = int(data_w), int(data_h)
+    u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+    u.time, u.dt = float(time), float(dt)     # double -> fp32 exactly as gl.uniform1f does
+    for k, v in s.items():
+        setattr(u, k, float(v))
+    return u
+
+
+def snoise3(x, y, z):
+    return lib().to_snoise3(float(x), float(y), float(z))
+
+
+def logic_step(u, state, flow, targets=None, y0=0):
+    """state: [rows, W, 4] f32 band starting at global row y0; flow: [fh, fw, 4]."""
+    state = np.ascontiguousarray(state, np.float32)
+    flow = np.ascontiguousarray(flow, np.float32)
+    rows, W = state.shape[:2]
+    assert W == u.data_w and state.shape[2] == 4
+    out = np.empty_like(state)
+    tp = None
+    if targets is not None:
+        targets = np.ascontiguousarray(targets, np.float32)
+        assert targets.shape == state.shape
+        tp = _fp(targets)
+    fh, fw = flow.shape[:2]
+    lib().to_logic_step(C.byref(u), _fp(state), _fp(out), int(y0), int(rows), _fp(flow), fw, fh, tp)
+    return out
+
+
+def spawn_init(shape):
+    out = np.empty(tuple(shape) + (4,), np.float32)
+    lib().to_spawn_init(_fp(out), out.size // 4)
+    return out

@@ -1,0 +1,133 @@
+"""TEST INFRASTRUCTURE - runs the reference itself (build container only).
+
+Drives the reference's own prebuilt bundle (/root/reference/docs/js/index.js: UMD
+`Tendrils`, compiled logic.frag inlined) and the compiled shader strings of
+/root/reference/docs/js/demo.js inside kaleido's headless Chromium + SwiftShader
+(software WebGL 1, fp32 highp).  Used only by oracle/gen_fixtures.py to produce
+the numeric golden vectors under tests/golden/.  The reference text is read at
+run time from /root/reference, concatenated with oracle/harness.js in /tmp and
+never written into this repository.  Not importable on the GPU box (no
+/root/reference there) - nothing in tests/, bench.py or the product imports it.
+"""
+import base64
+import json
+import os
+import re
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _b64(a, dtype):
+    return base64.b64encode(np.ascontiguousarray(a, dtype=dtype).tobytes()).decode()
+
+
+def _f32(s, shape):
+    return np.frombuffer(base64.b64decode(s), dtype=np.float32).reshape(shape).copy()
+
+
+class RefRunner:
+    def __init__(self):
+        from kaleido.scopes.plotly import PlotlyScope
+
+        self._tmp = tempfile.mkdtemp(prefix="tendrils_oracle_")
+        stub = os.path.join(self._tmp, "stub.js")
+        with open(os.path.join(REF, "docs/js/index.js")) as f:
+            bundle = f.read()
+        with open(os.path.join(HERE, "harness.js")) as f:
+            harness = f.read()
+        with open(stub, "w") as f:
+            f.write(bundle + "\n" + harness)
+        self._scope = PlotlyScope(plotlyjs="file://" + stub)
+        self._demo_shaders = None
+
+    def _run(self, job):
+        raw = self._scope.transform({"data": [], "layout": {"job": job}}, format="svg")
+        res = json.loads(raw.decode())
+        if "error" in res:
+            raise RuntimeError("oracle harness: %s\n%s" % (res["error"], res.get("stack")))
+        return res
+
+    def probe(self):
+        return self._run({"kind": "probe"})
+
+    # -- reference Tendrils.step() ------------------------------------------------
+    def logic(self, state, flow=None, targets=None, uniforms=None, time0=0.0, steps=1,
+              view=(64, 64), flow_shape=None, view_size=None, return_each=False, rows=None):
+        """state: [N,N,4] f32 indexed [y][x][c]; flow: [H,W,4]; returns list of [N,N,4]."""
+        N = state.shape[0]
+        assert state.shape == (N, N, 4)
+        job = {"kind": "logic", "N": N, "viewW": int(view[0]), "viewH": int(view[1]),
+               "state": uniforms or {}, "time0": float(time0), "steps": int(steps),
+               "returnEach": bool(return_each),
+               "inputs": {"state": _b64(state, np.float32)}}
+        if flow is not None:
+            fh, fw = flow.shape[:2]
+            if flow_shape is None:
+                flow_shape = (fw, fh)
+            assert (fw, fh) == tuple(flow_shape)
+            job["inputs"]["flow"] = _b64(flow, np.float32)
+        if flow_shape is not None:
+            job["flowW"], job["flowH"] = int(flow_shape[0]), int(flow_shape[1])
+        if targets is not None:
+            job["inputs"]["targets"] = _b64(targets, np.float32)
+        if view_size is not None:
+            job["viewSize"] = [float(view_size[0]), float(view_size[1])]
+        if rows is not None:
+            job["rows"] = [[int(a), int(b)] for a, b in rows]
+        res = self._run(job)
+        if res.get("err"):
+            raise RuntimeError("GL error %s" % res["err"])
+        if rows is not None:
+            outs = [[_f32(b, (r[1] - r[0], N, 4)) for b, r in zip(bands, rows)] for bands in res["out"]]
+        else:
+            outs = [_f32(o, (N, N, 4)) for o in res["out"]]
+        return outs, res
+
+    # -- compiled shader strings of demo.js --------------------------------------
+    def demo_shaders(self):
+        if self._demo_shaders is None:
+            with open(os.path.join(REF, "docs/js/demo.js")) as f:
+                s = f.read()
+            lits = re.findall(r'"((?:[^"\\]|\\.)*?GLSLIFY(?:[^"\\]|\\.)*?)"', s)
+            lits = [t.encode().decode("unicode_escape") for t in lits]
+            out = {}
+            for t in lits:
+                if "attribute vec2 position" in t and "uv = position" in t and "viewSize" not in t:
+                    out.setdefault("screen_vert", t)
+                elif "uniform float radius;" in t and "randoms" in t:
+                    out["spawn_ball"] = t
+                elif "uniform sampler2D last;" in t and "gradMag" in t:
+                    out["optical_flow"] = t
+                elif "spawnData" in t and "const float samples = 5.0" in t and "flowDecay" in t:
+                    out["spawn_flow_sample"] = t
+                elif "spawnData" in t and "const float samples = 2.0" in t:
+                    out["spawn_data_sample"] = t
+                elif "const vec2 pos = vec2(inert)" in t or ("vec4(pos, vel)" in t and "inert" in t):
+                    out["spawn_init"] = t
+            self._demo_shaders = out
+        return self._demo_shaders
+
+    def shader(self, frag, out_shape, textures=None, uniforms=None, blend=False, dst=None):
+        """One big-triangle pass of compiled reference shader `frag` (name in demo_shaders())."""
+        sh = self.demo_shaders()
+        w, h = out_shape
+        tex = {}
+        for name, arr in (textures or {}).items():
+            th, tw = arr.shape[:2]
+            if arr.dtype == np.uint8:
+                tex[name] = {"type": "u8", "w": tw, "h": th, "data": _b64(arr, np.uint8)}
+            else:
+                tex[name] = {"type": "f32", "w": tw, "h": th, "data": _b64(arr, np.float32)}
+        job = {"kind": "shader", "vert": sh["screen_vert"], "frag": sh[frag],
+               "outW": int(w), "outH": int(h), "textures": tex, "uniforms": uniforms or {},
+               "blend": bool(blend)}
+        if dst is not None:
+            job["dst"] = _b64(dst, np.float32)
+        res = self._run(job)
+        if res.get("err"):
+            raise RuntimeError("GL error %s" % res["err"])
+        return _f32(res["out"], (h, w, 4))

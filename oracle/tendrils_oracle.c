@@ -1,0 +1,224 @@
+/*
+ * TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C, strict IEEE fp32, no FMA contraction) of the
+ * reference's GPGPU particle path, used only as the parity checker by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+ * (tendrils_amd/) never links, loads or calls anything in this file.
+ *
+ * Parity status: PINNED.  Every function below is checked against golden
+ * vectors captured from the reference's own compiled shaders executed in this
+ * build container (oracle/gen_fixtures.py -> tests/golden/), see
+ * tests/test_oracle_golden.py.  to_logic_step is bit-exact against those
+ * captures; tolerances for the other passes are stated in the tests.
+ *
+ * Build: oracle/Makefile (-O2 -ffp-contract=off, no -ffast-math: every
+ * `a*b+c` below is two correctly rounded fp32 operations, which is what the
+ * reference's shader compiler emitted in the captures).
+ *
+ * Each function cites the reference file:line it follows
+ * (paths relative to /root/reference).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "tendrils_oracle.h"
+
+/* ------------------------------------------------------------------------- */
+/* glsl-noise 0.0.0 simplex/3d (Ashima/McEwan `snoise(vec3)`), required by    */
+/* src/logic.frag:36; source is not vendored under src/, the compiled text    */
+/* is inlined in docs/js/index.js:56 (shader lines 48-138).  Algorithm        */
+/* restated per component; association order as in the GLSL expressions.      */
+/* ------------------------------------------------------------------------- */
+
+static inline float mod289f(float x)
+{
+    /* mod289: x - floor(x * (1.0 / 289.0)) * 289.0 */
+    const float inv289 = 1.0f / 289.0f;
+    return x - floorf(x * inv289) * 289.0f;
+}
+
+static inline float permutef(float x)
+{
+    /* permute: mod289(((x*34.0)+1.0)*x) */
+    return mod289f(((x * 34.0f) + 1.0f) * x);
+}
+
+static inline float stepf(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+
+static inline float dot3f(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return ax * bx + ay * by + az * bz;
+}
+
+float to_snoise3(float vx, float vy, float vz)
+{
+    const float Cx = 1.0f / 6.0f, Cy = 1.0f / 3.0f;
+    const float n_ = 0.142857142857f;
+    const float nsx = n_ * 2.0f - 0.0f, nsy = n_ * 0.5f - 1.0f, nsz = n_ * 1.0f - 0.0f;
+
+    /* first corner */
+    float s = dot3f(vx, vy, vz, Cy, Cy, Cy);
+    float ix = floorf(vx + s), iy = floorf(vy + s), iz = floorf(vz + s);
+    float t = dot3f(ix, iy, iz, Cx, Cx, Cx);
+    float x0x = vx - ix + t, x0y = vy - iy + t, x0z = vz - iz + t;
+
+    /* other corners */
+    float gx = stepf(x0y, x0x), gy = stepf(x0z, x0y), gz = stepf(x0x, x0z);
+    float lx = 1.0f - gx, ly = 1.0f - gy, lz = 1.0f - gz;
+    float i1x = fminf(gx, lz), i1y = fminf(gy, lx), i1z = fminf(gz, ly);
+    float i2x = fmaxf(gx, lz), i2y = fmaxf(gy, lx), i2z = fmaxf(gz, ly);
+
+    float cx[4][3]; /* offsets from each simplex corner */
+    cx[0][0] = x0x;             cx[0][1] = x0y;             cx[0][2] = x0z;
+    cx[1][0] = x0x - i1x + Cx;  cx[1][1] = x0y - i1y + Cx;  cx[1][2] = x0z - i1z + Cx;
+    cx[2][0] = x0x - i2x + Cy;  cx[2][1] = x0y - i2y + Cy;  cx[2][2] = x0z - i2z + Cy;
+    cx[3][0] = x0x - 0.5f;      cx[3][1] = x0y - 0.5f;      cx[3][2] = x0z - 0.5f;
+
+    /* permutations */
+    ix = mod289f(ix); iy = mod289f(iy); iz = mod289f(iz);
+    const float oz[4] = {0.0f, i1z, i2z, 1.0f};
+    const float oy[4] = {0.0f, i1y, i2y, 1.0f};
+    const float ox[4] = {0.0f, i1x, i2x, 1.0f};
+
+    float acc = 0.0f, mm[4], gd[4];
+    for (int k = 0; k < 4; ++k) {
+        float p = permutef(permutef(permutef(iz + oz[k]) + iy + oy[k]) + ix + ox[k]);
+
+        /* gradient: 7x7 points over a square, mapped onto an octahedron */
+        float j = p - 49.0f * floorf(p * nsz * nsz);
+        float x_ = floorf(j * nsz);
+        float y_ = floorf(j - 7.0f * x_);
+        float x = x_ * nsx + nsy;
+        float y = y_ * nsx + nsy;
+        float h = 1.0f - fabsf(x) - fabsf(y);
+        float sx = floorf(x) * 2.0f + 1.0f;
+        float sy = floorf(y) * 2.0f + 1.0f;
+        float sh = -stepf(h, 0.0f);
+        float px = x + sx * sh, py = y + sy * sh, pz = h;
+
+        /* normalise (taylorInvSqrt) */
+        float norm = 1.79284291400159f - 0.85373472095314f * dot3f(px, py, pz, px, py, pz);
+        px *= norm; py *= norm; pz *= norm;
+
+        float m = fmaxf(0.6f - dot3f(cx[k][0], cx[k][1], cx[k][2], cx[k][0], cx[k][1], cx[k][2]), 0.0f);
+        m = m * m;
+        mm[k] = m * m;
+        gd[k] = dot3f(px, py, pz, cx[k][0], cx[k][1], cx[k][2]);
+    }
+    acc = mm[0] * gd[0] + mm[1] * gd[1] + mm[2] * gd[2] + mm[3] * gd[3];
+    return 42.0f * acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* src/logic.frag                                                             */
+/* ------------------------------------------------------------------------- */
+
+/* src/logic.frag:41-43 */
+static inline float varyf(float base, float offset, float variance)
+{
+    return base + (offset * variance * base);
+}
+
+/* NEAREST + CLAMP_TO_EDGE texel fetch (gl-fbo colour textures: docs/js/index.js:42) */
+static inline int nearest_texel(float u, int n)
+{
+    float f = floorf(u * (float)n);
+    if (!(f > 0.0f)) return 0;          /* also catches NaN */
+    if (f > (float)(n - 1)) return n - 1;
+    return (int)f;
+}
+
+/* src/flow/get.glsl:3-5 */
+static inline void flow_get(const float *texel, float time, float decay, float *fx, float *fy)
+{
+    float k = fmaxf(0.0f, 1.0f - ((time - texel[2]) * decay));
+    *fx = texel[0] * k;
+    *fy = texel[1] * k;
+}
+
+/* One fragment of src/logic.frag:45-101 at global texel (x, y). */
+static void logic_texel(const to_logic_uniforms *u, int x, int y, const float *in,
+                        const float *flow, int fw, int fh, const float *target_texel, float *out)
+{
+    const float W = (float)u->data_w, H = (float)u->data_h;
+    float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;    /* gl_FragCoord.xy */
+    float uvx = fcx / W, uvy = fcy / H;                      /* :46 */
+    float posx = in[0], posy = in[1], velx = in[2], vely = in[3];
+    float npx = posx, npy = posy, nvx = velx, nvy = vely;
+
+    /* :52  `pos != inert` on a vec2 is true when ANY component differs */
+    if (posx != TO_INERT || posy != TO_INERT) {
+        float i = (fcx + (fcy * W)) / (W * H);               /* :57-58 */
+
+        float nscale = varyf(u->noiseScale, i, u->varyNoiseScale);
+        float noisex = posx * nscale, noisey = posy * nscale;    /* :62 */
+        float noiseTime = u->time * varyf(u->noiseSpeed, i, u->varyNoiseSpeed); /* :65 */
+
+        float wx = to_snoise3(noisex, noisey, uvx + noiseTime);               /* :67 */
+        float wy = to_snoise3(noisex, noisey, uvy + noiseTime + 1234.5678f);  /* :68 */
+
+        /* :75 flowAtScreenPos(pos*viewSize, ...): src/flow/flow-at-screen-pos.glsl:13-27
+         * with levels = stride = 1 (single tap, factor 1, flowMax 1);
+         * posToUV = glsl-map map(v,-1,1,0,1) = 0 + (1-0)*(v-(-1))/(1-(-1)) */
+        float sx = posx * u->viewSize[0], sy = posy * u->viewSize[1];
+        float fu = 0.0f + (1.0f * (sx + 1.0f)) / 2.0f;
+        float fv = 0.0f + (1.0f * (sy + 1.0f)) / 2.0f;
+        const float *ft = flow + 4 * ((size_t)nearest_texel(fv, fh) * fw + nearest_texel(fu, fw));
+        float gxf, gyf;
+        flow_get(ft, u->time, u->flowDecay, &gxf, &gyf);
+        float ffx = (0.0f + gxf * 1.0f) / 1.0f, ffy = (0.0f + gyf * 1.0f) / 1.0f;
+
+        /* :79-82 */
+        float vfw = varyf(u->forceWeight, i, u->varyForce);
+        float vflw = varyf(u->flowWeight, i, u->varyFlow);
+        float vnw = varyf(u->noiseWeight, i, u->varyNoise);
+        nvx = (velx * u->damping * u->dt) + (vfw * ((ffx * u->dt * vflw) + (wx * u->dt * vnw)));
+        nvy = (vely * u->damping * u->dt) + (vfw * ((ffy * u->dt * vflw) + (wy * u->dt * vnw)));
+
+        /* :85 */
+        float vtg = varyf(u->target, i, u->varyTarget);
+        nvx += (target_texel[0] - posx) * vtg;
+        nvy += (target_texel[1] - posy) * vtg;
+
+        /* :92-94 (speed == 0 gives 0/0 = NaN, as in the reference) */
+        float speed = sqrtf(nvx * nvx + nvy * nvy);
+        float r = fminf(speed, u->speedLimit) / speed;
+        nvx *= r; nvy *= r;
+
+        /* :97 */
+        npx = posx + nvx; npy = posy + nvy;
+    }
+    out[0] = npx; out[1] = npy; out[2] = nvx; out[3] = nvy;   /* :100 */
+}
+
+/*
+ * One `Particles.step` pass (src/particles.js:123-145) over rows
+ * [y0, y0+rows) of a data_w x data_h state texture.  `in`/`out`/`targets`
+ * point at the first of those rows (row-major RGBA32F texels, texel (x,y) at
+ * [(y-y0)*data_w + x]).  `targets` may be NULL = a texture of zeros (a fresh
+ * gl-fbo colour attachment).
+ */
+void to_logic_step(const to_logic_uniforms *u, const float *in, float *out, int y0, int rows,
+                   const float *flow, int fw, int fh, const float *targets)
+{
+    static const float zero4[4] = {0, 0, 0, 0};
+    const int W = u->data_w;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) {
+        for (int x = 0; x < W; ++x) {
+            size_t o = 4 * ((size_t)r * W + x);
+            logic_texel(u, x, y0 + r, in + o, flow, fw, fh, targets ? targets + o : zero4, out + o);
+        }
+    }
+}
+
+/* src/spawn/init/index.frag:5-10, src/spawn/init/cpu.js:3-8 */
+void to_spawn_init(float *out, size_t texels)
+{
+    for (size_t k = 0; k < texels; ++k) {
+        out[4 * k + 0] = TO_INERT; out[4 * k + 1] = TO_INERT;
+        out[4 * k + 2] = 0.0f;     out[4 * k + 3] = 0.0f;
+    }
+}
