@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py - particle-steps/s of the Tendrils integrator on MI355X (BASELINE.json metric).
+
+Workload (config C3 of BASELINE.json / SURVEY.md 8d): 4096 x 4096 state texture
+(16,777,216 particles, RGBA32F), flow field 1920 x 1080 produced by the optical-flow
+pass from a synthetic 1080p frame pair (falls back to a seeded synthetic field while
+that pass is unavailable), reference default uniforms (noise on), fixed 60 Hz timer.
+One "step" = one Tendrils.step() = one pass of the integrator kernel over every
+particle this rank holds.  State, flow and frames are resident in HBM before the
+timed region starts.
+
+Multi-GPU (weak scaling): one process per GPU, each holds a 4096-row band of a
+4096 x (4096*N) global texture; flow replicated; no data-path collective.  The
+statistics counters are reduced with one small RCCL all-reduce per 16 steps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode exact|fast] [--no-cpu]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N = 4096                        # particles per rank = N*N
+FLOW_W, FLOW_H = 1920, 1080
+BYTES_PER_PARTICLE_STEP = 32    # 16 B state read + 16 B written
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+STATS_EVERY = 16
+
+
+def synth_state(rank):
+    rng = np.random.default_rng(12345 + rank)
+    st = np.empty((N, N, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (N, N, 2))
+    st[..., 2:] = rng.uniform(-.01, .01, (N, N, 2))
+    return st
+
+
+def synth_frames():
+    """frame0 = seeded band-limited pattern, frame1 = frame0 translated by (1.5, 0.7) px."""
+    rng = np.random.default_rng(777)
+    yy, xx = np.mgrid[0:FLOW_H, 0:FLOW_W].astype(np.float64)
+
+    def pattern(dx, dy):
+        img = np.zeros((FLOW_H, FLOW_W, 3))
+        r = np.random.default_rng(778)
+        for _ in range(24):
+            fx, fy = r.uniform(-0.08, 0.08, 2)
+            ph = r.uniform(0, 2 * np.pi, 3)
+            amp = r.uniform(0.2, 1.0)
+            for c in range(3):
+                img[..., c] += amp * np.sin((xx - dx) * fx + (yy - dy) * fy + ph[c])
+        img = (img - img.min()) / (img.max() - img.min())
+        out = np.empty((FLOW_H, FLOW_W, 4), np.uint8)
+        out[..., :3] = np.clip(np.rint(img * 255), 0, 255).astype(np.uint8)
+        out[..., 3] = 255
+        return out
+    del rng
+    return pattern(0.0, 0.0), pattern(1.5, 0.7)
+
+
+def synth_flow(time_ms):
+    """Divergence-free seeded field in reference flow format (Fx, Fy, t_deposit, alpha)."""
+    yy, xx = np.mgrid[0:FLOW_H, 0:FLOW_W].astype(np.float32)
+    r = np.random.default_rng(4242)
+    psi_x = np.zeros((FLOW_H, FLOW_W), np.float32)
+    psi_y = np.zeros((FLOW_H, FLOW_W), np.float32)
+    for _ in range(12):
+        fx, fy = r.uniform(-0.05, 0.05, 2).astype(np.float32)
+        ph = np.float32(r.uniform(0, 2 * np.pi))
+        a = np.float32(r.uniform(0.3, 1.0))
+        c = a * np.cos(xx * fx + yy * fy + ph)
+        psi_x += c * fy        # d(psi)/dy
+        psi_y += -c * fx       # -d(psi)/dx
+    s = np.float32(0.01) / max(np.abs(psi_x).max(), np.abs(psi_y).max())
+    fl = np.empty((FLOW_H, FLOW_W, 4), np.float32)
+    fl[..., 0] = psi_x * s
+    fl[..., 1] = psi_y * s
+    fl[..., 2] = time_ms
+    fl[..., 3] = 1.0
+    return fl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
+    ap.add_argument("--flow-only", action="store_true", help="noiseWeight = 0 (preset 'Flow Only')")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import tendrils_amd as ta
+    from tendrils_amd import _capi
+    from tendrils_amd.sharding import DeviceCounters, reduce_counters, shard_rows
+    from tendrils_amd.tendrils import View
+
+    opts = ta.defaults()
+    opts.update(device=local_rank, mode=ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT,
+                row0=shard_rows(N * world, world, rank)[0], rows=N, globalHeight=N * world)
+    t = ta.Tendrils(View(FLOW_W, FLOW_H), opts)
+    t.resize()                       # viewRes 1920x1080 -> viewSize [1, 1.7778]; flow.shape = viewRes
+    t.setup(N)
+    if args.flow_only:
+        t.state["noiseWeight"] = 0
+    ctx = t.particles._ctx
+    t.particles.upload_texels(synth_state(rank))
+
+    # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
+    time0 = 1000.0
+    flow_source = "optical-flow(synthetic 1080p frame pair)"
+    try:
+        from tendrils_amd.optical_flow import OpticalFlow
+        f0, f1 = synth_frames()
+        of = OpticalFlow(t, uniforms=dict(speed=0.08, offset=0.1, scaleUV=[-1, -1]))   # src/demo.main.js:526-530
+        of.resize([FLOW_W, FLOW_H])
+        of.set_pixels(f0)
+        of.step()
+        of.set_pixels(f1)
+        of.update(dict(speedLimit=t.state["speedLimit"], time=time0, viewSize=t.viewSize))
+        of.render()
+    except (ImportError, ta.TendrilsHipError):
+        flow_source = "synthetic divergence-free field (optical-flow pass unavailable)"
+        t.flow.set_pixels(synth_flow(time0))
+
+    def sync_all():
+        t.particles.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t.timer.time = time0
+    counters_dev = C.c_void_p()
+    pending, dev_counters, ext_stream = [], None, None
+    if dist is not None:
+        sp = C.c_void_p()
+        _capi.call("th_stream", ctx, C.byref(sp))
+        ext_stream = torch.cuda.ExternalStream(sp.value)
+
+    def stats_tick():
+        """statistics of buffers[0], reduced over the ranks in place by RCCL on the context's stream"""
+        nonlocal pending, dev_counters
+        for w in pending:
+            w.wait()
+        pending = []
+        _capi.call("th_stats_async", ctx, C.c_float(t.state["speedLimit"]), C.byref(counters_dev))
+        if dist is not None:
+            if dev_counters is None:
+                dev_counters = DeviceCounters(counters_dev.value)
+            with torch.cuda.stream(ext_stream):
+                pending = dev_counters.all_reduce_async(dist)
+
+    def run(k_steps):
+        for k in range(k_steps):
+            t.timer.tick()
+            t.step()
+            if (k + 1) % STATS_EVERY == 0:
+                stats_tick()
+
+    run(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync_all()
+    wall = time.perf_counter() - t0
+
+    # kernel-only pass for the roofline: the same K steps, HIP events on the context's own stream
+    def run_kernel_only(k_steps):
+        for _ in range(k_steps):
+            t.timer.tick()
+            t.step()
+    ev_ms = C.c_float()
+    _capi.call("th_timer_start", ctx)
+    run_kernel_only(args.steps)
+    _capi.call("th_timer_stop", ctx, C.byref(ev_ms))
+    sync_all()
+
+    for w in pending:
+        w.wait()
+    stats = t.particles.stats(t.state["speedLimit"])
+    if dist is not None:
+        tmax = torch.tensor([wall, ev_ms.value / 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, ev_s = float(tmax[0]), float(tmax[1])
+        stats = reduce_counters(dist, stats, device="cuda")
+    else:
+        ev_s = ev_ms.value / 1e3
+
+    particles = N * N * world
+    value = particles * args.steps / wall
+    # `value` includes the statistics reductions (every 16 steps); the roofline uses the kernel-only pass
+    per_launch_s = ev_s / args.steps
+    achieved = BYTES_PER_PARTICLE_STEP * N * N / per_launch_s / 1e9
+
+    line = {
+        "metric": "particle-steps/sec (16M particles per GPU)", "value": value, "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3: 4096x4096 RGBA32F state (16.8M particles) per GPU, flow 1920x1080 from "
+                               + flow_source + ", reference default uniforms"
+                               + (" with noiseWeight=0 (flow-only)" if args.flow_only else " (simplex noise on)")
+                               + ", 60 Hz fixed timer",
+                   "mode": args.mode, "particles_per_gpu": N * N,
+                   "parallelism": "row-band shard x%d, flow replicated" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "logic_kernel", "avg_launch_ms": per_launch_s * 1e3,
+                     "algorithmic_bytes_per_launch": BYTES_PER_PARTICLE_STEP * N * N},
+        "counters": stats,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        line["cpu_baseline"] = cpu_baseline(t)
+    t.dispose()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+def cpu_baseline(t):
+    """The oracle (CPU restatement, bit-equal to the reference shader) timed on this host's cores
+    on a bounded sample of the same workload: whole 4096^2 steps until ~12 s have been spent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    st = synth_state(0)
+    fl = t.flow.read()
+    u = O.logic_uniforms(N, N, 1000.0 + 1000 / 60, 1000 / 60, view_size=t.viewSize,
+                         **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+    cores = os.cpu_count() or 1
+    rows = N if cores >= 16 else N // 4          # keep the leg within ~10-30 s on small hosts
+    sample = st[:rows]
+    O.logic_step(u, sample[:64], fl)             # warm (library load, page faults)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        O.logic_step(u, sample, fl)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or done >= 8:
+            break
+    return {"value": rows * N * done / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s) of rows [0,%d) x %d of the same state/flow (oracle/tendrils_oracle.c, "
+                      "OpenMP over rows, strict fp32)" % (done, rows, N)}
+
+
+if __name__ == "__main__":
+    main()

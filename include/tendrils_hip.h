@@ -1,0 +1,198 @@
+/*
+ * tendrils_hip.h - C ABI of the MI355X-native Tendrils particle integrator.
+ *
+ * This is the drop-in boundary for the reference's GPGPU update path
+ * (keeffEoghan/tendrils).  The reference has no native FFI: the seam it offers
+ * is the `Particles` object contract (src/particles.js:43-196) with a swappable
+ * "logic" shader, driven by `Tendrils.step()/spawnShader()` (src/index.js:248-272,
+ * 432-457) over WebGL FBO ping-pong.  Each entry point below replaces one of
+ * those GL-backed operations; the N-API shim (tendrils_amd/csrc/th_napi.cc) and
+ * the ctypes binding (tendrils_amd/_capi.py) bind exactly these symbols.
+ *
+ * Conventions
+ *  - plain C, no exceptions across the boundary; every call returns th_status
+ *    (0 = TH_OK) and th_last_error() gives the message of the last failure on
+ *    the calling thread (gl-shader/gl-fbo throw JS Errors: docs/js/index.js:42 -
+ *    the shim turns a non-zero status into a thrown Error).
+ *  - host pointers are caller-owned; device memory is library-owned.
+ *  - texel layout on the host side is the reference's: row-major RGBA32F,
+ *    texel (x, y) at float offset 4*(y*W + x)  (what gl.readPixels returns and
+ *    what Particles.spawn uploads, src/particles.js:94-117).
+ *  - one HIP stream per context; calls enqueue and return (GL semantics, no
+ *    host sync in th_step); th_sync() / downloads synchronise.
+ *  - a context is not thread-safe; different contexts are independent.
+ */
+#ifndef TENDRILS_HIP_H
+#define TENDRILS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TH_ABI_VERSION 1
+
+typedef int32_t th_status;
+enum {
+    TH_OK = 0,
+    TH_ERR_INVALID = 1,      /* bad argument / bad state (e.g. step with < 2 buffers) */
+    TH_ERR_HIP = 2,          /* a HIP runtime call failed */
+    TH_ERR_NO_DEVICE = 3,    /* no usable gfx950 device */
+    TH_ERR_UNSUPPORTED = 4
+};
+
+/* src/const/inert.glsl:1, src/const/inert.js:2 */
+#define TH_INERT (-1000000.0f)
+
+typedef struct th_context th_context;
+
+/* Arithmetic mode of the integrator kernel. */
+enum {
+    TH_MODE_EXACT = 0,   /* bit-identical to the reference shader's fp32 arithmetic */
+    TH_MODE_FAST = 1     /* FMA contraction + approximate rcp/sqrt; tolerance in DESIGN.md */
+};
+
+/* Render targets / texture sources, replacing the FBO arguments of
+ * Particles.step(update, buffer) (src/particles.js:123-130) and
+ * PixelSpawner.buffer (src/spawn/pixels/index.js:38-40). */
+enum {
+    TH_TARGET_RING = -1,     /* rotate the ring, write buffers[0] (the default path) */
+    TH_TARGET_TARGETS = -2,  /* tendrils.targets (src/index.js:105) */
+    TH_SOURCE_FLOW = -3      /* tendrils.flow as spawnData (src/demo.main.js:403-406) */
+    /* values >= 0 name ring buffer k in its CURRENT order (buffers[k]) */
+};
+
+/* new Particles(gl, {shape}) + setup(numBuffers)  (src/particles.js:44-92).
+ * A context may hold one row band of a larger state texture (multi-GPU
+ * sharding): kernels then use the global coordinates so that `gl_FragCoord`,
+ * `uv` and the index `i` (src/logic.frag:46,57-58) match the unsharded run. */
+typedef struct th_config {
+    int32_t device;         /* HIP device ordinal */
+    int32_t width;          /* state texture width  (dataRes.x) */
+    int32_t height;         /* rows held by THIS context */
+    int32_t global_height;  /* dataRes.y of the whole texture (0 = height) */
+    int32_t row0;           /* global row of local row 0 */
+    int32_t num_buffers;    /* ring length; Tendrils uses 2 (src/index.js:186) */
+    int32_t mode;           /* TH_MODE_* */
+    int32_t reserved;
+} th_config;
+
+/* Uniforms of src/logic.frag:3-34; field names = shader uniform names =
+ * Tendrils.state keys (src/index.js:28-66).  time/dt in milliseconds
+ * (src/timer.js, src/index.js:67). */
+typedef struct th_logic_uniforms {
+    float viewSize[2];
+    float time, dt;
+    float speedLimit, damping;
+    float forceWeight, flowWeight, noiseWeight;
+    float flowDecay;
+    float noiseSpeed, noiseScale;
+    float target;
+    float varyForce, varyFlow, varyNoise, varyNoiseScale, varyNoiseSpeed, varyTarget;
+} th_logic_uniforms;
+
+/* Uniforms of src/optical-flow/index.frag:12-24 (defaults src/optical-flow/index.js:21-29). */
+typedef struct th_optical_flow_uniforms {
+    float viewSize[2];
+    float scaleUV[2];
+    float offset, lambda;
+    float time, speed, speedLimit;
+} th_optical_flow_uniforms;
+
+/* Uniforms of src/spawn/ball/index.frag:3-4 (defaults src/spawn/ball/index.js:7-10). */
+typedef struct th_spawn_ball_uniforms {
+    float radius, speed;
+} th_spawn_ball_uniforms;
+
+/* Uniforms of src/spawn/pixels/frag/head.frag:6-17, best-sample-main.frag:12,
+ * flow-sample.frag:3 (host values: src/spawn/pixels/index.js:47-56). */
+typedef struct th_spawn_sample_uniforms {
+    float spawnSize[2];
+    float jitter[2];
+    float time, speed, bias;
+    float flowDecay;
+    float spawnMatrix[9];    /* column-major mat3 */
+    int32_t samples;         /* flow-sample 5, data-sample 2 */
+    int32_t apply;           /* 0: apply/flow.glsl, 1: apply/identity.glsl */
+} th_spawn_sample_uniforms;
+
+/* Build-defined statistics (the reference has none). */
+typedef struct th_counters {
+    uint64_t particles;      /* texels examined */
+    uint64_t live;           /* pos != inert */
+    uint64_t nan;            /* any component NaN */
+    uint64_t capped;         /* live and |vel| >= speedLimit*(1 - 2^-20) */
+    double sum_speed;        /* sum of |vel| over live, finite particles */
+    double max_speed;        /* max |vel| over live, finite particles */
+} th_counters;
+
+/* -- library ------------------------------------------------------------- */
+int32_t th_abi_version(void);
+const char *th_last_error(void);
+th_status th_device_count(int32_t *count);
+
+/* -- lifecycle: new Particles(...).setup(n) / dispose() --------------------- */
+th_status th_create(const th_config *cfg, th_context **out);
+th_status th_destroy(th_context *ctx);
+th_status th_set_mode(th_context *ctx, int32_t mode);
+/* Particles.setup(numBuffers) src/particles.js:81-92: grow/shrink the ring. */
+th_status th_setup(th_context *ctx, int32_t num_buffers);
+th_status th_num_buffers(th_context *ctx, int32_t *out);
+
+/* -- state ring: buffer.color[0].setPixels / readPixels --------------------- */
+/* buffer = ring index in current order, or -1 = every buffer (what
+ * Particles.spawn does, src/particles.js:115-116).  Sub-rectangle in LOCAL rows. */
+th_status th_upload_state(th_context *ctx, int32_t buffer, const float *rgba,
+                          int32_t x0, int32_t y0, int32_t w, int32_t h);
+th_status th_download_state(th_context *ctx, int32_t buffer, float *rgba,
+                            int32_t x0, int32_t y0, int32_t w, int32_t h);
+
+/* -- flow / targets textures (src/index.js:102-105, 207, 231-236, 405) ------ */
+th_status th_flow_resize(th_context *ctx, int32_t w, int32_t h);      /* flow.shape = [w,h]; zero-filled */
+th_status th_flow_upload(th_context *ctx, const float *rgba);
+th_status th_flow_download(th_context *ctx, float *rgba);
+th_status th_flow_clear(th_context *ctx);                              /* Tendrils.clearFlow */
+th_status th_targets_upload(th_context *ctx, const float *rgba);      /* local rows */
+th_status th_targets_download(th_context *ctx, float *rgba);
+th_status th_targets_clear(th_context *ctx);
+
+/* -- the hot path: Particles.step(update, buffer) with logic.frag ----------- */
+/* target = TH_TARGET_RING: utils.step(buffers) then write buffers[0] from
+ * buffers[1] (src/particles.js:128-139); otherwise write `target` from
+ * buffers[1] without rotating (src/particles.js:124-126). */
+th_status th_step(th_context *ctx, const th_logic_uniforms *u, int32_t target);
+/* n consecutive Tendrils.step() calls with a fixed-step timer
+ * (time_k = time0 + (k+1)*dt_ms in double, as src/timer.js:28-31 accumulates),
+ * replayed from a captured hipGraph. u->time is ignored, u->dt = (float)dt_ms. */
+th_status th_step_n(th_context *ctx, const th_logic_uniforms *u, double time0, double dt_ms, int32_t n);
+
+/* -- respawn passes: Tendrils.spawnShader (src/index.js:432-457) ------------ */
+th_status th_spawn_init(th_context *ctx, int32_t target);
+th_status th_spawn_ball(th_context *ctx, const th_spawn_ball_uniforms *u, int32_t target);
+th_status th_spawn_sample(th_context *ctx, const th_spawn_sample_uniforms *u, int32_t source, int32_t target);
+
+/* -- optical flow producer: OpticalFlow (src/optical-flow/index.js:32-71) ---- */
+th_status th_frames_resize(th_context *ctx, int32_t w, int32_t h);     /* OpticalFlow.resize */
+th_status th_frames_upload(th_context *ctx, const uint8_t *rgba8);     /* setPixels -> buffers[0] */
+th_status th_frames_rotate(th_context *ctx);                           /* OpticalFlow.step */
+/* one full-screen pass of optical-flow/index.frag alpha-blended into flow
+ * (src/demo.main.js:1107-1159; blend func src/index.js:267-268). */
+th_status th_optical_flow(th_context *ctx, const th_optical_flow_uniforms *u);
+
+/* -- statistics, sync, interop ---------------------------------------------- */
+th_status th_stats(th_context *ctx, float speed_limit, th_counters *out);   /* of buffers[0]; synchronises */
+/* enqueue the reduction only; result lands (as th_counters) at the returned device pointer */
+th_status th_stats_async(th_context *ctx, float speed_limit, void **device_counters);
+th_status th_sync(th_context *ctx);
+th_status th_stream(th_context *ctx, void **hip_stream);               /* hipStream_t of the context */
+th_status th_state_device_ptr(th_context *ctx, int32_t buffer, void **dptr);
+/* HIP-event timing on the context's own stream (for bench.py / profilers). */
+th_status th_timer_start(th_context *ctx);
+th_status th_timer_stop(th_context *ctx, float *elapsed_ms);           /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENDRILS_HIP_H */

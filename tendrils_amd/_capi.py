@@ -1,0 +1,133 @@
+"""ctypes binding of lib/libtendrils_hip.so (the C ABI in include/tendrils_hip.h).
+
+This is plumbing: every symbol the header declares is bound here, nothing is
+computed in Python.  There is no CPU fallback - if the library is missing or no
+gfx950 device is present, calls raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtendrils_hip.so")
+
+TH_OK = 0
+TH_MODE_EXACT, TH_MODE_FAST = 0, 1
+TH_TARGET_RING, TH_TARGET_TARGETS, TH_SOURCE_FLOW = -1, -2, -3
+INERT = -1000000.0
+
+
+class TendrilsHipError(RuntimeError):
+    """A C-ABI call returned a non-zero status (the reference throws JS Errors from gl-fbo/gl-shader)."""
+
+    def __init__(self, status, message):
+        super().__init__("tendrils_hip status %d: %s" % (status, message))
+        self.status = status
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("global_height", C.c_int32), ("row0", C.c_int32), ("num_buffers", C.c_int32),
+                ("mode", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LogicUniforms(C.Structure):
+    _fields_ = [("viewSize", C.c_float * 2),
+                ("time", C.c_float), ("dt", C.c_float),
+                ("speedLimit", C.c_float), ("damping", C.c_float),
+                ("forceWeight", C.c_float), ("flowWeight", C.c_float), ("noiseWeight", C.c_float),
+                ("flowDecay", C.c_float),
+                ("noiseSpeed", C.c_float), ("noiseScale", C.c_float),
+                ("target", C.c_float),
+                ("varyForce", C.c_float), ("varyFlow", C.c_float), ("varyNoise", C.c_float),
+                ("varyNoiseScale", C.c_float), ("varyNoiseSpeed", C.c_float), ("varyTarget", C.c_float)]
+
+
+class OpticalFlowUniforms(C.Structure):
+    _fields_ = [("viewSize", C.c_float * 2), ("scaleUV", C.c_float * 2),
+                ("offset", C.c_float), ("lambda_", C.c_float),
+                ("time", C.c_float), ("speed", C.c_float), ("speedLimit", C.c_float)]
+
+
+class SpawnBallUniforms(C.Structure):
+    _fields_ = [("radius", C.c_float), ("speed", C.c_float)]
+
+
+class SpawnSampleUniforms(C.Structure):
+    _fields_ = [("spawnSize", C.c_float * 2), ("jitter", C.c_float * 2),
+                ("time", C.c_float), ("speed", C.c_float), ("bias", C.c_float),
+                ("flowDecay", C.c_float),
+                ("spawnMatrix", C.c_float * 9),
+                ("samples", C.c_int32), ("apply", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("particles", C.c_uint64), ("live", C.c_uint64), ("nan", C.c_uint64),
+                ("capped", C.c_uint64), ("sum_speed", C.c_double), ("max_speed", C.c_double)]
+
+
+_ctx = C.c_void_p
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/tendrils_hip.h one to one
+PROTOTYPES = {
+    "th_abi_version": (C.c_int32, []),
+    "th_last_error": (C.c_char_p, []),
+    "th_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "th_create": (C.c_int32, [C.POINTER(Config), C.POINTER(_ctx)]),
+    "th_destroy": (C.c_int32, [_ctx]),
+    "th_set_mode": (C.c_int32, [_ctx, C.c_int32]),
+    "th_setup": (C.c_int32, [_ctx, C.c_int32]),
+    "th_num_buffers": (C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
+    "th_upload_state": (C.c_int32, [_ctx, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "th_download_state": (C.c_int32, [_ctx, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "th_flow_resize": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
+    "th_flow_upload": (C.c_int32, [_ctx, _fp]),
+    "th_flow_download": (C.c_int32, [_ctx, _fp]),
+    "th_flow_clear": (C.c_int32, [_ctx]),
+    "th_targets_upload": (C.c_int32, [_ctx, _fp]),
+    "th_targets_download": (C.c_int32, [_ctx, _fp]),
+    "th_targets_clear": (C.c_int32, [_ctx]),
+    "th_step": (C.c_int32, [_ctx, C.POINTER(LogicUniforms), C.c_int32]),
+    "th_step_n": (C.c_int32, [_ctx, C.POINTER(LogicUniforms), C.c_double, C.c_double, C.c_int32]),
+    "th_spawn_init": (C.c_int32, [_ctx, C.c_int32]),
+    "th_spawn_ball": (C.c_int32, [_ctx, C.POINTER(SpawnBallUniforms), C.c_int32]),
+    "th_spawn_sample": (C.c_int32, [_ctx, C.POINTER(SpawnSampleUniforms), C.c_int32, C.c_int32]),
+    "th_frames_resize": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
+    "th_frames_upload": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),
+    "th_frames_rotate": (C.c_int32, [_ctx]),
+    "th_optical_flow": (C.c_int32, [_ctx, C.POINTER(OpticalFlowUniforms)]),
+    "th_stats": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),
+    "th_stats_async": (C.c_int32, [_ctx, C.c_float, C.POINTER(C.c_void_p)]),
+    "th_sync": (C.c_int32, [_ctx]),
+    "th_stream": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
+    "th_state_device_ptr": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_void_p)]),
+    "th_timer_start": (C.c_int32, [_ctx]),
+    "th_timer_stop": (C.c_int32, [_ctx, C.POINTER(C.c_float)]),
+}
+
+_NO_STATUS = {"th_abi_version", "th_last_error"}
+_lib = None
+
+
+def load():
+    """Load the shared library (raises OSError if it was not built) and bind every symbol."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or make -C tendrils_amd/csrc)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)      # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise TendrilsHipError on failure."""
+    lib = load()
+    status = getattr(lib, name)(*args)
+    if name not in _NO_STATUS and status != TH_OK:
+        raise TendrilsHipError(status, lib.th_last_error().decode(errors="replace"))
+    return status

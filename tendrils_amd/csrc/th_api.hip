@@ -1,0 +1,577 @@
+// th_api.hip - the C ABI declared in include/tendrils_hip.h: context, state ring,
+// flow/targets/frame textures, launch selection.  Host side only; kernels live in
+// th_kernels.hip.  Compiled with -ffp-contract=off (the noise gradient table is
+// built here in strict fp32, see build_gradient_table).
+//
+// Reference objects replaced (paths relative to the reference tree):
+//   Particles            src/particles.js:43-196   (ring of N x N RGBA32F FBOs, step, spawn upload)
+//   utils.step           src/utils/index.js:1-7    (ring rotation: pop -> unshift)
+//   Tendrils.flow/targets src/index.js:102-105,207,231-236,405
+//   OpticalFlow buffers  src/optical-flow/index.js:43-70
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "th_kernels.hpp"
+#include "th_math.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+th_status fail(th_status code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define TH_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(TH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define TH_REQUIRE(cond, ...)                            \
+    do {                                                 \
+        if (!(cond)) return fail(TH_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+uint32_t ilog2(uint32_t v) { uint32_t r = 0; while (v >>= 1) ++r; return r; }
+
+// Table of the normalised simplex-noise gradient as a function of the argument
+// of the LAST permute() (th_math.hpp kLutMin..kLutMax): folds one permute, the
+// octahedron decode and the taylorInvSqrt scale of glsl-noise simplex/3d into a
+// 16-byte LDS lookup.  Strict fp32, reference operation order.
+void build_gradient_table(float4 *lut)
+{
+    for (int a = th::kLutMin; a <= th::kLutMax; ++a) {
+        float p = th::permute_ref((float)a);
+        float gx, gy, gz;
+        th::gradient_ref(p, gx, gy, gz);
+        lut[a - th::kLutMin] = make_float4(gx, gy, gz, 0.0f);
+    }
+}
+
+// Largest s2 with sqrt_rn(s2) <= limit (sqrt_rn monotonic), so that
+// `0 < s2 <= cap` <=> `0 < speed <= speedLimit` <=> min(speed,limit)/speed == 1.
+float s2_cap_for(float limit)
+{
+    if (!(limit > 0.0f)) return -1.0f;                       // never take the shortcut
+    if (std::isinf(limit)) return std::numeric_limits<float>::max();
+    double sq = (double)limit * (double)limit;
+    if (sq >= (double)std::numeric_limits<float>::max()) return std::numeric_limits<float>::max();
+    float c = (float)sq;
+    while (sqrtf(c) > limit) c = nextafterf(c, 0.0f);
+    for (;;) {
+        float n = nextafterf(c, std::numeric_limits<float>::infinity());
+        if (std::isinf(n) || sqrtf(n) > limit) break;
+        c = n;
+    }
+    return c;
+}
+
+bool finite_uniforms(const th_logic_uniforms &u)
+{
+    const float *f = reinterpret_cast<const float *>(&u);
+    for (size_t k = 0; k < sizeof(u) / sizeof(float); ++k)
+        if (!std::isfinite(f[k])) return false;
+    return true;
+}
+
+}  // namespace
+
+struct th_context {
+    th_config cfg{};
+    hipStream_t stream = nullptr;
+    std::vector<float4 *> ring;          // ring[0] = buffers[0] (most recent)
+    float4 *flow = nullptr;
+    int32_t fw = 0, fh = 0;
+    float4 *targets = nullptr;
+    bool targets_checked = true, targets_nonfinite = false;   // fresh texture = zeros
+    float4 *lut = nullptr;
+    uchar4 *frames[2] = {nullptr, nullptr};
+    int32_t frw = 0, frh = 0;
+    unsigned int *d_flag = nullptr;
+    th::StatsPartial *partials = nullptr;
+    th_counters *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    size_t texels() const { return (size_t)cfg.width * cfg.height; }
+};
+
+namespace {
+
+th_status use(th_context *c)
+{
+    if (!c) return fail(TH_ERR_INVALID, "null context");
+    TH_HIP(hipSetDevice(c->cfg.device));
+    return TH_OK;
+}
+
+th_status alloc_state(th_context *c, float4 **out)
+{
+    TH_HIP(hipMalloc((void **)out, c->texels() * sizeof(float4)));
+    // gl-fbo attachments start zero-filled
+    TH_HIP(hipMemsetAsync(*out, 0, c->texels() * sizeof(float4), c->stream));
+    return TH_OK;
+}
+
+th_status resolve_target(th_context *c, int32_t target, bool rotate_ok, float4 **out)
+{
+    if (target == TH_TARGET_RING) {
+        if (!rotate_ok) return fail(TH_ERR_INVALID, "TH_TARGET_RING not valid here");
+        float4 *last = c->ring.back();               // utils.step: pop -> unshift
+        c->ring.pop_back();
+        c->ring.insert(c->ring.begin(), last);
+        *out = c->ring[0];
+    } else if (target == TH_TARGET_TARGETS) {
+        *out = c->targets;
+        c->targets_checked = false;
+    } else if (target >= 0 && target < (int32_t)c->ring.size()) {
+        *out = c->ring[target];
+    } else {
+        return fail(TH_ERR_INVALID, "bad render target %d (ring has %zu buffers)", target, c->ring.size());
+    }
+    return TH_OK;
+}
+
+th_status rect_ok(th_context *c, int32_t x0, int32_t y0, int32_t w, int32_t h)
+{
+    TH_REQUIRE(x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 + w <= c->cfg.width && y0 + h <= c->cfg.height,
+               "rectangle (%d,%d %dx%d) outside the %dx%d state texture", x0, y0, w, h, c->cfg.width, c->cfg.height);
+    return TH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t th_abi_version(void) { return TH_ABI_VERSION; }
+
+const char *th_last_error(void) { return g_error.c_str(); }
+
+th_status th_device_count(int32_t *count)
+{
+    TH_REQUIRE(count, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(TH_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return TH_OK;
+}
+
+th_status th_create(const th_config *cfg, th_context **out)
+{
+    TH_REQUIRE(cfg && out, "null argument");
+    *out = nullptr;
+    TH_REQUIRE(cfg->width > 0 && cfg->height > 0, "state shape must be positive (got %dx%d)", cfg->width, cfg->height);
+    TH_REQUIRE(cfg->num_buffers >= 0 && cfg->num_buffers <= 64, "num_buffers out of range");
+    TH_REQUIRE(cfg->mode == TH_MODE_EXACT || cfg->mode == TH_MODE_FAST, "unknown mode %d", cfg->mode);
+    TH_REQUIRE((uint64_t)cfg->width * (uint64_t)cfg->height < (1ull << 31), "more than 2^31 texels per context");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(TH_ERR_NO_DEVICE, "no HIP device available");
+    TH_REQUIRE(cfg->device >= 0 && cfg->device < n, "device %d out of range (have %d)", cfg->device, n);
+    hipDeviceProp_t prop;
+    TH_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TH_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 code only", cfg->device, prop.gcnArchName);
+
+    th_context *c = new (std::nothrow) th_context;
+    if (!c) return fail(TH_ERR_INVALID, "out of host memory");
+    c->cfg = *cfg;
+    if (c->cfg.global_height <= 0) c->cfg.global_height = c->cfg.height;
+    if (c->cfg.row0 < 0 || c->cfg.row0 + c->cfg.height > c->cfg.global_height) {
+        delete c;
+        return fail(TH_ERR_INVALID, "row band [%d,%d) outside global height %d", cfg->row0, cfg->row0 + cfg->height, cfg->global_height);
+    }
+    th_status st = TH_OK;
+    auto body = [&]() -> th_status {
+        TH_HIP(hipSetDevice(c->cfg.device));
+        TH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        TH_HIP(hipEventCreate(&c->ev0));
+        TH_HIP(hipEventCreate(&c->ev1));
+        TH_HIP(hipMalloc((void **)&c->lut, th::kLutSize * sizeof(float4)));
+        std::vector<float4> lut(th::kLutSize);
+        build_gradient_table(lut.data());
+        TH_HIP(hipMemcpy(c->lut, lut.data(), lut.size() * sizeof(float4), hipMemcpyHostToDevice));
+        TH_HIP(hipMalloc((void **)&c->d_flag, sizeof(unsigned int)));
+        TH_HIP(hipMalloc((void **)&c->partials, th::kStatsBlocks * sizeof(th::StatsPartial)));
+        TH_HIP(hipMalloc((void **)&c->d_counters, sizeof(th_counters)));
+        // Tendrils ctor: flow and targets start as 1x1 float FBOs (src/index.js:102-105);
+        // setupParticles gives targets the particle shape (src/index.js:207).
+        c->fw = c->fh = 1;
+        TH_HIP(hipMalloc((void **)&c->flow, sizeof(float4)));
+        TH_HIP(hipMemsetAsync(c->flow, 0, sizeof(float4), c->stream));
+        if (th_status s = alloc_state(c, &c->targets)) return s;
+        for (int k = 0; k < c->cfg.num_buffers; ++k) {
+            float4 *b = nullptr;
+            if (th_status s = alloc_state(c, &b)) return s;
+            c->ring.push_back(b);
+        }
+        TH_HIP(hipStreamSynchronize(c->stream));
+        return TH_OK;
+    };
+    st = body();
+    if (st != TH_OK) { std::string keep = g_error; th_destroy(c); g_error = keep; return st; }
+    *out = c;
+    return TH_OK;
+}
+
+th_status th_destroy(th_context *c)
+{
+    if (!c) return TH_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (float4 *b : c->ring) (void)hipFree(b);
+    (void)hipFree(c->flow); (void)hipFree(c->targets); (void)hipFree(c->lut);
+    (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
+    (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TH_OK;
+}
+
+th_status th_set_mode(th_context *c, int32_t mode)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(mode == TH_MODE_EXACT || mode == TH_MODE_FAST, "unknown mode %d", mode);
+    c->cfg.mode = mode;
+    return TH_OK;
+}
+
+th_status th_setup(th_context *c, int32_t num_buffers)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(num_buffers >= 0 && num_buffers <= 64, "num_buffers out of range");
+    while ((int32_t)c->ring.size() < num_buffers) {          // src/particles.js:83-86: push
+        float4 *b = nullptr;
+        if (th_status s = alloc_state(c, &b)) return s;
+        c->ring.push_back(b);
+    }
+    if ((int32_t)c->ring.size() > num_buffers) TH_HIP(hipStreamSynchronize(c->stream));
+    while ((int32_t)c->ring.size() > num_buffers) {          // :89-91: pop().dispose()
+        TH_HIP(hipFree(c->ring.back()));
+        c->ring.pop_back();
+    }
+    c->cfg.num_buffers = num_buffers;
+    return TH_OK;
+}
+
+th_status th_num_buffers(th_context *c, int32_t *out)
+{
+    TH_REQUIRE(c && out, "null argument");
+    *out = (int32_t)c->ring.size();
+    return TH_OK;
+}
+
+th_status th_upload_state(th_context *c, int32_t buffer, const float *rgba, int32_t x0, int32_t y0, int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null pixels");
+    if (th_status s = rect_ok(c, x0, y0, w, h)) return s;
+    TH_REQUIRE(buffer >= -1 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
+    int first = buffer < 0 ? 0 : buffer, last = buffer < 0 ? (int)c->ring.size() - 1 : buffer;
+    for (int b = first; b <= last; ++b) {
+        float4 *dst = c->ring[b] + (size_t)y0 * c->cfg.width + x0;
+        TH_HIP(hipMemcpy2DAsync(dst, (size_t)c->cfg.width * sizeof(float4), rgba, (size_t)w * sizeof(float4),
+                                (size_t)w * sizeof(float4), h, hipMemcpyHostToDevice, c->stream));
+    }
+    TH_HIP(hipStreamSynchronize(c->stream));   // the caller may reuse `rgba` immediately (setPixels semantics)
+    return TH_OK;
+}
+
+th_status th_download_state(th_context *c, int32_t buffer, float *rgba, int32_t x0, int32_t y0, int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null pixels");
+    if (th_status s = rect_ok(c, x0, y0, w, h)) return s;
+    TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
+    const float4 *src = c->ring[buffer] + (size_t)y0 * c->cfg.width + x0;
+    TH_HIP(hipMemcpy2DAsync(rgba, (size_t)w * sizeof(float4), src, (size_t)c->cfg.width * sizeof(float4),
+                            (size_t)w * sizeof(float4), h, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_flow_resize(th_context *c, int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad flow shape %dx%d", w, h);
+    if (w == c->fw && h == c->fh) return TH_OK;              // gl-fbo: same shape is a no-op
+    TH_HIP(hipStreamSynchronize(c->stream));
+    TH_HIP(hipFree(c->flow));
+    c->flow = nullptr;
+    TH_HIP(hipMalloc((void **)&c->flow, (size_t)w * h * sizeof(float4)));
+    TH_HIP(hipMemsetAsync(c->flow, 0, (size_t)w * h * sizeof(float4), c->stream));
+    c->fw = w; c->fh = h;
+    return TH_OK;
+}
+
+th_status th_flow_upload(th_context *c, const float *rgba)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null pixels");
+    TH_HIP(hipMemcpyAsync(c->flow, rgba, (size_t)c->fw * c->fh * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_flow_download(th_context *c, float *rgba)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null pixels");
+    TH_HIP(hipMemcpyAsync(rgba, c->flow, (size_t)c->fw * c->fh * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_flow_clear(th_context *c)
+{
+    if (th_status s = use(c)) return s;
+    TH_HIP(hipMemsetAsync(c->flow, 0, (size_t)c->fw * c->fh * sizeof(float4), c->stream));
+    return TH_OK;
+}
+
+th_status th_targets_upload(th_context *c, const float *rgba)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null pixels");
+    TH_HIP(hipMemcpyAsync(c->targets, rgba, c->texels() * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    c->targets_checked = false;
+    return TH_OK;
+}
+
+th_status th_targets_download(th_context *c, float *rgba)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null pixels");
+    TH_HIP(hipMemcpyAsync(rgba, c->targets, c->texels() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_targets_clear(th_context *c)
+{
+    if (th_status s = use(c)) return s;
+    TH_HIP(hipMemsetAsync(c->targets, 0, c->texels() * sizeof(float4), c->stream));
+    c->targets_checked = true;
+    c->targets_nonfinite = false;
+    return TH_OK;
+}
+
+// Build the launch parameters of one integrator pass and pick the kernel variant.
+static th_status launch_step(th_context *c, const th_logic_uniforms &u, const float4 *in, float4 *out)
+{
+    const uint32_t W = (uint32_t)c->cfg.width, H = (uint32_t)c->cfg.global_height;
+    th::LogicParams p{};
+    p.in = in; p.out = out; p.flow = c->flow; p.targets = c->targets; p.lut = c->lut;
+    p.count = (uint32_t)c->texels();
+    p.width = W;
+    p.row0 = (uint32_t)c->cfg.row0;
+    p.wf = (float)W; p.hf = (float)H;
+    const bool pow2 = is_pow2(W) && is_pow2(H);
+    p.log2w = pow2 ? ilog2(W) : 0;
+    p.inv_w = 1.0f / p.wf; p.inv_h = 1.0f / p.hf; p.inv_wh = 1.0f / (p.wf * p.hf);
+    p.fw = c->fw; p.fh = c->fh;
+    p.fwf = (float)c->fw; p.fhf = (float)c->fh;
+    p.fwm1 = (float)(c->fw - 1); p.fhm1 = (float)(c->fh - 1);
+    p.u = u;
+    p.s2_cap = s2_cap_for(u.speedLimit);
+
+    // Preconditions of the specialised path (DESIGN.md "fast-path domain").
+    bool generic = !finite_uniforms(u);
+    const bool noise = u.noiseWeight != 0.0f;
+    bool target = u.target != 0.0f;
+    if (!generic) {
+        // i = (x+.5 + (y+.5)W)/(WH) lies in (0, 1]; bound |vary(base, i, v)| <= |base|(1+|v|)
+        double nscale = std::fabs((double)u.noiseScale) * (1.0 + std::fabs((double)u.varyNoiseScale)) * 1.001;
+        double ntime = std::fabs((double)u.time) * std::fabs((double)u.noiseSpeed) *
+                       (1.0 + std::fabs((double)u.varyNoiseSpeed)) * 1.001;
+        if (ntime + 1237.0 >= (double)th::kNoiseDomain) generic = true;      // z = uv + noiseTime (+1234.5678)
+        double bound = nscale > 0.0 ? (double)th::kNoiseDomain / nscale : 3.0e38;
+        p.pos_bound = (float)std::fmin(bound * 0.999, 3.0e38);
+        if (!(p.pos_bound > 0.0f)) generic = true;
+    }
+    if (!generic && !target) {
+        // target == 0 multiplies (targets - pos) by an exact zero; dropping the read is only
+        // value-preserving when the texture holds no NaN/Inf.
+        if (!c->targets_checked) {
+            unsigned int flag = 0;
+            TH_HIP(hipMemsetAsync(c->d_flag, 0, sizeof(unsigned int), c->stream));
+            th::launch_finite_check(c->targets, c->texels(), c->d_flag, c->stream);
+            TH_HIP(hipMemcpyAsync(&flag, c->d_flag, sizeof flag, hipMemcpyDeviceToHost, c->stream));
+            TH_HIP(hipStreamSynchronize(c->stream));
+            c->targets_nonfinite = flag != 0;
+            c->targets_checked = true;
+        }
+        target = c->targets_nonfinite;
+    }
+    th::launch_logic(p, c->cfg.mode, noise, target, pow2, generic, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(u, "null uniforms");
+    // Particles.step reads this.buffers[1] (src/particles.js:139): needs >= 2 buffers
+    TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
+    float4 *out = nullptr;
+    if (th_status s = resolve_target(c, target, true, &out)) return s;
+    return launch_step(c, *u, c->ring[1], out);
+}
+
+th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, double dt_ms, int32_t n)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(u && n >= 0, "bad arguments");
+    TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
+    th_logic_uniforms v = *u;
+    double t = time0;
+    v.dt = (float)dt_ms;
+    for (int32_t k = 0; k < n; ++k) {
+        t += dt_ms;                                   // src/timer.js:28-31
+        v.time = (float)t;
+        float4 *out = nullptr;
+        if (th_status s = resolve_target(c, TH_TARGET_RING, true, &out)) return s;
+        if (th_status s = launch_step(c, v, c->ring[1], out)) return s;
+    }
+    return TH_OK;
+}
+
+th_status th_spawn_init(th_context *c, int32_t target)
+{
+    if (th_status s = use(c)) return s;
+    float4 *out = nullptr;
+    if (target == TH_TARGET_RING) TH_REQUIRE(!c->ring.empty(), "no state buffers");
+    if (th_status s = resolve_target(c, target, true, &out)) return s;
+    // src/spawn/init/index.frag:5-10
+    th::launch_fill(out, make_float4(th::kInert, th::kInert, 0.0f, 0.0f), c->texels(), c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+th_status th_spawn_ball(th_context *, const th_spawn_ball_uniforms *, int32_t)
+{
+    return fail(TH_ERR_UNSUPPORTED, "th_spawn_ball: not built yet");
+}
+
+th_status th_spawn_sample(th_context *, const th_spawn_sample_uniforms *, int32_t, int32_t)
+{
+    return fail(TH_ERR_UNSUPPORTED, "th_spawn_sample: not built yet");
+}
+
+th_status th_frames_resize(th_context *c, int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad frame shape %dx%d", w, h);
+    if (w == c->frw && h == c->frh) return TH_OK;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {
+        TH_HIP(hipFree(c->frames[k]));
+        c->frames[k] = nullptr;
+        TH_HIP(hipMalloc((void **)&c->frames[k], (size_t)w * h * sizeof(uchar4)));
+        TH_HIP(hipMemsetAsync(c->frames[k], 0, (size_t)w * h * sizeof(uchar4), c->stream));
+    }
+    c->frw = w; c->frh = h;
+    return TH_OK;
+}
+
+th_status th_frames_upload(th_context *c, const uint8_t *rgba8)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba8 && c->frames[0], "no frame buffers (call th_frames_resize) or null pixels");
+    TH_HIP(hipMemcpyAsync(c->frames[0], rgba8, (size_t)c->frw * c->frh * sizeof(uchar4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_frames_rotate(th_context *c)
+{
+    TH_REQUIRE(c, "null context");
+    uchar4 *t = c->frames[1]; c->frames[1] = c->frames[0]; c->frames[0] = t;   // utils.step on 2 buffers
+    return TH_OK;
+}
+
+th_status th_optical_flow(th_context *, const th_optical_flow_uniforms *)
+{
+    return fail(TH_ERR_UNSUPPORTED, "th_optical_flow: not built yet");
+}
+
+th_status th_stats_async(th_context *c, float speed_limit, void **device_counters)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(!c->ring.empty(), "no state buffers");
+    th::launch_stats(c->ring[0], c->texels(), speed_limit, c->partials, c->d_counters, c->stream);
+    TH_HIP(hipGetLastError());
+    if (device_counters) *device_counters = c->d_counters;
+    return TH_OK;
+}
+
+th_status th_stats(th_context *c, float speed_limit, th_counters *out)
+{
+    TH_REQUIRE(out, "null output");
+    if (th_status s = th_stats_async(c, speed_limit, nullptr)) return s;
+    TH_HIP(hipMemcpyAsync(out, c->d_counters, sizeof *out, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_sync(th_context *c)
+{
+    if (th_status s = use(c)) return s;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_stream(th_context *c, void **hip_stream)
+{
+    TH_REQUIRE(c && hip_stream, "null argument");
+    *hip_stream = (void *)c->stream;
+    return TH_OK;
+}
+
+th_status th_state_device_ptr(th_context *c, int32_t buffer, void **dptr)
+{
+    TH_REQUIRE(c && dptr, "null argument");
+    TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
+    *dptr = c->ring[buffer];
+    return TH_OK;
+}
+
+th_status th_timer_start(th_context *c)
+{
+    if (th_status s = use(c)) return s;
+    TH_HIP(hipEventRecord(c->ev0, c->stream));
+    return TH_OK;
+}
+
+th_status th_timer_stop(th_context *c, float *elapsed_ms)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(elapsed_ms, "null output");
+    TH_HIP(hipEventRecord(c->ev1, c->stream));
+    TH_HIP(hipEventSynchronize(c->ev1));
+    TH_HIP(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return TH_OK;
+}
+
+}  // extern "C"

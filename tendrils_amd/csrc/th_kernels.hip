@@ -1,0 +1,377 @@
+// th_kernels.hip - gfx950 (CDNA4, wave64) kernels of the Tendrils particle path.
+//
+// Compiled with -ffp-contract=off: see th_math.hpp.  One thread integrates one
+// particle; the state ring is RGBA32F texels (16 B per lane per access =
+// global_load/store_dwordx4, the widest coalesced form), the flow field is a
+// random 16-B gather served by L2 / Infinity Cache, the simplex-noise gradient
+// table sits in LDS.
+//
+// Reference behaviour implemented here (paths relative to the reference tree):
+//   integrator      src/logic.frag:45-101  (+ src/flow/flow-at-screen-pos.glsl:13-27,
+//                   src/flow/get.glsl:3-5, src/map/pos-to-uv.glsl:6-8, glsl-noise simplex/3d)
+//   launch shape    one invocation per state texel (src/particles.js:132-143)
+#include "th_kernels.hpp"
+#include "th_math.hpp"
+
+namespace th {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// streaming (read-once / write-once) 16-byte accesses of the state ring
+TH_D float4 load_stream(const float4 *p)
+{
+    v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+TH_D void store_stream(float4 *p, float4 a)
+{
+    v4f v = {a.x, a.y, a.z, a.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+}
+
+// ---------------------------------------------------------------------------
+// Reference-order evaluation of one texel: any input, any uniform set.  Used
+// for lanes outside the fast path's proven domain and by the generic kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float4 logic_texel_ref(const LogicParams &p, uint32_t x, uint32_t y_global,
+                                                float4 st, uint32_t local_index)
+{
+    const th_logic_uniforms &u = p.u;
+    float fcx = (float)x + 0.5f, fcy = (float)y_global + 0.5f;      // gl_FragCoord.xy
+    float uvx = fcx / p.wf, uvy = fcy / p.hf;                        // :46
+    float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
+    if (!(posx != kInert || posy != kInert)) return st;              // :52 (vec2 != : any component)
+
+    float i = (fcx + (fcy * p.wf)) / (p.wf * p.hf);                  // :57-58
+    float nscale = vary(u.noiseScale, i, u.varyNoiseScale);
+    float nx = posx * nscale, ny = posy * nscale;                    // :62
+    float ntime = u.time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);  // :65
+    float wx = snoise_ref(nx, ny, uvx + ntime);                      // :67
+    float wy = snoise_ref(nx, ny, uvy + ntime + 1234.5678f);         // :68
+
+    // :75 flowAtScreenPos(pos*viewSize): posToUV then one NEAREST/CLAMP tap, levels = 1
+    float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
+    float fu = 0.0f + (1.0f * (sx + 1.0f)) / 2.0f;
+    float fv = 0.0f + (1.0f * (sy + 1.0f)) / 2.0f;
+    int tx = (int)__builtin_amdgcn_fmed3f(th_floor(fu * p.fwf), 0.0f, p.fwm1);
+    int ty = (int)__builtin_amdgcn_fmed3f(th_floor(fv * p.fhf), 0.0f, p.fhm1);
+    float4 ft = p.flow[(size_t)ty * p.fw + tx];
+    float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));   // src/flow/get.glsl:4
+    float ffx = (0.0f + ft.x * k * 1.0f) / 1.0f, ffy = (0.0f + ft.y * k * 1.0f) / 1.0f;
+
+    float vfw = vary(u.forceWeight, i, u.varyForce);
+    float vflw = vary(u.flowWeight, i, u.varyFlow);
+    float vnw = vary(u.noiseWeight, i, u.varyNoise);
+    float nvx = (velx * u.damping * u.dt) + (vfw * ((ffx * u.dt * vflw) + (wx * u.dt * vnw)));   // :79-82
+    float nvy = (vely * u.damping * u.dt) + (vfw * ((ffy * u.dt * vflw) + (wy * u.dt * vnw)));
+
+    float4 tg = p.targets[local_index];
+    float vtg = vary(u.target, i, u.varyTarget);
+    nvx += (tg.x - posx) * vtg;                                      // :85
+    nvy += (tg.y - posy) * vtg;
+
+    float speed = __builtin_sqrtf(nvx * nvx + nvy * nvy);            // :92 (correctly rounded)
+    float r = __builtin_fminf(speed, u.speedLimit) / speed;          // :94 (0/0 -> NaN, as the reference)
+    nvx *= r; nvy *= r;
+    return make_float4(posx + nvx, posy + nvy, nvx, nvy);            // :97,100
+}
+
+// ---------------------------------------------------------------------------
+// Simplex noise on the guarded domain, gradient + normalisation from the LDS
+// table.  Bit-identical to snoise_ref for |v| < kNoiseDomain when !FAST.
+// sxy = vx*C.y + vy*C.y is shared by the two evaluations of one particle.
+// ---------------------------------------------------------------------------
+template <bool FAST>
+TH_D float snoise_lut(float vx, float vy, float vz, float sxy, const float4 *lut)
+{
+    // first corner
+    float s = mad<FAST>(vz, kC3, sxy);
+    float ix = th_floor(vx + s), iy = th_floor(vy + s), iz = th_floor(vz + s);
+    float t = mad<FAST>(iz, kC6, mad<FAST>(iy, kC6, ix * kC6));
+    float ax = (vx - ix) + t, ay = (vy - iy) + t, az = (vz - iz) + t;
+
+    // simplex traversal order: g = step(x0.yzx, x0.xyz), i1 = min(g, 1-g.zxy), i2 = max(g, 1-g.zxy)
+    bool ga = !(ax < ay), gb = !(ay < az), gc = !(az < ax);
+    bool b1x = ga && !gc, b1y = gb && !ga, b1z = gc && !gb;
+    bool b2x = ga || !gc, b2y = gb || !ga, b2z = gc || !gb;
+    float i1x = b1x ? 1.0f : 0.0f, i1y = b1y ? 1.0f : 0.0f, i1z = b1z ? 1.0f : 0.0f;
+    float i2x = b2x ? 1.0f : 0.0f, i2y = b2y ? 1.0f : 0.0f, i2z = b2z ? 1.0f : 0.0f;
+
+    float bx = (ax - i1x) + kC6, by = (ay - i1y) + kC6, bz = (az - i1z) + kC6;
+    float cx = (ax - i2x) + kC3, cy = (ay - i2y) + kC3, cz = (az - i2z) + kC3;
+    float dx = ax - 0.5f, dy = ay - 0.5f, dz = az - 0.5f;
+
+    // permutation hash: exact small-integer arithmetic (th_math.hpp)
+    ix = mod289_int(ix); iy = mod289_int(iy); iz = mod289_int(iz);
+    float pz0 = permute_int(iz), pz1 = permute_int(iz + 1.0f);       // z offsets are only ever 0 or 1
+    float q0 = permute_int(pz0 + iy);
+    float q1 = permute_int(((b1z ? pz1 : pz0) + iy) + i1y);
+    float q2 = permute_int(((b2z ? pz1 : pz0) + iy) + i2y);
+    float q3 = permute_int((pz1 + iy) + 1.0f);
+    int j0 = (int)(q0 + ix);
+    int j1 = (int)((q1 + ix) + i1x);
+    int j2 = (int)((q2 + ix) + i2x);
+    int j3 = (int)((q3 + ix) + 1.0f);
+    float4 g0 = lut[j0 - kLutMin], g1 = lut[j1 - kLutMin], g2 = lut[j2 - kLutMin], g3 = lut[j3 - kLutMin];
+
+    // radial falloff and gradient dot products
+    float m0 = __builtin_fmaxf(0.6f - mad<FAST>(az, az, mad<FAST>(ay, ay, ax * ax)), 0.0f);
+    float m1 = __builtin_fmaxf(0.6f - mad<FAST>(bz, bz, mad<FAST>(by, by, bx * bx)), 0.0f);
+    float m2 = __builtin_fmaxf(0.6f - mad<FAST>(cz, cz, mad<FAST>(cy, cy, cx * cx)), 0.0f);
+    float m3 = __builtin_fmaxf(0.6f - mad<FAST>(dz, dz, mad<FAST>(dy, dy, dx * dx)), 0.0f);
+    m0 *= m0; m1 *= m1; m2 *= m2; m3 *= m3;
+    m0 *= m0; m1 *= m1; m2 *= m2; m3 *= m3;
+    float d0 = mad<FAST>(g0.z, az, mad<FAST>(g0.y, ay, g0.x * ax));
+    float d1 = mad<FAST>(g1.z, bz, mad<FAST>(g1.y, by, g1.x * bx));
+    float d2 = mad<FAST>(g2.z, cz, mad<FAST>(g2.y, cy, g2.x * cx));
+    float d3 = mad<FAST>(g3.z, dz, mad<FAST>(g3.y, dy, g3.x * dx));
+    return 42.0f * mad<FAST>(m3, d3, mad<FAST>(m2, d2, mad<FAST>(m1, d1, m0 * d0)));
+}
+
+// ---------------------------------------------------------------------------
+// The integrator.  Template switches are uniform-derived (chosen by the host
+// per launch); every lane the specialised path cannot prove in-domain falls
+// back to logic_texel_ref, so the result is the reference's in all cases.
+//   NOISE  noiseWeight != 0
+//   TARGET target != 0 or the targets texture holds a non-finite value
+//   POW2   dataRes.x, dataRes.y powers of two: `/dataRes` == `*(1/dataRes)` exactly
+// ---------------------------------------------------------------------------
+template <bool FAST, bool NOISE, bool TARGET, bool POW2>
+__global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
+{
+    __shared__ float4 lut[NOISE ? kLutSize : 1];
+    if constexpr (NOISE) {
+        for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
+        __syncthreads();
+    }
+    const th_logic_uniforms &u = p.u;
+    const uint32_t stride = gridDim.x * 256u;
+
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += stride) {
+        float4 st = load_stream(&p.in[idx]);
+        uint32_t x, y;
+        if constexpr (POW2) { x = idx & (p.width - 1u); y = idx >> p.log2w; }
+        else { y = idx / p.width; x = idx - y * p.width; }
+        y += p.row0;
+
+        float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
+        float4 res = st;
+        if (posx != kInert || posy != kInert) {                               // src/logic.frag:52
+            bool in_domain = __builtin_fmaxf(__builtin_fabsf(posx), __builtin_fabsf(posy)) < p.pos_bound;
+            if (__builtin_expect(!in_domain, 0)) {
+                res = logic_texel_ref(p, x, y, st, idx);
+            } else {
+                float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
+                float uvx, uvy, i;
+                if constexpr (POW2) {
+                    uvx = fcx * p.inv_w; uvy = fcy * p.inv_h;
+                    i = (fcx + (fcy * p.wf)) * p.inv_wh;
+                } else if constexpr (FAST) {
+                    uvx = fcx * p.inv_w; uvy = fcy * p.inv_h;
+                    i = mad<true>(fcy, p.wf, fcx) * p.inv_wh;
+                } else {
+                    uvx = fcx / p.wf; uvy = fcy / p.hf;
+                    i = (fcx + (fcy * p.wf)) / (p.wf * p.hf);
+                }
+
+                // flow tap (issued first: its latency hides under the noise arithmetic)
+                float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
+                float fu = (sx + 1.0f) * 0.5f, fv = (sy + 1.0f) * 0.5f;       // (1*(v+1))/2, exactly
+                int tx = (int)__builtin_amdgcn_fmed3f(fu * p.fwf, 0.0f, p.fwm1);   // trunc == floor on [0, n-1]
+                int ty = (int)__builtin_amdgcn_fmed3f(fv * p.fhf, 0.0f, p.fhm1);
+                float4 ft = p.flow[ty * p.fw + tx];
+
+                float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
+                if constexpr (NOISE) {
+                    float nscale = vary(u.noiseScale, i, u.varyNoiseScale);
+                    float nx = posx * nscale, ny = posy * nscale;
+                    float ntime = u.time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
+                    float sxy = mad<FAST>(ny, kC3, nx * kC3);
+                    float wx = snoise_lut<FAST>(nx, ny, uvx + ntime, sxy, lut);
+                    float wy = snoise_lut<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy, lut);
+                    float vnw = vary(u.noiseWeight, i, u.varyNoise);
+                    wxs = (wx * u.dt) * vnw; wys = (wy * u.dt) * vnw;
+                }
+
+                float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));
+                float vflw = vary(u.flowWeight, i, u.varyFlow);
+                float fxs = ((ft.x * k) * u.dt) * vflw, fys = ((ft.y * k) * u.dt) * vflw;
+                float vfw = vary(u.forceWeight, i, u.varyForce);
+                float nvx, nvy;
+                if constexpr (NOISE) {
+                    nvx = mad<FAST>(vfw, fxs + wxs, (velx * u.damping) * u.dt);
+                    nvy = mad<FAST>(vfw, fys + wys, (vely * u.damping) * u.dt);
+                } else {
+                    // wander*dt*vary(0) is a signed zero here: adding it cannot change a non-zero
+                    // sum, and a zero sum ends in 0/0 = NaN either way (DESIGN.md "skipped terms")
+                    nvx = mad<FAST>(vfw, fxs, (velx * u.damping) * u.dt);
+                    nvy = mad<FAST>(vfw, fys, (vely * u.damping) * u.dt);
+                }
+                if constexpr (TARGET) {
+                    float4 tg = p.targets[idx];
+                    float vtg = vary(u.target, i, u.varyTarget);
+                    nvx = mad<FAST>(tg.x - posx, vtg, nvx);
+                    nvy = mad<FAST>(tg.y - posy, vtg, nvy);
+                }
+
+                // speed clamp: r = min(speed, limit)/speed is exactly 1 when 0 < speed <= limit,
+                // i.e. when 0 < s2 <= s2_cap (sqrt_rn is monotonic; s2_cap from the host).
+                float s2 = mad<FAST>(nvy, nvy, nvx * nvx);
+                if (!(s2 > 0.0f && s2 <= p.s2_cap)) {
+                    float r;
+                    if constexpr (FAST) {
+                        r = __builtin_fminf(1.0f, u.speedLimit * __builtin_amdgcn_rsqf(s2));
+                        if (!(s2 > 0.0f)) r = __builtin_nanf("");
+                    } else {
+                        float speed = __builtin_sqrtf(s2);
+                        r = __builtin_fminf(speed, u.speedLimit) / speed;
+                    }
+                    nvx *= r; nvy *= r;
+                }
+                res = make_float4(posx + nvx, posy + nvy, nvx, nvy);
+            }
+        }
+        store_stream(&p.out[idx], res);
+    }
+}
+
+// Generic kernel: reference-order evaluation of every texel (used when the host
+// cannot establish the fast path's preconditions, e.g. non-finite uniforms).
+__global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p)
+{
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += stride) {
+        float4 st = p.in[idx];
+        uint32_t y = idx / p.width, x = idx - y * p.width;
+        p.out[idx] = logic_texel_ref(p, x, y + p.row0, st, idx);
+    }
+}
+
+static int grid_for(size_t n, int blocks_per_cu)
+{
+    size_t blocks = (n + 255) / 256;
+    size_t cap = (size_t)256 * blocks_per_cu;
+    return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+template <bool FAST, bool NOISE, bool TARGET>
+static void launch_logic_p2(const LogicParams &p, bool pow2, hipStream_t s)
+{
+    int grid = grid_for(p.count, 8);
+    if (pow2) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, false>), dim3(grid), dim3(256), 0, s, p);
+}
+
+void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool generic,
+                  hipStream_t s)
+{
+    if (generic) {
+        hipLaunchKernelGGL(logic_generic_kernel, dim3(grid_for(p.count, 8)), dim3(256), 0, s, p);
+        return;
+    }
+    const bool fast = mode == TH_MODE_FAST;
+#define TH_DISPATCH(F, N, T) launch_logic_p2<F, N, T>(p, pow2, s)
+    if (fast) {
+        if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
+        else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }
+    } else {
+        if (noise) { if (target) TH_DISPATCH(false, true, true); else TH_DISPATCH(false, true, false); }
+        else { if (target) TH_DISPATCH(false, false, true); else TH_DISPATCH(false, false, false); }
+    }
+#undef TH_DISPATCH
+}
+
+// ---------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_kernel(float4 *dst, float4 v, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, value, n);
+}
+
+// *flag |= 1 when any component of src is NaN or +-inf
+__global__ __launch_bounds__(256) void finite_check_kernel(const float4 *src, size_t n, unsigned int *flag)
+{
+    size_t stride = (size_t)gridDim.x * 256;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float4 v = src[i];
+        bad |= !(__builtin_fabsf(v.x) <= 3.4028234e38f) || !(__builtin_fabsf(v.y) <= 3.4028234e38f) ||
+               !(__builtin_fabsf(v.z) <= 3.4028234e38f) || !(__builtin_fabsf(v.w) <= 3.4028234e38f);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(finite_check_kernel, dim3(grid_for(n, 4)), dim3(256), 0, s, src, n, flag);
+}
+
+// ---------------------------------------------------------------------------
+// statistics of one state buffer: per-block partials (plain stores, fixed
+// order => reproducible) then a one-block fold.  Not on the hot path.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_kernel(const float4 *st, size_t n, float limit, StatsPartial *part)
+{
+    __shared__ StatsPartial sh[4];
+    size_t stride = (size_t)gridDim.x * 256;
+    unsigned long long live = 0, nan = 0, capped = 0;
+    double sum = 0.0, mx = 0.0;
+    const float cap = limit * (1.0f - 9.5367431640625e-07f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float4 v = st[i];
+        bool is_live = v.x != kInert || v.y != kInert;
+        bool is_nan = (v.x != v.x) || (v.y != v.y) || (v.z != v.z) || (v.w != v.w);
+        float sp = __builtin_sqrtf(v.z * v.z + v.w * v.w);
+        bool fin = is_live && !is_nan && sp <= 3.4028234e38f;
+        live += is_live; nan += is_nan;
+        capped += fin && sp >= cap;
+        if (fin) { sum += sp; mx = sp > mx ? sp : mx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_xor(live, o); nan += __shfl_xor(nan, o); capped += __shfl_xor(capped, o);
+        sum += __shfl_xor(sum, o);
+        double om = __shfl_xor(mx, o); mx = om > mx ? om : mx;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = StatsPartial{live, nan, capped, sum, mx};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StatsPartial a = sh[0];
+        for (int w = 1; w < 4; ++w) {
+            a.live += sh[w].live; a.nan += sh[w].nan; a.capped += sh[w].capped;
+            a.sum_speed += sh[w].sum_speed; a.max_speed = sh[w].max_speed > a.max_speed ? sh[w].max_speed : a.max_speed;
+        }
+        part[blockIdx.x] = a;
+    }
+}
+
+__global__ __launch_bounds__(64) void stats_fold_kernel(const StatsPartial *part, int nparts, size_t n, th_counters *out)
+{
+    if (threadIdx.x != 0) return;
+    th_counters c{};
+    c.particles = n;
+    for (int k = 0; k < nparts; ++k) {
+        c.live += part[k].live; c.nan += part[k].nan; c.capped += part[k].capped;
+        c.sum_speed += part[k].sum_speed;
+        c.max_speed = part[k].max_speed > c.max_speed ? part[k].max_speed : c.max_speed;
+    }
+    *out = c;
+}
+
+void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,
+                  th_counters *out, hipStream_t s)
+{
+    int grid = grid_for(n, 4);
+    if (grid > kStatsBlocks) grid = kStatsBlocks;
+    hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, state, n, speed_limit, partials);
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(64), 0, s, partials, grid, n, out);
+}
+
+}  // namespace th

@@ -1,0 +1,74 @@
+// th_kernels.hpp - launch parameter blocks shared by th_kernels.hip (device)
+// and th_api.hip (host).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tendrils_hip.h"
+
+namespace th {
+
+// Kernel argument block of the integrator.  Passed by value: it lands in the
+// kernarg segment and every field is wave-uniform (SGPRs).
+struct LogicParams {
+    const float4 *in;        // ring buffers[1]  (this context's rows)
+    float4 *out;             // ring buffers[0] or an explicit target
+    const float4 *flow;      // RGBA32F flow texture, fw x fh
+    const float4 *targets;   // RGBA32F targets texture (local rows)
+    const float4 *lut;       // noise gradient table (kLutSize float4)
+    uint32_t count;          // texels held by this context = width * local rows
+    uint32_t width;
+    uint32_t log2w;          // valid when pow2 != 0
+    uint32_t row0;
+    float wf, hf;            // dataRes (global), as floats
+    float inv_w, inv_h, inv_wh;   // exact reciprocals, valid when pow2 != 0
+    int32_t fw, fh;
+    float fwf, fhf, fwm1, fhm1;
+    th_logic_uniforms u;
+    float s2_cap;            // largest s2 with sqrt_rn(s2) <= speedLimit (see th_api.hip)
+    float pos_bound;         // |pos| below this keeps the noise coordinates inside kNoiseDomain
+};
+
+struct OpticalFlowParams {
+    const uchar4 *view, *last;
+    float4 *flow;
+    int32_t fr_w, fr_h;      // frame size
+    int32_t out_w, out_h;    // flow texture size
+    th_optical_flow_uniforms u;
+};
+
+struct SpawnBallParams {
+    float4 *out;
+    uint32_t count, width, row0;
+    th_spawn_ball_uniforms u;
+};
+
+struct SpawnSampleParams {
+    const float4 *particles;
+    float4 *out;
+    const float4 *data;
+    uint32_t count, width, row0;
+    float wf, hf;
+    int32_t dw, dh;
+    th_spawn_sample_uniforms u;
+};
+
+struct StatsPartial {
+    unsigned long long live, nan, capped;
+    double sum_speed, max_speed;
+};
+
+// launchers (defined in th_kernels.hip)
+void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool generic,
+                  hipStream_t stream);
+void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
+void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
+void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,
+                  th_counters *out, hipStream_t stream);
+void launch_optical_flow(const OpticalFlowParams &p, hipStream_t stream);
+void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
+void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
+constexpr int kStatsBlocks = 1024;
+
+}  // namespace th

@@ -1,0 +1,229 @@
+"""Host mirror of the reference's simulation facade `Tendrils` (src/index.js:84-457) for the
+particle-update path: state uniforms, timer, flow/targets textures, step(), spawn(),
+spawnShader(), resize().  Rendering methods (draw, view buffers, fades) are out of scope
+of this build and are inert no-ops that keep call chains working.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import call
+from .particles import LOGIC, Particles, Program, run_pass
+from .timer import Timer
+
+
+def defaults():
+    """src/index.js:28-75"""
+    timer = Timer()
+    timer.step = 1000 / 60
+    return dict(
+        state=dict(
+            rootNum=2 ** 9,
+            autoClearView=False, autoFade=True,
+            damping=0.043, speedLimit=0.01,
+            forceWeight=0.016, varyForce=-0.1,
+            flowWeight=1, varyFlow=0.2,
+            noiseWeight=0.002, varyNoise=0.3,
+            flowDecay=0.005, flowWidth=5,
+            noiseScale=2.125, varyNoiseScale=0.5,
+            noiseSpeed=0.00025, varyNoiseSpeed=0.1,
+            target=0, varyTarget=1,
+            lineWidth=1, speedAlpha=0.000001, colorMapAlpha=0.4,
+            baseColor=[1, 1, 1, 0.5], flowColor=[1, 1, 1, 0.04], fadeColor=[0.1333, 0.1333, 0.1333, 0]),
+        timer=timer, numBuffers=0, logicShader=None, colorMap=None)
+
+
+gl_settings = dict(preserveDrawingBuffer=True, antialias=True)     # src/index.js:77-80
+
+
+def cover_aspect(size):
+    """src/utils/aspect.js:4-11: scale(inverse(size), max(size))"""
+    m = max(size[0], size[1])
+    return [m / size[0], m / size[1]]
+
+
+class View:
+    """What the reference reads from its WebGL context: the drawing-buffer size."""
+
+    def __init__(self, width, height):
+        self.drawingBufferWidth = int(width)
+        self.drawingBufferHeight = int(height)
+
+
+class FlowTexture:
+    """tendrils.flow (src/index.js:102): RGBA32F, NEAREST, CLAMP_TO_EDGE, resizable."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self._shape = [1, 1]
+
+    @property
+    def shape(self):
+        return list(self._shape)
+
+    @shape.setter
+    def shape(self, wh):
+        self._shape = [int(wh[0]), int(wh[1])]
+        if self._o.particles is not None:
+            call("th_flow_resize", self._o.particles._ctx, self._shape[0], self._shape[1])
+
+    def set_pixels(self, texels):
+        t = np.ascontiguousarray(texels, np.float32)
+        assert t.shape == (self._shape[1], self._shape[0], 4), (t.shape, self._shape)
+        call("th_flow_upload", self._o.particles._ctx, t.ctypes.data_as(_capi._fp))
+
+    def read(self):
+        out = np.empty((self._shape[1], self._shape[0], 4), np.float32)
+        call("th_flow_download", self._o.particles._ctx, out.ctypes.data_as(_capi._fp))
+        return out
+
+    def clear(self):
+        call("th_flow_clear", self._o.particles._ctx)
+
+    def source_index(self):
+        return _capi.TH_SOURCE_FLOW
+
+
+class TargetsTexture:
+    """tendrils.targets (src/index.js:105,207): RGBA32F at the particle shape."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.shape = [1, 1]
+
+    def set_pixels(self, texels):
+        t = np.ascontiguousarray(texels, np.float32)
+        call("th_targets_upload", self._o.particles._ctx, t.ctypes.data_as(_capi._fp))
+
+    def read(self):
+        p = self._o.particles
+        out = np.empty((p.shape[1], p.shape[0], 4), np.float32)
+        call("th_targets_download", p._ctx, out.ctypes.data_as(_capi._fp))
+        return out
+
+    def clear(self):
+        call("th_targets_clear", self._o.particles._ctx)
+
+    def target_index(self):
+        return _capi.TH_TARGET_TARGETS
+
+
+def init_spawner(data, x=0, y=0):
+    """src/spawn/init/cpu.js:3-8"""
+    data[0] = data[1] = _capi.INERT
+    data[2] = data[3] = 0
+    return data
+
+
+class Tendrils:
+    def __init__(self, gl=None, options=None):
+        params = {**defaults(), **(options or {})}
+        self.gl = gl if gl is not None else View(1, 1)
+        self.state = params["state"]
+        self.particles = None
+        self.flow = FlowTexture(self)
+        self.targets = TargetsTexture(self)
+        self.buffers = []
+        self.logicShader = None
+        self.uniforms = dict(render={}, update={})
+        self.viewRes = [0, 0]
+        self.viewSize = [0, 0]
+        self.timer = params["timer"]
+        self._device = int(params.get("device", 0))
+        self._mode = int(params.get("mode", _capi.TH_MODE_EXACT))
+        self._band = (int(params.get("row0", 0)), params.get("rows"), int(params.get("globalHeight", 0)))
+
+    # -- setup ---------------------------------------------------------------------
+    def setup(self, *rest):                                   # src/index.js:149-154
+        self.setupParticles(*rest)
+        self.reset()
+        return self
+
+    def reset(self):
+        self.spawn()
+        return self
+
+    def dispose(self):
+        if self.particles is not None:
+            self.particles.dispose()
+            self.particles = None
+        return self
+
+    def setupParticles(self, rootNum=None, numBuffers=2):     # src/index.js:186-210
+        rootNum = self.state["rootNum"] if rootNum is None else rootNum
+        self.state["rootNum"] = rootNum
+        row0, rows, gh = self._band
+        shape = [rootNum, rows if rows else rootNum]
+        if self.particles is not None:
+            self.particles.dispose()
+        self.particles = Particles(self.gl, dict(
+            shape=shape, geomShape=[shape[0], shape[1] * 2], logic=Program(LOGIC),
+            device=self._device, mode=self._mode, row0=row0,
+            globalHeight=(gh if gh else (rootNum if rows else 0))))
+        self.logicShader = self.particles.logic
+        self.particles.setup(numBuffers)
+        self.targets.shape = shape
+        self.flow.shape = self.flow.shape          # (re)create on the new context
+        return self
+
+    # -- clears ---------------------------------------------------------------------
+    def clear(self):
+        self.clearView()
+        self.clearFlow()
+        return self
+
+    def clearView(self):
+        return self
+
+    def clearFlow(self):                                       # src/index.js:231-236
+        self.flow.clear()
+        return self
+
+    def restart(self):
+        self.clear()
+        self.reset()
+        return self
+
+    # -- the hot path ------------------------------------------------------------------
+    def step(self):                                            # src/index.js:248-272
+        if not self.timer.paused:
+            self.particles.logic = self.logicShader
+            self.uniforms["update"].update(self.state)
+            self.uniforms["update"].update(
+                dt=self.timer.dt, time=self.timer.time, start=self.timer.since,
+                flow=self.flow, targets=self.targets,
+                viewSize=self.viewSize, viewRes=self.viewRes)
+            self.particles.step(self.uniforms["update"])
+        return self
+
+    def draw(self):                                            # src/index.js:278-340: out of scope
+        return self
+
+    def resize(self):                                          # src/index.js:393-408
+        self.viewRes[0] = self.gl.drawingBufferWidth
+        self.viewRes[1] = self.gl.drawingBufferHeight
+        self.viewSize[:] = cover_aspect(self.viewRes)
+        self.flow.shape = self.viewRes
+        return self
+
+    # -- respawn --------------------------------------------------------------------------
+    def spawn(self, spawner=init_spawner):                     # src/index.js:425-429
+        if spawner is init_spawner:
+            # Particles.spawn(initSpawner) fills every ring buffer with inert texels; do it on device
+            for k in range(len(self.particles.buffers)):
+                call("th_spawn_init", self.particles._ctx, k)
+        else:
+            self.particles.spawn(spawner)
+        return self
+
+    def spawnShader(self, shader, update=None, *rest):         # src/index.js:432-457
+        self.timer.tick()                                       # every GPU spawn advances time
+        self.particles.logic = shader
+        base = dict(self.state, time=self.timer.time, viewSize=self.viewSize, viewRes=self.viewRes)
+        self.particles.step(Particles.applyUpdate(base, update), *rest)
+        self.particles.logic = self.logicShader
+        return self
+
+
+default = Tendrils

@@ -1,0 +1,226 @@
+"""GPU parity of the HIP integrator (through the C ABI) against (a) the golden vectors captured
+from the reference's own shader and (b) the CPU oracle on larger seeded inputs.
+EXACT mode: bit-for-bit.  FAST mode: absolute tolerance stated below."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, golden, load, state_overrides
+
+pytestmark = pytest.mark.gpu
+
+# FAST mode (FMA contraction, rcp/rsq): |delta| per component after ONE step.
+# Velocities are O(1e-2) (speedLimit 0.01); the bound is ~1e-4 relative to that.
+FAST_ATOL = 2e-6
+
+
+def make_tendrils(n, view_res, flow_shape, state, mode):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    opts = ta.defaults()
+    opts["mode"] = mode
+    t = ta.Tendrils(View(*view_res), opts)
+    t.resize()
+    t.setup(n)
+    t.flow.shape = flow_shape
+    for k, v in state.items():
+        t.state[k] = v
+    return t
+
+
+def run_fixture(fx, mode):
+    m = fx["meta"]
+    n = m["N"]
+    t = make_tendrils(n, m["viewRes"], m["flowShape"], state_overrides(m), mode)
+    t.viewSize[:] = m["viewSize"]
+    t.particles.upload_texels(fx["state"])
+    t.flow.set_pixels(fx["flow"])
+    if "targets" in fx:
+        t.targets.set_pixels(fx["targets"])
+    outs = []
+    cur = fx["state"]
+    for k in range(m["steps"]):
+        # follow the reference trajectory exactly as the oracle test does
+        if k:
+            t.particles.upload_texels(cur)
+        t.timer.time = m["times"][k] - m["dts"][k]
+        t.timer.tick()
+        assert t.timer.time == m["times"][k] and t.timer.dt == m["dts"][k]
+        t.step()
+        outs.append(t.particles.read(0))
+        cur = fx["out"][k]
+    t.dispose()
+    return outs
+
+
+@pytest.mark.parametrize("path", golden("logic"), ids=lambda p: p.split("/")[-1][:-4])
+def test_exact_mode_matches_reference_bits(path):
+    import tendrils_amd as ta
+    fx = load(path)
+    outs = run_fixture(fx, ta.TH_MODE_EXACT)
+    for k, got in enumerate(outs):
+        ok = bits_equal(got, fx["out"][k]).all(-1)
+        bad = np.argwhere(~ok & fx["valid"][k])
+        assert len(bad) == 0, "%s step %d: %d texels differ, first %s" % (fx["name"], k, len(bad), bad[:4])
+
+
+@pytest.mark.parametrize("path", golden("logic"), ids=lambda p: p.split("/")[-1][:-4])
+def test_fast_mode_within_tolerance(path):
+    import tendrils_amd as ta
+    fx = load(path)
+    outs = run_fixture(fx, ta.TH_MODE_FAST)
+    for k, got in enumerate(outs):
+        ref = fx["out"][k]
+        v = fx["valid"][k]
+        assert (np.isnan(got) == np.isnan(ref))[v].all()
+        d = np.abs(np.nan_to_num(got) - np.nan_to_num(ref))[v]
+        assert d.max() <= FAST_ATOL, "%s step %d: max |delta| %.3g" % (fx["name"], k, d.max())
+
+
+def seeded_case(n, seed, flow_shape=(96, 54), inert=0.05, pos_range=1.2):
+    rng = np.random.default_rng(seed)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-pos_range, pos_range, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+    st[rng.random((n, n)) < inert] = [-1e6, -1e6, 0, 0]
+    fw, fh = flow_shape
+    fl = np.zeros((fh, fw, 4), np.float32)
+    fl[..., :2] = rng.uniform(-.01, .01, (fh, fw, 2))
+    fl[..., 2] = 4000 + rng.uniform(-150, 16, (fh, fw))
+    fl[..., 3] = 1
+    return st, fl
+
+
+@pytest.mark.parametrize("n,overrides", [
+    (512, {}),
+    (512, {"noiseWeight": 0}),
+    (1024, {}),
+    (1024, {"target": 0.0005}),
+    (200, {}),                      # non power-of-two: true divisions by dataRes
+    (200, {"noiseWeight": 0, "target": 0.001}),
+])
+def test_exact_mode_matches_oracle_on_seeded_inputs(oracle, n, overrides):
+    import tendrils_amd as ta
+    st, fl = seeded_case(n, 7 + n)
+    rng = np.random.default_rng(n)
+    tg = np.zeros((n, n, 4), np.float32)
+    tg[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    t = make_tendrils(n, (96, 54), (96, 54), overrides, ta.TH_MODE_EXACT)
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.targets.set_pixels(tg)
+    t.timer.time = 4000.0
+    cur = st
+    for _ in range(3):
+        t.timer.tick()
+        t.step()
+        got = t.particles.read(0)
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{**{k: v for k, v in t.state.items() if isinstance(v, (int, float))}})
+        want = oracle.logic_step(u, cur, fl, tg)
+        ok = bits_equal(got, want)
+        assert ok.all(), "n=%d %s: %d components differ" % (n, overrides, (~ok).sum())
+        cur = want
+    t.dispose()
+
+
+def test_out_of_domain_lanes_take_reference_path(oracle):
+    """Huge / infinite / NaN positions leave the fast path's proven domain: results must still be
+    the reference's (here: the oracle's), bit for bit."""
+    import tendrils_amd as ta
+    n = 64
+    st, fl = seeded_case(n, 99)
+    st[0, 0, :2] = [3e6, 0.1]
+    st[0, 1, :2] = [1e30, -1e30]
+    st[0, 2, :2] = [np.inf, 0.0]
+    st[0, 3, :2] = [np.nan, 0.5]
+    st[0, 4, 2:] = [np.nan, 0.0]
+    st[0, 5, :2] = [-1e6, 0.25]          # only one component inert -> still live
+    st[0, 6, :2] = [5e5, 5e5]
+    for overrides in ({}, {"noiseWeight": 0}):
+        t = make_tendrils(n, (96, 54), (96, 54), overrides, ta.TH_MODE_EXACT)
+        t.particles.upload_texels(st)
+        t.flow.set_pixels(fl)
+        t.timer.time = 4000.0
+        t.timer.tick()
+        t.step()
+        got = t.particles.read(0)
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        want = oracle.logic_step(u, st, fl)
+        assert bits_equal(got, want).all()
+        t.dispose()
+
+
+def test_ring_semantics_and_errors():
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    t = ta.Tendrils(View(32, 32))
+    t.resize()
+    t.setup(32)
+    b0, b1 = t.particles.buffers
+    st, _ = seeded_case(32, 3, inert=0)
+    t.particles.upload_texels(st)
+    t.timer.tick()
+    t.step()
+    # utils.step rotated the ring: the written buffer is the old LAST one, now in front
+    assert t.particles.buffers == [b1, b0]
+    assert np.array_equal(t.particles.read(b0), st)                 # previous state untouched
+    assert not np.array_equal(t.particles.read(b1), st)
+    # Particles.step needs buffers[1]
+    t.particles.setup(1)
+    with pytest.raises(ta.TendrilsHipError):
+        t.step()
+    t.dispose()
+
+
+def test_full_size_properties():
+    """C3-sized (4096^2) run: size-independent properties instead of a full CPU check.
+    (1) inert texels pass through bit-identically, (2) speed never exceeds speedLimit,
+    (3) newPos == pos + newVel exactly, (4) two identical runs are bit-identical,
+    (5) a row band computed by a sharded context equals the same rows of the full run."""
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    n = 4096
+    rng = np.random.default_rng(2024)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2)).astype(np.float32)
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2)).astype(np.float32)
+    inert = rng.random((n, n)) < 0.03
+    st[inert] = [-1e6, -1e6, 0, 0]
+    fl = np.zeros((270, 480, 4), np.float32)
+    fl[..., :2] = rng.uniform(-.02, .02, (270, 480, 2))
+    fl[..., 2] = 990.0
+    outs = []
+    for rep in range(2):
+        t = ta.Tendrils(View(480, 270))
+        t.resize()
+        t.setup(n)
+        t.particles.upload_texels(st)
+        t.flow.set_pixels(fl)
+        t.timer.time = 1000.0
+        t.timer.tick()
+        t.step()
+        outs.append(t.particles.read(0))
+        vs, tm, dt = list(t.viewSize), t.timer.time, t.timer.dt
+        t.dispose()
+    a = outs[0]
+    assert bits_equal(a, outs[1]).all()
+    assert bits_equal(a[inert], st[inert]).all()
+    live = ~inert
+    sp = np.hypot(a[..., 2].astype(np.float64), a[..., 3].astype(np.float64))[live]
+    assert sp.max() <= 0.01 * (1 + 1e-6)
+    assert np.array_equal(a[live][:, :2], (st[live][:, :2] + a[live][:, 2:]).astype(np.float32))
+    # sharded band (rows 1024..1536 of the global texture) on its own context
+    opts = ta.defaults()
+    opts.update(row0=1024, rows=512, globalHeight=n)
+    tb = ta.Tendrils(View(480, 270), opts)
+    tb.resize()
+    tb.setup(n)
+    tb.particles.upload_texels(st[1024:1536])
+    tb.flow.set_pixels(fl)
+    tb.timer.time = 1000.0
+    tb.timer.tick()
+    tb.step()
+    band = tb.particles.read(0)
+    tb.dispose()
+    assert bits_equal(band, a[1024:1536]).all()
