@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -99,6 +100,7 @@ struct th_context {
     hipStream_t stream = nullptr;
     std::vector<float4 *> ring;          // ring[0] = buffers[0] (most recent)
     float4 *flow = nullptr;
+    float2 *flow_dec = nullptr;          // per-step decoded plane (launch_flow_decode)
     int32_t fw = 0, fh = 0;
     float4 *targets = nullptr;
     bool targets_checked = true, targets_nonfinite = false;   // fresh texture = zeros
@@ -216,6 +218,7 @@ th_status th_create(const th_config *cfg, th_context **out)
         c->fw = c->fh = 1;
         TH_HIP(hipMalloc((void **)&c->flow, sizeof(float4)));
         TH_HIP(hipMemsetAsync(c->flow, 0, sizeof(float4), c->stream));
+        TH_HIP(hipMalloc((void **)&c->flow_dec, sizeof(float2)));
         if (th_status s = alloc_state(c, &c->targets)) return s;
         for (int k = 0; k < c->cfg.num_buffers; ++k) {
             float4 *b = nullptr;
@@ -237,7 +240,7 @@ th_status th_destroy(th_context *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (float4 *b : c->ring) (void)hipFree(b);
-    (void)hipFree(c->flow); (void)hipFree(c->targets); (void)hipFree(c->lut);
+    (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -316,8 +319,10 @@ th_status th_flow_resize(th_context *c, int32_t w, int32_t h)
     if (w == c->fw && h == c->fh) return TH_OK;              // gl-fbo: same shape is a no-op
     TH_HIP(hipStreamSynchronize(c->stream));
     TH_HIP(hipFree(c->flow));
-    c->flow = nullptr;
+    TH_HIP(hipFree(c->flow_dec));
+    c->flow = nullptr; c->flow_dec = nullptr;
     TH_HIP(hipMalloc((void **)&c->flow, (size_t)w * h * sizeof(float4)));
+    TH_HIP(hipMalloc((void **)&c->flow_dec, (size_t)w * h * sizeof(float2)));
     TH_HIP(hipMemsetAsync(c->flow, 0, (size_t)w * h * sizeof(float4), c->stream));
     c->fw = w; c->fh = h;
     return TH_OK;
@@ -381,7 +386,7 @@ static th_status launch_step(th_context *c, const th_logic_uniforms &u, const fl
 {
     const uint32_t W = (uint32_t)c->cfg.width, H = (uint32_t)c->cfg.global_height;
     th::LogicParams p{};
-    p.in = in; p.out = out; p.flow = c->flow; p.targets = c->targets; p.lut = c->lut;
+    p.in = in; p.out = out; p.flow = c->flow; p.flow_dec = c->flow_dec; p.targets = c->targets; p.lut = c->lut;
     p.count = (uint32_t)c->texels();
     p.width = W;
     p.row0 = (uint32_t)c->cfg.row0;
@@ -396,7 +401,8 @@ static th_status launch_step(th_context *c, const th_logic_uniforms &u, const fl
     p.s2_cap = s2_cap_for(u.speedLimit);
 
     // Preconditions of the specialised path (DESIGN.md "fast-path domain").
-    bool generic = !finite_uniforms(u);
+    static const bool force_generic = getenv("TH_FORCE_GENERIC") != nullptr;   // test hook
+    bool generic = force_generic || !finite_uniforms(u);
     const bool noise = u.noiseWeight != 0.0f;
     bool target = u.target != 0.0f;
     if (!generic) {
@@ -423,7 +429,12 @@ static th_status launch_step(th_context *c, const th_logic_uniforms &u, const fl
         }
         target = c->targets_nonfinite;
     }
-    th::launch_logic(p, c->cfg.mode, noise, target, pow2, generic, c->stream);
+    // Decode the flow once per step when that is cheaper than decoding per particle: it shrinks the
+    // random-gather footprint (the L2/Infinity-Fabric miss traffic is what bounds this kernel).
+    const size_t flow_texels = (size_t)c->fw * c->fh;
+    const bool decoded = !generic && c->texels() >= 2 * flow_texels;
+    if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, c->stream);
+    th::launch_logic(p, c->cfg.mode, noise, target, pow2, decoded, generic, c->stream);
     TH_HIP(hipGetLastError());
     return TH_OK;
 }

@@ -135,8 +135,9 @@ TH_D float snoise_lut(float vx, float vy, float vz, float sxy, const float4 *lut
 //   NOISE  noiseWeight != 0
 //   TARGET target != 0 or the targets texture holds a non-finite value
 //   POW2   dataRes.x, dataRes.y powers of two: `/dataRes` == `*(1/dataRes)` exactly
+//   DECODED the flow tap reads the per-step decoded float2 plane (8 B) instead of RGBA32F (16 B)
 // ---------------------------------------------------------------------------
-template <bool FAST, bool NOISE, bool TARGET, bool POW2>
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
 __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 {
     __shared__ float4 lut[NOISE ? kLutSize : 1];
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
         float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
         float4 res = st;
         if (posx != kInert || posy != kInert) {                               // src/logic.frag:52
-            bool in_domain = __builtin_fmaxf(__builtin_fabsf(posx), __builtin_fabsf(posy)) < p.pos_bound;
+            // two compares (not max): a NaN in either component must fail the test
+            bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
             if (__builtin_expect(!in_domain, 0)) {
                 res = logic_texel_ref(p, x, y, st, idx);
             } else {
@@ -179,7 +181,10 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
                 float fu = (sx + 1.0f) * 0.5f, fv = (sy + 1.0f) * 0.5f;       // (1*(v+1))/2, exactly
                 int tx = (int)__builtin_amdgcn_fmed3f(fu * p.fwf, 0.0f, p.fwm1);   // trunc == floor on [0, n-1]
                 int ty = (int)__builtin_amdgcn_fmed3f(fv * p.fhf, 0.0f, p.fhm1);
-                float4 ft = p.flow[ty * p.fw + tx];
+                float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
+                float4 ft;
+                if constexpr (DECODED) { float2 d = p.flow_dec[ty * p.fw + tx]; ffx = d.x; ffy = d.y; }
+                else ft = p.flow[ty * p.fw + tx];
 
                 float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
                 if constexpr (NOISE) {
@@ -193,9 +198,12 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
                     wxs = (wx * u.dt) * vnw; wys = (wy * u.dt) * vnw;
                 }
 
-                float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));
+                if constexpr (!DECODED) {
+                    float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));
+                    ffx = ft.x * k; ffy = ft.y * k;
+                }
                 float vflw = vary(u.flowWeight, i, u.varyFlow);
-                float fxs = ((ft.x * k) * u.dt) * vflw, fys = ((ft.y * k) * u.dt) * vflw;
+                float fxs = (ffx * u.dt) * vflw, fys = (ffy * u.dt) * vflw;
                 float vfw = vary(u.forceWeight, i, u.varyForce);
                 float nvx, nvy;
                 if constexpr (NOISE) {
@@ -255,22 +263,24 @@ static int grid_for(size_t n, int blocks_per_cu)
 }
 
 template <bool FAST, bool NOISE, bool TARGET>
-static void launch_logic_p2(const LogicParams &p, bool pow2, hipStream_t s)
+static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
     int grid = grid_for(p.count, 8);
-    if (pow2) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, false>), dim3(grid), dim3(256), 0, s, p);
+#define TH_GO(P2, DEC) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC>), dim3(grid), dim3(256), 0, s, p)
+    if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
+    else { if (decoded) TH_GO(false, true); else TH_GO(false, false); }
+#undef TH_GO
 }
 
-void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool generic,
-                  hipStream_t s)
+void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
+                  bool generic, hipStream_t s)
 {
     if (generic) {
         hipLaunchKernelGGL(logic_generic_kernel, dim3(grid_for(p.count, 8)), dim3(256), 0, s, p);
         return;
     }
     const bool fast = mode == TH_MODE_FAST;
-#define TH_DISPATCH(F, N, T) launch_logic_p2<F, N, T>(p, pow2, s)
+#define TH_DISPATCH(F, N, T) launch_logic_p2<F, N, T>(p, pow2, decoded, s)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }
@@ -279,6 +289,24 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
         else { if (target) TH_DISPATCH(false, false, true); else TH_DISPATCH(false, false, false); }
     }
 #undef TH_DISPATCH
+}
+
+// Per-texel flow decode for one step (src/flow/get.glsl:3-5).  Sampling is NEAREST and get() is
+// pointwise, so decoding per texel is bit-identical to decoding per particle; it halves the
+// footprint of the random gather (16 -> 8 B per texel).
+__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time, float decay)
+{
+    size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        float4 f = flow[i];
+        float k = __builtin_fmaxf(0.0f, 1.0f - ((time - f.z) * decay));
+        dec[i] = make_float2(f.x * k, f.y * k);
+    }
+}
+
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay);
 }
 
 // ---------------------------------------------------------------------------
@@ -352,17 +380,34 @@ __global__ __launch_bounds__(256) void stats_kernel(const float4 *st, size_t n, 
     }
 }
 
-__global__ __launch_bounds__(64) void stats_fold_kernel(const StatsPartial *part, int nparts, size_t n, th_counters *out)
+__global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *part, int nparts, size_t n, th_counters *out)
 {
-    if (threadIdx.x != 0) return;
-    th_counters c{};
-    c.particles = n;
-    for (int k = 0; k < nparts; ++k) {
-        c.live += part[k].live; c.nan += part[k].nan; c.capped += part[k].capped;
-        c.sum_speed += part[k].sum_speed;
-        c.max_speed = part[k].max_speed > c.max_speed ? part[k].max_speed : c.max_speed;
+    __shared__ StatsPartial sh[4];
+    unsigned long long live = 0, nan = 0, capped = 0;
+    double sum = 0.0, mx = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 256) {      // fixed assignment => reproducible sums
+        live += part[k].live; nan += part[k].nan; capped += part[k].capped;
+        sum += part[k].sum_speed;
+        mx = part[k].max_speed > mx ? part[k].max_speed : mx;
     }
-    *out = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        live += __shfl_xor(live, o); nan += __shfl_xor(nan, o); capped += __shfl_xor(capped, o);
+        sum += __shfl_xor(sum, o);
+        double om = __shfl_xor(mx, o); mx = om > mx ? om : mx;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = StatsPartial{live, nan, capped, sum, mx};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        th_counters c{};
+        c.particles = n;
+        for (int w = 0; w < 4; ++w) {
+            c.live += sh[w].live; c.nan += sh[w].nan; c.capped += sh[w].capped;
+            c.sum_speed += sh[w].sum_speed;
+            c.max_speed = sh[w].max_speed > c.max_speed ? sh[w].max_speed : c.max_speed;
+        }
+        *out = c;
+    }
 }
 
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,
@@ -371,7 +416,7 @@ void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial
     int grid = grid_for(n, 4);
     if (grid > kStatsBlocks) grid = kStatsBlocks;
     hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, state, n, speed_limit, partials);
-    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(64), 0, s, partials, grid, n, out);
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, s, partials, grid, n, out);
 }
 
 }  // namespace th

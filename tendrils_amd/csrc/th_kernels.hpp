@@ -15,6 +15,7 @@ struct LogicParams {
     const float4 *in;        // ring buffers[1]  (this context's rows)
     float4 *out;             // ring buffers[0] or an explicit target
     const float4 *flow;      // RGBA32F flow texture, fw x fh
+    const float2 *flow_dec;  // flow decoded for this step's time: xy * max(0, 1-(time-z)*decay)
     const float4 *targets;   // RGBA32F targets texture (local rows)
     const float4 *lut;       // noise gradient table (kLutSize float4)
     uint32_t count;          // texels held by this context = width * local rows
@@ -60,8 +61,9 @@ struct StatsPartial {
 };
 
 // launchers (defined in th_kernels.hip)
-void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool generic,
-                  hipStream_t stream);
+void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
+                  bool generic, hipStream_t stream);
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t stream);
 void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
 void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,

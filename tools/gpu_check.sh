@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 echo "== node: $(node --version 2>&1 | head -1)   nproc: $(nproc)"
 echo "== pytest -m gpu"
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; tail -15 gpurun_out/pytest_gpu.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke.log
 if [ "${1:-}" != "quick" ]; then
@@ -14,13 +14,13 @@ if [ "${1:-}" != "quick" ]; then
   timeout 300 tools/bin/microbench 2>&1 | tee gpurun_out/microbench.log
 fi
 echo "== bench exact"
-timeout 900 python bench.py --steps 100 --warmup 10 2>&1 | tail -3 | tee gpurun_out/bench_exact.log
+timeout 900 python bench.py --steps 100 --warmup 10 > gpurun_out/bench_exact.log 2>&1; tail -2 gpurun_out/bench_exact.log
 echo "== bench exact flow-only"
-timeout 600 python bench.py --steps 100 --warmup 10 --flow-only --no-cpu 2>&1 | tail -3 | tee gpurun_out/bench_exact_flowonly.log
+timeout 600 python bench.py --steps 100 --warmup 10 --flow-only --no-cpu > gpurun_out/bench_exact_flowonly.log 2>&1; tail -2 gpurun_out/bench_exact_flowonly.log
 echo "== bench fast"
-timeout 600 python bench.py --steps 100 --warmup 10 --mode fast --no-cpu 2>&1 | tail -3 | tee gpurun_out/bench_fast.log
+timeout 600 python bench.py --steps 100 --warmup 10 --mode fast --no-cpu > gpurun_out/bench_fast.log 2>&1; tail -2 gpurun_out/bench_fast.log
 echo "== bench force-dist (RCCL path at world size 1)"
-timeout 600 python bench.py --steps 50 --warmup 5 --force-dist --no-cpu 2>&1 | tail -3 | tee gpurun_out/bench_forcedist.log
+timeout 600 python bench.py --steps 50 --warmup 5 --force-dist --no-cpu > gpurun_out/bench_forcedist.log 2>&1; tail -12 gpurun_out/bench_forcedist.log
 echo "== rocprofv3 kernel trace"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -64,6 +64,31 @@ __global__ __launch_bounds__(256) void gather_kernel(const T *table, unsigned ma
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// cache-policy variants of the 8-B gather (4 loads in flight per lane, then one wait)
+template <int POL>
+__global__ __launch_bounds__(256) void gather_policy_kernel(const v2f *table, unsigned mask, float *out, int per_thread, unsigned seed)
+{
+    unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + seed;
+    float acc = 0;
+    for (int i = 0; i < per_thread; i += 4) {
+        const v2f *p[4];
+        for (int j = 0; j < 4; ++j) { s = s * 1664525u + 1013904223u; p[j] = table + ((s >> 4) & mask); }
+        v2f v0, v1, v2, v3;
+#define LD4(suffix) asm volatile("global_load_dwordx2 %0, %4, off " suffix "\n global_load_dwordx2 %1, %5, off " suffix "\n" \
+                                 "global_load_dwordx2 %2, %6, off " suffix "\n global_load_dwordx2 %3, %7, off " suffix "\n s_waitcnt vmcnt(0)" \
+                                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory")
+        if (POL == 0) LD4("");
+        else if (POL == 1) LD4("nt");
+        else if (POL == 2) LD4("sc1");
+        else if (POL == 3) LD4("sc0 sc1");
+        else if (POL == 4) LD4("sc0");
+        else LD4("sc1 nt");
+#undef LD4
+        acc += v0.x + v1.x + v2.x + v3.x;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void copy_kernel(const v4f *in, v4f *out, size_t n)
 {
@@ -131,6 +156,31 @@ int main()
             }
             CK(hipFree(table));
         }
+    }
+
+    // ---- gather cache policies (8-B, 16 MiB table) ----
+    {
+        size_t bytes = (size_t)16 << 20;
+        void *table; CK(hipMalloc(&table, bytes)); CK(hipMemset(table, 0, bytes));
+        unsigned mask = (unsigned)(bytes / 8 - 1);
+        const char *pn[] = {"default", "nt", "sc1", "sc0 sc1", "sc0", "sc1 nt"};
+        int grid = 256 * 8, per_thread = 64;
+        for (int pol = 0; pol < 6; ++pol)
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                switch (pol) {
+                case 0: hipLaunchKernelGGL(gather_policy_kernel<0>, dim3(grid), dim3(256), 0, 0, (const v2f *)table, mask, out, per_thread, 5u + rep); break;
+                case 1: hipLaunchKernelGGL(gather_policy_kernel<1>, dim3(grid), dim3(256), 0, 0, (const v2f *)table, mask, out, per_thread, 5u + rep); break;
+                case 2: hipLaunchKernelGGL(gather_policy_kernel<2>, dim3(grid), dim3(256), 0, 0, (const v2f *)table, mask, out, per_thread, 5u + rep); break;
+                case 3: hipLaunchKernelGGL(gather_policy_kernel<3>, dim3(grid), dim3(256), 0, 0, (const v2f *)table, mask, out, per_thread, 5u + rep); break;
+                case 4: hipLaunchKernelGGL(gather_policy_kernel<4>, dim3(grid), dim3(256), 0, 0, (const v2f *)table, mask, out, per_thread, 5u + rep); break;
+                case 5: hipLaunchKernelGGL(gather_policy_kernel<5>, dim3(grid), dim3(256), 0, 0, (const v2f *)table, mask, out, per_thread, 5u + rep); break;
+                }
+                CK(hipEventRecord(e1));
+                float ms = time_ms(e0, e1);
+                if (rep == 2) printf("gather 8-B 16 MiB policy %-8s: %.3f ms  %.2f G gathers/s\n", pn[pol], ms, (double)grid * 256 * per_thread / ms / 1e6);
+            }
+        CK(hipFree(table));
     }
 
     // ---- copy ----
