@@ -150,6 +150,45 @@ def gen_logic(r, only):
                    zero_flow=True, state=st, view=(32, 32))
 
 
+def gen_optical_flow(r, only):
+    """One blended pass of the reference's optical-flow shader (docs/js/demo.js:73) per case.
+    Frames are regenerated from seeds by tests/helpers.py:synth_frame; only parameters and the
+    reference output (whole texture, or row bands for the 1080p case) are stored."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from helpers import of_inputs
+    cases = [
+        # name, frame (w,h), out (w,h), uniforms, bands
+        ("of_default_64", (64, 48), (64, 48), dict(viewSize=[1, 1], scaleUV=[1, -1], offset=1.0 / 64, speed=1,
+                                                   speedLimit=1, time=1234.5), None),
+        # demo settings src/demo.main.js:526-530 (speed .08, offset .1, scaleUV [-1,-1]) + tendrils speedLimit
+        ("of_demo_96x64", (64, 48), (96, 64), dict(viewSize=[1, 1.5], scaleUV=[-1, -1], offset=0.1, speed=0.08,
+                                                   speedLimit=0.01, time=777.0), None),
+        ("of_demo_240x135", (160, 90), (240, 135), dict(viewSize=[1, 240 / 135], scaleUV=[-1, -1], offset=0.1,
+                                                        speed=0.08, speedLimit=0.01, time=5016.67), None),
+        ("of_texel_offset_240x135", (240, 135), (240, 135), dict(viewSize=[1, 240 / 135], scaleUV=[-1, -1],
+                                                                 offset=1.0 / 240, speed=0.08, speedLimit=0.01,
+                                                                 time=5016.67), None),
+        # C3: 1080p frames and flow; only three 8-row bands are kept
+        ("of_c3_1080p", (1920, 1080), (1920, 1080), dict(viewSize=[1, 1920 / 1080], scaleUV=[-1, -1], offset=0.1,
+                                                         speed=0.08, speedLimit=0.01, time=1000.0),
+         [(0, 8), (536, 544), (1072, 1080)]),
+    ]
+    for name, fr, out, un, bands in cases:
+        if only and only not in name:
+            continue
+        un = dict(un)
+        un["lambda"] = 0.001
+        seed = sum(map(ord, name))
+        meta = dict(kind="optical_flow", frame=list(fr), out=list(out), uniforms=un, seed=seed,
+                    shift8=[12, 6], bands=bands)          # frame1 = frame0 translated by (1.5, 0.75) px
+        f0, f1, dst = of_inputs(meta)
+        ow, oh = out
+        ref = r.shader("optical_flow", (ow, oh), textures={"view": f1, "last": f0}, uniforms=un, blend=True, dst=dst)
+        if bands:
+            ref = np.concatenate([ref[a:b] for a, b in bands])
+        save(name, out=ref, uniforms=json.dumps(meta))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -157,6 +196,7 @@ def main():
     r = RefRunner()
     print("oracle:", r.probe())
     gen_logic(r, args.only)
+    gen_optical_flow(r, args.only)
 
 
 if __name__ == "__main__":

@@ -112,6 +112,7 @@
   }
   function makeTex(gl, spec) {
     var tex = gl.createTexture();
+    gl.activeTexture(gl.TEXTURE0 + 7);      // scratch unit: creation must not rebind a sampler's unit
     gl.bindTexture(gl.TEXTURE_2D, tex);
     gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MIN_FILTER, gl.NEAREST);
     gl.texParameteri(gl.TEXTURE_2D, gl.TEXTURE_MAG_FILTER, gl.NEAREST);

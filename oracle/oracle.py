@@ -86,6 +86,9 @@ def lib():
                                     fp, C.c_int, C.c_int, fp]
         L.to_spawn_init.restype = None
         L.to_spawn_init.argtypes = [fp, C.c_size_t]
+        L.to_optical_flow.restype = None
+        L.to_optical_flow.argtypes = [C.POINTER(OpticalFlowUniforms), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
+                                      C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -132,4 +135,27 @@ def logic_step(u, state, flow, targets=None, y0=0):
 def spawn_init(shape):
     out = np.empty(tuple(shape) + (4,), np.float32)
     lib().to_spawn_init(_fp(out), out.size // 4)
+    return out
+
+
+def optical_flow_uniforms(time, view_size=(1.0, 1.0), scaleUV=(1.0, -1.0), offset=1.0, lambda_=0.001,
+                          speed=1.0, speedLimit=1.0, **_):
+    """defaults: /root/reference/src/optical-flow/index.js:21-29"""
+    u = OpticalFlowUniforms()
+    u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+    u.scaleUV[0], u.scaleUV[1] = float(scaleUV[0]), float(scaleUV[1])
+    u.offset, u.lambda_, u.time, u.speed, u.speedLimit = float(offset), float(lambda_), float(time), float(speed), float(speedLimit)
+    return u
+
+
+def optical_flow(u, view, last, flow, blend=True):
+    """view/last: [h, w, 4] uint8; flow: [H, W, 4] f32 (destination contents); returns the new flow."""
+    view = np.ascontiguousarray(view, np.uint8)
+    last = np.ascontiguousarray(last, np.uint8)
+    out = np.array(flow, np.float32, order="C", copy=True)
+    h, w = view.shape[:2]
+    assert last.shape == view.shape
+    lib().to_optical_flow(C.byref(u), view.ctypes.data_as(C.POINTER(C.c_uint8)),
+                          last.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, _fp(out), out.shape[1], out.shape[0],
+                          1 if blend else 0)
     return out

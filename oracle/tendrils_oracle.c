@@ -222,3 +222,80 @@ void to_spawn_init(float *out, size_t texels)
         out[4 * k + 2] = 0.0f;     out[4 * k + 3] = 0.0f;
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* src/optical-flow/index.frag:55-81 (compiled text: docs/js/demo.js:73)       */
+/* ------------------------------------------------------------------------- */
+
+/* NEAREST + CLAMP_TO_EDGE texel index of an 8-bit-per-channel texture as the captured
+ * reference run computed it: the coordinate is clamped to [0, 1), truncated to 16 fractional
+ * bits, and the texel is (coord16 * size) >> 16.  Differs from floor(u*size) only for
+ * coordinates within 2^-16 of a texel boundary (GL leaves that precision to the implementation;
+ * float textures - flow, state - took the plain floor path, see nearest_texel). */
+static inline int nearest_texel_fx16(float u, int n)
+{
+    float c = u;
+    if (!(c > 0.0f)) c = 0.0f;
+    if (c > 65535.0f / 65536.0f) c = 65535.0f / 65536.0f;
+    uint32_t fx = (uint32_t)(c * 65536.0f);
+    return (int)((fx * (uint32_t)n) >> 16);
+}
+
+/* texture2D on an RGBA8 NEAREST/CLAMP texture, then grayScale()
+ * (src/utils/gray-scale.glsl:2): dot(rgb, (0.3, 0.59, 0.11)) */
+static inline float gray_tap(const uint8_t *img, int w, int h, float u, float v)
+{
+    const uint8_t *t = img + 4 * ((size_t)nearest_texel_fx16(v, h) * w + nearest_texel_fx16(u, w));
+    /* UNORM8 -> float: GL leaves the conversion's rounding to the implementation; the captured
+     * reference run widened to UNORM16 (c*257) and scaled by 1/65535 (bit-exact match), which
+     * equals c/255 to within 1 ulp. */
+    const float k = 1.0f / 65535.0f;
+    float r = (float)(t[0] * 257) * k, g = (float)(t[1] * 257) * k, b = (float)(t[2] * 257) * k;
+    return r * 0.3f + g * 0.59f + b * 0.11f;
+}
+
+void to_optical_flow(const to_optical_flow_uniforms *u, const uint8_t *view, const uint8_t *last,
+                     int fr_w, int fr_h, float *flow, int out_w, int out_h, int blend)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < out_h; ++y) {
+        for (int x = 0; x < out_w; ++x) {
+            /* varying uv = position.xy (src/screen/index.vert:6-10): NDC of the pixel centre,
+             * interpolated by the rasteriser as (x+0.5)*A - 1 with gradient A = d(uv)/dx.
+             * A == fl(2/W) in every captured reference run kept as a fixture (64, 96, 240,
+             * 1920 wide; 48, 64, 135, 1080 high); the reference rasteriser derives A through an
+             * approximate reciprocal and can be 1 ulp off at other sizes (e.g. W = 100), where
+             * GL leaves the interpolation precision implementation-defined. */
+            float ux = ((float)x + 0.5f) * (2.0f / (float)out_w) - 1.0f;
+            float uy = ((float)y + 0.5f) * (2.0f / (float)out_h) - 1.0f;
+            /* :56 st = posToUV(uv*scaleUV/viewSize) */
+            float px = ux * u->scaleUV[0] / u->viewSize[0], py = uy * u->scaleUV[1] / u->viewSize[1];
+            float sx = 0.0f + (1.0f * (px + 1.0f)) / 2.0f, sy = 0.0f + (1.0f * (py + 1.0f)) / 2.0f;
+            float o = u->offset;
+            /* :63-67 */
+            float gx = (gray_tap(view, fr_w, fr_h, sx + o, sy + 0.0f) - gray_tap(view, fr_w, fr_h, sx - o, sy - 0.0f)) +
+                       (gray_tap(last, fr_w, fr_h, sx + o, sy + 0.0f) - gray_tap(last, fr_w, fr_h, sx - o, sy - 0.0f));
+            float gy = (gray_tap(view, fr_w, fr_h, sx + 0.0f, sy + o) - gray_tap(view, fr_w, fr_h, sx - 0.0f, sy - o)) +
+                       (gray_tap(last, fr_w, fr_h, sx + 0.0f, sy + o) - gray_tap(last, fr_w, fr_h, sx - 0.0f, sy - o));
+            float gm = sqrtf((gx * gx) + (gy * gy) + u->lambda);                     /* :69 */
+            float diff = gray_tap(view, fr_w, fr_h, sx, sy) - gray_tap(last, fr_w, fr_h, sx, sy);   /* :72 */
+            float vx = (diff * (gx / gm)) * u->speed, vy = (diff * (gy / gm)) * u->speed;            /* :78 */
+            /* :80 bezier(vec3(0,0,1), t) = (0*ut+0*t)*ut + (0*ut+1*t)*t  (src/utils/bezier.glsl:9-13) */
+            float t = sqrtf(vx * vx + vy * vy) / u->speedLimit;
+            float ut = 1.0f - t;
+            float bz = (0.0f * ut + 0.0f * t) * ut + (0.0f * ut + 1.0f * t) * t;
+            float fx = bz * vx, fy = bz * vy;
+            /* flow(vel, speedLimit): src/flow/apply/state.glsl:5-16 */
+            float a = fminf(sqrtf(fx * fx + fy * fy) / u->speedLimit, 1.0f);
+            float src[4] = {fx, fy, u->time, a};
+            float *d = flow + 4 * ((size_t)y * out_w + x);
+            if (blend) {
+                /* gl.blendFunc(SRC_ALPHA, ONE_MINUS_SRC_ALPHA) on a float target (src/index.js:267-268) */
+                float ia = 1.0f - a;
+                for (int c = 0; c < 4; ++c) d[c] = src[c] * a + d[c] * ia;
+            } else {
+                for (int c = 0; c < 4; ++c) d[c] = src[c];
+            }
+        }
+    }
+}

@@ -522,9 +522,21 @@ th_status th_frames_rotate(th_context *c)
     return TH_OK;
 }
 
-th_status th_optical_flow(th_context *, const th_optical_flow_uniforms *)
+th_status th_optical_flow(th_context *c, const th_optical_flow_uniforms *u)
 {
-    return fail(TH_ERR_UNSUPPORTED, "th_optical_flow: not built yet");
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(u, "null uniforms");
+    TH_REQUIRE(c->frames[0] && c->frames[1], "no frame buffers (call th_frames_resize)");
+    th::OpticalFlowParams p{};
+    p.view = c->frames[0]; p.last = c->frames[1];      // OpticalFlow.update: view = buffers[0], last = buffers[1]
+    p.flow = c->flow;
+    p.fr_w = c->frw; p.fr_h = c->frh;
+    p.out_w = c->fw; p.out_h = c->fh;
+    p.grad_x = 2.0f / (float)c->fw; p.grad_y = 2.0f / (float)c->fh;
+    p.u = *u;
+    th::launch_optical_flow(p, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
 }
 
 th_status th_stats_async(th_context *c, float speed_limit, void **device_counters)

@@ -17,6 +17,14 @@ namespace th {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+static int grid_for(size_t n, int blocks_per_cu)
+{
+    size_t blocks = (n + 255) / 256;
+    size_t cap = (size_t)256 * blocks_per_cu;
+    return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+
 // streaming (read-once / write-once) 16-byte accesses of the state ring
 TH_D float4 load_stream(const float4 *p)
 {
@@ -255,13 +263,6 @@ __global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p)
     }
 }
 
-static int grid_for(size_t n, int blocks_per_cu)
-{
-    size_t blocks = (n + 255) / 256;
-    size_t cap = (size_t)256 * blocks_per_cu;
-    return (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
-}
-
 template <bool FAST, bool NOISE, bool TARGET>
 static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
@@ -307,6 +308,76 @@ __global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, fl
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t s)
 {
     if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay);
+}
+
+// ---------------------------------------------------------------------------
+// Optical-flow producer: src/optical-flow/index.frag:55-81, one thread per flow texel,
+// alpha-blended into the flow texture (SRC_ALPHA, ONE_MINUS_SRC_ALPHA: src/index.js:267-268).
+// Ten NEAREST/CLAMP taps of the two RGBA8 frames; neighbouring lanes read neighbouring
+// texels, so every tap is a coalesced 4-byte-per-lane load served by L2.
+// ---------------------------------------------------------------------------
+// NEAREST + CLAMP_TO_EDGE index into an 8-bit-per-channel texture, with the coordinate
+// precision of the captured reference run: clamp to [0, 1), truncate to 16 fractional bits,
+// texel = (coord16 * size) >> 16 (equals floor(u*size) except within 2^-16 of a texel boundary).
+TH_D int nearest_texel_fx16(float u, unsigned n)
+{
+    float c = __builtin_amdgcn_fmed3f(u, 0.0f, 65535.0f / 65536.0f);
+    unsigned fx = (unsigned)(c * 65536.0f);
+    return (int)((fx * n) >> 16);
+}
+
+// texture2D on RGBA8 then grayScale() (src/utils/gray-scale.glsl:2).  UNORM8 -> float as
+// (c*257) * (1/65535): what the captured reference run did; equals c/255 within 1 ulp.
+TH_D float gray_tap(const uchar4 *img, int w, int h, float u, float v)
+{
+    uchar4 t = img[nearest_texel_fx16(v, (unsigned)h) * w + nearest_texel_fx16(u, (unsigned)w)];
+    const float k = 1.0f / 65535.0f;
+    float r = ((float)t.x * 257.0f) * k, g = ((float)t.y * 257.0f) * k, b = ((float)t.z * 257.0f) * k;
+    return r * 0.3f + g * 0.59f + b * 0.11f;
+}
+
+template <bool BLEND>
+__global__ __launch_bounds__(256) void optical_flow_kernel(const OpticalFlowParams p)
+{
+    const th_optical_flow_uniforms &u = p.u;
+    const int n = p.out_w * p.out_h;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        int y = idx / p.out_w, x = idx - y * p.out_w;
+        // varying uv = position.xy (src/screen/index.vert:6-10): NDC of the pixel centre, as the
+        // rasteriser interpolates it: (x+0.5)*A - 1 with gradient A = fl(2/W)  (DESIGN.md "optical flow")
+        float ux = ((float)x + 0.5f) * p.grad_x - 1.0f;
+        float uy = ((float)y + 0.5f) * p.grad_y - 1.0f;
+        float px = ux * u.scaleUV[0] / u.viewSize[0], py = uy * u.scaleUV[1] / u.viewSize[1];
+        float sx = (px + 1.0f) * 0.5f, sy = (py + 1.0f) * 0.5f;          // posToUV, exactly (1*(v+1))/2
+        float o = u.offset;
+#define TAP(img, a, b) gray_tap(img, p.fr_w, p.fr_h, a, b)
+        float gx = (TAP(p.view, sx + o, sy) - TAP(p.view, sx - o, sy)) + (TAP(p.last, sx + o, sy) - TAP(p.last, sx - o, sy));
+        float gy = (TAP(p.view, sx, sy + o) - TAP(p.view, sx, sy - o)) + (TAP(p.last, sx, sy + o) - TAP(p.last, sx, sy - o));
+        float diff = TAP(p.view, sx, sy) - TAP(p.last, sx, sy);
+#undef TAP
+        float gm = __builtin_sqrtf((gx * gx) + (gy * gy) + u.lambda);
+        float vx = (diff * (gx / gm)) * u.speed, vy = (diff * (gy / gm)) * u.speed;
+        // bezier(vec3(0,0,1), t) (src/utils/bezier.glsl:9-13), literal operation order
+        float t = __builtin_sqrtf(vx * vx + vy * vy) / u.speedLimit;
+        float ut = 1.0f - t;
+        float bz = (0.0f * ut + 0.0f * t) * ut + (0.0f * ut + 1.0f * t) * t;
+        float fx = bz * vx, fy = bz * vy;
+        // flow(vel, speedLimit): vec4(vel, time, min(length(vel)/speedLimit, 1))  src/flow/apply/state.glsl:5-16
+        float a = __builtin_fminf(__builtin_sqrtf(fx * fx + fy * fy) / u.speedLimit, 1.0f);
+        float4 src = make_float4(fx, fy, u.time, a);
+        if constexpr (BLEND) {
+            float4 d = p.flow[idx];
+            float ia = 1.0f - a;
+            src = make_float4(src.x * a + d.x * ia, src.y * a + d.y * ia, src.z * a + d.z * ia, src.w * a + d.w * ia);
+        }
+        p.flow[idx] = src;
+    }
+}
+
+void launch_optical_flow(const OpticalFlowParams &p, hipStream_t s)
+{
+    size_t n = (size_t)p.out_w * p.out_h;
+    if (n) hipLaunchKernelGGL(optical_flow_kernel<true>, dim3(grid_for(n, 8)), dim3(256), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct OpticalFlowParams {
     float4 *flow;
     int32_t fr_w, fr_h;      // frame size
     int32_t out_w, out_h;    // flow texture size
+    float grad_x, grad_y;    // d(uv)/d(pixel) of the full-screen pass: fl(2/out_w), fl(2/out_h)
     th_optical_flow_uniforms u;
 };
 

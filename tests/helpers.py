@@ -31,3 +31,49 @@ def bits_equal(a, b):
 def state_overrides(meta):
     """Uniform values the reference actually used (Tendrils.state after overrides)."""
     return {k: v for k, v in meta["state"].items()}
+
+
+def synth_frame(w, h, seed, shift8=(0, 0)):
+    """Deterministic smooth RGBA8 frame (integer arithmetic only, so it is reproducible on any
+    host): a seeded low-resolution grid, bilinearly upsampled.  shift8 = translation in 1/8 px."""
+    rng = np.random.default_rng(seed)
+    cell = 8
+    gw, gh = w // cell + 4, h // cell + 4
+    grid = rng.integers(0, 256, (gh, gw, 3), dtype=np.int64)
+    ys = (np.arange(h, dtype=np.int64) * 8 + shift8[1] + 8 * cell)[:, None]
+    xs = (np.arange(w, dtype=np.int64) * 8 + shift8[0] + 8 * cell)[None, :]
+    gy, fy = ys // (8 * cell), ys % (8 * cell)
+    gx, fx = xs // (8 * cell), xs % (8 * cell)
+    q = 8 * cell
+    out = np.empty((h, w, 4), np.uint8)
+    for c in range(3):
+        g = grid[..., c]
+        top = g[gy, gx] * (q - fx) + g[gy, gx + 1] * fx
+        bot = g[gy + 1, gx] * (q - fx) + g[gy + 1, gx + 1] * fx
+        out[..., c] = ((top * (q - fy) + bot * fy) // (q * q)).astype(np.uint8)
+    out[..., 3] = 255
+    return out
+
+
+def of_inputs(meta):
+    """Inputs of an optical-flow fixture, regenerated from its seeds: (last frame, view frame,
+    destination flow contents before the blended pass)."""
+    fw, fh = meta["frame"]
+    ow, oh = meta["out"]
+    seed = meta["seed"]
+    f0 = synth_frame(fw, fh, seed)
+    f1 = synth_frame(fw, fh, seed, shift8=tuple(meta["shift8"]))
+    rng = np.random.default_rng(seed)
+    dst = np.zeros((oh, ow, 4), np.float32)
+    dst[..., :2] = rng.uniform(-.01, .01, (oh, ow, 2))
+    dst[..., 2] = meta["uniforms"]["time"] - 60.0
+    dst[..., 3] = rng.uniform(0, 1, (oh, ow))
+    return f0, f1, dst
+
+
+def of_expected(fx, full):
+    """Select the rows a fixture stores from a full [H, W, 4] result."""
+    bands = fx["meta"].get("bands")
+    if not bands:
+        return full
+    return np.concatenate([full[a:b] for a, b in bands])
