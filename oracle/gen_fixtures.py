@@ -142,7 +142,7 @@ def gen_logic(r, only):
         logic_case(r, name, **kw)
 
     # zero speed -> 0/0 = NaN (src/logic.frag:92-94): zero velocity, no forces
-    if not only or "zero_speed" in only:
+    if not only or only in "logic_zero_speed_32":
         rng = np.random.default_rng(113)
         st = rand_state(rng, 32, 0.0)
         st[::2, :, 2:] = 0.0
@@ -189,6 +189,38 @@ def gen_optical_flow(r, only):
         save(name, out=ref, uniforms=json.dumps(meta))
 
 
+def gen_spawn(r, only):
+    """Respawn shaders (docs/js/demo.js:71-72): ball, flow-sample, data-sample.  Their hashes
+    amplify the platform's sin(), so these captures pin statistics, not bits."""
+    if not only or only in "spawn_ball_default_64 spawn_ball_demo_128":
+        for name, n, un in (("spawn_ball_default_64", 64, dict(radius=1.0, speed=0.0)),
+                            ("spawn_ball_demo_128", 128, dict(radius=0.3, speed=0.005))):   # src/demo.main.js:1402-1405
+            ref = r.shader("spawn_ball", (n, n), uniforms=un)
+            save(name, out=ref, uniforms=json.dumps(dict(kind="spawn_ball", N=n, uniforms=un)))
+    rng = np.random.default_rng(4711)
+    n, (fw, fh) = 64, (96, 54)
+    st = rand_state(rng, n, 0.3, 1.0, 0.004)
+    time = 2016.67
+    fl = rand_flow(rng, fw, fh, time, 0.01, 100.0)
+    ident = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    view_size = [1.0, 96 / 54]
+    if not only or only in "spawn_flow_sample_64":
+        # spawnFlow(): spawnSize = [1,-1]/viewSize, buffer = tendrils.flow  (src/demo.main.js:403-424);
+        # jitter = aspect(viewRes, jitterRad=2) = 2/viewRes  (src/spawn/pixels/index.js:19,53)
+        un = dict(dataRes=[n, n], geomRes=[n, 2 * n], spawnSize=[1 / view_size[0], -1 / view_size[1]],
+                  jitter=[2 / fw, 2 / fh], time=time, speed=1.0, bias=1.0, flowDecay=0.005, spawnMatrix=ident)
+        ref = r.shader("spawn_flow_sample", (n, n), textures={"particles": st, "spawnData": fl}, uniforms=un)
+        save("spawn_flow_sample_64", state=st, data=fl, out=ref,
+             uniforms=json.dumps(dict(kind="spawn_sample", N=n, samples=5, apply=0, uniforms=un)))
+    if not only or only in "spawn_data_sample_64":
+        # spawnFastest(): buffer = particles.buffers[0], spawnSize = particles.shape (src/demo.main.js:437-441)
+        un = dict(dataRes=[n, n], geomRes=[n, 2 * n], spawnSize=[n, n], jitter=[2 / fw, 2 / fh], time=time,
+                  speed=1.0, bias=1.0, spawnMatrix=ident)
+        ref = r.shader("spawn_data_sample", (n, n), textures={"particles": st, "spawnData": st}, uniforms=un)
+        save("spawn_data_sample_64", state=st, data=st, out=ref,
+             uniforms=json.dumps(dict(kind="spawn_sample", N=n, samples=2, apply=1, uniforms=un)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -197,6 +229,7 @@ def main():
     print("oracle:", r.probe())
     gen_logic(r, args.only)
     gen_optical_flow(r, args.only)
+    gen_spawn(r, args.only)
 
 
 if __name__ == "__main__":

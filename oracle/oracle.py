@@ -89,6 +89,12 @@ def lib():
         L.to_optical_flow.restype = None
         L.to_optical_flow.argtypes = [C.POINTER(OpticalFlowUniforms), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8),
                                       C.c_int, C.c_int, fp, C.c_int, C.c_int, C.c_int]
+        L.to_random.restype = C.c_float
+        L.to_random.argtypes = [C.c_float, C.c_float]
+        L.to_spawn_ball.restype = None
+        L.to_spawn_ball.argtypes = [C.POINTER(SpawnBallUniforms), fp, C.c_int, C.c_int, C.c_int]
+        L.to_spawn_sample.restype = None
+        L.to_spawn_sample.argtypes = [C.POINTER(SpawnSampleUniforms), fp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -158,4 +164,35 @@ def optical_flow(u, view, last, flow, blend=True):
     lib().to_optical_flow(C.byref(u), view.ctypes.data_as(C.POINTER(C.c_uint8)),
                           last.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, _fp(out), out.shape[1], out.shape[0],
                           1 if blend else 0)
+    return out
+
+
+def spawn_ball(w, rows, radius=1.0, speed=0.0, y0=0):
+    """src/spawn/ball/index.js:7-10 defaults: radius 1, speed 0."""
+    u = SpawnBallUniforms(radius=float(radius), speed=float(speed))
+    out = np.empty((rows, w, 4), np.float32)
+    lib().to_spawn_ball(C.byref(u), _fp(out), int(w), int(y0), int(rows))
+    return out
+
+
+def spawn_sample_uniforms(data_w, data_h, time, samples, apply, spawnSize=(1.0, 1.0), jitter=(0.0, 0.0),
+                          speed=1.0, bias=1.0, flowDecay=0.005, spawnMatrix=(1, 0, 0, 0, 1, 0, 0, 0, 1)):
+    u = SpawnSampleUniforms()
+    u.data_w, u.data_h = int(data_w), int(data_h)
+    u.spawnSize[0], u.spawnSize[1] = float(spawnSize[0]), float(spawnSize[1])
+    u.jitter[0], u.jitter[1] = float(jitter[0]), float(jitter[1])
+    u.time, u.speed, u.bias, u.flowDecay = float(time), float(speed), float(bias), float(flowDecay)
+    for k in range(9):
+        u.spawnMatrix[k] = float(spawnMatrix[k])
+    u.samples, u.apply = int(samples), int(apply)
+    return u
+
+
+def spawn_sample(u, particles, spawn_data, y0=0):
+    particles = np.ascontiguousarray(particles, np.float32)
+    spawn_data = np.ascontiguousarray(spawn_data, np.float32)
+    out = np.empty_like(particles)
+    rows = particles.shape[0]
+    sh, sw = spawn_data.shape[:2]
+    lib().to_spawn_sample(C.byref(u), _fp(particles), _fp(out), int(y0), int(rows), _fp(spawn_data), sw, sh)
     return out

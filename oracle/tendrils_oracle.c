@@ -299,3 +299,156 @@ void to_optical_flow(const to_optical_flow_uniforms *u, const uint8_t *view, con
         }
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* Respawn passes.  The GLSL hash `fract(sin(x)*43758.5453)` (glsl-random      */
+/* 0.0.5) and angleToVec()'s cos/sin amplify the last bits of the platform's   */
+/* sin/cos, so no two GL implementations agree on them.  This   */
+/* build pins them: sin/cos are evaluated by the fixed fp64 sequence below     */
+/* (quadrant reduction + Taylor polynomials, every step an IEEE fp64 fma/mul/  */
+/* add) and rounded once to fp32 - reproducible bit-for-bit on any IEEE        */
+/* machine, and within one fp32 rounding of the true value.  Against the       */
+/* reference captures these passes are therefore checked statistically.        */
+/* ------------------------------------------------------------------------- */
+
+static void sincos_pinned(float xf, float *s_out, float *c_out)
+{
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2_HI = 1.57079632679489655800e+00;   /* pi/2 rounded to fp64 */
+    const double PIO2_LO = 6.12323399573676603587e-17;   /* pi/2 - PIO2_HI */
+    double x = (double)xf;
+    double k = __builtin_rint(x * TWO_OVER_PI);
+    double r = __builtin_fma(-k, PIO2_HI, x);
+    r = __builtin_fma(-k, PIO2_LO, r);
+    double r2 = r * r;
+    /* sin(r) = r + r^3*(S1 + r^2*(S2 + ...)), |r| <= pi/4 */
+    double ps = -1.0 / 1307674368000.0;                       /* -1/15! */
+    ps = __builtin_fma(ps, r2, 1.0 / 6227020800.0);           /*  1/13! */
+    ps = __builtin_fma(ps, r2, -1.0 / 39916800.0);            /* -1/11! */
+    ps = __builtin_fma(ps, r2, 1.0 / 362880.0);               /*  1/9!  */
+    ps = __builtin_fma(ps, r2, -1.0 / 5040.0);                /* -1/7!  */
+    ps = __builtin_fma(ps, r2, 1.0 / 120.0);                  /*  1/5!  */
+    ps = __builtin_fma(ps, r2, -1.0 / 6.0);                   /* -1/3!  */
+    double sr = __builtin_fma(ps * r2, r, r);
+    /* cos(r) = 1 + r^2*(C1 + r^2*(C2 + ...)) */
+    double pc = 1.0 / 20922789888000.0;                       /*  1/16! */
+    pc = __builtin_fma(pc, r2, -1.0 / 87178291200.0);         /* -1/14! */
+    pc = __builtin_fma(pc, r2, 1.0 / 479001600.0);            /*  1/12! */
+    pc = __builtin_fma(pc, r2, -1.0 / 3628800.0);             /* -1/10! */
+    pc = __builtin_fma(pc, r2, 1.0 / 40320.0);                /*  1/8!  */
+    pc = __builtin_fma(pc, r2, -1.0 / 720.0);                 /* -1/6!  */
+    pc = __builtin_fma(pc, r2, 1.0 / 24.0);                   /*  1/4!  */
+    pc = __builtin_fma(pc, r2, -0.5);                         /* -1/2!  */
+    double cr = __builtin_fma(pc, r2, 1.0);
+    long q = (long)k & 3;                                     /* two's complement: valid for k < 0 */
+    double s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+    double c = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+static inline float modf_glsl(float x, float y) { return x - y * floorf(x / y); }   /* GLSL mod() */
+static inline float fractf_glsl(float x) { return x - floorf(x); }                 /* GLSL fract() */
+
+/* glsl-random 0.0.5 (required at src/spawn/ball/index.frag:6, src/spawn/pixels/frag/head.frag:21;
+ * compiled text docs/js/demo.js:71): fract(sin(mod(dot(co,(12.9898,78.233)),3.14))*43758.5453) */
+float to_random(float cox, float coy)
+{
+    float dt = cox * 12.9898f + coy * 78.233f;
+    float sn = modf_glsl(dt, 3.14f);
+    float s, c;
+    sincos_pinned(sn, &s, &c);
+    return fractf_glsl(s * 43758.5453f);
+}
+
+/* src/spawn/ball/index.frag:11-19 */
+void to_spawn_ball(const to_spawn_ball_uniforms *u, float *out, int w, int y0, int rows)
+{
+    const float tau = 6.28318530717958647692f;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) {
+        for (int x = 0; x < w; ++x) {
+            float fx = (float)x + 0.5f, fy = (float)(y0 + r) + 0.5f;
+            float r0 = to_random(fx * 1.7654f + 2.3675f, fy * 1.7654f + 2.3675f);
+            float r1 = to_random(fx * 1.23494f + 0.36434f, fy * 1.23494f + 0.36434f);
+            float r2 = to_random(fx * 0.327789f + 3.498787f, fy * 0.327789f + 3.498787f);
+            float r3 = to_random(fx * 9.0374f + 0.2773f, fy * 9.0374f + 0.2773f);
+            float s0, c0, s1, c1;
+            sincos_pinned(r0 * tau, &s0, &c0);        /* angleToVec: vec2(cos, sin), src/utils/angle-to-vec.glsl */
+            sincos_pinned(r2 * tau, &s1, &c1);
+            float *o = out + 4 * ((size_t)r * w + x);
+            o[0] = c0 * r1 * u->radius; o[1] = s0 * r1 * u->radius;
+            o[2] = c1 * r3 * u->speed;  o[3] = s1 * r3 * u->speed;
+        }
+    }
+}
+
+/* float-texture NEAREST/CLAMP fetch at uv */
+static inline const float *tex_f32(const float *tex, int w, int h, float u, float v)
+{
+    return tex + 4 * ((size_t)nearest_texel(v, h) * w + nearest_texel(u, w));
+}
+
+/* src/spawn/pixels/frag/head.frag:28-34; mix(a,b,t) = a*(1-t) + b*t (GLSL ES 1.0 8.3) */
+static void spawn_to_pos(const to_spawn_sample_uniforms *u, float uvx, float uvy, float *px, float *py)
+{
+    float tt = u->time * 0.001f;
+    float ra = to_random(uvx - 1.2345f + tt, uvy - 1.2345f + tt);
+    float rb = to_random(uvx + 1.2345f + tt, uvy + 1.2345f + tt);
+    float ox = (-u->jitter[0]) * (1.0f - ra) + u->jitter[0] * ra;
+    float oy = (-u->jitter[1]) * (1.0f - rb) + u->jitter[1] * rb;
+    /* uvToPos = map(uv, 0,1, -1,1) = -1 + (1-(-1))*(v-0)/(1-0)   (glsl-map 1.0.1) */
+    float qx = -1.0f + (2.0f * ((uvx + ox) - 0.0f)) / 1.0f;
+    float qy = -1.0f + (2.0f * ((uvy + oy) - 0.0f)) / 1.0f;
+    qx = qx * 1.0f * u->spawnSize[0];                       /* *flipUV*spawnSize, flipUV = (1,-1) */
+    qy = qy * -1.0f * u->spawnSize[1];
+    /* transform(mat3 m, vec2 v) = (m*vec3(v,1)).xy, column-major m */
+    const float *m = u->spawnMatrix;
+    *px = m[0] * qx + m[3] * qy + m[6] * 1.0f;
+    *py = m[1] * qx + m[4] * qy + m[7] * 1.0f;
+}
+
+/* src/spawn/pixels/frag/best-sample-main.frag:21-46 */
+void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, float *out,
+                     int y0, int rows, const float *spawn_data, int sw, int sh)
+{
+    const int W = u->data_w;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) {
+        for (int x = 0; x < W; ++x) {
+            size_t o = 4 * ((size_t)r * W + x);
+            float uvx = ((float)x + 0.5f) / (float)u->data_w, uvy = ((float)(y0 + r) + 0.5f) / (float)u->data_h;
+            float st[4] = {particles[o], particles[o + 1], particles[o + 2], particles[o + 3]};
+            float add = 1.2345f + (u->time * 0.001f);
+            float base[4] = {st[0] + uvx + add, st[1] + uvy + add, st[2] + uvx + add, st[3] + uvy + add};
+            for (int n = 0; n < u->samples; ++n) {
+                float fn = (float)n;
+                float su = modf_glsl(to_random(base[0] + fn, base[1] + fn), 1.0f);
+                float sv = modf_glsl(to_random(base[2] + fn, base[3] + fn), 1.0f);
+                float px, py;
+                spawn_to_pos(u, su, sv, &px, &py);
+                const float *t = tex_f32(spawn_data, sw, sh, su, sv);
+                float other[4];
+                if (u->apply == 0) {
+                    /* apply/flow.glsl:11-13: vec4(pos, getFlow(pixel, time, decay)) */
+                    float k = fmaxf(0.0f, 1.0f - ((u->time - t[2]) * u->flowDecay));
+                    other[0] = px; other[1] = py; other[2] = t[0] * k; other[3] = t[1] * k;
+                } else {
+                    /* data-sample.frag: identity after filter/pass/vignette.glsl:9-11 with
+                     * curve (0.1,1,1), mid 0.5, limit 0.6 (vignette-head.glsl:4-6) */
+                    float dx = su - 0.5f, dy = sv - 0.5f;
+                    float amt = fminf(1.0f - (sqrtf(dx * dx + dy * dy) / 0.6f), 1.0f);
+                    float ut = 1.0f - amt;
+                    float bz = (0.1f * ut + 1.0f * amt) * ut + (1.0f * ut + 1.0f * amt) * amt;
+                    float vg = fmaxf(0.0f, bz);
+                    for (int c = 0; c < 4; ++c) other[c] = t[c] * vg;
+                }
+                float cand[4] = {other[0], other[1], other[2] * u->speed, other[3] * u->speed};
+                float tc = st[2] * st[2] + st[3] * st[3], tn = cand[2] * cand[2] + cand[3] * cand[3];
+                if (!(tc > u->bias * tn))       /* pick(): keep current only if strictly greater */
+                    for (int c = 0; c < 4; ++c) st[c] = cand[c];
+            }
+            for (int c = 0; c < 4; ++c) out[o + c] = st[c];
+        }
+    }
+}

@@ -480,14 +480,47 @@ th_status th_spawn_init(th_context *c, int32_t target)
     return TH_OK;
 }
 
-th_status th_spawn_ball(th_context *, const th_spawn_ball_uniforms *, int32_t)
+th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t target)
 {
-    return fail(TH_ERR_UNSUPPORTED, "th_spawn_ball: not built yet");
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(u, "null uniforms");
+    if (target == TH_TARGET_RING) TH_REQUIRE(!c->ring.empty(), "no state buffers");
+    float4 *out = nullptr;
+    if (th_status s = resolve_target(c, target, true, &out)) return s;
+    th::SpawnBallParams p{};
+    p.out = out; p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
+    p.u = *u;
+    th::launch_spawn_ball(p, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
 }
 
-th_status th_spawn_sample(th_context *, const th_spawn_sample_uniforms *, int32_t, int32_t)
+th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target)
 {
-    return fail(TH_ERR_UNSUPPORTED, "th_spawn_sample: not built yet");
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(u, "null uniforms");
+    TH_REQUIRE(u->samples >= 0 && u->samples <= 64, "samples out of range");
+    TH_REQUIRE(u->apply == 0 || u->apply == 1, "unknown apply mode %d", u->apply);
+    // the pass reads `particles` = buffers[1] like every Particles.step (src/particles.js:139)
+    TH_REQUIRE(c->ring.size() >= 2, "spawn pass needs at least 2 state buffers (have %zu)", c->ring.size());
+    float4 *out = nullptr;
+    if (th_status s = resolve_target(c, target, true, &out)) return s;
+    th::SpawnSampleParams p{};
+    p.particles = c->ring[1];
+    p.out = out;
+    // `source` names the spawnData texture in the ring order the pass sees (after the rotation)
+    if (source == TH_SOURCE_FLOW) { p.data = c->flow; p.dw = c->fw; p.dh = c->fh; }
+    else if (source >= 0 && source < (int32_t)c->ring.size()) {
+        if (c->cfg.height != c->cfg.global_height)
+            return fail(TH_ERR_UNSUPPORTED, "sampling the particle texture needs the whole texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
+        p.data = c->ring[source]; p.dw = c->cfg.width; p.dh = c->cfg.height;
+    } else return fail(TH_ERR_INVALID, "bad spawnData source %d", source);
+    p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
+    p.wf = (float)c->cfg.width; p.hf = (float)c->cfg.global_height;
+    p.u = *u;
+    th::launch_spawn_sample(p, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
 }
 
 th_status th_frames_resize(th_context *c, int32_t w, int32_t h)

@@ -381,6 +381,142 @@ void launch_optical_flow(const OpticalFlowParams &p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
+// Respawn passes (src/spawn/ball/index.frag, src/spawn/pixels/frag/*).  The GLSL hash
+// fract(sin(x)*43758.5453) (glsl-random 0.0.5) and angleToVec() amplify the last bits of
+// the platform's sin/cos; this build pins them to one fixed fp64 sequence (quadrant
+// reduction, Taylor polynomials in fma form, one rounding to fp32) so that host and device
+// agree bit-for-bit and the value is within one fp32 rounding of the true one.
+// ---------------------------------------------------------------------------
+TH_D void sincos_pinned(float xf, float &s_out, float &c_out)
+{
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2_HI = 1.57079632679489655800e+00;
+    const double PIO2_LO = 6.12323399573676603587e-17;
+    double x = (double)xf;
+    double k = __builtin_rint(x * TWO_OVER_PI);
+    double r = __builtin_fma(-k, PIO2_HI, x);
+    r = __builtin_fma(-k, PIO2_LO, r);
+    double r2 = r * r;
+    double ps = -1.0 / 1307674368000.0;
+    ps = __builtin_fma(ps, r2, 1.0 / 6227020800.0);
+    ps = __builtin_fma(ps, r2, -1.0 / 39916800.0);
+    ps = __builtin_fma(ps, r2, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, r2, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, r2, 1.0 / 120.0);
+    ps = __builtin_fma(ps, r2, -1.0 / 6.0);
+    double sr = __builtin_fma(ps * r2, r, r);
+    double pc = 1.0 / 20922789888000.0;
+    pc = __builtin_fma(pc, r2, -1.0 / 87178291200.0);
+    pc = __builtin_fma(pc, r2, 1.0 / 479001600.0);
+    pc = __builtin_fma(pc, r2, -1.0 / 3628800.0);
+    pc = __builtin_fma(pc, r2, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, r2, -1.0 / 720.0);
+    pc = __builtin_fma(pc, r2, 1.0 / 24.0);
+    pc = __builtin_fma(pc, r2, -0.5);
+    double cr = __builtin_fma(pc, r2, 1.0);
+    long long q = (long long)k & 3;
+    double s = (q == 0) ? sr : (q == 1) ? cr : (q == 2) ? -sr : -cr;
+    double c = (q == 0) ? cr : (q == 1) ? -sr : (q == 2) ? -cr : sr;
+    s_out = (float)s;
+    c_out = (float)c;
+}
+
+TH_D float mod_glsl(float x, float y) { return x - y * th_floor(x / y); }
+TH_D float fract_glsl(float x) { return x - th_floor(x); }
+
+// glsl-random 0.0.5
+TH_D float random_glsl(float cox, float coy)
+{
+    float dt = cox * 12.9898f + coy * 78.233f;
+    float sn = mod_glsl(dt, 3.14f);
+    float s, c;
+    sincos_pinned(sn, s, c);
+    return fract_glsl(s * 43758.5453f);
+}
+
+// src/spawn/ball/index.frag:11-19
+__global__ __launch_bounds__(256) void spawn_ball_kernel(const SpawnBallParams p)
+{
+    const float tau = 6.28318530717958647692f;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += gridDim.x * 256u) {
+        uint32_t y = idx / p.width, x = idx - y * p.width;
+        float fx = (float)x + 0.5f, fy = (float)(y + p.row0) + 0.5f;
+        float r0 = random_glsl(fx * 1.7654f + 2.3675f, fy * 1.7654f + 2.3675f);
+        float r1 = random_glsl(fx * 1.23494f + 0.36434f, fy * 1.23494f + 0.36434f);
+        float r2 = random_glsl(fx * 0.327789f + 3.498787f, fy * 0.327789f + 3.498787f);
+        float r3 = random_glsl(fx * 9.0374f + 0.2773f, fy * 9.0374f + 0.2773f);
+        float s0, c0, s1, c1;
+        sincos_pinned(r0 * tau, s0, c0);
+        sincos_pinned(r2 * tau, s1, c1);
+        p.out[idx] = make_float4(c0 * r1 * p.u.radius, s0 * r1 * p.u.radius, c1 * r3 * p.u.speed, s1 * r3 * p.u.speed);
+    }
+}
+
+void launch_spawn_ball(const SpawnBallParams &p, hipStream_t s)
+{
+    if (p.count) hipLaunchKernelGGL(spawn_ball_kernel, dim3(grid_for(p.count, 8)), dim3(256), 0, s, p);
+}
+
+TH_D int nearest_texel_f32(float u, float nf, float nm1)
+{
+    return (int)__builtin_amdgcn_fmed3f(th_floor(u * nf), 0.0f, nm1);
+}
+
+// src/spawn/pixels/frag/best-sample-main.frag:21-46 with head.frag:28-34
+__global__ __launch_bounds__(256) void spawn_sample_kernel(const SpawnSampleParams p)
+{
+    const th_spawn_sample_uniforms &u = p.u;
+    const float dwf = (float)p.dw, dhf = (float)p.dh, dwm1 = (float)(p.dw - 1), dhm1 = (float)(p.dh - 1);
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += gridDim.x * 256u) {
+        uint32_t y = idx / p.width, x = idx - y * p.width;
+        float uvx = ((float)x + 0.5f) / p.wf, uvy = ((float)(y + p.row0) + 0.5f) / p.hf;
+        float4 st = p.particles[idx];
+        float tt = u.time * 0.001f;
+        float add = 1.2345f + tt;
+        float b0 = st.x + uvx + add, b1 = st.y + uvy + add, b2 = st.z + uvx + add, b3 = st.w + uvy + add;
+        for (int n = 0; n < u.samples; ++n) {
+            float fn = (float)n;
+            float su = mod_glsl(random_glsl(b0 + fn, b1 + fn), 1.0f);
+            float sv = mod_glsl(random_glsl(b2 + fn, b3 + fn), 1.0f);
+            // spawnToPos: jitter, uvToPos, flipUV*spawnSize, mat3 transform
+            float ra = random_glsl(su - 1.2345f + tt, sv - 1.2345f + tt);
+            float rb = random_glsl(su + 1.2345f + tt, sv + 1.2345f + tt);
+            float ox = (-u.jitter[0]) * (1.0f - ra) + u.jitter[0] * ra;
+            float oy = (-u.jitter[1]) * (1.0f - rb) + u.jitter[1] * rb;
+            float qx = -1.0f + (2.0f * ((su + ox) - 0.0f)) / 1.0f;
+            float qy = -1.0f + (2.0f * ((sv + oy) - 0.0f)) / 1.0f;
+            qx = qx * 1.0f * u.spawnSize[0];
+            qy = qy * -1.0f * u.spawnSize[1];
+            const float *m = u.spawnMatrix;
+            float px = m[0] * qx + m[3] * qy + m[6] * 1.0f;
+            float py = m[1] * qx + m[4] * qy + m[7] * 1.0f;
+            float4 t = p.data[nearest_texel_f32(sv, dhf, dhm1) * p.dw + nearest_texel_f32(su, dwf, dwm1)];
+            float4 other;
+            if (u.apply == 0) {            // apply/flow.glsl: vec4(pos, getFlow(pixel, time, decay))
+                float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - t.z) * u.flowDecay));
+                other = make_float4(px, py, t.x * k, t.y * k);
+            } else {                       // data-sample: identity after the vignette pass
+                float dx = su - 0.5f, dy = sv - 0.5f;
+                float amt = __builtin_fminf(1.0f - (__builtin_sqrtf(dx * dx + dy * dy) / 0.6f), 1.0f);
+                float ut = 1.0f - amt;
+                float bz = (0.1f * ut + 1.0f * amt) * ut + (1.0f * ut + 1.0f * amt) * amt;
+                float vg = __builtin_fmaxf(0.0f, bz);
+                other = make_float4(t.x * vg, t.y * vg, t.z * vg, t.w * vg);
+            }
+            float4 cand = make_float4(other.x, other.y, other.z * u.speed, other.w * u.speed);
+            float tc = st.z * st.z + st.w * st.w, tn = cand.z * cand.z + cand.w * cand.w;
+            if (!(tc > u.bias * tn)) st = cand;
+        }
+        p.out[idx] = st;
+    }
+}
+
+void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t s)
+{
+    if (p.count) hipLaunchKernelGGL(spawn_sample_kernel, dim3(grid_for(p.count, 8)), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
 // small utility kernels
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fill_kernel(float4 *dst, float4 v, size_t n)

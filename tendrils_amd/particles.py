@@ -237,6 +237,10 @@ def run_pass(particles, program, uniforms, target):
         s.apply = int(program.fixed["apply"])
         src = uniforms.get("spawnData")
         source = src if isinstance(src, int) else src.source_index()
+        if source >= 0 and target == _capi.TH_TARGET_RING:
+            # the C side resolves ring indices AFTER utils.step() rotated the ring (the order the
+            # pass sees); `source` was taken from the pre-rotation list
+            source = (source + 1) % len(particles.buffers)
         call("th_spawn_sample", ctx, C.byref(s), source, target)
     else:
         raise ValueError("unknown program kind %r" % (kind,))

@@ -1,0 +1,76 @@
+"""GPU parity of the respawn kernels through the spawner mirrors: bit-for-bit against the oracle
+(same pinned sin/cos), statistically against the reference captures."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, golden, load
+from test_spawn_oracle import oracle_spawn
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n, view=(96, 54)):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    t = ta.Tendrils(View(*view))
+    t.resize()
+    t.setup(n)
+    return t
+
+
+@pytest.mark.parametrize("path", [p for p in golden("spawn") if "ball" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_spawn_ball(oracle, path):
+    from tendrils_amd.spawn import spawnBall
+    fx = load(path)
+    m = fx["meta"]
+    t = make(m["N"])
+    time0 = t.timer.time
+    spawnBall(None, dict(uniforms=m["uniforms"])).spawn(t)
+    assert t.timer.time == time0 + t.timer.step            # spawnShader ticks the timer (src/index.js:433)
+    got = t.particles.read(0)
+    t.dispose()
+    assert bits_equal(got, oracle_spawn(oracle, fx)).all()
+    ref = fx["out"]
+    assert abs(got.mean() - ref.mean()) < 0.02 * ref.std() + 1e-9
+
+
+@pytest.mark.parametrize("path", [p for p in golden("spawn") if "sample" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_spawn_sample(oracle, path):
+    from tendrils_amd.spawn import PixelSpawner, data_sample_frag, flow_sample_frag
+    fx = load(path)
+    m = fx["meta"]
+    un = m["uniforms"]
+    t = make(m["N"])
+    t.particles.upload_texels(fx["state"])
+    flow_src = m["apply"] == 0
+    if flow_src:
+        t.flow.set_pixels(fx["data"])
+        t.state["flowDecay"] = un["flowDecay"]
+    sp = PixelSpawner(None, dict(shader=flow_sample_frag() if flow_src else data_sample_frag(),
+                                 buffer=t.flow if flow_src else t.particles.buffers[0],
+                                 spawnSize=un["spawnSize"], speed=un["speed"], bias=un["bias"]))
+    t.timer.time = un["time"] - t.timer.step               # spawnShader ticks first
+    sp.spawn(t)
+    assert abs(t.timer.time - un["time"]) < 1e-9
+    assert np.allclose(sp.jitter, un["jitter"])
+    got = t.particles.read(0)
+    t.dispose()
+    want = oracle_spawn(oracle, fx)
+    assert bits_equal(got, want).all()
+
+
+def test_spawn_init_and_targets(oracle):
+    from tendrils_amd.spawn import spawnBall, spawner
+    t = make(64)
+    spawnBall(None, dict(uniforms=dict(radius=0.5, speed=0.01))).spawn(t)
+    b0 = t.particles.buffers[0]
+    ball = t.particles.read(b0)
+    # render the ball into the targets texture: no ring rotation (src/particles.js:124-126)
+    order = list(t.particles.buffers)
+    spawnBall(None, dict(uniforms=dict(radius=0.25, speed=0.0))).spawn(t, t.targets)
+    assert t.particles.buffers == order
+    assert bits_equal(t.targets.read(), oracle.spawn_ball(64, 64, radius=0.25, speed=0.0)).all()
+    assert bits_equal(t.particles.read(b0), ball).all()
+    spawner().spawn(t)                                     # default program: all inert
+    assert bits_equal(t.particles.read(0), oracle.spawn_init((64, 64))).all()
+    t.dispose()
