@@ -95,9 +95,13 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
+    ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
     ap.add_argument("--flow-only", action="store_true", help="noiseWeight = 0 (preset 'Flow Only')")
     args = ap.parse_args()
 
+    global FLOW_W, FLOW_H
+    if args.flow_size:
+        FLOW_W, FLOW_H = (int(v) for v in args.flow_size.lower().split("x"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +138,7 @@ def main():
     # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
     time0 = 1000.0
     flow_source = "optical-flow(synthetic 1080p frame pair)"
+    of = None
     try:
         from tendrils_amd.optical_flow import OpticalFlow
         f0, f1 = synth_frames()
@@ -145,6 +150,7 @@ def main():
         of.update(dict(speedLimit=t.state["speedLimit"], time=time0, viewSize=t.viewSize))
         of.render()
     except (ImportError, ta.TendrilsHipError):
+        of = None
         flow_source = "synthetic divergence-free field (optical-flow pass unavailable)"
         t.flow.set_pixels(synth_flow(time0))
 
@@ -182,6 +188,9 @@ def main():
             t.step()
             if (k + 1) % STATS_EVERY == 0:
                 stats_tick()
+                if of is not None:      # keep the field alive: re-stamp it from the frame pair (blended)
+                    of.update(dict(speedLimit=t.state["speedLimit"], time=t.timer.time, viewSize=t.viewSize))
+                    of.render()
 
     run(args.warmup)
     sync_all()
