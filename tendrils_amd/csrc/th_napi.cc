@@ -1,0 +1,407 @@
+// th_napi.cc - thin N-API shim over the C ABI in include/tendrils_hip.h.
+//
+// The reference's host is JavaScript: `Particles` (src/particles.js) drives WebGL through
+// stackgl (gl-fbo / gl-shader / gl-texture2d).  This addon is the replacement for that GL
+// layer: tendrils_amd/js/*.js keep the reference's object model and call these functions
+// where the reference called gl.*.  Every export maps 1:1 to one th_* entry point; a
+// non-zero status becomes a thrown JS Error carrying th_last_error() (gl-fbo / gl-shader
+// throw JS Errors the same way: docs/js/index.js:42).
+//
+// Plain N-API (node_api.h, ABI-stable C interface); built with g++, no node-gyp:
+//   g++ -shared -fPIC -I/usr/include/node th_napi.cc -ltendrils_hip
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "tendrils_hip.h"
+
+namespace {
+
+#define NAPI_OK(call)                                                  \
+    do {                                                               \
+        if ((call) != napi_ok) {                                       \
+            napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+            return nullptr;                                            \
+        }                                                              \
+    } while (0)
+
+napi_value throw_status(napi_env env, th_status st, const char *what)
+{
+    char msg[640];
+    snprintf(msg, sizeof msg, "tendrils_hip %s: status %d: %s", what, (int)st, th_last_error());
+    napi_throw_error(env, nullptr, msg);
+    return nullptr;
+}
+
+#define TH_CALL(what, expr)                                   \
+    do {                                                      \
+        th_status st_ = (expr);                               \
+        if (st_ != TH_OK) return throw_status(env, st_, what); \
+    } while (0)
+
+struct Args {
+    napi_env env;
+    size_t argc = 12;
+    napi_value argv[12];
+    bool ok = true;
+    Args(napi_env e, napi_callback_info info) : env(e)
+    {
+        ok = napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) == napi_ok;
+    }
+    th_context *ctx(size_t i)
+    {
+        void *p = nullptr;
+        if (i >= argc || napi_get_value_external(env, argv[i], &p) != napi_ok || !p) { ok = false; return nullptr; }
+        return *static_cast<th_context **>(p);
+    }
+    int32_t i32(size_t i)
+    {
+        int32_t v = 0;
+        if (i >= argc || napi_get_value_int32(env, argv[i], &v) != napi_ok) ok = false;
+        return v;
+    }
+    double f64(size_t i)
+    {
+        double v = 0;
+        if (i >= argc || napi_get_value_double(env, argv[i], &v) != napi_ok) ok = false;
+        return v;
+    }
+    // typed array -> raw pointer + element count
+    void *typed(size_t i, napi_typedarray_type want, size_t *len)
+    {
+        napi_typedarray_type t;
+        void *data = nullptr;
+        size_t n = 0;
+        if (i >= argc || napi_get_typedarray_info(env, argv[i], &t, &n, &data, nullptr, nullptr) != napi_ok || t != want) {
+            ok = false;
+            return nullptr;
+        }
+        if (len) *len = n;
+        return data;
+    }
+    // Float32Array whose layout is the named uniform struct
+    template <typename T>
+    bool uniforms(size_t i, T *out)
+    {
+        size_t n = 0;
+        float *f = static_cast<float *>(typed(i, napi_float32_array, &n));
+        if (!f || n * sizeof(float) != sizeof(T)) { ok = false; return false; }
+        memcpy(out, f, sizeof(T));
+        return true;
+    }
+};
+
+#define BAD_ARGS(name)                                              \
+    do {                                                            \
+        napi_throw_type_error(env, nullptr, name ": bad arguments"); \
+        return nullptr;                                             \
+    } while (0)
+
+napi_value undefined(napi_env env)
+{
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+void finalize_ctx(napi_env, void *data, void *)
+{
+    th_context **slot = static_cast<th_context **>(data);
+    if (*slot) th_destroy(*slot);
+    delete slot;
+}
+
+// create(device, width, height, globalHeight, row0, numBuffers, mode) -> handle
+napi_value Create(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_config cfg{};
+    cfg.device = a.i32(0); cfg.width = a.i32(1); cfg.height = a.i32(2); cfg.global_height = a.i32(3);
+    cfg.row0 = a.i32(4); cfg.num_buffers = a.i32(5); cfg.mode = a.i32(6);
+    if (!a.ok) BAD_ARGS("create");
+    th_context *c = nullptr;
+    TH_CALL("th_create", th_create(&cfg, &c));
+    th_context **slot = new th_context *(c);
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, slot, finalize_ctx, nullptr, &ext));
+    return ext;
+}
+
+napi_value Destroy(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    void *p = nullptr;
+    if (a.argc < 1 || napi_get_value_external(env, a.argv[0], &p) != napi_ok || !p) BAD_ARGS("destroy");
+    th_context **slot = static_cast<th_context **>(p);
+    if (*slot) { th_destroy(*slot); *slot = nullptr; }
+    return undefined(env);
+}
+
+napi_value AbiVersion(napi_env env, napi_callback_info)
+{
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, th_abi_version(), &v));
+    return v;
+}
+
+napi_value DeviceCount(napi_env env, napi_callback_info)
+{
+    int32_t n = 0;
+    TH_CALL("th_device_count", th_device_count(&n));
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, n, &v));
+    return v;
+}
+
+#define CTX_ONLY(fn_name, th_fn)                                   \
+    napi_value fn_name(napi_env env, napi_callback_info info)      \
+    {                                                              \
+        Args a(env, info);                                         \
+        th_context *c = a.ctx(0);                                  \
+        if (!a.ok) BAD_ARGS(#th_fn);                               \
+        TH_CALL(#th_fn, th_fn(c));                                 \
+        return undefined(env);                                     \
+    }
+
+#define CTX_I32(fn_name, th_fn)                                    \
+    napi_value fn_name(napi_env env, napi_callback_info info)      \
+    {                                                              \
+        Args a(env, info);                                         \
+        th_context *c = a.ctx(0);                                  \
+        int32_t v = a.i32(1);                                      \
+        if (!a.ok) BAD_ARGS(#th_fn);                               \
+        TH_CALL(#th_fn, th_fn(c, v));                              \
+        return undefined(env);                                     \
+    }
+
+CTX_I32(SetMode, th_set_mode)
+CTX_I32(Setup, th_setup)
+CTX_ONLY(FlowClear, th_flow_clear)
+CTX_ONLY(TargetsClear, th_targets_clear)
+CTX_I32(SpawnInit, th_spawn_init)
+CTX_ONLY(FramesRotate, th_frames_rotate)
+CTX_ONLY(Sync, th_sync)
+
+napi_value NumBuffers(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_num_buffers");
+    int32_t n = 0;
+    TH_CALL("th_num_buffers", th_num_buffers(c, &n));
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, n, &v));
+    return v;
+}
+
+// uploadState(ctx, buffer, Float32Array, x0, y0, w, h) / downloadState(...)
+template <bool UP>
+napi_value StateXfer(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t buffer = a.i32(1);
+    size_t n = 0;
+    float *px = static_cast<float *>(a.typed(2, napi_float32_array, &n));
+    int32_t x0 = a.i32(3), y0 = a.i32(4), w = a.i32(5), h = a.i32(6);
+    if (!a.ok || w <= 0 || h <= 0 || n < (size_t)w * h * 4) BAD_ARGS("state transfer");
+    if (UP) TH_CALL("th_upload_state", th_upload_state(c, buffer, px, x0, y0, w, h));
+    else TH_CALL("th_download_state", th_download_state(c, buffer, px, x0, y0, w, h));
+    return undefined(env);
+}
+
+napi_value FlowResize(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t w = a.i32(1), h = a.i32(2);
+    if (!a.ok) BAD_ARGS("th_flow_resize");
+    TH_CALL("th_flow_resize", th_flow_resize(c, w, h));
+    return undefined(env);
+}
+
+napi_value FramesResize(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t w = a.i32(1), h = a.i32(2);
+    if (!a.ok) BAD_ARGS("th_frames_resize");
+    TH_CALL("th_frames_resize", th_frames_resize(c, w, h));
+    return undefined(env);
+}
+
+// (ctx, Float32Array) transfers; the caller sizes the array from the shapes it set
+#define CTX_F32(fn_name, th_fn)                                                  \
+    napi_value fn_name(napi_env env, napi_callback_info info)                    \
+    {                                                                            \
+        Args a(env, info);                                                       \
+        th_context *c = a.ctx(0);                                                \
+        size_t n = 0;                                                            \
+        float *px = static_cast<float *>(a.typed(1, napi_float32_array, &n));    \
+        int32_t expect = a.i32(2);                                               \
+        if (!a.ok || n < (size_t)expect) BAD_ARGS(#th_fn);                       \
+        TH_CALL(#th_fn, th_fn(c, px));                                           \
+        return undefined(env);                                                   \
+    }
+CTX_F32(FlowUpload, th_flow_upload)
+CTX_F32(FlowDownload, th_flow_download)
+CTX_F32(TargetsUpload, th_targets_upload)
+CTX_F32(TargetsDownload, th_targets_download)
+
+napi_value FramesUpload(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    uint8_t *px = static_cast<uint8_t *>(a.typed(1, napi_uint8_array, &n));
+    int32_t expect = a.i32(2);
+    if (!a.ok || n < (size_t)expect) BAD_ARGS("th_frames_upload");
+    TH_CALL("th_frames_upload", th_frames_upload(c, px));
+    return undefined(env);
+}
+
+// step(ctx, Float32Array(19) uniforms, target)
+napi_value Step(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_logic_uniforms u;
+    a.uniforms(1, &u);
+    int32_t target = a.i32(2);
+    if (!a.ok) BAD_ARGS("th_step");
+    TH_CALL("th_step", th_step(c, &u, target));
+    return undefined(env);
+}
+
+// stepN(ctx, uniforms, time0, dtMs, n)
+napi_value StepN(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_logic_uniforms u;
+    a.uniforms(1, &u);
+    double t0 = a.f64(2), dt = a.f64(3);
+    int32_t n = a.i32(4);
+    if (!a.ok) BAD_ARGS("th_step_n");
+    TH_CALL("th_step_n", th_step_n(c, &u, t0, dt, n));
+    return undefined(env);
+}
+
+napi_value SpawnBall(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_spawn_ball_uniforms u;
+    a.uniforms(1, &u);
+    int32_t target = a.i32(2);
+    if (!a.ok) BAD_ARGS("th_spawn_ball");
+    TH_CALL("th_spawn_ball", th_spawn_ball(c, &u, target));
+    return undefined(env);
+}
+
+// spawnSample(ctx, Float32Array(17) float uniforms, samples, apply, source, target)
+napi_value SpawnSample(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    float *f = static_cast<float *>(a.typed(1, napi_float32_array, &n));
+    th_spawn_sample_uniforms u{};
+    if (!f || n != 17) a.ok = false;
+    else memcpy(&u, f, 17 * sizeof(float));
+    u.samples = a.i32(2); u.apply = a.i32(3);
+    int32_t source = a.i32(4), target = a.i32(5);
+    if (!a.ok) BAD_ARGS("th_spawn_sample");
+    TH_CALL("th_spawn_sample", th_spawn_sample(c, &u, source, target));
+    return undefined(env);
+}
+
+napi_value OpticalFlow(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_optical_flow_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_optical_flow");
+    TH_CALL("th_optical_flow", th_optical_flow(c, &u));
+    return undefined(env);
+}
+
+// stats(ctx, speedLimit) -> {particles, live, nan, capped, sumSpeed, maxSpeed}
+napi_value Stats(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    double limit = a.f64(1);
+    if (!a.ok) BAD_ARGS("th_stats");
+    th_counters k{};
+    TH_CALL("th_stats", th_stats(c, (float)limit, &k));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    const char *names[] = {"particles", "live", "nan", "capped", "sumSpeed", "maxSpeed"};
+    double vals[] = {(double)k.particles, (double)k.live, (double)k.nan, (double)k.capped, k.sum_speed, k.max_speed};
+    for (int i = 0; i < 6; ++i) {
+        NAPI_OK(napi_create_double(env, vals[i], &v));
+        NAPI_OK(napi_set_named_property(env, o, names[i], v));
+    }
+    return o;
+}
+
+napi_value TimerStart(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_timer_start");
+    TH_CALL("th_timer_start", th_timer_start(c));
+    return undefined(env);
+}
+
+napi_value TimerStop(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_timer_stop");
+    float ms = 0;
+    TH_CALL("th_timer_stop", th_timer_stop(c, &ms));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, ms, &v));
+    return v;
+}
+
+napi_value Init(napi_env env, napi_value exports)
+{
+    struct { const char *name; napi_callback fn; } table[] = {
+        {"abiVersion", AbiVersion}, {"deviceCount", DeviceCount},
+        {"create", Create}, {"destroy", Destroy}, {"setMode", SetMode}, {"setup", Setup}, {"numBuffers", NumBuffers},
+        {"uploadState", StateXfer<true>}, {"downloadState", StateXfer<false>},
+        {"flowResize", FlowResize}, {"flowUpload", FlowUpload}, {"flowDownload", FlowDownload}, {"flowClear", FlowClear},
+        {"targetsUpload", TargetsUpload}, {"targetsDownload", TargetsDownload}, {"targetsClear", TargetsClear},
+        {"step", Step}, {"stepN", StepN},
+        {"spawnInit", SpawnInit}, {"spawnBall", SpawnBall}, {"spawnSample", SpawnSample},
+        {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
+        {"opticalFlow", OpticalFlow},
+        {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
+    };
+    for (auto &e : table) {
+        napi_value fn;
+        if (napi_create_function(env, e.name, NAPI_AUTO_LENGTH, e.fn, nullptr, &fn) != napi_ok) return nullptr;
+        if (napi_set_named_property(env, exports, e.name, fn) != napi_ok) return nullptr;
+    }
+    napi_value v;
+    struct { const char *name; int32_t val; } consts[] = {
+        {"MODE_EXACT", TH_MODE_EXACT}, {"MODE_FAST", TH_MODE_FAST},
+        {"TARGET_RING", TH_TARGET_RING}, {"TARGET_TARGETS", TH_TARGET_TARGETS}, {"SOURCE_FLOW", TH_SOURCE_FLOW},
+    };
+    for (auto &e : consts) {
+        if (napi_create_int32(env, e.val, &v) != napi_ok) return nullptr;
+        if (napi_set_named_property(env, exports, e.name, v) != napi_ok) return nullptr;
+    }
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

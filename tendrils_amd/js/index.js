@@ -1,0 +1,177 @@
+'use strict';
+// Mirror of the reference's facade `Tendrils` (src/index.js:84-457) for the particle-update
+// path: state uniforms, timer, flow/targets textures, step(), spawn(), spawnShader(), resize().
+// Rendering (draw, view buffers, fades) is out of this build's scope and kept as chainable no-ops.
+const native = require('./native');
+const { Particles, Program } = require('./particles');
+const { Timer } = require('./timer');
+const { coverAspect, inert } = require('./utils');
+
+const defaults = () => ({                         // src/index.js:28-75
+  state: {
+    rootNum: Math.pow(2, 9),
+    autoClearView: false, autoFade: true,
+    damping: 0.043, speedLimit: 0.01,
+    forceWeight: 0.016, varyForce: -0.1,
+    flowWeight: 1, varyFlow: 0.2,
+    noiseWeight: 0.002, varyNoise: 0.3,
+    flowDecay: 0.005, flowWidth: 5,
+    noiseScale: 2.125, varyNoiseScale: 0.5,
+    noiseSpeed: 0.00025, varyNoiseSpeed: 0.1,
+    target: 0, varyTarget: 1,
+    lineWidth: 1, speedAlpha: 0.000001, colorMapAlpha: 0.4,
+    baseColor: [1, 1, 1, 0.5], flowColor: [1, 1, 1, 0.04], fadeColor: [0.1333, 0.1333, 0.1333, 0]
+  },
+  timer: Object.assign(new Timer(), { step: 1000 / 60 }),
+  numBuffers: 0,
+  logicShader: null,
+  colorMap: null
+});
+
+const glSettings = { preserveDrawingBuffer: true, antialias: true };   // src/index.js:77-80
+
+// tendrils.flow (src/index.js:102): RGBA32F, NEAREST, CLAMP_TO_EDGE, resizable
+class FlowTexture {
+  constructor(owner) { this.owner = owner; this._shape = [1, 1]; }
+  get shape() { return [...this._shape]; }
+  set shape(wh) {
+    this._shape = [wh[0] | 0, wh[1] | 0];
+    if (this.owner.particles) native.flowResize(this.owner.particles.handle, this._shape[0], this._shape[1]);
+  }
+  setPixels(texels) { native.flowUpload(this.owner.particles.handle, texels, this._shape[0] * this._shape[1] * 4); }
+  read(out) {
+    const px = (out || new Float32Array(this._shape[0] * this._shape[1] * 4));
+    native.flowDownload(this.owner.particles.handle, px, px.length);
+    return px;
+  }
+  clear() { native.flowClear(this.owner.particles.handle); }
+  sourceIndex() { return native.SOURCE_FLOW; }
+}
+
+// tendrils.targets (src/index.js:105,207)
+class TargetsTexture {
+  constructor(owner) { this.owner = owner; this.shape = [1, 1]; }
+  setPixels(texels) { native.targetsUpload(this.owner.particles.handle, texels, this.shape[0] * this.shape[1] * 4); }
+  read(out) {
+    const px = (out || new Float32Array(this.shape[0] * this.shape[1] * 4));
+    native.targetsDownload(this.owner.particles.handle, px, px.length);
+    return px;
+  }
+  clear() { native.targetsClear(this.owner.particles.handle); }
+  targetIndex() { return native.TARGET_TARGETS; }
+}
+
+const initSpawner = (data) => {                   // src/spawn/init/cpu.js:3-8
+  data[0] = data[1] = inert;
+  data[2] = data[3] = 0;
+  return data;
+};
+
+class Tendrils {
+  constructor(gl, options) {
+    const params = { ...defaults(), ...options };
+
+    // `gl` only needs drawingBufferWidth/Height here (what resize() reads)
+    this.gl = (gl || { drawingBufferWidth: 1, drawingBufferHeight: 1 });
+    this.state = params.state;
+    this.flow = new FlowTexture(this);
+    this.targets = new TargetsTexture(this);
+    this.buffers = [];
+    this.logicShader = null;
+    this.uniforms = { render: {}, update: {} };
+    this.particles = null;
+    this.viewRes = [0, 0];
+    this.viewSize = [0, 0];
+    this.timer = params.timer;
+    this.device = params.device | 0;
+    this.mode = params.mode | 0;
+  }
+
+  setup(...rest) { this.setupParticles(...rest); this.reset(); return this; }
+  reset() { this.spawn(); return this; }
+
+  dispose() {
+    if (this.particles) { this.particles.dispose(); this.particles = null; }
+    return this;
+  }
+
+  setupParticles(rootNum = this.state.rootNum, numBuffers = 2) {   // src/index.js:186-210
+    this.state.rootNum = rootNum;
+    const shape = [rootNum, rootNum];
+
+    if (this.particles) this.particles.dispose();
+    this.particles = new Particles(this.gl, {
+      shape,
+      geomShape: [shape[0], shape[1] * 2],
+      logic: new Program('logic'),
+      device: this.device,
+      mode: this.mode
+    });
+    this.logicShader = this.particles.logic;
+    this.particles.setup(numBuffers);
+    this.targets.shape = shape;
+    this.flow.shape = this.flow.shape;            // (re)create on the new context
+    return this;
+  }
+
+  clear() { this.clearView(); this.clearFlow(); return this; }
+  clearView() { return this; }
+  clearFlow() { this.flow.clear(); return this; }   // src/index.js:231-236
+  restart() { this.clear(); this.reset(); return this; }
+
+  step() {                                         // src/index.js:248-272
+    if (!this.timer.paused) {
+      this.particles.logic = this.logicShader;
+
+      Object.assign(this.uniforms.update, this.state, {
+        dt: this.timer.dt,
+        time: this.timer.time,
+        start: this.timer.since,
+        flow: this.flow,
+        targets: this.targets,
+        viewSize: this.viewSize,
+        viewRes: this.viewRes
+      });
+
+      this.particles.step(this.uniforms.update);
+    }
+    return this;
+  }
+
+  draw() { return this; }                          // src/index.js:278-340: out of scope
+
+  resize() {                                       // src/index.js:393-408
+    this.viewRes[0] = this.gl.drawingBufferWidth;
+    this.viewRes[1] = this.gl.drawingBufferHeight;
+    coverAspect(this.viewSize, this.viewRes);
+    this.flow.shape = this.viewRes;
+    return this;
+  }
+
+  spawn(spawner = initSpawner) {                   // src/index.js:425-429
+    if (spawner === initSpawner) {
+      // Particles.spawn(initSpawner) leaves every ring buffer inert: fill them on the device
+      this.particles.buffers.forEach((b, k) => native.spawnInit(this.particles.handle, k));
+    } else {
+      this.particles.spawn(spawner);
+    }
+    return this;
+  }
+
+  spawnShader(shader, update, ...rest) {           // src/index.js:432-457
+    this.timer.tick();                             // every GPU spawn advances time
+    this.particles.logic = shader;
+
+    this.particles.step(Particles.applyUpdate({
+      ...this.state,
+      time: this.timer.time,
+      viewSize: this.viewSize,
+      viewRes: this.viewRes
+    }, update), ...rest);
+
+    this.particles.logic = this.logicShader;
+    return this;
+  }
+}
+
+module.exports = { defaults, glSettings, Tendrils, Particles, Program, Timer, default: Tendrils };

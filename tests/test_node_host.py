@@ -1,0 +1,158 @@
+"""The Node host (tendrils_amd/js + the N-API shim): CPU-side checks that it loads and mirrors the
+reference's host logic; GPU-side parity through the JS API against the golden vectors."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, bits_equal, golden, load, of_expected, of_inputs, state_overrides
+
+NODE = shutil.which("node")
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+ADDON = os.path.join(ROOT, "tendrils_amd", "lib", "tendrils_hip.node")
+
+
+def node(script, *args, cwd=ROOT):
+    return subprocess.run([NODE, "-e", script, *args], cwd=cwd, capture_output=True, text=True, timeout=300)
+
+
+def test_addon_loads_and_exports_the_abi():
+    if not os.path.exists(ADDON):
+        import __graft_entry__ as g
+        g.build()
+    r = node("const a=require('./tendrils_amd/lib/tendrils_hip.node');"
+             "console.log(JSON.stringify({n:Object.keys(a).length,abi:a.abiVersion(),ring:a.TARGET_RING}))")
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout)
+    assert info == {"n": 34, "abi": 1, "ring": -1}
+
+
+def test_timer_matches_reference_semantics():
+    """Fixed-step, wall-clock, pause, end and loop behaviour of src/timer.js, JS mirror vs Python mirror."""
+    from tendrils_amd.timer import Timer
+    script = """
+    const {Timer}=require('./tendrils_amd/js/timer');
+    const out=[];
+    let t=Object.assign(new Timer(1000,1000),{step:1000/60});
+    for(let k=0;k<3;++k){t.tick(); out.push([t.time,t.dt]);}
+    t.paused=true; t.tick(); out.push([t.time,t.dt,t.offset]); t.paused=false;
+    t.end=80; t.tick(); out.push([t.time,t.dt,t.paused]); t.tick(); out.push([t.time,t.dt,t.paused]);
+    t=Object.assign(new Timer(0,0),{step:30,end:100,loop:true}); for(let k=0;k<5;++k){t.tick(); out.push([t.time,t.dt]);}
+    t=new Timer(5000,5000); t.tick(5250); out.push([t.time,t.dt]); t.rate=2; t.tick(5300); out.push([t.time,t.dt]);
+    console.log(JSON.stringify(out));
+    """
+    r = node(script)
+    assert r.returncode == 0, r.stderr
+    js = json.loads(r.stdout)
+    out = []
+    t = Timer(1000, 1000)
+    t.step = 1000 / 60
+    for _ in range(3):
+        t.tick()
+        out.append([t.time, t.dt])
+    t.paused = True
+    t.tick()
+    out.append([t.time, t.dt, t.offset])
+    t.paused = False
+    t.end = 80
+    t.tick()
+    out.append([t.time, t.dt, t.paused])
+    t.tick()
+    out.append([t.time, t.dt, t.paused])
+    t = Timer(0, 0)
+    t.step, t.end, t.loop = 30, 100, True
+    for _ in range(5):
+        t.tick()
+        out.append([t.time, t.dt])
+    t = Timer(5000, 5000)
+    t.tick(5250)
+    out.append([t.time, t.dt])
+    t.rate = 2
+    t.tick(5300)
+    out.append([t.time, t.dt])
+    assert js == json.loads(json.dumps(out))
+
+
+def test_no_gpu_throws_a_js_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = node("const T=require('./tendrils_amd/js');const t=new T.Tendrils({drawingBufferWidth:8,drawingBufferHeight:8});"
+             "t.resize();try{t.setup(8);console.log('no error')}catch(e){console.log('threw '+e.message)}")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("threw tendrils_hip th_create")
+
+
+def run_case(tmp_path, spec, arrays):
+    for name, arr in arrays.items():
+        np.ascontiguousarray(arr).tofile(str(tmp_path / name))
+    (tmp_path / "case.json").write_text(json.dumps(spec))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "run_case.js"), str(tmp_path / "case.json")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["logic_default_64", "logic_target_strong_64", "logic_multistep_64",
+                                  "logic_npot_48", "logic_c1_256"])
+def test_js_step_matches_reference_bits(tmp_path, name):
+    fx = load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    m = fx["meta"]
+    n = m["N"]
+    arrays = {"state.bin": fx["state"], "flow.bin": fx["flow"]}
+    spec = dict(kind="logic", N=n, viewRes=m["viewRes"], flowShape=m["flowShape"], viewSize=m["viewSize"],
+                state=state_overrides(m), steps=m["steps"], time0=m["times"][0] - m["dts"][0],
+                times=m["times"], dts=m["dts"],
+                inputs=dict(state="state.bin", flow="flow.bin"))
+    if "targets" in fx:
+        arrays["targets.bin"] = fx["targets"]
+        spec["inputs"]["targets"] = "targets.bin"
+    if m["steps"] > 1:
+        spec["follow"] = []
+        for k in range(m["steps"] - 1):
+            arrays["follow_%d.bin" % k] = fx["out"][k]
+            spec["follow"].append("follow_%d.bin" % k)
+    run_case(tmp_path, spec, arrays)
+    for k in range(m["steps"]):
+        got = np.fromfile(str(tmp_path / ("out_%d.bin" % k)), np.float32).reshape(n, n, 4)
+        ok = bits_equal(got, fx["out"][k]).all(-1)
+        assert (ok | ~fx["valid"][k]).all(), "%s step %d" % (name, k)
+    res = json.loads((tmp_path / "result.json").read_text())
+    assert res["time"] == m["times"][-1]
+
+
+@pytest.mark.gpu
+def test_js_optical_flow_and_spawners(tmp_path, oracle):
+    from test_spawn_oracle import oracle_spawn
+    # optical flow
+    fx = load(os.path.join(ROOT, "tests", "golden", "of_demo_240x135.npz"))
+    m = fx["meta"]
+    f0, f1, dst = of_inputs(m)
+    d = tmp_path / "of"
+    d.mkdir()
+    run_case(d, dict(kind="optical_flow", N=8, viewRes=m["out"], frame=m["frame"], uniforms=m["uniforms"],
+                     inputs=dict(flow="flow.bin", last="last.bin", view="view.bin")),
+             {"flow.bin": dst, "last.bin": f0, "view.bin": f1})
+    got = np.fromfile(str(d / "out_0.bin"), np.float32).reshape(m["out"][1], m["out"][0], 4)
+    assert bits_equal(of_expected(fx, got), fx["out"]).all()
+    # spawners: bit-equal to the oracle (same pinned sin/cos)
+    for name in ("spawn_ball_demo_128", "spawn_flow_sample_64", "spawn_data_sample_64"):
+        fx = load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        m = fx["meta"]
+        d = tmp_path / name
+        d.mkdir()
+        spec = dict(kind=m["kind"], N=m["N"], viewRes=[96, 54], uniforms=m["uniforms"], inputs={})
+        arrays = {}
+        if m["kind"] == "spawn_sample":
+            spec.update(apply=m["apply"], state={"flowDecay": m["uniforms"].get("flowDecay", 0.005)})
+            arrays["state.bin"] = fx["state"]
+            spec["inputs"]["state"] = "state.bin"
+            if m["apply"] == 0:
+                arrays["flow.bin"] = fx["data"]
+                spec["inputs"]["flow"] = "flow.bin"
+        run_case(d, spec, arrays)
+        got = np.fromfile(str(d / "out_0.bin"), np.float32).reshape(m["N"], m["N"], 4)
+        assert bits_equal(got, oracle_spawn(oracle, fx)).all(), name
