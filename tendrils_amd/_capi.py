@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtendrils_hip.so")
+LIB_PATH = os.environ.get("TH_LIB") or os.path.join(HERE, "lib", "libtendrils_hip.so")   # TH_LIB: diagnostic builds
 
 TH_OK = 0
 TH_MODE_EXACT, TH_MODE_FAST = 0, 1

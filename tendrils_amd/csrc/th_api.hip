@@ -112,6 +112,13 @@ struct th_context {
     th_counters *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
+    // XCD-affine bucketing of the slot order (th_kernels.hip "Bucketing"); lazily allocated
+    uint32_t *perm = nullptr, *perm_alt = nullptr, *src_slot = nullptr;
+    float4 *spare = nullptr;             // spare state buffer the permutes ping-pong through
+    uint32_t *bucket_mem = nullptr;      // hist[kBuckets] | cursor[kBuckets] | xcd work counters[8]
+    bool bucketed = false;               // ring buffers currently in bucket (slot) order
+    int steps_since_bucket = 0;
+
     size_t texels() const { return (size_t)cfg.width * cfg.height; }
 };
 
@@ -155,6 +162,74 @@ th_status rect_ok(th_context *c, int32_t x0, int32_t y0, int32_t w, int32_t h)
 {
     TH_REQUIRE(x0 >= 0 && y0 >= 0 && w > 0 && h > 0 && x0 + w <= c->cfg.width && y0 + h <= c->cfg.height,
                "rectangle (%d,%d %dx%d) outside the %dx%d state texture", x0, y0, w, h, c->cfg.width, c->cfg.height);
+    return TH_OK;
+}
+
+
+// ---- slot order management ---------------------------------------------------------------------
+// Policy: bucket when the decoded flow plane cannot live in one XCD's 4 MiB L2 and there are
+// enough particles for the one-off sort to pay back.  TH_BUCKET=0/1 forces it off/on,
+// TH_REBUCKET_STEPS sets the re-sort period (particles drift at most speedLimit per step).
+int bucket_policy()
+{
+    static const int v = [] { const char *e = getenv("TH_BUCKET"); return e ? atoi(e) : -1; }();
+    return v;
+}
+int rebucket_period()
+{
+    static const int v = [] { const char *e = getenv("TH_REBUCKET_STEPS"); int n = e ? atoi(e) : 128; return n > 0 ? n : 128; }();
+    return v;
+}
+bool want_bucketing(const th_context *c)
+{
+    const size_t flow_texels = (size_t)c->fw * c->fh;
+    if (c->texels() < 2 * flow_texels) return false;           // the decoded plane is not used at all
+    if (bucket_policy() == 0) return false;
+    if (bucket_policy() == 1) return true;
+    return c->texels() >= ((size_t)1 << 20) && flow_texels * sizeof(float2) > ((size_t)3 << 20);
+}
+
+th_status ensure_identity(th_context *c)
+{
+    if (!c->bucketed) return TH_OK;
+    for (float4 *&b : c->ring) {
+        th::launch_unpermute_state(c->spare, b, c->perm, (uint32_t)c->texels(), c->stream);
+        float4 *t = b; b = c->spare; c->spare = t;
+    }
+    TH_HIP(hipGetLastError());
+    c->bucketed = false;
+    return TH_OK;
+}
+
+// (Re)sort the slots of every ring buffer by the flow region of the CURRENT state (ring[0]).
+th_status rebucket(th_context *c, const th_logic_uniforms &u)
+{
+    const uint32_t n = (uint32_t)c->texels();
+    if (!c->spare) {
+        TH_HIP(hipMalloc((void **)&c->spare, (size_t)n * sizeof(float4)));
+        TH_HIP(hipMalloc((void **)&c->perm, (size_t)n * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->perm_alt, (size_t)n * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->src_slot, (size_t)n * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->bucket_mem, (2 * th::kBuckets + 8) * sizeof(uint32_t)));
+        TH_HIP(hipMemsetAsync(c->bucket_mem, 0, (2 * th::kBuckets + 8) * sizeof(uint32_t), c->stream));
+    }
+    th::BucketParams b{};
+    b.state = c->ring[0];
+    b.count = n;
+    b.view_y = u.viewSize[1];
+    b.fhf = (float)c->fh; b.fhm1 = (float)(c->fh - 1); b.fh = (uint32_t)c->fh;
+    b.hist = c->bucket_mem; b.cursor = c->bucket_mem + th::kBuckets;
+    b.src_slot = c->src_slot;
+    th::launch_bucket_build(b, c->stream);
+    for (float4 *&buf : c->ring) {
+        th::launch_permute_state(c->spare, buf, c->src_slot, n, c->stream);
+        float4 *t = buf; buf = c->spare; c->spare = t;
+    }
+    th::launch_permute_ids(c->perm_alt, c->bucketed ? c->perm : nullptr, c->src_slot, n, c->stream);
+    uint32_t *t = c->perm; c->perm = c->perm_alt; c->perm_alt = t;
+    TH_HIP(hipGetLastError());
+    c->bucketed = true;
+    c->steps_since_bucket = 0;
     return TH_OK;
 }
 
@@ -243,6 +318,8 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
+    (void)hipFree(c->perm); (void)hipFree(c->perm_alt); (void)hipFree(c->src_slot); (void)hipFree(c->spare);
+    (void)hipFree(c->bucket_mem);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -261,6 +338,7 @@ th_status th_set_mode(th_context *c, int32_t mode)
 th_status th_setup(th_context *c, int32_t num_buffers)
 {
     if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(num_buffers >= 0 && num_buffers <= 64, "num_buffers out of range");
     while ((int32_t)c->ring.size() < num_buffers) {          // src/particles.js:83-86: push
         float4 *b = nullptr;
@@ -286,6 +364,7 @@ th_status th_num_buffers(th_context *c, int32_t *out)
 th_status th_upload_state(th_context *c, int32_t buffer, const float *rgba, int32_t x0, int32_t y0, int32_t w, int32_t h)
 {
     if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(rgba, "null pixels");
     if (th_status s = rect_ok(c, x0, y0, w, h)) return s;
     TH_REQUIRE(buffer >= -1 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
@@ -302,6 +381,7 @@ th_status th_upload_state(th_context *c, int32_t buffer, const float *rgba, int3
 th_status th_download_state(th_context *c, int32_t buffer, float *rgba, int32_t x0, int32_t y0, int32_t w, int32_t h)
 {
     if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(rgba, "null pixels");
     if (th_status s = rect_ok(c, x0, y0, w, h)) return s;
     TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
@@ -382,11 +462,13 @@ th_status th_targets_clear(th_context *c)
 }
 
 // Build the launch parameters of one integrator pass and pick the kernel variant.
-static th_status launch_step(th_context *c, const th_logic_uniforms &u, const float4 *in, float4 *out)
+// One integrator pass: pick the kernel variant and the slot layout, rotate / resolve the render
+// target, launch.
+static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t target)
 {
     const uint32_t W = (uint32_t)c->cfg.width, H = (uint32_t)c->cfg.global_height;
     th::LogicParams p{};
-    p.in = in; p.out = out; p.flow = c->flow; p.flow_dec = c->flow_dec; p.targets = c->targets; p.lut = c->lut;
+    p.flow = c->flow; p.flow_dec = c->flow_dec; p.targets = c->targets; p.lut = c->lut;
     p.count = (uint32_t)c->texels();
     p.width = W;
     p.row0 = (uint32_t)c->cfg.row0;
@@ -404,7 +486,7 @@ static th_status launch_step(th_context *c, const th_logic_uniforms &u, const fl
     static const bool force_generic = getenv("TH_FORCE_GENERIC") != nullptr;   // test hook
     bool generic = force_generic || !finite_uniforms(u);
     const bool noise = u.noiseWeight != 0.0f;
-    bool target = u.target != 0.0f;
+    bool use_targets = u.target != 0.0f;
     if (!generic) {
         // i = (x+.5 + (y+.5)W)/(WH) lies in (0, 1]; bound |vary(base, i, v)| <= |base|(1+|v|)
         double nscale = std::fabs((double)u.noiseScale) * (1.0 + std::fabs((double)u.varyNoiseScale)) * 1.001;
@@ -415,7 +497,7 @@ static th_status launch_step(th_context *c, const th_logic_uniforms &u, const fl
         p.pos_bound = (float)std::fmin(bound * 0.999, 3.0e38);
         if (!(p.pos_bound > 0.0f)) generic = true;
     }
-    if (!generic && !target) {
+    if (!generic && !use_targets) {
         // target == 0 multiplies (targets - pos) by an exact zero; dropping the read is only
         // value-preserving when the texture holds no NaN/Inf.
         if (!c->targets_checked) {
@@ -427,15 +509,32 @@ static th_status launch_step(th_context *c, const th_logic_uniforms &u, const fl
             c->targets_nonfinite = flag != 0;
             c->targets_checked = true;
         }
-        target = c->targets_nonfinite;
+        use_targets = c->targets_nonfinite;
     }
     // Decode the flow once per step when that is cheaper than decoding per particle: it shrinks the
     // random-gather footprint (the L2/Infinity-Fabric miss traffic is what bounds this kernel).
     const size_t flow_texels = (size_t)c->fw * c->fh;
     const bool decoded = !generic && c->texels() >= 2 * flow_texels;
-    if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, c->stream);
-    th::launch_logic(p, c->cfg.mode, noise, target, pow2, decoded, generic, c->stream);
+
+    // Slot layout: bucketed by flow region (XCD-affine launch) or texel order.  Decided on the
+    // CURRENT state, i.e. before the ring rotates.
+    const bool bucket = decoded && target == TH_TARGET_RING && want_bucketing(c);
+    if (bucket) {
+        if (!c->bucketed || c->steps_since_bucket >= rebucket_period())
+            if (th_status s = rebucket(c, u)) return s;
+    } else if (th_status s = ensure_identity(c)) return s;
+
+    float4 *out = nullptr;
+    if (th_status s = resolve_target(c, target, true, &out)) return s;
+    p.in = c->ring[1];            // Particles.step binds buffers[1] as `particles` (src/particles.js:139)
+    p.out = out;
+    p.perm = c->bucketed ? c->perm : nullptr;
+    p.cursors = c->bucketed ? c->bucket_mem + 2 * th::kBuckets : nullptr;
+
+    if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, p.cursors, c->stream);
+    th::launch_logic(p, c->cfg.mode, noise, use_targets, pow2, decoded, generic, c->stream);
     TH_HIP(hipGetLastError());
+    ++c->steps_since_bucket;
     return TH_OK;
 }
 
@@ -445,9 +544,7 @@ th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
     TH_REQUIRE(u, "null uniforms");
     // Particles.step reads this.buffers[1] (src/particles.js:139): needs >= 2 buffers
     TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
-    float4 *out = nullptr;
-    if (th_status s = resolve_target(c, target, true, &out)) return s;
-    return launch_step(c, *u, c->ring[1], out);
+    return step_once(c, *u, target);
 }
 
 th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, double dt_ms, int32_t n)
@@ -461,9 +558,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     for (int32_t k = 0; k < n; ++k) {
         t += dt_ms;                                   // src/timer.js:28-31
         v.time = (float)t;
-        float4 *out = nullptr;
-        if (th_status s = resolve_target(c, TH_TARGET_RING, true, &out)) return s;
-        if (th_status s = launch_step(c, v, c->ring[1], out)) return s;
+        if (th_status s = step_once(c, v, TH_TARGET_RING)) return s;
     }
     return TH_OK;
 }
@@ -471,6 +566,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
 th_status th_spawn_init(th_context *c, int32_t target)
 {
     if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     float4 *out = nullptr;
     if (target == TH_TARGET_RING) TH_REQUIRE(!c->ring.empty(), "no state buffers");
     if (th_status s = resolve_target(c, target, true, &out)) return s;
@@ -483,6 +579,7 @@ th_status th_spawn_init(th_context *c, int32_t target)
 th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t target)
 {
     if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(u, "null uniforms");
     if (target == TH_TARGET_RING) TH_REQUIRE(!c->ring.empty(), "no state buffers");
     float4 *out = nullptr;
@@ -498,6 +595,7 @@ th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t 
 th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target)
 {
     if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(u->samples >= 0 && u->samples <= 64, "samples out of range");
     TH_REQUIRE(u->apply == 0 || u->apply == 1, "unknown apply mode %d", u->apply);
@@ -608,6 +706,8 @@ th_status th_stream(th_context *c, void **hip_stream)
 th_status th_state_device_ptr(th_context *c, int32_t buffer, void **dptr)
 {
     TH_REQUIRE(c && dptr, "null argument");
+    if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // the pointer is only meaningful in texel order
     TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
     *dptr = c->ring[buffer];
     return TH_OK;

@@ -86,12 +86,19 @@ __device__ __forceinline__ float4 logic_texel_ref(const LogicParams &p, uint32_t
 
 // ---------------------------------------------------------------------------
 // Simplex noise on the guarded domain, gradient + normalisation from the LDS
-// table.  Bit-identical to snoise_ref for |v| < kNoiseDomain when !FAST.
-// sxy = vx*C.y + vy*C.y is shared by the two evaluations of one particle.
+// table (snoise_corners + snoise_finish).  Bit-identical to snoise_ref for |v| < kNoiseDomain
+// when !FAST.  sxy = vx*C.y + vy*C.y is shared by the two evaluations of one particle.
 // ---------------------------------------------------------------------------
+// Lattice part of one evaluation: corner offsets and the table index of each corner's gradient.
+struct NoiseCorners {
+    float ax, ay, az, bx, by, bz, cx, cy, cz, dx, dy, dz;
+    int j0, j1, j2, j3;
+};
+
 template <bool FAST>
-TH_D float snoise_lut(float vx, float vy, float vz, float sxy, const float4 *lut)
+TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy)
 {
+    NoiseCorners n;
     // first corner
     float s = mad<FAST>(vz, kC3, sxy);
     float ix = th_floor(vx + s), iy = th_floor(vy + s), iz = th_floor(vz + s);
@@ -105,9 +112,10 @@ TH_D float snoise_lut(float vx, float vy, float vz, float sxy, const float4 *lut
     float i1x = b1x ? 1.0f : 0.0f, i1y = b1y ? 1.0f : 0.0f, i1z = b1z ? 1.0f : 0.0f;
     float i2x = b2x ? 1.0f : 0.0f, i2y = b2y ? 1.0f : 0.0f, i2z = b2z ? 1.0f : 0.0f;
 
-    float bx = (ax - i1x) + kC6, by = (ay - i1y) + kC6, bz = (az - i1z) + kC6;
-    float cx = (ax - i2x) + kC3, cy = (ay - i2y) + kC3, cz = (az - i2z) + kC3;
-    float dx = ax - 0.5f, dy = ay - 0.5f, dz = az - 0.5f;
+    n.ax = ax; n.ay = ay; n.az = az;
+    n.bx = (ax - i1x) + kC6; n.by = (ay - i1y) + kC6; n.bz = (az - i1z) + kC6;
+    n.cx = (ax - i2x) + kC3; n.cy = (ay - i2y) + kC3; n.cz = (az - i2z) + kC3;
+    n.dx = ax - 0.5f; n.dy = ay - 0.5f; n.dz = az - 0.5f;
 
     // permutation hash: exact small-integer arithmetic (th_math.hpp)
     ix = mod289_int(ix); iy = mod289_int(iy); iz = mod289_int(iz);
@@ -116,23 +124,27 @@ TH_D float snoise_lut(float vx, float vy, float vz, float sxy, const float4 *lut
     float q1 = permute_int(((b1z ? pz1 : pz0) + iy) + i1y);
     float q2 = permute_int(((b2z ? pz1 : pz0) + iy) + i2y);
     float q3 = permute_int((pz1 + iy) + 1.0f);
-    int j0 = (int)(q0 + ix);
-    int j1 = (int)((q1 + ix) + i1x);
-    int j2 = (int)((q2 + ix) + i2x);
-    int j3 = (int)((q3 + ix) + 1.0f);
-    float4 g0 = lut[j0 - kLutMin], g1 = lut[j1 - kLutMin], g2 = lut[j2 - kLutMin], g3 = lut[j3 - kLutMin];
+    n.j0 = (int)(q0 + ix) - kLutMin;
+    n.j1 = (int)((q1 + ix) + i1x) - kLutMin;
+    n.j2 = (int)((q2 + ix) + i2x) - kLutMin;
+    n.j3 = (int)((q3 + ix) + 1.0f) - kLutMin;
+    return n;
+}
 
-    // radial falloff and gradient dot products
-    float m0 = __builtin_fmaxf(0.6f - mad<FAST>(az, az, mad<FAST>(ay, ay, ax * ax)), 0.0f);
-    float m1 = __builtin_fmaxf(0.6f - mad<FAST>(bz, bz, mad<FAST>(by, by, bx * bx)), 0.0f);
-    float m2 = __builtin_fmaxf(0.6f - mad<FAST>(cz, cz, mad<FAST>(cy, cy, cx * cx)), 0.0f);
-    float m3 = __builtin_fmaxf(0.6f - mad<FAST>(dz, dz, mad<FAST>(dy, dy, dx * dx)), 0.0f);
+// Radial falloff and gradient dot products, given the four table entries.
+template <bool FAST>
+TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2, float4 g3)
+{
+    float m0 = __builtin_fmaxf(0.6f - mad<FAST>(n.az, n.az, mad<FAST>(n.ay, n.ay, n.ax * n.ax)), 0.0f);
+    float m1 = __builtin_fmaxf(0.6f - mad<FAST>(n.bz, n.bz, mad<FAST>(n.by, n.by, n.bx * n.bx)), 0.0f);
+    float m2 = __builtin_fmaxf(0.6f - mad<FAST>(n.cz, n.cz, mad<FAST>(n.cy, n.cy, n.cx * n.cx)), 0.0f);
+    float m3 = __builtin_fmaxf(0.6f - mad<FAST>(n.dz, n.dz, mad<FAST>(n.dy, n.dy, n.dx * n.dx)), 0.0f);
     m0 *= m0; m1 *= m1; m2 *= m2; m3 *= m3;
     m0 *= m0; m1 *= m1; m2 *= m2; m3 *= m3;
-    float d0 = mad<FAST>(g0.z, az, mad<FAST>(g0.y, ay, g0.x * ax));
-    float d1 = mad<FAST>(g1.z, bz, mad<FAST>(g1.y, by, g1.x * bx));
-    float d2 = mad<FAST>(g2.z, cz, mad<FAST>(g2.y, cy, g2.x * cx));
-    float d3 = mad<FAST>(g3.z, dz, mad<FAST>(g3.y, dy, g3.x * dx));
+    float d0 = mad<FAST>(g0.z, n.az, mad<FAST>(g0.y, n.ay, g0.x * n.ax));
+    float d1 = mad<FAST>(g1.z, n.bz, mad<FAST>(g1.y, n.by, g1.x * n.bx));
+    float d2 = mad<FAST>(g2.z, n.cz, mad<FAST>(g2.y, n.cy, g2.x * n.cx));
+    float d3 = mad<FAST>(g3.z, n.dz, mad<FAST>(g3.y, n.dy, g3.x * n.dx));
     return 42.0f * mad<FAST>(m3, d3, mad<FAST>(m2, d2, mad<FAST>(m1, d1, m0 * d0)));
 }
 
@@ -145,7 +157,114 @@ TH_D float snoise_lut(float vx, float vy, float vz, float sxy, const float4 *lut
 //   POW2   dataRes.x, dataRes.y powers of two: `/dataRes` == `*(1/dataRes)` exactly
 //   DECODED the flow tap reads the per-step decoded float2 plane (8 B) instead of RGBA32F (16 B)
 // ---------------------------------------------------------------------------
+// One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
+TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid)
+{
+    const th_logic_uniforms &u = p.u;
+    float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
+    if (!(posx != kInert || posy != kInert)) return st;                   // src/logic.frag:52
+
+    uint32_t x, y;
+    if constexpr (POW2) { x = pid & (p.width - 1u); y = pid >> p.log2w; }
+    else { y = pid / p.width; x = pid - y * p.width; }
+    y += p.row0;
+
+    // two compares (not max): a NaN in either component must fail the test
+    bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
+    if (__builtin_expect(!in_domain, 0)) return logic_texel_ref(p, x, y, st, pid);
+
+    float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
+    float uvx, uvy, i;
+    if constexpr (POW2) {
+        uvx = fcx * p.inv_w; uvy = fcy * p.inv_h;
+        i = (fcx + (fcy * p.wf)) * p.inv_wh;
+    } else if constexpr (FAST) {
+        uvx = fcx * p.inv_w; uvy = fcy * p.inv_h;
+        i = mad<true>(fcy, p.wf, fcx) * p.inv_wh;
+    } else {
+        uvx = fcx / p.wf; uvy = fcy / p.hf;
+        i = (fcx + (fcy * p.wf)) / (p.wf * p.hf);
+    }
+
+    // flow tap (issued first: its latency hides under the noise arithmetic)
+    float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
+    float fu = (sx + 1.0f) * 0.5f, fv = (sy + 1.0f) * 0.5f;               // (1*(v+1))/2, exactly
+    int tx = (int)__builtin_amdgcn_fmed3f(fu * p.fwf, 0.0f, p.fwm1);      // trunc == floor on [0, n-1]
+    int ty = (int)__builtin_amdgcn_fmed3f(fv * p.fhf, 0.0f, p.fhm1);
+    float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
+    float4 ft;
+    if constexpr (DECODED) { float2 d = p.flow_dec[ty * p.fw + tx]; ffx = d.x; ffy = d.y; }
+    else ft = p.flow[ty * p.fw + tx];
+
+    float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
+    if constexpr (NOISE) {
+        float nscale = vary(u.noiseScale, i, u.varyNoiseScale);
+        float nx = posx * nscale, ny = posy * nscale;
+        float ntime = u.time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
+        float sxy = mad<FAST>(ny, kC3, nx * kC3);
+        // both lattice parts first, so that all eight table reads are in flight together
+        NoiseCorners na = snoise_corners<FAST>(nx, ny, uvx + ntime, sxy);
+        NoiseCorners nb = snoise_corners<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy);
+        float4 a0 = lut[na.j0], a1 = lut[na.j1], a2 = lut[na.j2], a3 = lut[na.j3];
+        float4 b0 = lut[nb.j0], b1 = lut[nb.j1], b2 = lut[nb.j2], b3 = lut[nb.j3];
+        float wx = snoise_finish<FAST>(na, a0, a1, a2, a3);
+        float wy = snoise_finish<FAST>(nb, b0, b1, b2, b3);
+        float vnw = vary(u.noiseWeight, i, u.varyNoise);
+        wxs = (wx * u.dt) * vnw; wys = (wy * u.dt) * vnw;
+    }
+
+    if constexpr (!DECODED) {
+        float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));
+        ffx = ft.x * k; ffy = ft.y * k;
+    }
+    float vflw = vary(u.flowWeight, i, u.varyFlow);
+    float fxs = (ffx * u.dt) * vflw, fys = (ffy * u.dt) * vflw;
+    float vfw = vary(u.forceWeight, i, u.varyForce);
+    float nvx, nvy;
+    if constexpr (NOISE) {
+        nvx = mad<FAST>(vfw, fxs + wxs, (velx * u.damping) * u.dt);
+        nvy = mad<FAST>(vfw, fys + wys, (vely * u.damping) * u.dt);
+    } else {
+        // wander*dt*vary(0) is a signed zero here: adding it cannot change a non-zero
+        // sum, and a zero sum ends in 0/0 = NaN either way (DESIGN.md "skipped terms")
+        nvx = mad<FAST>(vfw, fxs, (velx * u.damping) * u.dt);
+        nvy = mad<FAST>(vfw, fys, (vely * u.damping) * u.dt);
+    }
+    if constexpr (TARGET) {
+        float4 tg = p.targets[pid];
+        float vtg = vary(u.target, i, u.varyTarget);
+        nvx = mad<FAST>(tg.x - posx, vtg, nvx);
+        nvy = mad<FAST>(tg.y - posy, vtg, nvy);
+    }
+
+    // speed clamp: r = min(speed, limit)/speed is exactly 1 when 0 < speed <= limit,
+    // i.e. when 0 < s2 <= s2_cap (sqrt_rn is monotonic; s2_cap from the host).
+    float s2 = mad<FAST>(nvy, nvy, nvx * nvx);
+    if (!(s2 > 0.0f && s2 <= p.s2_cap)) {
+        float r;
+        if constexpr (FAST) {
+            r = __builtin_fminf(1.0f, u.speedLimit * __builtin_amdgcn_rsqf(s2));
+            if (!(s2 > 0.0f)) r = __builtin_nanf("");
+        } else {
+            float speed = __builtin_sqrtf(s2);
+            r = __builtin_fminf(speed, u.speedLimit) / speed;
+        }
+        nvx *= r; nvy *= r;
+    }
+    return make_float4(posx + nvx, posy + nvy, nvx, nvy);
+}
+
+// Slots handed out per work-queue dequeue in the bucketed kernel (8 iterations of a block).
+constexpr uint32_t kChunk = 2048;
+
+// BUCKETED = false: slot == particle id, plain grid-stride over texel order.
+// BUCKETED = true : slots are grouped by flow region (bucket_* kernels); `perm[slot]` is the
+//   particle id.  Each workgroup reads the id of the XCD it runs on (HW_REG_XCC_ID) and
+//   drains that XCD's eighth of the slot range from a per-XCD work counter, so one XCD's
+//   4 MiB L2 only ever sees about one eighth of the flow field; ranges of other XCDs are
+//   stolen afterwards.  Placement affects speed only, never results.
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool BUCKETED>
 __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 {
     __shared__ float4 lut[NOISE ? kLutSize : 1];
@@ -153,101 +272,40 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
         for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
         __syncthreads();
     }
-    const th_logic_uniforms &u = p.u;
-    const uint32_t stride = gridDim.x * 256u;
 
-    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += stride) {
-        float4 st = load_stream(&p.in[idx]);
-        uint32_t x, y;
-        if constexpr (POW2) { x = idx & (p.width - 1u); y = idx >> p.log2w; }
-        else { y = idx / p.width; x = idx - y * p.width; }
-        y += p.row0;
-
-        float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
-        float4 res = st;
-        if (posx != kInert || posy != kInert) {                               // src/logic.frag:52
-            // two compares (not max): a NaN in either component must fail the test
-            bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
-            if (__builtin_expect(!in_domain, 0)) {
-                res = logic_texel_ref(p, x, y, st, idx);
-            } else {
-                float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
-                float uvx, uvy, i;
-                if constexpr (POW2) {
-                    uvx = fcx * p.inv_w; uvy = fcy * p.inv_h;
-                    i = (fcx + (fcy * p.wf)) * p.inv_wh;
-                } else if constexpr (FAST) {
-                    uvx = fcx * p.inv_w; uvy = fcy * p.inv_h;
-                    i = mad<true>(fcy, p.wf, fcx) * p.inv_wh;
-                } else {
-                    uvx = fcx / p.wf; uvy = fcy / p.hf;
-                    i = (fcx + (fcy * p.wf)) / (p.wf * p.hf);
+    if constexpr (!BUCKETED) {
+        const uint32_t stride = gridDim.x * 256u;
+        uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (idx < p.count) nxt = load_stream(&p.in[idx]);
+        for (; idx < p.count; idx += stride) {
+            // software prefetch: the next texel of this lane is requested before this one is integrated
+            float4 st = nxt;
+            if (idx + stride < p.count) nxt = load_stream(&p.in[idx + stride]);
+            store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, idx));
+        }
+    } else {
+        __shared__ uint32_t s_chunk;
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+        const uint32_t per = (p.count + 7u) >> 3;
+        for (uint32_t v = 0; v < 8u; ++v) {
+            const uint32_t r = (xcc + v) & 7u;
+            const uint32_t lo = r * per;
+            const uint32_t hi = lo + per < p.count ? lo + per : p.count;
+            for (;;) {
+                if (threadIdx.x == 0) s_chunk = atomicAdd(&p.cursors[r], 1u);
+                __syncthreads();
+                const uint32_t base = lo + s_chunk * kChunk;
+                __syncthreads();
+                if (base >= hi || lo >= hi) break;
+                const uint32_t end = base + kChunk < hi ? base + kChunk : hi;
+                for (uint32_t s = base + threadIdx.x; s < end; s += 256u) {
+                    float4 st = load_stream(&p.in[s]);
+                    uint32_t pid = __builtin_nontemporal_load(&p.perm[s]);
+                    store_stream(&p.out[s], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, pid));
                 }
-
-                // flow tap (issued first: its latency hides under the noise arithmetic)
-                float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
-                float fu = (sx + 1.0f) * 0.5f, fv = (sy + 1.0f) * 0.5f;       // (1*(v+1))/2, exactly
-                int tx = (int)__builtin_amdgcn_fmed3f(fu * p.fwf, 0.0f, p.fwm1);   // trunc == floor on [0, n-1]
-                int ty = (int)__builtin_amdgcn_fmed3f(fv * p.fhf, 0.0f, p.fhm1);
-                float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
-                float4 ft;
-                if constexpr (DECODED) { float2 d = p.flow_dec[ty * p.fw + tx]; ffx = d.x; ffy = d.y; }
-                else ft = p.flow[ty * p.fw + tx];
-
-                float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
-                if constexpr (NOISE) {
-                    float nscale = vary(u.noiseScale, i, u.varyNoiseScale);
-                    float nx = posx * nscale, ny = posy * nscale;
-                    float ntime = u.time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
-                    float sxy = mad<FAST>(ny, kC3, nx * kC3);
-                    float wx = snoise_lut<FAST>(nx, ny, uvx + ntime, sxy, lut);
-                    float wy = snoise_lut<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy, lut);
-                    float vnw = vary(u.noiseWeight, i, u.varyNoise);
-                    wxs = (wx * u.dt) * vnw; wys = (wy * u.dt) * vnw;
-                }
-
-                if constexpr (!DECODED) {
-                    float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));
-                    ffx = ft.x * k; ffy = ft.y * k;
-                }
-                float vflw = vary(u.flowWeight, i, u.varyFlow);
-                float fxs = (ffx * u.dt) * vflw, fys = (ffy * u.dt) * vflw;
-                float vfw = vary(u.forceWeight, i, u.varyForce);
-                float nvx, nvy;
-                if constexpr (NOISE) {
-                    nvx = mad<FAST>(vfw, fxs + wxs, (velx * u.damping) * u.dt);
-                    nvy = mad<FAST>(vfw, fys + wys, (vely * u.damping) * u.dt);
-                } else {
-                    // wander*dt*vary(0) is a signed zero here: adding it cannot change a non-zero
-                    // sum, and a zero sum ends in 0/0 = NaN either way (DESIGN.md "skipped terms")
-                    nvx = mad<FAST>(vfw, fxs, (velx * u.damping) * u.dt);
-                    nvy = mad<FAST>(vfw, fys, (vely * u.damping) * u.dt);
-                }
-                if constexpr (TARGET) {
-                    float4 tg = p.targets[idx];
-                    float vtg = vary(u.target, i, u.varyTarget);
-                    nvx = mad<FAST>(tg.x - posx, vtg, nvx);
-                    nvy = mad<FAST>(tg.y - posy, vtg, nvy);
-                }
-
-                // speed clamp: r = min(speed, limit)/speed is exactly 1 when 0 < speed <= limit,
-                // i.e. when 0 < s2 <= s2_cap (sqrt_rn is monotonic; s2_cap from the host).
-                float s2 = mad<FAST>(nvy, nvy, nvx * nvx);
-                if (!(s2 > 0.0f && s2 <= p.s2_cap)) {
-                    float r;
-                    if constexpr (FAST) {
-                        r = __builtin_fminf(1.0f, u.speedLimit * __builtin_amdgcn_rsqf(s2));
-                        if (!(s2 > 0.0f)) r = __builtin_nanf("");
-                    } else {
-                        float speed = __builtin_sqrtf(s2);
-                        r = __builtin_fminf(speed, u.speedLimit) / speed;
-                    }
-                    nvx *= r; nvy *= r;
-                }
-                res = make_float4(posx + nvx, posy + nvy, nvx, nvy);
             }
         }
-        store_stream(&p.out[idx], res);
     }
 }
 
@@ -264,12 +322,15 @@ __global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p)
 }
 
 template <bool FAST, bool NOISE, bool TARGET>
-static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
+static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, bool bucketed, hipStream_t s)
 {
     int grid = grid_for(p.count, 8);
-#define TH_GO(P2, DEC) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC>), dim3(grid), dim3(256), 0, s, p)
-    if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
-    else { if (decoded) TH_GO(false, true); else TH_GO(false, false); }
+#define TH_GO(P2, DEC, BK) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, BK>), dim3(grid), dim3(256), 0, s, p)
+    if (bucketed) {
+        grid = 2048;      // persistent workgroups: 8 per CU, 256 per XCD
+        if (pow2) TH_GO(true, true, true); else TH_GO(false, true, true);
+    } else if (pow2) { if (decoded) TH_GO(true, true, false); else TH_GO(true, false, false); }
+    else { if (decoded) TH_GO(false, true, false); else TH_GO(false, false, false); }
 #undef TH_GO
 }
 
@@ -281,7 +342,8 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
         return;
     }
     const bool fast = mode == TH_MODE_FAST;
-#define TH_DISPATCH(F, N, T) launch_logic_p2<F, N, T>(p, pow2, decoded, s)
+    const bool bucketed = p.perm != nullptr;      // bucketed launches always use the decoded plane
+#define TH_DISPATCH(F, N, T) launch_logic_p2<F, N, T>(p, pow2, decoded, bucketed, s)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }
@@ -292,11 +354,125 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
 #undef TH_DISPATCH
 }
 
+// ---------------------------------------------------------------------------
+// Bucketing: group particle SLOTS by the flow region their particle currently samples, so that
+// the XCD-affine launch above keeps the random flow gather inside one XCD's L2.  Counting sort
+// over kBuckets bands of flow rows; order inside a bucket is arbitrary (results do not depend on
+// slot order: every particle reads only its own texel, src/logic.frag:48,75,85).
+// ---------------------------------------------------------------------------
+TH_D uint32_t bucket_key(const BucketParams &b, float4 st)
+{
+    // same flow row as integrate(); inert / NaN particles never sample the flow: park them in bucket 0
+    if (!(st.x != kInert || st.y != kInert)) return 0u;
+    float fv = (st.y * b.view_y + 1.0f) * 0.5f;
+    int ty = (int)__builtin_amdgcn_fmed3f(fv * b.fhf, 0.0f, b.fhm1);
+    return ((uint32_t)ty * kBuckets) / b.fh;
+}
+
+constexpr uint32_t kBucketChunk = 4096;     // slots per workgroup: 16 per thread
+
+__global__ __launch_bounds__(256) void bucket_hist_kernel(const BucketParams b)
+{
+    __shared__ uint32_t lh[kBuckets];
+    if (threadIdx.x < kBuckets) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kBucketChunk;
+    for (uint32_t k = 0; k < 16; ++k) {
+        uint32_t s = base + k * 256u + threadIdx.x;
+        if (s < b.count) atomicAdd(&lh[bucket_key(b, b.state[s])], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBuckets && lh[threadIdx.x]) atomicAdd(&b.hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+// exclusive scan of the histogram into the scatter cursors; clears the histogram for the next use
+__global__ __launch_bounds__(64) void bucket_scan_kernel(uint32_t *hist, uint32_t *cursor)
+{
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < kBuckets; ++k) { uint32_t c = hist[k]; cursor[k] = acc; acc += c; hist[k] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const BucketParams b)
+{
+    __shared__ uint32_t lh[kBuckets], lbase[kBuckets];
+    if (threadIdx.x < kBuckets) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kBucketChunk;
+    uint32_t key[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        uint32_t s = base + k * 256u + threadIdx.x;
+        key[k] = s < b.count ? bucket_key(b, b.state[s]) : 0xffffffffu;
+        if (s < b.count) atomicAdd(&lh[key[k]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kBuckets) {
+        uint32_t c = lh[threadIdx.x];
+        lbase[threadIdx.x] = c ? atomicAdd(&b.cursor[threadIdx.x], c) : 0u;     // reserve a run per bucket
+        lh[threadIdx.x] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        uint32_t s = base + k * 256u + threadIdx.x;
+        if (key[k] != 0xffffffffu) b.src_slot[lbase[key[k]] + atomicAdd(&lh[key[k]], 1u)] = s;
+    }
+}
+
+// dst[d] = src[src_slot[d]]  (gather form: random 16-byte reads, coalesced writes)
+__global__ __launch_bounds__(256) void permute_state_kernel(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n)
+{
+    for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < n; d += gridDim.x * 256u) dst[d] = src[src_slot[d]];
+}
+
+// new_perm[d] = old_perm ? old_perm[src_slot[d]] : src_slot[d]
+__global__ __launch_bounds__(256) void permute_ids_kernel(uint32_t *dst, const uint32_t *old_perm, const uint32_t *src_slot, uint32_t n)
+{
+    for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < n; d += gridDim.x * 256u) {
+        uint32_t s = src_slot[d];
+        dst[d] = old_perm ? old_perm[s] : s;
+    }
+}
+
+// back to texel order: dst[perm[s]] = src[s]
+__global__ __launch_bounds__(256) void unpermute_state_kernel(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n)
+{
+    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) dst[perm[s]] = src[s];
+}
+
+void launch_bucket_build(const BucketParams &b, hipStream_t s)
+{
+    int grid = (int)((b.count + kBucketChunk - 1) / kBucketChunk);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, s, b.hist, b.cursor);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, s, b);
+}
+
+void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(permute_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, src_slot, n);
+}
+
+void launch_permute_ids(uint32_t *dst, const uint32_t *old_perm, const uint32_t *src_slot, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(permute_ids_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, old_perm, src_slot, n);
+}
+
+void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(unpermute_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, perm, n);
+}
+
 // Per-texel flow decode for one step (src/flow/get.glsl:3-5).  Sampling is NEAREST and get() is
 // pointwise, so decoding per texel is bit-identical to decoding per particle; it halves the
 // footprint of the random gather (16 -> 8 B per texel).
-__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time, float decay)
+__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time, float decay,
+                                                          uint32_t *zero8)
 {
+    // also resets the per-XCD work counters of the bucketed integrator launch that follows
+    if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float4 f = flow[i];
@@ -305,9 +481,10 @@ __global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, fl
     }
 }
 
-void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t s)
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, uint32_t *zero8,
+                        hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay);
+    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay, zero8);
 }
 
 // ---------------------------------------------------------------------------

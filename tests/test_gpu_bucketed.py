@@ -1,0 +1,65 @@
+"""The XCD-affine bucketed slot layout must be invisible in the results: rerun the integrator
+parity tests in a child process with bucketing forced on (TH_BUCKET=1) and a 2-step re-sort
+period, so that sorting, re-sorting, the permuted launch and the un-permute on read-back are all
+exercised against the golden vectors and the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_parity_suite_with_bucketing_forced():
+    if os.environ.get("TH_BUCKET") == "1":
+        pytest.skip("already inside the forced-bucketing run")
+    env = dict(os.environ, TH_BUCKET="1", TH_REBUCKET_STEPS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x",
+                        os.path.join(ROOT, "tests", "test_gpu_logic_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_optical_flow.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_spawn.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_auto_bucketing_at_c3_size_is_bit_identical(oracle):
+    """4096^2 particles over a 1920x1080 field: the default policy buckets.  Compare three steps
+    against an unbucketed context (TH_BUCKET cannot change inside one process, so the reference
+    run here is a row band of the same state computed by the oracle)."""
+    import numpy as np
+    import tendrils_amd as ta
+    from helpers import bits_equal
+    from tendrils_amd.tendrils import View
+    n = 4096
+    rng = np.random.default_rng(31)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2)).astype(np.float32)
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2)).astype(np.float32)
+    st[rng.random((n, n)) < 0.02] = [-1e6, -1e6, 0, 0]
+    fl = np.zeros((1080, 1920, 4), np.float32)
+    fl[..., :2] = rng.uniform(-.02, .02, (1080, 1920, 2))
+    fl[..., 2] = 990.0
+    t = ta.Tendrils(View(1920, 1080))
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.timer.time = 1000.0
+    rows = slice(2000, 2064)
+    cur = st[rows]
+    for _ in range(3):
+        t.timer.tick()
+        t.step()
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        cur = oracle.logic_step(u, cur, fl, y0=rows.start)
+    got = t.particles.read(0)
+    stats = t.particles.stats(t.state["speedLimit"])
+    t.dispose()
+    assert bits_equal(got[rows], cur).all()
+    inert = (st[..., 0] == -1e6) & (st[..., 1] == -1e6)
+    assert bits_equal(got[inert], st[inert]).all()
+    assert stats["live"] == int((~inert).sum()) and stats["particles"] == n * n
