@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
+    ap.add_argument("--in-view", action="store_true", help="experiment: keep every particle inside the view (|y*viewSize.y| < 1)")
     ap.add_argument("--flow-only", action="store_true", help="noiseWeight = 0 (preset 'Flow Only')")
     args = ap.parse_args()
 
@@ -133,7 +134,11 @@ def main():
     if args.flow_only:
         t.state["noiseWeight"] = 0
     ctx = t.particles._ctx
-    t.particles.upload_texels(synth_state(rank))
+    st0 = synth_state(rank)
+    if args.in_view:
+        st0[..., 1] *= np.float32(0.56)
+    t.particles.upload_texels(st0)
+    del st0
 
     # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
     time0 = 1000.0

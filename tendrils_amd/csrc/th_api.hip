@@ -115,8 +115,10 @@ struct th_context {
     // XCD-affine bucketing of the slot order (th_kernels.hip "Bucketing"); lazily allocated
     uint32_t *perm = nullptr, *perm_alt = nullptr, *src_slot = nullptr;
     float4 *spare = nullptr;             // spare state buffer the permutes ping-pong through
-    uint32_t *bucket_mem = nullptr;      // hist[kBuckets] | cursor[kBuckets] | xcd work counters[8]
+    uint32_t *bucket_mem = nullptr;      // hist[kBuckets] | cursor[kBuckets]
     bool bucketed = false;               // ring buffers currently in bucket (slot) order
+    bool bucket_wanted = false;          // last periodic decision (histogram of the interior share)
+    bool bucket_evaluated = false;
     int steps_since_bucket = 0;
 
     size_t texels() const { return (size_t)cfg.width * cfg.height; }
@@ -167,9 +169,13 @@ th_status rect_ok(th_context *c, int32_t x0, int32_t y0, int32_t w, int32_t h)
 
 
 // ---- slot order management ---------------------------------------------------------------------
-// Policy: bucket when the decoded flow plane cannot live in one XCD's 4 MiB L2 and there are
-// enough particles for the one-off sort to pay back.  TH_BUCKET=0/1 forces it off/on,
-// TH_REBUCKET_STEPS sets the re-sort period (particles drift at most speedLimit per step).
+// Policy.  Bucketing pays when the random flow gather misses L2: the decoded plane does not fit
+// one XCD's 4 MiB L2, there are enough particles to amortise the sort, and most particles sample
+// the interior of the field (particles outside the view all clamp onto the two edge rows, which
+// are cache-hot in any order).  Measured at C3 (profiles/r1_c_bucketing.txt): particles inside
+// the view 0.272 -> 0.204 ms per step; 44 % outside the view 0.204 -> 0.208 ms.  The interior
+// share is read from the sort's own histogram once per period.  TH_BUCKET=0/1 forces the layout
+// off/on; TH_REBUCKET_STEPS sets the period (particles drift at most speedLimit per step).
 int bucket_policy()
 {
     static const int v = [] { const char *e = getenv("TH_BUCKET"); return e ? atoi(e) : -1; }();
@@ -180,7 +186,7 @@ int rebucket_period()
     static const int v = [] { const char *e = getenv("TH_REBUCKET_STEPS"); int n = e ? atoi(e) : 128; return n > 0 ? n : 128; }();
     return v;
 }
-bool want_bucketing(const th_context *c)
+bool bucketing_possible(const th_context *c)
 {
     const size_t flow_texels = (size_t)c->fw * c->fh;
     if (c->texels() < 2 * flow_texels) return false;           // the decoded plane is not used at all
@@ -201,7 +207,8 @@ th_status ensure_identity(th_context *c)
     return TH_OK;
 }
 
-// (Re)sort the slots of every ring buffer by the flow region of the CURRENT state (ring[0]).
+// Once per period: histogram the CURRENT state (ring[0]) by flow region, decide, and (re)sort the
+// slots of every ring buffer when bucketing is on.
 th_status rebucket(th_context *c, const th_logic_uniforms &u)
 {
     const uint32_t n = (uint32_t)c->texels();
@@ -210,8 +217,8 @@ th_status rebucket(th_context *c, const th_logic_uniforms &u)
         TH_HIP(hipMalloc((void **)&c->perm, (size_t)n * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->perm_alt, (size_t)n * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->src_slot, (size_t)n * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->bucket_mem, (2 * th::kBuckets + 8) * sizeof(uint32_t)));
-        TH_HIP(hipMemsetAsync(c->bucket_mem, 0, (2 * th::kBuckets + 8) * sizeof(uint32_t), c->stream));
+        TH_HIP(hipMalloc((void **)&c->bucket_mem, 2 * th::kBuckets * sizeof(uint32_t)));
+        TH_HIP(hipMemsetAsync(c->bucket_mem, 0, 2 * th::kBuckets * sizeof(uint32_t), c->stream));
     }
     th::BucketParams b{};
     b.state = c->ring[0];
@@ -220,7 +227,20 @@ th_status rebucket(th_context *c, const th_logic_uniforms &u)
     b.fhf = (float)c->fh; b.fhm1 = (float)(c->fh - 1); b.fh = (uint32_t)c->fh;
     b.hist = c->bucket_mem; b.cursor = c->bucket_mem + th::kBuckets;
     b.src_slot = c->src_slot;
-    th::launch_bucket_build(b, c->stream);
+    th::launch_bucket_hist(b, c->stream);
+    c->steps_since_bucket = 0;
+    if (bucket_policy() != 1) {
+        uint32_t hist[th::kBuckets];
+        TH_HIP(hipMemcpyAsync(hist, c->bucket_mem, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));
+        const double edge = (double)hist[0] + (double)hist[th::kBuckets - 1];   // clamped rows (+ inert)
+        c->bucket_wanted = edge <= 0.30 * (double)n;
+        if (!c->bucket_wanted) {
+            TH_HIP(hipMemsetAsync(c->bucket_mem, 0, th::kBuckets * sizeof(uint32_t), c->stream));
+            return ensure_identity(c);
+        }
+    } else c->bucket_wanted = true;
+    th::launch_bucket_scatter(b, c->stream);
     for (float4 *&buf : c->ring) {
         th::launch_permute_state(c->spare, buf, c->src_slot, n, c->stream);
         float4 *t = buf; buf = c->spare; c->spare = t;
@@ -229,7 +249,6 @@ th_status rebucket(th_context *c, const th_logic_uniforms &u)
     uint32_t *t = c->perm; c->perm = c->perm_alt; c->perm_alt = t;
     TH_HIP(hipGetLastError());
     c->bucketed = true;
-    c->steps_since_bucket = 0;
     return TH_OK;
 }
 
@@ -518,10 +537,12 @@ static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t ta
 
     // Slot layout: bucketed by flow region (XCD-affine launch) or texel order.  Decided on the
     // CURRENT state, i.e. before the ring rotates.
-    const bool bucket = decoded && target == TH_TARGET_RING && want_bucketing(c);
-    if (bucket) {
-        if (!c->bucketed || c->steps_since_bucket >= rebucket_period())
+    const bool may_bucket = decoded && target == TH_TARGET_RING && bucketing_possible(c);
+    if (may_bucket) {
+        if (!c->bucket_evaluated || c->steps_since_bucket >= rebucket_period() || (c->bucket_wanted && !c->bucketed)) {
             if (th_status s = rebucket(c, u)) return s;
+            c->bucket_evaluated = true;
+        }
     } else if (th_status s = ensure_identity(c)) return s;
 
     float4 *out = nullptr;
@@ -529,9 +550,8 @@ static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t ta
     p.in = c->ring[1];            // Particles.step binds buffers[1] as `particles` (src/particles.js:139)
     p.out = out;
     p.perm = c->bucketed ? c->perm : nullptr;
-    p.cursors = c->bucketed ? c->bucket_mem + 2 * th::kBuckets : nullptr;
 
-    if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, p.cursors, c->stream);
+    if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, c->stream);
     th::launch_logic(p, c->cfg.mode, noise, use_targets, pow2, decoded, generic, c->stream);
     TH_HIP(hipGetLastError());
     ++c->steps_since_bucket;

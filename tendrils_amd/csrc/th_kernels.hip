@@ -255,15 +255,15 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     return make_float4(posx + nvx, posy + nvy, nvx, nvy);
 }
 
-// Slots handed out per work-queue dequeue in the bucketed kernel (8 iterations of a block).
-constexpr uint32_t kChunk = 2048;
 
 // BUCKETED = false: slot == particle id, plain grid-stride over texel order.
-// BUCKETED = true : slots are grouped by flow region (bucket_* kernels); `perm[slot]` is the
-//   particle id.  Each workgroup reads the id of the XCD it runs on (HW_REG_XCC_ID) and
-//   drains that XCD's eighth of the slot range from a per-XCD work counter, so one XCD's
-//   4 MiB L2 only ever sees about one eighth of the flow field; ranges of other XCDs are
-//   stolen afterwards.  Placement affects speed only, never results.
+// BUCKETED = true : slots are grouped by flow region (bucket_* kernels) and `perm[slot]` is the
+//   particle id.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one: checked
+//   with HW_REG_XCC_ID, tools/xcc_census.hip), so group g = blockIdx % 8 sweeps the g-th eighth
+//   of the slot range and one XCD's 4 MiB L2 only ever sees about one eighth of the flow field.
+//   Inside its eighth a group walks grid-stride, i.e. all of its workgroups stream one contiguous
+//   window: per-workgroup contiguous chunks ran 1.9x slower (DRAM locality of 2048 separate
+//   streams, profiles/r1_c_*).  The XCD mapping affects speed only, never results.
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool BUCKETED>
 __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 {
@@ -273,39 +273,34 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
         __syncthreads();
     }
 
+    uint32_t idx, stride, end;
     if constexpr (!BUCKETED) {
-        const uint32_t stride = gridDim.x * 256u;
-        uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (idx < p.count) nxt = load_stream(&p.in[idx]);
-        for (; idx < p.count; idx += stride) {
-            // software prefetch: the next texel of this lane is requested before this one is integrated
-            float4 st = nxt;
-            if (idx + stride < p.count) nxt = load_stream(&p.in[idx + stride]);
-            store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, idx));
-        }
+        idx = blockIdx.x * 256u + threadIdx.x;
+        stride = gridDim.x * 256u;
+        end = p.count;
     } else {
-        __shared__ uint32_t s_chunk;
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
-        const uint32_t per = (p.count + 7u) >> 3;
-        for (uint32_t v = 0; v < 8u; ++v) {
-            const uint32_t r = (xcc + v) & 7u;
-            const uint32_t lo = r * per;
-            const uint32_t hi = lo + per < p.count ? lo + per : p.count;
-            for (;;) {
-                if (threadIdx.x == 0) s_chunk = atomicAdd(&p.cursors[r], 1u);
-                __syncthreads();
-                const uint32_t base = lo + s_chunk * kChunk;
-                __syncthreads();
-                if (base >= hi || lo >= hi) break;
-                const uint32_t end = base + kChunk < hi ? base + kChunk : hi;
-                for (uint32_t s = base + threadIdx.x; s < end; s += 256u) {
-                    float4 st = load_stream(&p.in[s]);
-                    uint32_t pid = __builtin_nontemporal_load(&p.perm[s]);
-                    store_stream(&p.out[s], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, pid));
-                }
-            }
+        const uint32_t group = blockIdx.x & 7u, rank = blockIdx.x >> 3, per = (p.count + 7u) >> 3;
+        const uint32_t lo = group * per;
+        idx = lo + rank * 256u + threadIdx.x;
+        stride = (gridDim.x >> 3) * 256u;
+        end = lo + per < p.count ? lo + per : p.count;
+    }
+
+    // software prefetch: the next texel of this lane is requested before this one is integrated
+    float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t npid = idx;
+    if (idx < end) {
+        nxt = load_stream(&p.in[idx]);
+        if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx]);
+    }
+    for (; idx < end; idx += stride) {
+        float4 st = nxt;
+        uint32_t pid = BUCKETED ? npid : idx;
+        if (idx + stride < end) {
+            nxt = load_stream(&p.in[idx + stride]);
+            if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx + stride]);
         }
+        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, pid));
     }
 }
 
@@ -327,7 +322,7 @@ static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, bool 
     int grid = grid_for(p.count, 8);
 #define TH_GO(P2, DEC, BK) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, BK>), dim3(grid), dim3(256), 0, s, p)
     if (bucketed) {
-        grid = 2048;      // persistent workgroups: 8 per CU, 256 per XCD
+        grid = 2048;      // 8 workgroups per CU, 256 per XCD group (a multiple of 8 is required)
         if (pow2) TH_GO(true, true, true); else TH_GO(false, true, true);
     } else if (pow2) { if (decoded) TH_GO(true, true, false); else TH_GO(true, false, false); }
     else { if (decoded) TH_GO(false, true, false); else TH_GO(false, false, false); }
@@ -442,12 +437,19 @@ __global__ __launch_bounds__(256) void unpermute_state_kernel(float4 *dst, const
     for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) dst[perm[s]] = src[s];
 }
 
-void launch_bucket_build(const BucketParams &b, hipStream_t s)
+static int bucket_grid(const BucketParams &b) { return (int)((b.count + kBucketChunk - 1) / kBucketChunk); }
+
+// histogram only (b.hist accumulates; the caller may read it back to decide whether to sort)
+void launch_bucket_hist(const BucketParams &b, hipStream_t s)
 {
-    int grid = (int)((b.count + kBucketChunk - 1) / kBucketChunk);
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3(grid), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(bucket_hist_kernel, dim3(bucket_grid(b)), dim3(256), 0, s, b);
+}
+
+// scan + scatter: consumes (and clears) the histogram, fills b.src_slot
+void launch_bucket_scatter(const BucketParams &b, hipStream_t s)
+{
     hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, s, b.hist, b.cursor);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(grid), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(bucket_grid(b)), dim3(256), 0, s, b);
 }
 
 void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n, hipStream_t s)
@@ -468,11 +470,8 @@ void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm
 // Per-texel flow decode for one step (src/flow/get.glsl:3-5).  Sampling is NEAREST and get() is
 // pointwise, so decoding per texel is bit-identical to decoding per particle; it halves the
 // footprint of the random gather (16 -> 8 B per texel).
-__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time, float decay,
-                                                          uint32_t *zero8)
+__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time, float decay)
 {
-    // also resets the per-XCD work counters of the bucketed integrator launch that follows
-    if (zero8 && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float4 f = flow[i];
@@ -481,10 +480,9 @@ __global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, fl
     }
 }
 
-void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, uint32_t *zero8,
-                        hipStream_t s)
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay, zero8);
+    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay);
 }
 
 // ---------------------------------------------------------------------------

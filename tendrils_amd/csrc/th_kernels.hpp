@@ -30,7 +30,6 @@ struct LogicParams {
     float s2_cap;            // largest s2 with sqrt_rn(s2) <= speedLimit (see th_api.hip)
     float pos_bound;         // |pos| below this keeps the noise coordinates inside kNoiseDomain
     const uint32_t *perm;    // bucketed launches: slot -> particle id (nullptr = identity, texel order)
-    uint32_t *cursors;       // bucketed launches: 8 per-XCD work counters, zero at launch
 };
 
 // Counting sort of particle slots by flow region (th_kernels.hip "Bucketing").
@@ -79,9 +78,9 @@ struct StatsPartial {
 // launchers (defined in th_kernels.hip)
 void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
                   bool generic, hipStream_t stream);
-void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, uint32_t *zero8,
-                        hipStream_t stream);
-void launch_bucket_build(const BucketParams &b, hipStream_t stream);
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t stream);
+void launch_bucket_hist(const BucketParams &b, hipStream_t stream);
+void launch_bucket_scatter(const BucketParams &b, hipStream_t stream);
 void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n, hipStream_t stream);
 void launch_permute_ids(uint32_t *dst, const uint32_t *old_perm, const uint32_t *src_slot, uint32_t n, hipStream_t stream);
 void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t stream);
