@@ -191,6 +191,11 @@ th_status th_state_device_ptr(th_context *ctx, int32_t buffer, void **dptr);
 /* HIP-event timing on the context's own stream (for bench.py / profilers). */
 th_status th_timer_start(th_context *ctx);
 th_status th_timer_stop(th_context *ctx, float *elapsed_ms);           /* synchronises */
+/* Per-launch timing of the integrator kernel alone: while enabled, every th_step records a HIP
+ * event pair around its logic-kernel launch; _read synchronises, returns the mean duration and the
+ * number of launches since the last read, and resets. */
+th_status th_kernel_timing(th_context *ctx, int32_t enable);
+th_status th_kernel_timing_read(th_context *ctx, float *mean_ms, int32_t *launches);
 
 #ifdef __cplusplus
 }

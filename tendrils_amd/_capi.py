@@ -103,6 +103,8 @@ PROTOTYPES = {
     "th_state_device_ptr": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_void_p)]),
     "th_timer_start": (C.c_int32, [_ctx]),
     "th_timer_stop": (C.c_int32, [_ctx, C.POINTER(C.c_float)]),
+    "th_kernel_timing": (C.c_int32, [_ctx, C.c_int32]),
+    "th_kernel_timing_read": (C.c_int32, [_ctx, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 
 _NO_STATUS = {"th_abi_version", "th_last_error"}

@@ -111,6 +111,9 @@ struct th_context {
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool kernel_timing = false;          // th_kernel_timing: event pair around every logic launch
+    std::vector<hipEvent_t> kt_events;   // pairs (start, stop); kt_used of them recorded
+    size_t kt_used = 0;
 
     // XCD-affine bucketing of the slot order (th_kernels.hip "Bucketing"); lazily allocated
     uint32_t *perm = nullptr, *perm_alt = nullptr, *src_slot = nullptr;
@@ -339,6 +342,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
     (void)hipFree(c->perm); (void)hipFree(c->perm_alt); (void)hipFree(c->src_slot); (void)hipFree(c->spare);
     (void)hipFree(c->bucket_mem);
+    for (hipEvent_t e : c->kt_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -552,7 +556,19 @@ static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t ta
     p.perm = c->bucketed ? c->perm : nullptr;
 
     if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, c->stream);
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    if (c->kernel_timing) {
+        if (c->kt_used + 2 > c->kt_events.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            TH_HIP(hipEventCreate(&a)); TH_HIP(hipEventCreate(&b));
+            c->kt_events.push_back(a); c->kt_events.push_back(b);
+        }
+        k0 = c->kt_events[c->kt_used]; k1 = c->kt_events[c->kt_used + 1];
+        c->kt_used += 2;
+        TH_HIP(hipEventRecord(k0, c->stream));
+    }
     th::launch_logic(p, c->cfg.mode, noise, use_targets, pow2, decoded, generic, c->stream);
+    if (k1) TH_HIP(hipEventRecord(k1, c->stream));
     TH_HIP(hipGetLastError());
     ++c->steps_since_bucket;
     return TH_OK;
@@ -747,6 +763,31 @@ th_status th_timer_stop(th_context *c, float *elapsed_ms)
     TH_HIP(hipEventRecord(c->ev1, c->stream));
     TH_HIP(hipEventSynchronize(c->ev1));
     TH_HIP(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return TH_OK;
+}
+
+th_status th_kernel_timing(th_context *c, int32_t enable)
+{
+    if (th_status s = use(c)) return s;
+    c->kernel_timing = enable != 0;
+    if (!enable) c->kt_used = 0;
+    return TH_OK;
+}
+
+th_status th_kernel_timing_read(th_context *c, float *mean_ms, int32_t *launches)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(mean_ms && launches, "null output");
+    TH_HIP(hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (size_t k = 0; k + 1 < c->kt_used; k += 2) {
+        float ms = 0.0f;
+        TH_HIP(hipEventElapsedTime(&ms, c->kt_events[k], c->kt_events[k + 1]));
+        sum += ms;
+    }
+    *launches = (int32_t)(c->kt_used / 2);
+    *mean_ms = *launches ? (float)(sum / *launches) : 0.0f;
+    c->kt_used = 0;
     return TH_OK;
 }
 

@@ -371,6 +371,34 @@ napi_value TimerStop(napi_env env, napi_callback_info info)
     return v;
 }
 
+napi_value KernelTiming(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t on = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_kernel_timing");
+    TH_CALL("th_kernel_timing", th_kernel_timing(c, on));
+    return undefined(env);
+}
+
+// kernelTimingRead(ctx) -> {meanMs, launches}
+napi_value KernelTimingRead(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_kernel_timing_read");
+    float ms = 0;
+    int32_t n = 0;
+    TH_CALL("th_kernel_timing_read", th_kernel_timing_read(c, &ms, &n));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_double(env, ms, &v));
+    NAPI_OK(napi_set_named_property(env, o, "meanMs", v));
+    NAPI_OK(napi_create_int32(env, n, &v));
+    NAPI_OK(napi_set_named_property(env, o, "launches", v));
+    return o;
+}
+
 napi_value Init(napi_env env, napi_value exports)
 {
     struct { const char *name; napi_callback fn; } table[] = {
@@ -384,6 +412,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
+        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},
     };
     for (auto &e : table) {
         napi_value fn;
