@@ -95,6 +95,18 @@ bool finite_uniforms(const th_logic_uniforms &u)
 
 }  // namespace
 
+// One captured th_step_n sequence (see th_step_n).
+struct GraphEntry {
+    int32_t n = 0, mode = 0;
+    uint32_t flags = 0;
+    std::vector<float4 *> ring;          // ring order at capture time
+    const uint32_t *perm = nullptr;
+    th::LogicParams key{};               // launch parameters with time zeroed
+    hipGraphExec_t exec = nullptr;
+    float *times_dev = nullptr, *times_host = nullptr;
+    hipEvent_t copied = nullptr;         // times_host -> times_dev copy of the last replay
+};
+
 struct th_context {
     th_config cfg{};
     hipStream_t stream = nullptr;
@@ -114,6 +126,7 @@ struct th_context {
     bool kernel_timing = false;          // th_kernel_timing: event pair around every logic launch
     std::vector<hipEvent_t> kt_events;   // pairs (start, stop); kt_used of them recorded
     size_t kt_used = 0;
+    std::vector<GraphEntry> graphs;      // th_step_n cache
 
     // XCD-affine bucketing of the slot order (th_kernels.hip "Bucketing"); lazily allocated
     uint32_t *perm = nullptr, *perm_alt = nullptr, *src_slot = nullptr;
@@ -170,6 +183,23 @@ th_status rect_ok(th_context *c, int32_t x0, int32_t y0, int32_t w, int32_t h)
     return TH_OK;
 }
 
+
+// ---- captured th_step_n sequences -------------------------------------------------------------
+void destroy_graph(GraphEntry &g)
+{
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.times_dev) (void)hipFree(g.times_dev);
+    if (g.times_host) (void)hipHostFree(g.times_host);
+    if (g.copied) (void)hipEventDestroy(g.copied);
+    g = GraphEntry{};
+}
+
+void clear_graphs(th_context *c)
+{
+    if (!c->graphs.empty() && c->stream) (void)hipStreamSynchronize(c->stream);
+    for (GraphEntry &g : c->graphs) destroy_graph(g);
+    c->graphs.clear();
+}
 
 // ---- slot order management ---------------------------------------------------------------------
 // Policy.  Bucketing pays when the random flow gather misses L2: the decoded plane does not fit
@@ -340,6 +370,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
+    clear_graphs(c);
     (void)hipFree(c->perm); (void)hipFree(c->perm_alt); (void)hipFree(c->src_slot); (void)hipFree(c->spare);
     (void)hipFree(c->bucket_mem);
     for (hipEvent_t e : c->kt_events) (void)hipEventDestroy(e);
@@ -361,6 +392,7 @@ th_status th_set_mode(th_context *c, int32_t mode)
 th_status th_setup(th_context *c, int32_t num_buffers)
 {
     if (th_status s = use(c)) return s;
+    clear_graphs(c);
     if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(num_buffers >= 0 && num_buffers <= 64, "num_buffers out of range");
     while ((int32_t)c->ring.size() < num_buffers) {          // src/particles.js:83-86: push
@@ -421,6 +453,7 @@ th_status th_flow_resize(th_context *c, int32_t w, int32_t h)
     TH_REQUIRE(w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad flow shape %dx%d", w, h);
     if (w == c->fw && h == c->fh) return TH_OK;              // gl-fbo: same shape is a no-op
     TH_HIP(hipStreamSynchronize(c->stream));
+    clear_graphs(c);
     TH_HIP(hipFree(c->flow));
     TH_HIP(hipFree(c->flow_dec));
     c->flow = nullptr; c->flow_dec = nullptr;
@@ -485,19 +518,26 @@ th_status th_targets_clear(th_context *c)
 }
 
 // Build the launch parameters of one integrator pass and pick the kernel variant.
-// One integrator pass: pick the kernel variant and the slot layout, rotate / resolve the render
-// target, launch.
-static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t target)
+// ---- one integrator pass = plan (host decisions, may synchronise) + enqueue (launches only) -------
+struct StepPlan {
+    th::LogicParams p{};         // everything except in / out / perm / time_dev
+    bool noise = false, use_targets = false, pow2 = false, decoded = false, generic = false;
+};
+
+// Pick the kernel variant and bring the slot layout up to date.  `u.time` must be the time of
+// largest magnitude the plan will be used with (it only enters the domain checks here).
+static th_status plan_step(th_context *c, const th_logic_uniforms &u, int32_t target, StepPlan &plan)
 {
     const uint32_t W = (uint32_t)c->cfg.width, H = (uint32_t)c->cfg.global_height;
-    th::LogicParams p{};
+    th::LogicParams &p = plan.p;
+    p = th::LogicParams{};
     p.flow = c->flow; p.flow_dec = c->flow_dec; p.targets = c->targets; p.lut = c->lut;
     p.count = (uint32_t)c->texels();
     p.width = W;
     p.row0 = (uint32_t)c->cfg.row0;
     p.wf = (float)W; p.hf = (float)H;
-    const bool pow2 = is_pow2(W) && is_pow2(H);
-    p.log2w = pow2 ? ilog2(W) : 0;
+    plan.pow2 = is_pow2(W) && is_pow2(H);
+    p.log2w = plan.pow2 ? ilog2(W) : 0;
     p.inv_w = 1.0f / p.wf; p.inv_h = 1.0f / p.hf; p.inv_wh = 1.0f / (p.wf * p.hf);
     p.fw = c->fw; p.fh = c->fh;
     p.fwf = (float)c->fw; p.fhf = (float)c->fh;
@@ -507,20 +547,20 @@ static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t ta
 
     // Preconditions of the specialised path (DESIGN.md "fast-path domain").
     static const bool force_generic = getenv("TH_FORCE_GENERIC") != nullptr;   // test hook
-    bool generic = force_generic || !finite_uniforms(u);
-    const bool noise = u.noiseWeight != 0.0f;
-    bool use_targets = u.target != 0.0f;
-    if (!generic) {
+    plan.generic = force_generic || !finite_uniforms(u);
+    plan.noise = u.noiseWeight != 0.0f;
+    plan.use_targets = u.target != 0.0f;
+    if (!plan.generic) {
         // i = (x+.5 + (y+.5)W)/(WH) lies in (0, 1]; bound |vary(base, i, v)| <= |base|(1+|v|)
         double nscale = std::fabs((double)u.noiseScale) * (1.0 + std::fabs((double)u.varyNoiseScale)) * 1.001;
         double ntime = std::fabs((double)u.time) * std::fabs((double)u.noiseSpeed) *
                        (1.0 + std::fabs((double)u.varyNoiseSpeed)) * 1.001;
-        if (ntime + 1237.0 >= (double)th::kNoiseDomain) generic = true;      // z = uv + noiseTime (+1234.5678)
+        if (ntime + 1237.0 >= (double)th::kNoiseDomain) plan.generic = true;  // z = uv + noiseTime (+1234.5678)
         double bound = nscale > 0.0 ? (double)th::kNoiseDomain / nscale : 3.0e38;
         p.pos_bound = (float)std::fmin(bound * 0.999, 3.0e38);
-        if (!(p.pos_bound > 0.0f)) generic = true;
+        if (!(p.pos_bound > 0.0f)) plan.generic = true;
     }
-    if (!generic && !use_targets) {
+    if (!plan.generic && !plan.use_targets) {
         // target == 0 multiplies (targets - pos) by an exact zero; dropping the read is only
         // value-preserving when the texture holds no NaN/Inf.
         if (!c->targets_checked) {
@@ -532,32 +572,49 @@ static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t ta
             c->targets_nonfinite = flag != 0;
             c->targets_checked = true;
         }
-        use_targets = c->targets_nonfinite;
+        plan.use_targets = c->targets_nonfinite;
     }
     // Decode the flow once per step when that is cheaper than decoding per particle: it shrinks the
     // random-gather footprint (the L2/Infinity-Fabric miss traffic is what bounds this kernel).
     const size_t flow_texels = (size_t)c->fw * c->fh;
-    const bool decoded = !generic && c->texels() >= 2 * flow_texels;
+    plan.decoded = !plan.generic && c->texels() >= 2 * flow_texels;
 
     // Slot layout: bucketed by flow region (XCD-affine launch) or texel order.  Decided on the
     // CURRENT state, i.e. before the ring rotates.
-    const bool may_bucket = decoded && target == TH_TARGET_RING && bucketing_possible(c);
+    const bool may_bucket = plan.decoded && target == TH_TARGET_RING && bucketing_possible(c);
     if (may_bucket) {
         if (!c->bucket_evaluated || c->steps_since_bucket >= rebucket_period() || (c->bucket_wanted && !c->bucketed)) {
             if (th_status s = rebucket(c, u)) return s;
             c->bucket_evaluated = true;
         }
     } else if (th_status s = ensure_identity(c)) return s;
+    return TH_OK;
+}
 
+static uint32_t plan_flags(const StepPlan &plan)
+{
+    return (plan.noise ? 1u : 0u) | (plan.use_targets ? 2u : 0u) | (plan.pow2 ? 4u : 0u) | (plan.decoded ? 8u : 0u) |
+           (plan.generic ? 16u : 0u);
+}
+
+// Rotate / resolve the render target and launch (flow decode +) the integrator.  Launches only:
+// safe inside a stream capture.  `time_dev` (optional) overrides plan.p.u.time on the device.
+static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t target, float time, const float *time_dev,
+                              bool timing)
+{
+    th::LogicParams p = plan.p;
     float4 *out = nullptr;
     if (th_status s = resolve_target(c, target, true, &out)) return s;
     p.in = c->ring[1];            // Particles.step binds buffers[1] as `particles` (src/particles.js:139)
     p.out = out;
     p.perm = c->bucketed ? c->perm : nullptr;
+    p.u.time = time;
+    p.time_dev = time_dev;
 
-    if (decoded) th::launch_flow_decode(c->flow, c->flow_dec, flow_texels, u.time, u.flowDecay, c->stream);
+    if (plan.decoded)
+        th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, time, time_dev, p.u.flowDecay, c->stream);
     hipEvent_t k0 = nullptr, k1 = nullptr;
-    if (c->kernel_timing) {
+    if (timing && c->kernel_timing) {
         if (c->kt_used + 2 > c->kt_events.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             TH_HIP(hipEventCreate(&a)); TH_HIP(hipEventCreate(&b));
@@ -567,7 +624,7 @@ static th_status step_once(th_context *c, const th_logic_uniforms &u, int32_t ta
         c->kt_used += 2;
         TH_HIP(hipEventRecord(k0, c->stream));
     }
-    th::launch_logic(p, c->cfg.mode, noise, use_targets, pow2, decoded, generic, c->stream);
+    th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, c->stream);
     if (k1) TH_HIP(hipEventRecord(k1, c->stream));
     TH_HIP(hipGetLastError());
     ++c->steps_since_bucket;
@@ -580,22 +637,93 @@ th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
     TH_REQUIRE(u, "null uniforms");
     // Particles.step reads this.buffers[1] (src/particles.js:139): needs >= 2 buffers
     TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
-    return step_once(c, *u, target);
+    StepPlan plan;
+    if (th_status s = plan_step(c, *u, target, plan)) return s;
+    return enqueue_step(c, plan, target, u->time, nullptr, true);
 }
 
+// n fixed-step Tendrils.step() calls.  The launch sequence (2 kernels per step) is captured once into
+// a hipGraph per (n, uniforms, ring order, layout) and replayed; the per-step `time` values live in a
+// small device array refreshed before every replay, so replays need no node updates.
 th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, double dt_ms, int32_t n)
 {
     if (th_status s = use(c)) return s;
     TH_REQUIRE(u && n >= 0, "bad arguments");
     TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
+    if (n == 0) return TH_OK;
     th_logic_uniforms v = *u;
-    double t = time0;
     v.dt = (float)dt_ms;
+    std::vector<float> times((size_t)n);
+    double t = time0, tmax = 0.0;
     for (int32_t k = 0; k < n; ++k) {
-        t += dt_ms;                                   // src/timer.js:28-31
-        v.time = (float)t;
-        if (th_status s = step_once(c, v, TH_TARGET_RING)) return s;
+        t += dt_ms;                                   // src/timer.js:28-31: time accumulates in double
+        times[(size_t)k] = (float)t;
+        if (std::fabs(t) > std::fabs(tmax)) tmax = t;
     }
+    v.time = (float)tmax;
+    StepPlan plan;
+    if (th_status s = plan_step(c, v, TH_TARGET_RING, plan)) return s;
+
+    static const bool graphs_on = [] { const char *e = getenv("TH_GRAPH"); return !e || atoi(e) != 0; }();
+    const bool layout_stable = !c->bucket_evaluated || !bucketing_possible(c) ||
+                               c->steps_since_bucket + n <= rebucket_period();
+    if (!graphs_on || n < 2 || !layout_stable) {
+        for (int32_t k = 0; k < n; ++k) {
+            if (k) { v.time = times[(size_t)k]; if (th_status s = plan_step(c, v, TH_TARGET_RING, plan)) return s; }
+            if (th_status s = enqueue_step(c, plan, TH_TARGET_RING, times[(size_t)k], nullptr, true)) return s;
+        }
+        return TH_OK;
+    }
+
+    // cache lookup: same n, same parameters (time excluded), same ring order and layout
+    th::LogicParams key = plan.p;
+    key.u.time = 0.0f;
+    GraphEntry *hit = nullptr;
+    for (GraphEntry &g : c->graphs)
+        if (g.n == n && g.mode == c->cfg.mode && g.ring == c->ring && g.perm == (c->bucketed ? c->perm : nullptr) &&
+            g.flags == plan_flags(plan) && memcmp(&g.key, &key, sizeof key) == 0) { hit = &g; break; }
+    if (!hit) {
+        if (c->graphs.size() >= 8) { destroy_graph(c->graphs.front()); c->graphs.erase(c->graphs.begin()); }
+        GraphEntry g;
+        g.n = n; g.mode = c->cfg.mode; g.ring = c->ring; g.perm = c->bucketed ? c->perm : nullptr;
+        g.flags = plan_flags(plan); g.key = key;
+        TH_HIP(hipMalloc((void **)&g.times_dev, (size_t)n * sizeof(float)));
+        TH_HIP(hipHostMalloc((void **)&g.times_host, (size_t)n * sizeof(float)));
+        TH_HIP(hipEventCreate(&g.copied));
+        const std::vector<float4 *> ring_before = c->ring;
+        const int since_before = c->steps_since_bucket;
+        hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+        th_status st = TH_OK;
+        if (e == hipSuccess) {
+            for (int32_t k = 0; k < n && st == TH_OK; ++k)
+                st = enqueue_step(c, plan, TH_TARGET_RING, 0.0f, g.times_dev + k, false);
+            hipGraph_t graph = nullptr;
+            e = hipStreamEndCapture(c->stream, &graph);
+            if (e == hipSuccess && st == TH_OK) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        c->ring = ring_before;                         // the capture only recorded; nothing ran yet
+        c->steps_since_bucket = since_before;
+        if (e != hipSuccess || st != TH_OK) {
+            destroy_graph(g);
+            if (st != TH_OK) return st;
+            return fail(TH_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+        }
+        c->graphs.push_back(g);
+        hit = &c->graphs.back();
+    }
+    TH_HIP(hipEventSynchronize(hit->copied));          // previous replay's copy out of times_host is done
+    memcpy(hit->times_host, times.data(), (size_t)n * sizeof(float));
+    TH_HIP(hipMemcpyAsync(hit->times_dev, hit->times_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipGraphLaunch(hit->exec, c->stream));
+    for (int32_t k = 0; k < n; ++k) {                  // host-side ring bookkeeping of the n rotations
+        float4 *last = c->ring.back();
+        c->ring.pop_back();
+        c->ring.insert(c->ring.begin(), last);
+    }
+    c->steps_since_bucket += n;
+    // times_host must stay untouched until the copy has run; a later replay of this entry waits here
+    TH_HIP(hipEventRecord(hit->copied, c->stream));
     return TH_OK;
 }
 

@@ -265,8 +265,10 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
 //   window: per-workgroup contiguous chunks ran 1.9x slower (DRAM locality of 2048 separate
 //   streams, profiles/r1_c_*).  The XCD mapping affects speed only, never results.
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool BUCKETED>
-__global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
+__global__ __launch_bounds__(256) void logic_kernel(const LogicParams p_in)
 {
+    LogicParams p = p_in;
+    if (p.time_dev) p.u.time = *p.time_dev;        // captured-graph replays keep `time` in device memory
     __shared__ float4 lut[NOISE ? kLutSize : 1];
     if constexpr (NOISE) {
         for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
@@ -306,8 +308,10 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 
 // Generic kernel: reference-order evaluation of every texel (used when the host
 // cannot establish the fast path's preconditions, e.g. non-finite uniforms).
-__global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p)
+__global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p_in)
 {
+    LogicParams p = p_in;
+    if (p.time_dev) p.u.time = *p.time_dev;
     const uint32_t stride = gridDim.x * 256u;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += stride) {
         float4 st = p.in[idx];
@@ -470,8 +474,10 @@ void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm
 // Per-texel flow decode for one step (src/flow/get.glsl:3-5).  Sampling is NEAREST and get() is
 // pointwise, so decoding per texel is bit-identical to decoding per particle; it halves the
 // footprint of the random gather (16 -> 8 B per texel).
-__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time, float decay)
+__global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, float2 *dec, size_t n, float time,
+                                                          const float *time_dev, float decay)
 {
+    if (time_dev) time = *time_dev;
     size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float4 f = flow[i];
@@ -480,9 +486,10 @@ __global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, fl
     }
 }
 
-void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t s)
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
+                        hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, decay);
+    if (n) hipLaunchKernelGGL(flow_decode_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, dec, n, time, time_dev, decay);
 }
 
 // ---------------------------------------------------------------------------

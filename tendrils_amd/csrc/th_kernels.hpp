@@ -30,6 +30,7 @@ struct LogicParams {
     float s2_cap;            // largest s2 with sqrt_rn(s2) <= speedLimit (see th_api.hip)
     float pos_bound;         // |pos| below this keeps the noise coordinates inside kNoiseDomain
     const uint32_t *perm;    // bucketed launches: slot -> particle id (nullptr = identity, texel order)
+    const float *time_dev;   // graph replays: `time` is read from here instead of u.time (nullptr = u.time)
 };
 
 // Counting sort of particle slots by flow region (th_kernels.hip "Bucketing").
@@ -78,7 +79,8 @@ struct StatsPartial {
 // launchers (defined in th_kernels.hip)
 void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
                   bool generic, hipStream_t stream);
-void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, float decay, hipStream_t stream);
+void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
+                        hipStream_t stream);
 void launch_bucket_hist(const BucketParams &b, hipStream_t stream);
 void launch_bucket_scatter(const BucketParams &b, hipStream_t stream);
 void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n, hipStream_t stream);

@@ -138,6 +138,24 @@ class Tendrils {
     return this;
   }
 
+  // n x (timer.tick(); step()) for a fixed-step, unpaused timer, as one captured-graph replay
+  stepN(n) {
+    const tm = this.timer;
+    if (tm.paused || tm.step < 0 || tm.end >= 0) {
+      for (let k = 0; k < n; ++k) { tm.tick(); this.step(); }
+      return this;
+    }
+    this.particles.logic = this.logicShader;
+    const dt = tm.step * tm.rate;
+    Object.assign(this.uniforms.update, this.state, {
+      dt, time: tm.time, start: tm.since, flow: this.flow, targets: this.targets,
+      viewSize: this.viewSize, viewRes: this.viewRes
+    });
+    this.particles.stepN(this.uniforms.update, tm.time, dt, n);
+    for (let k = 0; k < n; ++k) tm.tick();
+    return this;
+  }
+
   draw() { return this; }                          // src/index.js:278-340: out of scope
 
   resize() {                                       // src/index.js:393-408

@@ -163,6 +163,19 @@ class Particles {
     if (!buffer) step(this.buffers);             // the library rotated its ring the same way
   }
 
+  // n consecutive logic passes with a fixed-step timer (time_k = time0 + (k+1)*dtMs, accumulated in
+  // double like src/timer.js:28-31), replayed from a captured hipGraph.  Extension: the reference
+  // issues these one draw call at a time.
+  stepN(update, time0, dtMs, n) {
+    if (this.logic.kind !== 'logic') throw new Error('stepN runs the logic program only');
+    const uniforms = Particles.applyUpdate(Object.assign(this.logic.uniforms, {
+      dataRes: this.shape,
+      geomRes: this.geomShape
+    }), update);
+    native.stepN(this.handle, packLogic(uniforms), time0, dtMs, n);
+    for (let k = 0; k < (n % Math.max(this.buffers.length, 1)); ++k) step(this.buffers);
+  }
+
   draw() {}                                       // no display on this path (src/particles.js:147-158)
 
   updateLogic(logic) { this.logic = ((logic instanceof Program) ? logic : new Program('logic')); }

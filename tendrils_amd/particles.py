@@ -160,6 +160,20 @@ class Particles:
             # utils.step(this.buffers): pop -> unshift  (src/utils/index.js:1-7); the C side did the same
             self.buffers.insert(0, self.buffers.pop())
 
+    def step_n(self, update, time0, dt_ms, n):
+        """n consecutive logic passes with a fixed-step timer (time_k = time0 + (k+1)*dt_ms, accumulated in
+        double like src/timer.js:28-31), replayed from a captured hipGraph.  Extension: the reference
+        issues these one draw call at a time."""
+        uniforms = Particles.applyUpdate(
+            dict(self.logic.uniforms, dataRes=self.shape, geomRes=self.geomShape), update)
+        self.logic.uniforms = uniforms
+        if self.logic.kind != LOGIC:
+            raise ValueError("step_n runs the logic program only")
+        s = logic_uniforms(uniforms)
+        call("th_step_n", self._ctx, C.byref(s), C.c_double(time0), C.c_double(dt_ms), int(n))
+        for _ in range(int(n) % max(len(self.buffers), 1)):
+            self.buffers.insert(0, self.buffers.pop())
+
     def draw(self, update=None, mode=None):          # src/particles.js:147-158 - no display here
         return None
 

@@ -197,6 +197,24 @@ class Tendrils:
             self.particles.step(self.uniforms["update"])
         return self
 
+    def step_n(self, n):
+        """n x (timer.tick(); step()) for a fixed-step, unpaused timer, as one captured-graph replay."""
+        tm = self.timer
+        if tm.paused or tm.step < 0 or tm.end >= 0:
+            for _ in range(n):
+                tm.tick()
+                self.step()
+            return self
+        self.particles.logic = self.logicShader
+        dt = tm.step * tm.rate
+        self.uniforms["update"].update(self.state)
+        self.uniforms["update"].update(dt=dt, time=tm.time, start=tm.since, flow=self.flow, targets=self.targets,
+                                       viewSize=self.viewSize, viewRes=self.viewRes)
+        self.particles.step_n(self.uniforms["update"], tm.time, dt, n)
+        for _ in range(n):
+            tm.tick()
+        return self
+
     def draw(self):                                            # src/index.js:278-340: out of scope
         return self
 

@@ -30,7 +30,10 @@ if (spec.inputs.targets) t.targets.setPixels(f32(spec.inputs.targets));
 
 if (spec.kind === 'logic') {
   t.timer.time = spec.time0;
-  for (let k = 0; k < spec.steps; ++k) {
+  if (spec.stepN) {
+    t.stepN(spec.steps);
+    save(`out_${spec.steps - 1}.bin`, t.particles.read(0));
+  } else for (let k = 0; k < spec.steps; ++k) {
     if (k && spec.follow) t.particles.uploadTexels(f32(spec.follow[k - 1]));
     if (spec.times) t.timer.time = spec.times[k] - spec.dts[k];
     t.timer.tick();

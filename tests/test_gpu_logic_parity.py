@@ -224,3 +224,29 @@ def test_full_size_properties():
     band = tb.particles.read(0)
     tb.dispose()
     assert bits_equal(band, a[1024:1536]).all()
+
+
+@pytest.mark.parametrize("n,steps", [(256, 7), (64, 4), (200, 5)])
+def test_step_n_graph_equals_single_steps(n, steps):
+    """th_step_n (captured hipGraph, device-resident per-step time) == the same number of th_step calls,
+    bit for bit, including a second replay of the cached graph and the odd/even ring parity."""
+    import tendrils_amd as ta
+    st, fl = seeded_case(n, 1000 + n)
+    outs = []
+    for graph in (False, True):
+        t = make_tendrils(n, (96, 54), (96, 54), {}, ta.TH_MODE_EXACT)
+        t.particles.upload_texels(st)
+        t.flow.set_pixels(fl)
+        t.timer.time = 4000.0
+        for _ in range(3):               # 3 batches: capture, replay (other ring parity when steps is odd), replay
+            if graph:
+                t.step_n(steps)
+            else:
+                for _ in range(steps):
+                    t.timer.tick()
+                    t.step()
+        outs.append((t.particles.read(0), t.particles.read(1), t.timer.time))
+        t.dispose()
+    assert outs[0][2] == outs[1][2]
+    assert bits_equal(outs[0][0], outs[1][0]).all()
+    assert bits_equal(outs[0][1], outs[1][1]).all()

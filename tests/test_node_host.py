@@ -156,3 +156,33 @@ def test_js_optical_flow_and_spawners(tmp_path, oracle):
         run_case(d, spec, arrays)
         got = np.fromfile(str(d / "out_0.bin"), np.float32).reshape(m["N"], m["N"], 4)
         assert bits_equal(got, oracle_spawn(oracle, fx)).all(), name
+
+
+@pytest.mark.gpu
+def test_js_step_n_matches_python_single_steps(tmp_path):
+    """Tendrils.stepN in the Node host (hipGraph replay) == the same steps issued one by one from Python."""
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    n, steps = 128, 6
+    rng = np.random.default_rng(8)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+    fl = np.zeros((54, 96, 4), np.float32)
+    fl[..., :2] = rng.uniform(-.01, .01, (54, 96, 2))
+    fl[..., 2] = 1990.0
+    run_case(tmp_path, dict(kind="logic", N=n, viewRes=[96, 54], steps=steps, time0=2000.0, stepN=True,
+                            inputs=dict(state="state.bin", flow="flow.bin")), {"state.bin": st, "flow.bin": fl})
+    got = np.fromfile(str(tmp_path / ("out_%d.bin" % (steps - 1))), np.float32).reshape(n, n, 4)
+    t = ta.Tendrils(View(96, 54))
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.timer.time = 2000.0
+    for _ in range(steps):
+        t.timer.tick()
+        t.step()
+    want = t.particles.read(0)
+    t.dispose()
+    assert bits_equal(got, want).all()
