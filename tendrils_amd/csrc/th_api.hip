@@ -131,7 +131,7 @@ struct th_context {
     // XCD-affine bucketing of the slot order (th_kernels.hip "Bucketing"); lazily allocated
     uint32_t *perm = nullptr, *perm_alt = nullptr, *src_slot = nullptr;
     float4 *spare = nullptr;             // spare state buffer the permutes ping-pong through
-    uint32_t *bucket_mem = nullptr;      // hist[kBuckets] | cursor[kBuckets]
+    uint32_t *bucket_mem = nullptr;      // hist[kBuckets+1] | cursor[kBuckets+3]
     bool bucketed = false;               // ring buffers currently in bucket (slot) order
     bool bucket_wanted = false;          // last periodic decision (histogram of the interior share)
     bool bucket_evaluated = false;
@@ -201,14 +201,14 @@ void clear_graphs(th_context *c)
     c->graphs.clear();
 }
 
+constexpr size_t kBucketWords = 2 * th::kBuckets + 4;
+
 // ---- slot order management ---------------------------------------------------------------------
 // Policy.  Bucketing pays when the random flow gather misses L2: the decoded plane does not fit
-// one XCD's 4 MiB L2, there are enough particles to amortise the sort, and most particles sample
-// the interior of the field (particles outside the view all clamp onto the two edge rows, which
-// are cache-hot in any order).  Measured at C3 (profiles/r1_c_bucketing.txt): particles inside
-// the view 0.272 -> 0.204 ms per step; 44 % outside the view 0.204 -> 0.208 ms.  The interior
-// share is read from the sort's own histogram once per period.  TH_BUCKET=0/1 forces the layout
-// off/on; TH_REBUCKET_STEPS sets the period (particles drift at most speedLimit per step).
+// one XCD's 4 MiB L2, there are enough particles to amortise the sort, and at most 30 % of them are in
+// the edge class (outside the view / inert), read from the sort's own histogram once per period
+// (measurements: profiles/r1_c_bucketing.txt).  TH_BUCKET=0/1 forces the layout off/on; TH_REBUCKET_STEPS sets
+// the period (particles drift at most speedLimit per step).
 int bucket_policy()
 {
     static const int v = [] { const char *e = getenv("TH_BUCKET"); return e ? atoi(e) : -1; }();
@@ -250,26 +250,27 @@ th_status rebucket(th_context *c, const th_logic_uniforms &u)
         TH_HIP(hipMalloc((void **)&c->perm, (size_t)n * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->perm_alt, (size_t)n * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->src_slot, (size_t)n * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->bucket_mem, 2 * th::kBuckets * sizeof(uint32_t)));
-        TH_HIP(hipMemsetAsync(c->bucket_mem, 0, 2 * th::kBuckets * sizeof(uint32_t), c->stream));
+        TH_HIP(hipMalloc((void **)&c->bucket_mem, kBucketWords * sizeof(uint32_t)));
+        TH_HIP(hipMemsetAsync(c->bucket_mem, 0, kBucketWords * sizeof(uint32_t), c->stream));
     }
     th::BucketParams b{};
     b.state = c->ring[0];
     b.count = n;
     b.view_y = u.viewSize[1];
     b.fhf = (float)c->fh; b.fhm1 = (float)(c->fh - 1); b.fh = (uint32_t)c->fh;
-    b.hist = c->bucket_mem; b.cursor = c->bucket_mem + th::kBuckets;
+    b.hist = c->bucket_mem; b.cursor = c->bucket_mem + th::kBuckets + 1;
     b.src_slot = c->src_slot;
     th::launch_bucket_hist(b, c->stream);
     c->steps_since_bucket = 0;
     if (bucket_policy() != 1) {
-        uint32_t hist[th::kBuckets];
-        TH_HIP(hipMemcpyAsync(hist, c->bucket_mem, sizeof hist, hipMemcpyDeviceToHost, c->stream));
+        // the sort's own histogram tells how many particles sample the interior of the field; particles
+        // outside the view all tap the two edge rows, which are cache-hot in any slot order
+        uint32_t edge = 0;
+        TH_HIP(hipMemcpyAsync(&edge, c->bucket_mem + th::kBuckets, sizeof edge, hipMemcpyDeviceToHost, c->stream));
         TH_HIP(hipStreamSynchronize(c->stream));
-        const double edge = (double)hist[0] + (double)hist[th::kBuckets - 1];   // clamped rows (+ inert)
-        c->bucket_wanted = edge <= 0.30 * (double)n;
+        c->bucket_wanted = (double)edge <= 0.30 * (double)n;
         if (!c->bucket_wanted) {
-            TH_HIP(hipMemsetAsync(c->bucket_mem, 0, th::kBuckets * sizeof(uint32_t), c->stream));
+            TH_HIP(hipMemsetAsync(c->bucket_mem, 0, (th::kBuckets + 1) * sizeof(uint32_t), c->stream));
             return ensure_identity(c);
         }
     } else c->bucket_wanted = true;

@@ -355,25 +355,34 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
 
 // ---------------------------------------------------------------------------
 // Bucketing: group particle SLOTS by the flow region their particle currently samples, so that
-// the XCD-affine launch above keeps the random flow gather inside one XCD's L2.  Counting sort
-// over kBuckets bands of flow rows; order inside a bucket is arbitrary (results do not depend on
-// slot order: every particle reads only its own texel, src/logic.frag:48,75,85).
+// the XCD-affine launch above keeps the random flow gather inside one XCD's L2.
+//   * interior particles: counting sort over kBuckets bands of flow rows, then cut into 8 equal
+//     shares (by particle count) in row order: share g = the field region XCD group g works in;
+//   * edge class: particles outside the view (their tap clamps onto row 0 or the last row: two
+//     cache-hot rows) and inert particles (no tap at all) are dealt evenly to all 8 groups, so
+//     that they do not push the interior particles into fewer XCDs.
+// Slot order of group g: [interior share g][edge share g]; group g owns slots [g*S/8, (g+1)*S/8)
+// to within rounding.  Order inside a bucket is arbitrary - results do not depend on slot order:
+// every particle reads only its own texel (src/logic.frag:48,75,85).
 // ---------------------------------------------------------------------------
+constexpr uint32_t kEdgeKey = kBuckets;          // counters: kBuckets interior bands + 1 edge class
+constexpr uint32_t kKeys = kBuckets + 1;
+
 TH_D uint32_t bucket_key(const BucketParams &b, float4 st)
 {
-    // same flow row as integrate(); inert / NaN particles never sample the flow: park them in bucket 0
-    if (!(st.x != kInert || st.y != kInert)) return 0u;
-    float fv = (st.y * b.view_y + 1.0f) * 0.5f;
-    int ty = (int)__builtin_amdgcn_fmed3f(fv * b.fhf, 0.0f, b.fhm1);
-    return ((uint32_t)ty * kBuckets) / b.fh;
+    if (!(st.x != kInert || st.y != kInert)) return kEdgeKey;          // inert: never samples the flow
+    float fv = (st.y * b.view_y + 1.0f) * 0.5f;                         // same flow row as flow tap in integrate()
+    float r = fv * b.fhf;
+    if (!(r >= 1.0f && r < b.fhm1)) return kEdgeKey;                    // clamps to row 0 / last row (or NaN)
+    return ((uint32_t)(int)r * kBuckets) / b.fh;
 }
 
 constexpr uint32_t kBucketChunk = 4096;     // slots per workgroup: 16 per thread
 
 __global__ __launch_bounds__(256) void bucket_hist_kernel(const BucketParams b)
 {
-    __shared__ uint32_t lh[kBuckets];
-    if (threadIdx.x < kBuckets) lh[threadIdx.x] = 0;
+    __shared__ uint32_t lh[kKeys];
+    if (threadIdx.x < kKeys) lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kBucketChunk;
     for (uint32_t k = 0; k < 16; ++k) {
@@ -381,24 +390,46 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(const BucketParams b)
         if (s < b.count) atomicAdd(&lh[bucket_key(b, b.state[s])], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kBuckets && lh[threadIdx.x]) atomicAdd(&b.hist[threadIdx.x], lh[threadIdx.x]);
+    if (threadIdx.x < kKeys && lh[threadIdx.x]) atomicAdd(&b.hist[threadIdx.x], lh[threadIdx.x]);
 }
 
-// exclusive scan of the histogram into the scatter cursors; clears the histogram for the next use
+// Exclusive scan of the histogram into per-class rank cursors (interior ranks count through the
+// bands in row order, edge ranks start at 0); totals go to cursor[kKeys] (interior) and
+// cursor[kKeys+1] (edge).  Clears the histogram for the next use.
 __global__ __launch_bounds__(64) void bucket_scan_kernel(uint32_t *hist, uint32_t *cursor)
 {
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
         for (uint32_t k = 0; k < kBuckets; ++k) { uint32_t c = hist[k]; cursor[k] = acc; acc += c; hist[k] = 0; }
+        cursor[kEdgeKey] = 0;
+        cursor[kKeys] = acc;
+        cursor[kKeys + 1] = hist[kEdgeKey];
+        hist[kEdgeKey] = 0;
     }
+}
+
+// rank inside a class -> final slot (see the layout above); start(g) = floor(g*total/8)
+TH_D uint32_t share_start(uint32_t g, uint32_t total) { return (uint32_t)(((unsigned long long)g * total) >> 3); }
+TH_D uint32_t final_slot(uint32_t rank, bool edge, uint32_t n_int, uint32_t n_edge)
+{
+    const uint32_t total = edge ? n_edge : n_int;
+    uint32_t g = (uint32_t)((8ull * rank) / total);
+    g = g > 7u ? 7u : g;
+    while (rank < share_start(g, total)) --g;
+    while (g < 7u && rank >= share_start(g + 1u, total)) ++g;
+    const uint32_t group_start = share_start(g, n_int) + share_start(g, n_edge);
+    const uint32_t int_in_group = share_start(g + 1u, n_int) - share_start(g, n_int);
+    return edge ? group_start + int_in_group + (rank - share_start(g, n_edge))
+                : group_start + (rank - share_start(g, n_int));
 }
 
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const BucketParams b)
 {
-    __shared__ uint32_t lh[kBuckets], lbase[kBuckets];
-    if (threadIdx.x < kBuckets) lh[threadIdx.x] = 0;
+    __shared__ uint32_t lh[kKeys], lbase[kKeys];
+    if (threadIdx.x < kKeys) lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kBucketChunk;
+    const uint32_t n_int = b.cursor[kKeys], n_edge = b.cursor[kKeys + 1];
     uint32_t key[16];
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
@@ -407,16 +438,19 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const BucketParams 
         if (s < b.count) atomicAdd(&lh[key[k]], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < kBuckets) {
+    if (threadIdx.x < kKeys) {
         uint32_t c = lh[threadIdx.x];
-        lbase[threadIdx.x] = c ? atomicAdd(&b.cursor[threadIdx.x], c) : 0u;     // reserve a run per bucket
+        lbase[threadIdx.x] = c ? atomicAdd(&b.cursor[threadIdx.x], c) : 0u;     // reserve a run of ranks per key
         lh[threadIdx.x] = 0;
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
         uint32_t s = base + k * 256u + threadIdx.x;
-        if (key[k] != 0xffffffffu) b.src_slot[lbase[key[k]] + atomicAdd(&lh[key[k]], 1u)] = s;
+        if (key[k] != 0xffffffffu) {
+            uint32_t rank = lbase[key[k]] + atomicAdd(&lh[key[k]], 1u);
+            b.src_slot[final_slot(rank, key[k] == kEdgeKey, n_int, n_edge)] = s;
+        }
     }
 }
 

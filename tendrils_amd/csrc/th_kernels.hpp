@@ -41,8 +41,8 @@ struct BucketParams {
     float view_y;            // viewSize.y
     float fhf, fhm1;
     uint32_t fh;
-    uint32_t *hist;          // [kBuckets], zero on entry
-    uint32_t *cursor;        // [kBuckets]
+    uint32_t *hist;          // [kBuckets + 1] (interior bands + edge class), zero on entry
+    uint32_t *cursor;        // [kBuckets + 3]: rank cursors, then the two class totals
     uint32_t *src_slot;      // out: new slot d takes the particle of old slot src_slot[d]
 };
 
