@@ -235,10 +235,14 @@ def main():
                 pending = dev_counters.all_reduce_async(dist)
 
     def run(k_steps):
-        for k in range(k_steps):
-            t.timer.tick()
-            t.step()
-            if (k + 1) % STATS_EVERY == 0:
+        # the step loop is replayed from captured hipGraphs (Tendrils.step_n -> th_step_n), 16 steps per
+        # replay; between replays: statistics (+ their RCCL reduction) and the optical-flow refresh
+        done = 0
+        while done < k_steps:
+            n = min(STATS_EVERY, k_steps - done)
+            t.step_n(n)
+            done += n
+            if n == STATS_EVERY:
                 stats_tick()
                 if of is not None:      # keep the field alive: re-stamp it from the frame pair (blended)
                     of.update(dict(speedLimit=t.state["speedLimit"], time=t.timer.time, viewSize=t.viewSize))
