@@ -542,58 +542,125 @@ TH_D int nearest_texel_fx16(float u, unsigned n)
     return (int)((fx * n) >> 16);
 }
 
-// texture2D on RGBA8 then grayScale() (src/utils/gray-scale.glsl:2).  UNORM8 -> float as
-// (c*257) * (1/65535): what the captured reference run did; equals c/255 within 1 ulp.
-TH_D float gray_tap(const uchar4 *img, int w, int h, float u, float v)
+// gray value of frame texel (tx, ty): texture2D on RGBA8 then grayScale() (src/utils/gray-scale.glsl:2).
+// UNORM8 -> float as (c*257) * (1/65535): what the captured reference run did; equals c/255 within 1 ulp.
+TH_D float gray_texel(const uchar4 *img, int w, int tx, int ty)
 {
-    uchar4 t = img[nearest_texel_fx16(v, (unsigned)h) * w + nearest_texel_fx16(u, (unsigned)w)];
+    uchar4 t = img[ty * w + tx];
     const float k = 1.0f / 65535.0f;
     float r = ((float)t.x * 257.0f) * k, g = ((float)t.y * 257.0f) * k, b = ((float)t.z * 257.0f) * k;
     return r * 0.3f + g * 0.59f + b * 0.11f;
 }
 
-template <bool BLEND>
-__global__ __launch_bounds__(256) void optical_flow_kernel(const OpticalFlowParams p)
+// shader arithmetic after the ten taps (src/optical-flow/index.frag:69-80) + the blend
+TH_D void optical_flow_finish(const OpticalFlowParams &p, int idx, float gx, float gy, float diff)
 {
     const th_optical_flow_uniforms &u = p.u;
-    const int n = p.out_w * p.out_h;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-        int y = idx / p.out_w, x = idx - y * p.out_w;
-        // varying uv = position.xy (src/screen/index.vert:6-10): NDC of the pixel centre, as the
-        // rasteriser interpolates it: (x+0.5)*A - 1 with gradient A = fl(2/W)  (DESIGN.md "optical flow")
-        float ux = ((float)x + 0.5f) * p.grad_x - 1.0f;
-        float uy = ((float)y + 0.5f) * p.grad_y - 1.0f;
-        float px = ux * u.scaleUV[0] / u.viewSize[0], py = uy * u.scaleUV[1] / u.viewSize[1];
-        float sx = (px + 1.0f) * 0.5f, sy = (py + 1.0f) * 0.5f;          // posToUV, exactly (1*(v+1))/2
-        float o = u.offset;
-#define TAP(img, a, b) gray_tap(img, p.fr_w, p.fr_h, a, b)
-        float gx = (TAP(p.view, sx + o, sy) - TAP(p.view, sx - o, sy)) + (TAP(p.last, sx + o, sy) - TAP(p.last, sx - o, sy));
-        float gy = (TAP(p.view, sx, sy + o) - TAP(p.view, sx, sy - o)) + (TAP(p.last, sx, sy + o) - TAP(p.last, sx, sy - o));
-        float diff = TAP(p.view, sx, sy) - TAP(p.last, sx, sy);
-#undef TAP
-        float gm = __builtin_sqrtf((gx * gx) + (gy * gy) + u.lambda);
-        float vx = (diff * (gx / gm)) * u.speed, vy = (diff * (gy / gm)) * u.speed;
-        // bezier(vec3(0,0,1), t) (src/utils/bezier.glsl:9-13), literal operation order
-        float t = __builtin_sqrtf(vx * vx + vy * vy) / u.speedLimit;
-        float ut = 1.0f - t;
-        float bz = (0.0f * ut + 0.0f * t) * ut + (0.0f * ut + 1.0f * t) * t;
-        float fx = bz * vx, fy = bz * vy;
-        // flow(vel, speedLimit): vec4(vel, time, min(length(vel)/speedLimit, 1))  src/flow/apply/state.glsl:5-16
-        float a = __builtin_fminf(__builtin_sqrtf(fx * fx + fy * fy) / u.speedLimit, 1.0f);
-        float4 src = make_float4(fx, fy, u.time, a);
-        if constexpr (BLEND) {
-            float4 d = p.flow[idx];
-            float ia = 1.0f - a;
-            src = make_float4(src.x * a + d.x * ia, src.y * a + d.y * ia, src.z * a + d.z * ia, src.w * a + d.w * ia);
-        }
-        p.flow[idx] = src;
+    float gm = __builtin_sqrtf((gx * gx) + (gy * gy) + u.lambda);
+    float vx = (diff * (gx / gm)) * u.speed, vy = (diff * (gy / gm)) * u.speed;
+    // bezier(vec3(0,0,1), t) (src/utils/bezier.glsl:9-13), literal operation order
+    float t = __builtin_sqrtf(vx * vx + vy * vy) / u.speedLimit;
+    float ut = 1.0f - t;
+    float bz = (0.0f * ut + 0.0f * t) * ut + (0.0f * ut + 1.0f * t) * t;
+    float fx = bz * vx, fy = bz * vy;
+    // flow(vel, speedLimit): vec4(vel, time, min(length(vel)/speedLimit, 1))  src/flow/apply/state.glsl:5-16
+    float a = __builtin_fminf(__builtin_sqrtf(fx * fx + fy * fy) / u.speedLimit, 1.0f);
+    // gl.blendFunc(SRC_ALPHA, ONE_MINUS_SRC_ALPHA) on the float target
+    float4 d = p.flow[idx];
+    float ia = 1.0f - a;
+    p.flow[idx] = make_float4(fx * a + d.x * ia, fy * a + d.y * ia, u.time * a + d.z * ia, a * a + d.w * ia);
+}
+
+// varying uv -> frame uv of output texel coordinate c along one axis (src/optical-flow/index.frag:56):
+// NDC of the pixel centre as the rasteriser interpolates it, (c+0.5)*A - 1 with A = fl(2/size)
+// (DESIGN.md "optical flow"), then posToUV(uv*scaleUV/viewSize).
+TH_D float frame_uv(int c, float grad, float scale, float view)
+{
+    float u = ((float)c + 0.5f) * grad - 1.0f;
+    float q = u * scale / view;
+    return (q + 1.0f) * 0.5f;              // posToUV, exactly (1*(v+1))/2
+}
+
+constexpr int kOfTileW = 32, kOfTileH = 8;          // output texels per workgroup (32 x 8 lanes)
+constexpr int kOfLdsTexels = 3072;                   // staged frame texels per frame (12 KiB per frame)
+
+// One workgroup = a 32 x 8 tile of flow texels.  When the ten taps of the whole tile fall inside a
+// small box of frame texels (offset of a few texels: the reference default `offset` scaled to
+// texels, SURVEY.md C3 offset = 1/1920), both frames' box is converted to gray ONCE and staged in
+// LDS - each staged texel then serves ~5 taps of neighbouring lanes and the UNORM8->gray arithmetic
+// runs once per frame texel instead of once per tap.  Otherwise (the demo's offset = 0.1 UV = 192
+// texels at 1080p: no reuse inside a tile) every tap is a coalesced global load served by L2.
+// Tap texel indices are computed identically on both paths, so the result is bit-identical.
+__global__ __launch_bounds__(256) void optical_flow_kernel(const OpticalFlowParams p)
+{
+    __shared__ float lds_view[kOfLdsTexels], lds_last[kOfLdsTexels];
+    __shared__ int box[4];                               // x0, x1, y0, y1 (frame texels, inclusive)
+    const th_optical_flow_uniforms &u = p.u;
+    const int lx = threadIdx.x & (kOfTileW - 1), ly = threadIdx.x >> 5;
+    const int tiles_x = (p.out_w + kOfTileW - 1) / kOfTileW;
+    const int bx = (blockIdx.x % tiles_x) * kOfTileW, by = (blockIdx.x / tiles_x) * kOfTileH;
+    const int x = bx + lx, y = by + ly;
+    const float o = u.offset;
+
+    // box of the tile's taps: the tap index is monotonic in the output coordinate for a fixed offset,
+    // so the extremes are reached at the tile's first / last column (row) with offsets -o, 0, +o
+    if (threadIdx.x < 12) {
+        const int axis = threadIdx.x / 6, rest = threadIdx.x % 6, edge = rest / 3, k = rest % 3;
+        const float off = k == 0 ? -o : (k == 1 ? 0.0f : o);
+        int c = axis == 0 ? (edge ? min(bx + kOfTileW, p.out_w) - 1 : bx) : (edge ? min(by + kOfTileH, p.out_h) - 1 : by);
+        float s = axis == 0 ? frame_uv(c, p.grad_x, u.scaleUV[0], u.viewSize[0]) : frame_uv(c, p.grad_y, u.scaleUV[1], u.viewSize[1]);
+        int t = nearest_texel_fx16(s + off, (unsigned)(axis == 0 ? p.fr_w : p.fr_h));
+        // (threads 0..11 are one wave: its LDS operations execute in program order)
+        if (threadIdx.x == 0) { box[0] = t; box[1] = t; }
+        if (threadIdx.x == 6) { box[2] = t; box[3] = t; }
+        atomicMin(&box[2 * axis], t);
+        atomicMax(&box[2 * axis + 1], t);
     }
+    __syncthreads();
+    const int x0 = box[0], y0 = box[2], bw = box[1] - box[0] + 1, bh = box[3] - box[2] + 1;
+    const bool tiled = bw * bh <= kOfLdsTexels;          // workgroup-uniform
+    if (tiled) {
+        for (int t = threadIdx.x; t < bw * bh; t += 256) {
+            int ty = t / bw, tx = t - ty * bw;
+            lds_view[t] = gray_texel(p.view, p.fr_w, x0 + tx, y0 + ty);
+            lds_last[t] = gray_texel(p.last, p.fr_w, x0 + tx, y0 + ty);
+        }
+    }
+    __syncthreads();
+    if (x >= p.out_w || y >= p.out_h) return;
+
+    const float sx = frame_uv(x, p.grad_x, u.scaleUV[0], u.viewSize[0]);
+    const float sy = frame_uv(y, p.grad_y, u.scaleUV[1], u.viewSize[1]);
+    const int txm = nearest_texel_fx16(sx - o, (unsigned)p.fr_w), txc = nearest_texel_fx16(sx, (unsigned)p.fr_w),
+              txp = nearest_texel_fx16(sx + o, (unsigned)p.fr_w);
+    const int tym = nearest_texel_fx16(sy - o, (unsigned)p.fr_h), tyc = nearest_texel_fx16(sy, (unsigned)p.fr_h),
+              typ = nearest_texel_fx16(sy + o, (unsigned)p.fr_h);
+    float gx, gy, diff;
+    if (tiled) {
+#define V(tx, ty) lds_view[((ty) - y0) * bw + ((tx) - x0)]
+#define L(tx, ty) lds_last[((ty) - y0) * bw + ((tx) - x0)]
+        gx = (V(txp, tyc) - V(txm, tyc)) + (L(txp, tyc) - L(txm, tyc));          // :63-64
+        gy = (V(txc, typ) - V(txc, tym)) + (L(txc, typ) - L(txc, tym));          // :66-67
+        diff = V(txc, tyc) - L(txc, tyc);                                         // :72
+#undef V
+#undef L
+    } else {
+#define V(tx, ty) gray_texel(p.view, p.fr_w, tx, ty)
+#define L(tx, ty) gray_texel(p.last, p.fr_w, tx, ty)
+        gx = (V(txp, tyc) - V(txm, tyc)) + (L(txp, tyc) - L(txm, tyc));
+        gy = (V(txc, typ) - V(txc, tym)) + (L(txc, typ) - L(txc, tym));
+        diff = V(txc, tyc) - L(txc, tyc);
+#undef V
+#undef L
+    }
+    optical_flow_finish(p, y * p.out_w + x, gx, gy, diff);
 }
 
 void launch_optical_flow(const OpticalFlowParams &p, hipStream_t s)
 {
-    size_t n = (size_t)p.out_w * p.out_h;
-    if (n) hipLaunchKernelGGL(optical_flow_kernel<true>, dim3(grid_for(n, 8)), dim3(256), 0, s, p);
+    if (p.out_w <= 0 || p.out_h <= 0) return;
+    const int tiles = ((p.out_w + kOfTileW - 1) / kOfTileW) * ((p.out_h + kOfTileH - 1) / kOfTileH);
+    hipLaunchKernelGGL(optical_flow_kernel, dim3(tiles), dim3(256), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------
