@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 N = 4096                        # particles per rank = N*N
 FLOW_W, FLOW_H = 1920, 1080
-BYTES_PER_PARTICLE_STEP = 32    # 16 B state read + 16 B written
+BYTES_PER_PARTICLE_STEP = 32    # 16 B state read + 16 B written; 8 + 8 with --state f16
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 STATS_EVERY = 16
 
@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure HBM traffic")
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
+    ap.add_argument("--state", default="f32", choices=["f32", "f16"], help="state ring storage (f16 = packed 8 B/particle, config C5)")
     ap.add_argument("--in-view", action="store_true", help="experiment: keep every particle inside the view (|y*viewSize.y| < 1)")
     ap.add_argument("--flow-only", action="store_true", help="noiseWeight = 0 (preset 'Flow Only')")
     args = ap.parse_args()
@@ -154,7 +155,7 @@ def main():
     traffic, traffic_note = None, "not measured"
     under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
     if rank == 0 and world == 1 and not args.no_traffic and not args.force_dist and not under_profiler:
-        extra = ["--mode", args.mode] + (["--flow-only"] if args.flow_only else []) + \
+        extra = ["--mode", args.mode, "--state", args.state] + (["--flow-only"] if args.flow_only else []) + \
                 (["--in-view"] if args.in_view else []) + (["--flow-size", args.flow_size] if args.flow_size else [])
         traffic, traffic_note = measure_traffic(extra)
 
@@ -174,7 +175,8 @@ def main():
 
     opts = ta.defaults()
     opts.update(device=local_rank, mode=ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT,
-                row0=shard_rows(N * world, world, rank)[0], rows=N, globalHeight=N * world)
+                row0=shard_rows(N * world, world, rank)[0], rows=N, globalHeight=N * world,
+                stateFormat=ta.TH_STATE_F16 if args.state == "f16" else ta.TH_STATE_F32)
     t = ta.Tendrils(View(FLOW_W, FLOW_H), opts)
     t.resize()                       # viewRes 1920x1080 -> viewSize [1, 1.7778]; flow.shape = viewRes
     t.setup(N)
@@ -281,27 +283,28 @@ def main():
         ev_s, kern_s = ev_ms.value / 1e3, k_ms.value / 1e3
 
     particles = N * N * world
+    bytes_per_step = BYTES_PER_PARTICLE_STEP // (2 if args.state == "f16" else 1)
     value = particles * args.steps / wall
     # `value` includes the statistics reductions (every 16 steps); the roofline uses the kernel-only pass
     per_launch_s = kern_s                       # mean logic_kernel duration (event pair per launch)
-    achieved = BYTES_PER_PARTICLE_STEP * N * N / per_launch_s / 1e9
+    achieved = bytes_per_step * N * N / per_launch_s / 1e9
 
     line = {
         "metric": "particle-steps/sec (16M particles per GPU)", "value": value, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",     # arithmetic is fp32 in both storage formats
         "config": {"workload": "C3: 4096x4096 RGBA32F state (16.8M particles) per GPU, flow 1920x1080 from "
                                + flow_source + ", reference default uniforms"
                                + (" with noiseWeight=0 (flow-only)" if args.flow_only else " (simplex noise on)")
                                + ", 60 Hz fixed timer",
-                   "mode": args.mode, "particles_per_gpu": N * N,
+                   "mode": args.mode, "state_storage": args.state, "particles_per_gpu": N * N,
                    "parallelism": "row-band shard x%d, flow replicated" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "logic_kernel", "avg_launch_ms": per_launch_s * 1e3,
                      "avg_step_ms_on_stream": ev_s / args.steps * 1e3,
-                     "algorithmic_bytes_per_launch": BYTES_PER_PARTICLE_STEP * N * N},
+                     "algorithmic_bytes_per_launch": bytes_per_step * N * N},
         "counters": stats,
     }
 

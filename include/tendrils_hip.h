@@ -54,6 +54,13 @@ enum {
     TH_MODE_FAST = 1     /* FMA contraction + approximate rcp/sqrt; tolerance in DESIGN.md */
 };
 
+/* Storage format of the state ring.  The host side of the ABI always speaks RGBA32F texels. */
+enum {
+    TH_STATE_F32 = 0,    /* RGBA32F, the reference's texture format (gl-fbo {float:true}, src/particles.js:84-85) */
+    TH_STATE_F16 = 1     /* 8 B per particle: SNORM16 position over [-2,2) + fp16 velocity (config C5; build-defined,
+                            the reference has no half path).  Arithmetic stays fp32; only the storage is quantised. */
+};
+
 /* Render targets / texture sources, replacing the FBO arguments of
  * Particles.step(update, buffer) (src/particles.js:123-130) and
  * PixelSpawner.buffer (src/spawn/pixels/index.js:38-40). */
@@ -76,7 +83,7 @@ typedef struct th_config {
     int32_t row0;           /* global row of local row 0 */
     int32_t num_buffers;    /* ring length; Tendrils uses 2 (src/index.js:186) */
     int32_t mode;           /* TH_MODE_* */
-    int32_t reserved;
+    int32_t state_format;   /* TH_STATE_* : storage of the state ring */
 } th_config;
 
 /* Uniforms of src/logic.frag:3-34; field names = shader uniform names =

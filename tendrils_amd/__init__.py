@@ -6,12 +6,12 @@ Python host mirror of the reference's JS interface for that path
 (`Particles`, `Tendrils`, `Timer`, spawners, `OpticalFlow`), used by the tests
 and bench.py; the Node host (tendrils_amd/js) binds the same C ABI through N-API.
 """
-from ._capi import (INERT, TH_MODE_EXACT, TH_MODE_FAST, TH_SOURCE_FLOW, TH_TARGET_RING,
-                    TH_TARGET_TARGETS, TendrilsHipError)
+from ._capi import (INERT, TH_MODE_EXACT, TH_MODE_FAST, TH_SOURCE_FLOW, TH_STATE_F16, TH_STATE_F32,
+                    TH_TARGET_RING, TH_TARGET_TARGETS, TendrilsHipError)
 from .particles import Particles, defaults as particles_defaults
 from .tendrils import Tendrils, defaults, gl_settings
 from .timer import Timer
 
 __all__ = ["Particles", "Tendrils", "Timer", "defaults", "particles_defaults", "gl_settings",
-           "TendrilsHipError", "INERT", "TH_MODE_EXACT", "TH_MODE_FAST", "TH_TARGET_RING",
+           "TendrilsHipError", "INERT", "TH_MODE_EXACT", "TH_MODE_FAST", "TH_STATE_F32", "TH_STATE_F16", "TH_TARGET_RING",
            "TH_TARGET_TARGETS", "TH_SOURCE_FLOW"]

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("TH_LIB") or os.path.join(HERE, "lib", "libtendrils_hi
 
 TH_OK = 0
 TH_MODE_EXACT, TH_MODE_FAST = 0, 1
+TH_STATE_F32, TH_STATE_F16 = 0, 1
 TH_TARGET_RING, TH_TARGET_TARGETS, TH_SOURCE_FLOW = -1, -2, -3
 INERT = -1000000.0
 
@@ -27,7 +28,7 @@ class TendrilsHipError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
                 ("global_height", C.c_int32), ("row0", C.c_int32), ("num_buffers", C.c_int32),
-                ("mode", C.c_int32), ("reserved", C.c_int32)]
+                ("mode", C.c_int32), ("state_format", C.c_int32)]
 
 
 class LogicUniforms(C.Structure):

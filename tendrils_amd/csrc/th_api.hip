@@ -110,7 +110,9 @@ struct GraphEntry {
 struct th_context {
     th_config cfg{};
     hipStream_t stream = nullptr;
-    std::vector<float4 *> ring;          // ring[0] = buffers[0] (most recent)
+    std::vector<float4 *> ring;          // ring[0] = buffers[0] (most recent); TH_STATE_F16: packed, 8 B per texel
+    bool packed = false;                 // cfg.state_format == TH_STATE_F16
+    float4 *tmp[3] = {nullptr, nullptr, nullptr};   // f32 staging for the non-hot operations on a packed ring
     float4 *flow = nullptr;
     float2 *flow_dec = nullptr;          // per-step decoded plane (launch_flow_decode)
     int32_t fw = 0, fh = 0;
@@ -138,6 +140,7 @@ struct th_context {
     int steps_since_bucket = 0;
 
     size_t texels() const { return (size_t)cfg.width * cfg.height; }
+    size_t state_bytes() const { return texels() * (packed ? sizeof(uint2) : sizeof(float4)); }
 };
 
 namespace {
@@ -151,9 +154,9 @@ th_status use(th_context *c)
 
 th_status alloc_state(th_context *c, float4 **out)
 {
-    TH_HIP(hipMalloc((void **)out, c->texels() * sizeof(float4)));
-    // gl-fbo attachments start zero-filled
-    TH_HIP(hipMemsetAsync(*out, 0, c->texels() * sizeof(float4), c->stream));
+    TH_HIP(hipMalloc((void **)out, c->state_bytes()));
+    // gl-fbo attachments start zero-filled (all-zero bits are the zero state in the packed format too)
+    TH_HIP(hipMemsetAsync(*out, 0, c->state_bytes(), c->stream));
     return TH_OK;
 }
 
@@ -183,6 +186,40 @@ th_status rect_ok(th_context *c, int32_t x0, int32_t y0, int32_t w, int32_t h)
     return TH_OK;
 }
 
+
+// ---- packed ring: f32 staging for everything except the hot step ---------------------------------
+th_status staging(th_context *c, int k, float4 **out)
+{
+    if (!c->tmp[k]) TH_HIP(hipMalloc((void **)&c->tmp[k], c->texels() * sizeof(float4)));
+    *out = c->tmp[k];
+    return TH_OK;
+}
+
+// f32 view of ring buffer `buf` in staging slot k (a no-op for an f32 ring: returns the buffer itself)
+th_status unpacked_view(th_context *c, float4 *buf, int k, float4 **out)
+{
+    if (!c->packed) { *out = buf; return TH_OK; }
+    if (th_status s = staging(c, k, out)) return s;
+    th::launch_unpack_state(*out, buf, (uint32_t)c->texels(), c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+// where a pass that renders into ring buffer `buf` should write (staging slot k when packed) ...
+th_status render_target(th_context *c, float4 *buf, int k, float4 **out)
+{
+    if (!c->packed || buf == c->targets) { *out = buf; return TH_OK; }
+    return staging(c, k, out);
+}
+
+// ... and the commit of that staging buffer into the packed ring buffer
+th_status commit_target(th_context *c, float4 *buf, float4 *rendered)
+{
+    if (rendered == buf) return TH_OK;
+    th::launch_pack_state(buf, rendered, (uint32_t)c->texels(), c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
 
 // ---- captured th_step_n sequences -------------------------------------------------------------
 void destroy_graph(GraphEntry &g)
@@ -221,6 +258,7 @@ int rebucket_period()
 }
 bool bucketing_possible(const th_context *c)
 {
+    if (c->packed) return false;                                 // packed ring: texel order only
     const size_t flow_texels = (size_t)c->fw * c->fh;
     if (c->texels() < 2 * flow_texels) return false;           // the decoded plane is not used at all
     if (bucket_policy() == 0) return false;
@@ -311,6 +349,7 @@ th_status th_create(const th_config *cfg, th_context **out)
     TH_REQUIRE(cfg->width > 0 && cfg->height > 0, "state shape must be positive (got %dx%d)", cfg->width, cfg->height);
     TH_REQUIRE(cfg->num_buffers >= 0 && cfg->num_buffers <= 64, "num_buffers out of range");
     TH_REQUIRE(cfg->mode == TH_MODE_EXACT || cfg->mode == TH_MODE_FAST, "unknown mode %d", cfg->mode);
+    TH_REQUIRE(cfg->state_format == TH_STATE_F32 || cfg->state_format == TH_STATE_F16, "unknown state format %d", cfg->state_format);
     TH_REQUIRE((uint64_t)cfg->width * (uint64_t)cfg->height < (1ull << 31), "more than 2^31 texels per context");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(TH_ERR_NO_DEVICE, "no HIP device available");
@@ -323,6 +362,7 @@ th_status th_create(const th_config *cfg, th_context **out)
     th_context *c = new (std::nothrow) th_context;
     if (!c) return fail(TH_ERR_INVALID, "out of host memory");
     c->cfg = *cfg;
+    c->packed = cfg->state_format == TH_STATE_F16;
     if (c->cfg.global_height <= 0) c->cfg.global_height = c->cfg.height;
     if (c->cfg.row0 < 0 || c->cfg.row0 + c->cfg.height > c->cfg.global_height) {
         delete c;
@@ -347,7 +387,9 @@ th_status th_create(const th_config *cfg, th_context **out)
         TH_HIP(hipMalloc((void **)&c->flow, sizeof(float4)));
         TH_HIP(hipMemsetAsync(c->flow, 0, sizeof(float4), c->stream));
         TH_HIP(hipMalloc((void **)&c->flow_dec, sizeof(float2)));
-        if (th_status s = alloc_state(c, &c->targets)) return s;
+        // targets is an RGBA32F texture in every state format
+        TH_HIP(hipMalloc((void **)&c->targets, c->texels() * sizeof(float4)));
+        TH_HIP(hipMemsetAsync(c->targets, 0, c->texels() * sizeof(float4), c->stream));
         for (int k = 0; k < c->cfg.num_buffers; ++k) {
             float4 *b = nullptr;
             if (th_status s = alloc_state(c, &b)) return s;
@@ -372,6 +414,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
     clear_graphs(c);
+    for (float4 *t : c->tmp) (void)hipFree(t);
     (void)hipFree(c->perm); (void)hipFree(c->perm_alt); (void)hipFree(c->src_slot); (void)hipFree(c->spare);
     (void)hipFree(c->bucket_mem);
     for (hipEvent_t e : c->kt_events) (void)hipEventDestroy(e);
@@ -426,9 +469,12 @@ th_status th_upload_state(th_context *c, int32_t buffer, const float *rgba, int3
     TH_REQUIRE(buffer >= -1 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
     int first = buffer < 0 ? 0 : buffer, last = buffer < 0 ? (int)c->ring.size() - 1 : buffer;
     for (int b = first; b <= last; ++b) {
-        float4 *dst = c->ring[b] + (size_t)y0 * c->cfg.width + x0;
+        float4 *view = nullptr;                 // packed ring: edit an f32 copy, then re-pack
+        if (th_status s = unpacked_view(c, c->ring[b], 0, &view)) return s;
+        float4 *dst = view + (size_t)y0 * c->cfg.width + x0;
         TH_HIP(hipMemcpy2DAsync(dst, (size_t)c->cfg.width * sizeof(float4), rgba, (size_t)w * sizeof(float4),
                                 (size_t)w * sizeof(float4), h, hipMemcpyHostToDevice, c->stream));
+        if (th_status s = commit_target(c, c->ring[b], view)) return s;
     }
     TH_HIP(hipStreamSynchronize(c->stream));   // the caller may reuse `rgba` immediately (setPixels semantics)
     return TH_OK;
@@ -441,7 +487,9 @@ th_status th_download_state(th_context *c, int32_t buffer, float *rgba, int32_t 
     TH_REQUIRE(rgba, "null pixels");
     if (th_status s = rect_ok(c, x0, y0, w, h)) return s;
     TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
-    const float4 *src = c->ring[buffer] + (size_t)y0 * c->cfg.width + x0;
+    float4 *view = nullptr;
+    if (th_status s = unpacked_view(c, c->ring[buffer], 0, &view)) return s;
+    const float4 *src = view + (size_t)y0 * c->cfg.width + x0;
     TH_HIP(hipMemcpy2DAsync(rgba, (size_t)w * sizeof(float4), src, (size_t)c->cfg.width * sizeof(float4),
                             (size_t)w * sizeof(float4), h, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));
@@ -606,8 +654,16 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     th::LogicParams p = plan.p;
     float4 *out = nullptr;
     if (th_status s = resolve_target(c, target, true, &out)) return s;
-    p.in = c->ring[1];            // Particles.step binds buffers[1] as `particles` (src/particles.js:139)
-    p.out = out;
+    // A packed (TH_STATE_F16) ring runs the packed kernel on the default path (ring -> ring, specialised
+    // kernel); explicit targets and the generic kernel go through f32 staging.
+    const bool packed_kernel = c->packed && target == TH_TARGET_RING && !plan.generic;
+    float4 *in = c->ring[1], *rt = out;     // Particles.step binds buffers[1] as `particles` (src/particles.js:139)
+    if (c->packed && !packed_kernel) {
+        if (th_status s = unpacked_view(c, c->ring[1], 1, &in)) return s;
+        if (th_status s = render_target(c, out, 0, &rt)) return s;
+    }
+    p.in = in;
+    p.out = rt;
     p.perm = c->bucketed ? c->perm : nullptr;
     p.u.time = time;
     p.time_dev = time_dev;
@@ -625,9 +681,12 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         c->kt_used += 2;
         TH_HIP(hipEventRecord(k0, c->stream));
     }
-    th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, c->stream);
+    th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel,
+                     c->stream);
     if (k1) TH_HIP(hipEventRecord(k1, c->stream));
     TH_HIP(hipGetLastError());
+    if (c->packed && !packed_kernel)
+        if (th_status s = commit_target(c, out, rt)) return s;
     ++c->steps_since_bucket;
     return TH_OK;
 }
@@ -668,7 +727,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     static const bool graphs_on = [] { const char *e = getenv("TH_GRAPH"); return !e || atoi(e) != 0; }();
     const bool layout_stable = !c->bucket_evaluated || !bucketing_possible(c) ||
                                c->steps_since_bucket + n <= rebucket_period();
-    if (!graphs_on || n < 2 || !layout_stable) {
+    if (!graphs_on || n < 2 || !layout_stable || (c->packed && plan.generic)) {
         for (int32_t k = 0; k < n; ++k) {
             if (k) { v.time = times[(size_t)k]; if (th_status s = plan_step(c, v, TH_TARGET_RING, plan)) return s; }
             if (th_status s = enqueue_step(c, plan, TH_TARGET_RING, times[(size_t)k], nullptr, true)) return s;
@@ -736,9 +795,11 @@ th_status th_spawn_init(th_context *c, int32_t target)
     if (target == TH_TARGET_RING) TH_REQUIRE(!c->ring.empty(), "no state buffers");
     if (th_status s = resolve_target(c, target, true, &out)) return s;
     // src/spawn/init/index.frag:5-10
-    th::launch_fill(out, make_float4(th::kInert, th::kInert, 0.0f, 0.0f), c->texels(), c->stream);
+    float4 *rt = nullptr;
+    if (th_status s = render_target(c, out, 0, &rt)) return s;
+    th::launch_fill(rt, make_float4(th::kInert, th::kInert, 0.0f, 0.0f), c->texels(), c->stream);
     TH_HIP(hipGetLastError());
-    return TH_OK;
+    return commit_target(c, out, rt);
 }
 
 th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t target)
@@ -749,12 +810,14 @@ th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t 
     if (target == TH_TARGET_RING) TH_REQUIRE(!c->ring.empty(), "no state buffers");
     float4 *out = nullptr;
     if (th_status s = resolve_target(c, target, true, &out)) return s;
+    float4 *rt = nullptr;
+    if (th_status s = render_target(c, out, 0, &rt)) return s;
     th::SpawnBallParams p{};
-    p.out = out; p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
+    p.out = rt; p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
     p.u = *u;
     th::launch_spawn_ball(p, c->stream);
     TH_HIP(hipGetLastError());
-    return TH_OK;
+    return commit_target(c, out, rt);
 }
 
 th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target)
@@ -768,22 +831,28 @@ th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int3
     TH_REQUIRE(c->ring.size() >= 2, "spawn pass needs at least 2 state buffers (have %zu)", c->ring.size());
     float4 *out = nullptr;
     if (th_status s = resolve_target(c, target, true, &out)) return s;
+    float4 *rt = nullptr, *particles = nullptr;
+    if (th_status s = render_target(c, out, 0, &rt)) return s;
+    if (th_status s = unpacked_view(c, c->ring[1], 1, &particles)) return s;
     th::SpawnSampleParams p{};
-    p.particles = c->ring[1];
-    p.out = out;
+    p.particles = particles;
+    p.out = rt;
     // `source` names the spawnData texture in the ring order the pass sees (after the rotation)
     if (source == TH_SOURCE_FLOW) { p.data = c->flow; p.dw = c->fw; p.dh = c->fh; }
     else if (source >= 0 && source < (int32_t)c->ring.size()) {
         if (c->cfg.height != c->cfg.global_height)
             return fail(TH_ERR_UNSUPPORTED, "sampling the particle texture needs the whole texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
-        p.data = c->ring[source]; p.dw = c->cfg.width; p.dh = c->cfg.height;
+        float4 *data = nullptr;
+        if (source == 1) data = particles;
+        else if (th_status s = unpacked_view(c, c->ring[source], 2, &data)) return s;
+        p.data = data; p.dw = c->cfg.width; p.dh = c->cfg.height;
     } else return fail(TH_ERR_INVALID, "bad spawnData source %d", source);
     p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
     p.wf = (float)c->cfg.width; p.hf = (float)c->cfg.global_height;
     p.u = *u;
     th::launch_spawn_sample(p, c->stream);
     TH_HIP(hipGetLastError());
-    return TH_OK;
+    return commit_target(c, out, rt);
 }
 
 th_status th_frames_resize(th_context *c, int32_t w, int32_t h)
@@ -839,7 +908,9 @@ th_status th_stats_async(th_context *c, float speed_limit, void **device_counter
 {
     if (th_status s = use(c)) return s;
     TH_REQUIRE(!c->ring.empty(), "no state buffers");
-    th::launch_stats(c->ring[0], c->texels(), speed_limit, c->partials, c->d_counters, c->stream);
+    float4 *view = nullptr;
+    if (th_status s = unpacked_view(c, c->ring[0], 0, &view)) return s;
+    th::launch_stats(view, c->texels(), speed_limit, c->partials, c->d_counters, c->stream);
     TH_HIP(hipGetLastError());
     if (device_counters) *device_counters = c->d_counters;
     return TH_OK;

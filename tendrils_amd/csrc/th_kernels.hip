@@ -16,6 +16,7 @@
 namespace th {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 static int grid_for(size_t n, int blocks_per_cu)
 {
@@ -35,6 +36,68 @@ TH_D void store_stream(float4 *p, float4 a)
 {
     v4f v = {a.x, a.y, a.z, a.w};
     __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+}
+
+// ---------------------------------------------------------------------------
+// Packed state (TH_STATE_F16, config C5): 8 bytes per particle instead of 16.
+//   word 0: position, two SNORM16 over [-2, 2): q = rint(clamp(p * 16384, -32767, 32767));
+//           (-32768, -32768) = inert (src/const/inert.glsl), (-32768, 0) = NaN position
+//   word 1: velocity, two IEEE fp16 (round to nearest even)
+// The integrator arithmetic is unchanged (fp32, exact or fast) on the DECODED values; only the
+// storage is quantised.  The reference has no half path: this encoding is defined by this build
+// (DESIGN.md "packed state") and mirrored for the tests in tests/helpers.py.
+// ---------------------------------------------------------------------------
+TH_D float4 unpack_state(uint2 w)
+{
+    int xs = (int)(short)(w.x & 0xffffu), ys = (int)(short)(w.x >> 16);
+    _Float16 hx, hy;
+    unsigned short ux = (unsigned short)(w.y & 0xffffu), uy = (unsigned short)(w.y >> 16);
+    __builtin_memcpy(&hx, &ux, 2); __builtin_memcpy(&hy, &uy, 2);
+    float4 s;
+    s.z = (float)hx; s.w = (float)hy;
+    if (xs == -32768) {
+        if (ys == -32768) { s.x = kInert; s.y = kInert; }
+        else { s.x = __builtin_nanf(""); s.y = __builtin_nanf(""); }
+    } else {
+        s.x = (float)xs * 6.103515625e-05f; s.y = (float)ys * 6.103515625e-05f;       // exact: / 16384
+    }
+    return s;
+}
+
+TH_D uint2 pack_state(float4 s)
+{
+    unsigned px;
+    if (!(s.x != kInert || s.y != kInert)) px = 0x80008000u;
+    else if (s.x != s.x || s.y != s.y) px = 0x00008000u;
+    else {
+        int xs = (int)__builtin_rintf(__builtin_amdgcn_fmed3f(s.x * 16384.0f, -32767.0f, 32767.0f));
+        int ys = (int)__builtin_rintf(__builtin_amdgcn_fmed3f(s.y * 16384.0f, -32767.0f, 32767.0f));
+        px = ((unsigned)xs & 0xffffu) | ((unsigned)ys << 16);
+    }
+    _Float16 hx = (_Float16)s.z, hy = (_Float16)s.w;
+    unsigned short ux, uy;
+    __builtin_memcpy(&ux, &hx, 2); __builtin_memcpy(&uy, &hy, 2);
+    return make_uint2(px, (unsigned)ux | ((unsigned)uy << 16));
+}
+
+__global__ __launch_bounds__(256) void pack_state_kernel(uint2 *dst, const float4 *src, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = pack_state(src[i]);
+}
+
+__global__ __launch_bounds__(256) void unpack_state_kernel(float4 *dst, const uint2 *src, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = unpack_state(src[i]);
+}
+
+void launch_pack_state(void *dst, const float4 *src, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(pack_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, (uint2 *)dst, src, n);
+}
+
+void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(unpack_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, (const uint2 *)src, n);
 }
 
 // ---------------------------------------------------------------------------
@@ -306,6 +369,33 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p_in)
     }
 }
 
+// Packed-state integrator (TH_STATE_F16): same per-particle arithmetic on the decoded texel, 8 B in / 8 B out.
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
+__global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p_in)
+{
+    LogicParams p = p_in;
+    if (p.time_dev) p.u.time = *p.time_dev;
+    __shared__ float4 lut[NOISE ? kLutSize : 1];
+    if constexpr (NOISE) {
+        for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
+        __syncthreads();
+    }
+    const v2u *in = reinterpret_cast<const v2u *>(p.in);
+    v2u *out = reinterpret_cast<v2u *>(p.out);
+    const uint32_t stride = gridDim.x * 256u;
+    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    v2u nxt = {0x80008000u, 0u};
+    if (idx < p.count) nxt = __builtin_nontemporal_load(&in[idx]);
+    for (; idx < p.count; idx += stride) {
+        v2u w = nxt;
+        if (idx + stride < p.count) nxt = __builtin_nontemporal_load(&in[idx + stride]);
+        float4 r = integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, unpack_state(make_uint2(w.x, w.y)), idx);
+        uint2 q = pack_state(r);
+        v2u qq = {q.x, q.y};
+        __builtin_nontemporal_store(qq, &out[idx]);
+    }
+}
+
 // Generic kernel: reference-order evaluation of every texel (used when the host
 // cannot establish the fast path's preconditions, e.g. non-finite uniforms).
 __global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p_in)
@@ -333,16 +423,30 @@ static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, bool 
 #undef TH_GO
 }
 
-void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
-                  bool generic, hipStream_t s)
+template <bool FAST, bool NOISE, bool TARGET>
+static void launch_packed_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
-    if (generic) {
+    int grid = grid_for(p.count, 8);
+#define TH_GO(P2, DEC) hipLaunchKernelGGL((logic_packed_kernel<FAST, NOISE, TARGET, P2, DEC>), dim3(grid), dim3(256), 0, s, p)
+    if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
+    else { if (decoded) TH_GO(false, true); else TH_GO(false, false); }
+#undef TH_GO
+}
+
+void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
+                  bool generic, bool packed, hipStream_t s)
+{
+    if (generic) {          // texel-order f32 only (the host unpacks around it)
         hipLaunchKernelGGL(logic_generic_kernel, dim3(grid_for(p.count, 8)), dim3(256), 0, s, p);
         return;
     }
     const bool fast = mode == TH_MODE_FAST;
     const bool bucketed = p.perm != nullptr;      // bucketed launches always use the decoded plane
-#define TH_DISPATCH(F, N, T) launch_logic_p2<F, N, T>(p, pow2, decoded, bucketed, s)
+#define TH_DISPATCH(F, N, T)                                             \
+    do {                                                                 \
+        if (packed) launch_packed_p2<F, N, T>(p, pow2, decoded, s);      \
+        else launch_logic_p2<F, N, T>(p, pow2, decoded, bucketed, s);    \
+    } while (0)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }

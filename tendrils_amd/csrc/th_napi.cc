@@ -114,13 +114,14 @@ void finalize_ctx(napi_env, void *data, void *)
     delete slot;
 }
 
-// create(device, width, height, globalHeight, row0, numBuffers, mode) -> handle
+// create(device, width, height, globalHeight, row0, numBuffers, mode[, stateFormat]) -> handle
 napi_value Create(napi_env env, napi_callback_info info)
 {
     Args a(env, info);
     th_config cfg{};
     cfg.device = a.i32(0); cfg.width = a.i32(1); cfg.height = a.i32(2); cfg.global_height = a.i32(3);
     cfg.row0 = a.i32(4); cfg.num_buffers = a.i32(5); cfg.mode = a.i32(6);
+    cfg.state_format = a.argc > 7 ? a.i32(7) : TH_STATE_F32;
     if (!a.ok) BAD_ARGS("create");
     th_context *c = nullptr;
     TH_CALL("th_create", th_create(&cfg, &c));
@@ -421,7 +422,7 @@ napi_value Init(napi_env env, napi_value exports)
     }
     napi_value v;
     struct { const char *name; int32_t val; } consts[] = {
-        {"MODE_EXACT", TH_MODE_EXACT}, {"MODE_FAST", TH_MODE_FAST},
+        {"MODE_EXACT", TH_MODE_EXACT}, {"MODE_FAST", TH_MODE_FAST}, {"STATE_F32", TH_STATE_F32}, {"STATE_F16", TH_STATE_F16},
         {"TARGET_RING", TH_TARGET_RING}, {"TARGET_TARGETS", TH_TARGET_TARGETS}, {"SOURCE_FLOW", TH_SOURCE_FLOW},
     };
     for (auto &e : consts) {

@@ -85,6 +85,7 @@ class Tendrils {
     this.timer = params.timer;
     this.device = params.device | 0;
     this.mode = params.mode | 0;
+    this.stateFormat = params.stateFormat | 0;
   }
 
   setup(...rest) { this.setupParticles(...rest); this.reset(); return this; }
@@ -105,7 +106,8 @@ class Tendrils {
       geomShape: [shape[0], shape[1] * 2],
       logic: new Program('logic'),
       device: this.device,
-      mode: this.mode
+      mode: this.mode,
+      stateFormat: this.stateFormat
     });
     this.logicShader = this.particles.logic;
     this.particles.setup(numBuffers);

@@ -103,7 +103,7 @@ class Particles {
     };
     this.nextId = 0;
     this.handle = native.create(params.device | 0, this.shape[0], this.shape[1],
-      params.globalHeight | 0, params.row0 | 0, 0, params.mode | 0);
+      params.globalHeight | 0, params.row0 | 0, 0, params.mode | 0, params.stateFormat | 0);
   }
 
   setup(numBuffers = 1) {                       // src/particles.js:81-92

@@ -83,7 +83,7 @@ class Particles:
         self._next_id = 0
         cfg = _capi.Config(device=self._device, width=self.shape[0], height=self.shape[1],
                            global_height=self._global_height, row0=self._row0, num_buffers=0,
-                           mode=self._mode, reserved=0)
+                           mode=self._mode, state_format=int(params.get("stateFormat", 0)))
         self._ctx = C.c_void_p()
         call("th_create", C.byref(cfg), C.byref(self._ctx))
 

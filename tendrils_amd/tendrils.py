@@ -132,6 +132,7 @@ class Tendrils:
         self.timer = params["timer"]
         self._device = int(params.get("device", 0))
         self._mode = int(params.get("mode", _capi.TH_MODE_EXACT))
+        self._state_format = int(params.get("stateFormat", _capi.TH_STATE_F32))
         self._band = (int(params.get("row0", 0)), params.get("rows"), int(params.get("globalHeight", 0)))
 
     # -- setup ---------------------------------------------------------------------
@@ -159,7 +160,7 @@ class Tendrils:
             self.particles.dispose()
         self.particles = Particles(self.gl, dict(
             shape=shape, geomShape=[shape[0], shape[1] * 2], logic=Program(LOGIC),
-            device=self._device, mode=self._mode, row0=row0,
+            device=self._device, mode=self._mode, stateFormat=self._state_format, row0=row0,
             globalHeight=(gh if gh else (rootNum if rows else 0))))
         self.logicShader = self.particles.logic
         self.particles.setup(numBuffers)

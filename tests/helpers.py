@@ -77,3 +77,41 @@ def of_expected(fx, full):
     if not bands:
         return full
     return np.concatenate([full[a:b] for a, b in bands])
+
+
+# ---- packed state (TH_STATE_F16) - the build-defined encoding of include/tendrils_hip.h, mirrored in numpy ----
+def pack_state(st):
+    """[..., 4] f32 texels -> [..., 2] uint32 words (SNORM16 position over [-2,2) | fp16 velocity)."""
+    st = np.asarray(st, np.float32)
+    x, y = st[..., 0], st[..., 1]
+    inert = (x == np.float32(-1e6)) & (y == np.float32(-1e6))
+    nan = np.isnan(x) | np.isnan(y)
+    with np.errstate(invalid="ignore"):
+        qx = np.rint(np.clip(x * np.float32(16384), -32767, 32767)).astype(np.float32)
+        qy = np.rint(np.clip(y * np.float32(16384), -32767, 32767)).astype(np.float32)
+    qx = np.where(nan, 0, qx).astype(np.int32)
+    qy = np.where(nan, 0, qy).astype(np.int32)
+    qx = np.where(inert | nan, -32768, qx)
+    qy = np.where(inert, -32768, np.where(nan, 0, qy))
+    w0 = (qx.astype(np.uint32) & 0xffff) | ((qy.astype(np.uint32) & 0xffff) << 16)
+    with np.errstate(over="ignore"):
+        h = st[..., 2:].astype(np.float16).view(np.uint16).astype(np.uint32)
+    w1 = h[..., 0] | (h[..., 1] << 16)
+    return np.stack([w0, w1], -1).astype(np.uint32)
+
+
+def unpack_state(w):
+    """inverse of pack_state (exact)."""
+    w = np.asarray(w, np.uint32)
+    xs = (w[..., 0] & 0xffff).astype(np.uint16).view(np.int16).astype(np.int32)
+    ys = (w[..., 0] >> 16).astype(np.uint16).view(np.int16).astype(np.int32)
+    out = np.empty(w.shape[:-1] + (4,), np.float32)
+    out[..., 0] = xs.astype(np.float32) * np.float32(2.0 ** -14)
+    out[..., 1] = ys.astype(np.float32) * np.float32(2.0 ** -14)
+    inert = (xs == -32768) & (ys == -32768)
+    nan = (xs == -32768) & ~inert
+    out[inert, 0] = out[inert, 1] = np.float32(-1e6)
+    out[nan, 0] = out[nan, 1] = np.nan
+    out[..., 2] = (w[..., 1] & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
+    out[..., 3] = (w[..., 1] >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    return out

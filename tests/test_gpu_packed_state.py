@@ -1,0 +1,92 @@
+"""Packed state (TH_STATE_F16, config C5): 8 B per particle.  The arithmetic is the same exact fp32
+integrator applied to the DECODED texel; only the storage is quantised.  So for a state that is
+already representable, K steps on the GPU must equal K x [decode -> oracle step -> encode], bit for bit
+(the encoding is defined by this build; tests/helpers.py mirrors it in numpy)."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, pack_state, unpack_state
+from test_gpu_logic_parity import seeded_case
+
+pytestmark = pytest.mark.gpu
+
+
+def packed_tendrils(n, view, overrides=None):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    opts = ta.defaults()
+    opts["stateFormat"] = ta.TH_STATE_F16
+    t = ta.Tendrils(View(*view), opts)
+    t.resize()
+    t.setup(n)
+    t.state.update(overrides or {})
+    return t
+
+
+def test_numpy_mirror_roundtrip():
+    rng = np.random.default_rng(0)
+    st = np.empty((64, 64, 4), np.float32)
+    st[..., :2] = rng.uniform(-2.5, 2.5, (64, 64, 2))
+    st[..., 2:] = rng.uniform(-.02, .02, (64, 64, 2))
+    st[0, :8] = [-1e6, -1e6, 0, 0]
+    st[1, :4, 0] = np.nan
+    q = unpack_state(pack_state(st))
+    assert bits_equal(unpack_state(pack_state(q)), q).all()                  # idempotent on representable states
+    live = ~((st[..., 0] == -1e6) & (st[..., 1] == -1e6)) & ~np.isnan(st[..., 0])
+    inside = live & (np.abs(st[..., :2]) < 1.99).all(-1)
+    assert np.abs(q[inside][:, :2] - st[inside][:, :2]).max() <= 2.0 ** -15  # half a position quantum
+    assert np.allclose(q[live][:, 2:], st[live][:, 2:], rtol=2.0 ** -11, atol=1e-7)
+    assert (q[0, :8, 0] == -1e6).all() and np.isnan(q[1, :4, 0]).all()
+
+
+@pytest.mark.parametrize("n,overrides", [(256, {}), (256, {"noiseWeight": 0}), (200, {"target": 0.0005})])
+def test_packed_steps_equal_decode_oracle_encode(oracle, n, overrides):
+    st, fl = seeded_case(n, 4242 + n)
+    st[0, :3, 0] = np.nan                                   # NaN marker survives
+    st = unpack_state(pack_state(st))                       # a representable start state
+    rng = np.random.default_rng(n)
+    tg = np.zeros((n, n, 4), np.float32)
+    tg[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    t = packed_tendrils(n, (96, 54), overrides)
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.targets.set_pixels(tg)
+    assert bits_equal(t.particles.read(0), st).all()        # upload -> pack -> unpack -> download is lossless here
+    t.timer.time = 4000.0
+    cur = st
+    for _ in range(4):
+        t.timer.tick()
+        t.step()
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        cur = unpack_state(pack_state(oracle.logic_step(u, cur, fl, tg)))
+        assert bits_equal(t.particles.read(0), cur).all()
+    t.dispose()
+
+
+def test_packed_graph_replay_and_spawners(oracle):
+    from tendrils_amd.spawn import spawnBall
+    n = 128
+    st, fl = seeded_case(n, 99)
+    st = unpack_state(pack_state(st))
+    outs = []
+    for graph in (False, True):
+        t = packed_tendrils(n, (96, 54))
+        t.particles.upload_texels(st)
+        t.flow.set_pixels(fl)
+        t.timer.time = 4000.0
+        if graph:
+            t.step_n(6)
+        else:
+            for _ in range(6):
+                t.timer.tick()
+                t.step()
+        outs.append(t.particles.read(0))
+        stats = t.particles.stats(t.state["speedLimit"])
+        assert stats["particles"] == n * n
+        # a spawn pass renders f32 and is re-packed
+        spawnBall(None, dict(uniforms=dict(radius=0.5, speed=0.004))).spawn(t)
+        ball = t.particles.read(0)
+        assert bits_equal(ball, unpack_state(pack_state(oracle.spawn_ball(n, n, radius=0.5, speed=0.004)))).all()
+        t.dispose()
+    assert bits_equal(outs[0], outs[1]).all()
