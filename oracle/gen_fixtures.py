@@ -150,6 +150,42 @@ def gen_logic(r, only):
                    zero_flow=True, state=st, view=(32, 32))
 
 
+def gen_logic_4096(r, only):
+    """C3-sized state texture: the index i = (x+.5 + (y+.5)*W)/(W*H) loses low bits in fp32 once
+    (y+.5)*W >= 2^24 (src/logic.frag:57-58) - must be mirrored, not fixed.  The state is generated
+    inside the page from an integer hash (tests/helpers.py:hashed_state is the same generator); only
+    row bands of the reference output are stored."""
+    name = "logic_4096_bands"
+    if only and only not in name:
+        return
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from helpers import hashed_state
+    n, seed, inert_mod = 4096, 20240, 37
+    rng = np.random.default_rng(seed)
+    fw, fh = 240, 135
+    time0 = 60000.0
+    fl = rand_flow(rng, fw, fh, time0 + 1000.0 / 60.0, 0.01)
+    bands = [(0, 2), (1022, 1026), (2047, 2049), (3070, 3074), (4094, 4096)]
+    outs, res = r.logic(None, flow=fl, time0=time0, steps=1, view=(fw, fh), flow_shape=(fw, fh), rows=bands,
+                        state_gen=dict(N=n, seed=seed, inertMod=inert_mod))
+    # validity (QUAD NOTE) per band from the regenerated input
+    valids = []
+    for (a, b) in bands:
+        st = hashed_state(n, seed, inert_mod, rows=(a - a % 2, b + b % 2))
+        inert = (st[..., 0] == INERT) & (st[..., 1] == INERT)
+        v = np.ones(inert.shape, bool)
+        for yy in range(0, inert.shape[0] - 1, 2):
+            if inert[yy, 0]:
+                for (dy, dx) in ((0, 1), (1, 0), (1, 1)):
+                    if not inert[yy + dy, dx]:
+                        v[yy + dy, dx] = False
+        valids.append(v[a % 2: a % 2 + (b - a)])
+    meta = dict(kind="logic_bands", N=n, seed=seed, inertMod=inert_mod, bands=bands, times=res["times"], dts=res["dts"],
+                viewSize=res["viewSize"], viewRes=res["viewRes"], flowShape=res["flowShape"],
+                state={k: v for k, v in res["state"].items() if isinstance(v, (int, float))}, ref_ms=res["ms"])
+    save(name, flow=fl, out=np.concatenate(outs[0]), valid=np.concatenate(valids), uniforms=json.dumps(meta))
+
+
 def gen_optical_flow(r, only):
     """One blended pass of the reference's optical-flow shader (docs/js/demo.js:73) per case.
     Frames are regenerated from seeds by tests/helpers.py:synth_frame; only parameters and the
@@ -228,6 +264,7 @@ def main():
     r = RefRunner()
     print("oracle:", r.probe())
     gen_logic(r, args.only)
+    gen_logic_4096(r, args.only)
     gen_optical_flow(r, args.only)
     gen_spawn(r, args.only)
 

@@ -64,7 +64,29 @@
     var k;
     for (k in (job.state || {})) t.state[k] = job.state[k];
 
-    var st = f32FromB64(job.inputs.state);
+    // state either supplied, or generated here from an integer hash (large N: too big to ship as base64);
+    // the same generator lives in tests/helpers.py:hashed_state
+    var st;
+    if (job.inputs.stateGen) {
+      var seed = job.inputs.stateGen.seed >>> 0, inertMod = job.inputs.stateGen.inertMod >>> 0;
+      st = new Float32Array(4 * N * N);
+      var hash = function (v) {           // 32-bit integer mix (Math.imul keeps it exact)
+        v = Math.imul(v ^ (v >>> 16), 0x7feb352d) >>> 0;
+        v = Math.imul(v ^ (v >>> 15), 0x846ca68b) >>> 0;
+        return (v ^ (v >>> 16)) >>> 0;
+      };
+      for (var q = 0; q < N * N; ++q) {
+        var b = hash((q * 4 + seed) >>> 0);
+        if (inertMod && (b % inertMod) === 0) { st[4 * q] = -1000000; st[4 * q + 1] = -1000000; st[4 * q + 2] = 0; st[4 * q + 3] = 0; continue; }
+        // 24-bit mantissas so that every value is exactly representable in fp32
+        st[4 * q] = ((hash((q * 4 + seed) >>> 0) >>> 8) - 8388608) / 8388608;                 // pos.x in [-1, 1)
+        st[4 * q + 1] = ((hash((q * 4 + 1 + seed) >>> 0) >>> 8) - 8388608) / 8388608;         // pos.y
+        st[4 * q + 2] = ((hash((q * 4 + 2 + seed) >>> 0) >>> 8) - 8388608) / 838860800;       // vel.x in [-.01, .01)
+        st[4 * q + 3] = ((hash((q * 4 + 3 + seed) >>> 0) >>> 8) - 8388608) / 838860800;       // vel.y
+      }
+    } else {
+      st = f32FromB64(job.inputs.state);
+    }
     for (var b = 0; b < t.particles.buffers.length; ++b)
       uploadF32(gl, t.particles.buffers[b].color[0].handle, N, N, st);
     if (job.inputs.flow)

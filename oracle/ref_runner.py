@@ -56,14 +56,18 @@ class RefRunner:
 
     # -- reference Tendrils.step() ------------------------------------------------
     def logic(self, state, flow=None, targets=None, uniforms=None, time0=0.0, steps=1,
-              view=(64, 64), flow_shape=None, view_size=None, return_each=False, rows=None):
+              view=(64, 64), flow_shape=None, view_size=None, return_each=False, rows=None, state_gen=None):
         """state: [N,N,4] f32 indexed [y][x][c]; flow: [H,W,4]; returns list of [N,N,4]."""
-        N = state.shape[0]
-        assert state.shape == (N, N, 4)
+        if state_gen is not None:            # {"N":..., "seed":..., "inertMod":...}: generated inside the page
+            N = int(state_gen["N"])
+            inputs = {"stateGen": {"seed": int(state_gen["seed"]), "inertMod": int(state_gen.get("inertMod", 0))}}
+        else:
+            N = state.shape[0]
+            assert state.shape == (N, N, 4)
+            inputs = {"state": _b64(state, np.float32)}
         job = {"kind": "logic", "N": N, "viewW": int(view[0]), "viewH": int(view[1]),
                "state": uniforms or {}, "time0": float(time0), "steps": int(steps),
-               "returnEach": bool(return_each),
-               "inputs": {"state": _b64(state, np.float32)}}
+               "returnEach": bool(return_each), "inputs": inputs}
         if flow is not None:
             fh, fw = flow.shape[:2]
             if flow_shape is None:

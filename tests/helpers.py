@@ -10,7 +10,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def golden(kind):
-    return sorted(glob.glob(os.path.join(GOLDEN, kind + "_*.npz")))
+    """fixtures of one kind; the row-band fixture of the 4096^2 run has its own tests"""
+    return sorted(p for p in glob.glob(os.path.join(GOLDEN, kind + "_*.npz")) if not p.endswith("_bands.npz"))
 
 
 def load(path):
@@ -114,4 +115,30 @@ def unpack_state(w):
     out[nan, 0] = out[nan, 1] = np.nan
     out[..., 2] = (w[..., 1] & 0xffff).astype(np.uint16).view(np.float16).astype(np.float32)
     out[..., 3] = (w[..., 1] >> 16).astype(np.uint16).view(np.float16).astype(np.float32)
+    return out
+
+
+def hashed_state(n, seed, inert_mod=0, rows=None):
+    """Deterministic integer-hash state (same generator as oracle/harness.js `stateGen`): every value has
+    a 24-bit mantissa, so JS doubles and numpy agree exactly.  rows = (y0, y1) returns only that band."""
+    y0, y1 = rows if rows else (0, n)
+    q = (np.arange(y0 * n, y1 * n, dtype=np.uint64))
+
+    def mix(v):
+        v = v & 0xffffffff
+        v = ((v ^ (v >> 16)) * 0x7feb352d) & 0xffffffff
+        v = ((v ^ (v >> 15)) * 0x846ca68b) & 0xffffffff
+        return (v ^ (v >> 16)) & 0xffffffff
+
+    out = np.empty((y1 - y0, n, 4), np.float32)
+    cols = []
+    for c in range(4):
+        hv = mix(q * 4 + c + seed).astype(np.int64)
+        val = ((hv >> 8) - 8388608).astype(np.float64)
+        cols.append(val / (8388608.0 if c < 2 else 838860800.0))
+    st = np.stack(cols, -1).astype(np.float32).reshape(y1 - y0, n, 4)
+    if inert_mod:
+        b = mix(q * 4 + seed).astype(np.int64)
+        st[(b % inert_mod == 0).reshape(y1 - y0, n)] = [-1e6, -1e6, 0, 0]
+    out[:] = st
     return out

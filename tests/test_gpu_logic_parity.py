@@ -250,3 +250,32 @@ def test_step_n_graph_equals_single_steps(n, steps):
     assert outs[0][2] == outs[1][2]
     assert bits_equal(outs[0][0], outs[1][0]).all()
     assert bits_equal(outs[0][1], outs[1][1]).all()
+
+
+def test_c3_size_matches_reference_row_bands():
+    """4096^2 on the GPU against the row bands captured from the reference's own 4096^2 run."""
+    import os
+    import tendrils_amd as ta
+    from helpers import GOLDEN, hashed_state
+    from tendrils_amd.tendrils import View
+    fx = load(os.path.join(GOLDEN, "logic_4096_bands.npz"))
+    m = fx["meta"]
+    n = m["N"]
+    t = ta.Tendrils(View(*m["viewRes"]))
+    t.resize()
+    t.setup(n)
+    for k, v in state_overrides(m).items():
+        t.state[k] = v
+    t.particles.upload_texels(hashed_state(n, m["seed"], m["inertMod"]))
+    t.flow.set_pixels(fx["flow"])
+    t.timer.time = m["times"][0] - m["dts"][0]
+    t.timer.tick()
+    assert t.timer.time == m["times"][0]
+    t.step()
+    got = t.particles.read(0)
+    t.dispose()
+    row = 0
+    for (a, b) in m["bands"]:
+        ok = bits_equal(got[a:b], fx["out"][row:row + (b - a)]).all(-1)
+        assert (ok | ~fx["valid"][row:row + (b - a)]).all(), "rows %d..%d" % (a, b)
+        row += b - a
