@@ -88,7 +88,7 @@ def synth_flow(time_ms):
 
 
 def measure_traffic(extra_args):
-    """HBM traffic of one logic_kernel launch from rocprofv3 PMC counters, as
+    """HBM traffic of one launch of the dominant integrator kernel from rocprofv3 PMC counters, as
     MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes of the
     same workload (short child runs of this script), FETCH_SIZE doubled (gfx950 tallies the 128-B
     requests of a wide coalesced stream at 64 B), both in KiB.  Runs before this process touches the
@@ -105,18 +105,23 @@ def measure_traffic(extra_args):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="th_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "8", "--warmup", "2", "--no-cpu",
-               "--no-traffic"] + extra_args
+               sys.executable, os.path.abspath(__file__), "--steps", "32", "--warmup", "16", "--no-cpu",
+               "--no-traffic", "--traffic-child"] + extra_args
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=240, check=True)
-            rows = []
+            by_kernel = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "logic_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
-                        rows.append(float(row["Counter_Value"]))
+                    if row.get("Counter_Name") == counter:
+                        for kname in ("logic_fused_kernel", "logic_packed_kernel", "logic_kernel"):
+                            if kname in row.get("Kernel_Name", ""):
+                                by_kernel.setdefault(kname, []).append(float(row["Counter_Value"]))
+                                break
+            rows = next((by_kernel[k] for k in ("logic_fused_kernel", "logic_packed_kernel", "logic_kernel")
+                         if k in by_kernel), [])
             if not rows:
-                return None, "no %s rows for logic_kernel" % counter
+                return None, "no %s rows for the integrator kernel" % counter
             vals[counter] = sum(rows) / len(rows)
         except (subprocess.SubprocessError, OSError) as e:
             return None, "%s pass failed: %s" % (counter, type(e).__name__)
@@ -134,6 +139,7 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure HBM traffic")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # PMC child: fused launches only
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
     ap.add_argument("--state", default="f32", choices=["f32", "f16"], help="state ring storage (f16 = packed 8 B/particle, config C5)")
@@ -257,17 +263,27 @@ def main():
     sync_all()
     wall = time.perf_counter() - t0
 
-    # kernel-only pass for the roofline: the same K steps, HIP events on the context's own stream
+    # kernel-only pass for the roofline: the same K steps in the same launches as the timed region
+    # (th_step_n: 16 steps fused per logic_fused_kernel launch), a HIP event pair around every launch
+    # on the context's own stream
     def run_kernel_only(k_steps):
-        for _ in range(k_steps):
-            t.timer.tick()
-            t.step()
+        done = 0
+        while done < k_steps:
+            n = min(STATS_EVERY, k_steps - done)
+            t.step_n(n)
+            done += n
     ev_ms, k_ms, k_n = C.c_float(), C.c_float(), C.c_int32()
-    _capi.call("th_kernel_timing", ctx, 1)                 # HIP event pair around every logic_kernel launch
+    _capi.call("th_kernel_timing", ctx, 1)
     _capi.call("th_timer_start", ctx)
     run_kernel_only(args.steps)
-    _capi.call("th_timer_stop", ctx, C.byref(ev_ms))       # whole step (flow decode + logic), same stream
+    _capi.call("th_timer_stop", ctx, C.byref(ev_ms))
     _capi.call("th_kernel_timing_read", ctx, C.byref(k_ms), C.byref(k_n))
+    # and the single-step kernel (one Tendrils.step() per launch) for reference
+    s_ms, s_n = C.c_float(), C.c_int32()
+    for _ in range(32):
+        t.timer.tick()
+        t.step()
+    _capi.call("th_kernel_timing_read", ctx, C.byref(s_ms), C.byref(s_n))
     _capi.call("th_kernel_timing", ctx, 0)
     sync_all()
 
@@ -275,19 +291,24 @@ def main():
         w.wait()
     stats = t.particles.stats(t.state["speedLimit"])
     if dist is not None:
-        tmax = torch.tensor([wall, ev_ms.value / 1e3, k_ms.value / 1e3], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([wall, ev_ms.value / 1e3, k_ms.value / 1e3, s_ms.value / 1e3], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, ev_s, kern_s = float(tmax[0]), float(tmax[1]), float(tmax[2])
+        wall, ev_s, kern_s, single_s = (float(v) for v in tmax)
         stats = reduce_counters(dist, stats, device="cuda")
     else:
-        ev_s, kern_s = ev_ms.value / 1e3, k_ms.value / 1e3
+        ev_s, kern_s, single_s = ev_ms.value / 1e3, k_ms.value / 1e3, s_ms.value / 1e3
 
     particles = N * N * world
     bytes_per_step = BYTES_PER_PARTICLE_STEP // (2 if args.state == "f16" else 1)
     value = particles * args.steps / wall
-    # `value` includes the statistics reductions (every 16 steps); the roofline uses the kernel-only pass
-    per_launch_s = kern_s                       # mean logic_kernel duration (event pair per launch)
-    achieved = bytes_per_step * N * N / per_launch_s / 1e9
+    # `value` includes the statistics reductions and the optical-flow refresh (every 16 steps); the roofline
+    # uses the kernel-only pass: mean duration of the launches that did the K steps (k_n launches)
+    launches = max(int(k_n.value), 1)
+    per_launch_s = kern_s                       # mean launch duration (event pair per launch)
+    steps_per_launch = args.steps / launches
+    alg_bytes_per_launch = bytes_per_step * N * N * steps_per_launch
+    achieved = alg_bytes_per_launch / per_launch_s / 1e9
+    kernel_name = "logic_fused_kernel" if steps_per_launch > 1 else "logic_kernel"
 
     line = {
         "metric": "particle-steps/sec (16M particles per GPU)", "value": value, "unit": "particle-steps/s",
@@ -302,9 +323,12 @@ def main():
                    "parallelism": "row-band shard x%d, flow replicated" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                     "kernel": "logic_kernel", "avg_launch_ms": per_launch_s * 1e3,
+                     "kernel": kernel_name, "avg_launch_ms": per_launch_s * 1e3, "launches": launches,
+                     "steps_per_launch": steps_per_launch, "particle_steps_per_launch": N * N * steps_per_launch,
                      "avg_step_ms_on_stream": ev_s / args.steps * 1e3,
-                     "algorithmic_bytes_per_launch": bytes_per_step * N * N},
+                     "single_step_kernel": {"kernel": "logic_kernel", "avg_launch_ms": single_s * 1e3,
+                                            "achieved": bytes_per_step * N * N / single_s / 1e9},
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         "counters": stats,
     }
 

@@ -10,6 +10,7 @@
 //   OpticalFlow buffers  src/optical-flow/index.js:43-70
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -724,10 +725,49 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     StepPlan plan;
     if (th_status s = plan_step(c, v, TH_TARGET_RING, plan)) return s;
 
+    // Temporal fusion (logic_fused_kernel): all n steps of a particle in one pass, <= kMaxFusedSteps per launch.
+    // Needs the plain 2-buffer ring (only the last two states survive n rotations), the specialised kernel and
+    // an f32 ring.  TH_FUSE=0 turns it off (the tests compare both paths).
+    static const bool fuse_on = [] { const char *e = getenv("TH_FUSE"); return !e || atoi(e) != 0; }();
+    if (fuse_on && n >= 2 && c->ring.size() == 2 && !plan.generic && !c->packed) {
+        {   // (the slot layout was brought up to date by plan_step above; the re-sort period is approximate)
+            int32_t done = 0;
+            while (done < n) {
+                const int32_t m = std::min<int32_t>(n - done, (int32_t)th::kMaxFusedSteps);
+                th::LogicParams p = plan.p;
+                float4 *cur = c->ring[0], *other = c->ring[1];
+                p.in = cur;
+                // a lane only ever touches its own texel, so one of the two outputs may overwrite the input;
+                // after m rotations of [cur, other]: m even -> [cur, other], m odd -> [other, cur]
+                p.out = (m & 1) ? other : cur;             // state m     (ends up in buffers[0])
+                p.out_prev = (m & 1) ? cur : other;        // state m - 1 (ends up in buffers[1])
+                p.perm = c->bucketed ? c->perm : nullptr;
+                p.nsteps = (uint32_t)m;
+                for (int32_t k = 0; k < m; ++k) p.times[k] = times[(size_t)(done + k)];
+                hipEvent_t k0 = nullptr, k1 = nullptr;
+                if (c->kernel_timing) {
+                    if (c->kt_used + 2 > c->kt_events.size()) {
+                        hipEvent_t ea = nullptr, eb = nullptr;
+                        TH_HIP(hipEventCreate(&ea)); TH_HIP(hipEventCreate(&eb));
+                        c->kt_events.push_back(ea); c->kt_events.push_back(eb);
+                    }
+                    k0 = c->kt_events[c->kt_used]; k1 = c->kt_events[c->kt_used + 1];
+                    c->kt_used += 2;
+                    TH_HIP(hipEventRecord(k0, c->stream));
+                }
+                th::launch_logic_fused(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, c->stream);
+                if (k1) TH_HIP(hipEventRecord(k1, c->stream));
+                TH_HIP(hipGetLastError());
+                if (m & 1) { c->ring[0] = other; c->ring[1] = cur; }
+                c->steps_since_bucket += m;
+                done += m;
+            }
+            return TH_OK;
+        }
+    }
+
     static const bool graphs_on = [] { const char *e = getenv("TH_GRAPH"); return !e || atoi(e) != 0; }();
-    const bool layout_stable = !c->bucket_evaluated || !bucketing_possible(c) ||
-                               c->steps_since_bucket + n <= rebucket_period();
-    if (!graphs_on || n < 2 || !layout_stable || (c->packed && plan.generic)) {
+    if (!graphs_on || n < 2 || (c->packed && plan.generic)) {
         for (int32_t k = 0; k < n; ++k) {
             if (k) { v.time = times[(size_t)k]; if (th_status s = plan_step(c, v, TH_TARGET_RING, plan)) return s; }
             if (th_status s = enqueue_step(c, plan, TH_TARGET_RING, times[(size_t)k], nullptr, true)) return s;

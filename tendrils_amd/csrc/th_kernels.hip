@@ -105,7 +105,7 @@ void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t s
 // for lanes outside the fast path's proven domain and by the generic kernel.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float4 logic_texel_ref(const LogicParams &p, uint32_t x, uint32_t y_global,
-                                                float4 st, uint32_t local_index)
+                                                float4 st, uint32_t local_index, float time)
 {
     const th_logic_uniforms &u = p.u;
     float fcx = (float)x + 0.5f, fcy = (float)y_global + 0.5f;      // gl_FragCoord.xy
@@ -116,7 +116,7 @@ __device__ __forceinline__ float4 logic_texel_ref(const LogicParams &p, uint32_t
     float i = (fcx + (fcy * p.wf)) / (p.wf * p.hf);                  // :57-58
     float nscale = vary(u.noiseScale, i, u.varyNoiseScale);
     float nx = posx * nscale, ny = posy * nscale;                    // :62
-    float ntime = u.time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);  // :65
+    float ntime = time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);  // :65
     float wx = snoise_ref(nx, ny, uvx + ntime);                      // :67
     float wy = snoise_ref(nx, ny, uvy + ntime + 1234.5678f);         // :68
 
@@ -127,7 +127,7 @@ __device__ __forceinline__ float4 logic_texel_ref(const LogicParams &p, uint32_t
     int tx = (int)__builtin_amdgcn_fmed3f(th_floor(fu * p.fwf), 0.0f, p.fwm1);
     int ty = (int)__builtin_amdgcn_fmed3f(th_floor(fv * p.fhf), 0.0f, p.fhm1);
     float4 ft = p.flow[(size_t)ty * p.fw + tx];
-    float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));   // src/flow/get.glsl:4
+    float k = __builtin_fmaxf(0.0f, 1.0f - ((time - ft.z) * u.flowDecay));   // src/flow/get.glsl:4
     float ffx = (0.0f + ft.x * k * 1.0f) / 1.0f, ffy = (0.0f + ft.y * k * 1.0f) / 1.0f;
 
     float vfw = vary(u.forceWeight, i, u.varyForce);
@@ -222,7 +222,7 @@ TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2,
 // ---------------------------------------------------------------------------
 // One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
-TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid)
+TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time)
 {
     const th_logic_uniforms &u = p.u;
     float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
@@ -235,7 +235,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
 
     // two compares (not max): a NaN in either component must fail the test
     bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
-    if (__builtin_expect(!in_domain, 0)) return logic_texel_ref(p, x, y, st, pid);
+    if (__builtin_expect(!in_domain, 0)) return logic_texel_ref(p, x, y, st, pid, time);
 
     float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
     float uvx, uvy, i;
@@ -264,7 +264,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     if constexpr (NOISE) {
         float nscale = vary(u.noiseScale, i, u.varyNoiseScale);
         float nx = posx * nscale, ny = posy * nscale;
-        float ntime = u.time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
+        float ntime = time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
         float sxy = mad<FAST>(ny, kC3, nx * kC3);
         // both lattice parts first, so that all eight table reads are in flight together
         NoiseCorners na = snoise_corners<FAST>(nx, ny, uvx + ntime, sxy);
@@ -278,7 +278,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     }
 
     if constexpr (!DECODED) {
-        float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - ft.z) * u.flowDecay));
+        float k = __builtin_fmaxf(0.0f, 1.0f - ((time - ft.z) * u.flowDecay));
         ffx = ft.x * k; ffy = ft.y * k;
     }
     float vflw = vary(u.flowWeight, i, u.varyFlow);
@@ -328,10 +328,9 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
 //   window: per-workgroup contiguous chunks ran 1.9x slower (DRAM locality of 2048 separate
 //   streams, profiles/r1_c_*).  The XCD mapping affects speed only, never results.
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool BUCKETED>
-__global__ __launch_bounds__(256) void logic_kernel(const LogicParams p_in)
+__global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 {
-    LogicParams p = p_in;
-    if (p.time_dev) p.u.time = *p.time_dev;        // captured-graph replays keep `time` in device memory
+    const float time = p.time_dev ? *p.time_dev : p.u.time;     // captured-graph replays keep `time` in device memory
     __shared__ float4 lut[NOISE ? kLutSize : 1];
     if constexpr (NOISE) {
         for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
@@ -365,16 +364,15 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p_in)
             nxt = load_stream(&p.in[idx + stride]);
             if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx + stride]);
         }
-        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, pid));
+        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, pid, time));
     }
 }
 
 // Packed-state integrator (TH_STATE_F16): same per-particle arithmetic on the decoded texel, 8 B in / 8 B out.
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
-__global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p_in)
+__global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p)
 {
-    LogicParams p = p_in;
-    if (p.time_dev) p.u.time = *p.time_dev;
+    const float time = p.time_dev ? *p.time_dev : p.u.time;
     __shared__ float4 lut[NOISE ? kLutSize : 1];
     if constexpr (NOISE) {
         for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
@@ -389,7 +387,7 @@ __global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p_i
     for (; idx < p.count; idx += stride) {
         v2u w = nxt;
         if (idx + stride < p.count) nxt = __builtin_nontemporal_load(&in[idx + stride]);
-        float4 r = integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, unpack_state(make_uint2(w.x, w.y)), idx);
+        float4 r = integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, unpack_state(make_uint2(w.x, w.y)), idx, time);
         uint2 q = pack_state(r);
         v2u qq = {q.x, q.y};
         __builtin_nontemporal_store(qq, &out[idx]);
@@ -398,15 +396,14 @@ __global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p_i
 
 // Generic kernel: reference-order evaluation of every texel (used when the host
 // cannot establish the fast path's preconditions, e.g. non-finite uniforms).
-__global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p_in)
+__global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p)
 {
-    LogicParams p = p_in;
-    if (p.time_dev) p.u.time = *p.time_dev;
+    const float time = p.time_dev ? *p.time_dev : p.u.time;
     const uint32_t stride = gridDim.x * 256u;
     for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += stride) {
         float4 st = p.in[idx];
         uint32_t y = idx / p.width, x = idx - y * p.width;
-        p.out[idx] = logic_texel_ref(p, x, y + p.row0, st, idx);
+        p.out[idx] = logic_texel_ref(p, x, y + p.row0, st, idx, time);
     }
 }
 
@@ -447,6 +444,84 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
         if (packed) launch_packed_p2<F, N, T>(p, pow2, decoded, s);      \
         else launch_logic_p2<F, N, T>(p, pow2, decoded, bucketed, s);    \
     } while (0)
+    if (fast) {
+        if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
+        else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }
+    } else {
+        if (noise) { if (target) TH_DISPATCH(false, true, true); else TH_DISPATCH(false, true, false); }
+        else { if (target) TH_DISPATCH(false, false, true); else TH_DISPATCH(false, false, false); }
+    }
+#undef TH_DISPATCH
+}
+
+// ---------------------------------------------------------------------------
+// Temporal fusion for th_step_n: `nsteps` consecutive steps of one particle in ONE pass.  Particles
+// are independent and flow / targets do not change inside a th_step_n call, so the intermediate
+// states need not travel through HBM: the pass reads state 0 once and writes only the two states a
+// 2-buffer ring keeps (state nsteps -> out, state nsteps-1 -> out_prev; each lane touches only its
+// own texel, so out_prev may alias the input).  Streamed bytes per particle-step drop from 32 to
+// 48/nsteps; every step still performs its own flow tap and the full arithmetic, in the same
+// operation order - results are bit-identical to nsteps separate launches.
+// The flow tap reads the RGBA32F texel and decodes per particle (one decoded plane per step time
+// would multiply the gather footprint by nsteps).
+// ---------------------------------------------------------------------------
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
+__global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
+{
+    __shared__ float4 lut[NOISE ? kLutSize : 1];
+    if constexpr (NOISE) {
+        for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
+        __syncthreads();
+    }
+    uint32_t idx, stride, end;
+    if constexpr (!BUCKETED) {
+        idx = blockIdx.x * 256u + threadIdx.x;
+        stride = gridDim.x * 256u;
+        end = p.count;
+    } else {
+        const uint32_t group = blockIdx.x & 7u, rank = blockIdx.x >> 3, per = (p.count + 7u) >> 3;
+        const uint32_t lo = group * per;
+        idx = lo + rank * 256u + threadIdx.x;
+        stride = (gridDim.x >> 3) * 256u;
+        end = lo + per < p.count ? lo + per : p.count;
+    }
+    float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t npid = idx;
+    if (idx < end) {
+        nxt = load_stream(&p.in[idx]);
+        if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx]);
+    }
+    for (; idx < end; idx += stride) {
+        float4 st = nxt, prev = nxt;
+        uint32_t pid = BUCKETED ? npid : idx;
+        if (idx + stride < end) {
+            nxt = load_stream(&p.in[idx + stride]);
+            if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx + stride]);
+        }
+        for (uint32_t k = 0; k < p.nsteps; ++k) {
+            prev = st;
+            st = integrate<FAST, NOISE, TARGET, POW2, false>(p, lut, st, pid, p.times[k]);
+        }
+        store_stream(&p.out_prev[idx], prev);
+        store_stream(&p.out[idx], st);
+    }
+}
+
+template <bool FAST, bool NOISE, bool TARGET>
+static void launch_fused_p2(const LogicParams &p, bool pow2, hipStream_t s)
+{
+    const bool bucketed = p.perm != nullptr;
+    const int grid = bucketed ? 2048 : grid_for(p.count, 8);
+#define TH_GO(P2, BK) hipLaunchKernelGGL((logic_fused_kernel<FAST, NOISE, TARGET, P2, BK>), dim3(grid), dim3(256), 0, s, p)
+    if (pow2) { if (bucketed) TH_GO(true, true); else TH_GO(true, false); }
+    else { if (bucketed) TH_GO(false, true); else TH_GO(false, false); }
+#undef TH_GO
+}
+
+void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, hipStream_t s)
+{
+    const bool fast = mode == TH_MODE_FAST;
+#define TH_DISPATCH(F, N, T) launch_fused_p2<F, N, T>(p, pow2, s)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }

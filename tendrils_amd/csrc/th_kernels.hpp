@@ -9,6 +9,8 @@
 
 namespace th {
 
+constexpr uint32_t kMaxFusedSteps = 32;
+
 // Kernel argument block of the integrator.  Passed by value: it lands in the
 // kernarg segment and every field is wave-uniform (SGPRs).
 struct LogicParams {
@@ -31,6 +33,10 @@ struct LogicParams {
     float pos_bound;         // |pos| below this keeps the noise coordinates inside kNoiseDomain
     const uint32_t *perm;    // bucketed launches: slot -> particle id (nullptr = identity, texel order)
     const float *time_dev;   // graph replays: `time` is read from here instead of u.time (nullptr = u.time)
+    // fused multi-step launches (logic_fused_kernel): nsteps consecutive steps per particle in one pass
+    float4 *out_prev;        // receives state nsteps-1 (p.out receives state nsteps); may alias p.in
+    uint32_t nsteps;
+    float times[kMaxFusedSteps];   // `time` of each fused step
 };
 
 // Counting sort of particle slots by flow region (th_kernels.hip "Bucketing").
@@ -79,6 +85,7 @@ struct StatsPartial {
 // launchers (defined in th_kernels.hip)
 void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
                   bool generic, bool packed, hipStream_t stream);
+void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, hipStream_t stream);
 void launch_pack_state(void *dst, const float4 *src, uint32_t n, hipStream_t stream);      // f32 texels -> TH_STATE_F16
 void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t stream);
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
