@@ -31,7 +31,7 @@ N = 4096                        # particles per rank = N*N
 FLOW_W, FLOW_H = 1920, 1080
 BYTES_PER_PARTICLE_STEP = 32    # 16 B state read + 16 B written; 8 + 8 with --state f16
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
-STATS_EVERY = 16
+STATS_EVERY = 32        # steps per fused launch and per statistics reduction (= th::kMaxFusedSteps)
 
 
 def synth_state(rank):
@@ -105,7 +105,7 @@ def measure_traffic(extra_args):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="th_pmc_", dir="/tmp")
         cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "32", "--warmup", "16", "--no-cpu",
+               sys.executable, os.path.abspath(__file__), "--steps", "64", "--warmup", "32", "--no-cpu",
                "--no-traffic", "--traffic-child"] + extra_args
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
@@ -134,8 +134,8 @@ def measure_traffic(extra_args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure HBM traffic")

@@ -168,12 +168,29 @@ TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy)
     float t = mad<FAST>(iz, kC6, mad<FAST>(iy, kC6, ix * kC6));
     float ax = (vx - ix) + t, ay = (vy - iy) + t, az = (vz - iz) + t;
 
-    // simplex traversal order: g = step(x0.yzx, x0.xyz), i1 = min(g, 1-g.zxy), i2 = max(g, 1-g.zxy)
-    bool ga = !(ax < ay), gb = !(ay < az), gc = !(az < ax);
-    bool b1x = ga && !gc, b1y = gb && !ga, b1z = gc && !gb;
-    bool b2x = ga || !gc, b2y = gb || !ga, b2z = gc || !gb;
-    float i1x = b1x ? 1.0f : 0.0f, i1y = b1y ? 1.0f : 0.0f, i1z = b1z ? 1.0f : 0.0f;
-    float i2x = b2x ? 1.0f : 0.0f, i2y = b2y ? 1.0f : 0.0f, i2z = b2z ? 1.0f : 0.0f;
+    // simplex traversal order: g = step(x0.yzx, x0.xyz) (g.x = !(x0.x < x0.y) ...), i1 = min(g, 1-g.zxy),
+    // i2 = max(g, 1-g.zxy).  Written on the three "less-than" masks only (values are finite here):
+    // i1 = (g.x & !g.z, ...) = (l3 & !l1, l1 & !l2, l2 & !l3), i2 = (g.x | !g.z, ...) = (l3 | !l1, ...)
+    // Three compares, the six masks by scalar-unit algebra (s_andn2 / s_orn2), selects from the masks.
+    // (hipcc would issue a second vector compare for every negated mask.)
+    float i1x, i1y, i1z, i2x, i2y, i2z;
+    unsigned long long mz1, mz2;           // b1z, b2z: select pz1 / pz0 below
+    {
+        unsigned long long l1, l2, l3, t;
+        asm("v_cmp_lt_f32 %[l1], %[ax], %[ay]\n\t"
+            "v_cmp_lt_f32 %[l2], %[ay], %[az]\n\t"
+            "v_cmp_lt_f32 %[l3], %[az], %[ax]\n\t"
+            "s_andn2_b64 %[t], %[l3], %[l1]\n\t"     "v_cndmask_b32 %[i1x], 0, 1.0, %[t]\n\t"
+            "s_andn2_b64 %[t], %[l1], %[l2]\n\t"     "v_cndmask_b32 %[i1y], 0, 1.0, %[t]\n\t"
+            "s_andn2_b64 %[mz1], %[l2], %[l3]\n\t"   "v_cndmask_b32 %[i1z], 0, 1.0, %[mz1]\n\t"
+            "s_orn2_b64 %[t], %[l3], %[l1]\n\t"      "v_cndmask_b32 %[i2x], 0, 1.0, %[t]\n\t"
+            "s_orn2_b64 %[t], %[l1], %[l2]\n\t"      "v_cndmask_b32 %[i2y], 0, 1.0, %[t]\n\t"
+            "s_orn2_b64 %[mz2], %[l2], %[l3]\n\t"    "v_cndmask_b32 %[i2z], 0, 1.0, %[mz2]"
+            : [l1] "=&s"(l1), [l2] "=&s"(l2), [l3] "=&s"(l3), [t] "=&s"(t), [mz1] "=&s"(mz1), [mz2] "=&s"(mz2),
+              [i1x] "=&v"(i1x), [i1y] "=&v"(i1y), [i1z] "=&v"(i1z), [i2x] "=&v"(i2x), [i2y] "=&v"(i2y), [i2z] "=&v"(i2z)
+            : [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az)
+            : "scc");
+    }
 
     n.ax = ax; n.ay = ay; n.az = az;
     n.bx = (ax - i1x) + kC6; n.by = (ay - i1y) + kC6; n.bz = (az - i1z) + kC6;
@@ -184,14 +201,31 @@ TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy)
     ix = mod289_int(ix); iy = mod289_int(iy); iz = mod289_int(iz);
     float pz0 = permute_int(iz), pz1 = permute_int(iz + 1.0f);       // z offsets are only ever 0 or 1
     float q0 = permute_int(pz0 + iy);
-    float q1 = permute_int(((b1z ? pz1 : pz0) + iy) + i1y);
-    float q2 = permute_int(((b2z ? pz1 : pz0) + iy) + i2y);
+    float sel1, sel2;
+    asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
+        : "=&v"(sel1), "=&v"(sel2) : "v"(pz0), "v"(pz1), "s"(mz1), "s"(mz2));
+    float q1 = permute_int((sel1 + iy) + i1y);
+    float q2 = permute_int((sel2 + iy) + i2y);
     float q3 = permute_int((pz1 + iy) + 1.0f);
-    n.j0 = (int)(q0 + ix) - kLutMin;
-    n.j1 = (int)((q1 + ix) + i1x) - kLutMin;
-    n.j2 = (int)((q2 + ix) + i2x) - kLutMin;
-    n.j3 = (int)((q3 + ix) + 1.0f) - kLutMin;
+    // Table index without a float->int conversion: the last-stage argument is a small integer, so
+    // adding 2^23 (+ the table bias) leaves it in the low mantissa bits of the sum; every addition
+    // stays exact (all values are integers below 2^24).  lut_index() turns the bits into an LDS offset.
+    const float ixm = ix + (8388608.0f - (float)kLutMin);
+    n.j0 = __float_as_int(q0 + ixm);
+    n.j1 = __float_as_int((q1 + ixm) + i1x);
+    n.j2 = __float_as_int((q2 + ixm) + i2x);
+    n.j3 = __float_as_int((q3 + ixm) + 1.0f);
     return n;
+}
+
+// table entry of a magic-number index produced by snoise_corners: low 24 bits = entry number
+TH_D float4 lut_at(const float4 *lut, int magic)
+{
+    // v_mul_u32_u24 multiplies the LOW 24 BITS of its operands: one full-rate op strips the exponent
+    // and scales to the byte offset (written as asm so that the masking is not optimised away)
+    unsigned off;
+    asm("v_mul_u32_u24 %0, %1, 16" : "=v"(off) : "v"(magic));
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lut) + off);
 }
 
 // Radial falloff and gradient dot products, given the four table entries.
@@ -269,8 +303,8 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
         // both lattice parts first, so that all eight table reads are in flight together
         NoiseCorners na = snoise_corners<FAST>(nx, ny, uvx + ntime, sxy);
         NoiseCorners nb = snoise_corners<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy);
-        float4 a0 = lut[na.j0], a1 = lut[na.j1], a2 = lut[na.j2], a3 = lut[na.j3];
-        float4 b0 = lut[nb.j0], b1 = lut[nb.j1], b2 = lut[nb.j2], b3 = lut[nb.j3];
+        float4 a0 = lut_at(lut, na.j0), a1 = lut_at(lut, na.j1), a2 = lut_at(lut, na.j2), a3 = lut_at(lut, na.j3);
+        float4 b0 = lut_at(lut, nb.j0), b1 = lut_at(lut, nb.j1), b2 = lut_at(lut, nb.j2), b3 = lut_at(lut, nb.j3);
         float wx = snoise_finish<FAST>(na, a0, a1, a2, a3);
         float wy = snoise_finish<FAST>(nb, b0, b1, b2, b3);
         float vnw = vary(u.noiseWeight, i, u.varyNoise);
