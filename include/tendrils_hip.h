@@ -171,8 +171,10 @@ th_status th_targets_clear(th_context *ctx);
  * buffers[1] without rotating (src/particles.js:124-126). */
 th_status th_step(th_context *ctx, const th_logic_uniforms *u, int32_t target);
 /* n consecutive Tendrils.step() calls with a fixed-step timer
- * (time_k = time0 + (k+1)*dt_ms in double, as src/timer.js:28-31 accumulates),
- * replayed from a captured hipGraph. u->time is ignored, u->dt = (float)dt_ms. */
+ * (time_k = time0 + (k+1)*dt_ms in double, as src/timer.js:28-31 accumulates).
+ * Result and ring order are identical to n th_step calls; internally the steps of a
+ * particle are fused into one pass per <= 32 steps (2-buffer f32 ring), else replayed
+ * from a captured hipGraph.  u->time is ignored, u->dt = (float)dt_ms. */
 th_status th_step_n(th_context *ctx, const th_logic_uniforms *u, double time0, double dt_ms, int32_t n);
 
 /* -- respawn passes: Tendrils.spawnShader (src/index.js:432-457) ------------ */
