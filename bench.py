@@ -134,8 +134,8 @@ def measure_traffic(extra_args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that measure HBM traffic")
@@ -264,7 +264,7 @@ def main():
     wall = time.perf_counter() - t0
 
     # kernel-only pass for the roofline: the same K steps in the same launches as the timed region
-    # (th_step_n: 16 steps fused per logic_fused_kernel launch), a HIP event pair around every launch
+    # (th_step_n: STATS_EVERY steps fused per logic_fused_kernel launch), a HIP event pair around every launch
     # on the context's own stream
     def run_kernel_only(k_steps):
         done = 0
@@ -301,7 +301,7 @@ def main():
     particles = N * N * world
     bytes_per_step = BYTES_PER_PARTICLE_STEP // (2 if args.state == "f16" else 1)
     value = particles * args.steps / wall
-    # `value` includes the statistics reductions and the optical-flow refresh (every 16 steps); the roofline
+    # `value` includes the statistics reductions and the optical-flow refresh (every STATS_EVERY steps); the roofline
     # uses the kernel-only pass: mean duration of the launches that did the K steps (k_n launches)
     launches = max(int(k_n.value), 1)
     per_launch_s = kern_s                       # mean launch duration (event pair per launch)

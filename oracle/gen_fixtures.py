@@ -186,6 +186,65 @@ def gen_logic_4096(r, only):
     save(name, flow=fl, out=np.concatenate(outs[0]), valid=np.concatenate(valids), uniforms=json.dumps(meta))
 
 
+def band_valid(n, seed, inert_mod, bands):
+    """QUAD NOTE validity of the rows in `bands`, from the regenerated hashed input."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from helpers import hashed_state
+    valids = []
+    for (a, b) in bands:
+        st = hashed_state(n, seed, inert_mod, rows=(a - a % 2, b + b % 2))
+        inert = (st[..., 0] == INERT) & (st[..., 1] == INERT)
+        v = np.ones(inert.shape, bool)
+        for yy in range(0, inert.shape[0] - 1, 2):
+            if inert[yy, 0]:
+                for (dy, dx) in ((0, 1), (1, 0), (1, 1)):
+                    if not inert[yy + dy, dx]:
+                        v[yy + dy, dx] = False
+        valids.append(v[a % 2: a % 2 + (b - a)])
+    return np.concatenate(valids)
+
+
+def gen_logic_config_bands(r, only):
+    """BASELINE.json configs C2 and C4 as reference captures (row bands, hashed state generated in the page).
+    C2: 1024^2, "curl-noise" flow 1024x1024 (tests/helpers.py:curl_flow - regenerated by the tests, not stored),
+        K = 4 steps with every step's bands kept.
+    C4: 8192^2 (= MAX_TEXTURE_SIZE of the reference's GL here), bands around the 8-way shard boundaries."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+    from helpers import curl_flow
+    name = "logic_c2_1024_bands"
+    if not only or only in name:
+        n, seed, inert_mod, steps = 1024, 31337, 41, 4
+        time0 = 5000.0
+        fw = fh = 1024
+        flow_gen = dict(kind="curl", w=fw, h=fh, seed=77, time=time0 + 1000.0 / 60.0)
+        fl = curl_flow(fw, fh, flow_gen["seed"], flow_gen["time"])
+        bands = [(0, 4), (510, 514), (1020, 1024)]
+        outs, res = r.logic(None, flow=fl, time0=time0, steps=steps, view=(fw, fh), flow_shape=(fw, fh), rows=bands,
+                            state_gen=dict(N=n, seed=seed, inertMod=inert_mod), return_each=True)
+        meta = dict(kind="logic_bands", N=n, seed=seed, inertMod=inert_mod, bands=bands, steps=steps, flowGen=flow_gen,
+                    times=res["times"], dts=res["dts"], viewSize=res["viewSize"], viewRes=res["viewRes"],
+                    flowShape=res["flowShape"],
+                    state={k: v for k, v in res["state"].items() if isinstance(v, (int, float))}, ref_ms=res["ms"])
+        save(name, out=np.stack([np.concatenate(o) for o in outs]), valid=band_valid(n, seed, inert_mod, bands),
+             uniforms=json.dumps(meta))
+    name = "logic_c4_8192_bands"
+    if not only or only in name:
+        n, seed, inert_mod = 8192, 8192017, 29
+        rng = np.random.default_rng(seed)
+        fw, fh = 240, 135
+        time0 = 120000.0
+        fl = rand_flow(rng, fw, fh, time0 + 1000.0 / 60.0, 0.01)
+        bands = [(0, 1), (1023, 1025), (2047, 2049), (4095, 4097), (6143, 6145), (7167, 7169), (8191, 8192)]
+        outs, res = r.logic(None, flow=fl, time0=time0, steps=1, view=(fw, fh), flow_shape=(fw, fh), rows=bands,
+                            state_gen=dict(N=n, seed=seed, inertMod=inert_mod))
+        meta = dict(kind="logic_bands", N=n, seed=seed, inertMod=inert_mod, bands=bands, steps=1,
+                    times=res["times"], dts=res["dts"], viewSize=res["viewSize"], viewRes=res["viewRes"],
+                    flowShape=res["flowShape"],
+                    state={k: v for k, v in res["state"].items() if isinstance(v, (int, float))}, ref_ms=res["ms"])
+        save(name, flow=fl, out=np.stack([np.concatenate(outs[0])]), valid=band_valid(n, seed, inert_mod, bands),
+             uniforms=json.dumps(meta))
+
+
 def gen_optical_flow(r, only):
     """One blended pass of the reference's optical-flow shader (docs/js/demo.js:73) per case.
     Frames are regenerated from seeds by tests/helpers.py:synth_frame; only parameters and the
@@ -265,6 +324,7 @@ def main():
     print("oracle:", r.probe())
     gen_logic(r, args.only)
     gen_logic_4096(r, args.only)
+    gen_logic_config_bands(r, args.only)
     gen_optical_flow(r, args.only)
     gen_spawn(r, args.only)
 

@@ -142,3 +142,53 @@ def hashed_state(n, seed, inert_mod=0, rows=None):
         st[(b % inert_mod == 0).reshape(y1 - y0, n)] = [-1e6, -1e6, 0, 0]
     out[:] = st
     return out
+
+
+def _mix32(v):
+    v = v & 0xffffffff
+    v = ((v ^ (v >> 16)) * 0x7feb352d) & 0xffffffff
+    v = ((v ^ (v >> 15)) * 0x846ca68b) & 0xffffffff
+    return (v ^ (v >> 16)) & 0xffffffff
+
+
+def curl_flow(w, h, seed, time, cells=12, mag=0.01, max_age=150.0):
+    """Config C2's "curl-noise flow field" (the reference has none: SURVEY.md 8d defines it): a divergence-free
+    field F = (dpsi/dy, -dpsi/dx) of a smooth seeded potential, written in the reference's flow format
+    (Fx, Fy, deposit time, alpha).  psi = smoothstep-interpolated integer-hash lattice, evaluated on the texel
+    corner grid in float64 with + - * only, so every machine regenerates the same bits; the discrete curl
+    (differences of corner values) is exactly divergence-free."""
+    lat = (_mix32(np.arange((cells + 2) * (cells + 2), dtype=np.uint64) + np.uint64(seed)) >> 8).astype(np.float64)
+    lat = (lat / 8388608.0 - 1.0).reshape(cells + 2, cells + 2)
+
+    def axis(n):
+        g = np.arange(n + 1, dtype=np.float64) * cells / n         # corner k at k*cells/n, in [0, cells]
+        c = np.minimum(np.floor(g), cells - 1)
+        f = g - c
+        return c.astype(np.int64), f * f * (3.0 - 2.0 * f)
+
+    cx, sx = axis(w)
+    cy, sy = axis(h)
+    a = lat[cy][:, cx]; b = lat[cy][:, cx + 1]; c = lat[cy + 1][:, cx]; d = lat[cy + 1][:, cx + 1]
+    top = a + (b - a) * sx[None, :]
+    bot = c + (d - c) * sx[None, :]
+    psi = top + (bot - top) * sy[:, None]                           # (h+1, w+1) corner values
+    scale = mag * min(w, h) / (2.0 * cells)
+    fx = (psi[1:, :-1] + psi[1:, 1:] - psi[:-1, :-1] - psi[:-1, 1:]) * (0.5 * scale)     # dpsi/dy at the texel centre
+    fy = (psi[:-1, :-1] + psi[1:, :-1] - psi[:-1, 1:] - psi[1:, 1:]) * (0.5 * scale)     # -dpsi/dx
+    age = (_mix32(np.arange(w * h, dtype=np.uint64) + np.uint64(seed * 7 + 1)) >> 8).astype(np.float64)
+    age = (age / 16777216.0 * max_age).reshape(h, w)
+    fl = np.empty((h, w, 4), np.float32)
+    fl[..., 0] = fx
+    fl[..., 1] = fy
+    fl[..., 2] = (np.float64(time) - age)
+    fl[..., 3] = 1.0
+    return fl
+
+
+def band_fixture_flow(fx):
+    """Flow field of a *_bands fixture: stored, or regenerated from meta["flowGen"]."""
+    g = fx["meta"].get("flowGen")
+    if g is None:
+        return fx["flow"]
+    assert g["kind"] == "curl"
+    return curl_flow(g["w"], g["h"], g["seed"], g["time"])

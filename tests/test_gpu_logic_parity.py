@@ -279,3 +279,91 @@ def test_c3_size_matches_reference_row_bands():
         ok = bits_equal(got[a:b], fx["out"][row:row + (b - a)]).all(-1)
         assert (ok | ~fx["valid"][row:row + (b - a)]).all(), "rows %d..%d" % (a, b)
         row += b - a
+
+
+def test_c2_curl_flow_trajectory_matches_reference_row_bands():
+    """Config C2: 1024^2 particles, curl-noise flow 1024x1024, K = 4 steps - against the bands captured from the
+    reference's own run, step by step (single th_step calls) and again through the fused th_step_n."""
+    import os
+    import tendrils_amd as ta
+    from helpers import GOLDEN, band_fixture_flow, hashed_state
+    from tendrils_amd.tendrils import View
+    fx = load(os.path.join(GOLDEN, "logic_c2_1024_bands.npz"))
+    m = fx["meta"]
+    n, steps = m["N"], m["steps"]
+    flow = band_fixture_flow(fx)
+    st = hashed_state(n, m["seed"], m["inertMod"])
+
+    def check(got, k):
+        row = 0
+        for (a, b) in m["bands"]:
+            ok = bits_equal(got[a:b], fx["out"][k][row:row + (b - a)]).all(-1)
+            assert (ok | ~fx["valid"][row:row + (b - a)]).all(), "step %d rows %d..%d" % (k, a, b)
+            row += b - a
+
+    for fused in (False, True):
+        t = ta.Tendrils(View(*m["viewRes"]))
+        t.resize()
+        t.setup(n)
+        for k, v in state_overrides(m).items():
+            t.state[k] = v
+        t.particles.upload_texels(st)
+        t.flow.set_pixels(flow)
+        t.timer.time = m["times"][0] - m["dts"][0]
+        if fused:
+            t.step_n(steps)
+            assert t.timer.time == m["times"][-1]
+            check(t.particles.read(0), steps - 1)
+            check(t.particles.read(1), steps - 2)
+        else:
+            for k in range(steps):
+                t.timer.tick()
+                assert t.timer.time == m["times"][k]
+                t.step()
+                check(t.particles.read(0), k)
+        t.dispose()
+
+
+def test_c4_sharded_8192_matches_reference_row_bands():
+    """Config C4: 8192^2 particles as 8 row-band shards (one context per shard, run one after the other on this
+    GPU) - every shard reproduces the rows the reference's own unsharded 8192^2 run produced around its edges."""
+    import os
+    import tendrils_amd as ta
+    from helpers import GOLDEN, hashed_state
+    from tendrils_amd.sharding import shard_rows
+    from tendrils_amd.tendrils import View
+    path = os.path.join(GOLDEN, "logic_c4_8192_bands.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    fx = load(path)
+    m = fx["meta"]
+    n, world = m["N"], 8
+    offs, row = {}, 0
+    for (a, b) in m["bands"]:
+        offs[(a, b)] = row
+        row += b - a
+    checked = 0
+    for rank in range(world):
+        row0, rows = shard_rows(n, world, rank)
+        opts = ta.defaults()
+        opts.update(row0=row0, rows=rows, globalHeight=n)
+        t = ta.Tendrils(View(*m["viewRes"]), opts)
+        t.resize()
+        t.setup(n)
+        for k, v in state_overrides(m).items():
+            t.state[k] = v
+        t.particles.upload_texels(hashed_state(n, m["seed"], m["inertMod"], rows=(row0, row0 + rows)))
+        t.flow.set_pixels(fx["flow"])
+        t.timer.time = m["times"][0] - m["dts"][0]
+        t.timer.tick()
+        t.step()
+        got = t.particles.read(0)
+        t.dispose()
+        for (a, b), o in offs.items():
+            lo, hi = max(a, row0), min(b, row0 + rows)
+            if lo >= hi:
+                continue
+            ok = bits_equal(got[lo - row0:hi - row0], fx["out"][0][o + lo - a:o + hi - a]).all(-1)
+            assert (ok | ~fx["valid"][o + lo - a:o + hi - a]).all(), "rank %d rows %d..%d" % (rank, lo, hi)
+            checked += hi - lo
+    assert checked == row

@@ -90,3 +90,34 @@ def test_packed_graph_replay_and_spawners(oracle):
         assert bits_equal(ball, unpack_state(pack_state(oracle.spawn_ball(n, n, radius=0.5, speed=0.004)))).all()
         t.dispose()
     assert bits_equal(outs[0], outs[1]).all()
+
+
+@pytest.mark.parametrize("row0", [0, 8188, 16376])
+def test_c5_16384_wide_band_equals_oracle(oracle, row0):
+    """Config C5 geometry: a row band of the 16384^2 packed-state texture (index i = (fx + fy*W)/(W*H) with
+    W*H = 2^28, well past fp32's exact integers).  The reference's GL stops at 8192^2, so the pin here is the
+    restatement (itself pinned to the reference up to 8192^2) evaluated with the global coordinates."""
+    import tendrils_amd as ta
+    from helpers import hashed_state
+    from tendrils_amd.tendrils import View
+    n, rows = 16384, 8
+    st = unpack_state(pack_state(hashed_state(n, 555, 31, rows=(row0, row0 + rows))))
+    fl = seeded_case(64, 5)[1]
+    fl[..., 2] += 86000.0                                   # deposit times around the run's clock: live flow
+    opts = ta.defaults()
+    opts.update(stateFormat=ta.TH_STATE_F16, row0=row0, rows=rows, globalHeight=n)
+    t = ta.Tendrils(View(96, 54), opts)
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.timer.time = 90000.0
+    cur = st
+    for _ in range(3):
+        t.timer.tick()
+        t.step()
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        cur = unpack_state(pack_state(oracle.logic_step(u, cur, fl, y0=row0)))
+        assert bits_equal(t.particles.read(0), cur).all()
+    t.dispose()
