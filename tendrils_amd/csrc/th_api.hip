@@ -500,7 +500,7 @@ th_status th_download_state(th_context *c, int32_t buffer, float *rgba, int32_t 
 th_status th_flow_resize(th_context *c, int32_t w, int32_t h)
 {
     if (th_status s = use(c)) return s;
-    TH_REQUIRE(w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad flow shape %dx%d", w, h);
+    TH_REQUIRE(w > 0 && h > 0 && w < (1 << 24) && h < (1 << 24) && (uint64_t)w * h < (1ull << 28), "bad flow shape %dx%d", w, h);
     if (w == c->fw && h == c->fh) return TH_OK;              // gl-fbo: same shape is a no-op
     TH_HIP(hipStreamSynchronize(c->stream));
     clear_graphs(c);
