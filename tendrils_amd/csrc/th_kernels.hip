@@ -158,8 +158,26 @@ struct NoiseCorners {
     int j0, j1, j2, j3;
 };
 
-template <bool FAST>
-TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy)
+// perm table reads by magic-number index (see lut_at): entry k holds permute_int(k + kLutMin)
+TH_D float perm_at(const float *perm, int magic)
+{
+    unsigned off;
+    asm("v_mul_u32_u24 %0, %1, 4" : "=v"(off) : "v"(magic));
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(perm) + off);
+}
+TH_D float2 perm_pair_at(const float *perm, int magic)      // entries k and k + 1
+{
+    unsigned off;
+    asm("v_mul_u32_u24 %0, %1, 4" : "=v"(off) : "v"(magic));
+    const float *e = reinterpret_cast<const float *>(reinterpret_cast<const char *>(perm) + off);
+    return make_float2(e[0], e[1]);
+}
+
+// PTAB: the permutation polynomial of the first two hash stages is read from an LDS table of its own values
+// (perm[k] = permute_int(k + kLutMin), filled by the kernel with permute_int itself) instead of being evaluated:
+// 5 VALU per permute become one offset multiply + one LDS read.  Used where the launch is issue-bound.
+template <bool FAST, bool PTAB = false>
+TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy, const float *perm = nullptr)
 {
     NoiseCorners n;
     // first corner
@@ -199,14 +217,30 @@ TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy)
 
     // permutation hash: exact small-integer arithmetic (th_math.hpp)
     ix = mod289_int(ix); iy = mod289_int(iy); iz = mod289_int(iz);
-    float pz0 = permute_int(iz), pz1 = permute_int(iz + 1.0f);       // z offsets are only ever 0 or 1
-    float q0 = permute_int(pz0 + iy);
-    float sel1, sel2;
-    asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
-        : "=&v"(sel1), "=&v"(sel2) : "v"(pz0), "v"(pz1), "s"(mz1), "s"(mz2));
-    float q1 = permute_int((sel1 + iy) + i1y);
-    float q2 = permute_int((sel2 + iy) + i2y);
-    float q3 = permute_int((pz1 + iy) + 1.0f);
+    float q0, q1, q2, q3;
+    if constexpr (PTAB) {
+        // table index = value - kLutMin, carried in the low mantissa bits of value + 2^23 - kLutMin (exact: all
+        // integers below 2^24); the bias rides on iz / iy, so it costs one addition per stage
+        constexpr float kBias = 8388608.0f - (float)kLutMin;
+        const float2 pz = perm_pair_at(perm, __float_as_int(iz + kBias));   // permute(iz), permute(iz + 1)
+        const float iyb = iy + kBias;
+        float sel1, sel2;
+        asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
+            : "=&v"(sel1), "=&v"(sel2) : "v"(pz.x), "v"(pz.y), "s"(mz1), "s"(mz2));
+        q0 = perm_at(perm, __float_as_int(pz.x + iyb));
+        q1 = perm_at(perm, __float_as_int((sel1 + iyb) + i1y));
+        q2 = perm_at(perm, __float_as_int((sel2 + iyb) + i2y));
+        q3 = perm_at(perm, __float_as_int((pz.y + iyb) + 1.0f));
+    } else {
+        float pz0 = permute_int(iz), pz1 = permute_int(iz + 1.0f);       // z offsets are only ever 0 or 1
+        q0 = permute_int(pz0 + iy);
+        float sel1, sel2;
+        asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
+            : "=&v"(sel1), "=&v"(sel2) : "v"(pz0), "v"(pz1), "s"(mz1), "s"(mz2));
+        q1 = permute_int((sel1 + iy) + i1y);
+        q2 = permute_int((sel2 + iy) + i2y);
+        q3 = permute_int((pz1 + iy) + 1.0f);
+    }
     // Table index without a float->int conversion: the last-stage argument is a small integer, so
     // adding 2^23 (+ the table bias) leaves it in the low mantissa bits of the sum; every addition
     // stays exact (all values are integers below 2^24).  lut_index() turns the bits into an LDS offset.
@@ -255,8 +289,9 @@ TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2,
 //   DECODED the flow tap reads the per-step decoded float2 plane (8 B) instead of RGBA32F (16 B)
 // ---------------------------------------------------------------------------
 // One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
-TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time)
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false>
+TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
+                      const float *perm = nullptr)
 {
     const th_logic_uniforms &u = p.u;
     float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
@@ -301,8 +336,8 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
         float ntime = time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
         float sxy = mad<FAST>(ny, kC3, nx * kC3);
         // both lattice parts first, so that all eight table reads are in flight together
-        NoiseCorners na = snoise_corners<FAST>(nx, ny, uvx + ntime, sxy);
-        NoiseCorners nb = snoise_corners<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy);
+        NoiseCorners na = snoise_corners<FAST, PTAB>(nx, ny, uvx + ntime, sxy, perm);
+        NoiseCorners nb = snoise_corners<FAST, PTAB>(nx, ny, (uvy + ntime) + 1234.5678f, sxy, perm);
         float4 a0 = lut_at(lut, na.j0), a1 = lut_at(lut, na.j1), a2 = lut_at(lut, na.j2), a3 = lut_at(lut, na.j3);
         float4 b0 = lut_at(lut, nb.j0), b1 = lut_at(lut, nb.j1), b2 = lut_at(lut, nb.j2), b3 = lut_at(lut, nb.j3);
         float wx = snoise_finish<FAST>(na, a0, a1, a2, a3);
@@ -499,12 +534,20 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
 // The flow tap reads the RGBA32F texel and decodes per particle (one decoded plane per step time
 // would multiply the gather footprint by nsteps).
 // ---------------------------------------------------------------------------
+#ifdef TH_EXP_NO_PTAB
+constexpr bool kFusedPermTable = false;
+#else
+constexpr bool kFusedPermTable = true;
+#endif
+
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
 __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 {
     __shared__ float4 lut[NOISE ? kLutSize : 1];
+    __shared__ float perm[NOISE ? kLutSize + 1 : 1];       // permute_int over the hash domain (snoise_corners PTAB)
     if constexpr (NOISE) {
         for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
+        for (int k = threadIdx.x; k < kLutSize + 1; k += 256) perm[k] = permute_int((float)(k + kLutMin));
         __syncthreads();
     }
     uint32_t idx, stride, end;
@@ -534,7 +577,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
         }
         for (uint32_t k = 0; k < p.nsteps; ++k) {
             prev = st;
-            st = integrate<FAST, NOISE, TARGET, POW2, false>(p, lut, st, pid, p.times[k]);
+            st = integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, st, pid, p.times[k], perm);
         }
         store_stream(&p.out_prev[idx], prev);
         store_stream(&p.out[idx], st);
