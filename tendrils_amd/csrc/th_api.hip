@@ -243,7 +243,7 @@ constexpr size_t kBucketWords = 2 * th::kBuckets + 4;
 
 // ---- slot order management ---------------------------------------------------------------------
 // Policy.  Bucketing pays when the random flow gather misses L2: the decoded plane does not fit
-// one XCD's 4 MiB L2, there are enough particles to amortise the sort, and at most 30 % of them are in
+// one XCD's 4 MiB L2, there are enough particles to amortise the sort, and at most 50 % of them are in
 // the edge class (outside the view / inert), read from the sort's own histogram once per period
 // (measurements: profiles/r1_c_bucketing.txt).  TH_BUCKET=0/1 forces the layout off/on; TH_REBUCKET_STEPS sets
 // the period (particles drift at most speedLimit per step).
@@ -307,7 +307,7 @@ th_status rebucket(th_context *c, const th_logic_uniforms &u)
         uint32_t edge = 0;
         TH_HIP(hipMemcpyAsync(&edge, c->bucket_mem + th::kBuckets, sizeof edge, hipMemcpyDeviceToHost, c->stream));
         TH_HIP(hipStreamSynchronize(c->stream));
-        c->bucket_wanted = (double)edge <= 0.30 * (double)n;
+        c->bucket_wanted = (double)edge <= 0.50 * (double)n;
         if (!c->bucket_wanted) {
             TH_HIP(hipMemsetAsync(c->bucket_mem, 0, (th::kBuckets + 1) * sizeof(uint32_t), c->stream));
             return ensure_identity(c);
