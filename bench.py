@@ -284,6 +284,13 @@ def main():
         t.timer.tick()
         t.step()
     _capi.call("th_kernel_timing_read", ctx, C.byref(s_ms), C.byref(s_n))
+    # and the other arithmetic mode on the same fused launches (exact <-> fast; tolerance of fast mode: DESIGN.md 4)
+    o_ms, o_n = C.c_float(), C.c_int32()
+    other_mode = "exact" if args.mode == "fast" else "fast"
+    _capi.call("th_set_mode", ctx, ta.TH_MODE_EXACT if other_mode == "exact" else ta.TH_MODE_FAST)
+    run_kernel_only(8 * STATS_EVERY)
+    _capi.call("th_kernel_timing_read", ctx, C.byref(o_ms), C.byref(o_n))
+    _capi.call("th_set_mode", ctx, ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT)
     _capi.call("th_kernel_timing", ctx, 0)
     sync_all()
 
@@ -328,6 +335,8 @@ def main():
                      "avg_step_ms_on_stream": ev_s / args.steps * 1e3,
                      "single_step_kernel": {"kernel": "logic_kernel", "avg_launch_ms": single_s * 1e3,
                                             "achieved": bytes_per_step * N * N / single_s / 1e9},
+                     "other_mode": {"mode": other_mode, "avg_launch_ms": o_ms.value, "steps_per_launch": STATS_EVERY,
+                                    "achieved": bytes_per_step * N * N * STATS_EVERY / max(o_ms.value, 1e-9) / 1e6},
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
         "counters": stats,
     }

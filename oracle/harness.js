@@ -11,6 +11,9 @@
  * Job kinds (fig.layout.job):
  *   {kind:'probe'}                       -> renderer / extension info
  *   {kind:'logic', ...}                  -> reference Tendrils.step() K times
+ *   {kind:'deposit', ...}                -> reference Tendrils.draw(): the particle
+ *                                           lines (previous -> current) blended
+ *                                           into the flow FBO
  *   {kind:'shader', ...}                 -> one full-screen pass of a compiled
  *                                           reference shader string (spawners,
  *                                           optical flow) handed in by python
@@ -125,6 +128,33 @@
             state: t.state, err: gl.getError()};
   }
 
+  // ---- reference Tendrils.draw(): flow deposit ---------------------------------
+  function runDeposit(job) {
+    var T = window.Tendrils, N = job.N;
+    var gl = getGL(job.viewW, job.viewH, T);
+    var t = new T.Tendrils(gl, {});
+    t.resize();
+    t.setup(N);
+    if (job.viewSize) { t.viewSize[0] = job.viewSize[0]; t.viewSize[1] = job.viewSize[1]; }
+    var k;
+    for (k in (job.state || {})) t.state[k] = job.state[k];
+    uploadF32(gl, t.particles.buffers[0].color[0].handle, N, N, f32FromB64(job.inputs.current));
+    uploadF32(gl, t.particles.buffers[1].color[0].handle, N, N, f32FromB64(job.inputs.previous));
+    if (job.inputs.flow)
+      uploadF32(gl, t.flow.color[0].handle, t.flow.shape[0], t.flow.shape[1], f32FromB64(job.inputs.flow));
+    t.timer.time = job.time;
+    // GL state as Tendrils.step() leaves it (src/index.js:267-268) - draw() follows step() in the frame loop
+    gl.enable(gl.BLEND);
+    gl.blendFunc(gl.SRC_ALPHA, gl.ONE_MINUS_SRC_ALPHA);
+    t.draw();
+    t.flow.bind();
+    var out = f32ToB64(readFBO(gl, t.flow.shape[0], t.flow.shape[1]));
+    return {out: out, lineWidthRange: Array.prototype.slice.call(gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE)),
+            lineWidth: gl.getParameter(gl.LINE_WIDTH),
+            viewSize: [t.viewSize[0], t.viewSize[1]], viewRes: [t.viewRes[0], t.viewRes[1]],
+            flowShape: [t.flow.shape[0], t.flow.shape[1]], state: t.state, err: gl.getError()};
+  }
+
   // ---- one full-screen pass of a compiled reference shader -----------------
   function compile(gl, type, src) {
     var sh = gl.createShader(type);
@@ -215,6 +245,7 @@
                  maxTex: gl.getParameter(gl.MAX_TEXTURE_SIZE),
                  threads: navigator.hardwareConcurrency};
         } else if (job.kind === 'logic') res = runLogic(job);
+        else if (job.kind === 'deposit') res = runDeposit(job);
         else if (job.kind === 'shader') res = runShader(job);
         else res = {error: 'unknown job kind'};
       } catch (e) {

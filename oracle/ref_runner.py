@@ -91,6 +91,22 @@ class RefRunner:
             outs = [_f32(o, (N, N, 4)) for o in res["out"]]
         return outs, res
 
+    # -- reference Tendrils.draw(): flow deposit ------------------------------------
+    def deposit(self, current, previous, flow=None, uniforms=None, time=0.0, view=(64, 64), view_size=None):
+        """current/previous: [N,N,4] state textures; returns the flow FBO [H,W,4] after draw()."""
+        N = current.shape[0]
+        job = {"kind": "deposit", "N": N, "viewW": int(view[0]), "viewH": int(view[1]), "state": uniforms or {},
+               "time": float(time), "inputs": {"current": _b64(current, np.float32), "previous": _b64(previous, np.float32)}}
+        if flow is not None:
+            job["inputs"]["flow"] = _b64(flow, np.float32)
+        if view_size is not None:
+            job["viewSize"] = [float(view_size[0]), float(view_size[1])]
+        res = self._run(job)
+        if res.get("err"):
+            raise RuntimeError("GL error %s" % res["err"])
+        w, h = res["flowShape"]
+        return _f32(res["out"], (h, w, 4)), res
+
     # -- compiled shader strings of demo.js --------------------------------------
     def demo_shaders(self):
         if self._demo_shaders is None:
