@@ -607,7 +607,9 @@ static th_status plan_step(th_context *c, const th_logic_uniforms &u, int32_t ta
                        (1.0 + std::fabs((double)u.varyNoiseSpeed)) * 1.001;
         if (ntime + 1237.0 >= (double)th::kNoiseDomain) plan.generic = true;  // z = uv + noiseTime (+1234.5678)
         double bound = nscale > 0.0 ? (double)th::kNoiseDomain / nscale : 3.0e38;
-        p.pos_bound = (float)std::fmin(bound * 0.999, 3.0e38);
+        // capped below |inert| = 1e6: a lane inside the bound cannot be inert, so the specialised path tests
+        // the bound only and the inert pass-through lives on the (reference-order) fallback path
+        p.pos_bound = (float)std::fmin(bound * 0.999, 999999.0);
         if (!(p.pos_bound > 0.0f)) plan.generic = true;
     }
     if (!plan.generic && !plan.use_targets) {

@@ -158,26 +158,84 @@ struct NoiseCorners {
     int j0, j1, j2, j3;
 };
 
-// perm table reads by magic-number index (see lut_at): entry k holds permute_int(k + kLutMin)
-TH_D float perm_at(const float *perm, int magic)
+// ---- hash stages through LDS tables (issue-bound launches: the fused integrator) --------------------------
+// The first two permutation stages read the polynomial's own values from LDS instead of evaluating them, and the
+// whole index chain runs on integers that already are byte offsets, so no stage needs an offset multiply:
+//   permA[k] = 4 * permute_int(k)               k in [0, 290]: stage z (argument iz, iz + 1), 4 * value = offset unit of permB
+//   permB[k] = 16 * (permute_int(k) - kLutMin)  k in [0, 580]: stage y; + 16 * (ix + i) = byte offset of the gradient entry
+// Both are filled by the kernel with permute_int itself; mod289_int() results are exact integers in [0, 289].
+constexpr int kPermA = 292, kPermB = 584;                    // entries (multiples of 4)
+constexpr int kHashVec = (kPermA + kPermB) / 4;              // float4 slots in front of the gradient table
+struct HashTables {
+    const uint32_t *permA, *permB;
+};
+
+TH_D void fill_hash_tables(float4 *smem, const float4 *lut_global)
 {
-    unsigned off;
-    asm("v_mul_u32_u24 %0, %1, 4" : "=v"(off) : "v"(magic));
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(perm) + off);
-}
-TH_D float2 perm_pair_at(const float *perm, int magic)      // entries k and k + 1
-{
-    unsigned off;
-    asm("v_mul_u32_u24 %0, %1, 4" : "=v"(off) : "v"(magic));
-    const float *e = reinterpret_cast<const float *>(reinterpret_cast<const char *>(perm) + off);
-    return make_float2(e[0], e[1]);
+    uint32_t *a = reinterpret_cast<uint32_t *>(smem), *b = a + kPermA;
+    for (int k = threadIdx.x; k < kPermA; k += 256) a[k] = 4u * (uint32_t)permute_int((float)k);
+    for (int k = threadIdx.x; k < kPermB; k += 256) b[k] = 16u * (uint32_t)((int)permute_int((float)k) - kLutMin);
+    for (int k = threadIdx.x; k < kLutSize; k += 256) smem[kHashVec + k] = lut_global[k];
 }
 
-// PTAB: the permutation polynomial of the first two hash stages is read from an LDS table of its own values
-// (perm[k] = permute_int(k + kLutMin), filled by the kernel with permute_int itself) instead of being evaluated:
-// 5 VALU per permute become one offset multiply + one LDS read.  Used where the launch is issue-bound.
-template <bool FAST, bool PTAB = false>
-TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy, const float *perm = nullptr)
+template <bool FAST>
+TH_D NoiseCorners snoise_corners_tab(float vx, float vy, float vz, float sxy, const HashTables &T)
+{
+    NoiseCorners n;
+    float s = mad<FAST>(vz, kC3, sxy);
+    float ix = th_floor(vx + s), iy = th_floor(vy + s), iz = th_floor(vz + s);
+    float t = mad<FAST>(iz, kC6, mad<FAST>(iy, kC6, ix * kC6));
+    float ax = (vx - ix) + t, ay = (vy - iy) + t, az = (vz - iz) + t;
+
+    // traversal order masks as in snoise_corners; additionally the x / y offsets as index increments (0 or one entry)
+    float i1x, i1y, i1z, i2x, i2y, i2z;
+    uint32_t e1x, e2x, e1y, e2y;
+    unsigned long long mz1, mz2;
+    {
+        unsigned long long l1, l2, l3, m;
+        asm("v_cmp_lt_f32 %[l1], %[ax], %[ay]\n\t"
+            "v_cmp_lt_f32 %[l2], %[ay], %[az]\n\t"
+            "v_cmp_lt_f32 %[l3], %[az], %[ax]\n\t"
+            "s_andn2_b64 %[m], %[l3], %[l1]\n\t"     "v_cndmask_b32 %[i1x], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e1x], 0, 16, %[m]\n\t"
+            "s_andn2_b64 %[m], %[l1], %[l2]\n\t"     "v_cndmask_b32 %[i1y], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e1y], 0, 4, %[m]\n\t"
+            "s_andn2_b64 %[mz1], %[l2], %[l3]\n\t"   "v_cndmask_b32 %[i1z], 0, 1.0, %[mz1]\n\t"
+            "s_orn2_b64 %[m], %[l3], %[l1]\n\t"      "v_cndmask_b32 %[i2x], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e2x], 0, 16, %[m]\n\t"
+            "s_orn2_b64 %[m], %[l1], %[l2]\n\t"      "v_cndmask_b32 %[i2y], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e2y], 0, 4, %[m]\n\t"
+            "s_orn2_b64 %[mz2], %[l2], %[l3]\n\t"    "v_cndmask_b32 %[i2z], 0, 1.0, %[mz2]"
+            : [l1] "=&s"(l1), [l2] "=&s"(l2), [l3] "=&s"(l3), [m] "=&s"(m), [mz1] "=&s"(mz1), [mz2] "=&s"(mz2),
+              [i1x] "=&v"(i1x), [i1y] "=&v"(i1y), [i1z] "=&v"(i1z), [i2x] "=&v"(i2x), [i2y] "=&v"(i2y), [i2z] "=&v"(i2z),
+              [e1x] "=&v"(e1x), [e2x] "=&v"(e2x), [e1y] "=&v"(e1y), [e2y] "=&v"(e2y)
+            : [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az)
+            : "scc");
+    }
+    n.ax = ax; n.ay = ay; n.az = az;
+    n.bx = (ax - i1x) + kC6; n.by = (ay - i1y) + kC6; n.bz = (az - i1z) + kC6;
+    n.cx = (ax - i2x) + kC3; n.cy = (ay - i2y) + kC3; n.cz = (az - i2z) + kC3;
+    n.dx = ax - 0.5f; n.dy = ay - 0.5f; n.dz = az - 0.5f;
+
+    const uint32_t xi = (uint32_t)mod289_int(ix), yi = (uint32_t)mod289_int(iy), zi = (uint32_t)mod289_int(iz);
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.permA) + (zi << 2));
+    const uint32_t pz0 = pa[0], pz1 = pa[1];                    // 4 * permute(iz), 4 * permute(iz + 1)
+    uint32_t sel1, sel2;
+    asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
+        : "=&v"(sel1), "=&v"(sel2) : "v"(pz0), "v"(pz1), "s"(mz1), "s"(mz2));
+    const uint32_t y4 = yi << 2;
+    auto stage_y = [&](uint32_t off) { return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(T.permB) + off); };
+    const uint32_t q0 = stage_y(pz0 + y4), q1 = stage_y(sel1 + y4 + e1y), q2 = stage_y(sel2 + y4 + e2y),
+                   q3 = stage_y(pz1 + y4 + 4u);
+    const uint32_t x16 = xi << 4;
+    n.j0 = (int)(q0 + x16); n.j1 = (int)(q1 + x16 + e1x); n.j2 = (int)(q2 + x16 + e2x); n.j3 = (int)(q3 + x16 + 16u);
+    return n;
+}
+
+// gradient entry at a byte offset produced by snoise_corners_tab
+TH_D float4 lut_at_offset(const float4 *lut, int off)
+{
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lut) + off);
+}
+
+template <bool FAST>
+TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy)
 {
     NoiseCorners n;
     // first corner
@@ -217,30 +275,14 @@ TH_D NoiseCorners snoise_corners(float vx, float vy, float vz, float sxy, const 
 
     // permutation hash: exact small-integer arithmetic (th_math.hpp)
     ix = mod289_int(ix); iy = mod289_int(iy); iz = mod289_int(iz);
-    float q0, q1, q2, q3;
-    if constexpr (PTAB) {
-        // table index = value - kLutMin, carried in the low mantissa bits of value + 2^23 - kLutMin (exact: all
-        // integers below 2^24); the bias rides on iz / iy, so it costs one addition per stage
-        constexpr float kBias = 8388608.0f - (float)kLutMin;
-        const float2 pz = perm_pair_at(perm, __float_as_int(iz + kBias));   // permute(iz), permute(iz + 1)
-        const float iyb = iy + kBias;
-        float sel1, sel2;
-        asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
-            : "=&v"(sel1), "=&v"(sel2) : "v"(pz.x), "v"(pz.y), "s"(mz1), "s"(mz2));
-        q0 = perm_at(perm, __float_as_int(pz.x + iyb));
-        q1 = perm_at(perm, __float_as_int((sel1 + iyb) + i1y));
-        q2 = perm_at(perm, __float_as_int((sel2 + iyb) + i2y));
-        q3 = perm_at(perm, __float_as_int((pz.y + iyb) + 1.0f));
-    } else {
-        float pz0 = permute_int(iz), pz1 = permute_int(iz + 1.0f);       // z offsets are only ever 0 or 1
-        q0 = permute_int(pz0 + iy);
-        float sel1, sel2;
-        asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
-            : "=&v"(sel1), "=&v"(sel2) : "v"(pz0), "v"(pz1), "s"(mz1), "s"(mz2));
-        q1 = permute_int((sel1 + iy) + i1y);
-        q2 = permute_int((sel2 + iy) + i2y);
-        q3 = permute_int((pz1 + iy) + 1.0f);
-    }
+    float pz0 = permute_int(iz), pz1 = permute_int(iz + 1.0f);       // z offsets are only ever 0 or 1
+    float q0 = permute_int(pz0 + iy);
+    float sel1, sel2;
+    asm("v_cndmask_b32 %0, %2, %3, %4\n\tv_cndmask_b32 %1, %2, %3, %5"
+        : "=&v"(sel1), "=&v"(sel2) : "v"(pz0), "v"(pz1), "s"(mz1), "s"(mz2));
+    float q1 = permute_int((sel1 + iy) + i1y);
+    float q2 = permute_int((sel2 + iy) + i2y);
+    float q3 = permute_int((pz1 + iy) + 1.0f);
     // Table index without a float->int conversion: the last-stage argument is a small integer, so
     // adding 2^23 (+ the table bias) leaves it in the low mantissa bits of the sum; every addition
     // stays exact (all values are integers below 2^24).  lut_index() turns the bits into an LDS offset.
@@ -296,18 +338,18 @@ TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2,
 // One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false>
 TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
-                      const float *perm = nullptr)
+                      const HashTables *tabs = nullptr)
 {
     const th_logic_uniforms &u = p.u;
     float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
-    if (!(posx != kInert || posy != kInert)) return st;                   // src/logic.frag:52
 
     uint32_t x, y;
     if constexpr (POW2) { x = pid & (p.width - 1u); y = pid >> p.log2w; }
     else { y = pid / p.width; x = pid - y * p.width; }
     y += p.row0;
 
-    // two compares (not max): a NaN in either component must fail the test
+    // two compares (not max): a NaN in either component must fail the test.  pos_bound < |inert| (host), so inert
+    // particles (src/logic.frag:52) fail it too and are passed through by logic_texel_ref.
     bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
     if (__builtin_expect(!in_domain, 0)) return logic_texel_ref(p, x, y, st, pid, time);
 
@@ -341,10 +383,19 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
         float ntime = time * vary(u.noiseSpeed, i, u.varyNoiseSpeed);
         float sxy = mad<FAST>(ny, kC3, nx * kC3);
         // both lattice parts first, so that all eight table reads are in flight together
-        NoiseCorners na = snoise_corners<FAST, PTAB>(nx, ny, uvx + ntime, sxy, perm);
-        NoiseCorners nb = snoise_corners<FAST, PTAB>(nx, ny, (uvy + ntime) + 1234.5678f, sxy, perm);
-        float4 a0 = lut_at(lut, na.j0), a1 = lut_at(lut, na.j1), a2 = lut_at(lut, na.j2), a3 = lut_at(lut, na.j3);
-        float4 b0 = lut_at(lut, nb.j0), b1 = lut_at(lut, nb.j1), b2 = lut_at(lut, nb.j2), b3 = lut_at(lut, nb.j3);
+        NoiseCorners na, nb;
+        float4 a0, a1, a2, a3, b0, b1, b2, b3;
+        if constexpr (PTAB) {
+            na = snoise_corners_tab<FAST>(nx, ny, uvx + ntime, sxy, *tabs);
+            nb = snoise_corners_tab<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy, *tabs);
+            a0 = lut_at_offset(lut, na.j0); a1 = lut_at_offset(lut, na.j1); a2 = lut_at_offset(lut, na.j2); a3 = lut_at_offset(lut, na.j3);
+            b0 = lut_at_offset(lut, nb.j0); b1 = lut_at_offset(lut, nb.j1); b2 = lut_at_offset(lut, nb.j2); b3 = lut_at_offset(lut, nb.j3);
+        } else {
+            na = snoise_corners<FAST>(nx, ny, uvx + ntime, sxy);
+            nb = snoise_corners<FAST>(nx, ny, (uvy + ntime) + 1234.5678f, sxy);
+            a0 = lut_at(lut, na.j0); a1 = lut_at(lut, na.j1); a2 = lut_at(lut, na.j2); a3 = lut_at(lut, na.j3);
+            b0 = lut_at(lut, nb.j0); b1 = lut_at(lut, nb.j1); b2 = lut_at(lut, nb.j2); b3 = lut_at(lut, nb.j3);
+        }
         float wx = snoise_finish<FAST>(na, a0, a1, a2, a3);
         float wy = snoise_finish<FAST>(nb, b0, b1, b2, b3);
         float vnw = vary(u.noiseWeight, i, u.varyNoise);
@@ -548,11 +599,12 @@ constexpr bool kFusedPermTable = true;
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
 __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 {
-    __shared__ float4 lut[NOISE ? kLutSize : 1];
-    __shared__ float perm[NOISE ? kLutSize + 1 : 1];       // permute_int over the hash domain (snoise_corners PTAB)
+    // one LDS block: [permA | permB | gradient table], the hash tables first so that their reads need no base offset
+    __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
+    const float4 *lut = smem + (NOISE ? kHashVec : 0);
+    const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
     if constexpr (NOISE) {
-        for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
-        for (int k = threadIdx.x; k < kLutSize + 1; k += 256) perm[k] = permute_int((float)(k + kLutMin));
+        fill_hash_tables(smem, p.lut);
         __syncthreads();
     }
     uint32_t idx, stride, end;
@@ -582,7 +634,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
         }
         for (uint32_t k = 0; k < p.nsteps; ++k) {
             prev = st;
-            st = integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, st, pid, p.times[k], perm);
+            st = integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, st, pid, p.times[k], &tabs);
         }
         store_stream(&p.out_prev[idx], prev);
         store_stream(&p.out[idx], st);
