@@ -187,8 +187,11 @@ TH_D NoiseCorners snoise_corners_tab(float vx, float vy, float vz, float sxy, co
     float t = mad<FAST>(iz, kC6, mad<FAST>(iy, kC6, ix * kC6));
     float ax = (vx - ix) + t, ay = (vy - iy) + t, az = (vz - iz) + t;
 
-    // traversal order masks as in snoise_corners; additionally the x / y offsets as index increments (0 or one entry)
-    float i1x, i1y, i1z, i2x, i2y, i2z;
+    // Traversal order masks as in snoise_corners.  Here the second and third corner offsets are selected instead of
+    // subtracted: x0 - i1 with i1 in {0, 1} is x0 or x0 - 1 (exactly, signed zeros included), and x0 - 1 serves both
+    // corners; the x / y steps also come out as index increments (0 or one table entry) for the hash chain below.
+    const float ax1 = ax - 1.0f, ay1 = ay - 1.0f, az1 = az - 1.0f;
+    float bx, by, bz, cx, cy, cz;
     uint32_t e1x, e2x, e1y, e2y;
     unsigned long long mz1, mz2;
     {
@@ -196,21 +199,21 @@ TH_D NoiseCorners snoise_corners_tab(float vx, float vy, float vz, float sxy, co
         asm("v_cmp_lt_f32 %[l1], %[ax], %[ay]\n\t"
             "v_cmp_lt_f32 %[l2], %[ay], %[az]\n\t"
             "v_cmp_lt_f32 %[l3], %[az], %[ax]\n\t"
-            "s_andn2_b64 %[m], %[l3], %[l1]\n\t"     "v_cndmask_b32 %[i1x], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e1x], 0, 16, %[m]\n\t"
-            "s_andn2_b64 %[m], %[l1], %[l2]\n\t"     "v_cndmask_b32 %[i1y], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e1y], 0, 4, %[m]\n\t"
-            "s_andn2_b64 %[mz1], %[l2], %[l3]\n\t"   "v_cndmask_b32 %[i1z], 0, 1.0, %[mz1]\n\t"
-            "s_orn2_b64 %[m], %[l3], %[l1]\n\t"      "v_cndmask_b32 %[i2x], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e2x], 0, 16, %[m]\n\t"
-            "s_orn2_b64 %[m], %[l1], %[l2]\n\t"      "v_cndmask_b32 %[i2y], 0, 1.0, %[m]\n\t"   "v_cndmask_b32 %[e2y], 0, 4, %[m]\n\t"
-            "s_orn2_b64 %[mz2], %[l2], %[l3]\n\t"    "v_cndmask_b32 %[i2z], 0, 1.0, %[mz2]"
+            "s_andn2_b64 %[m], %[l3], %[l1]\n\t"     "v_cndmask_b32 %[bx], %[ax], %[ax1], %[m]\n\t"   "v_cndmask_b32 %[e1x], 0, 16, %[m]\n\t"
+            "s_andn2_b64 %[m], %[l1], %[l2]\n\t"     "v_cndmask_b32 %[by], %[ay], %[ay1], %[m]\n\t"   "v_cndmask_b32 %[e1y], 0, 4, %[m]\n\t"
+            "s_andn2_b64 %[mz1], %[l2], %[l3]\n\t"   "v_cndmask_b32 %[bz], %[az], %[az1], %[mz1]\n\t"
+            "s_orn2_b64 %[m], %[l3], %[l1]\n\t"      "v_cndmask_b32 %[cx], %[ax], %[ax1], %[m]\n\t"   "v_cndmask_b32 %[e2x], 0, 16, %[m]\n\t"
+            "s_orn2_b64 %[m], %[l1], %[l2]\n\t"      "v_cndmask_b32 %[cy], %[ay], %[ay1], %[m]\n\t"   "v_cndmask_b32 %[e2y], 0, 4, %[m]\n\t"
+            "s_orn2_b64 %[mz2], %[l2], %[l3]\n\t"    "v_cndmask_b32 %[cz], %[az], %[az1], %[mz2]"
             : [l1] "=&s"(l1), [l2] "=&s"(l2), [l3] "=&s"(l3), [m] "=&s"(m), [mz1] "=&s"(mz1), [mz2] "=&s"(mz2),
-              [i1x] "=&v"(i1x), [i1y] "=&v"(i1y), [i1z] "=&v"(i1z), [i2x] "=&v"(i2x), [i2y] "=&v"(i2y), [i2z] "=&v"(i2z),
+              [bx] "=&v"(bx), [by] "=&v"(by), [bz] "=&v"(bz), [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz),
               [e1x] "=&v"(e1x), [e2x] "=&v"(e2x), [e1y] "=&v"(e1y), [e2y] "=&v"(e2y)
-            : [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az)
+            : [ax] "v"(ax), [ay] "v"(ay), [az] "v"(az), [ax1] "v"(ax1), [ay1] "v"(ay1), [az1] "v"(az1)
             : "scc");
     }
     n.ax = ax; n.ay = ay; n.az = az;
-    n.bx = (ax - i1x) + kC6; n.by = (ay - i1y) + kC6; n.bz = (az - i1z) + kC6;
-    n.cx = (ax - i2x) + kC3; n.cy = (ay - i2y) + kC3; n.cz = (az - i2z) + kC3;
+    n.bx = bx + kC6; n.by = by + kC6; n.bz = bz + kC6;
+    n.cx = cx + kC3; n.cy = cy + kC3; n.cz = cz + kC3;
     n.dx = ax - 0.5f; n.dy = ay - 0.5f; n.dz = az - 0.5f;
 
     const uint32_t xi = (uint32_t)mod289_int(ix), yi = (uint32_t)mod289_int(iy), zi = (uint32_t)mod289_int(iz);
@@ -371,10 +374,11 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     float fu = (sx + 1.0f) * 0.5f, fv = (sy + 1.0f) * 0.5f;               // (1*(v+1))/2, exactly
     int tx = (int)__builtin_amdgcn_fmed3f(fu * p.fwf, 0.0f, p.fwm1);      // trunc == floor on [0, n-1]
     int ty = (int)__builtin_amdgcn_fmed3f(fv * p.fhf, 0.0f, p.fhm1);
+    const int texel = ty * p.fw + tx;
     float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
     float4 ft;
-    if constexpr (DECODED) { float2 d = p.flow_dec[ty * p.fw + tx]; ffx = d.x; ffy = d.y; }
-    else ft = p.flow[ty * p.fw + tx];
+    if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
+    else ft = p.flow[texel];
 
     float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
     if constexpr (NOISE) {
