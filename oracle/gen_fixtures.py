@@ -150,6 +150,24 @@ def gen_logic(r, only):
                    zero_flow=True, state=st, view=(32, 32))
 
 
+def gen_logic_denormal(r, only):
+    """Velocities whose squares underflow: speed = length(newVel) passes through the denormal range and reaches
+    0 -> 0/0 = NaN (src/logic.frag:92-94).  Pins the flush-to-zero behaviour of the reference's arithmetic."""
+    name = "logic_denormal_16"
+    if only and only not in name:
+        return
+    rng = np.random.default_rng(114)
+    n = 16
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.9, 0.9, (n, n, 2))
+    mag = 10.0 ** rng.uniform(-24, -17, (n, n))
+    ang = rng.uniform(0, 2 * np.pi, (n, n))
+    st[..., 2] = mag * np.cos(ang)
+    st[..., 3] = mag * np.sin(ang)
+    logic_case(r, name, n=n, seed=114, uniforms={"noiseWeight": 0}, zero_flow=True, state=st, view=(16, 16), steps=3,
+               time0=1000.0)
+
+
 def gen_logic_4096(r, only):
     """C3-sized state texture: the index i = (x+.5 + (y+.5)*W)/(W*H) loses low bits in fp32 once
     (y+.5)*W >= 2^24 (src/logic.frag:57-58) - must be mirrored, not fixed.  The state is generated
@@ -323,6 +341,7 @@ def main():
     r = RefRunner()
     print("oracle:", r.probe())
     gen_logic(r, args.only)
+    gen_logic_denormal(r, args.only)
     gen_logic_4096(r, args.only)
     gen_logic_config_bands(r, args.only)
     gen_optical_flow(r, args.only)
