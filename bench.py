@@ -232,8 +232,10 @@ def main():
     def stats_tick():
         """statistics of buffers[0], reduced over the ranks in place by RCCL on the context's stream"""
         nonlocal pending, dev_counters
-        for w in pending:
-            w.wait()
+        if pending:        # the context's stream waits (on the device) for the previous reduction before the
+            with torch.cuda.stream(ext_stream):     # counters are overwritten; the host does not block
+                for w in pending:
+                    w.wait()
         pending = []
         _capi.call("th_stats_async", ctx, C.c_float(t.state["speedLimit"]), C.byref(counters_dev))
         if dist is not None:
@@ -243,8 +245,8 @@ def main():
                 pending = dev_counters.all_reduce_async(dist)
 
     def run(k_steps):
-        # the step loop is replayed from captured hipGraphs (Tendrils.step_n -> th_step_n), 16 steps per
-        # replay; between replays: statistics (+ their RCCL reduction) and the optical-flow refresh
+        # the step loop runs as fused launches (Tendrils.step_n -> th_step_n), STATS_EVERY steps each;
+        # between launches: statistics (+ their RCCL reduction) and the optical-flow refresh
         done = 0
         while done < k_steps:
             n = min(STATS_EVERY, k_steps - done)
@@ -294,8 +296,10 @@ def main():
     _capi.call("th_kernel_timing", ctx, 0)
     sync_all()
 
-    for w in pending:
-        w.wait()
+    if pending:
+        with torch.cuda.stream(ext_stream):
+            for w in pending:
+                w.wait()
     stats = t.particles.stats(t.state["speedLimit"])
     if dist is not None:
         tmax = torch.tensor([wall, ev_ms.value / 1e3, k_ms.value / 1e3, s_ms.value / 1e3], dtype=torch.float64, device="cuda")

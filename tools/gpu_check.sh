@@ -22,6 +22,6 @@ timeout 600 python bench.py --steps 256 --warmup 32 --mode fast --no-cpu > gpuru
 echo "== bench force-dist (RCCL path at world size 1)"
 timeout 600 python bench.py --steps 128 --warmup 32 --force-dist --no-cpu > gpurun_out/bench_forcedist.log 2>&1; tail -12 gpurun_out/bench_forcedist.log
 echo "== rocprofv3 kernel trace"
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 128 --warmup 32 --no-cpu --no-traffic > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-traffic > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name '*stats*' | head; for f in $(find gpurun_out/prof -name '*kernel_stats.csv'); do head -12 $f; done
