@@ -121,13 +121,16 @@ def snoise3(x, y, z):
     return lib().to_snoise3(float(x), float(y), float(z))
 
 
-def logic_step(u, state, flow, targets=None, y0=0):
-    """state: [rows, W, 4] f32 band starting at global row y0; flow: [fh, fw, 4]."""
+def logic_step(u, state, flow, targets=None, y0=0, out=None):
+    """state: [rows, W, 4] f32 band starting at global row y0; flow: [fh, fw, 4].  `out` may be given to reuse a
+    buffer (timing runs: keeps page faults of a fresh 256 MiB array out of the measurement)."""
     state = np.ascontiguousarray(state, np.float32)
     flow = np.ascontiguousarray(flow, np.float32)
     rows, W = state.shape[:2]
     assert W == u.data_w and state.shape[2] == 4
-    out = np.empty_like(state)
+    if out is None:
+        out = np.empty_like(state)
+    assert out.shape == state.shape and out.dtype == np.float32 and out.flags.c_contiguous
     tp = None
     if targets is not None:
         targets = np.ascontiguousarray(targets, np.float32)
