@@ -319,14 +319,17 @@ def main():
     steps_per_launch = args.steps / launches
     alg_bytes_per_launch = bytes_per_step * N * N * steps_per_launch
     achieved = alg_bytes_per_launch / per_launch_s / 1e9
-    kernel_name = "logic_fused_kernel" if steps_per_launch > 1 else "logic_kernel"
+    packed = args.state == "f16"
+    kernel_name = ("logic_fused_packed_kernel" if packed else "logic_fused_kernel") if steps_per_launch > 1 else \
+        ("logic_packed_kernel" if packed else "logic_kernel")
 
     line = {
         "metric": "particle-steps/sec (16M particles per GPU)", "value": value, "unit": "particle-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",     # arithmetic is fp32 in both storage formats
-        "config": {"workload": "C3: 4096x4096 RGBA32F state (16.8M particles) per GPU, flow 1920x1080 from "
+        "config": {"workload": "C3: 4096x4096 " + ("packed 8-B (SNORM16 pos + fp16 vel)" if args.state == "f16" else "RGBA32F")
+                               + " state (16.8M particles) per GPU, flow 1920x1080 from "
                                + flow_source + ", reference default uniforms"
                                + (" with noiseWeight=0 (flow-only)" if args.flow_only else " (simplex noise on)")
                                + ", 60 Hz fixed timer",
@@ -337,7 +340,7 @@ def main():
                      "kernel": kernel_name, "avg_launch_ms": per_launch_s * 1e3, "launches": launches,
                      "steps_per_launch": steps_per_launch, "particle_steps_per_launch": N * N * steps_per_launch,
                      "avg_step_ms_on_stream": ev_s / args.steps * 1e3,
-                     "single_step_kernel": {"kernel": "logic_kernel", "avg_launch_ms": single_s * 1e3,
+                     "single_step_kernel": {"kernel": "logic_packed_kernel" if args.state == "f16" else "logic_kernel", "avg_launch_ms": single_s * 1e3,
                                             "achieved": bytes_per_step * N * N / single_s / 1e9},
                      "other_mode": {"mode": other_mode, "avg_launch_ms": o_ms.value, "steps_per_launch": STATS_EVERY,
                                     "achieved": bytes_per_step * N * N * STATS_EVERY / max(o_ms.value, 1e-9) / 1e6},

@@ -728,10 +728,10 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     if (th_status s = plan_step(c, v, TH_TARGET_RING, plan)) return s;
 
     // Temporal fusion (logic_fused_kernel): all n steps of a particle in one pass, <= kMaxFusedSteps per launch.
-    // Needs the plain 2-buffer ring (only the last two states survive n rotations), the specialised kernel and
-    // an f32 ring.  TH_FUSE=0 turns it off (the tests compare both paths).
+    // Needs the plain 2-buffer ring (only the last two states survive n rotations) and the specialised kernel;
+    // both ring formats.  TH_FUSE=0 turns it off (the tests compare both paths).
     static const bool fuse_on = [] { const char *e = getenv("TH_FUSE"); return !e || atoi(e) != 0; }();
-    if (fuse_on && n >= 2 && c->ring.size() == 2 && !plan.generic && !c->packed) {
+    if (fuse_on && n >= 2 && c->ring.size() == 2 && !plan.generic) {
         {   // (the slot layout was brought up to date by plan_step above; the re-sort period is approximate)
             int32_t done = 0;
             while (done < n) {
@@ -757,7 +757,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                     c->kt_used += 2;
                     TH_HIP(hipEventRecord(k0, c->stream));
                 }
-                th::launch_logic_fused(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, c->stream);
+                th::launch_logic_fused(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, c->packed, c->stream);
                 if (k1) TH_HIP(hipEventRecord(k1, c->stream));
                 TH_HIP(hipGetLastError());
                 if (m & 1) { c->ring[0] = other; c->ring[1] = cur; }

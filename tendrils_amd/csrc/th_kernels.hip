@@ -354,7 +354,10 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     // two compares (not max): a NaN in either component must fail the test.  pos_bound < |inert| (host), so inert
     // particles (src/logic.frag:52) fail it too and are passed through by logic_texel_ref.
     bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
-    if (__builtin_expect(!in_domain, 0)) return logic_texel_ref(p, x, y, st, pid, time);
+    if (__builtin_expect(!in_domain, 0)) {
+        if (!(posx != kInert || posy != kInert)) return st;              // inert: pass through (src/logic.frag:52)
+        return logic_texel_ref(p, x, y, st, pid, time);
+    }
 
     float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
     float uvx, uvy, i;
@@ -645,9 +648,47 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
     }
 }
 
-template <bool FAST, bool NOISE, bool TARGET>
-static void launch_fused_p2(const LogicParams &p, bool pow2, hipStream_t s)
+// Packed ring (TH_STATE_F16): the same fusion on 8-B texels.  The storage quantisation is part of every step
+// (a step reads what the previous one stored), so each intermediate state goes through pack -> unpack in
+// registers: bit-identical to nsteps logic_packed_kernel launches.
+template <bool FAST, bool NOISE, bool TARGET, bool POW2>
+__global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicParams p)
 {
+    __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
+    const float4 *lut = smem + (NOISE ? kHashVec : 0);
+    const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
+    if constexpr (NOISE) {
+        fill_hash_tables(smem, p.lut);
+        __syncthreads();
+    }
+    const v2u *in = reinterpret_cast<const v2u *>(p.in);
+    v2u *out = reinterpret_cast<v2u *>(p.out), *out_prev = reinterpret_cast<v2u *>(p.out_prev);
+    const uint32_t stride = gridDim.x * 256u;
+    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    v2u nxt = {0x80008000u, 0u};
+    if (idx < p.count) nxt = __builtin_nontemporal_load(&in[idx]);
+    for (; idx < p.count; idx += stride) {
+        uint2 w = make_uint2(nxt.x, nxt.y), wprev = w;
+        if (idx + stride < p.count) nxt = __builtin_nontemporal_load(&in[idx + stride]);
+        for (uint32_t k = 0; k < p.nsteps; ++k) {
+            wprev = w;
+            w = pack_state(integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, unpack_state(w), idx, p.times[k], &tabs));
+        }
+        v2u a = {wprev.x, wprev.y}, b = {w.x, w.y};
+        __builtin_nontemporal_store(a, &out_prev[idx]);
+        __builtin_nontemporal_store(b, &out[idx]);
+    }
+}
+
+template <bool FAST, bool NOISE, bool TARGET>
+static void launch_fused_p2(const LogicParams &p, bool pow2, bool packed, hipStream_t s)
+{
+    if (packed) {
+        const int pgrid = grid_for(p.count, 8);
+        if (pow2) hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, true>), dim3(pgrid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, false>), dim3(pgrid), dim3(256), 0, s, p);
+        return;
+    }
     const bool bucketed = p.perm != nullptr;
     const int grid = bucketed ? 2048 : grid_for(p.count, 8);
 #define TH_GO(P2, BK) hipLaunchKernelGGL((logic_fused_kernel<FAST, NOISE, TARGET, P2, BK>), dim3(grid), dim3(256), 0, s, p)
@@ -656,10 +697,10 @@ static void launch_fused_p2(const LogicParams &p, bool pow2, hipStream_t s)
 #undef TH_GO
 }
 
-void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, hipStream_t s)
+void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool packed, hipStream_t s)
 {
     const bool fast = mode == TH_MODE_FAST;
-#define TH_DISPATCH(F, N, T) launch_fused_p2<F, N, T>(p, pow2, s)
+#define TH_DISPATCH(F, N, T) launch_fused_p2<F, N, T>(p, pow2, packed, s)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }

@@ -85,7 +85,7 @@ struct StatsPartial {
 // launchers (defined in th_kernels.hip)
 void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool decoded,
                   bool generic, bool packed, hipStream_t stream);
-void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, hipStream_t stream);
+void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool packed, hipStream_t stream);
 void launch_pack_state(void *dst, const float4 *src, uint32_t n, hipStream_t stream);      // f32 texels -> TH_STATE_F16
 void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t stream);
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
