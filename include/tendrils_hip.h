@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 1
+#define TH_ABI_VERSION 2
 
 typedef int32_t th_status;
 enum {
@@ -131,6 +131,8 @@ typedef struct th_counters {
     uint64_t live;           /* pos != inert */
     uint64_t nan;            /* any component NaN */
     uint64_t capped;         /* live and |vel| >= speedLimit*(1 - 2^-20) */
+    uint64_t respawned;      /* particles (re)spawned into the state ring on this context since th_create: every texel
+                                of a th_spawn_ball pass, the accepted candidates of a th_spawn_sample pass */
     double sum_speed;        /* sum of |vel| over live, finite particles */
     double max_speed;        /* max |vel| over live, finite particles */
 } th_counters;

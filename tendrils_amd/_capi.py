@@ -63,7 +63,8 @@ class SpawnSampleUniforms(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("particles", C.c_uint64), ("live", C.c_uint64), ("nan", C.c_uint64),
-                ("capped", C.c_uint64), ("sum_speed", C.c_double), ("max_speed", C.c_double)]
+                ("capped", C.c_uint64), ("respawned", C.c_uint64),
+                ("sum_speed", C.c_double), ("max_speed", C.c_double)]
 
 
 _ctx = C.c_void_p

@@ -125,6 +125,7 @@ struct th_context {
     unsigned int *d_flag = nullptr;
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
+    unsigned long long *d_respawned = nullptr;   // [0]: particles replaced by respawn passes, [1]: scratch (passes into `targets`)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool kernel_timing = false;          // th_kernel_timing: event pair around every logic launch
     std::vector<hipEvent_t> kt_events;   // pairs (start, stop); kt_used of them recorded
@@ -382,6 +383,8 @@ th_status th_create(const th_config *cfg, th_context **out)
         TH_HIP(hipMalloc((void **)&c->d_flag, sizeof(unsigned int)));
         TH_HIP(hipMalloc((void **)&c->partials, th::kStatsBlocks * sizeof(th::StatsPartial)));
         TH_HIP(hipMalloc((void **)&c->d_counters, sizeof(th_counters)));
+        TH_HIP(hipMalloc((void **)&c->d_respawned, 2 * sizeof(unsigned long long)));
+        TH_HIP(hipMemset(c->d_respawned, 0, 2 * sizeof(unsigned long long)));
         // Tendrils ctor: flow and targets start as 1x1 float FBOs (src/index.js:102-105);
         // setupParticles gives targets the particle shape (src/index.js:207).
         c->fw = c->fh = 1;
@@ -413,7 +416,7 @@ th_status th_destroy(th_context *c)
     for (float4 *b : c->ring) (void)hipFree(b);
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
-    (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
     (void)hipFree(c->perm); (void)hipFree(c->perm_alt); (void)hipFree(c->src_slot); (void)hipFree(c->spare);
@@ -858,6 +861,7 @@ th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t 
     p.out = rt; p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
     p.u = *u;
     th::launch_spawn_ball(p, c->stream);
+    if (target != TH_TARGET_TARGETS) th::launch_counter_add(c->d_respawned, c->texels(), c->stream);
     TH_HIP(hipGetLastError());
     return commit_target(c, out, rt);
 }
@@ -892,6 +896,7 @@ th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int3
     p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
     p.wf = (float)c->cfg.width; p.hf = (float)c->cfg.global_height;
     p.u = *u;
+    p.accepted = c->d_respawned + (target == TH_TARGET_TARGETS ? 1 : 0);
     th::launch_spawn_sample(p, c->stream);
     TH_HIP(hipGetLastError());
     return commit_target(c, out, rt);
@@ -952,7 +957,7 @@ th_status th_stats_async(th_context *c, float speed_limit, void **device_counter
     TH_REQUIRE(!c->ring.empty(), "no state buffers");
     float4 *view = nullptr;
     if (th_status s = unpacked_view(c, c->ring[0], 0, &view)) return s;
-    th::launch_stats(view, c->texels(), speed_limit, c->partials, c->d_counters, c->stream);
+    th::launch_stats(view, c->texels(), speed_limit, c->partials, c->d_respawned, c->d_counters, c->stream);
     TH_HIP(hipGetLastError());
     if (device_counters) *device_counters = c->d_counters;
     return TH_OK;

@@ -1115,6 +1115,7 @@ __global__ __launch_bounds__(256) void spawn_sample_kernel(const SpawnSamplePara
         float tt = u.time * 0.001f;
         float add = 1.2345f + tt;
         float b0 = st.x + uvx + add, b1 = st.y + uvy + add, b2 = st.z + uvx + add, b3 = st.w + uvy + add;
+        bool took = false;
         for (int n = 0; n < u.samples; ++n) {
             float fn = (float)n;
             float su = mod_glsl(random_glsl(b0 + fn, b1 + fn), 1.0f);
@@ -1146,9 +1147,12 @@ __global__ __launch_bounds__(256) void spawn_sample_kernel(const SpawnSamplePara
             }
             float4 cand = make_float4(other.x, other.y, other.z * u.speed, other.w * u.speed);
             float tc = st.z * st.z + st.w * st.w, tn = cand.z * cand.z + cand.w * cand.w;
-            if (!(tc > u.bias * tn)) st = cand;
+            if (!(tc > u.bias * tn)) { st = cand; took = true; }
         }
         p.out[idx] = st;
+        const unsigned long long wave = __ballot(took);                 // statistics only: one atomic per wave
+        if (wave != 0ull && (threadIdx.x & 63u) == (unsigned)__builtin_ctzll(wave))
+            atomicAdd(p.accepted, (unsigned long long)__builtin_popcountll(wave));
     }
 }
 
@@ -1228,7 +1232,15 @@ __global__ __launch_bounds__(256) void stats_kernel(const float4 *st, size_t n, 
     }
 }
 
-__global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *part, int nparts, size_t n, th_counters *out)
+__global__ void counter_add_kernel(unsigned long long *counter, unsigned long long n) { *counter += n; }
+
+void launch_counter_add(unsigned long long *counter, unsigned long long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, s, counter, n);
+}
+
+__global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *part, int nparts, size_t n,
+                                                          const unsigned long long *respawned, th_counters *out)
 {
     __shared__ StatsPartial sh[4];
     unsigned long long live = 0, nan = 0, capped = 0;
@@ -1249,6 +1261,7 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *par
     if (threadIdx.x == 0) {
         th_counters c{};
         c.particles = n;
+        c.respawned = *respawned;
         for (int w = 0; w < 4; ++w) {
             c.live += sh[w].live; c.nan += sh[w].nan; c.capped += sh[w].capped;
             c.sum_speed += sh[w].sum_speed;
@@ -1259,12 +1272,12 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *par
 }
 
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,
-                  th_counters *out, hipStream_t s)
+                  const unsigned long long *respawned, th_counters *out, hipStream_t s)
 {
     int grid = grid_for(n, 4);
     if (grid > kStatsBlocks) grid = kStatsBlocks;
     hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, s, state, n, speed_limit, partials);
-    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, s, partials, grid, n, out);
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, s, partials, grid, n, respawned, out);
 }
 
 }  // namespace th

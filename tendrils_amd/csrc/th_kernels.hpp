@@ -75,6 +75,7 @@ struct SpawnSampleParams {
     float wf, hf;
     int32_t dw, dh;
     th_spawn_sample_uniforms u;
+    unsigned long long *accepted;   // += particles that took a candidate
 };
 
 struct StatsPartial {
@@ -97,8 +98,9 @@ void launch_permute_ids(uint32_t *dst, const uint32_t *old_perm, const uint32_t 
 void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t stream);
 void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
 void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
-void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,
+void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials, const unsigned long long *respawned,
                   th_counters *out, hipStream_t stream);
+void launch_counter_add(unsigned long long *counter, unsigned long long n, hipStream_t s);
 void launch_optical_flow(const OpticalFlowParams &p, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);

@@ -342,9 +342,10 @@ napi_value Stats(napi_env env, napi_callback_info info)
     TH_CALL("th_stats", th_stats(c, (float)limit, &k));
     napi_value o, v;
     NAPI_OK(napi_create_object(env, &o));
-    const char *names[] = {"particles", "live", "nan", "capped", "sumSpeed", "maxSpeed"};
-    double vals[] = {(double)k.particles, (double)k.live, (double)k.nan, (double)k.capped, k.sum_speed, k.max_speed};
-    for (int i = 0; i < 6; ++i) {
+    const char *names[] = {"particles", "live", "nan", "capped", "respawned", "sumSpeed", "maxSpeed"};
+    double vals[] = {(double)k.particles, (double)k.live, (double)k.nan, (double)k.capped, (double)k.respawned,
+                     k.sum_speed, k.max_speed};
+    for (int i = 0; i < 7; ++i) {
         NAPI_OK(napi_create_double(env, vals[i], &v));
         NAPI_OK(napi_set_named_property(env, o, names[i], v));
     }

@@ -18,7 +18,7 @@ def shard_rows(global_height, world, rank):
     return row0, rows
 
 
-COUNT_FIELDS = ("particles", "live", "nan", "capped")
+COUNT_FIELDS = ("particles", "live", "nan", "capped", "respawned")
 
 
 def reduce_counters(dist, counters, device=None):
@@ -39,7 +39,7 @@ def reduce_counters(dist, counters, device=None):
 
 
 class DeviceCounters:
-    """Zero-copy torch views of the context's device-side th_counters block (4 x u64, 2 x f64)
+    """Zero-copy torch views of the context's device-side th_counters block (5 x u64, 2 x f64)
     so that RCCL can reduce it in place on the context's own stream."""
 
     def __init__(self, dptr):
@@ -49,9 +49,9 @@ class DeviceCounters:
             def __init__(self, ptr, n, typestr):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
                                                  "version": 3, "strides": None}
-        self.counts = torch.as_tensor(_Span(dptr, 4, "<i8"), device="cuda")
-        self.sum_speed = torch.as_tensor(_Span(dptr + 32, 1, "<f8"), device="cuda")
-        self.max_speed = torch.as_tensor(_Span(dptr + 40, 1, "<f8"), device="cuda")
+        self.counts = torch.as_tensor(_Span(dptr, 5, "<i8"), device="cuda")
+        self.sum_speed = torch.as_tensor(_Span(dptr + 40, 1, "<f8"), device="cuda")
+        self.max_speed = torch.as_tensor(_Span(dptr + 48, 1, "<f8"), device="cuda")
 
     def all_reduce_async(self, dist):
         return [dist.all_reduce(self.counts, op=dist.ReduceOp.SUM, async_op=True),

@@ -54,9 +54,12 @@ def test_spawn_sample(oracle, path):
     assert abs(t.timer.time - un["time"]) < 1e-9
     assert np.allclose(sp.jitter, un["jitter"])
     got = t.particles.read(0)
+    respawned = t.particles.stats(0.01)["respawned"]
     t.dispose()
     want = oracle_spawn(oracle, fx)
     assert bits_equal(got, want).all()
+    # the respawn counter (th_counters.respawned) = particles that took a candidate
+    assert respawned == int((~bits_equal(want, fx["state"]).all(-1)).sum()) > 0
 
 
 def test_spawn_init_and_targets(oracle):
@@ -69,6 +72,7 @@ def test_spawn_init_and_targets(oracle):
     order = list(t.particles.buffers)
     spawnBall(None, dict(uniforms=dict(radius=0.25, speed=0.0))).spawn(t, t.targets)
     assert t.particles.buffers == order
+    assert t.particles.stats(0.01)["respawned"] == 64 * 64          # the ball pass; the pass into `targets` is not a respawn
     assert bits_equal(t.targets.read(), oracle.spawn_ball(64, 64, radius=0.25, speed=0.0)).all()
     assert bits_equal(t.particles.read(b0), ball).all()
     spawner().spawn(t)                                     # default program: all inert

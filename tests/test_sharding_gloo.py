@@ -47,14 +47,14 @@ def _worker(rank, world, port, n, out_dir):
     live = (band[..., 0] != -1e6) | (band[..., 1] != -1e6)
     sp = np.hypot(band[..., 2].astype(np.float64), band[..., 3].astype(np.float64))[live]
     local = dict(particles=band.shape[0] * n, live=int(live.sum()), nan=int(np.isnan(band).any(-1).sum()),
-                 capped=int((sp >= 0.01 * (1 - 2 ** -20)).sum()), sum_speed=float(sp.sum()),
+                 capped=int((sp >= 0.01 * (1 - 2 ** -20)).sum()), respawned=100 + rank, sum_speed=float(sp.sum()),
                  max_speed=float(sp.max()))
     red = reduce_counters(dist, local)
     if rank == 0:
         full = O.logic_step(u, st, fl)
         np.save(os.path.join(out_dir, "full.npy"), full)
         np.save(os.path.join(out_dir, "red.npy"), np.array([red[k] for k in
-                ("particles", "live", "nan", "capped", "sum_speed", "max_speed")], np.float64))
+                ("particles", "live", "nan", "capped", "sum_speed", "max_speed", "respawned")], np.float64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,3 +83,4 @@ def test_two_rank_bands_equal_unsharded_run(tmp_path, oracle):
     sp = np.hypot(full[..., 2].astype(np.float64), full[..., 3].astype(np.float64))[live]
     assert red[0] == n * n and red[1] == live.sum() and red[2] == 0
     assert abs(red[4] - sp.sum()) < 1e-9 * max(1.0, sp.sum()) and red[5] == sp.max()
+    assert red[6] == sum(100 + r for r in range(world))          # respawn counts add up over the ranks
