@@ -263,6 +263,69 @@ def gen_logic_config_bands(r, only):
              uniforms=json.dumps(meta))
 
 
+def gen_deposit(r, only):
+    """Tendrils.draw()'s flow pass (src/index.js:278-303) on the reference: current / previous state textures in,
+    flow FBO out.  The output is stored sparsely (texels that differ from the initial flow).  Every vertex pair
+    drawn here has two live vertices (the reference's behaviour with an inert vertex is undefined, see the oracle)."""
+    def case(name, n, view, seed, pos_range=1.0, step=0.03, with_flow=False, inert=0.0, layout=None, time=5016.67,
+             uniforms=None):
+        if only and only not in name:
+            return
+        rng = np.random.default_rng(seed)
+        fw, fh = view
+        prev = np.zeros((n, n, 4), np.float32)
+        if layout == "cells":            # one short line per 16x16-texel cell: isolated lines, ties provoked
+            cell = fw // n
+            for y in range(n):
+                for x in range(n):
+                    p0 = np.array([x * cell + 5 + rng.uniform(0, 6), y * cell + 5 + rng.uniform(0, 6)])
+                    if rng.random() < 0.15:
+                        p0 = np.round(p0 * 16) / 16
+                    prev[y, x, :2] = p0 / fw * 2 - 1
+            ang = rng.uniform(0, 2 * np.pi, (n, n))
+            length = rng.uniform(0, step, (n, n))
+            d = np.stack([np.cos(ang), np.sin(ang)], -1) * length[..., None] / fw * 2
+        elif layout == "border":         # endpoints concentrated around the edge of the view
+            side = rng.integers(0, 4, (n, n))
+            u = rng.uniform(-1.05, 1.05, (n, n))
+            e = rng.uniform(0.93, 1.07, (n, n)) * np.where(rng.random((n, n)) < 0.5, 1, -1)
+            prev[..., 0] = np.where(side < 2, e, u)
+            prev[..., 1] = np.where(side < 2, u, e) * (fh / fw)
+            d = rng.uniform(-step, step, (n, n, 2))
+        else:
+            prev[..., :2] = rng.uniform(-pos_range, pos_range, (n, n, 2))
+            d = rng.uniform(-step, step, (n, n, 2))
+        prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+        cur = prev.copy()
+        cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+        cur[..., :2] = (prev[..., :2] + d).astype(np.float32)
+        if inert > 0:
+            k = rng.random((n, n)) < inert
+            cur[k] = [INERT, INERT, 0, 0]
+            prev[k] = [INERT, INERT, 0, 0]
+        fl = None
+        if with_flow:
+            fl = rand_flow(rng, fw, fh, time, 0.01)
+        out, res = r.deposit(cur, prev, flow=fl, uniforms=uniforms, time=time, view=view)
+        base = fl if fl is not None else np.zeros((fh, fw, 4), np.float32)
+        idx = np.flatnonzero((out != base).any(-1)).astype(np.int32)
+        meta = dict(kind="deposit", N=n, viewRes=[fw, fh], viewSize=res["viewSize"], time=time,
+                    speedLimit=res["state"]["speedLimit"], seed=seed, lineWidthRange=res["lineWidthRange"],
+                    overrides=uniforms or {})
+        arrs = dict(current=cur, previous=prev, idx=idx, val=out.reshape(-1, 4)[idx], uniforms=json.dumps(meta))
+        if fl is not None:
+            arrs["flow"] = fl
+        save(name, **arrs)
+
+    case("deposit_isolated_64", 64, (1024, 1024), 301, layout="cells", step=4.5, time=1234.0)
+    case("deposit_subtexel_64", 64, (1024, 1024), 302, layout="cells", step=0.15, time=1234.0)
+    case("deposit_overlap_32", 32, (64, 64), 303)
+    case("deposit_nonsquare_flow_32", 32, (96, 54), 304, with_flow=True, inert=0.1)
+    case("deposit_border_48", 48, (96, 54), 305, layout="border", step=0.06)
+    case("deposit_long_lines_32", 32, (64, 64), 306, pos_range=1.3, step=0.2)
+    case("deposit_speedlimit_32", 32, (80, 60), 307, uniforms={"speedLimit": 0.004})
+
+
 def gen_optical_flow(r, only):
     """One blended pass of the reference's optical-flow shader (docs/js/demo.js:73) per case.
     Frames are regenerated from seeds by tests/helpers.py:synth_frame; only parameters and the
@@ -344,6 +407,7 @@ def main():
     gen_logic_denormal(r, args.only)
     gen_logic_4096(r, args.only)
     gen_logic_config_bands(r, args.only)
+    gen_deposit(r, args.only)
     gen_optical_flow(r, args.only)
     gen_spawn(r, args.only)
 

@@ -72,6 +72,11 @@ def build(force=False):
 _lib = None
 
 
+class DepositUniforms(C.Structure):
+    _fields_ = [("data_w", C.c_int32), ("data_h", C.c_int32), ("viewSize", C.c_float * 2),
+                ("time", C.c_float), ("speedLimit", C.c_float)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -95,6 +100,8 @@ def lib():
         L.to_spawn_ball.argtypes = [C.POINTER(SpawnBallUniforms), fp, C.c_int, C.c_int, C.c_int]
         L.to_spawn_sample.restype = None
         L.to_spawn_sample.argtypes = [C.POINTER(SpawnSampleUniforms), fp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.to_flow_deposit.restype = C.c_long
+        L.to_flow_deposit.argtypes = [C.POINTER(DepositUniforms), fp, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -199,3 +206,20 @@ def spawn_sample(u, particles, spawn_data, y0=0):
     sh, sw = spawn_data.shape[:2]
     lib().to_spawn_sample(C.byref(u), _fp(particles), _fp(out), int(y0), int(rows), _fp(spawn_data), sw, sh)
     return out
+
+
+def flow_deposit(current, previous, flow, time, view_size=(1.0, 1.0), speedLimit=0.01, coverage=False):
+    """Tendrils.draw()'s flow pass: blends the particle lines into a copy of `flow` [fh, fw, 4].
+    Returns (flow_out, fragments[, per-texel fragment counts])."""
+    current = np.ascontiguousarray(current, np.float32)
+    previous = np.ascontiguousarray(previous, np.float32)
+    out = np.array(flow, np.float32, copy=True, order="C")
+    h, w = current.shape[:2]
+    assert previous.shape == current.shape and current.shape[2] == 4 and out.shape[2] == 4
+    fh, fw = out.shape[:2]
+    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(speedLimit))
+    u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+    cov = np.zeros((fh, fw), np.int32) if coverage else None
+    n = lib().to_flow_deposit(C.byref(u), _fp(current), _fp(previous), _fp(out), fw, fh,
+                              cov.ctypes.data_as(C.POINTER(C.c_int32)) if coverage else None)
+    return (out, n, cov) if coverage else (out, n)

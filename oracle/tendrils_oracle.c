@@ -452,3 +452,180 @@ void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, 
         }
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Flow deposit.  Restates what the reference's draw() does to the flow FBO on the GL it was
+ * captured on (WebGL 1 over SwiftShader: ALIASED_LINE_WIDTH_RANGE = [1, 1]), pinned by tests/golden/deposit_*.npz:
+ *   vertex stream   Particles.generateLUT([w, 2h]): uv = (i/(w-1), j/(2h-1)) as Float32, i outer, j inner
+ *                   (src/particles.js:171-190); gl.LINES pairs stream vertices (2k, 2k+1) = (i, j = 2m), (i, 2m+1)
+ *   vertex shader   stateAtFrame (src/state/state-at-frame.glsl:12-22): nearIndex = uv.y*dataRes.y; the vertex reads
+ *                   `current` when fract(nearIndex) > 0.25, else `previous`, at (uv.x, floor(nearIndex)/dataRes.y);
+ *                   gl_Position = (state.xy*viewSize, 1, 1), color = (vel, time, min(|vel|/speedLimit, 1))
+ *                   (src/flow/vert/main.vert:10-17, apply/state.glsl:5-16) - only when state.xy != inert.
+ *                   (About half of the pairs read `current` twice at the same texel - zero-length, no fragments -
+ *                   as nearIndex drifts by j/(2h-1): that is the reference's behaviour and is kept.)
+ *   DEVIATION       a pair with an inert vertex: the reference leaves gl_Position and the varying unwritten
+ *                   (undefined by GLSL ES 1.00 10.x; the captured GL draws streaks towards clip-space (0,0,0,0)).
+ *                   Here such a pair draws nothing.
+ *   rasteriser      width-1 line = the hexagon spanned by the two endpoint diamonds (|dx|+|dy| <= 1/2 px), clipped
+ *                   to the view volume in clip space, vertices snapped to 1/16 px, scan-converted with ceil() edges:
+ *                   texel centres with left <= x < right (reproduces the captured coverage texel for texel: ties,
+ *                   sub-texel lines and lines crossing the view's edge included)
+ *   interpolation   the varying is linear along the SNAPPED endpoints (orthogonal projection, extrapolated beyond
+ *                   them, unclamped); coinciding snapped endpoints give the first vertex's values
+ *   blend           SRC_ALPHA, ONE_MINUS_SRC_ALPHA on all four channels, lines in stream order (src/index.js:267-268)
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { int live; float px, py; float c[4]; } deposit_vertex;
+
+static void deposit_fetch(const to_deposit_uniforms *u, const float *current, const float *previous,
+                          int i, int j, deposit_vertex *v)
+{
+    const int W = u->data_w, H = u->data_h;
+    const int lw = W > 2 ? W : 2, lh = 2 * H > 2 ? 2 * H : 2;
+    const double inv_x = 1.0 / (double)(lw - 1), inv_y = 1.0 / (double)(lh - 1);
+    const float uvx = (float)((double)i * inv_x), uvy = (float)((double)j * inv_y);   /* Float32Array of JS doubles */
+    const float near_index = uvy * (float)H;
+    const float fl = floorf(near_index);
+    const float offset = near_index - fl;                                             /* fract() */
+    const float ly = fl / (float)H;
+    const float *tex = offset > 0.25f ? current : previous;
+    const float *t = tex + 4 * ((size_t)nearest_texel(ly, H) * W + nearest_texel(uvx, W));
+    v->live = (t[0] != TO_INERT) || (t[1] != TO_INERT);
+    v->px = t[0] * u->viewSize[0];
+    v->py = t[1] * u->viewSize[1];
+    v->c[0] = t[2]; v->c[1] = t[3]; v->c[2] = u->time;
+    v->c[3] = fminf(sqrtf(t[2] * t[2] + t[3] * t[3]) / u->speedLimit, 1.0f);
+}
+
+static inline long ceil_div(long long a, long long b)     /* b > 0 */
+{
+    long long q = a / b;
+    if (a % b > 0) ++q;
+    return (long)q;
+}
+
+static inline int snap16(float ndc, float scale, float offset) { return (int)lrintf(ndc * scale + offset); }
+
+long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const float *previous,
+                     float *flow, int fw, int fh, int32_t *coverage)
+{
+    const int W = u->data_w, H = u->data_h;
+    const float wx16 = 8.0f * (float)fw, wy16 = 8.0f * (float)fh;          /* 16 * viewport/2 */
+    const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;                         /* texel centres at integer*16 */
+    const float hx = 0.5f / (0.5f * (float)fw), hy = 0.5f / (0.5f * (float)fh);   /* half a texel in NDC */
+    long fragments = 0;
+    enum { SPAN = 64 };
+    for (int i = 0; i < W; ++i) {
+        for (int m = 0; m < H; ++m) {
+            deposit_vertex a, b;
+            deposit_fetch(u, current, previous, i, 2 * m, &a);
+            deposit_fetch(u, current, previous, i, 2 * m + 1, &b);
+            if (!a.live || !b.live) continue;                                /* DEVIATION, see above */
+            const float dx = (0.5f * (float)fw) * (b.px - a.px), dy = (0.5f * (float)fh) * (b.py - a.py);
+            if (dx == 0.0f && dy == 0.0f) continue;
+            /* fixed-point range: endpoints beyond 1024 half-widths of the view (or non-finite) deposit nothing */
+            if (!(fabsf(a.px) <= 1024.0f && fabsf(a.py) <= 1024.0f && fabsf(b.px) <= 1024.0f && fabsf(b.py) <= 1024.0f))
+                continue;
+            /* the hexagon in clip space (w = 1): left, top, right, bottom of both endpoint diamonds */
+            const deposit_vertex *vv[2] = {&a, &b};
+            float hxv[6], hyv[6];
+            int sx[2], sy[2];
+            for (int k = 0; k < 2; ++k) { sx[k] = snap16(vv[k]->px, wx16, x0); sy[k] = snap16(vv[k]->py, wy16, y0); }
+#define TO_L(n, k) do { hxv[n] = vv[k]->px - hx; hyv[n] = vv[k]->py; } while (0)
+#define TO_T(n, k) do { hxv[n] = vv[k]->px; hyv[n] = vv[k]->py + hy; } while (0)
+#define TO_R(n, k) do { hxv[n] = vv[k]->px + hx; hyv[n] = vv[k]->py; } while (0)
+#define TO_B(n, k) do { hxv[n] = vv[k]->px; hyv[n] = vv[k]->py - hy; } while (0)
+            if (dx > dy) {
+                if (dx > -dy) { TO_L(0, 0); TO_T(1, 0); TO_T(2, 1); TO_R(3, 1); TO_B(4, 1); TO_B(5, 0); }
+                else          { TO_L(0, 1); TO_L(1, 0); TO_T(2, 0); TO_R(3, 0); TO_R(4, 1); TO_B(5, 1); }
+            } else {
+                if (dx > -dy) { TO_L(0, 0); TO_L(1, 1); TO_T(2, 1); TO_R(3, 1); TO_R(4, 0); TO_B(5, 0); }
+                else          { TO_L(0, 1); TO_T(1, 1); TO_T(2, 0); TO_R(3, 0); TO_B(4, 0); TO_B(5, 1); }
+            }
+#undef TO_L
+#undef TO_T
+#undef TO_R
+#undef TO_B
+            /* clip against the view volume's side planes (Sutherland-Hodgman, intersection as
+             * (dj*Vi - di*Vj) * (1/(dj - di)) with the inside vertex first), then snap to 1/16 texel */
+            float cx[16], cy[16], tx_[16], ty_[16];
+            int n = 6;
+            for (int k = 0; k < 6; ++k) { cx[k] = hxv[k]; cy[k] = hyv[k]; }
+            for (int plane = 0; plane < 4 && n >= 3; ++plane) {
+                int t = 0;
+                for (int k = 0; k < n; ++k) {
+                    const int j = k == n - 1 ? 0 : k + 1;
+                    float di, dj;
+                    switch (plane) {
+                    case 0: di = 1.0f + cx[k]; dj = 1.0f + cx[j]; break;     /* left   */
+                    case 1: di = 1.0f - cx[k]; dj = 1.0f - cx[j]; break;     /* right  */
+                    case 2: di = 1.0f - cy[k]; dj = 1.0f - cy[j]; break;     /* top    */
+                    default: di = 1.0f + cy[k]; dj = 1.0f + cy[j]; break;    /* bottom */
+                    }
+                    if (di >= 0.0f) {
+                        tx_[t] = cx[k]; ty_[t] = cy[k]; ++t;
+                        if (dj < 0.0f) {
+                            const float D = 1.0f / (dj - di);
+                            tx_[t] = (dj * cx[k] - di * cx[j]) * D; ty_[t] = (dj * cy[k] - di * cy[j]) * D; ++t;
+                        }
+                    } else if (dj > 0.0f) {
+                        const float D = 1.0f / (di - dj);
+                        tx_[t] = (di * cx[j] - dj * cx[k]) * D; ty_[t] = (di * cy[j] - dj * cy[k]) * D; ++t;
+                    }
+                }
+                n = t;
+                for (int k = 0; k < n; ++k) { cx[k] = tx_[k]; cy[k] = ty_[k]; }
+            }
+            if (n < 3) continue;
+            int PX[16], PY[16];
+            for (int k = 0; k < n; ++k) { PX[k] = snap16(cx[k], wx16, x0); PY[k] = snap16(cy[k], wy16, y0); }
+            int ymin = PY[0], ymax = PY[0];
+            for (int k = 1; k < n; ++k) { if (PY[k] < ymin) ymin = PY[k]; if (PY[k] > ymax) ymax = PY[k]; }
+            int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;               /* rows [r0, r1) */
+            if (r0 < 0) r0 = 0;
+            if (r1 > fh) r1 = fh;
+            if (r0 >= r1) continue;
+            /* long lines are walked in windows of SPAN rows */
+            for (int base = r0; base < r1; base += SPAN) {
+                const int top = base + SPAN < r1 ? base + SPAN : r1;
+                int left[SPAN], right[SPAN];
+                for (int k = 0; k < top - base; ++k) { left[k] = fw; right[k] = 0; }
+                for (int k = 0; k < n; ++k) {
+                    int Xa = PX[k], Ya = PY[k], Xb = PX[(k + 1) % n], Yb = PY[(k + 1) % n];
+                    if (Ya == Yb) continue;
+                    const int swap = Yb < Ya;
+                    const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
+                    int e0 = (Y1 + 15) >> 4, e1 = (Y2 + 15) >> 4;
+                    if (e0 < base) e0 = base;
+                    if (e1 > top) e1 = top;
+                    const long long DX = X2 - X1, DY = Y2 - Y1;
+                    for (int y = e0; y < e1; ++y) {
+                        long x = ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                        if (x < 0) x = 0;
+                        if (x > fw) x = fw;
+                        if (swap) right[y - base] = (int)x; else left[y - base] = (int)x;
+                    }
+                }
+                const long long ex = sx[1] - sx[0], ey = sy[1] - sy[0], den = ex * ex + ey * ey;
+                for (int y = base; y < top; ++y) {
+                    for (int x = left[y - base]; x < right[y - base]; ++x) {
+                        float c[4];
+                        if (den == 0) { for (int k = 0; k < 4; ++k) c[k] = a.c[k]; }
+                        else {
+                            const long long num = ((long long)(x << 4) - sx[0]) * ex + ((long long)(y << 4) - sy[0]) * ey;
+                            const float t = (float)num / (float)den;
+                            for (int k = 0; k < 4; ++k) c[k] = a.c[k] + t * (b.c[k] - a.c[k]);
+                        }
+                        float *d = flow + 4 * ((size_t)y * fw + x);
+                        const float sa = c[3], da = 1.0f - sa;
+                        for (int k = 0; k < 4; ++k) d[k] = c[k] * sa + d[k] * da;
+                        if (coverage) ++coverage[(size_t)y * fw + x];
+                        ++fragments;
+                    }
+                }
+            }
+        }
+    }
+    return fragments;
+}

@@ -78,6 +78,21 @@ typedef struct to_spawn_sample_uniforms {
 void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, float *out,
                      int y0, int rows, const float *spawn_data, int sw, int sh);
 
+/* Flow deposit: the particle lines of Tendrils.draw() (src/index.js:278-303) rendered into the flow FBO with the
+ * flow shader (src/flow/index.vert -> vert/main.vert:10-17, apply/state.glsl:5-16; index.frag).
+ * data_w/data_h = particle texture shape; the vertex stream is Particles.generateLUT(geomShape = [w, 2h])
+ * (src/particles.js:171-190, src/index.js:195-197) drawn as gl.LINES with lineWidth clamped to 1. */
+typedef struct to_deposit_uniforms {
+    int32_t data_w, data_h;
+    float viewSize[2];
+    float time, speedLimit;
+} to_deposit_uniforms;
+
+/* Blends every line in stream order into flow (fw x fh RGBA32F); returns the number of fragments.
+ * coverage (optional, fw*fh int32) receives the fragment count per texel. */
+long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const float *previous,
+                     float *flow, int fw, int fh, int32_t *coverage);
+
 #ifdef __cplusplus
 }
 #endif
