@@ -125,6 +125,13 @@ typedef struct th_spawn_sample_uniforms {
     int32_t apply;           /* 0: apply/flow.glsl, 1: apply/identity.glsl */
 } th_spawn_sample_uniforms;
 
+/* Uniforms of the flow pass of Tendrils.draw(): src/flow/vert/head.vert:8-12 (viewSize, time, speedLimit). */
+typedef struct th_deposit_uniforms {
+    float viewSize[2];
+    float time;
+    float speedLimit;
+} th_deposit_uniforms;
+
 /* Build-defined statistics (the reference has none). */
 typedef struct th_counters {
     uint64_t particles;      /* texels examined */
@@ -191,6 +198,14 @@ th_status th_frames_rotate(th_context *ctx);                           /* Optica
 /* one full-screen pass of optical-flow/index.frag alpha-blended into flow
  * (src/demo.main.js:1107-1159; blend func src/index.js:267-268). */
 th_status th_optical_flow(th_context *ctx, const th_optical_flow_uniforms *u);
+
+/* -- flow deposit: the flow pass of Tendrils.draw() (src/index.js:278-303) ----- */
+/* Renders every particle's (previous -> current) line (buffers[1] -> buffers[0]) into the flow texture as
+ * (vel, time, min(|vel|/speedLimit, 1)), alpha-blended in the reference's primitive order (width-1 lines: the GL the
+ * reference was captured on clamps flowWidth to 1).  fragments (optional) receives the number of fragments blended;
+ * the call synchronises once (the fragment lists are sized from a device count).
+ * Needs the whole particle texture on this context (TH_ERR_UNSUPPORTED on a row-band shard) and an f32 ring. */
+th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *fragments);
 
 /* -- statistics, sync, interop ---------------------------------------------- */
 th_status th_stats(th_context *ctx, float speed_limit, th_counters *out);   /* of buffers[0]; synchronises */

@@ -61,6 +61,10 @@ class SpawnSampleUniforms(C.Structure):
                 ("samples", C.c_int32), ("apply", C.c_int32)]
 
 
+class DepositUniforms(C.Structure):
+    _fields_ = [("viewSize", C.c_float * 2), ("time", C.c_float), ("speedLimit", C.c_float)]
+
+
 class Counters(C.Structure):
     _fields_ = [("particles", C.c_uint64), ("live", C.c_uint64), ("nan", C.c_uint64),
                 ("capped", C.c_uint64), ("respawned", C.c_uint64),
@@ -98,6 +102,7 @@ PROTOTYPES = {
     "th_frames_upload": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),
     "th_frames_rotate": (C.c_int32, [_ctx]),
     "th_optical_flow": (C.c_int32, [_ctx, C.POINTER(OpticalFlowUniforms)]),
+    "th_flow_deposit": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(C.c_uint64)]),
     "th_stats": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),
     "th_stats_async": (C.c_int32, [_ctx, C.c_float, C.POINTER(C.c_void_p)]),
     "th_sync": (C.c_int32, [_ctx]),

@@ -125,6 +125,10 @@ struct th_context {
     unsigned int *d_flag = nullptr;
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
+    // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
+    uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_cursor = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;
+    uint32_t *dep_list = nullptr;
+    size_t dep_texels = 0, dep_capacity = 0;
     unsigned long long *d_respawned = nullptr;   // [0]: particles replaced by respawn passes, [1]: scratch (passes into `targets`)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool kernel_timing = false;          // th_kernel_timing: event pair around every logic launch
@@ -416,6 +420,8 @@ th_status th_destroy(th_context *c)
     for (float4 *b : c->ring) (void)hipFree(b);
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
+    (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_cursor); (void)hipFree(c->dep_blocks);
+    (void)hipFree(c->dep_total); (void)hipFree(c->dep_list);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
@@ -900,6 +906,57 @@ th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int3
     th::launch_spawn_sample(p, c->stream);
     TH_HIP(hipGetLastError());
     return commit_target(c, out, rt);
+}
+
+th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
+    TH_REQUIRE(u, "null uniforms");
+    TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "flow deposit needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
+    if (c->packed) return fail(TH_ERR_UNSUPPORTED, "flow deposit reads an f32 state ring");
+    const size_t texels = (size_t)c->fw * c->fh;
+    TH_REQUIRE(texels > 0 && (uint64_t)c->cfg.width * c->cfg.height < (1ull << 32), "bad shapes");
+    if (c->dep_texels != texels) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_cursor); (void)hipFree(c->dep_blocks);
+        c->dep_count = c->dep_offset = c->dep_cursor = c->dep_blocks = nullptr;
+        TH_HIP(hipMalloc((void **)&c->dep_count, texels * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_offset, texels * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_cursor, texels * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_blocks((uint32_t)texels) * sizeof(uint32_t)));
+        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, sizeof(uint32_t)));
+        c->dep_texels = texels;
+    }
+    th::DepositParams p{};
+    p.cur = c->ring[0]; p.prev = c->ring[1]; p.flow = c->flow;
+    p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.height;
+    p.fw = c->fw; p.fh = c->fh;
+    p.view_x = u->viewSize[0]; p.view_y = u->viewSize[1]; p.time = u->time; p.speed_limit = u->speedLimit;
+    p.count = c->dep_count; p.offset = c->dep_offset; p.cursor = c->dep_cursor; p.list = c->dep_list;
+    TH_HIP(hipMemsetAsync(c->dep_count, 0, texels * sizeof(uint32_t), c->stream));
+    TH_HIP(hipMemsetAsync(c->dep_cursor, 0, texels * sizeof(uint32_t), c->stream));
+    th::launch_deposit_count(p, c->stream);
+    th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
+    uint32_t total = 0;
+    TH_HIP(hipMemcpyAsync(&total, c->dep_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    if (fragments) *fragments = total;
+    if (total == 0) return TH_OK;
+    if (c->dep_capacity < total) {
+        (void)hipFree(c->dep_list);
+        c->dep_list = nullptr;
+        const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
+        TH_HIP(hipMalloc((void **)&c->dep_list, cap * sizeof(uint32_t)));
+        c->dep_capacity = cap;
+    }
+    p.list = c->dep_list;
+    th::launch_deposit_scatter(p, c->stream);
+    th::launch_deposit_blend(p, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
 }
 
 th_status th_frames_resize(th_context *c, int32_t w, int32_t h)

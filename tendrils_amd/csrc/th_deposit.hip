@@ -1,0 +1,345 @@
+// th_deposit.hip - flow deposit: the particle lines of Tendrils.draw() blended into the flow field.
+//
+// Replaces the flow pass of draw() (src/index.js:278-303): particles.draw(render uniforms, gl.LINES) with the flow
+// shader (src/flow/index.vert -> vert/main.vert:10-17, apply/state.glsl:5-16, index.frag) into the flow FBO, blend
+// SRC_ALPHA / ONE_MINUS_SRC_ALPHA (src/index.js:267-268).  Semantics (vertex stream and pairing, width-1 line =
+// hexagon of the two endpoint diamonds, clip-space clipping, 1/16-texel snapping, ceil() scan conversion, varying
+// linear along the snapped endpoints, blending in stream order; a pair with an inert vertex draws nothing) are the
+// ones pinned against captures of the reference in tests/golden/deposit_*.npz; every arithmetic step below is
+// written in the same order and precision as the checker's restatement so that both agree bit for bit.
+//
+// GL blends fragments in primitive order, which a parallel machine has to reconstruct:
+//   1. deposit_raster_kernel<false>: one thread per line, rasterise, count fragments per flow texel (atomics)
+//   2. exclusive scan of the per-texel counts -> list offsets
+//   3. deposit_raster_kernel<true>: rasterise again, append the line's stream index to every covered texel's list
+//   4. deposit_blend_kernel: one thread per touched texel: sort its list (stream order), re-evaluate each line's
+//      varying at this texel and blend sequentially: dst = src*a + dst*(1-a), exactly GL's order and arithmetic.
+// The result is independent of thread scheduling (lists are sorted before use).
+#include "th_kernels.hpp"
+#include "th_math.hpp"
+
+namespace th {
+namespace {
+
+struct DepositVertex {
+    bool live;
+    float px, py;      // clip-space position (w = 1)
+    float c[4];        // varying: (vel.x, vel.y, time, min(|vel|/speedLimit, 1))
+};
+
+TH_D int dep_nearest(float u, int n)       // NEAREST + CLAMP_TO_EDGE on a float texture
+{
+    float f = th_floor(u * (float)n);
+    if (!(f > 0.0f)) return 0;
+    if (f > (float)(n - 1)) return n - 1;
+    return (int)f;
+}
+
+// vertex j of column i of the stream Particles.generateLUT([W, 2H]) through src/state/state-at-frame.glsl:12-22
+TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
+{
+    const int W = (int)p.W, H = (int)p.H;
+    const int lw = W > 2 ? W : 2, lh = 2 * H > 2 ? 2 * H : 2;
+    const double inv_x = 1.0 / (double)(lw - 1), inv_y = 1.0 / (double)(lh - 1);
+    const float uvx = (float)((double)i * inv_x), uvy = (float)((double)j * inv_y);   // Float32Array of JS doubles
+    const float near_index = uvy * (float)H;
+    const float fl = th_floor(near_index);
+    const float offset = near_index - fl;
+    const float ly = fl / (float)H;
+    const float4 *tex = offset > 0.25f ? p.cur : p.prev;
+    const float4 t = tex[(size_t)dep_nearest(ly, H) * W + dep_nearest(uvx, W)];
+    DepositVertex v;
+    v.live = (t.x != kInert) || (t.y != kInert);
+    v.px = t.x * p.view_x;
+    v.py = t.y * p.view_y;
+    v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
+    v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
+    return v;
+}
+
+TH_D long long dep_ceil_div(long long a, long long b)     // b > 0
+{
+    long long q = a / b;
+    if (a % b > 0) ++q;
+    return q;
+}
+
+TH_D int dep_snap(float ndc, float scale, float offset) { return (int)__builtin_rintf(ndc * scale + offset); }
+
+struct DepositLine {
+    bool draws;
+    DepositVertex a, b;
+    int sx[2], sy[2];          // snapped endpoints (1/16 texel, texel centres at multiples of 16)
+    int n;                     // polygon vertices after clipping
+    int PX[12], PY[12];
+};
+
+// everything about line `id` (stream index = i*H + m) that does not depend on the texel
+TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L, bool need_polygon)
+{
+    const uint32_t i = id / p.H, m = id - i * p.H;
+    L.draws = false;
+    L.a = dep_fetch(p, i, 2u * m);
+    L.b = dep_fetch(p, i, 2u * m + 1u);
+    if (!L.a.live || !L.b.live) return;                                  // see the header: inert vertex = no line
+    const float fw = (float)p.fw, fh = (float)p.fh;
+    const float dx = (0.5f * fw) * (L.b.px - L.a.px), dy = (0.5f * fh) * (L.b.py - L.a.py);
+    if (dx == 0.0f && dy == 0.0f) return;
+    if (!(__builtin_fabsf(L.a.px) <= 1024.0f && __builtin_fabsf(L.a.py) <= 1024.0f &&
+          __builtin_fabsf(L.b.px) <= 1024.0f && __builtin_fabsf(L.b.py) <= 1024.0f)) return;
+    const float wx16 = 8.0f * fw, wy16 = 8.0f * fh;
+    const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
+    L.sx[0] = dep_snap(L.a.px, wx16, x0); L.sy[0] = dep_snap(L.a.py, wy16, y0);
+    L.sx[1] = dep_snap(L.b.px, wx16, x0); L.sy[1] = dep_snap(L.b.py, wy16, y0);
+    L.draws = true;
+    if (!need_polygon) return;
+
+    const float hx = 0.5f / (0.5f * fw), hy = 0.5f / (0.5f * fh);      // half a texel in clip space
+    float cx[12], cy[12], tx[12], ty[12];
+    const DepositVertex *vv[2] = {&L.a, &L.b};
+#define TH_L(n, k) do { cx[n] = vv[k]->px - hx; cy[n] = vv[k]->py; } while (0)
+#define TH_T(n, k) do { cx[n] = vv[k]->px; cy[n] = vv[k]->py + hy; } while (0)
+#define TH_R(n, k) do { cx[n] = vv[k]->px + hx; cy[n] = vv[k]->py; } while (0)
+#define TH_B(n, k) do { cx[n] = vv[k]->px; cy[n] = vv[k]->py - hy; } while (0)
+    if (dx > dy) {
+        if (dx > -dy) { TH_L(0, 0); TH_T(1, 0); TH_T(2, 1); TH_R(3, 1); TH_B(4, 1); TH_B(5, 0); }
+        else          { TH_L(0, 1); TH_L(1, 0); TH_T(2, 0); TH_R(3, 0); TH_R(4, 1); TH_B(5, 1); }
+    } else {
+        if (dx > -dy) { TH_L(0, 0); TH_L(1, 1); TH_T(2, 1); TH_R(3, 1); TH_R(4, 0); TH_B(5, 0); }
+        else          { TH_L(0, 1); TH_T(1, 1); TH_T(2, 0); TH_R(3, 0); TH_B(4, 0); TH_B(5, 1); }
+    }
+#undef TH_L
+#undef TH_T
+#undef TH_R
+#undef TH_B
+    int n = 6;
+    bool inside = true;
+    for (int k = 0; k < 6; ++k)
+        inside = inside && (1.0f + cx[k] >= 0.0f) && (1.0f - cx[k] >= 0.0f) && (1.0f - cy[k] >= 0.0f) && (1.0f + cy[k] >= 0.0f);
+    if (!inside) {
+        // Sutherland-Hodgman against left, right, top, bottom; intersection (dj*Vi - di*Vj) * (1/(dj - di)), inside vertex first
+        for (int plane = 0; plane < 4 && n >= 3; ++plane) {
+            int t = 0;
+            for (int k = 0; k < n; ++k) {
+                const int j = k == n - 1 ? 0 : k + 1;
+                float di, dj;
+                switch (plane) {
+                case 0: di = 1.0f + cx[k]; dj = 1.0f + cx[j]; break;
+                case 1: di = 1.0f - cx[k]; dj = 1.0f - cx[j]; break;
+                case 2: di = 1.0f - cy[k]; dj = 1.0f - cy[j]; break;
+                default: di = 1.0f + cy[k]; dj = 1.0f + cy[j]; break;
+                }
+                if (di >= 0.0f) {
+                    tx[t] = cx[k]; ty[t] = cy[k]; ++t;
+                    if (dj < 0.0f) {
+                        const float D = 1.0f / (dj - di);
+                        tx[t] = (dj * cx[k] - di * cx[j]) * D; ty[t] = (dj * cy[k] - di * cy[j]) * D; ++t;
+                    }
+                } else if (dj > 0.0f) {
+                    const float D = 1.0f / (di - dj);
+                    tx[t] = (di * cx[j] - dj * cx[k]) * D; ty[t] = (di * cy[j] - dj * cy[k]) * D; ++t;
+                }
+            }
+            n = t;
+            for (int k = 0; k < n; ++k) { cx[k] = tx[k]; cy[k] = ty[k]; }
+        }
+        if (n < 3) { L.draws = false; return; }
+    }
+    L.n = n;
+    for (int k = 0; k < n; ++k) { L.PX[k] = dep_snap(cx[k], wx16, x0); L.PY[k] = dep_snap(cy[k], wy16, y0); }
+}
+
+// scan conversion: calls emit(x, y) for every covered texel.  Edges going up in y set `left`, edges going down set
+// `right` (a later edge overwrites an earlier one on the same row, as in the captured rasteriser); texels
+// left <= x < right.  Rows are walked in windows so that arbitrarily long lines need no large arrays.
+template <typename Emit>
+TH_D void dep_raster(const DepositParams &p, const DepositLine &L, Emit emit)
+{
+    int ymin = L.PY[0], ymax = L.PY[0];
+    for (int k = 1; k < L.n; ++k) { ymin = L.PY[k] < ymin ? L.PY[k] : ymin; ymax = L.PY[k] > ymax ? L.PY[k] : ymax; }
+    int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
+    if (r0 < 0) r0 = 0;
+    if (r1 > p.fh) r1 = p.fh;
+    constexpr int kWindow = 8;
+    for (int base = r0; base < r1; base += kWindow) {
+        const int top = base + kWindow < r1 ? base + kWindow : r1;
+        int left[kWindow], right[kWindow];
+#pragma unroll
+        for (int k = 0; k < kWindow; ++k) { left[k] = p.fw; right[k] = 0; }
+        for (int k = 0; k < L.n; ++k) {
+            const int kn = k + 1 == L.n ? 0 : k + 1;
+            const int Xa = L.PX[k], Ya = L.PY[k], Xb = L.PX[kn], Yb = L.PY[kn];
+            if (Ya == Yb) continue;
+            const bool swap = Yb < Ya;
+            const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
+            int e0 = (Y1 + 15) >> 4, e1 = (Y2 + 15) >> 4;
+            if (e0 < base) e0 = base;
+            if (e1 > top) e1 = top;
+            const long long DX = X2 - X1, DY = Y2 - Y1;
+            for (int y = e0; y < e1; ++y) {
+                long long x = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                if (x < 0) x = 0;
+                if (x > p.fw) x = p.fw;
+#pragma unroll
+                for (int w = 0; w < kWindow; ++w)          // static indexing keeps the spans in registers
+                    if (w == y - base) { if (swap) right[w] = (int)x; else left[w] = (int)x; }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < kWindow; ++w)
+            if (base + w < top)
+                for (int x = left[w]; x < right[w]; ++x) emit(x, base + w);
+    }
+}
+
+// passes 1 and 3: count, or append the line id to the covered texels' lists
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams p)
+{
+    const uint32_t lines = p.W * p.H;
+    for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < lines; id += gridDim.x * 256u) {
+        DepositLine L;
+        dep_setup(p, id, L, true);
+        if (!L.draws) continue;
+        dep_raster(p, L, [&](int x, int y) {
+            const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
+            if constexpr (SCATTER) {
+                const uint32_t slot = atomicAdd(&p.cursor[texel], 1u);
+                p.list[p.offset[texel] + slot] = id;
+            } else {
+                atomicAdd(&p.count[texel], 1u);
+            }
+        });
+    }
+}
+
+// pass 4: one thread per flow texel
+__global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p)
+{
+    const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh;
+    for (uint32_t texel = blockIdx.x * 256u + threadIdx.x; texel < texels; texel += gridDim.x * 256u) {
+        const uint32_t n = p.count[texel];
+        if (n == 0) continue;
+        uint32_t *ids = p.list + p.offset[texel];
+        // stream order: ascending line id.  Lists are short (a handful of lines per texel); insertion sort in place.
+        for (uint32_t k = 1; k < n; ++k) {
+            const uint32_t v = ids[k];
+            uint32_t q = k;
+            while (q > 0 && ids[q - 1] > v) { ids[q] = ids[q - 1]; --q; }
+            ids[q] = v;
+        }
+        const int x = (int)(texel % (uint32_t)p.fw), y = (int)(texel / (uint32_t)p.fw);
+        float4 d = p.flow[texel];
+        for (uint32_t k = 0; k < n; ++k) {
+            DepositLine L;
+            dep_setup(p, ids[k], L, false);
+            const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
+            float c[4];
+            if (den == 0) {
+                for (int q = 0; q < 4; ++q) c[q] = L.a.c[q];
+            } else {
+                const long long num = ((long long)(x << 4) - L.sx[0]) * ex + ((long long)(y << 4) - L.sy[0]) * ey;
+                const float t = (float)num / (float)den;
+                for (int q = 0; q < 4; ++q) c[q] = L.a.c[q] + t * (L.b.c[q] - L.a.c[q]);
+            }
+            const float sa = c[3], da = 1.0f - sa;
+            d.x = c[0] * sa + d.x * da;
+            d.y = c[1] * sa + d.y * da;
+            d.z = c[2] * sa + d.z * da;
+            d.w = c[3] * sa + d.w * da;
+        }
+        p.flow[texel] = d;
+    }
+}
+
+// ---- exclusive scan of the per-texel counts (three small kernels; 1024 elements per block) --------------------
+constexpr uint32_t kScanBlock = 1024;
+
+__global__ __launch_bounds__(256) void scan_local_kernel(const uint32_t *in, uint32_t *out, uint32_t *block_sums, uint32_t n)
+{
+    __shared__ uint32_t sh[256];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256u; o <<= 1) {           // Hillis-Steele over the 256 thread sums
+        uint32_t add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - s;                 // exclusive prefix of this thread inside the block
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+}
+
+__global__ __launch_bounds__(256) void scan_blocks_kernel(uint32_t *block_sums, uint32_t nblocks, uint32_t *total)
+{
+    __shared__ uint32_t carry;
+    __shared__ uint32_t sh[256];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 256u) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = idx < nblocks ? block_sums[idx] : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256u; o <<= 1) {
+            uint32_t add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (idx < nblocks) block_sums[idx] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sh[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *out, const uint32_t *block_sums, uint32_t n)
+{
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    const uint32_t add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
+}
+
+int deposit_grid(uint32_t n)
+{
+    uint32_t g = (n + 255u) / 256u;
+    return (int)(g < 1u ? 1u : (g > 8192u ? 8192u : g));
+}
+
+}  // namespace
+
+uint32_t deposit_scan_blocks(uint32_t texels) { return (texels + kScanBlock - 1) / kScanBlock; }
+
+void launch_deposit_count(const DepositParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(deposit_raster_kernel<false>, dim3(deposit_grid(p.W * p.H)), dim3(256), 0, s, p);
+}
+
+void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t s)
+{
+    const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh, nb = deposit_scan_blocks(texels);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, s, p.count, p.offset, block_sums, texels);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, block_sums, nb, total);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, s, p.offset, block_sums, texels);
+}
+
+void launch_deposit_scatter(const DepositParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(deposit_raster_kernel<true>, dim3(deposit_grid(p.W * p.H)), dim3(256), 0, s, p);
+}
+
+void launch_deposit_blend(const DepositParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid((uint32_t)p.fw * (uint32_t)p.fh)), dim3(256), 0, s, p);
+}
+
+}  // namespace th

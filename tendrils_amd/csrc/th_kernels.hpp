@@ -78,6 +78,17 @@ struct SpawnSampleParams {
     unsigned long long *accepted;   // += particles that took a candidate
 };
 
+// flow deposit (th_deposit.hip): draw()'s flow pass
+struct DepositParams {
+    const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order
+    float4 *flow;
+    uint32_t W, H;               // particle texture shape
+    int32_t fw, fh;              // flow texture shape
+    float view_x, view_y, time, speed_limit;
+    uint32_t *count, *offset, *cursor;   // per flow texel: fragments, list start, fill cursor
+    uint32_t *list;              // line stream indices, grouped by texel
+};
+
 struct StatsPartial {
     unsigned long long live, nan, capped;
     double sum_speed, max_speed;
@@ -102,6 +113,11 @@ void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial
                   th_counters *out, hipStream_t stream);
 void launch_counter_add(unsigned long long *counter, unsigned long long n, hipStream_t s);
 void launch_optical_flow(const OpticalFlowParams &p, hipStream_t stream);
+uint32_t deposit_scan_blocks(uint32_t texels);
+void launch_deposit_count(const DepositParams &p, hipStream_t stream);
+void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
+void launch_deposit_blend(const DepositParams &p, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
 constexpr int kStatsBlocks = 1024;

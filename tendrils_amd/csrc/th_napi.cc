@@ -331,6 +331,21 @@ napi_value OpticalFlow(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// flowDeposit(ctx, Float32Array [viewSize.x, viewSize.y, time, speedLimit]) -> fragments
+napi_value FlowDeposit(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_deposit_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_flow_deposit");
+    uint64_t fragments = 0;
+    TH_CALL("th_flow_deposit", th_flow_deposit(c, &u, &fragments));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)fragments, &v));
+    return v;
+}
+
 // stats(ctx, speedLimit) -> {particles, live, nan, capped, sumSpeed, maxSpeed}
 napi_value Stats(napi_env env, napi_callback_info info)
 {
@@ -413,6 +428,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"spawnInit", SpawnInit}, {"spawnBall", SpawnBall}, {"spawnSample", SpawnSample},
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
+        {"flowDeposit", FlowDeposit},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},
     };

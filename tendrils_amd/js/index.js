@@ -1,7 +1,8 @@
 'use strict';
 // Mirror of the reference's facade `Tendrils` (src/index.js:84-457) for the particle-update
 // path: state uniforms, timer, flow/targets textures, step(), spawn(), spawnShader(), resize().
-// Rendering (draw, view buffers, fades) is out of this build's scope and kept as chainable no-ops.
+// draw() runs the flow pass (particle lines into the flow field); the view render (view buffers, fades) is out of
+// this build's scope and kept as chainable no-ops.
 const native = require('./native');
 const { Particles, Program } = require('./particles');
 const { Timer } = require('./timer');
@@ -158,7 +159,11 @@ class Tendrils {
     return this;
   }
 
-  draw() { return this; }                          // src/index.js:278-340: out of scope
+  draw() {                                         // src/index.js:278-340: the flow pass (the view render is outside this build)
+    this.fragments = native.flowDeposit(this.particles.handle,
+      new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]));
+    return this;
+  }
 
   resize() {                                       // src/index.js:393-408
     this.viewRes[0] = this.gl.drawingBufferWidth;

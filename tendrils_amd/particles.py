@@ -186,6 +186,15 @@ class Particles:
     def sync(self):
         call("th_sync", self._ctx)
 
+    def deposit_flow(self, view_size, time, speed_limit):
+        """The flow pass of Tendrils.draw(): (previous -> current) lines blended into the flow texture
+        (src/index.js:295-303, src/particles.js:147-158).  Returns the number of fragments."""
+        u = _capi.DepositUniforms(time=float(time), speedLimit=float(speed_limit))
+        u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+        n = C.c_uint64(0)
+        call("th_flow_deposit", self._ctx, C.byref(u), C.byref(n))
+        return int(n.value)
+
     def stats(self, speed_limit):
         c = _capi.Counters()
         call("th_stats", self._ctx, C.c_float(speed_limit), C.byref(c))

@@ -216,7 +216,10 @@ class Tendrils:
             tm.tick()
         return self
 
-    def draw(self):                                            # src/index.js:278-340: out of scope
+    def draw(self):                                            # src/index.js:278-340
+        """The flow pass: particle lines into the flow texture (so that particles respond to each other's
+        wake).  The view render of the reference's draw() (display) is outside this build."""
+        self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
         return self
 
     def resize(self):                                          # src/index.js:393-408

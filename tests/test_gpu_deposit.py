@@ -1,0 +1,112 @@
+"""Flow deposit on the GPU (th_flow_deposit behind Tendrils.draw()): bit for bit against the CPU restatement
+(same arithmetic, same stream-order blending - the result must not depend on thread scheduling), and against the
+captures of the reference's own draw() with the tolerance of tests/test_deposit_oracle.py."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, golden, load
+from test_deposit_oracle import deposit_close, deposit_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def make(n, view_res, view_size=None, speed_limit=None):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    t = ta.Tendrils(View(*view_res))
+    t.resize()
+    t.setup(n)
+    if view_size is not None:
+        t.viewSize[:] = view_size
+    if speed_limit is not None:
+        t.state["speedLimit"] = speed_limit
+    return t
+
+
+def gpu_deposit(cur, prev, base, time, view_res, view_size, speed_limit):
+    t = make(cur.shape[0], view_res, view_size, speed_limit)
+    # buffers[0] = current, buffers[1] = previous (src/index.js:286, src/particles.js:153)
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.flow.set_pixels(base)
+    t.timer.time = time
+    t.draw()
+    got, frags = t.flow.read(), t.fragments
+    t.dispose()
+    return got, frags
+
+
+@pytest.mark.parametrize("path", golden("deposit"), ids=lambda p: p.split("/")[-1][:-4])
+def test_deposit_reference_capture_and_oracle(oracle, path):
+    fx = load(path)
+    m, base, ref = deposit_inputs(fx)
+    got, frags = gpu_deposit(fx["current"], fx["previous"], base, m["time"], m["viewRes"], m["viewSize"], m["speedLimit"])
+    want, n, cov = oracle.flow_deposit(fx["current"], fx["previous"], base, m["time"], view_size=m["viewSize"],
+                                       speedLimit=m["speedLimit"], coverage=True)
+    assert frags == n
+    assert bits_equal(got, want).all()
+    touched = np.zeros(cov.size, bool)
+    touched[fx["idx"]] = True
+    assert ((got != base).any(-1).ravel() == touched).all()          # the reference's coverage, texel for texel
+    assert deposit_close(got, ref, m["time"]).all()
+
+
+def test_deposit_crowded_texels_are_order_exact(oracle):
+    """Many lines through few texels (up to hundreds of fragments per texel): the blend must follow the stream
+    order whatever order the fragments were appended in."""
+    n, view = 128, (48, 27)
+    rng = np.random.default_rng(77)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.3, 0.3, (n, n, 2)) * [1.0, 27 / 48]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    k = rng.random((n, n)) < 0.2
+    cur[k] = [-1e6, -1e6, 0, 0]
+    base = np.zeros((27, 48, 4), np.float32)
+    outs = [gpu_deposit(cur, prev, base, 2500.0, view, None, None) for _ in range(2)]
+    want, frags, cov = oracle.flow_deposit(cur, prev, base, 2500.0, view_size=(1.0, 48 / 27), coverage=True)
+    assert cov.max() > 100 and outs[0][1] == frags
+    assert bits_equal(outs[0][0], want).all() and bits_equal(outs[1][0], want).all()
+
+
+def test_step_draw_loop_matches_oracle(oracle):
+    """The closed loop of the reference's frame: step() then draw(), the deposited wake steering the next step."""
+    import tendrils_amd as ta
+    n, view = 64, (96, 54)
+    rng = np.random.default_rng(5)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.9, 0.9, (n, n, 2)) * [1.0, 0.5]
+    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+    t = make(n, view)
+    t.particles.upload_texels(st)
+    t.timer.time = 1000.0
+    cur, prev = st.copy(), st.copy()
+    flow = np.zeros((54, 96, 4), np.float32)
+    for _ in range(5):
+        t.timer.tick()
+        t.step()
+        t.draw()
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        prev, cur = cur, oracle.logic_step(u, cur, flow)
+        flow, _ = oracle.flow_deposit(cur, prev, flow, t.timer.time, view_size=t.viewSize, speedLimit=t.state["speedLimit"])
+        assert bits_equal(t.particles.read(0), cur).all()
+        assert bits_equal(t.flow.read(), flow).all()
+    assert (flow[..., 3] != 0).sum() > 500
+    t.dispose()
+
+
+def test_deposit_needs_the_whole_texture():
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    opts = ta.defaults()
+    opts.update(row0=16, rows=16, globalHeight=64)
+    t = ta.Tendrils(View(32, 32), opts)
+    t.resize()
+    t.setup(64)
+    with pytest.raises(ta.TendrilsHipError) as e:
+        t.draw()
+    assert e.value.status == 4           # TH_ERR_UNSUPPORTED
+    t.dispose()
