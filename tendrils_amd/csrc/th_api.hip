@@ -127,7 +127,8 @@ struct th_context {
     th_counters *d_counters = nullptr;
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
     uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_cursor = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;
-    uint32_t *dep_list = nullptr;
+    uint32_t *dep_list = nullptr, *dep_order = nullptr;
+    float4 *dep_colors = nullptr;
     size_t dep_texels = 0, dep_capacity = 0;
     unsigned long long *d_respawned = nullptr;   // [0]: particles replaced by respawn passes, [1]: scratch (passes into `targets`)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -144,6 +145,7 @@ struct th_context {
     bool bucket_wanted = false;          // last periodic decision (histogram of the interior share)
     bool bucket_evaluated = false;
     int steps_since_bucket = 0;
+    long long total_steps = 0, hold_texel_order_until = 0;   // texel-order consumers (draw) keep the layout off for a period
 
     size_t texels() const { return (size_t)cfg.width * cfg.height; }
     size_t state_bytes() const { return texels() * (packed ? sizeof(uint2) : sizeof(float4)); }
@@ -421,7 +423,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_cursor); (void)hipFree(c->dep_blocks);
-    (void)hipFree(c->dep_total); (void)hipFree(c->dep_list);
+    (void)hipFree(c->dep_total); (void)hipFree(c->dep_list); (void)hipFree(c->dep_order); (void)hipFree(c->dep_colors);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
@@ -642,7 +644,8 @@ static th_status plan_step(th_context *c, const th_logic_uniforms &u, int32_t ta
 
     // Slot layout: bucketed by flow region (XCD-affine launch) or texel order.  Decided on the
     // CURRENT state, i.e. before the ring rotates.
-    const bool may_bucket = plan.decoded && target == TH_TARGET_RING && bucketing_possible(c);
+    const bool may_bucket = plan.decoded && target == TH_TARGET_RING && bucketing_possible(c) &&
+                            c->total_steps >= c->hold_texel_order_until;
     if (may_bucket) {
         if (!c->bucket_evaluated || c->steps_since_bucket >= rebucket_period() || (c->bucket_wanted && !c->bucketed)) {
             if (th_status s = rebucket(c, u)) return s;
@@ -699,7 +702,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     TH_HIP(hipGetLastError());
     if (c->packed && !packed_kernel)
         if (th_status s = commit_target(c, out, rt)) return s;
-    ++c->steps_since_bucket;
+    ++c->steps_since_bucket; ++c->total_steps;
     return TH_OK;
 }
 
@@ -770,7 +773,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 if (k1) TH_HIP(hipEventRecord(k1, c->stream));
                 TH_HIP(hipGetLastError());
                 if (m & 1) { c->ring[0] = other; c->ring[1] = cur; }
-                c->steps_since_bucket += m;
+                c->steps_since_bucket += m; c->total_steps += m;
                 done += m;
             }
             return TH_OK;
@@ -803,6 +806,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
         TH_HIP(hipEventCreate(&g.copied));
         const std::vector<float4 *> ring_before = c->ring;
         const int since_before = c->steps_since_bucket;
+        const long long total_before = c->total_steps;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         th_status st = TH_OK;
         if (e == hipSuccess) {
@@ -815,6 +819,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
         }
         c->ring = ring_before;                         // the capture only recorded; nothing ran yet
         c->steps_since_bucket = since_before;
+        c->total_steps = total_before;
         if (e != hipSuccess || st != TH_OK) {
             destroy_graph(g);
             if (st != TH_OK) return st;
@@ -832,7 +837,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
         c->ring.pop_back();
         c->ring.insert(c->ring.begin(), last);
     }
-    c->steps_since_bucket += n;
+    c->steps_since_bucket += n; c->total_steps += n;
     // times_host must stay untouched until the copy has run; a later replay of this entry waits here
     TH_HIP(hipEventRecord(hit->copied, c->stream));
     return TH_OK;
@@ -912,6 +917,7 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
 {
     if (th_status s = use(c)) return s;
     if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
+    c->hold_texel_order_until = c->total_steps + rebucket_period();   // a frame loop of step + draw stays in texel order
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
     if (c->cfg.height != c->cfg.global_height)
@@ -935,6 +941,10 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.height;
     p.fw = c->fw; p.fh = c->fh;
     p.view_x = u->viewSize[0]; p.view_y = u->viewSize[1]; p.time = u->time; p.speed_limit = u->speedLimit;
+    {
+        const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.height > 2 ? 2 * c->cfg.height : 2;
+        p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
+    }
     p.count = c->dep_count; p.offset = c->dep_offset; p.cursor = c->dep_cursor; p.list = c->dep_list;
     TH_HIP(hipMemsetAsync(c->dep_count, 0, texels * sizeof(uint32_t), c->stream));
     TH_HIP(hipMemsetAsync(c->dep_cursor, 0, texels * sizeof(uint32_t), c->stream));
@@ -946,13 +956,16 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (fragments) *fragments = total;
     if (total == 0) return TH_OK;
     if (c->dep_capacity < total) {
-        (void)hipFree(c->dep_list);
-        c->dep_list = nullptr;
+        (void)hipFree(c->dep_list); (void)hipFree(c->dep_order); (void)hipFree(c->dep_colors);
+        c->dep_list = c->dep_order = nullptr; c->dep_colors = nullptr;
+        c->dep_capacity = 0;
         const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
         TH_HIP(hipMalloc((void **)&c->dep_list, cap * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_order, cap * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_colors, cap * sizeof(float4)));
         c->dep_capacity = cap;
     }
-    p.list = c->dep_list;
+    p.list = c->dep_list; p.order = c->dep_order; p.colors = c->dep_colors;
     th::launch_deposit_scatter(p, c->stream);
     th::launch_deposit_blend(p, c->stream);
     TH_HIP(hipGetLastError());

@@ -11,10 +11,12 @@
 // GL blends fragments in primitive order, which a parallel machine has to reconstruct:
 //   1. deposit_raster_kernel<false>: one thread per line, rasterise, count fragments per flow texel (atomics)
 //   2. exclusive scan of the per-texel counts -> list offsets
-//   3. deposit_raster_kernel<true>: rasterise again, append the line's stream index to every covered texel's list
-//   4. deposit_blend_kernel: one thread per touched texel: sort its list (stream order), re-evaluate each line's
-//      varying at this texel and blend sequentially: dst = src*a + dst*(1-a), exactly GL's order and arithmetic.
-// The result is independent of thread scheduling (lists are sorted before use).
+//   3. deposit_raster_kernel<true>: rasterise again, append (line stream index, interpolated varying) to every
+//      covered texel's list
+//   4. deposit_blend_kernel: one thread per touched texel walks its list in ascending stream index and blends
+//      sequentially: dst = src*a + dst*(1-a), exactly GL's order and arithmetic.  Short lists are walked by
+//      repeated minimum search; long ones (crowded texels: thousands of fragments) are ranked by the whole wave first.
+// The result is independent of thread scheduling (the append order is never used).
 #include "th_kernels.hpp"
 #include "th_math.hpp"
 
@@ -39,9 +41,7 @@ TH_D int dep_nearest(float u, int n)       // NEAREST + CLAMP_TO_EDGE on a float
 TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
 {
     const int W = (int)p.W, H = (int)p.H;
-    const int lw = W > 2 ? W : 2, lh = 2 * H > 2 ? 2 * H : 2;
-    const double inv_x = 1.0 / (double)(lw - 1), inv_y = 1.0 / (double)(lh - 1);
-    const float uvx = (float)((double)i * inv_x), uvy = (float)((double)j * inv_y);   // Float32Array of JS doubles
+    const float uvx = (float)((double)i * p.inv_x), uvy = (float)((double)j * p.inv_y);   // Float32Array of JS doubles
     const float near_index = uvy * (float)H;
     const float fl = th_floor(near_index);
     const float offset = near_index - fl;
@@ -192,20 +192,36 @@ TH_D void dep_raster(const DepositParams &p, const DepositLine &L, Emit emit)
     }
 }
 
-// passes 1 and 3: count, or append the line id to the covered texels' lists
+// the varying of line L at texel (x, y): linear along the snapped endpoints, extrapolated, unclamped
+TH_D float4 dep_varying(const DepositLine &L, int x, int y)
+{
+    const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
+    if (den == 0) return make_float4(L.a.c[0], L.a.c[1], L.a.c[2], L.a.c[3]);
+    const long long num = ((long long)(x << 4) - L.sx[0]) * ex + ((long long)(y << 4) - L.sy[0]) * ey;
+    const float t = (float)num / (float)den;
+    return make_float4(L.a.c[0] + t * (L.b.c[0] - L.a.c[0]), L.a.c[1] + t * (L.b.c[1] - L.a.c[1]),
+                       L.a.c[2] + t * (L.b.c[2] - L.a.c[2]), L.a.c[3] + t * (L.b.c[3] - L.a.c[3]));
+}
+
+// passes 1 and 3: count, or append (line id, varying) to the covered texels' lists
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams p)
 {
     const uint32_t lines = p.W * p.H;
-    for (uint32_t id = blockIdx.x * 256u + threadIdx.x; id < lines; id += gridDim.x * 256u) {
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
+        // threads walk the particle texture row-major (coalesced state reads); the line's identity for the blend
+        // order stays its position in the column-major vertex stream
+        const uint32_t row = t / p.W, col = t - row * p.W;
+        const uint32_t id = col * p.H + row;
         DepositLine L;
         dep_setup(p, id, L, true);
         if (!L.draws) continue;
         dep_raster(p, L, [&](int x, int y) {
             const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
             if constexpr (SCATTER) {
-                const uint32_t slot = atomicAdd(&p.cursor[texel], 1u);
-                p.list[p.offset[texel] + slot] = id;
+                const uint32_t at = p.offset[texel] + atomicAdd(&p.cursor[texel], 1u);
+                p.list[at] = id;
+                p.colors[at] = dep_varying(L, x, y);
             } else {
                 atomicAdd(&p.count[texel], 1u);
             }
@@ -213,42 +229,59 @@ __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams
     }
 }
 
-// pass 4: one thread per flow texel
+TH_D void dep_blend(float4 &d, float4 c)
+{
+    const float sa = c.w, da = 1.0f - sa;
+    d.x = c.x * sa + d.x * da;
+    d.y = c.y * sa + d.y * da;
+    d.z = c.z * sa + d.z * da;
+    d.w = c.w * sa + d.w * da;
+}
+
+constexpr uint32_t kShortList = 24;      // up to here a thread orders its list by repeated minimum search
+
+// pass 4: one thread per flow texel; a wave helps its long lists
 __global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p)
 {
     const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh;
-    for (uint32_t texel = blockIdx.x * 256u + threadIdx.x; texel < texels; texel += gridDim.x * 256u) {
-        const uint32_t n = p.count[texel];
-        if (n == 0) continue;
-        uint32_t *ids = p.list + p.offset[texel];
-        // stream order: ascending line id.  Lists are short (a handful of lines per texel); insertion sort in place.
-        for (uint32_t k = 1; k < n; ++k) {
-            const uint32_t v = ids[k];
-            uint32_t q = k;
-            while (q > 0 && ids[q - 1] > v) { ids[q] = ids[q - 1]; --q; }
-            ids[q] = v;
-        }
-        const int x = (int)(texel % (uint32_t)p.fw), y = (int)(texel / (uint32_t)p.fw);
-        float4 d = p.flow[texel];
-        for (uint32_t k = 0; k < n; ++k) {
-            DepositLine L;
-            dep_setup(p, ids[k], L, false);
-            const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
-            float c[4];
-            if (den == 0) {
-                for (int q = 0; q < 4; ++q) c[q] = L.a.c[q];
-            } else {
-                const long long num = ((long long)(x << 4) - L.sx[0]) * ex + ((long long)(y << 4) - L.sy[0]) * ey;
-                const float t = (float)num / (float)den;
-                for (int q = 0; q < 4; ++q) c[q] = L.a.c[q] + t * (L.b.c[q] - L.a.c[q]);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base < texels; base += gridDim.x * 256u) {
+        const uint32_t texel = base + lane;
+        const uint32_t n = texel < texels ? p.count[texel] : 0u;
+        const uint32_t off = n ? p.offset[texel] : 0u;
+        if (n > 0 && n <= kShortList) {
+            float4 d = p.flow[texel];
+            long long last = -1;
+            for (uint32_t r = 0; r < n; ++r) {             // ids are distinct: next = the smallest id above the last one
+                uint32_t best = 0xffffffffu, bk = 0;
+                for (uint32_t k = 0; k < n; ++k) {
+                    const uint32_t id = p.list[off + k];
+                    if ((long long)id > last && id <= best) { best = id; bk = k; }
+                }
+                dep_blend(d, p.colors[off + bk]);
+                last = best;
             }
-            const float sa = c[3], da = 1.0f - sa;
-            d.x = c[0] * sa + d.x * da;
-            d.y = c[1] * sa + d.y * da;
-            d.z = c[2] * sa + d.z * da;
-            d.w = c[3] * sa + d.w * da;
+            p.flow[texel] = d;
         }
-        p.flow[texel] = d;
+        // long lists of this wave's 64 texels, one after the other, all lanes ranking: order[rank] = position
+        unsigned long long todo = __ballot(n > kShortList);
+        while (todo) {
+            const int owner = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t on = __shfl(n, owner), ooff = __shfl(off, owner);
+            for (uint32_t k = lane; k < on; k += 64u) {
+                const uint32_t id = p.list[ooff + k];
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < on; ++q) rank += p.list[ooff + q] < id ? 1u : 0u;
+                p.order[ooff + rank] = k;
+            }
+        }
+        __threadfence();
+        if (n > kShortList) {                              // the owner walks its ranked list (written by its own wave)
+            float4 d = p.flow[texel];
+            for (uint32_t r = 0; r < n; ++r) dep_blend(d, p.colors[off + p.order[off + r]]);
+            p.flow[texel] = d;
+        }
     }
 }
 

@@ -85,8 +85,11 @@ struct DepositParams {
     uint32_t W, H;               // particle texture shape
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
+    double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)
     uint32_t *count, *offset, *cursor;   // per flow texel: fragments, list start, fill cursor
     uint32_t *list;              // line stream indices, grouped by texel
+    uint32_t *order;             // long lists: position of the r-th fragment in stream order
+    float4 *colors;              // the fragments' interpolated varyings, same indexing as list
 };
 
 struct StatsPartial {

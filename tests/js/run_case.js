@@ -42,6 +42,17 @@ if (spec.kind === 'logic') {
   }
   fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, dt: t.timer.dt,
     order: t.particles.buffers.map((b) => b.id) }));
+} else if (spec.kind === 'frames') {            // the reference's frame loop: step() then draw() (flow deposit)
+  t.timer.time = spec.time0;
+  const fragments = [];
+  for (let k = 0; k < spec.frames; ++k) {
+    t.timer.tick();
+    t.step().draw();
+    fragments.push(t.fragments);
+  }
+  save('state.out.bin', t.particles.read(0));
+  save('flow.out.bin', t.flow.read());
+  fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, fragments }));
 } else if (spec.kind === 'optical_flow') {
   const of = new OpticalFlow(t);
   of.resize(spec.frame);

@@ -186,3 +186,30 @@ def test_js_step_n_matches_python_single_steps(tmp_path):
     want = t.particles.read(0)
     t.dispose()
     assert bits_equal(got, want).all()
+
+
+@pytest.mark.gpu
+def test_js_frame_loop_step_and_draw(tmp_path, oracle):
+    """Node host: Tendrils.step().draw() per frame (flow deposit closing the loop) == the oracle's step + deposit."""
+    n, frames = 48, 4
+    rng = np.random.default_rng(21)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.9, 0.9, (n, n, 2)) * [1.0, 0.5]
+    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+    run_case(tmp_path, dict(kind="frames", N=n, viewRes=[96, 54], frames=frames, time0=3000.0,
+                            inputs=dict(state="state.bin")), {"state.bin": st})
+    got_state = np.fromfile(str(tmp_path / "state.out.bin"), np.float32).reshape(n, n, 4)
+    got_flow = np.fromfile(str(tmp_path / "flow.out.bin"), np.float32).reshape(54, 96, 4)
+    res = json.load(open(str(tmp_path / "result.json")))
+    DEFAULT_STATE = oracle.DEFAULT_STATE
+    cur, prev, flow, time = st.copy(), st.copy(), np.zeros((54, 96, 4), np.float32), 3000.0
+    dt = 1000.0 / 60.0
+    counts = []
+    for _ in range(frames):
+        time += dt
+        u = oracle.logic_uniforms(n, n, time, dt, view_size=(1.0, 96 / 54), **DEFAULT_STATE)
+        prev, cur = cur, oracle.logic_step(u, cur, flow)
+        flow, k = oracle.flow_deposit(cur, prev, flow, time, view_size=(1.0, 96 / 54), speedLimit=DEFAULT_STATE["speedLimit"])
+        counts.append(k)
+    assert res["fragments"] == counts and abs(res["time"] - time) < 1e-9
+    assert bits_equal(got_state, cur).all() and bits_equal(got_flow, flow).all()

@@ -1,0 +1,54 @@
+"""Frame loop of the reference at C3: Tendrils.step() + Tendrils.draw() (flow deposit) per frame.
+Prints ms per frame part (HIP events on the context's stream) and fragments per frame."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (synthetic C3 inputs)
+import tendrils_amd as ta  # noqa: E402
+from tendrils_amd import _capi  # noqa: E402
+from tendrils_amd.tendrils import View  # noqa: E402
+
+N = int(os.environ.get("TH_N", "4096"))
+bench.N = N
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+in_view = "--in-view" in sys.argv
+
+t = ta.Tendrils(View(1920, 1080))
+t.resize()
+t.setup(N)
+st = bench.synth_state(0)
+if in_view:
+    st[..., 1] *= np.float32(0.56)
+t.particles.upload_texels(st)
+t.timer.time = 1000.0
+ctx = t.particles._ctx
+ms = C.c_float()
+
+
+def timed(fn):
+    _capi.call("th_timer_start", ctx)
+    fn()
+    _capi.call("th_timer_stop", ctx, C.byref(ms))
+    return ms.value
+
+
+for _ in range(5):                      # warm-up: the wake builds up, buffers are sized
+    t.timer.tick(); t.step(); t.draw()
+step_ms, draw_ms, frags = [], [], []
+for _ in range(frames):
+    t.timer.tick()
+    step_ms.append(timed(t.step))
+    draw_ms.append(timed(t.draw))
+    frags.append(t.fragments)
+stats = t.particles.stats(t.state["speedLimit"])
+print(json.dumps({"particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
+                  "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)),
+                  "fragments_per_frame": float(np.mean(frags)), "frames_per_s": 1e3 / float(np.mean(step_ms) + np.mean(draw_ms)),
+                  "live": stats["live"], "nan": stats["nan"]}))
+t.dispose()
