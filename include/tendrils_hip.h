@@ -204,7 +204,7 @@ th_status th_optical_flow(th_context *ctx, const th_optical_flow_uniforms *u);
  * (vel, time, min(|vel|/speedLimit, 1)), alpha-blended in the reference's primitive order (width-1 lines: the GL the
  * reference was captured on clamps flowWidth to 1).  fragments (optional) receives the number of fragments blended;
  * the call synchronises once (the fragment lists are sized from a device count).
- * Needs the whole particle texture on this context (TH_ERR_UNSUPPORTED on a row-band shard) and an f32 ring. */
+ * Needs the whole particle texture on this context (TH_ERR_UNSUPPORTED on a row-band shard). */
 th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *fragments);
 
 /* -- statistics, sync, interop ---------------------------------------------- */

@@ -922,7 +922,6 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "flow deposit needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
-    if (c->packed) return fail(TH_ERR_UNSUPPORTED, "flow deposit reads an f32 state ring");
     const size_t texels = (size_t)c->fw * c->fh;
     TH_REQUIRE(texels > 0 && (uint64_t)c->cfg.width * c->cfg.height < (1ull << 32), "bad shapes");
     if (c->dep_texels != texels) {
@@ -937,7 +936,13 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
         c->dep_texels = texels;
     }
     th::DepositParams p{};
-    p.cur = c->ring[0]; p.prev = c->ring[1]; p.flow = c->flow;
+    {   // a packed ring is read through f32 views (what the stored texels decode to)
+        float4 *cur = nullptr, *prev = nullptr;
+        if (th_status s = unpacked_view(c, c->ring[0], 0, &cur)) return s;
+        if (th_status s = unpacked_view(c, c->ring[1], 1, &prev)) return s;
+        p.cur = cur; p.prev = prev;
+    }
+    p.flow = c->flow;
     p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.height;
     p.fw = c->fw; p.fh = c->fh;
     p.view_x = u->viewSize[0]; p.view_y = u->viewSize[1]; p.time = u->time; p.speed_limit = u->speedLimit;

@@ -121,3 +121,27 @@ def test_c5_16384_wide_band_equals_oracle(oracle, row0):
         cur = unpack_state(pack_state(oracle.logic_step(u, cur, fl, y0=row0)))
         assert bits_equal(t.particles.read(0), cur).all()
     t.dispose()
+
+
+def test_packed_frame_loop_deposit(oracle):
+    """step() + draw() on the packed ring: the deposit reads what the stored texels decode to."""
+    n, view = 64, (96, 54)
+    rng = np.random.default_rng(9)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.9, 0.9, (n, n, 2)) * [1.0, 0.5]
+    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+    st = unpack_state(pack_state(st))
+    t = packed_tendrils(n, view)
+    t.particles.upload_texels(st)
+    t.timer.time = 1000.0
+    cur, prev, flow = st.copy(), st.copy(), np.zeros((54, 96, 4), np.float32)
+    for _ in range(3):
+        t.timer.tick()
+        t.step()
+        t.draw()
+        u = oracle.logic_uniforms(n, n, t.timer.time, t.timer.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        prev, cur = cur, unpack_state(pack_state(oracle.logic_step(u, cur, flow)))
+        flow, _ = oracle.flow_deposit(cur, prev, flow, t.timer.time, view_size=t.viewSize, speedLimit=t.state["speedLimit"])
+        assert bits_equal(t.particles.read(0), cur).all() and bits_equal(t.flow.read(), flow).all()
+    t.dispose()
