@@ -67,7 +67,8 @@ enum {
 enum {
     TH_TARGET_RING = -1,     /* rotate the ring, write buffers[0] (the default path) */
     TH_TARGET_TARGETS = -2,  /* tendrils.targets (src/index.js:105) */
-    TH_SOURCE_FLOW = -3      /* tendrils.flow as spawnData (src/demo.main.js:403-406) */
+    TH_SOURCE_FLOW = -3,     /* tendrils.flow as spawnData (src/demo.main.js:403-406) */
+    TH_SOURCE_IMAGE = -4     /* the spawner's own buffer: an RGBA image in a float texture (th_spawn_image_upload) */
     /* values >= 0 name ring buffer k in its CURRENT order (buffers[k]) */
 };
 
@@ -122,7 +123,8 @@ typedef struct th_spawn_sample_uniforms {
     float flowDecay;
     float spawnMatrix[9];    /* column-major mat3 */
     int32_t samples;         /* flow-sample 5, data-sample 2 */
-    int32_t apply;           /* 0: apply/flow.glsl, 1: apply/identity.glsl */
+    int32_t apply;           /* 0: apply/flow.glsl; 1: apply/identity.glsl over the vignette pass (data-sample.frag);
+                                2: apply/color.glsl over the vignette pass (best-sample.frag, index.frag) */
 } th_spawn_sample_uniforms;
 
 /* Uniforms of the flow pass of Tendrils.draw(): src/flow/vert/head.vert:8-12 (viewSize, time, speedLimit). */
@@ -190,6 +192,11 @@ th_status th_step_n(th_context *ctx, const th_logic_uniforms *u, double time0, d
 th_status th_spawn_init(th_context *ctx, int32_t target);
 th_status th_spawn_ball(th_context *ctx, const th_spawn_ball_uniforms *u, int32_t target);
 th_status th_spawn_sample(th_context *ctx, const th_spawn_sample_uniforms *u, int32_t source, int32_t target);
+/* src/spawn/pixels/index.frag (frag/direct-main.frag:10-21, colour apply over the vignette pass): every particle
+ * from its own texel of the spawn data (the image spawner of src/demo.main.js:455-512); u->samples is ignored. */
+th_status th_spawn_direct(th_context *ctx, const th_spawn_sample_uniforms *u, int32_t source, int32_t target);
+/* PixelSpawner.buffer (src/spawn/pixels/index.js:17,34-36: a float FBO) + setPixels: w x h RGBA float texels. */
+th_status th_spawn_image_upload(th_context *ctx, const float *rgba, int32_t w, int32_t h);
 
 /* -- optical flow producer: OpticalFlow (src/optical-flow/index.js:32-71) ---- */
 th_status th_frames_resize(th_context *ctx, int32_t w, int32_t h);     /* OpticalFlow.resize */

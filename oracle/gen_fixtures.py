@@ -397,6 +397,34 @@ def gen_spawn(r, only):
              uniforms=json.dumps(dict(kind="spawn_sample", N=n, samples=2, apply=1, uniforms=un)))
 
 
+def gen_spawn_image(r, only):
+    """Image spawners (src/demo.main.js:455-515): index.frag (direct) and best-sample.frag (6 samples) over an RGBA
+    image held in a float texture (PixelSpawner's default buffer, src/spawn/pixels/index.js:17).  The image is a
+    seeded 8-bit pattern / 255.  Direct spawn with zero jitter has no hash in it: positions are exact and the
+    velocities differ from this build only through cos/sin."""
+    rng = np.random.default_rng(4712)
+    n, (iw, ih) = 64, (80, 60)
+    img8 = rng.integers(0, 256, (ih, iw, 4), dtype=np.uint8)
+    img8[..., 3] = rng.integers(128, 256, (ih, iw))
+    img8[5:20, 10:30, :3] = [200, 30, 60]           # flat patches: grey (d = 0) and saturated
+    img8[30:40, 40:60, :3] = 128
+    img = (img8.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    st = rand_state(rng, n, 0.3, 1.0, 0.004)
+    time = 2016.67
+    flip = [-1, 0, 0, 0, 1, 0, 0, 0, 1]              # mat3.scale(identity, [-1, 1]) (src/demo.main.js:462-463)
+    for name, frag, jitter, speed in (("spawn_image_direct_64", "spawn_direct", [0.0, 0.0], 0.3),
+                                      ("spawn_image_direct_jitter_64", "spawn_direct", [2 / 96, 2 / 54], 0.3),
+                                      ("spawn_image_best_sample_64", "spawn_best_sample", [2 / 96, 2 / 54], 1.0)):
+        if only and only not in name:
+            continue
+        un = dict(dataRes=[n, n], geomRes=[n, 2 * n], spawnSize=[1.0, 0.75], jitter=jitter, time=time, speed=speed,
+                  bias=1.0, spawnMatrix=flip)
+        ref = r.shader(frag, (n, n), textures={"particles": st, "spawnData": img}, uniforms=un)
+        save(name, state=st, data=img, out=ref,
+             uniforms=json.dumps(dict(kind="spawn_direct" if frag == "spawn_direct" else "spawn_sample", N=n,
+                                      samples=6, apply=2, uniforms=un)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -410,6 +438,7 @@ def main():
     gen_deposit(r, args.only)
     gen_optical_flow(r, args.only)
     gen_spawn(r, args.only)
+    gen_spawn_image(r, args.only)
 
 
 if __name__ == "__main__":

@@ -100,6 +100,8 @@ def lib():
         L.to_spawn_ball.argtypes = [C.POINTER(SpawnBallUniforms), fp, C.c_int, C.c_int, C.c_int]
         L.to_spawn_sample.restype = None
         L.to_spawn_sample.argtypes = [C.POINTER(SpawnSampleUniforms), fp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.to_spawn_direct.restype = None
+        L.to_spawn_direct.argtypes = [C.POINTER(SpawnSampleUniforms), fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.to_flow_deposit.restype = C.c_long
         L.to_flow_deposit.argtypes = [C.POINTER(DepositUniforms), fp, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         _lib = L
@@ -223,3 +225,13 @@ def flow_deposit(current, previous, flow, time, view_size=(1.0, 1.0), speedLimit
     n = lib().to_flow_deposit(C.byref(u), _fp(current), _fp(previous), _fp(out), fw, fh,
                               cov.ctypes.data_as(C.POINTER(C.c_int32)) if coverage else None)
     return (out, n, cov) if coverage else (out, n)
+
+
+def spawn_direct(u, spawn_data, y0=0, rows=None):
+    """index.frag (direct-main): particle (x, y) from its own texel of spawn_data [sh, sw, 4]."""
+    spawn_data = np.ascontiguousarray(spawn_data, np.float32)
+    rows = u.data_h if rows is None else rows
+    out = np.empty((rows, u.data_w, 4), np.float32)
+    sh, sw = spawn_data.shape[:2]
+    lib().to_spawn_direct(C.byref(u), _fp(out), int(y0), int(rows), _fp(spawn_data), sw, sh)
+    return out

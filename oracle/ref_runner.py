@@ -122,6 +122,10 @@ class RefRunner:
                     out["spawn_ball"] = t
                 elif "uniform sampler2D last;" in t and "gradMag" in t:
                     out["optical_flow"] = t
+                elif "spawnData" in t and "rgb2hsv" in t and "const float samples = 6.0" in t:
+                    out["spawn_best_sample"] = t          # best-sample.frag: colour apply, vignette
+                elif "spawnData" in t and "rgb2hsv" in t and "samples" not in t:
+                    out["spawn_direct"] = t               # index.frag (direct-main)
                 elif "spawnData" in t and "const float samples = 5.0" in t and "flowDecay" in t:
                     out["spawn_flow_sample"] = t
                 elif "spawnData" in t and "const float samples = 2.0" in t:

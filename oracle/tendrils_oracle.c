@@ -408,6 +408,57 @@ static void spawn_to_pos(const to_spawn_sample_uniforms *u, float uvx, float uvy
     *py = m[1] * qx + m[4] * qy + m[7] * 1.0f;
 }
 
+/* filter/pass/vignette.glsl:9-11 with curve (0.1,1,1), mid 0.5, limit 0.6 (spawn/pixels/vignette-head.glsl:4-6) */
+static inline float spawn_vignette(float u, float v)
+{
+    float dx = u - 0.5f, dy = v - 0.5f;
+    float amt = fminf(1.0f - (sqrtf(dx * dx + dy * dy) / 0.6f), 1.0f);
+    float ut = 1.0f - amt;
+    float bz = (0.1f * ut + 1.0f * amt) * ut + (1.0f * ut + 1.0f * amt) * amt;     /* utils/bezier.glsl:9-13 */
+    return fmaxf(0.0f, bz);
+}
+
+/* spawn/pixels/apply/color.glsl:13-17 after the vignette pass (apply/compose-filter.glsl:10-12):
+ * vec4(pos, angleToVec((hsv.r + time*0.00003)*tau)*hsv.g*hsv.b*pixel.a), hsv = rgb2hsv(pixel.rgb)
+ * (libs/glsl-hsv/rgb-hsv.glsl:4-11).  cos/sin through the pinned evaluation (see sincos_pinned). */
+static void spawn_apply_color(const float *texel, float vg, float time, float px, float py, float *out)
+{
+    const float r = texel[0] * vg, g = texel[1] * vg, b = texel[2] * vg, a = texel[3] * vg;
+    float p0, p1, p2, p3;                                   /* vec4 p = (g < b) ? (b, g, -1, 2/3) : (g, b, 0, -1/3) */
+    if (g < b) { p0 = b; p1 = g; p2 = -1.0f; p3 = 2.0f / 3.0f; } else { p0 = g; p1 = b; p2 = 0.0f; p3 = -1.0f / 3.0f; }
+    float q0, q1, q2, q3;                                   /* vec4 q = (r < p.x) ? (p.xyw, r) : (r, p.yzx) */
+    if (r < p0) { q0 = p0; q1 = p1; q2 = p3; q3 = r; } else { q0 = r; q1 = p1; q2 = p2; q3 = p0; }
+    const float e = 1.0e-10f;
+    const float d = q0 - fminf(q3, q1);
+    const float h = fabsf(q2 + (q3 - q1) / (6.0f * d + e)), s = d / (q0 + e), v = q0;
+    float sn, cs;
+    sincos_pinned((h + (time * 0.00003f)) * 6.28318530717958647692f, &sn, &cs);
+    out[0] = px; out[1] = py;
+    out[2] = ((cs * s) * v) * a;
+    out[3] = ((sn * s) * v) * a;
+}
+
+/* src/spawn/pixels/frag/direct-main.frag:10-21 (index.frag: colour apply over the vignette pass):
+ * uv = (gl_FragCoord.xy/dataRes)*(geomRes/dataRes) with geomRes = [w, 2h] (src/index.js:195-197). */
+void to_spawn_direct(const to_spawn_sample_uniforms *u, float *out, int y0, int rows,
+                     const float *spawn_data, int sw, int sh)
+{
+    const int W = u->data_w;
+    for (int r = 0; r < rows; ++r) {
+        for (int x = 0; x < W; ++x) {
+            size_t o = 4 * ((size_t)r * W + x);
+            const float dw = (float)u->data_w, dh = (float)u->data_h;
+            float uvx = (((float)x + 0.5f) / dw) * (dw / dw);
+            float uvy = (((float)(y0 + r) + 0.5f) / dh) * ((2.0f * dh) / dh);
+            float px, py;
+            spawn_to_pos(u, uvx, uvy, &px, &py);
+            float st[4];
+            spawn_apply_color(tex_f32(spawn_data, sw, sh, uvx, uvy), spawn_vignette(uvx, uvy), u->time, px, py, st);
+            out[o] = st[0]; out[o + 1] = st[1]; out[o + 2] = st[2] * u->speed; out[o + 3] = st[3] * u->speed;
+        }
+    }
+}
+
 /* src/spawn/pixels/frag/best-sample-main.frag:21-46 */
 void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, float *out,
                      int y0, int rows, const float *spawn_data, int sw, int sh)
@@ -429,18 +480,17 @@ void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, 
                 spawn_to_pos(u, su, sv, &px, &py);
                 const float *t = tex_f32(spawn_data, sw, sh, su, sv);
                 float other[4];
-                if (u->apply == 0) {
+                if (u->apply == 2) {
+                    /* best-sample.frag: colour apply over the vignette pass */
+                    spawn_apply_color(t, spawn_vignette(su, sv), u->time, px, py, other);
+                } else if (u->apply == 0) {
                     /* apply/flow.glsl:11-13: vec4(pos, getFlow(pixel, time, decay)) */
                     float k = fmaxf(0.0f, 1.0f - ((u->time - t[2]) * u->flowDecay));
                     other[0] = px; other[1] = py; other[2] = t[0] * k; other[3] = t[1] * k;
                 } else {
                     /* data-sample.frag: identity after filter/pass/vignette.glsl:9-11 with
                      * curve (0.1,1,1), mid 0.5, limit 0.6 (vignette-head.glsl:4-6) */
-                    float dx = su - 0.5f, dy = sv - 0.5f;
-                    float amt = fminf(1.0f - (sqrtf(dx * dx + dy * dy) / 0.6f), 1.0f);
-                    float ut = 1.0f - amt;
-                    float bz = (0.1f * ut + 1.0f * amt) * ut + (1.0f * ut + 1.0f * amt) * amt;
-                    float vg = fmaxf(0.0f, bz);
+                    float vg = spawn_vignette(su, sv);
                     for (int c = 0; c < 4; ++c) other[c] = t[c] * vg;
                 }
                 float cand[4] = {other[0], other[1], other[2] * u->speed, other[3] * u->speed};

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("TH_LIB") or os.path.join(HERE, "lib", "libtendrils_hi
 TH_OK = 0
 TH_MODE_EXACT, TH_MODE_FAST = 0, 1
 TH_STATE_F32, TH_STATE_F16 = 0, 1
-TH_TARGET_RING, TH_TARGET_TARGETS, TH_SOURCE_FLOW = -1, -2, -3
+TH_TARGET_RING, TH_TARGET_TARGETS, TH_SOURCE_FLOW, TH_SOURCE_IMAGE = -1, -2, -3, -4
 INERT = -1000000.0
 
 
@@ -98,6 +98,8 @@ PROTOTYPES = {
     "th_spawn_init": (C.c_int32, [_ctx, C.c_int32]),
     "th_spawn_ball": (C.c_int32, [_ctx, C.POINTER(SpawnBallUniforms), C.c_int32]),
     "th_spawn_sample": (C.c_int32, [_ctx, C.POINTER(SpawnSampleUniforms), C.c_int32, C.c_int32]),
+    "th_spawn_direct": (C.c_int32, [_ctx, C.POINTER(SpawnSampleUniforms), C.c_int32, C.c_int32]),
+    "th_spawn_image_upload": (C.c_int32, [_ctx, _fp, C.c_int32, C.c_int32]),
     "th_frames_resize": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
     "th_frames_upload": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),
     "th_frames_rotate": (C.c_int32, [_ctx]),

@@ -130,6 +130,8 @@ struct th_context {
     uint32_t *dep_list = nullptr, *dep_order = nullptr;
     float4 *dep_colors = nullptr;
     size_t dep_texels = 0, dep_capacity = 0;
+    float4 *image = nullptr;             // PixelSpawner's own buffer (TH_SOURCE_IMAGE)
+    int32_t iw = 0, ih = 0;
     unsigned long long *d_respawned = nullptr;   // [0]: particles replaced by respawn passes, [1]: scratch (passes into `targets`)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool kernel_timing = false;          // th_kernel_timing: event pair around every logic launch
@@ -424,6 +426,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_cursor); (void)hipFree(c->dep_blocks);
     (void)hipFree(c->dep_total); (void)hipFree(c->dep_list); (void)hipFree(c->dep_order); (void)hipFree(c->dep_colors);
+    (void)hipFree(c->image);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
@@ -877,13 +880,13 @@ th_status th_spawn_ball(th_context *c, const th_spawn_ball_uniforms *u, int32_t 
     return commit_target(c, out, rt);
 }
 
-th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target)
+static th_status spawn_from_data(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target, bool direct)
 {
     if (th_status s = use(c)) return s;
     if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(u, "null uniforms");
-    TH_REQUIRE(u->samples >= 0 && u->samples <= 64, "samples out of range");
-    TH_REQUIRE(u->apply == 0 || u->apply == 1, "unknown apply mode %d", u->apply);
+    if (!direct) TH_REQUIRE(u->samples >= 0 && u->samples <= 64, "samples out of range");
+    TH_REQUIRE(direct || (u->apply >= 0 && u->apply <= 2), "unknown apply mode %d", u->apply);
     // the pass reads `particles` = buffers[1] like every Particles.step (src/particles.js:139)
     TH_REQUIRE(c->ring.size() >= 2, "spawn pass needs at least 2 state buffers (have %zu)", c->ring.size());
     float4 *out = nullptr;
@@ -896,7 +899,10 @@ th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int3
     p.out = rt;
     // `source` names the spawnData texture in the ring order the pass sees (after the rotation)
     if (source == TH_SOURCE_FLOW) { p.data = c->flow; p.dw = c->fw; p.dh = c->fh; }
-    else if (source >= 0 && source < (int32_t)c->ring.size()) {
+    else if (source == TH_SOURCE_IMAGE) {
+        TH_REQUIRE(c->image, "no spawn image (call th_spawn_image_upload)");
+        p.data = c->image; p.dw = c->iw; p.dh = c->ih;
+    } else if (source >= 0 && source < (int32_t)c->ring.size()) {
         if (c->cfg.height != c->cfg.global_height)
             return fail(TH_ERR_UNSUPPORTED, "sampling the particle texture needs the whole texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
         float4 *data = nullptr;
@@ -908,9 +914,35 @@ th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int3
     p.wf = (float)c->cfg.width; p.hf = (float)c->cfg.global_height;
     p.u = *u;
     p.accepted = c->d_respawned + (target == TH_TARGET_TARGETS ? 1 : 0);
-    th::launch_spawn_sample(p, c->stream);
+    if (direct) th::launch_spawn_direct(p, c->stream); else th::launch_spawn_sample(p, c->stream);
     TH_HIP(hipGetLastError());
     return commit_target(c, out, rt);
+}
+
+th_status th_spawn_sample(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target)
+{
+    return spawn_from_data(c, u, source, target, false);
+}
+
+th_status th_spawn_direct(th_context *c, const th_spawn_sample_uniforms *u, int32_t source, int32_t target)
+{
+    return spawn_from_data(c, u, source, target, true);
+}
+
+th_status th_spawn_image_upload(th_context *c, const float *rgba, int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba && w > 0 && h > 0 && w < (1 << 24) && h < (1 << 24) && (uint64_t)w * h < (1ull << 28), "bad image %dx%d", w, h);
+    if (w != c->iw || h != c->ih) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->image);
+        c->image = nullptr; c->iw = c->ih = 0;
+        TH_HIP(hipMalloc((void **)&c->image, (size_t)w * h * sizeof(float4)));
+        c->iw = w; c->ih = h;
+    }
+    TH_HIP(hipMemcpyAsync(c->image, rgba, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
 }
 
 th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)

@@ -1103,6 +1103,76 @@ TH_D int nearest_texel_f32(float u, float nf, float nm1)
     return (int)__builtin_amdgcn_fmed3f(th_floor(u * nf), 0.0f, nm1);
 }
 
+// filter/pass/vignette.glsl:9-11 with curve (0.1,1,1), mid 0.5, limit 0.6 (spawn/pixels/vignette-head.glsl:4-6)
+TH_D float spawn_vignette(float u, float v)
+{
+    float dx = u - 0.5f, dy = v - 0.5f;
+    float amt = __builtin_fminf(1.0f - (__builtin_sqrtf(dx * dx + dy * dy) / 0.6f), 1.0f);
+    float ut = 1.0f - amt;
+    float bz = (0.1f * ut + 1.0f * amt) * ut + (1.0f * ut + 1.0f * amt) * amt;
+    return __builtin_fmaxf(0.0f, bz);
+}
+
+// spawn/pixels/apply/color.glsl:13-17 over the vignette pass; rgb2hsv = libs/glsl-hsv/rgb-hsv.glsl:4-11
+TH_D float4 spawn_apply_color(float4 t, float vg, float time, float px, float py)
+{
+    const float r = t.x * vg, g = t.y * vg, b = t.z * vg, a = t.w * vg;
+    float p0, p1, p2, p3;
+    if (g < b) { p0 = b; p1 = g; p2 = -1.0f; p3 = 2.0f / 3.0f; } else { p0 = g; p1 = b; p2 = 0.0f; p3 = -1.0f / 3.0f; }
+    float q0, q1, q2, q3;
+    if (r < p0) { q0 = p0; q1 = p1; q2 = p3; q3 = r; } else { q0 = r; q1 = p1; q2 = p2; q3 = p0; }
+    const float e = 1.0e-10f;
+    const float d = q0 - __builtin_fminf(q3, q1);
+    const float h = __builtin_fabsf(q2 + (q3 - q1) / (6.0f * d + e)), s = d / (q0 + e), v = q0;
+    float sn, cs;
+    sincos_pinned((h + (time * 0.00003f)) * 6.28318530717958647692f, sn, cs);
+    return make_float4(px, py, ((cs * s) * v) * a, ((sn * s) * v) * a);
+}
+
+// spawnToPos (src/spawn/pixels/frag/head.frag:28-34): jitter, uvToPos, flipUV*spawnSize, mat3 transform
+TH_D void spawn_to_pos(const th_spawn_sample_uniforms &u, float su, float sv, float tt, float &px, float &py)
+{
+    float ra = random_glsl(su - 1.2345f + tt, sv - 1.2345f + tt);
+    float rb = random_glsl(su + 1.2345f + tt, sv + 1.2345f + tt);
+    float ox = (-u.jitter[0]) * (1.0f - ra) + u.jitter[0] * ra;
+    float oy = (-u.jitter[1]) * (1.0f - rb) + u.jitter[1] * rb;
+    float qx = -1.0f + (2.0f * ((su + ox) - 0.0f)) / 1.0f;
+    float qy = -1.0f + (2.0f * ((sv + oy) - 0.0f)) / 1.0f;
+    qx = qx * 1.0f * u.spawnSize[0];
+    qy = qy * -1.0f * u.spawnSize[1];
+    const float *m = u.spawnMatrix;
+    px = m[0] * qx + m[3] * qy + m[6] * 1.0f;
+    py = m[1] * qx + m[4] * qy + m[7] * 1.0f;
+}
+
+// src/spawn/pixels/index.frag = frag/direct-main.frag:10-21: uv = (gl_FragCoord.xy/dataRes)*(geomRes/dataRes),
+// geomRes = [w, 2h] (src/index.js:195-197)
+__global__ __launch_bounds__(256) void spawn_direct_kernel(const SpawnSampleParams p)
+{
+    const th_spawn_sample_uniforms &u = p.u;
+    const float dwf = (float)p.dw, dhf = (float)p.dh, dwm1 = (float)(p.dw - 1), dhm1 = (float)(p.dh - 1);
+    unsigned long long took = 0;
+    for (uint32_t idx = blockIdx.x * 256u + threadIdx.x; idx < p.count; idx += gridDim.x * 256u) {
+        uint32_t y = idx / p.width, x = idx - y * p.width;
+        float uvx = (((float)x + 0.5f) / p.wf) * (p.wf / p.wf);
+        float uvy = (((float)(y + p.row0) + 0.5f) / p.hf) * ((2.0f * p.hf) / p.hf);
+        float px, py;
+        spawn_to_pos(u, uvx, uvy, u.time * 0.001f, px, py);
+        float4 t = p.data[nearest_texel_f32(uvy, dhf, dhm1) * p.dw + nearest_texel_f32(uvx, dwf, dwm1)];
+        float4 st = spawn_apply_color(t, spawn_vignette(uvx, uvy), u.time, px, py);
+        p.out[idx] = make_float4(st.x, st.y, st.z * u.speed, st.w * u.speed);
+        ++took;
+    }
+    took += __shfl_xor(took, 32); took += __shfl_xor(took, 16); took += __shfl_xor(took, 8);
+    took += __shfl_xor(took, 4); took += __shfl_xor(took, 2); took += __shfl_xor(took, 1);
+    if ((threadIdx.x & 63u) == 0 && took) atomicAdd(p.accepted, took);
+}
+
+void launch_spawn_direct(const SpawnSampleParams &p, hipStream_t s)
+{
+    if (p.count) hipLaunchKernelGGL(spawn_direct_kernel, dim3(grid_for(p.count, 8)), dim3(256), 0, s, p);
+}
+
 // src/spawn/pixels/frag/best-sample-main.frag:21-46 with head.frag:28-34
 __global__ __launch_bounds__(256) void spawn_sample_kernel(const SpawnSampleParams p)
 {
@@ -1120,29 +1190,17 @@ __global__ __launch_bounds__(256) void spawn_sample_kernel(const SpawnSamplePara
             float fn = (float)n;
             float su = mod_glsl(random_glsl(b0 + fn, b1 + fn), 1.0f);
             float sv = mod_glsl(random_glsl(b2 + fn, b3 + fn), 1.0f);
-            // spawnToPos: jitter, uvToPos, flipUV*spawnSize, mat3 transform
-            float ra = random_glsl(su - 1.2345f + tt, sv - 1.2345f + tt);
-            float rb = random_glsl(su + 1.2345f + tt, sv + 1.2345f + tt);
-            float ox = (-u.jitter[0]) * (1.0f - ra) + u.jitter[0] * ra;
-            float oy = (-u.jitter[1]) * (1.0f - rb) + u.jitter[1] * rb;
-            float qx = -1.0f + (2.0f * ((su + ox) - 0.0f)) / 1.0f;
-            float qy = -1.0f + (2.0f * ((sv + oy) - 0.0f)) / 1.0f;
-            qx = qx * 1.0f * u.spawnSize[0];
-            qy = qy * -1.0f * u.spawnSize[1];
-            const float *m = u.spawnMatrix;
-            float px = m[0] * qx + m[3] * qy + m[6] * 1.0f;
-            float py = m[1] * qx + m[4] * qy + m[7] * 1.0f;
+            float px, py;
+            spawn_to_pos(u, su, sv, tt, px, py);
             float4 t = p.data[nearest_texel_f32(sv, dhf, dhm1) * p.dw + nearest_texel_f32(su, dwf, dwm1)];
             float4 other;
-            if (u.apply == 0) {            // apply/flow.glsl: vec4(pos, getFlow(pixel, time, decay))
+            if (u.apply == 2) {            // best-sample.frag: colour apply over the vignette pass
+                other = spawn_apply_color(t, spawn_vignette(su, sv), u.time, px, py);
+            } else if (u.apply == 0) {     // apply/flow.glsl: vec4(pos, getFlow(pixel, time, decay))
                 float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - t.z) * u.flowDecay));
                 other = make_float4(px, py, t.x * k, t.y * k);
             } else {                       // data-sample: identity after the vignette pass
-                float dx = su - 0.5f, dy = sv - 0.5f;
-                float amt = __builtin_fminf(1.0f - (__builtin_sqrtf(dx * dx + dy * dy) / 0.6f), 1.0f);
-                float ut = 1.0f - amt;
-                float bz = (0.1f * ut + 1.0f * amt) * ut + (1.0f * ut + 1.0f * amt) * amt;
-                float vg = __builtin_fmaxf(0.0f, bz);
+                float vg = spawn_vignette(su, sv);
                 other = make_float4(t.x * vg, t.y * vg, t.z * vg, t.w * vg);
             }
             float4 cand = make_float4(other.x, other.y, other.z * u.speed, other.w * u.speed);

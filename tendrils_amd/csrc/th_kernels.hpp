@@ -123,6 +123,7 @@ void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
+void launch_spawn_direct(const SpawnSampleParams &p, hipStream_t stream);
 constexpr int kStatsBlocks = 1024;
 
 }  // namespace th

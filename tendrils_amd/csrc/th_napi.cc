@@ -320,6 +320,36 @@ napi_value SpawnSample(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// spawnDirect(ctx, Float32Array(17) float uniforms, source, target)
+napi_value SpawnDirect(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    float *f = static_cast<float *>(a.typed(1, napi_float32_array, &n));
+    th_spawn_sample_uniforms u{};
+    if (!f || n != 17) a.ok = false;
+    else memcpy(&u, f, 17 * sizeof(float));
+    u.samples = 0; u.apply = 2;
+    int32_t source = a.i32(2), target = a.i32(3);
+    if (!a.ok) BAD_ARGS("th_spawn_direct");
+    TH_CALL("th_spawn_direct", th_spawn_direct(c, &u, source, target));
+    return undefined(env);
+}
+
+// spawnImageUpload(ctx, Float32Array rgba, w, h)
+napi_value SpawnImageUpload(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    float *px = static_cast<float *>(a.typed(1, napi_float32_array, &n));
+    int32_t w = a.i32(2), h = a.i32(3);
+    if (!a.ok || w <= 0 || h <= 0 || n < (size_t)w * (size_t)h * 4) BAD_ARGS("th_spawn_image_upload");
+    TH_CALL("th_spawn_image_upload", th_spawn_image_upload(c, px, w, h));
+    return undefined(env);
+}
+
 napi_value OpticalFlow(napi_env env, napi_callback_info info)
 {
     Args a(env, info);
@@ -426,6 +456,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"targetsUpload", TargetsUpload}, {"targetsDownload", TargetsDownload}, {"targetsClear", TargetsClear},
         {"step", Step}, {"stepN", StepN},
         {"spawnInit", SpawnInit}, {"spawnBall", SpawnBall}, {"spawnSample", SpawnSample},
+        {"spawnDirect", SpawnDirect}, {"spawnImageUpload", SpawnImageUpload},
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
         {"flowDeposit", FlowDeposit},
@@ -441,6 +472,7 @@ napi_value Init(napi_env env, napi_value exports)
     struct { const char *name; int32_t val; } consts[] = {
         {"MODE_EXACT", TH_MODE_EXACT}, {"MODE_FAST", TH_MODE_FAST}, {"STATE_F32", TH_STATE_F32}, {"STATE_F16", TH_STATE_F16},
         {"TARGET_RING", TH_TARGET_RING}, {"TARGET_TARGETS", TH_TARGET_TARGETS}, {"SOURCE_FLOW", TH_SOURCE_FLOW},
+        {"SOURCE_IMAGE", TH_SOURCE_IMAGE},
     };
     for (auto &e : consts) {
         if (napi_create_int32(env, e.val, &v) != napi_ok) return nullptr;

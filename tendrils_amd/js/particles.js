@@ -64,6 +64,7 @@ function runPass(particles, program, uniforms, target) {
       native.spawnBall(h, new Float32Array([+(uniforms.radius === undefined ? 1 : uniforms.radius),
         +(uniforms.speed || 0)]), target);
       break;
+    case 'spawn-direct':
     case 'spawn-sample': {
       const f = new Float32Array(17);
       const size = uniforms.spawnSize || [1, 1];
@@ -73,12 +74,14 @@ function runPass(particles, program, uniforms, target) {
       f[4] = +(uniforms.time || 0); f[5] = +(uniforms.speed === undefined ? 1 : uniforms.speed);
       f[6] = +(uniforms.bias === undefined ? 1 : uniforms.bias); f[7] = +(uniforms.flowDecay || 0);
       for (let k = 0; k < 9; ++k) f[8 + k] = m[k];
+      if (uniforms.spawnData.bindFor) uniforms.spawnData.bindFor(particles);   // the spawner's own image buffer
       let source = uniforms.spawnData.sourceIndex();
       if (source >= 0 && target === native.TARGET_RING) {
         // ring indices are resolved by the library after utils.step() rotated the ring
         source = (source + 1) % particles.buffers.length;
       }
-      native.spawnSample(h, f, program.fixed.samples, program.fixed.apply, source, target);
+      if (program.kind === 'spawn-direct') native.spawnDirect(h, f, source, target);
+      else native.spawnSample(h, f, program.fixed.samples, program.fixed.apply, source, target);
       break;
     }
     default:

@@ -24,7 +24,7 @@ class Program:
     """Stand-in for a compiled gl-shader object: names a kernel family."""
 
     def __init__(self, kind, **fixed):
-        self.kind = kind          # 'logic' | 'spawn-init' | 'spawn-ball' | 'spawn-sample'
+        self.kind = kind          # 'logic' | 'spawn-init' | 'spawn-ball' | 'spawn-sample' | 'spawn-direct'
         self.fixed = fixed        # compile-time constants of that shader (e.g. samples, apply)
         self.uniforms = {}
 
@@ -246,7 +246,7 @@ def run_pass(particles, program, uniforms, target):
     elif kind == "spawn-ball":
         s = _capi.SpawnBallUniforms(radius=float(uniforms.get("radius", 1)), speed=float(uniforms.get("speed", 0)))
         call("th_spawn_ball", ctx, C.byref(s), target)
-    elif kind == "spawn-sample":
+    elif kind in ("spawn-sample", "spawn-direct"):
         s = _capi.SpawnSampleUniforms()
         for name in ("spawnSize", "jitter"):
             v = uniforms.get(name, (1.0, 1.0))
@@ -256,15 +256,17 @@ def run_pass(particles, program, uniforms, target):
         m = uniforms.get("spawnMatrix", (1, 0, 0, 0, 1, 0, 0, 0, 1))
         for k in range(9):
             s.spawnMatrix[k] = float(m[k])
-        s.samples = int(program.fixed["samples"])
-        s.apply = int(program.fixed["apply"])
+        s.samples = int(program.fixed.get("samples", 0))
+        s.apply = int(program.fixed.get("apply", 2))
         src = uniforms.get("spawnData")
+        if hasattr(src, "bind_for"):                      # the spawner's own image buffer: uploaded on use
+            src.bind_for(particles)
         source = src if isinstance(src, int) else src.source_index()
         if source >= 0 and target == _capi.TH_TARGET_RING:
             # the C side resolves ring indices AFTER utils.step() rotated the ring (the order the
             # pass sees); `source` was taken from the pre-rotation list
             source = (source + 1) % len(particles.buffers)
-        call("th_spawn_sample", ctx, C.byref(s), source, target)
+        call("th_spawn_sample" if kind == "spawn-sample" else "th_spawn_direct", ctx, C.byref(s), source, target)
     else:
         raise ValueError("unknown program kind %r" % (kind,))
 

@@ -4,6 +4,7 @@
 from . import ball, init, pixels
 from .ball import spawnBall
 from .init import spawner
-from .pixels import PixelSpawner, data_sample_frag, flow_sample_frag
+from .pixels import ImageBuffer, PixelSpawner, best_sample_frag, data_sample_frag, flow_sample_frag, pixels_frag
 
-__all__ = ["init", "ball", "pixels", "spawner", "spawnBall", "PixelSpawner", "flow_sample_frag", "data_sample_frag"]
+__all__ = ["init", "ball", "pixels", "spawner", "spawnBall", "PixelSpawner", "flow_sample_frag", "data_sample_frag",
+           "best_sample_frag", "pixels_frag", "ImageBuffer"]

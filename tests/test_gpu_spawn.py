@@ -34,7 +34,7 @@ def test_spawn_ball(oracle, path):
     assert abs(got.mean() - ref.mean()) < 0.02 * ref.std() + 1e-9
 
 
-@pytest.mark.parametrize("path", [p for p in golden("spawn") if "sample" in p], ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("path", [p for p in golden("spawn") if "sample" in p and "image" not in p], ids=lambda p: p.split("/")[-1][:-4])
 def test_spawn_sample(oracle, path):
     from tendrils_amd.spawn import PixelSpawner, data_sample_frag, flow_sample_frag
     fx = load(path)
@@ -78,3 +78,30 @@ def test_spawn_init_and_targets(oracle):
     spawner().spawn(t)                                     # default program: all inert
     assert bits_equal(t.particles.read(0), oracle.spawn_init((64, 64))).all()
     t.dispose()
+
+
+@pytest.mark.parametrize("path", [p for p in golden("spawn") if "image" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_image_spawners(oracle, path):
+    """The image spawners of src/demo.main.js:455-515: PixelSpawner with its own buffer (setPixels), index.frag
+    (direct) and best-sample.frag (6 samples, colour apply over the vignette pass)."""
+    from tendrils_amd.spawn import PixelSpawner, best_sample_frag, pixels_frag
+    fx = load(path)
+    m, un = fx["meta"], fx["meta"]["uniforms"]
+    t = make(m["N"])
+    t.particles.upload_texels(fx["state"])
+    direct = m["kind"] == "spawn_direct"
+    sp = PixelSpawner(None, dict(shader=pixels_frag() if direct else best_sample_frag(),
+                                 spawnSize=un["spawnSize"], speed=un["speed"], bias=un["bias"],
+                                 jitterRad=2 if any(un["jitter"]) else 0))
+    sp.spawnMatrix = list(un["spawnMatrix"])
+    sp.setPixels(fx["data"])
+    t.timer.time = un["time"] - t.timer.step
+    sp.spawn(t)
+    assert np.allclose(sp.jitter, un["jitter"])
+    got = t.particles.read(0)
+    stats = t.particles.stats(0.01)
+    t.dispose()
+    assert bits_equal(got, oracle_spawn(oracle, fx)).all()
+    if direct:
+        assert stats["respawned"] == m["N"] * m["N"]
+        assert np.abs(got[..., 2:] - fx["out"][..., 2:]).max() <= 2e-7           # against the reference capture

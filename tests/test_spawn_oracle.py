@@ -16,6 +16,8 @@ def oracle_spawn(oracle, fx):
                                      spawnSize=un["spawnSize"], jitter=un["jitter"], speed=un["speed"],
                                      bias=un["bias"], flowDecay=un.get("flowDecay", 0.0),
                                      spawnMatrix=un["spawnMatrix"])
+    if m["kind"] == "spawn_direct":
+        return oracle.spawn_direct(u, fx["data"])
     return oracle.spawn_sample(u, fx["state"], fx["data"])
 
 
@@ -23,6 +25,18 @@ def oracle_spawn(oracle, fx):
 def test_spawn_statistics_match_reference(oracle, path):
     fx = load(path)
     got, ref = oracle_spawn(oracle, fx), fx["out"]
+    if fx["meta"]["kind"] == "spawn_direct":
+        # index.frag: no hash in the texel choice.  Velocities differ from the reference only through cos/sin
+        # (|d| <= 2e-7 at |v| <= 0.3); positions are exact without jitter, within the jitter range with it
+        # (uvToPos doubles it, spawnSize scales it: |d| <= 4*jitter*spawnSize)
+        un = fx["meta"]["uniforms"]
+        assert np.abs(got[..., 2:] - ref[..., 2:]).max() <= 2e-7
+        bound = 4 * np.abs(np.array(un["jitter"]) * np.array(un["spawnSize"])) * (1 + 1e-5)
+        d = np.abs(got[..., :2] - ref[..., :2])
+        assert (d[..., 0] <= bound[0]).all() and (d[..., 1] <= bound[1]).all()
+        if not any(un["jitter"]):
+            assert (got[..., :2].view(np.uint32) == ref[..., :2].view(np.uint32)).all()
+        return
     g, r = got.reshape(-1, 4).astype(np.float64), ref.reshape(-1, 4).astype(np.float64)
     for c in range(4):
         sd = max(r[:, c].std(), 1e-12)
