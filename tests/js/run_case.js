@@ -9,7 +9,7 @@ const root = path.join(__dirname, '..', '..');
 const T = require(path.join(root, 'tendrils_amd', 'js'));
 const { OpticalFlow } = require(path.join(root, 'tendrils_amd', 'js', 'optical-flow'));
 const { spawnBall } = require(path.join(root, 'tendrils_amd', 'js', 'spawn', 'ball'));
-const { PixelSpawner, flowSampleFrag, dataSampleFrag } = require(path.join(root, 'tendrils_amd', 'js', 'spawn', 'pixels'));
+const { PixelSpawner, flowSampleFrag, dataSampleFrag, bestSampleFrag, pixelsFrag } = require(path.join(root, 'tendrils_amd', 'js', 'spawn', 'pixels'));
 
 const spec = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
 const dir = path.dirname(process.argv[2]);
@@ -73,6 +73,18 @@ if (spec.kind === 'logic') {
     buffer: flowSrc ? t.flow : t.particles.buffers[0],
     spawnSize: spec.uniforms.spawnSize, speed: spec.uniforms.speed, bias: spec.uniforms.bias
   });
+  t.timer.time = spec.uniforms.time - t.timer.step;
+  sp.spawn(t);
+  save('out_0.bin', t.particles.read(0));
+  fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, jitter: sp.jitter }));
+} else if (spec.kind === 'spawn_image') {         // image spawners (src/demo.main.js:455-515)
+  const sp = new PixelSpawner(null, {
+    shader: spec.direct ? pixelsFrag() : bestSampleFrag(),
+    spawnSize: spec.uniforms.spawnSize, speed: spec.uniforms.speed, bias: spec.uniforms.bias,
+    jitterRad: spec.jitterRad
+  });
+  sp.spawnMatrix = spec.uniforms.spawnMatrix;
+  sp.setPixels(f32(spec.inputs.image), spec.imageShape);
   t.timer.time = spec.uniforms.time - t.timer.step;
   sp.spawn(t);
   save('out_0.bin', t.particles.read(0));

@@ -213,3 +213,18 @@ def test_js_frame_loop_step_and_draw(tmp_path, oracle):
         counts.append(k)
     assert res["fragments"] == counts and abs(res["time"] - time) < 1e-9
     assert bits_equal(got_state, cur).all() and bits_equal(got_flow, flow).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["spawn_image_direct_64", "spawn_image_best_sample_64"])
+def test_js_image_spawners(tmp_path, oracle, name):
+    from test_spawn_oracle import oracle_spawn
+    fx = load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    m, un = fx["meta"], fx["meta"]["uniforms"]
+    ih, iw = fx["data"].shape[:2]
+    run_case(tmp_path, dict(kind="spawn_image", N=m["N"], viewRes=[96, 54], direct=m["kind"] == "spawn_direct",
+                            jitterRad=2 if any(un["jitter"]) else 0, imageShape=[iw, ih], uniforms=un,
+                            inputs=dict(state="state.bin", image="image.bin")),
+             {"state.bin": fx["state"], "image.bin": fx["data"]})
+    got = np.fromfile(str(tmp_path / "out_0.bin"), np.float32).reshape(m["N"], m["N"], 4)
+    assert bits_equal(got, oracle_spawn(oracle, fx)).all()
