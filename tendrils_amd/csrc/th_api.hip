@@ -126,10 +126,11 @@ struct th_context {
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
-    uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_cursor = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;
-    uint32_t *dep_list = nullptr, *dep_order = nullptr;
+    uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line
+    uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     float4 *dep_colors = nullptr;
-    size_t dep_texels = 0, dep_capacity = 0;
+    void *dep_temp = nullptr;
+    size_t dep_lines = 0, dep_capacity = 0, dep_temp_bytes = 0;
     float4 *image = nullptr;             // PixelSpawner's own buffer (TH_SOURCE_IMAGE)
     int32_t iw = 0, ih = 0;
     unsigned long long *d_respawned = nullptr;   // [0]: particles replaced by respawn passes, [1]: scratch (passes into `targets`)
@@ -424,8 +425,9 @@ th_status th_destroy(th_context *c)
     for (float4 *b : c->ring) (void)hipFree(b);
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
-    (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_cursor); (void)hipFree(c->dep_blocks);
-    (void)hipFree(c->dep_total); (void)hipFree(c->dep_list); (void)hipFree(c->dep_order); (void)hipFree(c->dep_colors);
+    (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
+    for (uint32_t *q : c->dep_u32) (void)hipFree(q);
+    (void)hipFree(c->dep_colors); (void)hipFree(c->dep_temp);
     (void)hipFree(c->image);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
@@ -954,18 +956,17 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "flow deposit needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
-    const size_t texels = (size_t)c->fw * c->fh;
-    TH_REQUIRE(texels > 0 && (uint64_t)c->cfg.width * c->cfg.height < (1ull << 32), "bad shapes");
-    if (c->dep_texels != texels) {
+    const size_t lines = c->texels();
+    TH_REQUIRE((size_t)c->fw * c->fh > 0 && lines < (1ull << 32), "bad shapes");
+    if (c->dep_lines != lines) {
         TH_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_cursor); (void)hipFree(c->dep_blocks);
-        c->dep_count = c->dep_offset = c->dep_cursor = c->dep_blocks = nullptr;
-        TH_HIP(hipMalloc((void **)&c->dep_count, texels * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->dep_offset, texels * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->dep_cursor, texels * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_blocks((uint32_t)texels) * sizeof(uint32_t)));
+        (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks);
+        c->dep_count = c->dep_offset = c->dep_blocks = nullptr;
+        TH_HIP(hipMalloc((void **)&c->dep_count, lines * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_offset, lines * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_blocks((uint32_t)lines) * sizeof(uint32_t)));
         if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, sizeof(uint32_t)));
-        c->dep_texels = texels;
+        c->dep_lines = lines;
     }
     th::DepositParams p{};
     {   // a packed ring is read through f32 views (what the stored texels decode to)
@@ -982,9 +983,7 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
         const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.height > 2 ? 2 * c->cfg.height : 2;
         p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
     }
-    p.count = c->dep_count; p.offset = c->dep_offset; p.cursor = c->dep_cursor; p.list = c->dep_list;
-    TH_HIP(hipMemsetAsync(c->dep_count, 0, texels * sizeof(uint32_t), c->stream));
-    TH_HIP(hipMemsetAsync(c->dep_cursor, 0, texels * sizeof(uint32_t), c->stream));
+    p.count = c->dep_count; p.offset = c->dep_offset;
     th::launch_deposit_count(p, c->stream);
     th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
     uint32_t total = 0;
@@ -992,19 +991,28 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     TH_HIP(hipStreamSynchronize(c->stream));
     if (fragments) *fragments = total;
     if (total == 0) return TH_OK;
+    TH_REQUIRE(total < (1u << 31), "too many fragments (%u)", total);
     if (c->dep_capacity < total) {
-        (void)hipFree(c->dep_list); (void)hipFree(c->dep_order); (void)hipFree(c->dep_colors);
-        c->dep_list = c->dep_order = nullptr; c->dep_colors = nullptr;
+        for (uint32_t *&q : c->dep_u32) { (void)hipFree(q); q = nullptr; }
+        (void)hipFree(c->dep_colors); c->dep_colors = nullptr;
+        (void)hipFree(c->dep_temp); c->dep_temp = nullptr; c->dep_temp_bytes = 0;
         c->dep_capacity = 0;
         const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
-        TH_HIP(hipMalloc((void **)&c->dep_list, cap * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->dep_order, cap * sizeof(uint32_t)));
+        for (uint32_t *&q : c->dep_u32) TH_HIP(hipMalloc((void **)&q, cap * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_colors, cap * sizeof(float4)));
         c->dep_capacity = cap;
     }
-    p.list = c->dep_list; p.order = c->dep_order; p.colors = c->dep_colors;
+    p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
+    p.colors = c->dep_colors;
+    const size_t need = th::deposit_sort_temp_bytes(p, total);
+    if (c->dep_temp_bytes < need) {
+        (void)hipFree(c->dep_temp); c->dep_temp = nullptr; c->dep_temp_bytes = 0;
+        TH_HIP(hipMalloc(&c->dep_temp, need + need / 4));
+        c->dep_temp_bytes = need + need / 4;
+    }
     th::launch_deposit_scatter(p, c->stream);
-    th::launch_deposit_blend(p, c->stream);
+    TH_HIP(th::launch_deposit_sort(p, total, c->dep_temp, c->dep_temp_bytes, c->stream));
+    th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
     return TH_OK;
 }

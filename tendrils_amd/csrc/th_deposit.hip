@@ -9,14 +9,18 @@
 // written in the same order and precision as the checker's restatement so that both agree bit for bit.
 //
 // GL blends fragments in primitive order, which a parallel machine has to reconstruct:
-//   1. deposit_raster_kernel<false>: one thread per line, rasterise, count fragments per flow texel (atomics)
-//   2. exclusive scan of the per-texel counts -> list offsets
-//   3. deposit_raster_kernel<true>: rasterise again, append (line stream index, interpolated varying) to every
-//      covered texel's list
-//   4. deposit_blend_kernel: one thread per touched texel walks its list in ascending stream index and blends
-//      sequentially: dst = src*a + dst*(1-a), exactly GL's order and arithmetic.  Short lists are walked by
-//      repeated minimum search; long ones (crowded texels: thousands of fragments) are ranked by the whole wave first.
-// The result is independent of thread scheduling (the append order is never used).
+//   1. deposit_raster_kernel<false>: one thread per line, rasterise, store the line's fragment count at its stream
+//      index (no atomics)
+//   2. exclusive scan over the stream -> every line's first fragment slot: the fragment array is in stream order
+//   3. deposit_raster_kernel<true>: rasterise again, write (texel, interpolated varying) into the line's slots
+//   4. stable radix sort of the fragments by texel (rocPRIM through hipCUB): each texel's fragments end up
+//      contiguous and still in stream order
+//   5. deposit_blend_kernel: the thread at the head of a texel's run walks it and blends sequentially:
+//      dst = src*a + dst*(1-a), exactly GL's order and arithmetic.
+// No step depends on thread scheduling, and the cost does not depend on how crowded single texels are (the
+// wake makes particles converge: thousands of fragments in one texel are normal after a few dozen frames).
+#include <hipcub/hipcub.hpp>
+
 #include "th_kernels.hpp"
 #include "th_math.hpp"
 
@@ -203,29 +207,32 @@ TH_D float4 dep_varying(const DepositLine &L, int x, int y)
                        L.a.c[2] + t * (L.b.c[2] - L.a.c[2]), L.a.c[3] + t * (L.b.c[3] - L.a.c[3]));
 }
 
-// passes 1 and 3: count, or append (line id, varying) to the covered texels' lists
+// passes 1 and 3: count the line's fragments, or write them into its slots of the stream-ordered fragment array
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams p)
 {
     const uint32_t lines = p.W * p.H;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
-        // threads walk the particle texture row-major (coalesced state reads); the line's identity for the blend
-        // order stays its position in the column-major vertex stream
+        // threads walk the particle texture row-major (coalesced state reads); the line's place in the fragment
+        // array is its position in the column-major vertex stream
         const uint32_t row = t / p.W, col = t - row * p.W;
         const uint32_t id = col * p.H + row;
         DepositLine L;
         dep_setup(p, id, L, true);
-        if (!L.draws) continue;
-        dep_raster(p, L, [&](int x, int y) {
-            const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
-            if constexpr (SCATTER) {
-                const uint32_t at = p.offset[texel] + atomicAdd(&p.cursor[texel], 1u);
-                p.list[at] = id;
+        if constexpr (SCATTER) {
+            if (!L.draws) continue;
+            uint32_t at = p.offset[id];
+            dep_raster(p, L, [&](int x, int y) {
+                p.keys[at] = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
+                p.slots[at] = at;
                 p.colors[at] = dep_varying(L, x, y);
-            } else {
-                atomicAdd(&p.count[texel], 1u);
-            }
-        });
+                ++at;
+            });
+        } else {
+            uint32_t n = 0;
+            if (L.draws) dep_raster(p, L, [&](int, int) { ++n; });
+            p.count[id] = n;
+        }
     }
 }
 
@@ -238,54 +245,23 @@ TH_D void dep_blend(float4 &d, float4 c)
     d.w = c.w * sa + d.w * da;
 }
 
-constexpr uint32_t kShortList = 24;      // up to here a thread orders its list by repeated minimum search
-
-// pass 4: one thread per flow texel; a wave helps its long lists
-__global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p)
+// pass 5: fragments sorted by texel (stable: stream order inside a texel); the head of each run blends it
+__global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p, uint32_t total)
 {
-    const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh;
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base < texels; base += gridDim.x * 256u) {
-        const uint32_t texel = base + lane;
-        const uint32_t n = texel < texels ? p.count[texel] : 0u;
-        const uint32_t off = n ? p.offset[texel] : 0u;
-        if (n > 0 && n <= kShortList) {
-            float4 d = p.flow[texel];
-            long long last = -1;
-            for (uint32_t r = 0; r < n; ++r) {             // ids are distinct: next = the smallest id above the last one
-                uint32_t best = 0xffffffffu, bk = 0;
-                for (uint32_t k = 0; k < n; ++k) {
-                    const uint32_t id = p.list[off + k];
-                    if ((long long)id > last && id <= best) { best = id; bk = k; }
-                }
-                dep_blend(d, p.colors[off + bk]);
-                last = best;
-            }
-            p.flow[texel] = d;
-        }
-        // long lists of this wave's 64 texels, one after the other, all lanes ranking: order[rank] = position
-        unsigned long long todo = __ballot(n > kShortList);
-        while (todo) {
-            const int owner = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const uint32_t on = __shfl(n, owner), ooff = __shfl(off, owner);
-            for (uint32_t k = lane; k < on; k += 64u) {
-                const uint32_t id = p.list[ooff + k];
-                uint32_t rank = 0;
-                for (uint32_t q = 0; q < on; ++q) rank += p.list[ooff + q] < id ? 1u : 0u;
-                p.order[ooff + rank] = k;
-            }
-        }
-        __threadfence();
-        if (n > kShortList) {                              // the owner walks its ranked list (written by its own wave)
-            float4 d = p.flow[texel];
-            for (uint32_t r = 0; r < n; ++r) dep_blend(d, p.colors[off + p.order[off + r]]);
-            p.flow[texel] = d;
-        }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t texel = p.keys_sorted[i];
+        if (i > 0 && p.keys_sorted[i - 1] == texel) continue;
+        float4 d = p.flow[texel];
+        uint32_t j = i;
+        do {
+            dep_blend(d, p.colors[p.slots_sorted[j]]);
+            ++j;
+        } while (j < total && p.keys_sorted[j] == texel);
+        p.flow[texel] = d;
     }
 }
 
-// ---- exclusive scan of the per-texel counts (three small kernels; 1024 elements per block) --------------------
+// ---- exclusive scan of the per-line fragment counts (three small kernels; 1024 elements per block) -------------
 constexpr uint32_t kScanBlock = 1024;
 
 __global__ __launch_bounds__(256) void scan_local_kernel(const uint32_t *in, uint32_t *out, uint32_t *block_sums, uint32_t n)
@@ -350,7 +326,7 @@ int deposit_grid(uint32_t n)
 
 }  // namespace
 
-uint32_t deposit_scan_blocks(uint32_t texels) { return (texels + kScanBlock - 1) / kScanBlock; }
+uint32_t deposit_scan_blocks(uint32_t n) { return (n + kScanBlock - 1) / kScanBlock; }
 
 void launch_deposit_count(const DepositParams &p, hipStream_t s)
 {
@@ -359,10 +335,10 @@ void launch_deposit_count(const DepositParams &p, hipStream_t s)
 
 void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t s)
 {
-    const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh, nb = deposit_scan_blocks(texels);
-    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, s, p.count, p.offset, block_sums, texels);
+    const uint32_t lines = p.W * p.H, nb = deposit_scan_blocks(lines);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, s, p.count, p.offset, block_sums, lines);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, block_sums, nb, total);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, s, p.offset, block_sums, texels);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, s, p.offset, block_sums, lines);
 }
 
 void launch_deposit_scatter(const DepositParams &p, hipStream_t s)
@@ -370,9 +346,31 @@ void launch_deposit_scatter(const DepositParams &p, hipStream_t s)
     hipLaunchKernelGGL(deposit_raster_kernel<true>, dim3(deposit_grid(p.W * p.H)), dim3(256), 0, s, p);
 }
 
-void launch_deposit_blend(const DepositParams &p, hipStream_t s)
+static int deposit_key_bits(const DepositParams &p)
 {
-    hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid((uint32_t)p.fw * (uint32_t)p.fh)), dim3(256), 0, s, p);
+    const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh;
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < texels) ++bits;
+    return bits;
+}
+
+size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, p.keys, p.keys_sorted, p.slots, p.slots_sorted, (int)total, 0,
+                                             deposit_key_bits(p), (hipStream_t) nullptr);
+    return bytes;
+}
+
+hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t s)
+{
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, p.keys, p.keys_sorted, p.slots, p.slots_sorted, (int)total, 0,
+                                              deposit_key_bits(p), s);
+}
+
+void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
+{
+    hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
 }
 
 }  // namespace th

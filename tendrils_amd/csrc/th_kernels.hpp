@@ -86,10 +86,10 @@ struct DepositParams {
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
     double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)
-    uint32_t *count, *offset, *cursor;   // per flow texel: fragments, list start, fill cursor
-    uint32_t *list;              // line stream indices, grouped by texel
-    uint32_t *order;             // long lists: position of the r-th fragment in stream order
-    float4 *colors;              // the fragments' interpolated varyings, same indexing as list
+    uint32_t *count, *offset;    // per line (stream order): fragments, first slot in the fragment array
+    uint32_t *keys, *slots;      // per fragment (stream order): flow texel, own slot
+    uint32_t *keys_sorted, *slots_sorted;   // the same after the stable sort by texel
+    float4 *colors;              // per fragment (stream order): interpolated varying
 };
 
 struct StatsPartial {
@@ -120,7 +120,9 @@ uint32_t deposit_scan_blocks(uint32_t texels);
 void launch_deposit_count(const DepositParams &p, hipStream_t stream);
 void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
 void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
-void launch_deposit_blend(const DepositParams &p, hipStream_t stream);
+size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total);
+hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t stream);
+void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
 void launch_spawn_direct(const SpawnSampleParams &p, hipStream_t stream);
