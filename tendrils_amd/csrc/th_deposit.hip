@@ -180,8 +180,16 @@ TH_D void dep_raster(const DepositParams &p, const DepositLine &L, Emit emit)
             if (e0 < base) e0 = base;
             if (e1 > top) e1 = top;
             const long long DX = X2 - X1, DY = Y2 - Y1;
+            // short edges inside a 32768-texel-wide view (every practical case): the same quotient in 32-bit arithmetic
+            const bool small = DY < 1024 && DX > -4096 && DX < 4096 && X1 > -(1 << 19) && X1 < (1 << 19);
             for (int y = e0; y < e1; ++y) {
-                long long x = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                long long x;
+                if (small) {
+                    const int num = (int)DX * ((y << 4) - Y1) + X1 * (int)DY, den = 16 * (int)DY;
+                    int q = num / den;
+                    if (num % den > 0) ++q;
+                    x = q;
+                } else x = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
                 if (x < 0) x = 0;
                 if (x > p.fw) x = p.fw;
 #pragma unroll
@@ -213,8 +221,9 @@ __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams
 {
     const uint32_t lines = p.W * p.H;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
-        // threads walk the particle texture row-major (coalesced state reads); the line's place in the fragment
-        // array is its position in the column-major vertex stream
+        // threads walk the particle texture row-major (coalesced state reads; walking the column-major stream
+        // instead makes the fragment writes contiguous but the state reads strided: 3.6 -> 5.3 ms per draw at C3);
+        // the line's place in the fragment array is its position in the vertex stream
         const uint32_t row = t / p.W, col = t - row * p.W;
         const uint32_t id = col * p.H + row;
         DepositLine L;
