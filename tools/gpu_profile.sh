@@ -7,10 +7,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${TAG:-r1}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 20 --warmup 3 --no-cpu --no-traffic $*"
+ARGS="--steps 64 --warmup 32 --no-cpu --no-traffic $*"
 cd /tmp
 echo "== kernel trace"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu --no-traffic $* > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 64 --warmup 32 --no-cpu --no-traffic $* > $OUT/trace.log 2>&1
 run_pmc () {
   name=$1; shift
   echo "== pmc $name: $*"
