@@ -124,7 +124,8 @@ typedef struct th_spawn_sample_uniforms {
     float spawnMatrix[9];    /* column-major mat3 */
     int32_t samples;         /* flow-sample 5, data-sample 2 */
     int32_t apply;           /* 0: apply/flow.glsl; 1: apply/identity.glsl over the vignette pass (data-sample.frag);
-                                2: apply/color.glsl over the vignette pass (best-sample.frag, index.frag) */
+                                2: apply/color.glsl over the vignette pass (best-sample.frag, index.frag);
+                                3: apply/brightest.glsl (bright-sample.frag, GeometrySpawner) */
 } th_spawn_sample_uniforms;
 
 /* Uniforms of the flow pass of Tendrils.draw(): src/flow/vert/head.vert:8-12 (viewSize, time, speedLimit). */
@@ -197,6 +198,12 @@ th_status th_spawn_sample(th_context *ctx, const th_spawn_sample_uniforms *u, in
 th_status th_spawn_direct(th_context *ctx, const th_spawn_sample_uniforms *u, int32_t source, int32_t target);
 /* PixelSpawner.buffer (src/spawn/pixels/index.js:17,34-36: a float FBO) + setPixels: w x h RGBA float texels. */
 th_status th_spawn_image_upload(th_context *ctx, const float *rgba, int32_t w, int32_t h);
+/* GeometrySpawner.spawn's draw (src/spawn/geometry/index.js:97-115): resize the spawner's buffer to w x h, clear it,
+ * and blend `triangles` triangles (6 floats each: xy of three vertices, clip space before the viewSize scale of
+ * src/geom/vert/index.vert) in `color` (src/geom/frag/index.frag). */
+th_status th_spawn_image_triangles(th_context *ctx, const float *positions, int32_t triangles, const float viewSize[2],
+                                   const float color[4], int32_t w, int32_t h);
+th_status th_spawn_image_download(th_context *ctx, float *rgba);           /* read-back (tests) */
 
 /* -- optical flow producer: OpticalFlow (src/optical-flow/index.js:32-71) ---- */
 th_status th_frames_resize(th_context *ctx, int32_t w, int32_t h);     /* OpticalFlow.resize */

@@ -425,6 +425,38 @@ def gen_spawn_image(r, only):
                                       samples=6, apply=2, uniforms=un)))
 
 
+def gen_geometry(r, only):
+    """GeometrySpawner (src/spawn/geometry/index.js): the triangle draw into the spawner's buffer and the
+    bright-sample.frag pass over it.  Triangles as shuffle() builds them (centre + two rim vertices), from a seed."""
+    rng = np.random.default_rng(4713)
+    fw, fh = 96, 54
+    view_size = [1.0, fw / fh]
+    pos = []
+    for _ in range(7):
+        ang = rng.uniform(0, 2 * np.pi)
+        arc = 2 * np.pi * (0.01 + rng.uniform(0, 0.03) + (rng.random() < 0.5) * 0.25)
+        r1, r2 = 0.25 + rng.uniform(0, 1.3), 0.25 + rng.uniform(0, 1.3)
+        pos += [0.0, 0.0, np.cos(ang - arc) * r1, np.sin(ang - arc) * r1, np.cos(ang + arc) * r2, np.sin(ang + arc) * r2]
+    pos = [float(np.float32(v)) for v in pos]
+    if not only or only in "geometry_triangles_96x54":
+        for name, col in (("geometry_triangles_96x54", [1, 1, 1, 1]), ("geometry_triangles_translucent_96x54", [0.9, 0.5, 0.2, 0.6])):
+            img = r.shader("geometry_frag", (fw, fh), uniforms={"color": col, "viewSize": view_size}, blend=True,
+                           vert="geometry_vert", positions=pos)
+            save(name, positions=np.array(pos, np.float32), out=img,
+                 uniforms=json.dumps(dict(kind="geometry", shape=[fw, fh], viewSize=view_size, color=col)))
+    if not only or only in "spawn_geometry_bright_sample_64":
+        n = 64
+        st = rand_state(rng, n, 0.3, 1.0, 0.004)
+        img = r.shader("geometry_frag", (fw, fh), uniforms={"color": [1, 1, 1, 1], "viewSize": view_size}, blend=True,
+                       vert="geometry_vert", positions=pos)
+        # src/demo.main.js:446-447: speed 0.005, bias 1e2/5e-3
+        un = dict(dataRes=[n, n], geomRes=[n, 2 * n], spawnSize=[1.0, 1.0], jitter=[2 / fw, 2 / fh], time=2016.67,
+                  speed=0.005, bias=1e2 / 5e-3, spawnMatrix=[1, 0, 0, 0, 1, 0, 0, 0, 1])
+        ref = r.shader("spawn_bright_sample", (n, n), textures={"particles": st, "spawnData": img}, uniforms=un)
+        save("spawn_geometry_bright_sample_64", state=st, data=img, out=ref,
+             uniforms=json.dumps(dict(kind="spawn_sample", N=n, samples=6, apply=3, uniforms=un)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -439,6 +471,7 @@ def main():
     gen_optical_flow(r, args.only)
     gen_spawn(r, args.only)
     gen_spawn_image(r, args.only)
+    gen_geometry(r, args.only)
 
 
 if __name__ == "__main__":

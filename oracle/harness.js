@@ -218,14 +218,15 @@
     if (job.blend) { gl.enable(gl.BLEND); gl.blendFunc(gl.SRC_ALPHA, gl.ONE_MINUS_SRC_ALPHA); }
     else gl.disable(gl.BLEND);
 
-    // gl-big-triangle geometry
     var vb = gl.createBuffer();
     gl.bindBuffer(gl.ARRAY_BUFFER, vb);
-    gl.bufferData(gl.ARRAY_BUFFER, new Float32Array([-1, -1, -1, 4, 4, -1]), gl.STATIC_DRAW);
+    // gl-big-triangle geometry, or caller-supplied triangles (GeometrySpawner's draw, src/spawn/geometry/index.js:103-115)
+    var verts = job.positions ? new Float32Array(job.positions) : new Float32Array([-1, -1, -1, 4, 4, -1]);
+    gl.bufferData(gl.ARRAY_BUFFER, verts, gl.STATIC_DRAW);
     gl.enableVertexAttribArray(0);
     gl.vertexAttribPointer(0, 2, gl.FLOAT, false, 0, 0);
     gl.viewport(0, 0, job.outW, job.outH);
-    gl.drawArrays(gl.TRIANGLES, 0, 3);
+    gl.drawArrays(gl.TRIANGLES, 0, verts.length / 2);
     return {out: f32ToB64(readFBO(gl, job.outW, job.outH)), err: gl.getError()};
   }
 

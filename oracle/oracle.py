@@ -102,6 +102,8 @@ def lib():
         L.to_spawn_sample.argtypes = [C.POINTER(SpawnSampleUniforms), fp, fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.to_spawn_direct.restype = None
         L.to_spawn_direct.argtypes = [C.POINTER(SpawnSampleUniforms), fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.to_triangles.restype = None
+        L.to_triangles.argtypes = [fp, C.c_int, fp, fp, fp, C.c_int, C.c_int]
         L.to_flow_deposit.restype = C.c_long
         L.to_flow_deposit.argtypes = [C.POINTER(DepositUniforms), fp, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         _lib = L
@@ -234,4 +236,15 @@ def spawn_direct(u, spawn_data, y0=0, rows=None):
     out = np.empty((rows, u.data_w, 4), np.float32)
     sh, sw = spawn_data.shape[:2]
     lib().to_spawn_direct(C.byref(u), _fp(out), int(y0), int(rows), _fp(spawn_data), sw, sh)
+    return out
+
+
+def triangles(positions, shape, view_size=(1.0, 1.0), color=(1.0, 1.0, 1.0, 1.0), img=None):
+    """GeometrySpawner's draw: triangles (flat xy list, 6 floats each) into a cleared [h, w, 4] float image."""
+    w, h = shape
+    pos = np.ascontiguousarray(positions, np.float32).ravel()
+    out = np.zeros((h, w, 4), np.float32) if img is None else np.array(img, np.float32, copy=True, order="C")
+    vs = np.asarray(view_size, np.float32)
+    col = np.asarray(color, np.float32)
+    lib().to_triangles(_fp(pos), len(pos) // 6, _fp(vs), _fp(col), _fp(out), int(w), int(h))
     return out

@@ -122,6 +122,12 @@ class RefRunner:
                     out["spawn_ball"] = t
                 elif "uniform sampler2D last;" in t and "gradMag" in t:
                     out["optical_flow"] = t
+                elif "gl_Position = vec4(position*viewSize, 0.0, 1.0)" in t:
+                    out["geometry_vert"] = t              # src/geom/vert/index.vert
+                elif "gl_FragColor = color;" in t and "uniform vec4 color" in t and "varying" not in t:
+                    out["geometry_frag"] = t              # src/geom/frag/index.frag
+                elif "spawnData" in t and "luma" in t and "const float samples = 6.0" in t:
+                    out["spawn_bright_sample"] = t        # bright-sample.frag (GeometrySpawner)
                 elif "spawnData" in t and "rgb2hsv" in t and "const float samples = 6.0" in t:
                     out["spawn_best_sample"] = t          # best-sample.frag: colour apply, vignette
                 elif "spawnData" in t and "rgb2hsv" in t and "samples" not in t:
@@ -135,8 +141,10 @@ class RefRunner:
             self._demo_shaders = out
         return self._demo_shaders
 
-    def shader(self, frag, out_shape, textures=None, uniforms=None, blend=False, dst=None):
-        """One big-triangle pass of compiled reference shader `frag` (name in demo_shaders())."""
+    def shader(self, frag, out_shape, textures=None, uniforms=None, blend=False, dst=None, vert="screen_vert",
+               positions=None):
+        """One pass of compiled reference shader `frag` (name in demo_shaders()): the big triangle, or the
+        triangles in `positions` (flat xy list) with vertex shader `vert`."""
         sh = self.demo_shaders()
         w, h = out_shape
         tex = {}
@@ -146,11 +154,13 @@ class RefRunner:
                 tex[name] = {"type": "u8", "w": tw, "h": th, "data": _b64(arr, np.uint8)}
             else:
                 tex[name] = {"type": "f32", "w": tw, "h": th, "data": _b64(arr, np.float32)}
-        job = {"kind": "shader", "vert": sh["screen_vert"], "frag": sh[frag],
+        job = {"kind": "shader", "vert": sh[vert], "frag": sh[frag],
                "outW": int(w), "outH": int(h), "textures": tex, "uniforms": uniforms or {},
                "blend": bool(blend)}
         if dst is not None:
             job["dst"] = _b64(dst, np.float32)
+        if positions is not None:
+            job["positions"] = [float(v) for v in positions]
         res = self._run(job)
         if res.get("err"):
             raise RuntimeError("GL error %s" % res["err"])

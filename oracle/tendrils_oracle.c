@@ -480,7 +480,18 @@ void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, 
                 spawn_to_pos(u, su, sv, &px, &py);
                 const float *t = tex_f32(spawn_data, sw, sh, su, sv);
                 float other[4];
-                if (u->apply == 2) {
+                if (u->apply == 3) {
+                    /* bright-sample.frag -> apply/brightest.glsl:11-15 (no filter pass):
+                     * vec4(pos, angleToVec(mod(random(uv*dot(pixel.rg, pixel.ba)), 1.0)*tau)*luma(pixel)*pixel.a) */
+                    float sc = t[0] * t[2] + t[1] * t[3];
+                    float ang = modf_glsl(to_random(su * sc, sv * sc), 1.0f) * 6.28318530717958647692f;
+                    float sn, cs;
+                    sincos_pinned(ang, &sn, &cs);
+                    float lum = (t[0] * 0.299f + t[1] * 0.587f) + t[2] * 0.114f;       /* glsl-luma */
+                    other[0] = px; other[1] = py;
+                    other[2] = (cs * lum) * t[3];
+                    other[3] = (sn * lum) * t[3];
+                } else if (u->apply == 2) {
                     /* best-sample.frag: colour apply over the vignette pass */
                     spawn_apply_color(t, spawn_vignette(su, sv), u->time, px, py, other);
                 } else if (u->apply == 0) {
@@ -678,4 +689,88 @@ long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const f
         }
     }
     return fragments;
+}
+
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * GeometrySpawner's draw (src/spawn/geometry/index.js:97-115): triangles gl_Position = (position*viewSize, 0, 1)
+ * (src/geom/vert/index.vert:3-5) in a constant colour (src/geom/frag/index.frag:3-5) into the spawner's float
+ * buffer, blend SRC_ALPHA / ONE_MINUS_SRC_ALPHA as left by Tendrils.step().  Same rasteriser conventions as the
+ * flow deposit above (clip-space clipping, 1/16-texel snapping, ceil() scan conversion, texels left <= x < right);
+ * either winding is drawn (no culling).  Pinned by tests/golden/geometry_*.npz.
+ * ------------------------------------------------------------------------------------------------------------- */
+void to_triangles(const float *positions, int ntri, const float *view_size, const float *color,
+                  float *img, int w, int h)
+{
+    const float wx16 = 8.0f * (float)w, wy16 = 8.0f * (float)h;
+    const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
+    for (int t = 0; t < ntri; ++t) {
+        float cx[16], cy[16], tx_[16], ty_[16];
+        int n = 3;
+        for (int k = 0; k < 3; ++k) {
+            cx[k] = positions[6 * t + 2 * k] * view_size[0];
+            cy[k] = positions[6 * t + 2 * k + 1] * view_size[1];
+        }
+        for (int plane = 0; plane < 4 && n >= 3; ++plane) {
+            int q = 0;
+            for (int k = 0; k < n; ++k) {
+                const int j = k == n - 1 ? 0 : k + 1;
+                float di, dj;
+                switch (plane) {
+                case 0: di = 1.0f + cx[k]; dj = 1.0f + cx[j]; break;
+                case 1: di = 1.0f - cx[k]; dj = 1.0f - cx[j]; break;
+                case 2: di = 1.0f - cy[k]; dj = 1.0f - cy[j]; break;
+                default: di = 1.0f + cy[k]; dj = 1.0f + cy[j]; break;
+                }
+                if (di >= 0.0f) {
+                    tx_[q] = cx[k]; ty_[q] = cy[k]; ++q;
+                    if (dj < 0.0f) {
+                        const float D = 1.0f / (dj - di);
+                        tx_[q] = (dj * cx[k] - di * cx[j]) * D; ty_[q] = (dj * cy[k] - di * cy[j]) * D; ++q;
+                    }
+                } else if (dj > 0.0f) {
+                    const float D = 1.0f / (di - dj);
+                    tx_[q] = (di * cx[j] - dj * cx[k]) * D; ty_[q] = (di * cy[j] - dj * cy[k]) * D; ++q;
+                }
+            }
+            n = q;
+            for (int k = 0; k < n; ++k) { cx[k] = tx_[k]; cy[k] = ty_[k]; }
+        }
+        if (n < 3) continue;
+        int PX[16], PY[16];
+        for (int k = 0; k < n; ++k) { PX[k] = snap16(cx[k], wx16, x0); PY[k] = snap16(cy[k], wy16, y0); }
+        /* orientation of the snapped polygon: edges running up in y are left edges (as for the deposit's hexagons);
+         * a polygon of the other winding is walked backwards */
+        long long area2 = 0;
+        for (int k = 0; k < n; ++k) {
+            const int j = (k + 1) % n;
+            area2 += (long long)PX[k] * PY[j] - (long long)PX[j] * PY[k];
+        }
+        if (area2 == 0) continue;
+        if (area2 > 0)
+            for (int a = 0, b = n - 1; a < b; ++a, --b) {
+                int tmp = PX[a]; PX[a] = PX[b]; PX[b] = tmp;
+                tmp = PY[a]; PY[a] = PY[b]; PY[b] = tmp;
+            }
+        for (int y = 0; y < h; ++y) {
+            int left = w, right = 0;
+            for (int k = 0; k < n; ++k) {
+                int Xa = PX[k], Ya = PY[k], Xb = PX[(k + 1) % n], Yb = PY[(k + 1) % n];
+                if (Ya == Yb) continue;
+                const int swap = Yb < Ya;
+                const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
+                if (y < ((Y1 + 15) >> 4) || y >= ((Y2 + 15) >> 4)) continue;
+                const long long DX = X2 - X1, DY = Y2 - Y1;
+                long x = ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                if (x < 0) x = 0;
+                if (x > w) x = w;
+                if (swap) right = (int)x; else left = (int)x;
+            }
+            for (int x = left; x < right; ++x) {
+                float *d = img + 4 * ((size_t)y * w + x);
+                const float sa = color[3], da = 1.0f - sa;
+                for (int k = 0; k < 4; ++k) d[k] = color[k] * sa + d[k] * da;
+            }
+        }
+    }
 }

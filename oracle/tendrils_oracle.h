@@ -72,7 +72,8 @@ typedef struct to_spawn_sample_uniforms {
     float spawnMatrix[9];   /* column-major mat3 as uploaded by uniformMatrix3fv */
     int32_t samples;        /* 5 = flow-sample.frag:8, 2 = data-sample.frag:10 */
     int32_t apply;          /* 0 = apply/flow.glsl, 1 = identity over the vignette pass (data-sample.frag),
-                               2 = apply/color.glsl over the vignette pass (best-sample.frag, index.frag) */
+                               2 = apply/color.glsl over the vignette pass (best-sample.frag, index.frag),
+                               3 = apply/brightest.glsl (bright-sample.frag: GeometrySpawner) */
 } to_spawn_sample_uniforms;
 
 /* src/spawn/pixels/frag/best-sample-main.frag:21-46 over rows [y0,y0+rows). */
@@ -82,6 +83,10 @@ void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, 
 /* src/spawn/pixels/index.frag (frag/direct-main.frag:10-21): every particle from its own texel of spawn_data. */
 void to_spawn_direct(const to_spawn_sample_uniforms *u, float *out, int y0, int rows,
                      const float *spawn_data, int sw, int sh);
+
+/* GeometrySpawner's draw (src/spawn/geometry/index.js:97-115): ntri triangles (6 floats each) blended into img. */
+void to_triangles(const float *positions, int ntri, const float *view_size, const float *color,
+                  float *img, int w, int h);
 
 /* Flow deposit: the particle lines of Tendrils.draw() (src/index.js:278-303) rendered into the flow FBO with the
  * flow shader (src/flow/index.vert -> vert/main.vert:10-17, apply/state.glsl:5-16; index.frag).

@@ -100,6 +100,8 @@ PROTOTYPES = {
     "th_spawn_sample": (C.c_int32, [_ctx, C.POINTER(SpawnSampleUniforms), C.c_int32, C.c_int32]),
     "th_spawn_direct": (C.c_int32, [_ctx, C.POINTER(SpawnSampleUniforms), C.c_int32, C.c_int32]),
     "th_spawn_image_upload": (C.c_int32, [_ctx, _fp, C.c_int32, C.c_int32]),
+    "th_spawn_image_triangles": (C.c_int32, [_ctx, _fp, C.c_int32, _fp, _fp, C.c_int32, C.c_int32]),
+    "th_spawn_image_download": (C.c_int32, [_ctx, _fp]),
     "th_frames_resize": (C.c_int32, [_ctx, C.c_int32, C.c_int32]),
     "th_frames_upload": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),
     "th_frames_rotate": (C.c_int32, [_ctx]),

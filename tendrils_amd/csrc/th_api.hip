@@ -888,7 +888,7 @@ static th_status spawn_from_data(th_context *c, const th_spawn_sample_uniforms *
     if (th_status s = ensure_identity(c)) return s;      // these operate in texel order
     TH_REQUIRE(u, "null uniforms");
     if (!direct) TH_REQUIRE(u->samples >= 0 && u->samples <= 64, "samples out of range");
-    TH_REQUIRE(direct || (u->apply >= 0 && u->apply <= 2), "unknown apply mode %d", u->apply);
+    TH_REQUIRE(direct || (u->apply >= 0 && u->apply <= 3), "unknown apply mode %d", u->apply);
     // the pass reads `particles` = buffers[1] like every Particles.step (src/particles.js:139)
     TH_REQUIRE(c->ring.size() >= 2, "spawn pass needs at least 2 state buffers (have %zu)", c->ring.size());
     float4 *out = nullptr;
@@ -931,10 +931,21 @@ th_status th_spawn_direct(th_context *c, const th_spawn_sample_uniforms *u, int3
     return spawn_from_data(c, u, source, target, true);
 }
 
+static th_status image_resize(th_context *c, int32_t w, int32_t h);
+
 th_status th_spawn_image_upload(th_context *c, const float *rgba, int32_t w, int32_t h)
 {
     if (th_status s = use(c)) return s;
-    TH_REQUIRE(rgba && w > 0 && h > 0 && w < (1 << 24) && h < (1 << 24) && (uint64_t)w * h < (1ull << 28), "bad image %dx%d", w, h);
+    TH_REQUIRE(rgba, "null pixels");
+    if (th_status s = image_resize(c, w, h)) return s;
+    TH_HIP(hipMemcpyAsync(c->image, rgba, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+static th_status image_resize(th_context *c, int32_t w, int32_t h)
+{
+    TH_REQUIRE(w > 0 && h > 0 && w < (1 << 24) && h < (1 << 24) && (uint64_t)w * h < (1ull << 28), "bad image %dx%d", w, h);
     if (w != c->iw || h != c->ih) {
         TH_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->image);
@@ -942,7 +953,36 @@ th_status th_spawn_image_upload(th_context *c, const float *rgba, int32_t w, int
         TH_HIP(hipMalloc((void **)&c->image, (size_t)w * h * sizeof(float4)));
         c->iw = w; c->ih = h;
     }
-    TH_HIP(hipMemcpyAsync(c->image, rgba, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    return TH_OK;
+}
+
+th_status th_spawn_image_triangles(th_context *c, const float *positions, int32_t triangles, const float viewSize[2],
+                                   const float color[4], int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(triangles >= 0 && triangles <= (1 << 20) && (positions || triangles == 0) && viewSize && color, "bad arguments");
+    if (th_status s = image_resize(c, w, h)) return s;
+    TH_HIP(hipMemsetAsync(c->image, 0, (size_t)w * h * sizeof(float4), c->stream));      // gl.clear(COLOR_BUFFER_BIT)
+    if (triangles == 0) return TH_OK;
+    float *d_pos = nullptr;
+    th::TrianglePoly *d_polys = nullptr;
+    TH_HIP(hipMalloc((void **)&d_pos, (size_t)triangles * 6 * sizeof(float)));
+    TH_HIP(hipMalloc((void **)&d_polys, (size_t)triangles * sizeof(th::TrianglePoly)));
+    TH_HIP(hipMemcpyAsync(d_pos, positions, (size_t)triangles * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    th::launch_triangles(d_pos, triangles, viewSize[0], viewSize[1], make_float4(color[0], color[1], color[2], color[3]),
+                         d_polys, c->image, w, h, c->stream);
+    hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_pos); (void)hipFree(d_polys);
+    TH_HIP(e);
+    return TH_OK;
+}
+
+th_status th_spawn_image_download(th_context *c, float *rgba)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba && c->image, "no spawn image");
+    TH_HIP(hipMemcpyAsync(rgba, c->image, (size_t)c->iw * c->ih * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));
     return TH_OK;
 }

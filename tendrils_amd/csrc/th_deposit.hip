@@ -245,6 +245,8 @@ __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams
     }
 }
 
+TH_D void dep_blend_rgba(float4 &d, float4 c) { const float sa = c.w, da = 1.0f - sa; d.x = c.x * sa + d.x * da; d.y = c.y * sa + d.y * da; d.z = c.z * sa + d.z * da; d.w = c.w * sa + d.w * da; }
+
 TH_D void dep_blend(float4 &d, float4 c)
 {
     const float sa = c.w, da = 1.0f - sa;
@@ -327,6 +329,98 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *out, const uint
     for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
 }
 
+// ---- GeometrySpawner's draw (src/spawn/geometry/index.js:97-115): triangles into the spawner's float buffer ---------
+// gl_Position = (position*viewSize, 0, 1) (src/geom/vert/index.vert:3-5), constant colour (src/geom/frag/index.frag),
+// blend SRC_ALPHA / ONE_MINUS_SRC_ALPHA in primitive order; same rasteriser conventions as the lines above, either
+// winding drawn.  Kernel 1 clips, snaps and orients every triangle; kernel 2: one thread per texel walks the
+// triangles in order.
+__global__ void triangle_setup_kernel(const float *positions, int ntri, float view_x, float view_y, int w, int h, TrianglePoly *polys)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntri) return;
+    const float wx16 = 8.0f * (float)w, wy16 = 8.0f * (float)h;
+    const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
+    float cx[12], cy[12], tx[12], ty[12];
+    int n = 3;
+    for (int k = 0; k < 3; ++k) {
+        cx[k] = positions[6 * t + 2 * k] * view_x;
+        cy[k] = positions[6 * t + 2 * k + 1] * view_y;
+    }
+    for (int plane = 0; plane < 4 && n >= 3; ++plane) {
+        int q = 0;
+        for (int k = 0; k < n; ++k) {
+            const int j = k == n - 1 ? 0 : k + 1;
+            float di, dj;
+            switch (plane) {
+            case 0: di = 1.0f + cx[k]; dj = 1.0f + cx[j]; break;
+            case 1: di = 1.0f - cx[k]; dj = 1.0f - cx[j]; break;
+            case 2: di = 1.0f - cy[k]; dj = 1.0f - cy[j]; break;
+            default: di = 1.0f + cy[k]; dj = 1.0f + cy[j]; break;
+            }
+            if (di >= 0.0f) {
+                tx[q] = cx[k]; ty[q] = cy[k]; ++q;
+                if (dj < 0.0f) {
+                    const float D = 1.0f / (dj - di);
+                    tx[q] = (dj * cx[k] - di * cx[j]) * D; ty[q] = (dj * cy[k] - di * cy[j]) * D; ++q;
+                }
+            } else if (dj > 0.0f) {
+                const float D = 1.0f / (di - dj);
+                tx[q] = (di * cx[j] - dj * cx[k]) * D; ty[q] = (di * cy[j] - dj * cy[k]) * D; ++q;
+            }
+        }
+        n = q;
+        for (int k = 0; k < n; ++k) { cx[k] = tx[k]; cy[k] = ty[k]; }
+    }
+    TrianglePoly P;
+    P.n = 0;
+    if (n >= 3) {
+        for (int k = 0; k < n; ++k) { P.x[k] = dep_snap(cx[k], wx16, x0); P.y[k] = dep_snap(cy[k], wy16, y0); }
+        long long area2 = 0;
+        for (int k = 0; k < n; ++k) {
+            const int j = k + 1 == n ? 0 : k + 1;
+            area2 += (long long)P.x[k] * P.y[j] - (long long)P.x[j] * P.y[k];
+        }
+        if (area2 != 0) {
+            if (area2 > 0)
+                for (int a = 0, b = n - 1; a < b; ++a, --b) {
+                    int tmp = P.x[a]; P.x[a] = P.x[b]; P.x[b] = tmp;
+                    tmp = P.y[a]; P.y[a] = P.y[b]; P.y[b] = tmp;
+                }
+            P.n = n;
+        }
+    }
+    polys[t] = P;
+}
+
+__global__ __launch_bounds__(256) void triangle_fill_kernel(const TrianglePoly *polys, int ntri, float4 color, float4 *img, int w, int h)
+{
+    const uint32_t texels = (uint32_t)w * (uint32_t)h;
+    for (uint32_t texel = blockIdx.x * 256u + threadIdx.x; texel < texels; texel += gridDim.x * 256u) {
+        const int y = (int)(texel / (uint32_t)w), x = (int)(texel - (uint32_t)y * (uint32_t)w);
+        float4 d = img[texel];
+        bool touched = false;
+        for (int t = 0; t < ntri; ++t) {
+            const TrianglePoly &P = polys[t];
+            int left = w, right = 0;
+            for (int k = 0; k < P.n; ++k) {
+                const int kn = k + 1 == P.n ? 0 : k + 1;
+                const int Xa = P.x[k], Ya = P.y[k], Xb = P.x[kn], Yb = P.y[kn];
+                if (Ya == Yb) continue;
+                const bool swap = Yb < Ya;
+                const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
+                if (y < ((Y1 + 15) >> 4) || y >= ((Y2 + 15) >> 4)) continue;
+                const long long DX = X2 - X1, DY = Y2 - Y1;
+                long long e = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                if (e < 0) e = 0;
+                if (e > w) e = w;
+                if (swap) right = (int)e; else left = (int)e;
+            }
+            if (x >= left && x < right) { dep_blend_rgba(d, color); touched = true; }
+        }
+        if (touched) img[texel] = d;
+    }
+}
+
 int deposit_grid(uint32_t n)
 {
     uint32_t g = (n + 255u) / 256u;
@@ -375,6 +469,14 @@ hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *tem
 {
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, p.keys, p.keys_sorted, p.slots, p.slots_sorted, (int)total, 0,
                                               deposit_key_bits(p), s);
+}
+
+void launch_triangles(const float *positions, int ntri, float view_x, float view_y, float4 color, TrianglePoly *polys,
+                      float4 *img, int w, int h, hipStream_t s)
+{
+    if (ntri <= 0) return;
+    hipLaunchKernelGGL(triangle_setup_kernel, dim3((ntri + 63) / 64), dim3(64), 0, s, positions, ntri, view_x, view_y, w, h, polys);
+    hipLaunchKernelGGL(triangle_fill_kernel, dim3(deposit_grid((uint32_t)w * (uint32_t)h)), dim3(256), 0, s, polys, ntri, color, img, w, h);
 }
 
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)

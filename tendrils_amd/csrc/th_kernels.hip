@@ -1194,7 +1194,14 @@ __global__ __launch_bounds__(256) void spawn_sample_kernel(const SpawnSamplePara
             spawn_to_pos(u, su, sv, tt, px, py);
             float4 t = p.data[nearest_texel_f32(sv, dhf, dhm1) * p.dw + nearest_texel_f32(su, dwf, dwm1)];
             float4 other;
-            if (u.apply == 2) {            // best-sample.frag: colour apply over the vignette pass
+            if (u.apply == 3) {            // bright-sample.frag -> apply/brightest.glsl:11-15 (GeometrySpawner)
+                float sc = t.x * t.z + t.y * t.w;
+                float ang = mod_glsl(random_glsl(su * sc, sv * sc), 1.0f) * 6.28318530717958647692f;
+                float sn, cs;
+                sincos_pinned(ang, sn, cs);
+                float lum = (t.x * 0.299f + t.y * 0.587f) + t.z * 0.114f;
+                other = make_float4(px, py, (cs * lum) * t.w, (sn * lum) * t.w);
+            } else if (u.apply == 2) {     // best-sample.frag: colour apply over the vignette pass
                 other = spawn_apply_color(t, spawn_vignette(su, sv), u.time, px, py);
             } else if (u.apply == 0) {     // apply/flow.glsl: vec4(pos, getFlow(pixel, time, decay))
                 float k = __builtin_fmaxf(0.0f, 1.0f - ((u.time - t.z) * u.flowDecay));

@@ -92,6 +92,11 @@ struct DepositParams {
     float4 *colors;              // per fragment (stream order): interpolated varying
 };
 
+struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
+    int32_t n;
+    int32_t x[8], y[8];
+};
+
 struct StatsPartial {
     unsigned long long live, nan, capped;
     double sum_speed, max_speed;
@@ -120,6 +125,8 @@ uint32_t deposit_scan_blocks(uint32_t texels);
 void launch_deposit_count(const DepositParams &p, hipStream_t stream);
 void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
 void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
+void launch_triangles(const float *positions, int ntri, float view_x, float view_y, float4 color, TrianglePoly *polys,
+                      float4 *img, int w, int h, hipStream_t stream);
 size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total);
 hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);

@@ -350,6 +350,20 @@ napi_value SpawnImageUpload(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// spawnImageTriangles(ctx, Float32Array positions, Float32Array [viewSize.x, viewSize.y, r, g, b, a], w, h)
+napi_value SpawnImageTriangles(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0, m = 0;
+    float *pos = static_cast<float *>(a.typed(1, napi_float32_array, &n));
+    float *vc = static_cast<float *>(a.typed(2, napi_float32_array, &m));
+    int32_t w = a.i32(3), h = a.i32(4);
+    if (!a.ok || m != 6 || n % 6 != 0) BAD_ARGS("th_spawn_image_triangles");
+    TH_CALL("th_spawn_image_triangles", th_spawn_image_triangles(c, pos, (int32_t)(n / 6), vc, vc + 2, w, h));
+    return undefined(env);
+}
+
 napi_value OpticalFlow(napi_env env, napi_callback_info info)
 {
     Args a(env, info);
@@ -456,7 +470,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"targetsUpload", TargetsUpload}, {"targetsDownload", TargetsDownload}, {"targetsClear", TargetsClear},
         {"step", Step}, {"stepN", StepN},
         {"spawnInit", SpawnInit}, {"spawnBall", SpawnBall}, {"spawnSample", SpawnSample},
-        {"spawnDirect", SpawnDirect}, {"spawnImageUpload", SpawnImageUpload},
+        {"spawnDirect", SpawnDirect}, {"spawnImageUpload", SpawnImageUpload}, {"spawnImageTriangles", SpawnImageTriangles},
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
         {"flowDeposit", FlowDeposit},

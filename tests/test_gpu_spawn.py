@@ -34,7 +34,7 @@ def test_spawn_ball(oracle, path):
     assert abs(got.mean() - ref.mean()) < 0.02 * ref.std() + 1e-9
 
 
-@pytest.mark.parametrize("path", [p for p in golden("spawn") if "sample" in p and "image" not in p], ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("path", [p for p in golden("spawn") if "sample" in p and "image" not in p and "geometry" not in p], ids=lambda p: p.split("/")[-1][:-4])
 def test_spawn_sample(oracle, path):
     from tendrils_amd.spawn import PixelSpawner, data_sample_frag, flow_sample_frag
     fx = load(path)
@@ -105,3 +105,37 @@ def test_image_spawners(oracle, path):
     if direct:
         assert stats["respawned"] == m["N"] * m["N"]
         assert np.abs(got[..., 2:] - fx["out"][..., 2:]).max() <= 2e-7           # against the reference capture
+
+
+def test_geometry_spawner(oracle):
+    """GeometrySpawner (src/spawn/geometry/index.js): shuffle(), the triangle draw into the spawner's buffer
+    (bit-identical to the reference capture) and the bright-sample pass over it (bit-identical to the oracle)."""
+    import os
+    from helpers import GOLDEN
+    from tendrils_amd.spawn import GeometrySpawner
+    fx = load(os.path.join(GOLDEN, "geometry_triangles_96x54.npz"))
+    n = 64
+    t = make(n, view=(480, 270))                            # buffer = 0.2 * viewRes = 96 x 54
+    rng = np.random.default_rng(2)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.004, .004, (n, n, 2))
+    st[rng.random((n, n)) < 0.3] = [-1e6, -1e6, 0, 0]
+    t.particles.upload_texels(st)
+    sp = GeometrySpawner(None, dict(speed=0.005, bias=1e2 / 5e-3, positions=[0.0] * 42))     # src/demo.main.js:446-447
+    seq = iter(np.random.default_rng(7).random(1000))
+    sp.random = lambda: float(next(seq))
+    sp.shuffle()
+    assert all(sp.positions[k] == 0.0 for k in range(0, 42, 6)) and any(sp.positions)         # centre vertices stay put
+    sp.positions = [float(v) for v in fx["positions"]]
+    t.timer.time = 2000.0
+    sp.spawn(t)
+    img = sp.buffer.read()
+    assert bits_equal(img, fx["out"]).all()                  # the reference's own raster of these triangles
+    u = oracle.spawn_sample_uniforms(n, n, t.timer.time, 6, 3, spawnSize=sp.spawnSize, jitter=sp.jitter,
+                                     speed=sp.speed, bias=sp.bias, spawnMatrix=sp.spawnMatrix)
+    want = oracle.spawn_sample(u, st, img)
+    got = t.particles.read(0)
+    t.dispose()
+    assert bits_equal(got, want).all()
+    assert (~bits_equal(got, st).all(-1)).sum() > 100        # a fair number of particles took a candidate

@@ -62,3 +62,14 @@ def test_pinned_hash_is_the_rounded_true_sine(oracle):
         sn = f32(dt - f32(3.14) * np.floor(f32(dt / f32(3.14))))
         v = f32(f32(math.sin(float(sn))) * f32(43758.5453))
         assert L.to_random(float(a), float(b)) == f32(v - np.floor(v))
+
+
+@pytest.mark.parametrize("path", golden("geometry"), ids=lambda p: p.split("/")[-1][:-4])
+def test_geometry_triangles_bit_exact(oracle, path):
+    """GeometrySpawner's triangle draw against the reference capture: coverage and (for the translucent case)
+    the in-order blend of overlapping triangles, bit for bit."""
+    fx = load(path)
+    m = fx["meta"]
+    got = oracle.triangles(fx["positions"], m["shape"], view_size=m["viewSize"], color=m["color"])
+    assert (got.view(np.uint32) == fx["out"].view(np.uint32)).all()
+    assert (fx["out"][..., 3] != 0).sum() > 1000
