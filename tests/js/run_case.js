@@ -11,6 +11,8 @@ const { OpticalFlow } = require(path.join(root, 'tendrils_amd', 'js', 'optical-f
 const { spawnBall } = require(path.join(root, 'tendrils_amd', 'js', 'spawn', 'ball'));
 const { PixelSpawner, flowSampleFrag, dataSampleFrag, bestSampleFrag, pixelsFrag } = require(path.join(root, 'tendrils_amd', 'js', 'spawn', 'pixels'));
 
+const { GeometrySpawner } = require(path.join(root, 'tendrils_amd', 'js', 'spawn', 'geometry'));
+
 const spec = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
 const dir = path.dirname(process.argv[2]);
 const f32 = (name) => { const b = fs.readFileSync(path.join(dir, name)); return new Float32Array(b.buffer, b.byteOffset, b.length / 4); };
@@ -89,6 +91,15 @@ if (spec.kind === 'logic') {
   sp.spawn(t);
   save('out_0.bin', t.particles.read(0));
   fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, jitter: sp.jitter }));
+} else if (spec.kind === 'geometry') {            // GeometrySpawner (src/spawn/geometry/index.js)
+  const sp = new GeometrySpawner(null, { speed: spec.speed, bias: spec.bias, positions: Array(spec.positions.length).fill(0) });
+  sp.shuffle();                                   // exercises Math.random-driven shuffle; then pin the triangles
+  const moved = sp.positions.some((v) => v !== 0);
+  sp.positions = spec.positions;
+  t.timer.time = spec.time0;
+  sp.spawn(t);
+  save('out_0.bin', t.particles.read(0));
+  fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, jitter: sp.jitter, moved }));
 } else {
   throw new Error('unknown case kind ' + spec.kind);
 }

@@ -228,3 +228,23 @@ def test_js_image_spawners(tmp_path, oracle, name):
              {"state.bin": fx["state"], "image.bin": fx["data"]})
     got = np.fromfile(str(tmp_path / "out_0.bin"), np.float32).reshape(m["N"], m["N"], 4)
     assert bits_equal(got, oracle_spawn(oracle, fx)).all()
+
+
+@pytest.mark.gpu
+def test_js_geometry_spawner(tmp_path, oracle):
+    fx = load(os.path.join(ROOT, "tests", "golden", "geometry_triangles_96x54.npz"))
+    n = 64
+    rng = np.random.default_rng(3)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.004, .004, (n, n, 2))
+    st[rng.random((n, n)) < 0.3] = [-1e6, -1e6, 0, 0]
+    run_case(tmp_path, dict(kind="geometry", N=n, viewRes=[480, 270], speed=0.005, bias=1e2 / 5e-3, time0=2000.0,
+                            positions=[float(v) for v in fx["positions"]], inputs=dict(state="state.bin")),
+             {"state.bin": st})
+    got = np.fromfile(str(tmp_path / "out_0.bin"), np.float32).reshape(n, n, 4)
+    res = json.load(open(str(tmp_path / "result.json")))
+    assert res["moved"]
+    u = oracle.spawn_sample_uniforms(n, n, res["time"], 6, 3, spawnSize=[1, 1], jitter=res["jitter"], speed=0.005,
+                                     bias=1e2 / 5e-3, spawnMatrix=[1, 0, 0, 0, 1, 0, 0, 0, 1])
+    assert bits_equal(got, oracle.spawn_sample(u, st, fx["out"])).all()
