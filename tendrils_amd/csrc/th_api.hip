@@ -607,6 +607,7 @@ static th_status plan_step(th_context *c, const th_logic_uniforms &u, int32_t ta
     p.inv_w = 1.0f / p.wf; p.inv_h = 1.0f / p.hf; p.inv_wh = 1.0f / (p.wf * p.hf);
     p.fw = c->fw; p.fh = c->fh;
     p.fwf = (float)c->fw; p.fhf = (float)c->fh;
+    p.half_fw = 0.5f * p.fwf; p.half_fh = 0.5f * p.fhf;
     p.fwm1 = (float)(c->fw - 1); p.fhm1 = (float)(c->fh - 1);
     p.u = u;
     p.s2_cap = s2_cap_for(u.speedLimit);

@@ -374,9 +374,10 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
 
     // flow tap (issued first: its latency hides under the noise arithmetic)
     float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
-    float fu = (sx + 1.0f) * 0.5f, fv = (sy + 1.0f) * 0.5f;               // (1*(v+1))/2, exactly
-    int tx = (int)__builtin_amdgcn_fmed3f(fu * p.fwf, 0.0f, p.fwm1);      // trunc == floor on [0, n-1]
-    int ty = (int)__builtin_amdgcn_fmed3f(fv * p.fhf, 0.0f, p.fhm1);
+    // posToUV = (1*(v+1))/2, then *size: halving is exact, so ((v+1)*0.5)*size == (v+1)*(0.5*size) - one rounding
+    // either way (half_fw = 0.5*fw from the host; a denormal (v+1)/2 lands in texel 0 on both routes)
+    int tx = (int)__builtin_amdgcn_fmed3f((sx + 1.0f) * p.half_fw, 0.0f, p.fwm1);      // trunc == floor on [0, n-1]
+    int ty = (int)__builtin_amdgcn_fmed3f((sy + 1.0f) * p.half_fh, 0.0f, p.fhm1);
     const int texel = ty * p.fw + tx;
     float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
     float4 ft;

@@ -27,7 +27,7 @@ struct LogicParams {
     float wf, hf;            // dataRes (global), as floats
     float inv_w, inv_h, inv_wh;   // exact reciprocals, valid when pow2 != 0
     int32_t fw, fh;
-    float fwf, fhf, fwm1, fhm1;
+    float fwf, fhf, fwm1, fhm1, half_fw, half_fh;
     th_logic_uniforms u;
     float s2_cap;            // largest s2 with sqrt_rn(s2) <= speedLimit (see th_api.hip)
     float pos_bound;         // |pos| below this keeps the noise coordinates inside kNoiseDomain
