@@ -598,11 +598,7 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
 // The flow tap reads the RGBA32F texel and decodes per particle (one decoded plane per step time
 // would multiply the gather footprint by nsteps).
 // ---------------------------------------------------------------------------
-#ifdef TH_EXP_NO_PTAB
-constexpr bool kFusedPermTable = false;
-#else
-constexpr bool kFusedPermTable = true;
-#endif
+constexpr bool kFusedPermTable = true;      // hash stages through the LDS tables (snoise_corners_tab)
 
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
 __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
