@@ -218,8 +218,19 @@ th_status th_optical_flow(th_context *ctx, const th_optical_flow_uniforms *u);
  * (vel, time, min(|vel|/speedLimit, 1)), alpha-blended in the reference's primitive order (width-1 lines: the GL the
  * reference was captured on clamps flowWidth to 1).  fragments (optional) receives the number of fragments blended;
  * the call synchronises once (the fragment lists are sized from a device count).
- * Needs the whole particle texture on this context (TH_ERR_UNSUPPORTED on a row-band shard). */
+ * Needs the whole particle texture on this context (a row-band shard: th_deposit_emit / th_deposit_merge below). */
 th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *fragments);
+
+/* Row-band shards (multi-GPU): the deposit in two steps around one exchange (tendrils_amd/sharding.py).
+ *  th_deposit_emit: rasterise THIS context's lines; fragments sorted by key = (flow texel << 32) | global stream
+ *    index; *keys_dev = uint64[count], *colors_dev = float4[count] (device, owned by the context, valid until the
+ *    next deposit call on it).  The caller routes every fragment to the rank that owns its flow texel.
+ *  th_deposit_merge: blend the fragments received for the texels this rank owns (any order) into this context's
+ *    flow texture, in (texel, stream index) order - for the owned texels the result is the unsharded deposit's,
+ *    bit for bit.  The owners' texel ranges are then all-gathered into every rank's flow (th_flow_device_ptr). */
+th_status th_deposit_emit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev);
+th_status th_deposit_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
+th_status th_flow_device_ptr(th_context *ctx, void **dptr);
 
 /* -- statistics, sync, interop ---------------------------------------------- */
 th_status th_stats(th_context *ctx, float speed_limit, th_counters *out);   /* of buffers[0]; synchronises */

@@ -128,6 +128,12 @@ struct th_context {
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
     uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
+    unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
+    float4 *dep_colors_sorted = nullptr;
+    bool dep_wide = false;
+    unsigned long long *mrg_keys = nullptr;                          // th_deposit_merge scratch
+    uint32_t *mrg_vals[2] = {nullptr, nullptr};
+    size_t mrg_capacity = 0;
     float4 *dep_colors = nullptr;
     void *dep_temp = nullptr;
     size_t dep_lines = 0, dep_capacity = 0, dep_temp_bytes = 0;
@@ -427,6 +433,8 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
+    for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
+    (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
     (void)hipFree(c->dep_colors); (void)hipFree(c->dep_temp);
     (void)hipFree(c->image);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
@@ -988,17 +996,24 @@ th_status th_spawn_image_download(th_context *c, float *rgba)
     return TH_OK;
 }
 
-th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
+// ---- flow deposit ------------------------------------------------------------------------------------------
+static int deposit_texel_bits(const th_context *c)
 {
-    if (th_status s = use(c)) return s;
+    const uint64_t texels = (uint64_t)c->fw * c->fh;
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < texels) ++bits;
+    return bits;
+}
+
+// per-line buffers + parameters; counts this context's fragments (one sync)
+static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, uint32_t *total)
+{
     if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
     c->hold_texel_order_until = c->total_steps + rebucket_period();   // a frame loop of step + draw stays in texel order
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
-    if (c->cfg.height != c->cfg.global_height)
-        return fail(TH_ERR_UNSUPPORTED, "flow deposit needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
     const size_t lines = c->texels();
-    TH_REQUIRE((size_t)c->fw * c->fh > 0 && lines < (1ull << 32), "bad shapes");
+    TH_REQUIRE((size_t)c->fw * c->fh > 0 && (uint64_t)c->cfg.width * c->cfg.global_height < (1ull << 32), "bad shapes");
     if (c->dep_lines != lines) {
         TH_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks);
@@ -1006,10 +1021,10 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
         TH_HIP(hipMalloc((void **)&c->dep_count, lines * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_offset, lines * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_blocks((uint32_t)lines) * sizeof(uint32_t)));
-        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, sizeof(uint32_t)));
+        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 2 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag
         c->dep_lines = lines;
     }
-    th::DepositParams p{};
+    p = th::DepositParams{};
     {   // a packed ring is read through f32 views (what the stored texels decode to)
         float4 *cur = nullptr, *prev = nullptr;
         if (th_status s = unpacked_view(c, c->ring[0], 0, &cur)) return s;
@@ -1017,44 +1032,133 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
         p.cur = cur; p.prev = prev;
     }
     p.flow = c->flow;
-    p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.height;
+    p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.global_height;
+    p.row0 = (uint32_t)c->cfg.row0; p.rows = (uint32_t)c->cfg.height;
     p.fw = c->fw; p.fh = c->fh;
     p.view_x = u->viewSize[0]; p.view_y = u->viewSize[1]; p.time = u->time; p.speed_limit = u->speedLimit;
     {
-        const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.height > 2 ? 2 * c->cfg.height : 2;
+        const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.global_height > 2 ? 2 * c->cfg.global_height : 2;
         p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
     }
-    p.count = c->dep_count; p.offset = c->dep_offset;
+    p.count = c->dep_count; p.offset = c->dep_offset; p.oob = c->dep_total + 1;
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
     th::launch_deposit_count(p, c->stream);
     th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
-    uint32_t total = 0;
-    TH_HIP(hipMemcpyAsync(&total, c->dep_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    uint32_t host[2] = {0, 0};
+    TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));
-    if (fragments) *fragments = total;
-    if (total == 0) return TH_OK;
-    TH_REQUIRE(total < (1u << 31), "too many fragments (%u)", total);
+    if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d): the vertex stream of this texture height needs halo rows", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
+    TH_REQUIRE(host[0] < (1u << 31), "too many fragments (%u)", host[0]);
+    *total = host[0];
+    return TH_OK;
+}
+
+// per-fragment buffers for `total` fragments (grow-only)
+static th_status deposit_reserve(th_context *c, uint32_t total, bool wide)
+{
     if (c->dep_capacity < total) {
         for (uint32_t *&q : c->dep_u32) { (void)hipFree(q); q = nullptr; }
+        for (unsigned long long *&q : c->dep_u64) { (void)hipFree(q); q = nullptr; }
         (void)hipFree(c->dep_colors); c->dep_colors = nullptr;
-        (void)hipFree(c->dep_temp); c->dep_temp = nullptr; c->dep_temp_bytes = 0;
-        c->dep_capacity = 0;
+        (void)hipFree(c->dep_colors_sorted); c->dep_colors_sorted = nullptr;
+        c->dep_capacity = 0; c->dep_wide = false;
         const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
         for (uint32_t *&q : c->dep_u32) TH_HIP(hipMalloc((void **)&q, cap * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_colors, cap * sizeof(float4)));
         c->dep_capacity = cap;
     }
-    p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
-    p.colors = c->dep_colors;
-    const size_t need = th::deposit_sort_temp_bytes(p, total);
+    if (wide && !c->dep_wide) {
+        for (unsigned long long *&q : c->dep_u64) TH_HIP(hipMalloc((void **)&q, c->dep_capacity * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->dep_colors_sorted, c->dep_capacity * sizeof(float4)));
+        c->dep_wide = true;
+    }
+    return TH_OK;
+}
+
+static th_status deposit_temp(th_context *c, size_t need)
+{
     if (c->dep_temp_bytes < need) {
         (void)hipFree(c->dep_temp); c->dep_temp = nullptr; c->dep_temp_bytes = 0;
         TH_HIP(hipMalloc(&c->dep_temp, need + need / 4));
         c->dep_temp_bytes = need + need / 4;
     }
+    return TH_OK;
+}
+
+th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
+    th::DepositParams p;
+    uint32_t total = 0;
+    if (th_status s = deposit_count(c, u, p, &total)) return s;
+    if (fragments) *fragments = total;
+    if (total == 0) return TH_OK;
+    if (th_status s = deposit_reserve(c, total, false)) return s;
+    p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
+    p.colors = c->dep_colors;
+    if (th_status s = deposit_temp(c, th::deposit_sort_temp_bytes(p, total))) return s;
     th::launch_deposit_scatter(p, c->stream);
     TH_HIP(th::launch_deposit_sort(p, total, c->dep_temp, c->dep_temp_bytes, c->stream));
     th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count && keys_dev && colors_dev, "null outputs");
+    th::DepositParams p;
+    uint32_t total = 0;
+    if (th_status s = deposit_count(c, u, p, &total)) return s;
+    *count = total; *keys_dev = nullptr; *colors_dev = nullptr;
+    if (total == 0) return TH_OK;
+    if (th_status s = deposit_reserve(c, total, true)) return s;
+    p.keys64 = c->dep_u64[0]; p.slots = c->dep_u32[1]; p.colors = c->dep_colors;
+    const int bits = 32 + deposit_texel_bits(c);
+    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, bits))) return s;
+    th::launch_deposit_scatter(p, c->stream);
+    TH_HIP(th::launch_deposit_sort64(c->dep_u64[0], c->dep_u64[1], c->dep_u32[1], c->dep_u32[3], total, bits, c->dep_temp,
+                                     c->dep_temp_bytes, c->stream));
+    th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, c->dep_u32[3], total, c->stream);
+    TH_HIP(hipGetLastError());
+    TH_HIP(hipStreamSynchronize(c->stream));               // the caller hands the buffers to a collective on its own stream
+    *keys_dev = c->dep_u64[1]; *colors_dev = c->dep_colors_sorted;
+    return TH_OK;
+}
+
+th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
+{
+    if (th_status s = use(c)) return s;
+    if (count == 0) return TH_OK;
+    TH_REQUIRE(keys_dev && colors_dev && count < (1ull << 31), "bad fragment buffers");
+    const uint32_t total = (uint32_t)count;
+    if (c->mrg_capacity < total) {
+        (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
+        c->mrg_keys = nullptr; c->mrg_vals[0] = c->mrg_vals[1] = nullptr; c->mrg_capacity = 0;
+        const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
+        TH_HIP(hipMalloc((void **)&c->mrg_keys, cap * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->mrg_vals[0], cap * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->mrg_vals[1], cap * sizeof(uint32_t)));
+        c->mrg_capacity = cap;
+    }
+    const int bits = 32 + deposit_texel_bits(c);
+    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, bits))) return s;
+    th::launch_deposit_iota(c->mrg_vals[0], total, c->stream);
+    TH_HIP(th::launch_deposit_sort64(static_cast<const unsigned long long *>(keys_dev), c->mrg_keys, c->mrg_vals[0], c->mrg_vals[1],
+                                     total, bits, c->dep_temp, c->dep_temp_bytes, c->stream));
+    th::launch_deposit_blend64(c->flow, c->mrg_keys, c->mrg_vals[1], static_cast<const float4 *>(colors_dev), total, c->stream);
+    TH_HIP(hipGetLastError());
+    TH_HIP(hipStreamSynchronize(c->stream));               // the input buffers may be reused by the caller now
+    return TH_OK;
+}
+
+th_status th_flow_device_ptr(th_context *c, void **dptr)
+{
+    TH_REQUIRE(c && dptr, "null argument");
+    *dptr = c->flow;
     return TH_OK;
 }
 

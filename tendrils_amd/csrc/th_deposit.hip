@@ -51,7 +51,9 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
     const float offset = near_index - fl;
     const float ly = fl / (float)H;
     const float4 *tex = offset > 0.25f ? p.cur : p.prev;
-    const float4 t = tex[(size_t)dep_nearest(ly, H) * W + dep_nearest(uvx, W)];
+    int row = dep_nearest(ly, H) - (int)p.row0;              // row-band shard: the band must hold the row
+    if (row < 0 || row >= (int)p.rows) { *p.oob = 1u; row = row < 0 ? 0 : (int)p.rows - 1; }
+    const float4 t = tex[(size_t)row * W + dep_nearest(uvx, W)];
     DepositVertex v;
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
@@ -219,20 +221,23 @@ TH_D float4 dep_varying(const DepositLine &L, int x, int y)
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams p)
 {
-    const uint32_t lines = p.W * p.H;
+    const uint32_t lines = p.W * p.rows;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
         // threads walk the particle texture row-major (coalesced state reads; walking the column-major stream
         // instead makes the fragment writes contiguous but the state reads strided: 3.6 -> 5.3 ms per draw at C3);
         // the line's place in the fragment array is its position in the vertex stream
         const uint32_t row = t / p.W, col = t - row * p.W;
-        const uint32_t id = col * p.H + row;
+        const uint32_t id = col * p.H + p.row0 + row;            // position in the whole texture's vertex stream
+        const uint32_t local = col * p.rows + row;               // ... and among this band's lines (same order)
         DepositLine L;
         dep_setup(p, id, L, true);
         if constexpr (SCATTER) {
             if (!L.draws) continue;
-            uint32_t at = p.offset[id];
+            uint32_t at = p.offset[local];
             dep_raster(p, L, [&](int x, int y) {
-                p.keys[at] = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
+                const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
+                if (p.keys64) p.keys64[at] = ((unsigned long long)texel << 32) | id;
+                else p.keys[at] = texel;
                 p.slots[at] = at;
                 p.colors[at] = dep_varying(L, x, y);
                 ++at;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams
         } else {
             uint32_t n = 0;
             if (L.draws) dep_raster(p, L, [&](int, int) { ++n; });
-            p.count[id] = n;
+            p.count[local] = n;
         }
     }
 }
@@ -270,6 +275,33 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams 
         } while (j < total && p.keys_sorted[j] == texel);
         p.flow[texel] = d;
     }
+}
+
+// sharded form: the same walk over fragments sorted by (texel, global stream index)
+__global__ __launch_bounds__(256) void deposit_blend64_kernel(float4 *flow, const unsigned long long *keys, const uint32_t *slots,
+                                                              const float4 *colors, uint32_t total)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t texel = (uint32_t)(keys[i] >> 32);
+        if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == texel) continue;
+        float4 d = flow[texel];
+        uint32_t j = i;
+        do {
+            dep_blend(d, colors[slots[j]]);
+            ++j;
+        } while (j < total && (uint32_t)(keys[j] >> 32) == texel);
+        flow[texel] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void deposit_iota_kernel(uint32_t *dst, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = i;
+}
+
+__global__ __launch_bounds__(256) void deposit_gather_colors_kernel(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[index[i]];
 }
 
 // ---- exclusive scan of the per-line fragment counts (three small kernels; 1024 elements per block) -------------
@@ -433,12 +465,12 @@ uint32_t deposit_scan_blocks(uint32_t n) { return (n + kScanBlock - 1) / kScanBl
 
 void launch_deposit_count(const DepositParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(deposit_raster_kernel<false>, dim3(deposit_grid(p.W * p.H)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_raster_kernel<false>, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p);
 }
 
 void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t s)
 {
-    const uint32_t lines = p.W * p.H, nb = deposit_scan_blocks(lines);
+    const uint32_t lines = p.W * p.rows, nb = deposit_scan_blocks(lines);
     hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, s, p.count, p.offset, block_sums, lines);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, block_sums, nb, total);
     hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, s, p.offset, block_sums, lines);
@@ -446,7 +478,7 @@ void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t 
 
 void launch_deposit_scatter(const DepositParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(deposit_raster_kernel<true>, dim3(deposit_grid(p.W * p.H)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_raster_kernel<true>, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p);
 }
 
 static int deposit_key_bits(const DepositParams &p)
@@ -477,6 +509,37 @@ void launch_triangles(const float *positions, int ntri, float view_x, float view
     if (ntri <= 0) return;
     hipLaunchKernelGGL(triangle_setup_kernel, dim3((ntri + 63) / 64), dim3(64), 0, s, positions, ntri, view_x, view_y, w, h, polys);
     hipLaunchKernelGGL(triangle_fill_kernel, dim3(deposit_grid((uint32_t)w * (uint32_t)h)), dim3(256), 0, s, polys, ntri, color, img, w, h);
+}
+
+size_t deposit_sort64_temp_bytes(uint32_t total, int key_bits)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)total, 0, key_bits,
+                                             (hipStream_t) nullptr);
+    return bytes;
+}
+
+hipError_t launch_deposit_sort64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
+                                 uint32_t *vals_out, uint32_t total, int key_bits, void *temp, size_t temp_bytes, hipStream_t s)
+{
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, 0, key_bits, s);
+}
+
+void launch_deposit_iota(uint32_t *dst, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(deposit_iota_kernel, dim3(deposit_grid(n)), dim3(256), 0, s, dst, n);
+}
+
+void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(deposit_gather_colors_kernel, dim3(deposit_grid(n)), dim3(256), 0, s, dst, src, index, n);
+}
+
+void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
+                            const float4 *colors, uint32_t total, hipStream_t s)
+{
+    if (total) hipLaunchKernelGGL(deposit_blend64_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, flow, keys_sorted, slots_sorted, colors, total);
 }
 
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)

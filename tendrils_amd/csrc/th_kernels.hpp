@@ -82,7 +82,9 @@ struct SpawnSampleParams {
 struct DepositParams {
     const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order
     float4 *flow;
-    uint32_t W, H;               // particle texture shape
+    uint32_t W, H;               // particle texture shape (H = the WHOLE texture's height)
+    uint32_t row0, rows;         // the rows held by cur/prev (a row-band shard; row0 = 0, rows = H otherwise)
+    uint32_t *oob;               // set to 1 when a vertex lookup leaves the band
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
     double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)
@@ -90,6 +92,7 @@ struct DepositParams {
     uint32_t *keys, *slots;      // per fragment (stream order): flow texel, own slot
     uint32_t *keys_sorted, *slots_sorted;   // the same after the stable sort by texel
     float4 *colors;              // per fragment (stream order): interpolated varying
+    unsigned long long *keys64;  // sharded form: (texel << 32) | global stream index, per fragment
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
@@ -130,6 +133,14 @@ void launch_triangles(const float *positions, int ntri, float view_x, float view
 size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total);
 hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
+// sharded form: 64-bit (texel, stream index) keys
+size_t deposit_sort64_temp_bytes(uint32_t total, int key_bits);
+hipError_t launch_deposit_sort64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
+                                 uint32_t *vals_out, uint32_t total, int key_bits, void *temp, size_t temp_bytes, hipStream_t stream);
+void launch_deposit_iota(uint32_t *dst, uint32_t n, hipStream_t stream);
+void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);
+void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
+                            const float4 *colors, uint32_t total, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
 void launch_spawn_direct(const SpawnSampleParams &p, hipStream_t stream);

@@ -57,3 +57,98 @@ class DeviceCounters:
         return [dist.all_reduce(self.counts, op=dist.ReduceOp.SUM, async_op=True),
                 dist.all_reduce(self.sum_speed, op=dist.ReduceOp.SUM, async_op=True),
                 dist.all_reduce(self.max_speed, op=dist.ReduceOp.MAX, async_op=True)]
+
+
+# ---- flow deposit across row-band shards ------------------------------------------------------------------
+# Tendrils.draw() blends every particle line into the flow texture in the order of ONE vertex stream
+# (src/index.js:295-303); with the particles split into row bands that stream interleaves the bands column by
+# column.  Exact multi-GPU form: every rank rasterises its own lines into fragments keyed
+# (flow texel, global stream index) [th_deposit_emit]; an all-to-all sends each fragment to the rank owning that
+# texel (contiguous texel ranges of ceil(texels/world)); the owner blends its texels in key order
+# [th_deposit_merge]; an all-gather of the owned ranges restores the replicated flow texture.
+
+def device_view(ptr, shape, typestr):
+    """Zero-copy torch view of library-owned device memory."""
+    import torch
+
+    class _Span:
+        def __init__(self):
+            self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                             "version": 3, "strides": None}
+    return torch.as_tensor(_Span(), device="cuda")
+
+
+def owner_chunk(texels, world):
+    return (int(texels) + int(world) - 1) // int(world)
+
+
+def split_by_owner(keys, texels, world):
+    """keys: int64 tensor sorted by (texel << 32 | stream index).  Returns the per-destination counts (list)."""
+    import torch
+    chunk = owner_chunk(texels, world)
+    bounds = torch.tensor([min(r * chunk, texels) << 32 for r in range(1, world)], dtype=torch.int64, device=keys.device)
+    cuts = torch.searchsorted(keys, bounds).tolist() if world > 1 else []
+    edges = [0] + [int(v) for v in cuts] + [int(keys.numel())]
+    return [edges[r + 1] - edges[r] for r in range(world)]
+
+
+def emit_fragments(tendrils):
+    """th_deposit_emit on this rank's context -> (keys int64[n], colors float32[n, 4]) views (or empty tensors)."""
+    import torch
+    from . import _capi
+    p = tendrils.particles
+    u = _capi.DepositUniforms(time=float(tendrils.timer.time), speedLimit=float(tendrils.state["speedLimit"]))
+    u.viewSize[0], u.viewSize[1] = float(tendrils.viewSize[0]), float(tendrils.viewSize[1])
+    n, kp, cp = C.c_uint64(0), C.c_void_p(), C.c_void_p()
+    _capi.call("th_deposit_emit", p._ctx, C.byref(u), C.byref(n), C.byref(kp), C.byref(cp))
+    if n.value == 0:
+        return torch.empty(0, dtype=torch.int64, device="cuda"), torch.empty((0, 4), dtype=torch.float32, device="cuda")
+    return device_view(kp.value, (n.value,), "<i8"), device_view(cp.value, (n.value, 4), "<f4")
+
+
+def merge_fragments(tendrils, keys, colors):
+    from . import _capi
+    if keys.numel():
+        assert keys.is_contiguous() and colors.is_contiguous()
+        _capi.call("th_deposit_merge", tendrils.particles._ctx, C.c_void_p(keys.data_ptr()), C.c_void_p(colors.data_ptr()),
+                   C.c_uint64(keys.numel()))
+
+
+def flow_view(tendrils):
+    from . import _capi
+    fw, fh = tendrils.flow.shape
+    ptr = C.c_void_p()
+    _capi.call("th_flow_device_ptr", tendrils.particles._ctx, C.byref(ptr))
+    return device_view(ptr.value, (fw * fh, 4), "<f4")
+
+
+def draw_sharded(dist, tendrils):
+    """Tendrils.draw() (flow pass) for a row-band shard of a torch.distributed job (backend nccl = RCCL).
+    One exchange step: fragment all-to-all by flow-texel owner, then an all-gather of the owned flow ranges."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    fw, fh = tendrils.flow.shape
+    texels = fw * fh
+    keys, colors = emit_fragments(tendrils)
+    send = split_by_owner(keys, texels, world)
+    send_t = torch.tensor(send, dtype=torch.int64, device="cuda")
+    recv_t = torch.empty_like(send_t)
+    dist.all_to_all_single(recv_t, send_t)
+    recv = [int(v) for v in recv_t.tolist()]
+    rkeys = torch.empty(sum(recv), dtype=torch.int64, device="cuda")
+    rcolors = torch.empty((sum(recv), 4), dtype=torch.float32, device="cuda")
+    dist.all_to_all_single(rkeys, keys.contiguous(), recv, send)
+    dist.all_to_all_single(rcolors, colors.contiguous(), recv, send)
+    torch.cuda.synchronize()
+    merge_fragments(tendrils, rkeys, rcolors)
+    # owned ranges -> every rank's flow texture (equal chunks: pad the tail)
+    chunk = owner_chunk(texels, world)
+    flow = flow_view(tendrils)
+    mine = torch.zeros((chunk, 4), dtype=torch.float32, device="cuda")
+    lo, hi = min(rank * chunk, texels), min((rank + 1) * chunk, texels)
+    mine[:hi - lo] = flow[lo:hi]
+    gathered = torch.empty((world * chunk, 4), dtype=torch.float32, device="cuda")
+    dist.all_gather_into_tensor(gathered, mine)
+    flow.copy_(gathered[:texels])
+    torch.cuda.synchronize()
+    return int(keys.numel())

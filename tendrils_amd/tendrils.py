@@ -134,6 +134,7 @@ class Tendrils:
         self._mode = int(params.get("mode", _capi.TH_MODE_EXACT))
         self._state_format = int(params.get("stateFormat", _capi.TH_STATE_F32))
         self._band = (int(params.get("row0", 0)), params.get("rows"), int(params.get("globalHeight", 0)))
+        self.dist = params.get("dist")           # torch.distributed module of a row-band-sharded job (draw() exchanges)
 
     # -- setup ---------------------------------------------------------------------
     def setup(self, *rest):                                   # src/index.js:149-154
@@ -219,7 +220,11 @@ class Tendrils:
     def draw(self):                                            # src/index.js:278-340
         """The flow pass: particle lines into the flow texture (so that particles respond to each other's
         wake).  The view render of the reference's draw() (display) is outside this build."""
-        self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
+        if self.dist is not None:          # row-band shard of a torch.distributed job: emit / exchange / merge
+            from .sharding import draw_sharded
+            self.fragments = draw_sharded(self.dist, self)
+        else:
+            self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
         return self
 
     def resize(self):                                          # src/index.js:393-408

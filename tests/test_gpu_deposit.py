@@ -96,17 +96,3 @@ def test_step_draw_loop_matches_oracle(oracle):
         assert bits_equal(t.flow.read(), flow).all()
     assert (flow[..., 3] != 0).sum() > 500
     t.dispose()
-
-
-def test_deposit_needs_the_whole_texture():
-    import tendrils_amd as ta
-    from tendrils_amd.tendrils import View
-    opts = ta.defaults()
-    opts.update(row0=16, rows=16, globalHeight=64)
-    t = ta.Tendrils(View(32, 32), opts)
-    t.resize()
-    t.setup(64)
-    with pytest.raises(ta.TendrilsHipError) as e:
-        t.draw()
-    assert e.value.status == 4           # TH_ERR_UNSUPPORTED
-    t.dispose()

@@ -1,0 +1,120 @@
+"""Flow deposit across row-band shards: th_deposit_emit / th_deposit_merge and the ownership logic of
+tendrils_amd/sharding.py, with two shards as two contexts on this GPU and the exchange done by hand (the
+torch.distributed calls of draw_sharded are the same slices sent through all_to_all_single / all_gather).
+The result on every shard must equal the unsharded deposit bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def make_shard(n, view, row0, rows, st_cur, st_prev, base, time):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    opts = ta.defaults()
+    opts.update(row0=row0, rows=rows, globalHeight=n)
+    t = ta.Tendrils(View(*view), opts)
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(st_cur[row0:row0 + rows], 0)
+    t.particles.upload_texels(st_prev[row0:row0 + rows], 1)
+    t.flow.set_pixels(base)
+    t.timer.time = time
+    return t
+
+
+@pytest.mark.parametrize("n,view,world", [(64, (96, 54), 2), (128, (48, 27), 4), (64, (80, 60), 3)])
+def test_sharded_deposit_equals_unsharded(oracle, n, view, world):
+    torch = pytest.importorskip("torch")
+    from tendrils_amd import sharding
+    rng = np.random.default_rng(n + world)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, view[1] / view[0]]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    k = rng.random((n, n)) < 0.1
+    cur[k] = [-1e6, -1e6, 0, 0]
+    fw, fh = view
+    base = np.zeros((fh, fw, 4), np.float32)
+    base[..., :2] = rng.uniform(-.01, .01, (fh, fw, 2))
+    base[..., 2] = 2400.0
+    base[..., 3] = rng.uniform(0, 1, (fh, fw))
+    time = 2500.0
+    want, frags, cov = oracle.flow_deposit(cur, prev, base, time, view_size=(1.0, fw / fh), coverage=True)
+    assert cov.max() >= 3
+
+    shards = []
+    for r in range(world):
+        row0, rows = sharding.shard_rows(n, world, r)
+        shards.append(make_shard(n, view, row0, rows, cur, prev, base, time))
+    texels = fw * fh
+    chunk = sharding.owner_chunk(texels, world)
+    emitted = [sharding.emit_fragments(t) for t in shards]
+    assert sum(int(k.numel()) for k, _ in emitted) == frags
+    sends = [sharding.split_by_owner(k, texels, world) for k, _ in emitted]
+    # "all-to-all": destination d receives, from every source in rank order, the slice addressed to it
+    for d, t in enumerate(shards):
+        parts_k, parts_c = [], []
+        for s, (keys, colors) in enumerate(emitted):
+            lo = sum(sends[s][:d])
+            parts_k.append(keys[lo:lo + sends[s][d]].clone())
+            parts_c.append(colors[lo:lo + sends[s][d]].clone())
+        rk, rc = torch.cat(parts_k), torch.cat(parts_c)
+        if rk.numel():
+            assert int((rk >> 32).min()) >= d * chunk and int((rk >> 32).max()) < (d + 1) * chunk
+        sharding.merge_fragments(t, rk.contiguous(), rc.contiguous())
+    # "all-gather": every shard takes the owners' ranges
+    views = [sharding.flow_view(t) for t in shards]
+    owned = [views[d][min(d * chunk, texels):min((d + 1) * chunk, texels)].clone() for d in range(world)]
+    for v in views:
+        v.copy_(torch.cat(owned))
+    torch.cuda.synchronize()
+    for t in shards:
+        assert bits_equal(t.flow.read(), want).all()
+        t.dispose()
+
+
+def test_shard_draw_points_to_the_exchange():
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    opts = ta.defaults()
+    opts.update(row0=16, rows=16, globalHeight=64)
+    t = ta.Tendrils(View(32, 32), opts)
+    t.resize()
+    t.setup(64)
+    with pytest.raises(ta.TendrilsHipError) as e:
+        t.draw()
+    assert e.value.status == 4 and "th_deposit_emit" in str(e.value)
+    t.dispose()
+
+
+def test_draw_sharded_through_rccl_world_size_1(oracle):
+    """draw_sharded() itself - the torch.distributed (RCCL) calls - at world size 1 (the only size one GPU allows)."""
+    torch = pytest.importorskip("torch")
+    import os
+    import torch.distributed as dist
+    from tendrils_amd import sharding
+    n, view = 64, (96, 54)
+    rng = np.random.default_rng(12)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.9, 0.9, (n, n, 2)) * [1.0, 0.5]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.05, .05, (n, n, 2)).astype(np.float32)
+    base = np.zeros((54, 96, 4), np.float32)
+    want, frags = oracle.flow_deposit(cur, prev, base, 700.0, view_size=(1.0, 96 / 54))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        t = make_shard(n, view, 0, n, cur, prev, base, 700.0)
+        assert sharding.draw_sharded(dist, t) == frags
+        assert bits_equal(t.flow.read(), want).all()
+        t.dispose()
+    finally:
+        dist.destroy_process_group()

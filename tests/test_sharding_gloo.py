@@ -84,3 +84,41 @@ def test_two_rank_bands_equal_unsharded_run(tmp_path, oracle):
     assert red[0] == n * n and red[1] == live.sum() and red[2] == 0
     assert abs(red[4] - sp.sum()) < 1e-9 * max(1.0, sp.sum()) and red[5] == sp.max()
     assert red[6] == sum(100 + r for r in range(world))          # respawn counts add up over the ranks
+
+
+def _exchange_worker(rank, world, port, texels, out_dir):
+    """The fragment exchange of draw_sharded (counts, then keys, by flow-texel owner) over gloo, on synthetic
+    fragments: every rank ends up with exactly the fragments of its texel range."""
+    import torch
+    import torch.distributed as dist
+    from tendrils_amd.sharding import owner_chunk, split_by_owner
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    n = 5000 + 700 * rank
+    texel = rng.integers(0, texels, n).astype(np.int64)
+    ids = (rng.permutation(n).astype(np.int64) * world + rank)          # distinct stream indices across ranks
+    keys = torch.from_numpy(np.sort((texel << 32) | ids))
+    send = split_by_owner(keys, texels, world)
+    assert sum(send) == n
+    send_t = torch.tensor(send, dtype=torch.int64)
+    recv_t = torch.empty_like(send_t)
+    dist.all_to_all_single(recv_t, send_t)
+    recv = [int(v) for v in recv_t.tolist()]
+    rkeys = torch.empty(sum(recv), dtype=torch.int64)
+    dist.all_to_all_single(rkeys, keys, recv, send)
+    chunk = owner_chunk(texels, world)
+    got = rkeys.numpy()
+    assert ((got >> 32) >= rank * chunk).all() and ((got >> 32) < (rank + 1) * chunk).all()
+    np.save(os.path.join(out_dir, "sent_%d.npy" % rank), keys.numpy())
+    np.save(os.path.join(out_dir, "recv_%d.npy" % rank), got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fragment_exchange_by_texel_owner(tmp_path):
+    world, texels = 2, 96 * 54
+    mp.spawn(_exchange_worker, args=(world, _free_port(), texels, str(tmp_path)), nprocs=world, join=True)
+    sent = np.concatenate([np.load(tmp_path / ("sent_%d.npy" % r)) for r in range(world)])
+    recv = np.concatenate([np.load(tmp_path / ("recv_%d.npy" % r)) for r in range(world)])
+    assert np.array_equal(np.sort(sent), np.sort(recv))                  # nothing lost, nothing duplicated
