@@ -21,7 +21,8 @@ def test_parity_suite_with_bucketing_forced():
                         os.path.join(ROOT, "tests", "test_gpu_logic_parity.py"),
                         os.path.join(ROOT, "tests", "test_gpu_optical_flow.py"),
                         os.path.join(ROOT, "tests", "test_gpu_spawn.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_deposit.py")],
+                        os.path.join(ROOT, "tests", "test_gpu_deposit.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_fuzz.py")],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
