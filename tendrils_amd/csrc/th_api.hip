@@ -270,7 +270,7 @@ int bucket_policy()
 }
 int rebucket_period()
 {
-    static const int v = [] { const char *e = getenv("TH_REBUCKET_STEPS"); int n = e ? atoi(e) : 128; return n > 0 ? n : 128; }();
+    static const int v = [] { const char *e = getenv("TH_REBUCKET_STEPS"); int n = e ? atoi(e) : 256; return n > 0 ? n : 256; }();
     return v;
 }
 bool bucketing_possible(const th_context *c)
