@@ -230,6 +230,11 @@ th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_
  *    bit for bit.  The owners' texel ranges are then all-gathered into every rank's flow (th_flow_device_ptr). */
 th_status th_deposit_emit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev);
 th_status th_deposit_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
+/* For texture heights where the fp32 row lookup of the vertex stream (src/state/state-at-frame.glsl:12-22) lands one
+ * row beside the line's own row, a band needs its neighbours' edge rows: lo_dev = row row0-1, hi_dev = row
+ * row0+rows, each `width` RGBA32F texels of buffers[0] followed by `width` texels of buffers[1] (device memory owned
+ * by the caller, read by the next th_deposit_emit; NULL = none).  Without them such a lookup fails the emit. */
+th_status th_deposit_set_halo(th_context *ctx, const void *lo_dev, const void *hi_dev);
 th_status th_flow_device_ptr(th_context *ctx, void **dptr);
 
 /* -- statistics, sync, interop ---------------------------------------------- */

@@ -131,6 +131,7 @@ struct th_context {
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
     float4 *dep_colors_sorted = nullptr;
     bool dep_wide = false;
+    const float4 *halo_lo = nullptr, *halo_hi = nullptr;             // caller-owned neighbour rows (th_deposit_set_halo)
     unsigned long long *mrg_keys = nullptr;                          // th_deposit_merge scratch
     uint32_t *mrg_vals[2] = {nullptr, nullptr};
     size_t mrg_capacity = 0;
@@ -1041,13 +1042,14 @@ static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::
         p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
     }
     p.count = c->dep_count; p.offset = c->dep_offset; p.oob = c->dep_total + 1;
+    p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
     TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
     th::launch_deposit_count(p, c->stream);
     th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
     uint32_t host[2] = {0, 0};
     TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));
-    if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d): the vertex stream of this texture height needs halo rows", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
+    if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d) and no halo row was supplied (th_deposit_set_halo)", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
     TH_REQUIRE(host[0] < (1u << 31), "too many fragments (%u)", host[0]);
     *total = host[0];
     return TH_OK;
@@ -1126,6 +1128,14 @@ th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     TH_HIP(hipGetLastError());
     TH_HIP(hipStreamSynchronize(c->stream));               // the caller hands the buffers to a collective on its own stream
     *keys_dev = c->dep_u64[1]; *colors_dev = c->dep_colors_sorted;
+    return TH_OK;
+}
+
+th_status th_deposit_set_halo(th_context *c, const void *lo_dev, const void *hi_dev)
+{
+    TH_REQUIRE(c, "null context");
+    c->halo_lo = static_cast<const float4 *>(lo_dev);
+    c->halo_hi = static_cast<const float4 *>(hi_dev);
     return TH_OK;
 }
 

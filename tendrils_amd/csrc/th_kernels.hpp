@@ -84,7 +84,8 @@ struct DepositParams {
     float4 *flow;
     uint32_t W, H;               // particle texture shape (H = the WHOLE texture's height)
     uint32_t row0, rows;         // the rows held by cur/prev (a row-band shard; row0 = 0, rows = H otherwise)
-    uint32_t *oob;               // set to 1 when a vertex lookup leaves the band
+    uint32_t *oob;               // set to 1 when a vertex lookup leaves the band (and its halo rows)
+    const float4 *halo_lo, *halo_hi;   // row row0-1 / row0+rows of the neighbouring bands: W texels of `cur`, then W of `prev`
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
     double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)

@@ -106,6 +106,33 @@ def emit_fragments(tendrils):
     return device_view(kp.value, (n.value,), "<i8"), device_view(cp.value, (n.value, 4), "<f4")
 
 
+def edge_rows(tendrils):
+    """First and last row of buffers[0] and buffers[1] of this band: tensor [2, 2, W, 4] (a copy)."""
+    import torch
+    from . import _capi
+    p = tendrils.particles
+    p.sync()                                                     # the context's stream has produced the state
+    w, h = p.shape
+    out = torch.empty((2, 2, w, 4), dtype=torch.float32, device="cuda")
+    for b in range(2):
+        ptr = C.c_void_p()
+        _capi.call("th_state_device_ptr", p._ctx, b, C.byref(ptr))
+        buf = device_view(ptr.value, (h, w, 4), "<f4")
+        out[0, b] = buf[0]
+        out[1, b] = buf[h - 1]
+    torch.cuda.synchronize()
+    return out
+
+
+def set_halo(tendrils, lo, hi):
+    """lo / hi: [2 (cur, prev), W, 4] device tensors (or None) - the neighbouring bands' edge rows."""
+    from . import _capi
+    tendrils._halo = (lo, hi)                                    # keep the tensors alive while the library reads them
+    _capi.call("th_deposit_set_halo", tendrils.particles._ctx,
+               C.c_void_p(lo.data_ptr()) if lo is not None else None,
+               C.c_void_p(hi.data_ptr()) if hi is not None else None)
+
+
 def merge_fragments(tendrils, keys, colors):
     from . import _capi
     if keys.numel():
@@ -129,6 +156,17 @@ def draw_sharded(dist, tendrils):
     world, rank = dist.get_world_size(), dist.get_rank()
     fw, fh = tendrils.flow.shape
     texels = fw * fh
+    # edge rows of both state buffers to the neighbouring bands (the fp32 row lookup of the vertex stream can land
+    # one row beside a line's own row for some texture heights)
+    lo = hi = None
+    if tendrils._state_format == 0:                              # f32 ring (a packed band keeps to its own rows)
+        edges = edge_rows(tendrils)                              # [2 (first, last), 2 (cur, prev), W, 4]
+        every = torch.empty((world,) + tuple(edges.shape), dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(every, edges)
+        lo = every[rank - 1, 1].contiguous() if rank > 0 else None
+        hi = every[rank + 1, 0].contiguous() if rank + 1 < world else None
+        torch.cuda.synchronize()
+    set_halo(tendrils, lo, hi)
     keys, colors = emit_fragments(tendrils)
     send = split_by_owner(keys, texels, world)
     send_t = torch.tensor(send, dtype=torch.int64, device="cuda")

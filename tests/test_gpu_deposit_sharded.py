@@ -118,3 +118,37 @@ def test_draw_sharded_through_rccl_world_size_1(oracle):
         t.dispose()
     finally:
         dist.destroy_process_group()
+
+
+def test_band_edge_lookup_needs_and_uses_halo_rows(oracle):
+    """Texture height 100: the fp32 row lookup of the vertex stream lands on row 52 for line 53 (and 58 for 59).
+    A band starting at row 53 fails its emit without the neighbour's edge row and is exact with it."""
+    torch = pytest.importorskip("torch")
+    import tendrils_amd as ta
+    from tendrils_amd import sharding
+    n, view = 100, (96, 54)
+    rng = np.random.default_rng(100)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, 54 / 96]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.06, .06, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    base = np.zeros((54, 96, 4), np.float32)
+    want, frags = oracle.flow_deposit(cur, prev, base, 900.0, view_size=(1.0, 96 / 54))
+    bands = [(0, 53), (53, 47)]
+    shards = [make_shard(n, view, r0, rows, cur, prev, base, 900.0) for r0, rows in bands]
+    with pytest.raises(ta.TendrilsHipError) as e:
+        sharding.emit_fragments(shards[1])
+    assert e.value.status == 4 and "halo" in str(e.value)
+    edges = [sharding.edge_rows(t) for t in shards]
+    sharding.set_halo(shards[0], None, edges[1][0].contiguous())
+    sharding.set_halo(shards[1], edges[0][1].contiguous(), None)
+    emitted = [sharding.emit_fragments(t) for t in shards]
+    assert sum(int(k.numel()) for k, _ in emitted) == frags
+    keys = torch.cat([k for k, _ in emitted]).contiguous()
+    colors = torch.cat([c for _, c in emitted]).contiguous()
+    sharding.merge_fragments(shards[0], keys, colors)            # one owner for everything: order comes from the keys
+    assert bits_equal(shards[0].flow.read(), want).all()
+    for t in shards:
+        t.dispose()
