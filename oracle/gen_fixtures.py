@@ -274,6 +274,17 @@ def gen_deposit(r, only):
         rng = np.random.default_rng(seed)
         fw, fh = view
         prev = np.zeros((n, n, 4), np.float32)
+        if layout == "hashed":           # inputs regenerated by the tests (tests/helpers.py:deposit_hashed_inputs), not stored
+            sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tests"))
+            from helpers import deposit_hashed_inputs
+            cur, prev = deposit_hashed_inputs(n, seed, pos_range, step, inert)
+            out, res = r.deposit(cur, prev, uniforms=uniforms, time=time, view=view)
+            idx = np.flatnonzero((out != 0).any(-1)).astype(np.int32)
+            meta = dict(kind="deposit", N=n, viewRes=[fw, fh], viewSize=res["viewSize"], time=time,
+                        speedLimit=res["state"]["speedLimit"], seed=seed, lineWidthRange=res["lineWidthRange"],
+                        overrides=uniforms or {}, hashed=dict(pos_range=pos_range, step=step, inert=inert))
+            save(name, idx=idx, val=out.reshape(-1, 4)[idx], uniforms=json.dumps(meta))
+            return
         if layout == "cells":            # one short line per 16x16-texel cell: isolated lines, ties provoked
             cell = fw // n
             for y in range(n):
@@ -324,6 +335,9 @@ def gen_deposit(r, only):
     case("deposit_border_48", 48, (96, 54), 305, layout="border", step=0.06)
     case("deposit_long_lines_32", 32, (64, 64), 306, pos_range=1.3, step=0.2)
     case("deposit_speedlimit_32", 32, (80, 60), 307, uniforms={"speedLimit": 0.004})
+    # a frame-like load: 65 536 particles over a 480x270 field, steps of ~1-2 texels, a fifth outside the view,
+    # blended over an existing field: heavy overlap, every kind of tie and edge crossing at once
+    case("deposit_frame_256", 256, (240, 135), 308, layout="hashed", pos_range=1.15, step=0.012, inert=19)
 
 
 def gen_optical_flow(r, only):

@@ -192,3 +192,17 @@ def band_fixture_flow(fx):
         return fx["flow"]
     assert g["kind"] == "curl"
     return curl_flow(g["w"], g["h"], g["seed"], g["time"])
+
+
+def deposit_hashed_inputs(n, seed, pos_range, step, inert_mod):
+    """(current, previous) state textures of the large deposit fixture, from integer hashes (hashed_state) and
+    float32 operations only, so that the fixture need not store them."""
+    a = hashed_state(n, seed, inert_mod)                 # pos in [-1, 1), vel in [-.01, .01), some inert
+    b = hashed_state(n, seed + 7919, 0)
+    prev = a.copy()
+    live = ~((a[..., 0] == -1e6) & (a[..., 1] == -1e6))
+    prev[..., :2] = np.where(live[..., None], a[..., :2] * np.float32(pos_range), a[..., :2])
+    cur = prev.copy()
+    cur[..., :2] = np.where(live[..., None], prev[..., :2] + b[..., :2] * np.float32(step), prev[..., :2])
+    cur[..., 2:] = np.where(live[..., None], b[..., 2:], prev[..., 2:])
+    return cur.astype(np.float32), prev.astype(np.float32)

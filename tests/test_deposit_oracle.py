@@ -16,6 +16,10 @@ def deposit_close(got, ref, time):
 
 def deposit_inputs(fx):
     m = fx["meta"]
+    if "hashed" in m and "current" not in fx:
+        from helpers import deposit_hashed_inputs
+        h = m["hashed"]
+        fx["current"], fx["previous"] = deposit_hashed_inputs(m["N"], m["seed"], h["pos_range"], h["step"], h["inert"])
     fw, fh = m["viewRes"]
     base = fx["flow"] if "flow" in fx else np.zeros((fh, fw, 4), np.float32)
     ref = base.copy().reshape(-1, 4)
