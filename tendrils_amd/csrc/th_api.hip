@@ -1069,9 +1069,9 @@ static th_status deposit_reserve(th_context *c, uint32_t total, bool wide)
         TH_HIP(hipMalloc((void **)&c->dep_colors, cap * sizeof(float4)));
         c->dep_capacity = cap;
     }
+    if (!c->dep_colors_sorted) TH_HIP(hipMalloc((void **)&c->dep_colors_sorted, c->dep_capacity * sizeof(float4)));
     if (wide && !c->dep_wide) {
         for (unsigned long long *&q : c->dep_u64) TH_HIP(hipMalloc((void **)&q, c->dep_capacity * sizeof(unsigned long long)));
-        TH_HIP(hipMalloc((void **)&c->dep_colors_sorted, c->dep_capacity * sizeof(float4)));
         c->dep_wide = true;
     }
     return TH_OK;
@@ -1099,7 +1099,7 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (total == 0) return TH_OK;
     if (th_status s = deposit_reserve(c, total, false)) return s;
     p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
-    p.colors = c->dep_colors;
+    p.colors = c->dep_colors; p.colors_sorted = c->dep_colors_sorted;
     if (th_status s = deposit_temp(c, th::deposit_sort_temp_bytes(p, total))) return s;
     th::launch_deposit_scatter(p, c->stream);
     TH_HIP(th::launch_deposit_sort(p, total, c->dep_temp, c->dep_temp_bytes, c->stream));

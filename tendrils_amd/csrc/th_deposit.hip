@@ -272,11 +272,26 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams 
         const uint32_t texel = p.keys_sorted[i];
         if (i > 0 && p.keys_sorted[i - 1] == texel) continue;
         float4 d = p.flow[texel];
+        // the run's varyings are contiguous (gathered into sorted order): read four ahead of the dependent blends
         uint32_t j = i;
-        do {
-            dep_blend(d, p.colors[p.slots_sorted[j]]);
-            ++j;
-        } while (j < total && p.keys_sorted[j] == texel);
+        while (true) {
+            float4 c[4];
+            uint32_t k[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
+                c[q] = p.colors_sorted[at];
+                k[q] = p.keys_sorted[at];
+            }
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!done && j + (uint32_t)q < total && k[q] == texel) dep_blend(d, c[q]);
+                else done = true;
+            }
+            if (done) break;
+            j += 4u;
+        }
         p.flow[texel] = d;
     }
 }
@@ -548,6 +563,7 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
 
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
 {
+    launch_deposit_gather_colors(p.colors_sorted, p.colors, p.slots_sorted, total, s);
     hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
 }
 

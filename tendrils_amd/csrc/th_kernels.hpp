@@ -93,6 +93,7 @@ struct DepositParams {
     uint32_t *keys, *slots;      // per fragment (stream order): flow texel, own slot
     uint32_t *keys_sorted, *slots_sorted;   // the same after the stable sort by texel
     float4 *colors;              // per fragment (stream order): interpolated varying
+    float4 *colors_sorted;       // ... gathered into the sorted order
     unsigned long long *keys64;  // sharded form: (texel << 32) | global stream index, per fragment
 };
 

@@ -5,7 +5,11 @@ The result on every shard must equal the unsharded deposit bit for bit."""
 import numpy as np
 import pytest
 
-from helpers import bits_equal
+# torch bundles its own HIP runtime: it has to be loaded before libtendrils_hip.so pulls in the system one
+# (the other order leaves torch without devices); importing it at collection time guarantees that
+torch = pytest.importorskip("torch")
+
+from helpers import bits_equal  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
