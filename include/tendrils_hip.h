@@ -221,6 +221,13 @@ th_status th_optical_flow(th_context *ctx, const th_optical_flow_uniforms *u);
  * Needs the whole particle texture on this context (a row-band shard: th_deposit_emit / th_deposit_merge below). */
 th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *fragments);
 
+/* Trail export (build-defined; the reference never reads its lines back): the line list draw() hands to GL - same
+ * vertex stream, pairing and frame choice as the flow pass (src/state/state-at-frame.glsl:12-22, read by both
+ * src/flow/vert/main.vert and src/render/index.vert) - 12 floats per line in stream order: p0.xy, p1.xy (clip space
+ * = state.xy*viewSize), then the two vertices' (vel.x, vel.y, time, min(|vel|/speedLimit, 1)).  Lines with an inert
+ * vertex or zero length are left out.  lines == NULL queries the count; capacity is in lines. */
+th_status th_export_lines(th_context *ctx, const th_deposit_uniforms *u, float *lines, uint64_t capacity, uint64_t *count);
+
 /* Row-band shards (multi-GPU): the deposit in two steps around one exchange (tendrils_amd/sharding.py).
  *  th_deposit_emit: rasterise THIS context's lines; fragments sorted by key = (flow texel << 32) | global stream
  *    index; *keys_dev = uint64[count], *colors_dev = float4[count] (device, owned by the context, valid until the

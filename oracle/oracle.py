@@ -104,6 +104,8 @@ def lib():
         L.to_spawn_direct.argtypes = [C.POINTER(SpawnSampleUniforms), fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.to_triangles.restype = None
         L.to_triangles.argtypes = [fp, C.c_int, fp, fp, fp, C.c_int, C.c_int]
+        L.to_export_lines.restype = C.c_long
+        L.to_export_lines.argtypes = [C.POINTER(DepositUniforms), fp, fp, fp, C.c_long]
         L.to_flow_deposit.restype = C.c_long
         L.to_flow_deposit.argtypes = [C.POINTER(DepositUniforms), fp, fp, fp, C.c_int, C.c_int, C.POINTER(C.c_int32)]
         _lib = L
@@ -248,3 +250,15 @@ def triangles(positions, shape, view_size=(1.0, 1.0), color=(1.0, 1.0, 1.0, 1.0)
     col = np.asarray(color, np.float32)
     lib().to_triangles(_fp(pos), len(pos) // 6, _fp(vs), _fp(col), _fp(out), int(w), int(h))
     return out
+
+
+def export_lines(current, previous, time, view_size=(1.0, 1.0), speedLimit=0.01):
+    """The line list of draw(): [n, 12] float32 (p0.xy, p1.xy, c0, c1) in stream order."""
+    current = np.ascontiguousarray(current, np.float32)
+    previous = np.ascontiguousarray(previous, np.float32)
+    h, w = current.shape[:2]
+    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(speedLimit))
+    u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+    out = np.empty((w * h, 12), np.float32)
+    n = lib().to_export_lines(C.byref(u), _fp(current), _fp(previous), _fp(out), w * h)
+    return out[:n].copy()

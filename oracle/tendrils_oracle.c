@@ -774,3 +774,31 @@ void to_triangles(const float *positions, int ntri, const float *view_size, cons
         }
     }
 }
+
+
+/* Trail export (build-defined: the reference never reads its lines back): the line list that
+ * draw() hands to GL - the same vertex stream, pairing and frame choice as to_flow_deposit (src/render/index.vert
+ * and src/flow/vert/main.vert read the state through the same stateAtFrame) - as 12 floats per line in stream
+ * order: p0.xy, p1.xy (clip space = state.xy*viewSize), then the two vertices' (vel.x, vel.y, time, alpha).
+ * Lines with an inert vertex or zero length are left out.  Returns the number of lines. */
+long to_export_lines(const to_deposit_uniforms *u, const float *current, const float *previous, float *out, long capacity)
+{
+    const int W = u->data_w, H = u->data_h;
+    long n = 0;
+    for (int i = 0; i < W; ++i) {
+        for (int m = 0; m < H; ++m) {
+            deposit_vertex a, b;
+            deposit_fetch(u, current, previous, i, 2 * m, &a);
+            deposit_fetch(u, current, previous, i, 2 * m + 1, &b);
+            if (!a.live || !b.live) continue;
+            if (a.px == b.px && a.py == b.py) continue;
+            if (n < capacity) {
+                float *o = out + 12 * n;
+                o[0] = a.px; o[1] = a.py; o[2] = b.px; o[3] = b.py;
+                for (int k = 0; k < 4; ++k) { o[4 + k] = a.c[k]; o[8 + k] = b.c[k]; }
+            }
+            ++n;
+        }
+    }
+    return n;
+}

@@ -103,6 +103,9 @@ typedef struct to_deposit_uniforms {
 long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const float *previous,
                      float *flow, int fw, int fh, int32_t *coverage);
 
+/* Trail export: the (previous -> current) line list of draw(), 12 floats per line (see the .c file). */
+long to_export_lines(const to_deposit_uniforms *u, const float *current, const float *previous, float *out, long capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "th_frames_rotate": (C.c_int32, [_ctx]),
     "th_optical_flow": (C.c_int32, [_ctx, C.POINTER(OpticalFlowUniforms)]),
     "th_flow_deposit": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(C.c_uint64)]),
+    "th_export_lines": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), _fp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "th_deposit_emit": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "th_deposit_set_halo": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p]),
     "th_deposit_merge": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64]),

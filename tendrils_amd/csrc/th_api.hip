@@ -1006,8 +1006,8 @@ static int deposit_texel_bits(const th_context *c)
     return bits;
 }
 
-// per-line buffers + parameters; counts this context's fragments (one sync)
-static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, uint32_t *total)
+// per-line buffers + parameters
+static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p)
 {
     if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
     c->hold_texel_order_until = c->total_steps + rebucket_period();   // a frame loop of step + draw stays in texel order
@@ -1044,7 +1044,12 @@ static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::
     p.count = c->dep_count; p.offset = c->dep_offset; p.oob = c->dep_total + 1;
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
     TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
-    th::launch_deposit_count(p, c->stream);
+    return TH_OK;
+}
+
+// scan of p.count (filled by the caller's marking pass) -> p.offset, total (one sync); reports band violations
+static th_status deposit_scan_total(th_context *c, const th::DepositParams &p, uint32_t *total)
+{
     th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
     uint32_t host[2] = {0, 0};
     TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
@@ -1052,6 +1057,37 @@ static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::
     if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d) and no halo row was supplied (th_deposit_set_halo)", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
     TH_REQUIRE(host[0] < (1u << 31), "too many fragments (%u)", host[0]);
     *total = host[0];
+    return TH_OK;
+}
+
+// counts this context's fragments
+static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, uint32_t *total)
+{
+    if (th_status s = deposit_prepare(c, u, p)) return s;
+    th::launch_deposit_count(p, c->stream);
+    return deposit_scan_total(c, p, total);
+}
+
+th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *lines, uint64_t capacity, uint64_t *count)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count, "null count");
+    th::DepositParams p;
+    if (th_status s = deposit_prepare(c, u, p)) return s;
+    th::launch_export_mark(p, c->stream);
+    uint32_t total = 0;
+    if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    *count = total;
+    if (!lines || total == 0) return TH_OK;                  // size query
+    TH_REQUIRE(capacity >= total, "line buffer holds %llu of %u lines", (unsigned long long)capacity, total);
+    float *d_out = nullptr;
+    TH_HIP(hipMalloc((void **)&d_out, (size_t)total * 12 * sizeof(float)));
+    th::launch_export_write(p, d_out, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(lines, d_out, (size_t)total * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    TH_HIP(e);
     return TH_OK;
 }
 

@@ -380,6 +380,29 @@ __global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *out, const uint
     for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
 }
 
+// ---- trail export: the line list of draw() (12 floats per line, stream order) ---------------------------------
+// pass 1 marks the lines that exist (two live vertices, non-zero length), the scan places them, pass 2 writes them
+template <bool WRITE>
+__global__ __launch_bounds__(256) void export_lines_kernel(const DepositParams p, float *out)
+{
+    const uint32_t lines = p.W * p.rows;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
+        const uint32_t row = t / p.W, col = t - row * p.W;
+        const uint32_t id = col * p.H + p.row0 + row, local = col * p.rows + row;
+        const uint32_t i = id / p.H, m = id - i * p.H;
+        const DepositVertex a = dep_fetch(p, i, 2u * m), b = dep_fetch(p, i, 2u * m + 1u);
+        const bool exists = a.live && b.live && !(a.px == b.px && a.py == b.py);
+        if constexpr (WRITE) {
+            if (!exists) continue;
+            float *o = out + 12ull * p.offset[local];
+            o[0] = a.px; o[1] = a.py; o[2] = b.px; o[3] = b.py;
+            for (int k = 0; k < 4; ++k) { o[4 + k] = a.c[k]; o[8 + k] = b.c[k]; }
+        } else {
+            p.count[local] = exists ? 1u : 0u;
+        }
+    }
+}
+
 // ---- GeometrySpawner's draw (src/spawn/geometry/index.js:97-115): triangles into the spawner's float buffer ---------
 // gl_Position = (position*viewSize, 0, 1) (src/geom/vert/index.vert:3-5), constant colour (src/geom/frag/index.frag),
 // blend SRC_ALPHA / ONE_MINUS_SRC_ALPHA in primitive order; same rasteriser conventions as the lines above, either
@@ -520,6 +543,16 @@ hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *tem
 {
     return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, p.keys, p.keys_sorted, p.slots, p.slots_sorted, (int)total, 0,
                                               deposit_key_bits(p), s);
+}
+
+void launch_export_mark(const DepositParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(export_lines_kernel<false>, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p, (float *)nullptr);
+}
+
+void launch_export_write(const DepositParams &p, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(export_lines_kernel<true>, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p, out);
 }
 
 void launch_triangles(const float *positions, int ntri, float view_x, float view_y, float4 color, TrianglePoly *polys,

@@ -130,6 +130,8 @@ uint32_t deposit_scan_blocks(uint32_t texels);
 void launch_deposit_count(const DepositParams &p, hipStream_t stream);
 void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
 void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
+void launch_export_mark(const DepositParams &p, hipStream_t stream);
+void launch_export_write(const DepositParams &p, float *out, hipStream_t stream);
 void launch_triangles(const float *positions, int ntri, float view_x, float view_y, float4 color, TrianglePoly *polys,
                       float4 *img, int w, int h, hipStream_t stream);
 size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total);

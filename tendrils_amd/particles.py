@@ -195,6 +195,17 @@ class Particles:
         call("th_flow_deposit", self._ctx, C.byref(u), C.byref(n))
         return int(n.value)
 
+    def export_lines(self, view_size, time, speed_limit):
+        """The line list of draw() ([n, 12] float32: p0.xy, p1.xy, c0, c1 in stream order) for offline rendering."""
+        u = _capi.DepositUniforms(time=float(time), speedLimit=float(speed_limit))
+        u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+        n = C.c_uint64(0)
+        call("th_export_lines", self._ctx, C.byref(u), None, 0, C.byref(n))
+        out = np.empty((int(n.value), 12), np.float32)
+        if n.value:
+            call("th_export_lines", self._ctx, C.byref(u), out.ctypes.data_as(_capi._fp), n.value, C.byref(n))
+        return out
+
     def stats(self, speed_limit):
         c = _capi.Counters()
         call("th_stats", self._ctx, C.c_float(speed_limit), C.byref(c))

@@ -227,6 +227,10 @@ class Tendrils:
             self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
         return self
 
+    def export_lines(self):
+        """Trail export: the (previous -> current) line list this frame's draw() is made of (build-defined)."""
+        return self.particles.export_lines(self.viewSize, self.timer.time, self.state["speedLimit"])
+
     def resize(self):                                          # src/index.js:393-408
         self.viewRes[0] = self.gl.drawingBufferWidth
         self.viewRes[1] = self.gl.drawingBufferHeight

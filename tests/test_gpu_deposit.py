@@ -96,3 +96,27 @@ def test_step_draw_loop_matches_oracle(oracle):
         assert bits_equal(t.flow.read(), flow).all()
     assert (flow[..., 3] != 0).sum() > 500
     t.dispose()
+
+
+def test_export_lines_matches_oracle(oracle):
+    """Trail export: the line list of draw() (two live vertices, non-zero length), stream order, bit for bit."""
+    import tendrils_amd as ta
+    n, view = 100, (96, 54)
+    rng = np.random.default_rng(6)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-1.2, 1.2, (n, n, 2))
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.05, .05, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    cur[5, :7] = prev[5, :7]                                   # some particles did not move
+    t = make(n, view)
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.timer.time = 321.0
+    got = t.export_lines()
+    t.dispose()
+    want = oracle.export_lines(cur, prev, 321.0, view_size=(1.0, 96 / 54))
+    assert got.shape == want.shape and 3000 < len(got) < n * n
+    assert bits_equal(got, want).all()
