@@ -38,25 +38,28 @@ class GeometrySpawner extends PixelSpawner {
     this.random = Math.random;                     // replaceable for reproducible runs
   }
 
-  shuffle() {                                      // :53-95
-    const { shuffles, positions } = this;
-    const { radii, arcs, obtuse, size, count } = shuffles;
-    const [radiusMin, radiusMax] = radii;
-    const [arcOffset, arcOver] = arcs;
-    const { rate: obtuseRate, pad: obtusePad } = obtuse;
-    const step = size * count;
-    const tau = Math.PI * 2;
-    const random = this.random;
-    const radius = () => radiusMin + (random() * radiusMax);
-    for (let t = positions.length - 1; t >= 0; t -= step) {    // triangles, one vertex always in the centre
-      const angle = tau * random();
-      const arc = tau * (arcOffset + (random() * arcOver) + ((random() < obtuseRate) * obtusePad));
-      let rad = radius();
-      positions[t - 3] = Math.cos(angle - arc) * rad;
-      positions[t - 2] = Math.sin(angle - arc) * rad;
-      rad = radius();
-      positions[t - 1] = Math.cos(angle + arc) * rad;
-      positions[t - 0] = Math.sin(angle + arc) * rad;
+  // One random fan blade per triangle: vertex 0 stays at the origin, vertices 1 and 2 sit on either side of a
+  // random direction, `arc` apart from it, each at its own random radius (src/spawn/geometry/index.js:53-95).
+  // Triangles are visited last to first and draw (direction, arc width, obtuse?, radius, radius) from `random`
+  // in that order - the reference's consumption order, so a seeded generator reproduces its forms.
+  shuffle() {
+    const cfg = this.shuffles;
+    const perTriangle = cfg.size * cfg.count;
+    const fullTurn = 2 * Math.PI;
+    const draw = this.random;
+    const rimPoint = (direction) => {
+      const reach = cfg.radii[0] + draw() * cfg.radii[1];
+      return [Math.cos(direction) * reach, Math.sin(direction) * reach];
+    };
+    for (let last = this.positions.length - 1; last >= 0; last -= perTriangle) {
+      const heading = fullTurn * draw();
+      let spread = cfg.arcs[0] + draw() * cfg.arcs[1];
+      if (draw() < cfg.obtuse.rate) spread += cfg.obtuse.pad;
+      spread *= fullTurn;
+      const [ax, ay] = rimPoint(heading - spread);
+      const [bx, by] = rimPoint(heading + spread);
+      this.positions[last - 3] = ax; this.positions[last - 2] = ay;
+      this.positions[last - 1] = bx; this.positions[last] = by;
     }
     return this;
   }

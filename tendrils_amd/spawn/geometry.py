@@ -67,26 +67,28 @@ class GeometrySpawner(PixelSpawner):
         self.shuffles = shuffles
         self.random = random.random                          # Math.random: replaceable for reproducible runs
 
-    def shuffle(self):                                       # :53-95
-        sh = self.shuffles
-        radius_min, radius_max = sh["radii"]
-        arc_offset, arc_over = sh["arcs"]
-        rate, pad = sh["obtuse"]["rate"], sh["obtuse"]["pad"]
-        step = sh["size"] * sh["count"]
-        tau = math.pi * 2
-        rnd = self.random
-        pos = self.positions
-        t = len(pos) - 1
-        while t >= 0:                                        # triangles, one vertex always in the centre
-            angle = tau * rnd()
-            arc = tau * (arc_offset + (rnd() * arc_over) + ((rnd() < rate) * pad))
-            rad = radius_min + (rnd() * radius_max)
-            pos[t - 3] = math.cos(angle - arc) * rad
-            pos[t - 2] = math.sin(angle - arc) * rad
-            rad = radius_min + (rnd() * radius_max)
-            pos[t - 1] = math.cos(angle + arc) * rad
-            pos[t - 0] = math.sin(angle + arc) * rad
-            t -= step
+    def shuffle(self):
+        """One random fan blade per triangle: vertex 0 stays at the origin, vertices 1 and 2 sit on either side of a
+        random direction, `arc` apart from it, each at its own random radius (src/spawn/geometry/index.js:53-95).
+        Triangles are visited last to first and draw (direction, arc width, obtuse?, radius, radius) from
+        `self.random` in that order - the reference's consumption order."""
+        cfg = self.shuffles
+        per_triangle = cfg["size"] * cfg["count"]
+        full_turn = 2 * math.pi
+        draw = self.random
+
+        def rim_point(direction):
+            reach = cfg["radii"][0] + draw() * cfg["radii"][1]
+            return math.cos(direction) * reach, math.sin(direction) * reach
+
+        for last in range(len(self.positions) - 1, -1, -per_triangle):
+            heading = full_turn * draw()
+            spread = cfg["arcs"][0] + draw() * cfg["arcs"][1]
+            if draw() < cfg["obtuse"]["rate"]:
+                spread += cfg["obtuse"]["pad"]
+            spread *= full_turn
+            self.positions[last - 3], self.positions[last - 2] = rim_point(heading - spread)
+            self.positions[last - 1], self.positions[last] = rim_point(heading + spread)
         return self
 
     def spawn(self, tendrils, *rest):                        # :97-117
