@@ -1155,10 +1155,12 @@ th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (total == 0) return TH_OK;
     if (th_status s = deposit_reserve(c, total, true)) return s;
     p.keys64 = c->dep_u64[0]; p.slots = c->dep_u32[1]; p.colors = c->dep_colors;
+    // the fragment array is in this band's stream order already: a stable sort on the texel bits alone leaves it
+    // sorted by the whole (texel, stream index) key
     const int bits = 32 + deposit_texel_bits(c);
-    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, bits))) return s;
+    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, 32, bits))) return s;
     th::launch_deposit_scatter(p, c->stream);
-    TH_HIP(th::launch_deposit_sort64(c->dep_u64[0], c->dep_u64[1], c->dep_u32[1], c->dep_u32[3], total, bits, c->dep_temp,
+    TH_HIP(th::launch_deposit_sort64(c->dep_u64[0], c->dep_u64[1], c->dep_u32[1], c->dep_u32[3], total, 32, bits, c->dep_temp,
                                      c->dep_temp_bytes, c->stream));
     th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, c->dep_u32[3], total, c->stream);
     TH_HIP(hipGetLastError());
@@ -1191,10 +1193,10 @@ th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colo
         c->mrg_capacity = cap;
     }
     const int bits = 32 + deposit_texel_bits(c);
-    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, bits))) return s;
+    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, 0, bits))) return s;
     th::launch_deposit_iota(c->mrg_vals[0], total, c->stream);
     TH_HIP(th::launch_deposit_sort64(static_cast<const unsigned long long *>(keys_dev), c->mrg_keys, c->mrg_vals[0], c->mrg_vals[1],
-                                     total, bits, c->dep_temp, c->dep_temp_bytes, c->stream));
+                                     total, 0, bits, c->dep_temp, c->dep_temp_bytes, c->stream));
     th::launch_deposit_blend64(c->flow, c->mrg_keys, c->mrg_vals[1], static_cast<const float4 *>(colors_dev), total, c->stream);
     TH_HIP(hipGetLastError());
     TH_HIP(hipStreamSynchronize(c->stream));               // the input buffers may be reused by the caller now

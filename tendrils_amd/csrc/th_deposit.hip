@@ -563,19 +563,19 @@ void launch_triangles(const float *positions, int ntri, float view_x, float view
     hipLaunchKernelGGL(triangle_fill_kernel, dim3(deposit_grid((uint32_t)w * (uint32_t)h)), dim3(256), 0, s, polys, ntri, color, img, w, h);
 }
 
-size_t deposit_sort64_temp_bytes(uint32_t total, int key_bits)
+size_t deposit_sort64_temp_bytes(uint32_t total, int begin_bit, int end_bit)
 {
     size_t bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)total, 0, key_bits,
+                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)total, begin_bit, end_bit,
                                              (hipStream_t) nullptr);
     return bytes;
 }
 
 hipError_t launch_deposit_sort64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
-                                 uint32_t *vals_out, uint32_t total, int key_bits, void *temp, size_t temp_bytes, hipStream_t s)
+                                 uint32_t *vals_out, uint32_t total, int begin_bit, int end_bit, void *temp, size_t temp_bytes, hipStream_t s)
 {
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, 0, key_bits, s);
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, begin_bit, end_bit, s);
 }
 
 void launch_deposit_iota(uint32_t *dst, uint32_t n, hipStream_t s)

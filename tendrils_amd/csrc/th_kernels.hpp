@@ -138,9 +138,9 @@ size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total);
 hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
 // sharded form: 64-bit (texel, stream index) keys
-size_t deposit_sort64_temp_bytes(uint32_t total, int key_bits);
+size_t deposit_sort64_temp_bytes(uint32_t total, int begin_bit, int end_bit);
 hipError_t launch_deposit_sort64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
-                                 uint32_t *vals_out, uint32_t total, int key_bits, void *temp, size_t temp_bytes, hipStream_t stream);
+                                 uint32_t *vals_out, uint32_t total, int begin_bit, int end_bit, void *temp, size_t temp_bytes, hipStream_t stream);
 void launch_deposit_iota(uint32_t *dst, uint32_t n, hipStream_t stream);
 void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);
 void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
