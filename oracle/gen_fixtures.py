@@ -340,6 +340,26 @@ def gen_deposit(r, only):
     case("deposit_frame_256", 256, (240, 135), 308, layout="hashed", pos_range=1.15, step=0.012, inert=19)
 
 
+def gen_loop(r, only):
+    """The reference's frame loop, closed: Tendrils.step() then Tendrils.draw() for K frames from an empty flow
+    field - the deposited wake of every frame steers the next step.  No inert particles (see the deposit's
+    documented deviation)."""
+    name = "loop_frames_64"
+    if only and only not in name:
+        return
+    n, view, frames = 64, (96, 54), 6
+    rng = np.random.default_rng(31)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, 0.55]
+    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+    outs, res = r.logic(st, flow=None, time0=1000.0, steps=frames, view=view, return_each=True, draw=True)
+    fl = res["flow_out"]
+    idx = np.flatnonzero((fl != 0).any(-1)).astype(np.int32)
+    meta = dict(kind="loop", N=n, frames=frames, viewRes=list(view), viewSize=res["viewSize"], times=res["times"],
+                dts=res["dts"], state={k: v for k, v in res["state"].items() if isinstance(v, (int, float))})
+    save(name, state=st, out=np.stack(outs), flow_idx=idx, flow_val=fl.reshape(-1, 4)[idx], uniforms=json.dumps(meta))
+
+
 def gen_optical_flow(r, only):
     """One blended pass of the reference's optical-flow shader (docs/js/demo.js:73) per case.
     Frames are regenerated from seeds by tests/helpers.py:synth_frame; only parameters and the
@@ -482,6 +502,7 @@ def main():
     gen_logic_4096(r, args.only)
     gen_logic_config_bands(r, args.only)
     gen_deposit(r, args.only)
+    gen_loop(r, args.only)
     gen_optical_flow(r, args.only)
     gen_spawn(r, args.only)
     gen_spawn_image(r, args.only)

@@ -105,6 +105,7 @@
     for (var s = 0; s < job.steps; ++s) {
       t.timer.tick();
       t.step();
+      if (job.draw) t.draw();             // the reference's frame: step() then draw() (flow deposit + view render)
       times.push(t.timer.time); dts.push(t.timer.dt);
       if (job.returnEach || s === job.steps - 1) {
         t.particles.buffers[0].bind();
@@ -122,7 +123,9 @@
       }
     }
     var ms = performance.now() - t0;
-    return {out: outs, times: times, dts: dts, ms: ms,
+    var flowOut = null;
+    if (job.draw) { t.flow.bind(); flowOut = f32ToB64(readFBO(gl, t.flow.shape[0], t.flow.shape[1])); }
+    return {out: outs, times: times, dts: dts, ms: ms, flowOut: flowOut,
             viewSize: [t.viewSize[0], t.viewSize[1]], viewRes: [t.viewRes[0], t.viewRes[1]],
             flowShape: [t.flow.shape[0], t.flow.shape[1]],
             state: t.state, err: gl.getError()};

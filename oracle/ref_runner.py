@@ -56,7 +56,7 @@ class RefRunner:
 
     # -- reference Tendrils.step() ------------------------------------------------
     def logic(self, state, flow=None, targets=None, uniforms=None, time0=0.0, steps=1,
-              view=(64, 64), flow_shape=None, view_size=None, return_each=False, rows=None, state_gen=None):
+              view=(64, 64), flow_shape=None, view_size=None, return_each=False, rows=None, state_gen=None, draw=False):
         """state: [N,N,4] f32 indexed [y][x][c]; flow: [H,W,4]; returns list of [N,N,4]."""
         if state_gen is not None:            # {"N":..., "seed":..., "inertMod":...}: generated inside the page
             N = int(state_gen["N"])
@@ -67,7 +67,7 @@ class RefRunner:
             inputs = {"state": _b64(state, np.float32)}
         job = {"kind": "logic", "N": N, "viewW": int(view[0]), "viewH": int(view[1]),
                "state": uniforms or {}, "time0": float(time0), "steps": int(steps),
-               "returnEach": bool(return_each), "inputs": inputs}
+               "returnEach": bool(return_each), "inputs": inputs, "draw": bool(draw)}
         if flow is not None:
             fh, fw = flow.shape[:2]
             if flow_shape is None:
@@ -89,6 +89,9 @@ class RefRunner:
             outs = [[_f32(b, (r[1] - r[0], N, 4)) for b, r in zip(bands, rows)] for bands in res["out"]]
         else:
             outs = [_f32(o, (N, N, 4)) for o in res["out"]]
+        if res.get("flowOut"):
+            fw, fh = res["flowShape"]
+            res["flow_out"] = _f32(res["flowOut"], (fh, fw, 4))
         return outs, res
 
     # -- reference Tendrils.draw(): flow deposit ------------------------------------

@@ -62,3 +62,44 @@ def test_deposit_pairing_quirk_and_inert(oracle):
     cur[3, 5] = [-1e6, -1e6, 0, 0]                          # dies this frame: no streak
     _, _, cov2 = oracle.flow_deposit(cur, prev, np.zeros((v, v, 4), np.float32), 100.0, coverage=True)
     assert cov2[3 * cell:4 * cell, 5 * cell:6 * cell].sum() == 0 and cov2.sum() < cov.sum()
+
+
+def loop_reference(fx):
+    m = fx["meta"]
+    fw, fh = m["viewRes"]
+    flow = np.zeros((fh * fw, 4), np.float32)
+    flow[fx["flow_idx"]] = fx["flow_val"]
+    return m, flow.reshape(fh, fw, 4)
+
+
+def loop_close(states, flow, fx):
+    """Tolerance of the closed loop against the reference's own K frames: the deposit's value tolerance feeds back
+    into the next step through the flow tap, so states may drift by a few ulp (<= 2.5e-7 on positions in [-1, 1])
+    and the final field carries K deposits' worth of the per-deposit tolerance; coverage stays identical."""
+    m, ref_flow = loop_reference(fx)
+    for k, s in enumerate(states):
+        assert np.abs(s.astype(np.float64) - fx["out"][k]).max() <= 2.5e-7, "frame %d" % k
+    assert ((flow != 0).any(-1) == (ref_flow != 0).any(-1)).all()
+    d = np.abs(flow.astype(np.float64) - ref_flow)
+    t = m["times"][-1]
+    assert d[..., 0].max() <= 2e-7 and d[..., 1].max() <= 2e-7 and d[..., 2].max() <= 4e-6 * t and d[..., 3].max() <= 4e-5
+
+
+def test_closed_loop_against_reference_frames(oracle):
+    """K = 6 frames of the reference's own step() + draw(), restated: step, deposit, step on the deposited field ..."""
+    import os
+    from helpers import GOLDEN
+    fx = load(os.path.join(GOLDEN, "loop_frames_64.npz"))
+    m = fx["meta"]
+    n = m["N"]
+    fw, fh = m["viewRes"]
+    cur, prev, flow = fx["state"], fx["state"], np.zeros((fh, fw, 4), np.float32)
+    states = []
+    for k in range(m["frames"]):
+        u = oracle.logic_uniforms(n, n, m["times"][k], m["dts"][k], view_size=m["viewSize"], **oracle.DEFAULT_STATE)
+        prev, cur = cur, oracle.logic_step(u, cur, flow)
+        flow, _ = oracle.flow_deposit(cur, prev, flow, m["times"][k], view_size=m["viewSize"],
+                                      speedLimit=oracle.DEFAULT_STATE["speedLimit"])
+        states.append(cur)
+    loop_close(states, flow, fx)
+    assert (states[0].view(np.uint32) == fx["out"][0].view(np.uint32)).all()      # frame 0 has no wake yet: bit-exact

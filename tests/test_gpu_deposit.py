@@ -120,3 +120,27 @@ def test_export_lines_matches_oracle(oracle):
     want = oracle.export_lines(cur, prev, 321.0, view_size=(1.0, 96 / 54))
     assert got.shape == want.shape and 3000 < len(got) < n * n
     assert bits_equal(got, want).all()
+
+
+def test_closed_loop_against_reference_frames():
+    """The reference's own K = 6 frames of step() + draw() against the GPU frame loop (tolerances of
+    tests/test_deposit_oracle.py:loop_close; the first frame is bit-exact)."""
+    import os
+    from helpers import GOLDEN
+    from test_deposit_oracle import loop_close
+    fx = load(os.path.join(GOLDEN, "loop_frames_64.npz"))
+    m = fx["meta"]
+    t = make(m["N"], m["viewRes"], m["viewSize"])
+    t.particles.upload_texels(fx["state"])
+    t.timer.time = m["times"][0] - m["dts"][0]
+    states = []
+    for k in range(m["frames"]):
+        t.timer.tick()
+        assert t.timer.time == m["times"][k]
+        t.step()
+        t.draw()
+        states.append(t.particles.read(0))
+    flow = t.flow.read()
+    t.dispose()
+    loop_close(states, flow, fx)
+    assert bits_equal(states[0], fx["out"][0]).all()
