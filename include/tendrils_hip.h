@@ -6,8 +6,10 @@
  * is the `Particles` object contract (src/particles.js:43-196) with a swappable
  * "logic" shader, driven by `Tendrils.step()/spawnShader()` (src/index.js:248-272,
  * 432-457) over WebGL FBO ping-pong.  Each entry point below replaces one of
- * those GL-backed operations; the N-API shim (tendrils_amd/csrc/th_napi.cc) and
- * the ctypes binding (tendrils_amd/_capi.py) bind exactly these symbols.
+ * those GL-backed operations; the ctypes binding (tendrils_amd/_capi.py) binds exactly these
+ * symbols and the N-API shim (tendrils_amd/csrc/th_napi.cc) all of them except the multi-GPU
+ * exchange primitives (th_deposit_emit / _merge / _set_halo, th_flow_device_ptr: the sharded
+ * host is the Python one, over torch.distributed) and th_spawn_image_download.
  *
  * Conventions
  *  - plain C, no exceptions across the boundary; every call returns th_status

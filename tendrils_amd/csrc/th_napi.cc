@@ -390,6 +390,24 @@ napi_value FlowDeposit(napi_env env, napi_callback_info info)
     return v;
 }
 
+// exportLines(ctx, Float32Array [viewSize.x, viewSize.y, time, speedLimit]) -> Float32Array (12 floats per line)
+napi_value ExportLines(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_deposit_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_export_lines");
+    uint64_t n = 0;
+    TH_CALL("th_export_lines", th_export_lines(c, &u, nullptr, 0, &n));
+    napi_value buf, arr;
+    void *data = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 12 * sizeof(float), &data, &buf));
+    if (n) TH_CALL("th_export_lines", th_export_lines(c, &u, static_cast<float *>(data), n, &n));
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)n * 12, buf, 0, &arr));
+    return arr;
+}
+
 // stats(ctx, speedLimit) -> {particles, live, nan, capped, sumSpeed, maxSpeed}
 napi_value Stats(napi_env env, napi_callback_info info)
 {
@@ -473,7 +491,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"spawnDirect", SpawnDirect}, {"spawnImageUpload", SpawnImageUpload}, {"spawnImageTriangles", SpawnImageTriangles},
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
-        {"flowDeposit", FlowDeposit},
+        {"flowDeposit", FlowDeposit}, {"exportLines", ExportLines},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},
     };

@@ -159,6 +159,13 @@ class Tendrils {
     return this;
   }
 
+  // Trail export (build-defined): the (previous -> current) line list this frame's draw() is made of,
+  // 12 floats per line: p0.xy, p1.xy (clip space), then both vertices' (vel.x, vel.y, time, alpha).
+  exportLines() {
+    return native.exportLines(this.particles.handle,
+      new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]));
+  }
+
   draw() {                                         // src/index.js:278-340: the flow pass (the view render is outside this build)
     this.fragments = native.flowDeposit(this.particles.handle,
       new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]));

@@ -54,6 +54,7 @@ if (spec.kind === 'logic') {
   }
   save('state.out.bin', t.particles.read(0));
   save('flow.out.bin', t.flow.read());
+  save('lines.out.bin', t.exportLines());
   fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, fragments }));
 } else if (spec.kind === 'optical_flow') {
   const of = new OpticalFlow(t);

@@ -27,7 +27,7 @@ def test_addon_loads_and_exports_the_abi():
              "console.log(JSON.stringify({n:Object.keys(a).length,abi:a.abiVersion(),ring:a.TARGET_RING}))")
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout)
-    assert info == {"n": 43, "abi": 2, "ring": -1}
+    assert info == {"n": 44, "abi": 2, "ring": -1}
 
 
 def test_timer_matches_reference_semantics():
@@ -213,6 +213,8 @@ def test_js_frame_loop_step_and_draw(tmp_path, oracle):
         counts.append(k)
     assert res["fragments"] == counts and abs(res["time"] - time) < 1e-9
     assert bits_equal(got_state, cur).all() and bits_equal(got_flow, flow).all()
+    lines = np.fromfile(str(tmp_path / "lines.out.bin"), np.float32).reshape(-1, 12)
+    assert bits_equal(lines, oracle.export_lines(cur, prev, time, view_size=(1.0, 96 / 54))).all()
 
 
 @pytest.mark.gpu
