@@ -13,6 +13,8 @@
 #include "th_kernels.hpp"
 #include "th_math.hpp"
 
+#include <cstdlib>
+
 namespace th {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -356,6 +358,17 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
     if (__builtin_expect(!in_domain, 0)) {
         if (!(posx != kInert || posy != kInert)) return st;              // inert: pass through (src/logic.frag:52)
+        // A NaN or infinite position component makes every output component NaN in the reference: the first noise
+        // coordinate v = pos * noiseScale' is NaN or Inf, s = dot(v, C.yyy) and i = floor(v + s) follow, x0 = v - i + t
+        // is NaN (Inf - Inf), the gradient dot products are NaN and 42 * dot(m, NaN) is NaN whatever m is; wander
+        // is multiplied (never skipped) into newVel (src/logic.frag:79-82), min(NaN, limit)/NaN keeps it NaN (:94)
+        // and newPos = pos + newVel (:97).  No arithmetic is needed to produce that (NaN payloads are not pinned,
+        // DESIGN.md 4); particles that went 0/0 -> NaN (:92-94) would otherwise hold their whole wave on the
+        // reference-order path below for good.
+        if (!(__builtin_fabsf(posx) < __builtin_inff()) || !(__builtin_fabsf(posy) < __builtin_inff())) {
+            const float q = __builtin_nanf("");
+            return make_float4(q, q, q, q);
+        }
         return logic_texel_ref(p, x, y, st, pid, time);
     }
 
@@ -544,9 +557,11 @@ template <bool FAST, bool NOISE, bool TARGET>
 static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, bool bucketed, hipStream_t s)
 {
     int grid = grid_for(p.count, 8);
+    static const int grid_env = [] { const char *e = getenv("TH_STEP_GRID"); return e ? atoi(e) : 0; }();
+    if (grid_env > 0 && (int)((p.count + 255) / 256) >= grid_env) grid = grid_env;
 #define TH_GO(P2, DEC, BK) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, BK>), dim3(grid), dim3(256), 0, s, p)
     if (bucketed) {
-        grid = 2048;      // 8 workgroups per CU, 256 per XCD group (a multiple of 8 is required)
+        if (!(grid_env > 0 && grid == grid_env)) grid = 2048;      // 8 workgroups per CU, 256 per XCD group (a multiple of 8 is required)
         if (pow2) TH_GO(true, true, true); else TH_GO(false, true, true);
     } else if (pow2) { if (decoded) TH_GO(true, true, false); else TH_GO(true, false, false); }
     else { if (decoded) TH_GO(false, true, false); else TH_GO(false, false, false); }
@@ -677,17 +692,32 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
     }
 }
 
+// Launch shape of the fused passes: one 256-slot workgroup per 256 particles (no persistent grid).  A fused pass
+// is issue-bound and runs 5 workgroups per CU (82 VGPRs): a persistent grid of 2048 workgroups left the CUs
+// unevenly loaded at the end of the pass (1280 resident + a 768-workgroup second round); with one short
+// workgroup per 256 slots the dispatcher keeps every CU full until the last few (C3, exact: 0.098 -> 0.086 ms per
+// step, profiles/r2_a_grid_sweep.txt).  TH_FUSED_GRID overrides the workgroup count (experiments).
+static int fused_grid(uint32_t count, bool bucketed)
+{
+    static const int grid_env = [] { const char *e = getenv("TH_FUSED_GRID"); return e ? atoi(e) : 0; }();
+    const uint32_t blocks = (count + 255u) / 256u;
+    // bucketed: 8 XCD groups, group g = blockIdx % 8 sweeps its eighth of the slots
+    uint32_t grid = bucketed ? 8u * ((((count + 7u) >> 3) + 255u) / 256u) : blocks;
+    if (grid_env > 0 && blocks >= (uint32_t)grid_env) grid = (uint32_t)grid_env & ~7u;
+    return (int)(grid ? grid : 1u);
+}
+
 template <bool FAST, bool NOISE, bool TARGET>
 static void launch_fused_p2(const LogicParams &p, bool pow2, bool packed, hipStream_t s)
 {
     if (packed) {
-        const int pgrid = grid_for(p.count, 8);
+        const int pgrid = fused_grid(p.count, false);
         if (pow2) hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, true>), dim3(pgrid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, false>), dim3(pgrid), dim3(256), 0, s, p);
         return;
     }
     const bool bucketed = p.perm != nullptr;
-    const int grid = bucketed ? 2048 : grid_for(p.count, 8);
+    const int grid = fused_grid(p.count, bucketed);
 #define TH_GO(P2, BK) hipLaunchKernelGGL((logic_fused_kernel<FAST, NOISE, TARGET, P2, BK>), dim3(grid), dim3(256), 0, s, p)
     if (pow2) { if (bucketed) TH_GO(true, true); else TH_GO(true, false); }
     else { if (bucketed) TH_GO(false, true); else TH_GO(false, false); }
