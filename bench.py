@@ -165,15 +165,23 @@ def measure_pmc(extra_args, launch_len):
             for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            per_dispatch = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     cls = kernel_class(row.get("Kernel_Name", ""))
                     if cls:
-                        d = out_all.setdefault(cls, {})
-                        d.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                        if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and dur.get(row["Dispatch_Id"], 0) > 0:
-                            # summed over the 8 XCDs; cycles per ns = GHz (MI355X_MICROARCH.md, DVFS give-back)
-                            d.setdefault("clock_ghz", []).append(float(row["Counter_Value"]) / 8.0 / dur[row["Dispatch_Id"]])
+                        per_dispatch.setdefault((cls, row["Dispatch_Id"]), {})[row["Counter_Name"]] = float(row["Counter_Value"])
+            for (cls, did), cs in per_dispatch.items():
+                d = out_all.setdefault(cls, {})
+                for k, v in cs.items():
+                    d.setdefault(k, []).append(v)
+                if cs.get("GRBM_GUI_ACTIVE", 0) > 0:
+                    cyc = cs["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+                    if dur.get(did, 0) > 0:
+                        d.setdefault("clock_ghz", []).append(cyc / dur[did])          # cycles per ns
+                        d.setdefault("profiled_launch_ms", []).append(dur[did] * 1e-6)
+                    if "SQ_INSTS_VALU" in cs:      # issue slots used: 2 cycles per wave64 instruction on each of 1024 SIMDs
+                        d.setdefault("valu_issue_utilization", []).append(cs["SQ_INSTS_VALU"] * 2.0 / (cyc * 1024.0))
         except (subprocess.SubprocessError, OSError) as e:
             notes.append("pass %s failed: %s" % ("+".join(group), type(e).__name__))
         finally:
@@ -459,12 +467,14 @@ def main():
             v = counters["SQ_INSTS_VALU"]
             e["valu"] = {"wave_insts_per_launch": v, "per_wave_step": v / (particles_rank / 64.0 * steps_in_launch),
                          "achieved": v / launch_s, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": v / launch_s / VALU_PEAK}
-            if "clock_ghz" in counters:      # under the profiler (launches run ~3 % slower there)
-                ghz = counters["clock_ghz"]
-                e["valu"]["clock_ghz"] = ghz
-                e["valu"]["frac_at_held_clock"] = v / launch_s / (256 * 4 * ghz * 1e9 / 2)
+            if "clock_ghz" in counters:      # under the profiler (launches run a few % slower there)
+                e["valu"]["clock_ghz"] = counters["clock_ghz"]
+                e["valu"]["profiled_launch_ms"] = counters.get("profiled_launch_ms")
+                e["valu"]["issue_utilization_at_held_clock"] = counters.get("valu_issue_utilization")
                 e["valu"]["note"] = "peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction; clock_ghz = GRBM_GUI_ACTIVE / 8 / launch " \
-                                    "duration in the PMC child run: what the chip held under this load"
+                                    "duration and issue_utilization = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), both per " \
+                                    "dispatch in the PMC child run: the clock the chip held under this load and the share of its issue " \
+                                    "slots the launch used at that clock"
         if counters and "SQ_LDS_IDX_ACTIVE" in counters and counters["SQ_LDS_IDX_ACTIVE"] > 0:
             e["lds"] = {"bank_conflict_share": counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]}
         return e

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 2
+#define TH_ABI_VERSION 3
 
 typedef int32_t th_status;
 enum {
@@ -261,6 +261,16 @@ th_status th_timer_stop(th_context *ctx, float *elapsed_ms);           /* synchr
  * number of launches since the last read, and resets. */
 th_status th_kernel_timing(th_context *ctx, int32_t enable);
 th_status th_kernel_timing_read(th_context *ctx, float *mean_ms, int32_t *launches);
+/* Slot layout of the ring (build-defined, invisible in every result): how many ring buffers are held in a
+ * tile-sorted slot order, integrator passes since the last sort, and the flow taps since then that left the
+ * LDS-staged window of their workgroup (served by the global gather instead).  Synchronises. */
+typedef struct th_slot_order_info {
+    int32_t sorted_buffers;
+    int32_t steps_since_sort;
+    uint64_t window_misses;
+    uint64_t sorts;              /* sorts so far in this context's life */
+} th_slot_order_info;
+th_status th_slot_order(th_context *ctx, th_slot_order_info *out);
 
 #ifdef __cplusplus
 }

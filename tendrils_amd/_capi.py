@@ -71,6 +71,11 @@ class Counters(C.Structure):
                 ("sum_speed", C.c_double), ("max_speed", C.c_double)]
 
 
+class SlotOrderInfo(C.Structure):
+    _fields_ = [("sorted_buffers", C.c_int32), ("steps_since_sort", C.c_int32), ("window_misses", C.c_uint64),
+                ("sorts", C.c_uint64)]
+
+
 _ctx = C.c_void_p
 _fp = C.POINTER(C.c_float)
 
@@ -121,6 +126,7 @@ PROTOTYPES = {
     "th_timer_stop": (C.c_int32, [_ctx, C.POINTER(C.c_float)]),
     "th_kernel_timing": (C.c_int32, [_ctx, C.c_int32]),
     "th_kernel_timing_read": (C.c_int32, [_ctx, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "th_slot_order": (C.c_int32, [_ctx, C.POINTER(SlotOrderInfo)]),
 }
 
 _NO_STATUS = {"th_abi_version", "th_last_error"}

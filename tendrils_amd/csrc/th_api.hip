@@ -101,8 +101,7 @@ struct GraphEntry {
     int32_t n = 0, mode = 0;
     uint32_t flags = 0;
     std::vector<float4 *> ring;          // ring order at capture time
-    const uint32_t *perm = nullptr;
-    th::LogicParams key{};               // launch parameters with time zeroed
+    th::LogicParams key{};               // launch parameters (the fields same_key() compares)
     hipGraphExec_t exec = nullptr;
     float *times_dev = nullptr, *times_host = nullptr;
     hipEvent_t copied = nullptr;         // times_host -> times_dev copy of the last replay
@@ -147,15 +146,29 @@ struct th_context {
     size_t kt_used = 0;
     std::vector<GraphEntry> graphs;      // th_step_n cache
 
-    // XCD-affine bucketing of the slot order (th_kernels.hip "Bucketing"); lazily allocated
-    uint32_t *perm = nullptr, *perm_alt = nullptr, *src_slot = nullptr;
-    float4 *spare = nullptr;             // spare state buffer the permutes ping-pong through
-    uint32_t *bucket_mem = nullptr;      // hist[kBuckets+1] | cursor[kBuckets+3]
-    bool bucketed = false;               // ring buffers currently in bucket (slot) order
-    bool bucket_wanted = false;          // last periodic decision (histogram of the interior share)
-    bool bucket_evaluated = false;
-    int steps_since_bucket = 0;
+    // Tile-sorted slot orders (th_kernels.hip "Tile-sorted slot order"); lazily allocated.  Every ring buffer is in
+    // texel order or in one of `orders` (a step that re-sorts writes its output in a new order while its input keeps
+    // the old one, so two orders can be alive at a time).
+    struct SlotOrder {
+        uint32_t *perm = nullptr;            // slot -> particle id
+        th::TileChunk *chunks = nullptr;     // chunk table
+        th::ChunkRecord *records = nullptr;  // per chunk: tiles of the next positions (written by a COUNT pass)
+        uint32_t *nchunks = nullptr;
+        th::TileGeom geom{};                 // key function the order was sorted with
+        int32_t fw = 0, fh = 0;
+        int refs = 0;                        // ring buffers stored in this order
+    };
+    std::vector<SlotOrder> orders;
+    std::vector<std::pair<float4 *, int>> buf_order;   // ring buffers held in a sorted order (absent = texel order)
+    float4 *spare = nullptr;             // spare state buffer (ensure_identity moves through it)
+    uint32_t *tile_mem = nullptr;        // hist | cursor (kSortReplicas x kMaxTileBins words each) | misses
+    uint32_t max_chunks = 0;
+    int steps_since_sort = 0;
+    unsigned long long sorts = 0;
     long long total_steps = 0, hold_texel_order_until = 0;   // texel-order consumers (draw) keep the layout off for a period
+    uint32_t *miss_host = nullptr;       // pinned: window misses since the last sort, as of some recent launch
+    // a COUNT pass has histogrammed the tiles of the state it wrote: valid for a SCATTER pass that reads exactly that
+    struct { const float4 *buf = nullptr; int order = -1; th::TileGeom geom{}; long long at_step = -1; } counted;
 
     size_t texels() const { return (size_t)cfg.width * cfg.height; }
     size_t state_bytes() const { return texels() * (packed ? sizeof(uint2) : sizeof(float4)); }
@@ -256,14 +269,11 @@ void clear_graphs(th_context *c)
     c->graphs.clear();
 }
 
-constexpr size_t kBucketWords = 2 * th::kBuckets + 4;
-
 // ---- slot order management ---------------------------------------------------------------------
-// Policy.  Bucketing pays when the random flow gather misses L2: the decoded plane does not fit
-// one XCD's 4 MiB L2, there are enough particles to amortise the sort, and at most 50 % of them are in
-// the edge class (outside the view / inert), read from the sort's own histogram once per period
-// (measurements: profiles/r1_c_bucketing.txt).  TH_BUCKET=0/1 forces the layout off/on; TH_REBUCKET_STEPS sets
-// the period (particles drift at most speedLimit per step).
+// Policy.  Sorting the slots by flow tile pays when the random flow gather is what a step waits for: the decoded
+// plane does not fit one XCD's 4 MiB L2 and there are enough particles to amortise the sort (measurements:
+// profiles/r1_c_bucketing.txt, r2_b_*).  TH_BUCKET=0/1 forces the layout off/on (the parity suite reruns under 1);
+// TH_RESORT_STEPS / TH_REBUCKET_STEPS set the re-sort period of single-step / fused launches.
 int bucket_policy()
 {
     static const int v = [] { const char *e = getenv("TH_BUCKET"); return e ? atoi(e) : -1; }();
@@ -274,71 +284,131 @@ int rebucket_period()
     static const int v = [] { const char *e = getenv("TH_REBUCKET_STEPS"); int n = e ? atoi(e) : 256; return n > 0 ? n : 256; }();
     return v;
 }
-bool bucketing_possible(const th_context *c)
+int resort_period()
+{
+    static const int v = [] { const char *e = getenv("TH_RESORT_STEPS"); int n = e ? atoi(e) : 8; return n > 0 ? n : 8; }();
+    return v;
+}
+constexpr int kTileShift = 5;            // 32 x 32 texel tiles (th_kernels.hip kTile)
+constexpr size_t kTileWords = 2 * (size_t)th::kSortReplicas * th::kMaxTileBins;   // histogram + cursors, all copies
+uint32_t tile_count(const th_context *c, uint32_t *tiles_x)
+{
+    const uint32_t tx = ((uint32_t)c->fw + (1u << kTileShift) - 1u) >> kTileShift;
+    const uint32_t ty = ((uint32_t)c->fh + (1u << kTileShift) - 1u) >> kTileShift;
+    if (tiles_x) *tiles_x = tx;
+    return tx * ty;
+}
+bool sorting_possible(const th_context *c)
 {
     if (c->packed) return false;                                 // packed ring: texel order only
     const size_t flow_texels = (size_t)c->fw * c->fh;
     if (c->texels() < 2 * flow_texels) return false;           // the decoded plane is not used at all
+    if ((size_t)tile_count(c, nullptr) + 1 > th::kMaxTileBins) return false;
     if (bucket_policy() == 0) return false;
     if (bucket_policy() == 1) return true;
     return c->texels() >= ((size_t)1 << 20) && flow_texels * sizeof(float2) > ((size_t)3 << 20);
 }
 
-th_status ensure_identity(th_context *c)
+th::TileGeom tile_geom(const th_context *c, const th_logic_uniforms &u)
 {
-    if (!c->bucketed) return TH_OK;
-    for (float4 *&b : c->ring) {
-        th::launch_unpermute_state(c->spare, b, c->perm, (uint32_t)c->texels(), c->stream);
-        float4 *t = b; b = c->spare; c->spare = t;
-    }
-    TH_HIP(hipGetLastError());
-    c->bucketed = false;
+    th::TileGeom g{};
+    g.view_x = u.viewSize[0]; g.view_y = u.viewSize[1];
+    g.half_fw = 0.5f * (float)c->fw; g.half_fh = 0.5f * (float)c->fh;
+    g.fwm1 = (float)(c->fw - 1); g.fhm1 = (float)(c->fh - 1);
+    g.ntiles = tile_count(c, &g.tiles_x);
+    return g;
+}
+bool same_geom(const th::TileGeom &a, const th::TileGeom &b) { return memcmp(&a, &b, sizeof a) == 0; }
+
+int order_of(const th_context *c, const float4 *buf)
+{
+    for (const auto &e : c->buf_order) if (e.first == buf) return e.second;
+    return -1;
+}
+void set_order(th_context *c, float4 *buf, int order)
+{
+    for (size_t k = 0; k < c->buf_order.size(); ++k)
+        if (c->buf_order[k].first == buf) {
+            --c->orders[(size_t)c->buf_order[k].second].refs;
+            c->buf_order.erase(c->buf_order.begin() + (long)k);
+            break;
+        }
+    if (order >= 0) { c->buf_order.emplace_back(buf, order); ++c->orders[(size_t)order].refs; }
+}
+bool any_sorted(const th_context *c) { return !c->buf_order.empty(); }
+
+th_status sort_storage(th_context *c)
+{
+    if (c->tile_mem) return TH_OK;
+    const size_t n = c->texels();
+    TH_HIP(hipMalloc((void **)&c->spare, n * sizeof(float4)));
+    TH_HIP(hipMalloc((void **)&c->tile_mem, (kTileWords + 8) * sizeof(uint32_t)));
+    TH_HIP(hipMemsetAsync(c->tile_mem, 0, (kTileWords + 8) * sizeof(uint32_t), c->stream));
+    TH_HIP(hipHostMalloc((void **)&c->miss_host, 2 * sizeof(uint32_t)));
+    c->miss_host[0] = c->miss_host[1] = 0;
+    c->max_chunks = (uint32_t)(n / th::kTileChunk) + th::kMaxTileBins + 8u;
     return TH_OK;
 }
 
-// Once per period: histogram the CURRENT state (ring[0]) by flow region, decide, and (re)sort the
-// slots of every ring buffer when bucketing is on.
-th_status rebucket(th_context *c, const th_logic_uniforms &u)
+// an order no ring buffer is stored in (allocates the first few)
+th_status free_order(th_context *c, int *out)
 {
-    const uint32_t n = (uint32_t)c->texels();
-    if (!c->spare) {
-        TH_HIP(hipMalloc((void **)&c->spare, (size_t)n * sizeof(float4)));
-        TH_HIP(hipMalloc((void **)&c->perm, (size_t)n * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->perm_alt, (size_t)n * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->src_slot, (size_t)n * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->bucket_mem, kBucketWords * sizeof(uint32_t)));
-        TH_HIP(hipMemsetAsync(c->bucket_mem, 0, kBucketWords * sizeof(uint32_t), c->stream));
+    for (size_t k = 0; k < c->orders.size(); ++k) if (c->orders[k].refs == 0) { *out = (int)k; return TH_OK; }
+    th_context::SlotOrder o;
+    TH_HIP(hipMalloc((void **)&o.perm, c->texels() * sizeof(uint32_t)));
+    TH_HIP(hipMalloc((void **)&o.chunks, (size_t)c->max_chunks * sizeof(th::TileChunk)));
+    TH_HIP(hipMalloc((void **)&o.records, (size_t)c->max_chunks * sizeof(th::ChunkRecord)));
+    TH_HIP(hipMalloc((void **)&o.nchunks, sizeof(uint32_t)));
+    c->orders.push_back(o);
+    *out = (int)c->orders.size() - 1;
+    return TH_OK;
+}
+
+// every ring buffer back to texel order (reports whether anything was launched)
+th_status ensure_identity(th_context *c, bool *launched = nullptr)
+{
+    if (launched) *launched = false;
+    c->counted.buf = nullptr;
+    if (!any_sorted(c)) return TH_OK;
+    clear_graphs(c);                       // captured sequences name the ring buffers that are swapped below
+    for (float4 *&b : c->ring) {
+        const int o = order_of(c, b);
+        if (o < 0) continue;
+        th::launch_unpermute_state(c->spare, b, c->orders[(size_t)o].perm, (uint32_t)c->texels(), c->stream);
+        set_order(c, b, -1);
+        float4 *t = b; b = c->spare; c->spare = t;
+        if (launched) *launched = true;
     }
-    th::BucketParams b{};
-    b.state = c->ring[0];
-    b.count = n;
-    b.view_y = u.viewSize[1];
-    b.fhf = (float)c->fh; b.fhm1 = (float)(c->fh - 1); b.fh = (uint32_t)c->fh;
-    b.hist = c->bucket_mem; b.cursor = c->bucket_mem + th::kBuckets + 1;
-    b.src_slot = c->src_slot;
-    th::launch_bucket_hist(b, c->stream);
-    c->steps_since_bucket = 0;
-    if (bucket_policy() != 1) {
-        // the sort's own histogram tells how many particles sample the interior of the field; particles
-        // outside the view all tap the two edge rows, which are cache-hot in any slot order
-        uint32_t edge = 0;
-        TH_HIP(hipMemcpyAsync(&edge, c->bucket_mem + th::kBuckets, sizeof edge, hipMemcpyDeviceToHost, c->stream));
-        TH_HIP(hipStreamSynchronize(c->stream));
-        c->bucket_wanted = (double)edge <= 0.50 * (double)n;
-        if (!c->bucket_wanted) {
-            TH_HIP(hipMemsetAsync(c->bucket_mem, 0, (th::kBuckets + 1) * sizeof(uint32_t), c->stream));
-            return ensure_identity(c);
-        }
-    } else c->bucket_wanted = true;
-    th::launch_bucket_scatter(b, c->stream);
-    for (float4 *&buf : c->ring) {
-        th::launch_permute_state(c->spare, buf, c->src_slot, n, c->stream);
-        float4 *t = buf; buf = c->spare; c->spare = t;
-    }
-    th::launch_permute_ids(c->perm_alt, c->bucketed ? c->perm : nullptr, c->src_slot, n, c->stream);
-    uint32_t *t = c->perm; c->perm = c->perm_alt; c->perm_alt = t;
     TH_HIP(hipGetLastError());
-    c->bucketed = true;
+    return TH_OK;
+}
+
+// Count the tiles of `state` (any slot order) and lay out a new order for it: tile starts, rank cursors, chunk table.
+// The slots themselves are assigned by the kernel that moves the state (tile_scatter_kernel or a SCATTER step).
+th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, const uint32_t *perm_in, int *order,
+                     th::TileSortParams *params, bool have_hist = false)
+{
+    if (th_status s = sort_storage(c)) return s;
+    if (th_status s = free_order(c, order)) return s;
+    th_context::SlotOrder &o = c->orders[(size_t)*order];
+    o.geom = g; o.fw = c->fw; o.fh = c->fh;
+    th::TileSortParams b{};
+    b.state = state; b.perm_in = perm_in; b.count = (uint32_t)c->texels();
+    b.g = g;
+    b.hist = c->tile_mem; b.cursor = c->tile_mem + kTileWords / 2;
+    b.chunks = o.chunks; b.nchunks = o.nchunks;
+    b.perm_out = o.perm;
+    if (!have_hist) {          // (a COUNT pass whose histogram was never used may have left counts behind)
+        TH_HIP(hipMemsetAsync(b.hist, 0, kTileWords / 2 * sizeof(uint32_t), c->stream));
+        th::launch_tile_hist(b, c->stream);
+    }
+    th::launch_tile_scan(b, c->stream);
+    TH_HIP(hipMemsetAsync(c->tile_mem + kTileWords, 0, sizeof(uint32_t), c->stream));    // window misses
+    TH_HIP(hipGetLastError());
+    c->steps_since_sort = 0;
+    ++c->sorts;
+    c->counted.buf = nullptr;
+    if (params) *params = b;
     return TH_OK;
 }
 
@@ -441,8 +511,9 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
-    (void)hipFree(c->perm); (void)hipFree(c->perm_alt); (void)hipFree(c->src_slot); (void)hipFree(c->spare);
-    (void)hipFree(c->bucket_mem);
+    for (th_context::SlotOrder &o : c->orders) { (void)hipFree(o.perm); (void)hipFree(o.chunks); (void)hipFree(o.records); (void)hipFree(o.nchunks); }
+    (void)hipFree(c->spare); (void)hipFree(c->tile_mem);
+    if (c->miss_host) (void)hipHostFree(c->miss_host);
     for (hipEvent_t e : c->kt_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -597,6 +668,7 @@ th_status th_targets_clear(th_context *c)
 struct StepPlan {
     th::LogicParams p{};         // everything except in / out / perm / time_dev
     bool noise = false, use_targets = false, pow2 = false, decoded = false, generic = false;
+    bool may_sort = false;       // this pass may run on (and produce) tile-sorted slots
 };
 
 // Pick the kernel variant and bring the slot layout up to date.  `u.time` must be the time of
@@ -657,17 +729,23 @@ static th_status plan_step(th_context *c, const th_logic_uniforms &u, int32_t ta
     const size_t flow_texels = (size_t)c->fw * c->fh;
     plan.decoded = !plan.generic && c->texels() >= 2 * flow_texels;
 
-    // Slot layout: bucketed by flow region (XCD-affine launch) or texel order.  Decided on the
-    // CURRENT state, i.e. before the ring rotates.
-    const bool may_bucket = plan.decoded && target == TH_TARGET_RING && bucketing_possible(c) &&
-                            c->total_steps >= c->hold_texel_order_until;
-    if (may_bucket) {
-        if (!c->bucket_evaluated || c->steps_since_bucket >= rebucket_period() || (c->bucket_wanted && !c->bucketed)) {
-            if (th_status s = rebucket(c, u)) return s;
-            c->bucket_evaluated = true;
-        }
-    } else if (th_status s = ensure_identity(c)) return s;
+    // Slot layout (texel order or a tile-sorted order): only ring -> ring passes of the specialised f32 kernels run on
+    // sorted slots; the callers bring the layout up to date.
+    plan.may_sort = plan.decoded && target == TH_TARGET_RING && sorting_possible(c) &&
+                    c->total_steps >= c->hold_texel_order_until;
     return TH_OK;
+}
+
+// what a captured th_step_n sequence depends on besides the ring order and the kernel flags (`time` excluded: it lives in
+// device memory); an explicit field list - the struct has padding and fields the captured launches never read
+static bool same_key(const th::LogicParams &a, const th::LogicParams &b)
+{
+    th_logic_uniforms ua = a.u, ub = b.u;
+    ua.time = ub.time = 0.0f;
+    return a.flow == b.flow && a.flow_dec == b.flow_dec && a.targets == b.targets && a.lut == b.lut &&
+           a.count == b.count && a.width == b.width && a.log2w == b.log2w && a.row0 == b.row0 &&
+           a.wf == b.wf && a.hf == b.hf && a.fw == b.fw && a.fh == b.fh &&
+           memcmp(&ua, &ub, sizeof ua) == 0 && a.s2_cap == b.s2_cap && a.pos_bound == b.pos_bound;
 }
 
 static uint32_t plan_flags(const StepPlan &plan)
@@ -676,10 +754,23 @@ static uint32_t plan_flags(const StepPlan &plan)
            (plan.generic ? 16u : 0u);
 }
 
+static th_status timing_events(th_context *c, hipEvent_t *k0, hipEvent_t *k1)
+{
+    if (c->kt_used + 2 > c->kt_events.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        TH_HIP(hipEventCreate(&a)); TH_HIP(hipEventCreate(&b));
+        c->kt_events.push_back(a); c->kt_events.push_back(b);
+    }
+    *k0 = c->kt_events[c->kt_used]; *k1 = c->kt_events[c->kt_used + 1];
+    c->kt_used += 2;
+    return TH_OK;
+}
+
 // Rotate / resolve the render target and launch (flow decode +) the integrator.  Launches only:
 // safe inside a stream capture.  `time_dev` (optional) overrides plan.p.u.time on the device.
+// `sorted`: the pass may read and write tile-sorted slots (else every ring buffer is in texel order already).
 static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t target, float time, const float *time_dev,
-                              bool timing)
+                              bool timing, bool sorted = false)
 {
     th::LogicParams p = plan.p;
     float4 *out = nullptr;
@@ -694,30 +785,73 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     }
     p.in = in;
     p.out = rt;
-    p.perm = c->bucketed ? c->perm : nullptr;
     p.u.time = time;
     p.time_dev = time_dev;
 
     if (plan.decoded)
         th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, time, time_dev, p.u.flowDecay, c->stream);
+
+    // Sorted slots.  The input keeps its order; the output is written either at the same slots or - every
+    // resort_period() steps, and when the input is not sorted yet or was sorted for another view / field shape - at
+    // the slots of a new sort keyed on the input positions (counted just before the launch).
+    int in_order = sorted ? order_of(c, in) : -1, out_order = -1;
+    bool use_sorted = false, scatter = false, count = false;
+    if (sorted) {
+        const th::TileGeom g = tile_geom(c, p.u);
+        const bool stale = in_order >= 0 && (!same_geom(c->orders[(size_t)in_order].geom, g) ||
+                                             c->orders[(size_t)in_order].fw != c->fw || c->orders[(size_t)in_order].fh != c->fh);
+        if (stale) {                       // the chunk table no longer describes the field: start over from texel order
+            if (th_status s = ensure_identity(c)) return s;
+            in = c->ring[1]; out = rt = c->ring[0];
+            p.in = in; p.out = rt;
+            in_order = -1;
+        }
+        scatter = in_order < 0 || c->steps_since_sort >= resort_period();
+        use_sorted = true;
+        p.geom = g;
+        if (in_order >= 0) {
+            const th_context::SlotOrder &o = c->orders[(size_t)in_order];
+            p.perm = o.perm; p.chunks = o.chunks; p.nchunks = o.nchunks; p.records = o.records;
+        }
+        if (scatter) {
+            // counted by the pass that wrote `in`?  Then the histogram is complete and every chunk has its table.
+            const bool counted = in_order >= 0 && c->counted.buf == in && c->counted.order == in_order &&
+                                 same_geom(c->counted.geom, g) && c->counted.at_step == c->total_steps;
+            set_order(c, out, -1);         // the output buffer's old content (and order) dies here
+            th::TileSortParams b;
+            if (th_status s = begin_sort(c, g, in, in_order >= 0 ? c->orders[(size_t)in_order].perm : nullptr, &out_order, &b, counted)) return s;
+            p.cursor = b.cursor; p.perm_out = b.perm_out;
+            p.use_records = counted ? 1u : 0u;
+        } else {
+            out_order = in_order;
+            count = c->steps_since_sort + 1 >= resort_period();      // the next pass will re-sort: count for it
+            if (count) {
+                if (th_status s = sort_storage(c)) return s;
+                p.hist = c->tile_mem;
+                TH_HIP(hipMemsetAsync(p.hist, 0, kTileWords / 2 * sizeof(uint32_t), c->stream));
+            }
+        }
+        p.misses = c->tile_mem + kTileWords;
+    }
+
     hipEvent_t k0 = nullptr, k1 = nullptr;
     if (timing && c->kernel_timing) {
-        if (c->kt_used + 2 > c->kt_events.size()) {
-            hipEvent_t a = nullptr, b = nullptr;
-            TH_HIP(hipEventCreate(&a)); TH_HIP(hipEventCreate(&b));
-            c->kt_events.push_back(a); c->kt_events.push_back(b);
-        }
-        k0 = c->kt_events[c->kt_used]; k1 = c->kt_events[c->kt_used + 1];
-        c->kt_used += 2;
+        if (th_status s = timing_events(c, &k0, &k1)) return s;
         TH_HIP(hipEventRecord(k0, c->stream));
     }
-    th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel,
-                     c->stream);
+    if (use_sorted)
+        th::launch_logic_sorted(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, in_order >= 0, scatter, count, c->max_chunks, c->stream);
+    else
+        th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel,
+                         c->stream);
     if (k1) TH_HIP(hipEventRecord(k1, c->stream));
     TH_HIP(hipGetLastError());
+    if (target == TH_TARGET_RING || (target >= 0 && target < (int32_t)c->ring.size())) set_order(c, out, out_order);
     if (c->packed && !packed_kernel)
         if (th_status s = commit_target(c, out, rt)) return s;
-    ++c->steps_since_bucket; ++c->total_steps;
+    ++c->steps_since_sort; ++c->total_steps;
+    if (count) { c->counted.buf = out; c->counted.order = out_order; c->counted.geom = p.geom; c->counted.at_step = c->total_steps; }
+    else c->counted.buf = nullptr;
     return TH_OK;
 }
 
@@ -729,7 +863,9 @@ th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
     TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
     StepPlan plan;
     if (th_status s = plan_step(c, *u, target, plan)) return s;
-    return enqueue_step(c, plan, target, u->time, nullptr, true);
+    const bool sorted = plan.may_sort && !plan.generic && !c->packed;
+    if (!sorted) if (th_status s = ensure_identity(c)) return s;
+    return enqueue_step(c, plan, target, u->time, nullptr, true, sorted);
 }
 
 // n fixed-step Tendrils.step() calls.  The launch sequence (2 kernels per step) is captured once into
@@ -759,42 +895,63 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     // both ring formats.  TH_FUSE=0 turns it off (the tests compare both paths).
     static const bool fuse_on = [] { const char *e = getenv("TH_FUSE"); return !e || atoi(e) != 0; }();
     if (fuse_on && n >= 2 && c->ring.size() == 2 && !plan.generic) {
-        {   // (the slot layout was brought up to date by plan_step above; the re-sort period is approximate)
+        // Slot layout of the fused passes: the newest state (ring[0]) may be in a tile-sorted order; both outputs of a
+        // pass keep the slots of its input.  (Re)sorted every rebucket_period() steps by a plain move into the other
+        // buffer, whose content (state n-1 of the previous call) the pass overwrites anyway.
+        if (plan.may_sort && !c->packed) {
+            const th::TileGeom g = tile_geom(c, plan.p.u);
+            int o = order_of(c, c->ring[0]);
+            const bool stale = o >= 0 && (!same_geom(c->orders[(size_t)o].geom, g) || c->orders[(size_t)o].fw != c->fw ||
+                                          c->orders[(size_t)o].fh != c->fh);
+            if (o < 0 || stale || c->steps_since_sort >= rebucket_period()) {
+                float4 *cur = c->ring[0], *other = c->ring[1];
+                set_order(c, other, -1);
+                int fresh = -1;
+                th::TileSortParams b;
+                if (th_status s = begin_sort(c, g, cur, o >= 0 ? c->orders[(size_t)o].perm : nullptr, &fresh, &b)) return s;
+                b.state_out = other;
+                th::launch_tile_scatter(b, c->stream);
+                TH_HIP(hipGetLastError());
+                set_order(c, other, fresh);
+                set_order(c, cur, -1);                 // (its content is dead: the sorted copy is the newest state now)
+                c->ring[0] = other; c->ring[1] = cur;
+            }
+        } else if (th_status s = ensure_identity(c)) return s;
+        {
             int32_t done = 0;
             while (done < n) {
                 const int32_t m = std::min<int32_t>(n - done, (int32_t)th::kMaxFusedSteps);
                 th::LogicParams p = plan.p;
                 float4 *cur = c->ring[0], *other = c->ring[1];
+                const int order = order_of(c, cur);
                 p.in = cur;
                 // a lane only ever touches its own texel, so one of the two outputs may overwrite the input;
                 // after m rotations of [cur, other]: m even -> [cur, other], m odd -> [other, cur]
                 p.out = (m & 1) ? other : cur;             // state m     (ends up in buffers[0])
                 p.out_prev = (m & 1) ? cur : other;        // state m - 1 (ends up in buffers[1])
-                p.perm = c->bucketed ? c->perm : nullptr;
+                p.perm = order >= 0 ? c->orders[(size_t)order].perm : nullptr;
                 p.nsteps = (uint32_t)m;
                 for (int32_t k = 0; k < m; ++k) p.times[k] = times[(size_t)(done + k)];
                 hipEvent_t k0 = nullptr, k1 = nullptr;
                 if (c->kernel_timing) {
-                    if (c->kt_used + 2 > c->kt_events.size()) {
-                        hipEvent_t ea = nullptr, eb = nullptr;
-                        TH_HIP(hipEventCreate(&ea)); TH_HIP(hipEventCreate(&eb));
-                        c->kt_events.push_back(ea); c->kt_events.push_back(eb);
-                    }
-                    k0 = c->kt_events[c->kt_used]; k1 = c->kt_events[c->kt_used + 1];
-                    c->kt_used += 2;
+                    if (th_status s = timing_events(c, &k0, &k1)) return s;
                     TH_HIP(hipEventRecord(k0, c->stream));
                 }
                 th::launch_logic_fused(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, c->packed, c->stream);
                 if (k1) TH_HIP(hipEventRecord(k1, c->stream));
                 TH_HIP(hipGetLastError());
+                set_order(c, other, order);                // both outputs sit at the input's slots
+                c->counted.buf = nullptr;
                 if (m & 1) { c->ring[0] = other; c->ring[1] = cur; }
-                c->steps_since_bucket += m; c->total_steps += m;
+                c->steps_since_sort += m; c->total_steps += m;
                 done += m;
             }
             return TH_OK;
         }
     }
 
+    // everything below runs in texel order
+    if (th_status s = ensure_identity(c)) return s;
     static const bool graphs_on = [] { const char *e = getenv("TH_GRAPH"); return !e || atoi(e) != 0; }();
     if (!graphs_on || n < 2 || (c->packed && plan.generic)) {
         for (int32_t k = 0; k < n; ++k) {
@@ -809,18 +966,17 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     key.u.time = 0.0f;
     GraphEntry *hit = nullptr;
     for (GraphEntry &g : c->graphs)
-        if (g.n == n && g.mode == c->cfg.mode && g.ring == c->ring && g.perm == (c->bucketed ? c->perm : nullptr) &&
-            g.flags == plan_flags(plan) && memcmp(&g.key, &key, sizeof key) == 0) { hit = &g; break; }
+        if (g.n == n && g.mode == c->cfg.mode && g.ring == c->ring && g.flags == plan_flags(plan) && same_key(g.key, key)) { hit = &g; break; }
     if (!hit) {
         if (c->graphs.size() >= 8) { destroy_graph(c->graphs.front()); c->graphs.erase(c->graphs.begin()); }
         GraphEntry g;
-        g.n = n; g.mode = c->cfg.mode; g.ring = c->ring; g.perm = c->bucketed ? c->perm : nullptr;
+        g.n = n; g.mode = c->cfg.mode; g.ring = c->ring;
         g.flags = plan_flags(plan); g.key = key;
         TH_HIP(hipMalloc((void **)&g.times_dev, (size_t)n * sizeof(float)));
         TH_HIP(hipHostMalloc((void **)&g.times_host, (size_t)n * sizeof(float)));
         TH_HIP(hipEventCreate(&g.copied));
         const std::vector<float4 *> ring_before = c->ring;
-        const int since_before = c->steps_since_bucket;
+        const int since_before = c->steps_since_sort;
         const long long total_before = c->total_steps;
         hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
         th_status st = TH_OK;
@@ -833,7 +989,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
             if (graph) (void)hipGraphDestroy(graph);
         }
         c->ring = ring_before;                         // the capture only recorded; nothing ran yet
-        c->steps_since_bucket = since_before;
+        c->steps_since_sort = since_before;
         c->total_steps = total_before;
         if (e != hipSuccess || st != TH_OK) {
             destroy_graph(g);
@@ -852,7 +1008,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
         c->ring.pop_back();
         c->ring.insert(c->ring.begin(), last);
     }
-    c->steps_since_bucket += n; c->total_steps += n;
+    c->steps_since_sort += n; c->total_steps += n;
     // times_host must stay untouched until the copy has run; a later replay of this entry waits here
     TH_HIP(hipEventRecord(hit->copied, c->stream));
     return TH_OK;
@@ -1298,7 +1454,10 @@ th_status th_state_device_ptr(th_context *c, int32_t buffer, void **dptr)
 {
     TH_REQUIRE(c && dptr, "null argument");
     if (th_status s = use(c)) return s;
-    if (th_status s = ensure_identity(c)) return s;      // the pointer is only meaningful in texel order
+    bool moved = false;
+    if (th_status s = ensure_identity(c, &moved)) return s;      // the pointer is only meaningful in texel order
+    // the caller reads the buffer on a stream of its own: what was just enqueued on the context's stream must be done
+    if (moved) TH_HIP(hipStreamSynchronize(c->stream));
     TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
     *dptr = c->ring[buffer];
     return TH_OK;
@@ -1343,6 +1502,23 @@ th_status th_kernel_timing_read(th_context *c, float *mean_ms, int32_t *launches
     *launches = (int32_t)(c->kt_used / 2);
     *mean_ms = *launches ? (float)(sum / *launches) : 0.0f;
     c->kt_used = 0;
+    return TH_OK;
+}
+
+th_status th_slot_order(th_context *c, th_slot_order_info *out)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(out, "null output");
+    *out = th_slot_order_info{};
+    out->sorted_buffers = (int32_t)c->buf_order.size();
+    out->steps_since_sort = c->steps_since_sort;
+    out->sorts = c->sorts;
+    if (c->tile_mem) {
+        uint32_t m = 0;
+        TH_HIP(hipMemcpyAsync(&m, c->tile_mem + kTileWords, sizeof m, hipMemcpyDeviceToHost, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));
+        out->window_misses = m;
+    }
     return TH_OK;
 }
 

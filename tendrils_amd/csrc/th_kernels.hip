@@ -19,6 +19,7 @@ namespace th {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 static int grid_for(size_t n, int blocks_per_cu)
 {
@@ -341,9 +342,19 @@ TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2,
 //   DECODED the flow tap reads the per-step decoded float2 plane (8 B) instead of RGBA32F (16 B)
 // ---------------------------------------------------------------------------
 // One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false>
+// Workgroup-local copy of a window of the decoded flow plane (logic_sorted_kernel): kTileLW x kTileLW texels around
+// one kTile x kTile tile of the field, staged in LDS.  A tap inside the window is a ds_read_b64; a tap outside it
+// (the particle has drifted further than the halo since the last sort) is the ordinary global gather.
+constexpr int kTileShift = 5, kTile = 1 << kTileShift, kTileHalo = 8, kTileLW = kTile + 2 * kTileHalo;
+struct FlowWindow {
+    const __attribute__((address_space(3))) v2f *lds;
+    int x0, y0;              // flow texel held by lds[0]; rows/columns beyond the field edge hold the clamped texel
+    uint32_t misses;         // taps of this lane that left the window
+};
+
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false, bool WINDOW = false>
 TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
-                      const HashTables *tabs = nullptr)
+                      const HashTables *tabs = nullptr, FlowWindow *win = nullptr)
 {
     const th_logic_uniforms &u = p.u;
     float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
@@ -394,7 +405,22 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     const int texel = ty * p.fw + tx;
     float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
     float4 ft;
-    if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
+    if constexpr (WINDOW) {
+        // (the LDS read is unconditional and the gather a separate masked load: selecting between an LDS and a global
+        // ADDRESS would turn both into one flat_load, which waits for every outstanding load of the wave)
+        const unsigned lx = (unsigned)(tx - win->x0), ly = (unsigned)(ty - win->y0);
+        const bool inside = lx < (unsigned)kTileLW && ly < (unsigned)kTileLW;
+        const v2f w = win->lds[inside ? ly * kTileLW + lx : 0u];
+        ffx = w.x; ffy = w.y;
+        if (__builtin_expect(!inside, 0)) {
+            const float2 d = p.flow_dec[texel];
+            ffx = d.x; ffy = d.y;
+            // complete the gather INSIDE the branch: a load still pending at the join would make every wave - also the
+            // ones that skipped the branch - wait for vmcnt(0) there, i.e. for its prefetched state texels
+            asm volatile("" : "+v"(ffx), "+v"(ffy));
+            ++win->misses;
+        }
+    } else if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
     else ft = p.flow[texel];
 
     float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
@@ -423,7 +449,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
         wxs = (wx * u.dt) * vnw; wys = (wy * u.dt) * vnw;
     }
 
-    if constexpr (!DECODED) {
+    if constexpr (!DECODED && !WINDOW) {
         float k = __builtin_fmaxf(0.0f, 1.0f - ((time - ft.z) * u.flowDecay));
         ffx = ft.x * k; ffy = ft.y * k;
     }
@@ -465,15 +491,8 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
 }
 
 
-// BUCKETED = false: slot == particle id, plain grid-stride over texel order.
-// BUCKETED = true : slots are grouped by flow region (bucket_* kernels) and `perm[slot]` is the
-//   particle id.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one: checked
-//   with HW_REG_XCC_ID, tools/xcc_census.hip), so group g = blockIdx % 8 sweeps the g-th eighth
-//   of the slot range and one XCD's 4 MiB L2 only ever sees about one eighth of the flow field.
-//   Inside its eighth a group walks grid-stride, i.e. all of its workgroups stream one contiguous
-//   window: per-workgroup contiguous chunks ran 1.9x slower (DRAM locality of 2048 separate
-//   streams, profiles/r1_c_*).  The XCD mapping affects speed only, never results.
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool BUCKETED>
+// Texel order (slot == particle id): plain grid-stride, the next state texel of each lane prefetched one iteration ahead.
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
 __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 {
     const float time = p.time_dev ? *p.time_dev : p.u.time;     // captured-graph replays keep `time` in device memory
@@ -482,35 +501,14 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
         for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
         __syncthreads();
     }
-
-    uint32_t idx, stride, end;
-    if constexpr (!BUCKETED) {
-        idx = blockIdx.x * 256u + threadIdx.x;
-        stride = gridDim.x * 256u;
-        end = p.count;
-    } else {
-        const uint32_t group = blockIdx.x & 7u, rank = blockIdx.x >> 3, per = (p.count + 7u) >> 3;
-        const uint32_t lo = group * per;
-        idx = lo + rank * 256u + threadIdx.x;
-        stride = (gridDim.x >> 3) * 256u;
-        end = lo + per < p.count ? lo + per : p.count;
-    }
-
-    // software prefetch: the next texel of this lane is requested before this one is integrated
+    const uint32_t stride = gridDim.x * 256u, end = p.count;
+    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t npid = idx;
-    if (idx < end) {
-        nxt = load_stream(&p.in[idx]);
-        if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx]);
-    }
+    if (idx < end) nxt = load_stream(&p.in[idx]);
     for (; idx < end; idx += stride) {
         float4 st = nxt;
-        uint32_t pid = BUCKETED ? npid : idx;
-        if (idx + stride < end) {
-            nxt = load_stream(&p.in[idx + stride]);
-            if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx + stride]);
-        }
-        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, pid, time));
+        if (idx + stride < end) nxt = load_stream(&p.in[idx + stride]);
+        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, st, idx, time));
     }
 }
 
@@ -554,17 +552,14 @@ __global__ __launch_bounds__(256) void logic_generic_kernel(const LogicParams p)
 }
 
 template <bool FAST, bool NOISE, bool TARGET>
-static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, bool bucketed, hipStream_t s)
+static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
     int grid = grid_for(p.count, 8);
     static const int grid_env = [] { const char *e = getenv("TH_STEP_GRID"); return e ? atoi(e) : 0; }();
     if (grid_env > 0 && (int)((p.count + 255) / 256) >= grid_env) grid = grid_env;
-#define TH_GO(P2, DEC, BK) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, BK>), dim3(grid), dim3(256), 0, s, p)
-    if (bucketed) {
-        if (!(grid_env > 0 && grid == grid_env)) grid = 2048;      // 8 workgroups per CU, 256 per XCD group (a multiple of 8 is required)
-        if (pow2) TH_GO(true, true, true); else TH_GO(false, true, true);
-    } else if (pow2) { if (decoded) TH_GO(true, true, false); else TH_GO(true, false, false); }
-    else { if (decoded) TH_GO(false, true, false); else TH_GO(false, false, false); }
+#define TH_GO(P2, DEC) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC>), dim3(grid), dim3(256), 0, s, p)
+    if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
+    else { if (decoded) TH_GO(false, true); else TH_GO(false, false); }
 #undef TH_GO
 }
 
@@ -586,11 +581,10 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
         return;
     }
     const bool fast = mode == TH_MODE_FAST;
-    const bool bucketed = p.perm != nullptr;      // bucketed launches always use the decoded plane
 #define TH_DISPATCH(F, N, T)                                             \
     do {                                                                 \
         if (packed) launch_packed_p2<F, N, T>(p, pow2, decoded, s);      \
-        else launch_logic_p2<F, N, T>(p, pow2, decoded, bucketed, s);    \
+        else launch_logic_p2<F, N, T>(p, pow2, decoded, s);              \
     } while (0)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
@@ -739,118 +733,203 @@ void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target,
 }
 
 // ---------------------------------------------------------------------------
-// Bucketing: group particle SLOTS by the flow region their particle currently samples, so that
-// the XCD-affine launch above keeps the random flow gather inside one XCD's L2.
-//   * interior particles: counting sort over kBuckets bands of flow rows, then cut into 8 equal
-//     shares (by particle count) in row order: share g = the field region XCD group g works in;
-//   * edge class: particles outside the view (their tap clamps onto row 0 or the last row: two
-//     cache-hot rows) and inert particles (no tap at all) are dealt evenly to all 8 groups, so
-//     that they do not push the interior particles into fewer XCDs.
-// Slot order of group g: [interior share g][edge share g]; group g owns slots [g*S/8, (g+1)*S/8)
-// to within rounding.  Order inside a bucket is arbitrary - results do not depend on slot order:
-// every particle reads only its own texel (src/logic.frag:48,75,85).
+// Tile-sorted slot order.  Particles are independent, so the ring buffers may hold them in any
+// SLOT order as long as `perm[slot]` names the particle (its texel: gl_FragCoord, uv, the index i
+// and the targets texel all derive from it).  Sorting the slots by the kTile x kTile tile of the
+// flow field the particle taps turns the one random gather of the integrator (src/flow/
+// flow-at-screen-pos.glsl:13-27) into a workgroup-local LDS lookup:
+//   key      tile of the tap texel (same arithmetic as the tap itself); particles that tap nothing
+//            (inert, NaN / infinite position) form one extra class after the last tile
+//   sort     counting sort: tile_hist_kernel -> tile_scan_kernel (tile starts, rank cursors and the
+//            chunk table: <= kTileChunk slots of ONE tile per workgroup) -> the slots are assigned by
+//            the kernel that moves the state anyway: logic_sorted_kernel<.., SCATTER = true> writes the
+//            step's OUTPUT at the new slots (no extra pass over the state), tile_scatter_kernel is
+//            the plain move for launches that do not step (th_step_n's fused passes)
+//   launch   one workgroup per chunk stages its tile + kTileHalo texels of the decoded plane in LDS;
+//            chunks are dealt to the XCDs in eighths (blockIdx % 8 = XCD group, checked with
+//            HW_REG_XCC_ID in tools/xcc_census.hip), so one XCD's L2 serves one band of the field.
+// Slot order within a tile is whatever the rank atomics produce (it differs from run to run);
+// results do not depend on it: every particle reads only its own texel (src/logic.frag:48,75,85).
 // ---------------------------------------------------------------------------
-constexpr uint32_t kEdgeKey = kBuckets;          // counters: kBuckets interior bands + 1 edge class
-constexpr uint32_t kKeys = kBuckets + 1;
-
-TH_D uint32_t bucket_key(const BucketParams &b, float4 st)
+TH_D uint32_t tile_key(const TileGeom &g, float px, float py)
 {
-    if (!(st.x != kInert || st.y != kInert)) return kEdgeKey;          // inert: never samples the flow
-    float fv = (st.y * b.view_y + 1.0f) * 0.5f;                         // same flow row as flow tap in integrate()
-    float r = fv * b.fhf;
-    if (!(r >= 1.0f && r < b.fhm1)) return kEdgeKey;                    // clamps to row 0 / last row (or NaN)
-    return ((uint32_t)(int)r * kBuckets) / b.fh;
+    const bool taps = __builtin_fabsf(px) < __builtin_inff() && __builtin_fabsf(py) < __builtin_inff() &&
+                      (px != kInert || py != kInert);
+    if (!taps) return g.ntiles;
+    // the tap texel of integrate(): (pos * viewSize + 1) * (0.5 * size), clamped, truncated
+    const int tx = (int)__builtin_amdgcn_fmed3f((px * g.view_x + 1.0f) * g.half_fw, 0.0f, g.fwm1);
+    const int ty = (int)__builtin_amdgcn_fmed3f((py * g.view_y + 1.0f) * g.half_fh, 0.0f, g.fhm1);
+    return (uint32_t)(ty >> kTileShift) * g.tiles_x + (uint32_t)(tx >> kTileShift);
 }
 
-constexpr uint32_t kBucketChunk = 4096;     // slots per workgroup: 16 per thread
-
-__global__ __launch_bounds__(256) void bucket_hist_kernel(const BucketParams b)
+// Runs of equal keys among the valid lanes of a wave (valid lanes are a prefix of the wave).  In sorted input a
+// wave holds one or two runs, so a counter per run instead of per lane keeps the atomics off the hot tiles.
+//   head      this lane starts a run
+//   rank      position of this lane inside its run
+//   length    (head lanes) lanes in the run
+//   head_lane lane that starts this lane's run
+struct WaveRuns { bool head; uint32_t rank, length, head_lane; };
+TH_D WaveRuns wave_runs(uint32_t key, bool valid)
 {
-    __shared__ uint32_t lh[kKeys];
-    if (threadIdx.x < kKeys) lh[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * kBucketChunk;
-    for (uint32_t k = 0; k < 16; ++k) {
-        uint32_t s = base + k * 256u + threadIdx.x;
-        if (s < b.count) atomicAdd(&lh[bucket_key(b, b.state[s])], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < kKeys && lh[threadIdx.x]) atomicAdd(&b.hist[threadIdx.x], lh[threadIdx.x]);
+    const uint32_t lane = __lane_id();
+    const uint32_t prev = __shfl_up(key, 1);
+    const unsigned long long vmask = __ballot(valid);
+    const bool head = valid && (lane == 0 || key != prev);
+    const unsigned long long heads = __ballot(head);
+    WaveRuns r;
+    r.head = head;
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);          // heads at or below this lane
+    r.head_lane = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+    r.rank = lane - r.head_lane;
+    const unsigned long long above = lane < 63u ? (heads >> (lane + 1u)) : 0ull;   // heads after this lane
+    const uint32_t next = above ? lane + 1u + (uint32_t)__builtin_ctzll(above) : (uint32_t)__builtin_popcountll(vmask);
+    r.length = next - lane;
+    return r;
 }
 
-// Exclusive scan of the histogram into per-class rank cursors (interior ranks count through the
-// bands in row order, edge ranks start at 0); totals go to cursor[kKeys] (interior) and
-// cursor[kKeys+1] (edge).  Clears the histogram for the next use.
-__global__ __launch_bounds__(64) void bucket_scan_kernel(uint32_t *hist, uint32_t *cursor)
-{
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < kBuckets; ++k) { uint32_t c = hist[k]; cursor[k] = acc; acc += c; hist[k] = 0; }
-        cursor[kEdgeKey] = 0;
-        cursor[kKeys] = acc;
-        cursor[kKeys + 1] = hist[kEdgeKey];
-        hist[kEdgeKey] = 0;
-    }
-}
+// Counting through a small LDS table.  Global atomics on a few thousand adjacent counters are slow (16.8 M particles,
+// one atomic per run of a wave: 4.7 ms per pass), and a workgroup sweeping sorted slots meets only its own tile and
+// the tiles next to it, so every workgroup first counts in an open-addressed LDS table of kBinSlots keys and touches
+// the global counters once per distinct key; runs that find the table full go to the global counter directly.
+constexpr uint32_t kBinEmpty = 0xffffffffu;
+struct ChunkBins { uint32_t key[kBinSlots], count[kBinSlots], base[kBinSlots]; };
 
-// rank inside a class -> final slot (see the layout above); start(g) = floor(g*total/8)
-TH_D uint32_t share_start(uint32_t g, uint32_t total) { return (uint32_t)(((unsigned long long)g * total) >> 3); }
-TH_D uint32_t final_slot(uint32_t rank, bool edge, uint32_t n_int, uint32_t n_edge)
+TH_D void bins_clear(ChunkBins &t)
 {
-    const uint32_t total = edge ? n_edge : n_int;
-    uint32_t g = (uint32_t)((8ull * rank) / total);
-    g = g > 7u ? 7u : g;
-    while (rank < share_start(g, total)) --g;
-    while (g < 7u && rank >= share_start(g + 1u, total)) ++g;
-    const uint32_t group_start = share_start(g, n_int) + share_start(g, n_edge);
-    const uint32_t int_in_group = share_start(g + 1u, n_int) - share_start(g, n_int);
-    return edge ? group_start + int_in_group + (rank - share_start(g, n_edge))
-                : group_start + (rank - share_start(g, n_int));
+    if (threadIdx.x < kBinSlots) { t.key[threadIdx.x] = kBinEmpty; t.count[threadIdx.x] = 0u; t.base[threadIdx.x] = 0u; }
 }
-
-__global__ __launch_bounds__(256) void bucket_scatter_kernel(const BucketParams b)
+// table slot of `key` (claimed when absent and `insert`), -1 = not in the table / table full
+TH_D int bins_slot(ChunkBins &t, uint32_t key, bool insert)
 {
-    __shared__ uint32_t lh[kKeys], lbase[kKeys];
-    if (threadIdx.x < kKeys) lh[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * kBucketChunk;
-    const uint32_t n_int = b.cursor[kKeys], n_edge = b.cursor[kKeys + 1];
-    uint32_t key[16];
-#pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
-        uint32_t s = base + k * 256u + threadIdx.x;
-        key[k] = s < b.count ? bucket_key(b, b.state[s]) : 0xffffffffu;
-        if (s < b.count) atomicAdd(&lh[key[k]], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < kKeys) {
-        uint32_t c = lh[threadIdx.x];
-        lbase[threadIdx.x] = c ? atomicAdd(&b.cursor[threadIdx.x], c) : 0u;     // reserve a run of ranks per key
-        lh[threadIdx.x] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
-        uint32_t s = base + k * 256u + threadIdx.x;
-        if (key[k] != 0xffffffffu) {
-            uint32_t rank = lbase[key[k]] + atomicAdd(&lh[key[k]], 1u);
-            b.src_slot[final_slot(rank, key[k] == kEdgeKey, n_int, n_edge)] = s;
+    uint32_t h = (key * 2654435761u) >> (32 - kBinSlotsLog2);
+    for (uint32_t n = 0; n < kBinSlots; ++n, h = (h + 1u) & (kBinSlots - 1u)) {
+        const uint32_t k = *(volatile uint32_t *)&t.key[h];
+        if (k == key) return (int)h;
+        if (k == kBinEmpty) {
+            if (!insert) return -1;
+            const uint32_t old = atomicCAS(&t.key[h], kBinEmpty, key);
+            if (old == kBinEmpty || old == key) return (int)h;
         }
     }
+    return -1;
+}
+// The global counters themselves are kept in kSortReplicas copies kMaxTileBins words apart (a few thousand adjacent
+// words sit on a handful of memory channels, where the atomics of every workgroup would queue up: 16.8 M particles
+// in texel order, 4.7 ms per counting pass on one copy against 0.4 ms on 64).  The pass that counts and the pass that
+// hands out the slots must pick the same copy for a particle: `rep` is the input slot's 4096-block for passes over
+// linear blocks, the chunk number for passes that work from a chunk's record.
+TH_D uint32_t replica_of(uint32_t block) { return (block & (kSortReplicas - 1u)) * kMaxTileBins; }
+
+// count one run of a wave (call from its head lane)
+TH_D void bins_count(ChunkBins &t, uint32_t *global_hist, uint32_t rep, uint32_t key, uint32_t length)
+{
+    const int h = bins_slot(t, key, true);
+    if (h >= 0) atomicAdd(&t.count[h], length); else atomicAdd(&global_hist[rep + key], length);
+}
+// after a barrier: the table's totals to the global histogram (and, optionally, the table itself to `rec`)
+TH_D void bins_flush(const ChunkBins &t, uint32_t *global_hist, uint32_t rep, ChunkRecord *rec)
+{
+    if (threadIdx.x < kBinSlots) {
+        const uint32_t k = t.key[threadIdx.x], n = t.count[threadIdx.x];
+        if (k != kBinEmpty && n) atomicAdd(&global_hist[rep + k], n);
+        if (rec) { rec->key[threadIdx.x] = k; rec->count[threadIdx.x] = n; }
+    }
 }
 
-// dst[d] = src[src_slot[d]]  (gather form: random 16-byte reads, coalesced writes)
-__global__ __launch_bounds__(256) void permute_state_kernel(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n)
+__global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
 {
-    for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < n; d += gridDim.x * 256u) dst[d] = src[src_slot[d]];
+    __shared__ ChunkBins bins;
+    bins_clear(bins);
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kTileChunk;
+    for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
+        const uint32_t s = base + k * 256u + threadIdx.x;
+        const bool valid = s < b.count;
+        uint32_t key = 0;
+        if (valid) { const float4 st = b.state[s]; key = tile_key(b.g, st.x, st.y); }
+        const WaveRuns r = wave_runs(key, valid);
+        if (r.head) bins_count(bins, b.hist, replica_of(blockIdx.x), key, r.length);
+    }
+    __syncthreads();
+    bins_flush(bins, b.hist, replica_of(blockIdx.x), nullptr);
 }
 
-// new_perm[d] = old_perm ? old_perm[src_slot[d]] : src_slot[d]
-__global__ __launch_bounds__(256) void permute_ids_kernel(uint32_t *dst, const uint32_t *old_perm, const uint32_t *src_slot, uint32_t n)
+// One workgroup: exclusive scan of the histogram (bins = tiles + the no-tap class, summed over the copies) into the
+// first slot of every bin, the rank cursors of every copy (copy r of a bin starts where copies < r end) and the
+// chunk table.  Clears the histogram.
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const TileSortParams b)
 {
-    for (uint32_t d = blockIdx.x * 256u + threadIdx.x; d < n; d += gridDim.x * 256u) {
-        uint32_t s = src_slot[d];
-        dst[d] = old_perm ? old_perm[s] : s;
+    __shared__ uint32_t part_n[1024], part_c[1024];
+    const uint32_t bins = b.g.ntiles + 1u, per = (bins + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per < bins ? threadIdx.x * per : bins, hi = lo + per < bins ? lo + per : bins;
+    uint32_t n = 0, c = 0;
+    for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t h = 0;
+        for (uint32_t r = 0; r < kSortReplicas; ++r) h += b.hist[(size_t)r * kMaxTileBins + k];
+        n += h; c += (h + kTileChunk - 1u) / kTileChunk;
+    }
+    part_n[threadIdx.x] = n; part_c[threadIdx.x] = c;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {          // Hillis-Steele inclusive scan of the per-thread totals
+        uint32_t an = 0, ac = 0;
+        if (threadIdx.x >= off) { an = part_n[threadIdx.x - off]; ac = part_c[threadIdx.x - off]; }
+        __syncthreads();
+        part_n[threadIdx.x] += an; part_c[threadIdx.x] += ac;
+        __syncthreads();
+    }
+    uint32_t slot = part_n[threadIdx.x] - n, chunk = part_c[threadIdx.x] - c;
+    for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t h = 0;
+        for (uint32_t r = 0; r < kSortReplicas; ++r) {
+            const size_t w = (size_t)r * kMaxTileBins + k;
+            const uint32_t hr = b.hist[w];
+            b.hist[w] = 0;
+            b.cursor[w] = slot + h;
+            h += hr;
+        }
+        for (uint32_t done = 0; done < h; done += kTileChunk, ++chunk)
+            b.chunks[chunk] = TileChunk{slot + done, h - done < kTileChunk ? h - done : kTileChunk, k, 0u};
+        slot += h;
+    }
+    if (threadIdx.x == 1023u) *b.nchunks = part_c[1023];
+}
+
+// new slot of every valid lane: one returning atomic per run of equal (copy, key) words
+TH_D uint32_t reserve_slots(uint32_t *cursor, uint32_t word, bool valid)
+{
+    const WaveRuns r = wave_runs(word, valid);
+    uint32_t first = 0;
+    if (r.head) first = atomicAdd(&cursor[word], r.length);
+    return __shfl(first, r.head_lane) + r.rank;
+}
+// the same through a workgroup's table of reserved ranges (keys outside the table: the global cursor of copy `rep`)
+TH_D uint32_t reserve_slots(ChunkBins &t, uint32_t *cursor, uint32_t rep, uint32_t key, bool valid)
+{
+    const WaveRuns r = wave_runs(key, valid);
+    uint32_t first = 0;
+    if (r.head) {
+        const int h = bins_slot(t, key, false);
+        first = h >= 0 ? t.base[h] + atomicAdd(&t.count[h], r.length) : atomicAdd(&cursor[rep + key], r.length);
+    }
+    return __shfl(first, r.head_lane) + r.rank;
+}
+
+// The plain move: state (and particle ids) of slot order `perm_in` (nullptr = texel order) to the sorted slots.
+__global__ __launch_bounds__(256) void tile_scatter_kernel(const TileSortParams b)
+{
+    const uint32_t base = blockIdx.x * kTileChunk;
+    for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
+        const uint32_t s = base + k * 256u + threadIdx.x;
+        const bool valid = s < b.count;
+        float4 st = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t word = 0, pid = s;
+        if (valid) {
+            st = load_stream(&b.state[s]);
+            if (b.perm_in) pid = __builtin_nontemporal_load(&b.perm_in[s]);
+            word = replica_of(blockIdx.x) + tile_key(b.g, st.x, st.y);
+        }
+        const uint32_t d = reserve_slots(b.cursor, word, valid);
+        if (valid) { b.state_out[d] = st; b.perm_out[d] = pid; }
     }
 }
 
@@ -860,34 +939,192 @@ __global__ __launch_bounds__(256) void unpermute_state_kernel(float4 *dst, const
     for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) dst[perm[s]] = src[s];
 }
 
-static int bucket_grid(const BucketParams &b) { return (int)((b.count + kBucketChunk - 1) / kBucketChunk); }
+static int tile_grid(uint32_t count) { return (int)((count + kTileChunk - 1) / kTileChunk); }
 
-// histogram only (b.hist accumulates; the caller may read it back to decide whether to sort)
-void launch_bucket_hist(const BucketParams &b, hipStream_t s)
+void launch_tile_hist(const TileSortParams &b, hipStream_t s)
 {
-    hipLaunchKernelGGL(bucket_hist_kernel, dim3(bucket_grid(b)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
 }
 
-// scan + scatter: consumes (and clears) the histogram, fills b.src_slot
-void launch_bucket_scatter(const BucketParams &b, hipStream_t s)
+void launch_tile_scan(const TileSortParams &b, hipStream_t s)
 {
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(64), 0, s, b.hist, b.cursor);
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(bucket_grid(b)), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, b);
 }
 
-void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n, hipStream_t s)
+void launch_tile_scatter(const TileSortParams &b, hipStream_t s)
 {
-    hipLaunchKernelGGL(permute_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, src_slot, n);
-}
-
-void launch_permute_ids(uint32_t *dst, const uint32_t *old_perm, const uint32_t *src_slot, uint32_t n, hipStream_t s)
-{
-    hipLaunchKernelGGL(permute_ids_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, old_perm, src_slot, n);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
 }
 
 void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t s)
 {
     hipLaunchKernelGGL(unpermute_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, perm, n);
+}
+
+// ---------------------------------------------------------------------------
+// The single-step integrator over sorted slots.
+//   IN_TILED  the input is in a tile-sorted order (p.perm, p.chunks): one chunk per workgroup, the chunk's
+//             tile + halo staged in LDS, taps from there.  Otherwise the input is in texel order (the first
+//             sort of a context): chunks are runs of kTileChunk texels, taps are global gathers.
+//   SCATTER   the output goes to the slots of a NEW sort (key = tile of the INPUT position, counted by
+//             tile_hist_kernel over the same buffer), with the particle ids in p.perm_out.  Otherwise
+//             the output keeps the input's slot.
+// The hash stages of the noise run through the LDS tables of the fused kernel (snoise_corners_tab).
+// ---------------------------------------------------------------------------
+//   COUNT     (in-place passes) also histogram the tiles of the OUTPUT positions - the input of the next pass - and
+//             leave every chunk's table of (tile, count) in p.records, so that a SCATTER pass that follows needs no
+//             counting pass of its own and reserves its slots once per workgroup and tile (p.use_records)
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool IN_TILED, bool SCATTER, bool COUNT>
+__global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams p)
+{
+    __shared__ ChunkBins bins;
+    __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
+    __shared__ v2f window[IN_TILED ? kTileLW * kTileLW : 1];
+    const float time = p.time_dev ? *p.time_dev : p.u.time;
+    const float4 *lut = smem + (NOISE ? kHashVec : 0);
+    const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
+
+    TileChunk ch;
+    uint32_t c = blockIdx.x;
+    if constexpr (IN_TILED) {
+        // chunk of this workgroup: the chunk table is dealt to the 8 XCD groups in eighths
+        const uint32_t nchunks = *p.nchunks, per = (nchunks + 7u) >> 3;
+        c = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per || c >= nchunks) return;
+        ch = p.chunks[c];
+    } else {
+        const uint32_t start = blockIdx.x * kTileChunk;
+        if (start >= p.count) return;
+        ch = TileChunk{start, p.count - start < kTileChunk ? p.count - start : kTileChunk, p.geom.ntiles, 0u};
+    }
+    FlowWindow win{(const __attribute__((address_space(3))) v2f *)window, 0, 0, 0u};
+    const bool use_records = SCATTER && IN_TILED && p.use_records;
+    if constexpr (COUNT) bins_clear(bins);
+    if constexpr (SCATTER && IN_TILED) {
+        // the table the previous (COUNT) pass left for this chunk: reserve every tile's range with one atomic
+        if (use_records && threadIdx.x < kBinSlots) {
+            const uint32_t k = p.records[c].key[threadIdx.x], n = p.records[c].count[threadIdx.x];
+            bins.key[threadIdx.x] = k;
+            bins.count[threadIdx.x] = 0u;
+            bins.base[threadIdx.x] = (k != kBinEmpty && n) ? atomicAdd(&p.cursor[replica_of(c) + k], n) : 0u;
+        }
+    }
+    if constexpr (NOISE) fill_hash_tables(smem, p.lut);
+    if constexpr (IN_TILED) {
+        if (ch.tile < p.geom.ntiles) {
+            const int ty0 = (int)(ch.tile / p.geom.tiles_x), tx0 = (int)(ch.tile - (uint32_t)ty0 * p.geom.tiles_x);
+            win.x0 = tx0 * kTile - kTileHalo; win.y0 = ty0 * kTile - kTileHalo;
+            for (int t = threadIdx.x; t < kTileLW * kTileLW; t += 256) {
+                const int ly = t / kTileLW, lx = t - ly * kTileLW;
+                int gx = win.x0 + lx, gy = win.y0 + ly;
+                gx = gx < 0 ? 0 : (gx >= p.fw ? p.fw - 1 : gx);
+                gy = gy < 0 ? 0 : (gy >= p.fh ? p.fh - 1 : gy);
+                const float2 d = p.flow_dec[gy * p.fw + gx];
+                window[t] = v2f{d.x, d.y};
+            }
+        } else { win.x0 = -0x40000000; win.y0 = -0x40000000; }      // the no-tap class: nothing to stage
+    }
+    if constexpr (NOISE || IN_TILED || COUNT) __syncthreads();
+
+    // The chunk is swept 256 slots at a time, two iterations of state loads ahead.  The loads are unconditional - lanes and
+    // iterations beyond the chunk read its first slot instead (one line per wave) - because a load under a branch
+    // makes hipcc wait for it at the join.  Workgroups start at different offsets into their chunks (and wrap
+    // around): chunks of one tile are exact multiples of 64 KiB apart, and workgroups sweeping them in lockstep
+    // would all sit on the same memory channels.
+    const uint32_t iters = (ch.count + 255u) >> 8;
+    const uint32_t first = (blockIdx.x * 5u) % iters;
+    const uint32_t end = ch.start + ch.count;
+    auto slot_of = [&](uint32_t it) { uint32_t k = first + it; k = k >= iters ? k - iters : k; return ch.start + (k << 8) + threadIdx.x; };
+    auto load_slot = [&](uint32_t it, float4 &st, uint32_t &pid) {
+        uint32_t s = slot_of(it);
+        s = (it < iters && s < end) ? s : ch.start;
+        st = load_stream(&p.in[s]);
+        if constexpr (IN_TILED) pid = __builtin_nontemporal_load(&p.perm[s]);
+    };
+    auto body = [&](uint32_t it, float4 st, uint32_t pid_in) __attribute__((always_inline)) {
+        const uint32_t slot = slot_of(it);
+        const bool valid = slot < end;
+        const uint32_t pid = IN_TILED ? pid_in : slot;
+        uint32_t dst = slot;
+        // (whole waves reach this point together: the rank reservation and the counting are wave-wide operations)
+        if constexpr (SCATTER) {
+            const uint32_t key = valid ? tile_key(p.geom, st.x, st.y) : 0u;
+            // (without a record the histogram came from tile_hist_kernel: copies by the input slot's 4096-block)
+            if constexpr (IN_TILED) dst = use_records ? reserve_slots(bins, p.cursor, replica_of(c), key, valid)
+                                                      : reserve_slots(p.cursor, replica_of(slot >> 12) + key, valid);
+            else dst = reserve_slots(p.cursor, replica_of(blockIdx.x) + key, valid);
+        }
+        float4 r = st;
+        if (valid) {
+            if constexpr (IN_TILED) r = integrate<FAST, NOISE, TARGET, POW2, true, true, true>(p, lut, st, pid, time, &tabs, &win);
+            else r = integrate<FAST, NOISE, TARGET, POW2, true, true, false>(p, lut, st, pid, time, &tabs);
+            // (scattered runs start at any slot: plain stores, so that L2 can merge the partial lines two runs share)
+            if constexpr (SCATTER) { p.out[dst] = r; p.perm_out[dst] = pid; }
+            else store_stream(&p.out[dst], r);
+        }
+        if constexpr (COUNT) {
+            const uint32_t key = valid ? tile_key(p.geom, r.x, r.y) : 0u;
+            const WaveRuns w = wave_runs(key, valid);
+            if (w.head) bins_count(bins, p.hist, replica_of(c), key, w.length);
+        }
+    };
+    // three register sets, loop unrolled by three: every load goes into the set the previous body has just
+    // consumed, so no value that is still in flight is ever moved between registers
+    float4 q0, q1, q2;
+    uint32_t p0 = 0, p1 = 0, p2 = 0;
+    load_slot(0, q0, p0);
+    load_slot(1, q1, p1);
+    for (uint32_t it = 0; it < iters; it += 3u) {
+        load_slot(it + 2u, q2, p2);
+        body(it, q0, p0);
+        if (it + 1u >= iters) break;
+        load_slot(it + 3u, q0, p0);
+        body(it + 1u, q1, p1);
+        if (it + 2u >= iters) break;
+        load_slot(it + 4u, q1, p1);
+        body(it + 2u, q2, p2);
+    }
+    if constexpr (COUNT) {
+        __syncthreads();
+        bins_flush(bins, p.hist, replica_of(c), &p.records[c]);
+    }
+    if constexpr (IN_TILED) {
+        if (p.misses) {
+            uint32_t m = win.misses;
+            m += __shfl_xor(m, 32); m += __shfl_xor(m, 16); m += __shfl_xor(m, 8);
+            m += __shfl_xor(m, 4); m += __shfl_xor(m, 2); m += __shfl_xor(m, 1);
+            if ((threadIdx.x & 63u) == 0u && m) atomicAdd(p.misses, m);
+        }
+    }
+}
+
+template <bool FAST, bool NOISE, bool TARGET>
+static void launch_sorted_p2(const LogicParams &p, bool pow2, bool in_tiled, bool scatter, bool count, uint32_t max_chunks, hipStream_t s)
+{
+    // IN_TILED: an upper bound of the chunk count (the real one lives on the device), rounded up to the 8 XCD groups
+    const int grid = in_tiled ? (int)(((max_chunks + 7u) & ~7u)) : tile_grid(p.count);
+#define TH_GO(P2, IT, SC, CN) hipLaunchKernelGGL((logic_sorted_kernel<FAST, NOISE, TARGET, P2, IT, SC, CN>), dim3(grid), dim3(256), 0, s, p)
+    if (in_tiled) {
+        if (scatter) { if (pow2) TH_GO(true, true, true, false); else TH_GO(false, true, true, false); }
+        else if (count) { if (pow2) TH_GO(true, true, false, true); else TH_GO(false, true, false, true); }
+        else { if (pow2) TH_GO(true, true, false, false); else TH_GO(false, true, false, false); }
+    } else { if (pow2) TH_GO(true, false, true, false); else TH_GO(false, false, true, false); }
+#undef TH_GO
+}
+
+void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
+                         bool count, uint32_t max_chunks, hipStream_t s)
+{
+    const bool fast = mode == TH_MODE_FAST;
+#define TH_DISPATCH(F, N, T) launch_sorted_p2<F, N, T>(p, pow2, in_tiled, scatter, count, max_chunks, s)
+    if (fast) {
+        if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
+        else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }
+    } else {
+        if (noise) { if (target) TH_DISPATCH(false, true, true); else TH_DISPATCH(false, true, false); }
+        else { if (target) TH_DISPATCH(false, false, true); else TH_DISPATCH(false, false, false); }
+    }
+#undef TH_DISPATCH
 }
 
 // Per-texel flow decode for one step (src/flow/get.glsl:3-5).  Sampling is NEAREST and get() is

@@ -11,6 +11,20 @@ namespace th {
 
 constexpr uint32_t kMaxFusedSteps = 32;
 
+// Tile-sorted slot order (th_kernels.hip "Tile-sorted slot order")
+constexpr uint32_t kTileChunk = 4096;        // slots per workgroup (16 per thread), all of one tile
+constexpr uint32_t kMaxTileBins = 8192;      // tiles + 1: larger flow fields keep the texel order
+constexpr uint32_t kSortReplicas = 64;       // copies of the global sort counters (power of two)
+constexpr uint32_t kBinSlotsLog2 = 6, kBinSlots = 1u << kBinSlotsLog2;   // LDS table of the tiles one workgroup meets
+
+struct TileGeom {                // how a position maps to its flow tile: the tap arithmetic of the integrator
+    float view_x, view_y, half_fw, half_fh, fwm1, fhm1;
+    uint32_t tiles_x, ntiles;    // class `ntiles` = particles that tap nothing (inert, NaN / infinite position)
+};
+
+struct TileChunk { uint32_t start, count, tile, pad; };
+struct ChunkRecord { uint32_t key[kBinSlots], count[kBinSlots]; };   // a chunk's table of (tile, particles) of its next positions
+
 // Kernel argument block of the integrator.  Passed by value: it lands in the
 // kernarg segment and every field is wave-uniform (SGPRs).
 struct LogicParams {
@@ -31,7 +45,17 @@ struct LogicParams {
     th_logic_uniforms u;
     float s2_cap;            // largest s2 with sqrt_rn(s2) <= speedLimit (see th_api.hip)
     float pos_bound;         // |pos| below this keeps the noise coordinates inside kNoiseDomain
-    const uint32_t *perm;    // bucketed launches: slot -> particle id (nullptr = identity, texel order)
+    const uint32_t *perm;    // sorted slot order of `in`: slot -> particle id (nullptr = identity, texel order)
+    // logic_sorted_kernel
+    TileGeom geom;
+    const TileChunk *chunks; // chunk table of the input order
+    const uint32_t *nchunks;
+    uint32_t *cursor;        // SCATTER: rank cursors of the new order (tile_scan_kernel)
+    uint32_t *perm_out;      // SCATTER: particle ids of the new order
+    uint32_t *misses;        // += taps that left the staged window (nullptr = not counted)
+    uint32_t *hist;          // COUNT: histogram of the output positions' tiles
+    ChunkRecord *records;    // COUNT: written per chunk; SCATTER with use_records: read per chunk
+    uint32_t use_records;
     const float *time_dev;   // graph replays: `time` is read from here instead of u.time (nullptr = u.time)
     // fused multi-step launches (logic_fused_kernel): nsteps consecutive steps per particle in one pass
     float4 *out_prev;        // receives state nsteps-1 (p.out receives state nsteps); may alias p.in
@@ -39,17 +63,17 @@ struct LogicParams {
     float times[kMaxFusedSteps];   // `time` of each fused step
 };
 
-// Counting sort of particle slots by flow region (th_kernels.hip "Bucketing").
-constexpr uint32_t kBuckets = 64;
-struct BucketParams {
-    const float4 *state;     // current state in slot order
+struct TileSortParams {
+    const float4 *state;         // the state being sorted, in any slot order
+    const uint32_t *perm_in;     // that order (nullptr = texel order)
     uint32_t count;
-    float view_y;            // viewSize.y
-    float fhf, fhm1;
-    uint32_t fh;
-    uint32_t *hist;          // [kBuckets + 1] (interior bands + edge class), zero on entry
-    uint32_t *cursor;        // [kBuckets + 3]: rank cursors, then the two class totals
-    uint32_t *src_slot;      // out: new slot d takes the particle of old slot src_slot[d]
+    TileGeom g;
+    uint32_t *hist;              // [kSortReplicas][kMaxTileBins], zero on entry of tile_hist, cleared by tile_scan
+    uint32_t *cursor;            // [kSortReplicas][kMaxTileBins] next free slot of every bin, per copy
+    TileChunk *chunks;           // chunk table of the NEW order
+    uint32_t *nchunks;
+    float4 *state_out;           // tile_scatter only
+    uint32_t *perm_out;
 };
 
 struct OpticalFlowParams {
@@ -115,10 +139,11 @@ void launch_pack_state(void *dst, const float4 *src, uint32_t n, hipStream_t str
 void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t stream);
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
                         hipStream_t stream);
-void launch_bucket_hist(const BucketParams &b, hipStream_t stream);
-void launch_bucket_scatter(const BucketParams &b, hipStream_t stream);
-void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *src_slot, uint32_t n, hipStream_t stream);
-void launch_permute_ids(uint32_t *dst, const uint32_t *old_perm, const uint32_t *src_slot, uint32_t n, hipStream_t stream);
+void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
+                         bool count, uint32_t max_chunks, hipStream_t stream);
+void launch_tile_hist(const TileSortParams &b, hipStream_t stream);
+void launch_tile_scan(const TileSortParams &b, hipStream_t stream);
+void launch_tile_scatter(const TileSortParams &b, hipStream_t stream);
 void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t stream);
 void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
 void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
