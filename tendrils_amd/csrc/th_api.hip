@@ -125,13 +125,14 @@ struct th_context {
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
-    uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line
+    uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line; scan scratch
+    uint4 *dep_record = nullptr;         // per line: the texels of a short line
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
     float4 *dep_colors_sorted = nullptr;
     bool dep_wide = false;
     const float4 *halo_lo = nullptr, *halo_hi = nullptr;             // caller-owned neighbour rows (th_deposit_set_halo)
-    unsigned long long *mrg_keys = nullptr;                          // th_deposit_merge scratch
+    unsigned long long *mrg_keys = nullptr, *mrg_keys2 = nullptr;    // th_deposit_merge scratch (sort ping-pong)
     uint32_t *mrg_vals[2] = {nullptr, nullptr};
     size_t mrg_capacity = 0;
     float4 *dep_colors = nullptr;
@@ -503,6 +504,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
+    (void)hipFree(c->dep_record); (void)hipFree(c->mrg_keys2);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -1173,11 +1175,13 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     TH_REQUIRE((size_t)c->fw * c->fh > 0 && (uint64_t)c->cfg.width * c->cfg.global_height < (1ull << 32), "bad shapes");
     if (c->dep_lines != lines) {
         TH_HIP(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks);
-        c->dep_count = c->dep_offset = c->dep_blocks = nullptr;
+        (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_record);
+       
+        c->dep_count = c->dep_offset = c->dep_blocks = nullptr; c->dep_record = nullptr;
         TH_HIP(hipMalloc((void **)&c->dep_count, lines * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_offset, lines * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_blocks((uint32_t)lines) * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_record, 2 * lines * sizeof(uint4)));
+        TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height) * sizeof(uint32_t)));
         if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 2 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag
         c->dep_lines = lines;
     }
@@ -1197,7 +1201,7 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.global_height > 2 ? 2 * c->cfg.global_height : 2;
         p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
     }
-    p.count = c->dep_count; p.offset = c->dep_offset; p.oob = c->dep_total + 1;
+    p.count = c->dep_count; p.offset = c->dep_offset; p.record = c->dep_record; p.oob = c->dep_total + 1;
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
     TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
     return TH_OK;
@@ -1211,7 +1215,7 @@ static th_status deposit_scan_total(th_context *c, const th::DepositParams &p, u
     TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));
     if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d) and no halo row was supplied (th_deposit_set_halo)", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
-    TH_REQUIRE(host[0] < (1u << 31), "too many fragments (%u)", host[0]);
+    if (host[0] >= (1u << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one draw (2^31 or more)");
     *total = host[0];
     return TH_OK;
 }
@@ -1292,9 +1296,12 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (th_status s = deposit_reserve(c, total, false)) return s;
     p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
     p.colors = c->dep_colors; p.colors_sorted = c->dep_colors_sorted;
-    if (th_status s = deposit_temp(c, th::deposit_sort_temp_bytes(p, total))) return s;
+    const int bits = th::deposit_key_bits(p);
+    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 0, bits))) return s;
     th::launch_deposit_scatter(p, c->stream);
-    TH_HIP(th::launch_deposit_sort(p, total, c->dep_temp, c->dep_temp_bytes, c->stream));
+    if (th::launch_radix_sort_u32(p.keys, p.slots, p.keys_sorted, p.slots_sorted, total, 0, bits, c->dep_temp, true, c->stream) == 0) {
+        p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1];        // an even number of passes ends in the (a) buffers
+    }
     th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
     return TH_OK;
@@ -1314,14 +1321,14 @@ th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     // the fragment array is in this band's stream order already: a stable sort on the texel bits alone leaves it
     // sorted by the whole (texel, stream index) key
     const int bits = 32 + deposit_texel_bits(c);
-    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, 32, bits))) return s;
+    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 32, bits))) return s;
     th::launch_deposit_scatter(p, c->stream);
-    TH_HIP(th::launch_deposit_sort64(c->dep_u64[0], c->dep_u64[1], c->dep_u32[1], c->dep_u32[3], total, 32, bits, c->dep_temp,
-                                     c->dep_temp_bytes, c->stream));
-    th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, c->dep_u32[3], total, c->stream);
+    const int in_b = th::launch_radix_sort_u64(c->dep_u64[0], c->dep_u32[1], c->dep_u64[1], c->dep_u32[3], total, 32, bits, c->dep_temp,
+                                               true, c->stream);
+    th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, in_b ? c->dep_u32[3] : c->dep_u32[1], total, c->stream);
     TH_HIP(hipGetLastError());
     TH_HIP(hipStreamSynchronize(c->stream));               // the caller hands the buffers to a collective on its own stream
-    *keys_dev = c->dep_u64[1]; *colors_dev = c->dep_colors_sorted;
+    *keys_dev = in_b ? c->dep_u64[1] : c->dep_u64[0]; *colors_dev = c->dep_colors_sorted;
     return TH_OK;
 }
 
@@ -1340,20 +1347,22 @@ th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colo
     TH_REQUIRE(keys_dev && colors_dev && count < (1ull << 31), "bad fragment buffers");
     const uint32_t total = (uint32_t)count;
     if (c->mrg_capacity < total) {
-        (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
-        c->mrg_keys = nullptr; c->mrg_vals[0] = c->mrg_vals[1] = nullptr; c->mrg_capacity = 0;
+        (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
+        c->mrg_keys = c->mrg_keys2 = nullptr; c->mrg_vals[0] = c->mrg_vals[1] = nullptr; c->mrg_capacity = 0;
         const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
         TH_HIP(hipMalloc((void **)&c->mrg_keys, cap * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->mrg_keys2, cap * sizeof(unsigned long long)));
         TH_HIP(hipMalloc((void **)&c->mrg_vals[0], cap * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->mrg_vals[1], cap * sizeof(uint32_t)));
         c->mrg_capacity = cap;
     }
     const int bits = 32 + deposit_texel_bits(c);
-    if (th_status s = deposit_temp(c, th::deposit_sort64_temp_bytes(total, 0, bits))) return s;
-    th::launch_deposit_iota(c->mrg_vals[0], total, c->stream);
-    TH_HIP(th::launch_deposit_sort64(static_cast<const unsigned long long *>(keys_dev), c->mrg_keys, c->mrg_vals[0], c->mrg_vals[1],
-                                     total, 0, bits, c->dep_temp, c->dep_temp_bytes, c->stream));
-    th::launch_deposit_blend64(c->flow, c->mrg_keys, c->mrg_vals[1], static_cast<const float4 *>(colors_dev), total, c->stream);
+    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 0, bits))) return s;
+    // (the sort ping-pongs between its two buffer pairs: the caller's keys are copied, not sorted in place)
+    TH_HIP(hipMemcpyAsync(c->mrg_keys, keys_dev, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 0, bits, c->dep_temp, true, c->stream);
+    th::launch_deposit_blend64(c->flow, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
+                               static_cast<const float4 *>(colors_dev), total, c->stream);
     TH_HIP(hipGetLastError());
     TH_HIP(hipStreamSynchronize(c->stream));               // the input buffers may be reused by the caller now
     return TH_OK;

@@ -9,18 +9,19 @@
 // written in the same order and precision as the checker's restatement so that both agree bit for bit.
 //
 // GL blends fragments in primitive order, which a parallel machine has to reconstruct:
-//   1. deposit_raster_kernel<false>: one thread per line, rasterise, store the line's fragment count at its stream
-//      index (no atomics)
-//   2. exclusive scan over the stream -> every line's first fragment slot: the fragment array is in stream order
-//   3. deposit_raster_kernel<true>: rasterise again, write (texel, interpolated varying) into the line's slots
-//   4. stable radix sort of the fragments by texel (rocPRIM through hipCUB): each texel's fragments end up
-//      contiguous and still in stream order
+//   1. deposit_raster_kernel: one thread per line (threads walk the particle texture row-major: coalesced state
+//      reads), rasterise ONCE: the line's fragment count and - lines of up to four fragments, nearly all of them:
+//      particles move about a texel per step - the texels themselves go into a 16-byte record per line
+//   2. exclusive scan of the counts in STREAM order (column-major over the row-major count array: column sums per
+//      64-row block, one small scan, column prefixes) -> every line's first slot: the fragment array is in stream order
+//   3. deposit_emit_kernel: per line, the varying at the recorded texels (only the few long lines are rasterised
+//      again) -> (texel, interpolated varying) in the line's slots
+//   4. stable radix sort of the fragments by texel (th_sort.hip): each texel's fragments end up contiguous and still
+//      in stream order
 //   5. deposit_blend_kernel: the thread at the head of a texel's run walks it and blends sequentially:
 //      dst = src*a + dst*(1-a), exactly GL's order and arithmetic.
 // No step depends on thread scheduling, and the cost does not depend on how crowded single texels are (the
 // wake makes particles converge: thousands of fragments in one texel are normal after a few dozen frames).
-#include <hipcub/hipcub.hpp>
-
 #include "th_kernels.hpp"
 #include "th_math.hpp"
 
@@ -84,11 +85,12 @@ struct DepositLine {
     int PX[12], PY[12];
 };
 
-// everything about line `id` (stream index = i*H + m) that does not depend on the texel
-TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L, bool need_polygon)
+// everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
+TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L)
 {
     const uint32_t i = id / p.H, m = id - i * p.H;
     L.draws = false;
+    L.n = 0;
     L.a = dep_fetch(p, i, 2u * m);
     L.b = dep_fetch(p, i, 2u * m + 1u);
     if (!L.a.live || !L.b.live) return;                                  // see the header: inert vertex = no line
@@ -102,10 +104,18 @@ TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L, bool ne
     L.sx[0] = dep_snap(L.a.px, wx16, x0); L.sy[0] = dep_snap(L.a.py, wy16, y0);
     L.sx[1] = dep_snap(L.b.px, wx16, x0); L.sy[1] = dep_snap(L.b.py, wy16, y0);
     L.draws = true;
-    if (!need_polygon) return;
+}
 
+// The width-1 line as the hexagon of its two endpoint diamonds, in clip space (six vertices, statically indexed).
+// Returns kHexInside when all of it lies inside the view volume (it is rasterised as it stands), kHexOutside when all
+// six vertices are beyond ONE of the four planes (the clipper would then leave nothing: 44 % of the lines of the C3
+// bench, whose particles are spread over twice the view's height), else kHexClip.
+enum { kHexInside = 0, kHexClip = 1, kHexOutside = 2 };
+TH_D int dep_hexagon(const DepositParams &p, const DepositLine &L, float (&cx)[6], float (&cy)[6])
+{
+    const float fw = (float)p.fw, fh = (float)p.fh;
+    const float dx = (0.5f * fw) * (L.b.px - L.a.px), dy = (0.5f * fh) * (L.b.py - L.a.py);
     const float hx = 0.5f / (0.5f * fw), hy = 0.5f / (0.5f * fh);      // half a texel in clip space
-    float cx[12], cy[12], tx[12], ty[12];
     const DepositVertex *vv[2] = {&L.a, &L.b};
 #define TH_L(n, k) do { cx[n] = vv[k]->px - hx; cy[n] = vv[k]->py; } while (0)
 #define TH_T(n, k) do { cx[n] = vv[k]->px; cy[n] = vv[k]->py + hy; } while (0)
@@ -122,39 +132,60 @@ TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L, bool ne
 #undef TH_T
 #undef TH_R
 #undef TH_B
-    int n = 6;
-    bool inside = true;
-    for (int k = 0; k < 6; ++k)
-        inside = inside && (1.0f + cx[k] >= 0.0f) && (1.0f - cx[k] >= 0.0f) && (1.0f - cy[k] >= 0.0f) && (1.0f + cy[k] >= 0.0f);
-    if (!inside) {
-        // Sutherland-Hodgman against left, right, top, bottom; intersection (dj*Vi - di*Vj) * (1/(dj - di)), inside vertex first
-        for (int plane = 0; plane < 4 && n >= 3; ++plane) {
-            int t = 0;
-            for (int k = 0; k < n; ++k) {
-                const int j = k == n - 1 ? 0 : k + 1;
-                float di, dj;
-                switch (plane) {
-                case 0: di = 1.0f + cx[k]; dj = 1.0f + cx[j]; break;
-                case 1: di = 1.0f - cx[k]; dj = 1.0f - cx[j]; break;
-                case 2: di = 1.0f - cy[k]; dj = 1.0f - cy[j]; break;
-                default: di = 1.0f + cy[k]; dj = 1.0f + cy[j]; break;
-                }
-                if (di >= 0.0f) {
-                    tx[t] = cx[k]; ty[t] = cy[k]; ++t;
-                    if (dj < 0.0f) {
-                        const float D = 1.0f / (dj - di);
-                        tx[t] = (dj * cx[k] - di * cx[j]) * D; ty[t] = (dj * cy[k] - di * cy[j]) * D; ++t;
-                    }
-                } else if (dj > 0.0f) {
-                    const float D = 1.0f / (di - dj);
-                    tx[t] = (di * cx[j] - dj * cx[k]) * D; ty[t] = (di * cy[j] - dj * cy[k]) * D; ++t;
-                }
-            }
-            n = t;
-            for (int k = 0; k < n; ++k) { cx[k] = tx[k]; cy[k] = ty[k]; }
-        }
-        if (n < 3) { L.draws = false; return; }
+    bool inside = true, out0 = true, out1 = true, out2 = true, out3 = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const bool i0 = 1.0f + cx[k] >= 0.0f, i1 = 1.0f - cx[k] >= 0.0f, i2 = 1.0f - cy[k] >= 0.0f, i3 = 1.0f + cy[k] >= 0.0f;
+        inside = inside && i0 && i1 && i2 && i3;
+        out0 = out0 && !i0; out1 = out1 && !i1; out2 = out2 && !i2; out3 = out3 && !i3;
     }
+    return inside ? kHexInside : ((out0 || out1 || out2 || out3) ? kHexOutside : kHexClip);
+}
+
+// the hexagon snapped to the 1/16-texel grid: the polygon of a line that needs no clipping
+TH_D void dep_snap_hexagon(const DepositParams &p, const float (&cx)[6], const float (&cy)[6], int (&PX)[6], int (&PY)[6])
+{
+    const float wx16 = 8.0f * (float)p.fw, wy16 = 8.0f * (float)p.fh;
+    const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { PX[k] = dep_snap(cx[k], wx16, x0); PY[k] = dep_snap(cy[k], wy16, y0); }
+}
+
+// the hexagon clipped against the view volume (lines that cross the view's edge: the rare case, runtime-indexed arrays)
+TH_D void dep_clip_hexagon(const DepositParams &p, DepositLine &L, const float (&hx6)[6], const float (&hy6)[6])
+{
+    const float wx16 = 8.0f * (float)p.fw, wy16 = 8.0f * (float)p.fh;
+    const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
+    float cx[12], cy[12], tx[12], ty[12];
+    for (int k = 0; k < 6; ++k) { cx[k] = hx6[k]; cy[k] = hy6[k]; }
+    int n = 6;
+    // Sutherland-Hodgman against left, right, top, bottom; intersection (dj*Vi - di*Vj) * (1/(dj - di)), inside vertex first
+    for (int plane = 0; plane < 4 && n >= 3; ++plane) {
+        int t = 0;
+        for (int k = 0; k < n; ++k) {
+            const int j = k == n - 1 ? 0 : k + 1;
+            float di, dj;
+            switch (plane) {
+            case 0: di = 1.0f + cx[k]; dj = 1.0f + cx[j]; break;
+            case 1: di = 1.0f - cx[k]; dj = 1.0f - cx[j]; break;
+            case 2: di = 1.0f - cy[k]; dj = 1.0f - cy[j]; break;
+            default: di = 1.0f + cy[k]; dj = 1.0f + cy[j]; break;
+            }
+            if (di >= 0.0f) {
+                tx[t] = cx[k]; ty[t] = cy[k]; ++t;
+                if (dj < 0.0f) {
+                    const float D = 1.0f / (dj - di);
+                    tx[t] = (dj * cx[k] - di * cx[j]) * D; ty[t] = (dj * cy[k] - di * cy[j]) * D; ++t;
+                }
+            } else if (dj > 0.0f) {
+                const float D = 1.0f / (di - dj);
+                tx[t] = (di * cx[j] - dj * cx[k]) * D; ty[t] = (di * cy[j] - dj * cy[k]) * D; ++t;
+            }
+        }
+        n = t;
+        for (int k = 0; k < n; ++k) { cx[k] = tx[k]; cy[k] = ty[k]; }
+    }
+    if (n < 3) { L.draws = false; L.n = 0; return; }
     L.n = n;
     for (int k = 0; k < n; ++k) { L.PX[k] = dep_snap(cx[k], wx16, x0); L.PY[k] = dep_snap(cy[k], wy16, y0); }
 }
@@ -162,11 +193,14 @@ TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L, bool ne
 // scan conversion: calls emit(x, y) for every covered texel.  Edges going up in y set `left`, edges going down set
 // `right` (a later edge overwrites an earlier one on the same row, as in the captured rasteriser); texels
 // left <= x < right.  Rows are walked in windows so that arbitrarily long lines need no large arrays.
-template <typename Emit>
-TH_D void dep_raster(const DepositParams &p, const DepositLine &L, Emit emit)
+template <int N, typename Emit>
+TH_D void dep_raster_poly(const DepositParams &p, const int *PX, const int *PY, int count, Emit emit)
 {
-    int ymin = L.PY[0], ymax = L.PY[0];
-    for (int k = 1; k < L.n; ++k) { ymin = L.PY[k] < ymin ? L.PY[k] : ymin; ymax = L.PY[k] > ymax ? L.PY[k] : ymax; }
+    // N > 0: a polygon of exactly N vertices held in registers (loops unrolled, static indices); N == 0: `count` vertices
+    const int nv = N > 0 ? N : count;
+    int ymin = PY[0], ymax = PY[0];
+#pragma unroll
+    for (int k = 1; k < (N > 0 ? N : 12); ++k) if (k < nv) { ymin = PY[k] < ymin ? PY[k] : ymin; ymax = PY[k] > ymax ? PY[k] : ymax; }
     int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
     if (r0 < 0) r0 = 0;
     if (r1 > p.fh) r1 = p.fh;
@@ -176,9 +210,17 @@ TH_D void dep_raster(const DepositParams &p, const DepositLine &L, Emit emit)
         int left[kWindow], right[kWindow];
 #pragma unroll
         for (int k = 0; k < kWindow; ++k) { left[k] = p.fw; right[k] = 0; }
-        for (int k = 0; k < L.n; ++k) {
-            const int kn = k + 1 == L.n ? 0 : k + 1;
-            const int Xa = L.PX[k], Ya = L.PY[k], Xb = L.PX[kn], Yb = L.PY[kn];
+#pragma nounroll
+        for (int k = 0; k < nv; ++k) {
+            const int kn = k + 1 == nv ? 0 : k + 1;
+            int Xa, Ya, Xb, Yb;
+            if constexpr (N == 6) {
+                // the six vertices stay in registers: the loop is not unrolled (six copies of its body cost 190 VGPRs),
+                // a vertex is picked with a chain of selects instead of an index
+                auto pick = [](const int *v, int i) { int r = v[0]; r = i == 1 ? v[1] : r; r = i == 2 ? v[2] : r; r = i == 3 ? v[3] : r;
+                                                      r = i == 4 ? v[4] : r; r = i == 5 ? v[5] : r; return r; };
+                Xa = pick(PX, k); Ya = pick(PY, k); Xb = pick(PX, kn); Yb = pick(PY, kn);
+            } else { Xa = PX[k]; Ya = PY[k]; Xb = PX[kn]; Yb = PY[kn]; }
             if (Ya == Yb) continue;
             const bool swap = Yb < Ya;
             const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
@@ -210,6 +252,22 @@ TH_D void dep_raster(const DepositParams &p, const DepositLine &L, Emit emit)
     }
 }
 
+// a line, whichever way it has to go: straight from its hexagon, or clipped first
+template <typename Emit>
+TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
+{
+    float cx[6], cy[6];
+    const int where = dep_hexagon(p, L, cx, cy);
+    if (where == kHexInside) {
+        int PX[6], PY[6];
+        dep_snap_hexagon(p, cx, cy, PX, PY);
+        dep_raster_poly<6>(p, PX, PY, 6, emit);
+    } else if (where == kHexClip) {
+        dep_clip_hexagon(p, L, cx, cy);
+        if (L.draws) dep_raster_poly<0>(p, L.PX, L.PY, L.n, emit);
+    }
+}
+
 // the varying of line L at texel (x, y): linear along the snapped endpoints, extrapolated, unclamped
 TH_D float4 dep_varying(const DepositLine &L, int x, int y)
 {
@@ -221,37 +279,145 @@ TH_D float4 dep_varying(const DepositLine &L, int x, int y)
                        L.a.c[2] + t * (L.b.c[2] - L.a.c[2]), L.a.c[3] + t * (L.b.c[3] - L.a.c[3]));
 }
 
-// passes 1 and 3: count the line's fragments, or write them into its slots of the stream-ordered fragment array
-template <bool SCATTER>
+constexpr uint32_t kNeedsClip = 0xffffffffu;       // count[] marker between deposit_raster_kernel and its _clipped pass
+constexpr uint32_t kSlowChunk = 4096;              // lines a workgroup of the slow passes sifts at a time
+
+constexpr uint32_t kRecordTexels = 8;             // texels a line's record holds (two uint4 per line)
+struct LineRecord { uint32_t n, r[kRecordTexels]; };
+TH_D void rec_add(LineRecord &q, uint32_t texel)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < kRecordTexels; ++k) if (q.n == k) q.r[k] = texel;      // static indices: the record stays in registers
+    ++q.n;
+}
+TH_D void rec_store(const DepositParams &p, uint32_t t, const LineRecord &q)
+{
+    p.record[2u * t] = make_uint4(q.r[0], q.r[1], q.r[2], q.r[3]);
+    if (q.n > 4u) p.record[2u * t + 1u] = make_uint4(q.r[4], q.r[5], q.r[6], q.r[7]);
+}
+
+// pass 1: rasterise every line once: fragment count and (count <= kRecordTexels) the covered texels.  Lines whose hexagon crosses
+// the edge of the view volume are only marked here and done by deposit_raster_clipped_kernel: the clipper's
+// runtime-indexed arrays live in scratch memory, and this way the kernel every line goes through has none.
 __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams p)
 {
     const uint32_t lines = p.W * p.rows;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
-        // threads walk the particle texture row-major (coalesced state reads; walking the column-major stream
-        // instead makes the fragment writes contiguous but the state reads strided: 3.6 -> 5.3 ms per draw at C3);
-        // the line's place in the fragment array is its position in the vertex stream
+        // threads walk the particle texture row-major (coalesced state reads); the line's place in the fragment
+        // array is its position in the vertex stream (column-major): the scan below is over that order
         const uint32_t row = t / p.W, col = t - row * p.W;
         const uint32_t id = col * p.H + p.row0 + row;            // position in the whole texture's vertex stream
-        const uint32_t local = col * p.rows + row;               // ... and among this band's lines (same order)
+        LineRecord r{};
         DepositLine L;
-        dep_setup(p, id, L, true);
-        if constexpr (SCATTER) {
-            if (!L.draws) continue;
-            uint32_t at = p.offset[local];
-            dep_raster(p, L, [&](int x, int y) {
-                const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
-                if (p.keys64) p.keys64[at] = ((unsigned long long)texel << 32) | id;
-                else p.keys[at] = texel;
-                p.slots[at] = at;
-                p.colors[at] = dep_varying(L, x, y);
-                ++at;
-            });
-        } else {
-            uint32_t n = 0;
-            if (L.draws) dep_raster(p, L, [&](int, int) { ++n; });
-            p.count[local] = n;
+        dep_setup(p, id, L);
+        if (L.draws) {
+            float cx[6], cy[6];
+            const int where = dep_hexagon(p, L, cx, cy);
+            if (where == kHexInside) {
+                int PX[6], PY[6];
+                dep_snap_hexagon(p, cx, cy, PX, PY);
+                dep_raster_poly<6>(p, PX, PY, 6, [&](int x, int y) { rec_add(r, (uint32_t)y * (uint32_t)p.fw + (uint32_t)x); });
+            } else if (where == kHexClip) r.n = kNeedsClip;
         }
+        p.count[t] = r.n;
+        if (r.n && r.n != kNeedsClip) rec_store(p, t, r);
     }
+}
+
+// The slow passes concern few lines, spread thinly over the waves: a workgroup first sifts kSlowChunk lines for the
+// ones it has to do (into an LDS list), then works through that list with all its lanes.
+template <typename Want, typename Work>
+TH_D void dep_sift_and_work(const DepositParams &p, Want want, Work work)
+{
+    __shared__ uint32_t list[kSlowChunk];
+    __shared__ uint32_t listed;
+    const uint32_t lines = p.W * p.rows, chunks = (lines + kSlowChunk - 1u) / kSlowChunk;
+    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) listed = 0u;
+        __syncthreads();
+        for (uint32_t k = 0; k < kSlowChunk / 256u; ++k) {
+            const uint32_t t = chunk * kSlowChunk + k * 256u + threadIdx.x;
+            const bool mine = t < lines && want(p.count[t]);
+            const unsigned long long m = __ballot(mine);
+            if (m != 0ull) {
+                const uint32_t lane = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+                uint32_t first = 0;
+                if (lane == leader) first = atomicAdd(&listed, (uint32_t)__builtin_popcountll(m));
+                first = __shfl(first, leader);
+                if (mine) list[first + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < listed; e += 256u) work(list[e]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void deposit_raster_clipped_kernel(const DepositParams p)
+{
+    dep_sift_and_work(p, [](uint32_t n) { return n == kNeedsClip; }, [&](uint32_t t) {
+        const uint32_t row = t / p.W, col = t - row * p.W;
+        DepositLine L;
+        dep_setup(p, col * p.H + p.row0 + row, L);
+        LineRecord r{};
+        dep_raster_line(p, L, [&](int x, int y) { rec_add(r, (uint32_t)y * (uint32_t)p.fw + (uint32_t)x); });
+        p.count[t] = r.n;
+        if (r.n) rec_store(p, t, r);
+    });
+}
+
+// one fragment into slot `at` of the stream-ordered fragment array
+TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, uint32_t texel, int x, int y)
+{
+    if (p.keys64) p.keys64[at] = ((unsigned long long)texel << 32) | id;
+    else p.keys[at] = texel;                   // (the sort numbers the fragments itself)
+    p.colors[at] = dep_varying(L, x, y);
+}
+
+// pass 3: the fragments of the lines of up to kRecordTexels fragments, from their records, into the lines' slots.  Threads
+// walk patches of kPatchCols x 64 lines, one column per wave: a wave's lines are 64 consecutive positions of the
+// stream, so its fragments form ONE contiguous run of the fragment array (walking row-major, every lane writes
+// somewhere else: 1.2 ms for this pass at C3 against 0.x); the state texels of the patch are read as 16-byte pieces of
+// the rows, shared by the patch's waves through L1 / L2.
+constexpr uint32_t kPatchCols = 4, kPatchRows = 64;
+
+__global__ __launch_bounds__(256) void deposit_emit_kernel(const DepositParams p)
+{
+    const uint32_t patches_x = (p.W + kPatchCols - 1) / kPatchCols, patches_y = (p.rows + kPatchRows - 1) / kPatchRows;
+    const uint32_t patches = patches_x * patches_y;
+    for (uint32_t patch = blockIdx.x; patch < patches; patch += gridDim.x) {
+        // patches in column-major order too: consecutive workgroups continue each other's runs
+        const uint32_t px = patch / patches_y, py = patch - px * patches_y;
+        const uint32_t col = px * kPatchCols + (threadIdx.x >> 6), row = py * kPatchRows + (threadIdx.x & 63u);
+        if (col >= p.W || row >= p.rows) continue;
+        const uint32_t t = row * p.W + col;
+        const uint32_t n = p.count[t];
+        if (n == 0 || n > kRecordTexels) continue;
+        const uint32_t id = col * p.H + p.row0 + row;
+        const uint32_t at = p.offset[t];
+        DepositLine L;
+        dep_setup(p, id, L);           // vertices and snapped endpoints
+        const uint4 ra = p.record[2u * t];
+        uint4 rb = make_uint4(0u, 0u, 0u, 0u);
+        if (n > 4u) rb = p.record[2u * t + 1u];
+        const uint32_t tex[kRecordTexels] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (uint32_t k = 0; k < kRecordTexels; ++k)
+            if (k < n) { const uint32_t y = tex[k] / (uint32_t)p.fw; dep_put(p, L, id, at + k, tex[k], (int)(tex[k] - y * (uint32_t)p.fw), (int)y); }
+    }
+}
+
+// ... and the lines of more fragments than a record holds, rasterised again
+__global__ __launch_bounds__(256) void deposit_emit_long_kernel(const DepositParams p)
+{
+    dep_sift_and_work(p, [](uint32_t n) { return n > kRecordTexels; }, [&](uint32_t t) {
+        const uint32_t row = t / p.W, col = t - row * p.W;
+        const uint32_t id = col * p.H + p.row0 + row;
+        uint32_t at = p.offset[t];
+        DepositLine L;
+        dep_setup(p, id, L);
+        dep_raster_line(p, L, [&](int x, int y) { dep_put(p, L, id, at, (uint32_t)y * (uint32_t)p.fw + (uint32_t)x, x, y); ++at; });
+    });
 }
 
 TH_D void dep_blend_rgba(float4 &d, float4 c) { const float sa = c.w, da = 1.0f - sa; d.x = c.x * sa + d.x * da; d.y = c.y * sa + d.y * da; d.z = c.z * sa + d.z * da; d.w = c.w * sa + d.w * da; }
@@ -313,71 +479,77 @@ __global__ __launch_bounds__(256) void deposit_blend64_kernel(float4 *flow, cons
     }
 }
 
-__global__ __launch_bounds__(256) void deposit_iota_kernel(uint32_t *dst, uint32_t n)
-{
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = i;
-}
-
 __global__ __launch_bounds__(256) void deposit_gather_colors_kernel(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[index[i]];
 }
 
-// ---- exclusive scan of the per-line fragment counts (three small kernels; 1024 elements per block) -------------
-constexpr uint32_t kScanBlock = 1024;
+// ---- exclusive scan of the per-line fragment counts in stream order ---------------------------------------------
+// The counts lie row-major (count[row*W + col], as the threads that produced them walk), the stream runs column-major
+// (col*rows + row): offset(row, col) = (fragments of the columns before col) + (fragments of rows before `row` in col).
+constexpr uint32_t kColRows = 64;            // rows per partial sum
 
-__global__ __launch_bounds__(256) void scan_local_kernel(const uint32_t *in, uint32_t *out, uint32_t *block_sums, uint32_t n)
+// part[rb*W + col] = sum of count[r][col] over the rows of row block rb
+__global__ __launch_bounds__(256) void colscan_partial_kernel(const uint32_t *count, uint32_t W, uint32_t rows, uint32_t *part)
 {
-    __shared__ uint32_t sh[256];
-    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
-    uint32_t v[4], s = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t o = 1; o < 256u; o <<= 1) {           // Hillis-Steele over the 256 thread sums
-        uint32_t add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
-        __syncthreads();
-        sh[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = sh[threadIdx.x] - s;                 // exclusive prefix of this thread inside the block
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-    if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x, rb = blockIdx.y;
+    if (col >= W) return;
+    const uint32_t r0 = rb * kColRows, r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
+    uint32_t s = 0;
+    for (uint32_t r = r0; r < r1; ++r) s += count[(size_t)r * W + col];
+    part[(size_t)rb * W + col] = s;
 }
 
-__global__ __launch_bounds__(256) void scan_blocks_kernel(uint32_t *block_sums, uint32_t nblocks, uint32_t *total)
+// part -> exclusive prefix over the row blocks of every column (one thread per column), the column's total to coltotal
+// (saturated at 0xffffffff: 64-bit running sums, a total beyond 2^32 must be seen)
+__global__ __launch_bounds__(256) void colscan_prefix_kernel(uint32_t *part, uint32_t W, uint32_t nrb, uint32_t *coltotal)
 {
-    __shared__ uint32_t carry;
-    __shared__ uint32_t sh[256];
-    if (threadIdx.x == 0) carry = 0;
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x;
+    if (col >= W) return;
+    unsigned long long s = 0;
+    for (uint32_t rb = 0; rb < nrb; ++rb) {
+        const uint32_t v = part[(size_t)rb * W + col];
+        part[(size_t)rb * W + col] = (uint32_t)(s > 0xffffffffull ? 0xffffffffull : s);
+        s += v;
+    }
+    coltotal[col] = (uint32_t)(s > 0xffffffffull ? 0xffffffffull : s);
+}
+
+// one workgroup: coltotal -> colbase[col] = fragments of the columns before col (in place); the total to *total
+__global__ __launch_bounds__(1024) void colscan_bases_kernel(uint32_t W, uint32_t *colbase, uint32_t *total)
+{
+    __shared__ unsigned long long sh[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
     __syncthreads();
-    for (uint32_t base = 0; base < nblocks; base += 256u) {
-        const uint32_t idx = base + threadIdx.x;
-        const uint32_t v = idx < nblocks ? block_sums[idx] : 0u;
-        sh[threadIdx.x] = v;
+    for (uint32_t c0 = 0; c0 < W; c0 += 1024u) {
+        const uint32_t col = c0 + threadIdx.x;
+        const unsigned long long s = col < W ? colbase[col] : 0ull;
+        sh[threadIdx.x] = s;
         __syncthreads();
-        for (uint32_t o = 1; o < 256u; o <<= 1) {
-            uint32_t add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+        for (uint32_t o = 1; o < 1024u; o <<= 1) {
+            unsigned long long add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0ull;
             __syncthreads();
             sh[threadIdx.x] += add;
             __syncthreads();
         }
-        if (idx < nblocks) block_sums[idx] = carry + sh[threadIdx.x] - v;
+        const unsigned long long excl = carry + sh[threadIdx.x] - s;
+        if (col < W) colbase[col] = (uint32_t)(excl > 0xffffffffull ? 0xffffffffull : excl);
         __syncthreads();
-        if (threadIdx.x == 0) carry += sh[255];
+        if (threadIdx.x == 0) carry += sh[1023];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) *total = (uint32_t)(carry > 0xffffffffull ? 0xffffffffull : carry);
 }
 
-__global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *out, const uint32_t *block_sums, uint32_t n)
+__global__ __launch_bounds__(256) void colscan_offsets_kernel(const uint32_t *count, uint32_t W, uint32_t rows, const uint32_t *part,
+                                                              const uint32_t *colbase, uint32_t *offset)
 {
-    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
-    const uint32_t add = block_sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (base + k < n) out[base + k] += add;
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x, rb = blockIdx.y;
+    if (col >= W) return;
+    const uint32_t r0 = rb * kColRows, r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
+    uint32_t run = colbase[col] + part[(size_t)rb * W + col];
+    for (uint32_t r = r0; r < r1; ++r) { offset[(size_t)r * W + col] = run; run += count[(size_t)r * W + col]; }
 }
 
 // ---- trail export: the line list of draw() (12 floats per line, stream order) ---------------------------------
@@ -388,17 +560,17 @@ __global__ __launch_bounds__(256) void export_lines_kernel(const DepositParams p
     const uint32_t lines = p.W * p.rows;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
         const uint32_t row = t / p.W, col = t - row * p.W;
-        const uint32_t id = col * p.H + p.row0 + row, local = col * p.rows + row;
+        const uint32_t id = col * p.H + p.row0 + row;
         const uint32_t i = id / p.H, m = id - i * p.H;
         const DepositVertex a = dep_fetch(p, i, 2u * m), b = dep_fetch(p, i, 2u * m + 1u);
         const bool exists = a.live && b.live && !(a.px == b.px && a.py == b.py);
         if constexpr (WRITE) {
             if (!exists) continue;
-            float *o = out + 12ull * p.offset[local];
+            float *o = out + 12ull * p.offset[t];
             o[0] = a.px; o[1] = a.py; o[2] = b.px; o[3] = b.py;
             for (int k = 0; k < 4; ++k) { o[4 + k] = a.c[k]; o[8 + k] = b.c[k]; }
         } else {
-            p.count[local] = exists ? 1u : 0u;
+            p.count[t] = exists ? 1u : 0u;
         }
     }
 }
@@ -503,46 +675,39 @@ int deposit_grid(uint32_t n)
 
 }  // namespace
 
-uint32_t deposit_scan_blocks(uint32_t n) { return (n + kScanBlock - 1) / kScanBlock; }
+uint32_t deposit_scan_words(uint32_t W, uint32_t rows) { return ((rows + kColRows - 1) / kColRows) * W + W; }
 
 void launch_deposit_count(const DepositParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(deposit_raster_kernel<false>, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_raster_kernel, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_raster_clipped_kernel, dim3(deposit_grid((p.W * p.rows + 15u) / 16u)), dim3(256), 0, s, p);
 }
 
-void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t s)
+// scratch: deposit_scan_words(W, rows) words (row-block partial sums, then the column bases)
+void launch_deposit_scan(const DepositParams &p, uint32_t *scratch, uint32_t *total, hipStream_t s)
 {
-    const uint32_t lines = p.W * p.rows, nb = deposit_scan_blocks(lines);
-    hipLaunchKernelGGL(scan_local_kernel, dim3(nb), dim3(256), 0, s, p.count, p.offset, block_sums, lines);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, s, block_sums, nb, total);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, s, p.offset, block_sums, lines);
+    const uint32_t nrb = (p.rows + kColRows - 1) / kColRows;
+    uint32_t *part = scratch, *colbase = scratch + (size_t)nrb * p.W;
+    const dim3 grid((p.W + 255u) / 256u, nrb);
+    hipLaunchKernelGGL(colscan_partial_kernel, grid, dim3(256), 0, s, p.count, p.W, p.rows, part);
+    hipLaunchKernelGGL(colscan_prefix_kernel, dim3((p.W + 255u) / 256u), dim3(256), 0, s, part, p.W, nrb, colbase);
+    hipLaunchKernelGGL(colscan_bases_kernel, dim3(1), dim3(1024), 0, s, p.W, colbase, total);
+    hipLaunchKernelGGL(colscan_offsets_kernel, grid, dim3(256), 0, s, p.count, p.W, p.rows, part, colbase, p.offset);
 }
 
 void launch_deposit_scatter(const DepositParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(deposit_raster_kernel<true>, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p);
+    const uint32_t patches = ((p.W + kPatchCols - 1) / kPatchCols) * ((p.rows + kPatchRows - 1) / kPatchRows);
+    hipLaunchKernelGGL(deposit_emit_kernel, dim3(patches < 65536u * 16u ? (patches ? patches : 1u) : 65536u * 16u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_emit_long_kernel, dim3(deposit_grid((p.W * p.rows + 15u) / 16u)), dim3(256), 0, s, p);
 }
 
-static int deposit_key_bits(const DepositParams &p)
+int deposit_key_bits(const DepositParams &p)
 {
     const uint32_t texels = (uint32_t)p.fw * (uint32_t)p.fh;
     int bits = 1;
     while (bits < 32 && (1ull << bits) < texels) ++bits;
     return bits;
-}
-
-size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total)
-{
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, p.keys, p.keys_sorted, p.slots, p.slots_sorted, (int)total, 0,
-                                             deposit_key_bits(p), (hipStream_t) nullptr);
-    return bytes;
-}
-
-hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t s)
-{
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, p.keys, p.keys_sorted, p.slots, p.slots_sorted, (int)total, 0,
-                                              deposit_key_bits(p), s);
 }
 
 void launch_export_mark(const DepositParams &p, hipStream_t s)
@@ -561,26 +726,6 @@ void launch_triangles(const float *positions, int ntri, float view_x, float view
     if (ntri <= 0) return;
     hipLaunchKernelGGL(triangle_setup_kernel, dim3((ntri + 63) / 64), dim3(64), 0, s, positions, ntri, view_x, view_y, w, h, polys);
     hipLaunchKernelGGL(triangle_fill_kernel, dim3(deposit_grid((uint32_t)w * (uint32_t)h)), dim3(256), 0, s, polys, ntri, color, img, w, h);
-}
-
-size_t deposit_sort64_temp_bytes(uint32_t total, int begin_bit, int end_bit)
-{
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)total, begin_bit, end_bit,
-                                             (hipStream_t) nullptr);
-    return bytes;
-}
-
-hipError_t launch_deposit_sort64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
-                                 uint32_t *vals_out, uint32_t total, int begin_bit, int end_bit, void *temp, size_t temp_bytes, hipStream_t s)
-{
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)total, begin_bit, end_bit, s);
-}
-
-void launch_deposit_iota(uint32_t *dst, uint32_t n, hipStream_t s)
-{
-    if (n) hipLaunchKernelGGL(deposit_iota_kernel, dim3(deposit_grid(n)), dim3(256), 0, s, dst, n);
 }
 
 void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t s)

@@ -113,7 +113,8 @@ struct DepositParams {
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
     double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)
-    uint32_t *count, *offset;    // per line (stream order): fragments, first slot in the fragment array
+    uint32_t *count, *offset;    // per line (row-major, as the threads walk): fragments, first slot in the stream-ordered fragment array
+    uint4 *record;               // per line (two uint4): the texels of a line of <= 8 fragments
     uint32_t *keys, *slots;      // per fragment (stream order): flow texel, own slot
     uint32_t *keys_sorted, *slots_sorted;   // the same after the stable sort by texel
     float4 *colors;              // per fragment (stream order): interpolated varying
@@ -151,22 +152,25 @@ void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial
                   th_counters *out, hipStream_t stream);
 void launch_counter_add(unsigned long long *counter, unsigned long long n, hipStream_t s);
 void launch_optical_flow(const OpticalFlowParams &p, hipStream_t stream);
-uint32_t deposit_scan_blocks(uint32_t texels);
+uint32_t deposit_scan_words(uint32_t W, uint32_t rows);
 void launch_deposit_count(const DepositParams &p, hipStream_t stream);
-void launch_deposit_scan(const DepositParams &p, uint32_t *block_sums, uint32_t *total, hipStream_t stream);
+void launch_deposit_scan(const DepositParams &p, uint32_t *scratch, uint32_t *total, hipStream_t stream);
 void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
+int deposit_key_bits(const DepositParams &p);
 void launch_export_mark(const DepositParams &p, hipStream_t stream);
 void launch_export_write(const DepositParams &p, float *out, hipStream_t stream);
 void launch_triangles(const float *positions, int ntri, float view_x, float view_y, float4 color, TrianglePoly *polys,
                       float4 *img, int w, int h, hipStream_t stream);
-size_t deposit_sort_temp_bytes(const DepositParams &p, uint32_t total);
-hipError_t launch_deposit_sort(const DepositParams &p, uint32_t total, void *temp, size_t temp_bytes, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
-// sharded form: 64-bit (texel, stream index) keys
-size_t deposit_sort64_temp_bytes(uint32_t total, int begin_bit, int end_bit);
-hipError_t launch_deposit_sort64(const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in,
-                                 uint32_t *vals_out, uint32_t total, int begin_bit, int end_bit, void *temp, size_t temp_bytes, hipStream_t stream);
-void launch_deposit_iota(uint32_t *dst, uint32_t n, hipStream_t stream);
+// stable LSD radix sort of (key, u32 value) pairs by key bits [begin_bit, end_bit) (th_sort.hip): the passes ping-pong
+// between the (a) and (b) buffers; returns 0 when the result is in (a), 1 when it is in (b)
+constexpr uint32_t kRadixBits = 8;
+size_t radix_sort_temp_bytes(uint32_t n, int begin_bit, int end_bit);
+// iota: the values are the elements' positions 0..n-1 (vals_a need not be filled)
+int launch_radix_sort_u32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, uint32_t n, int begin_bit,
+                          int end_bit, void *temp, bool iota, hipStream_t stream);
+int launch_radix_sort_u64(unsigned long long *keys_a, uint32_t *vals_a, unsigned long long *keys_b, uint32_t *vals_b, uint32_t n,
+                          int begin_bit, int end_bit, void *temp, bool iota, hipStream_t stream);
 void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);
 void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                             const float4 *colors, uint32_t total, hipStream_t stream);
