@@ -491,6 +491,49 @@ def gen_geometry(r, only):
              uniforms=json.dumps(dict(kind="spawn_sample", N=n, samples=6, apply=3, uniforms=un)))
 
 
+def gen_spawn_map(r, only):
+    """Particles.spawn(map, pixels, offset) (src/particles.js:94-117): the [w, h, 4] staging array is filled x-outer /
+    y-inner and handed to setPixels - which texel ends up with map(x, y) is what these captures pin."""
+    if only and only != "spawn_map":
+        return
+    coef = [0.125, 0.0078125, -0.00048828125, -0.25, -0.001953125, 0.015625]        # exact in fp32
+    full, _ = r.spawn_map(16, coef)
+    save("spawn_map_full_16", buffers=np.stack(full), coef=np.array(coef), pixels=np.array([16, 16]), offset=np.array([0, 0]))
+    part, _ = r.spawn_map(24, coef, pixels=(5, 9), offset=(3, 11))
+    save("spawn_map_rect_24", buffers=np.stack(part), coef=np.array(coef), pixels=np.array([5, 9]), offset=np.array([3, 11]))
+
+
+TIMER_SCRIPT = [
+    ["new", 1000, 1000], ["set", "step", 1000 / 60], ["tick", None], ["tick", None], ["tick", None],
+    ["set", "paused", True], ["tick", None], ["tick", None], ["set", "paused", False], ["tick", None],
+    ["set", "end", 90], ["tick", None], ["tick", None], ["tick", None],                      # runs into `end`, pauses itself
+    ["new", 0, 0], ["set", "step", 30], ["set", "end", 100], ["set", "loop", True],
+    ["tick", None], ["tick", None], ["tick", None], ["tick", None], ["tick", None],          # wraps
+    ["new", 0, 0], ["set", "step", 30], ["set", "rate", -1], ["set", "end", -100], ["tick", None], ["tick", None],
+    ["tick", None], ["tick", None], ["tick", None],                                          # negative rate towards a negative end
+    ["new", 0, 0], ["set", "step", 25], ["set", "rate", -1.5], ["set", "end", 100], ["set", "loop", True],
+    ["tick", None], ["tick", None], ["tick", None],                                          # % keeps the dividend's sign
+    ["new", 5000, 5000], ["tick", 5250], ["set", "rate", 2], ["tick", 5300], ["seek", 100], ["tick", 5400],
+    ["scrub", 250], ["tick", 5450], ["set", "paused", True], ["tick", 5600], ["tick", 5700], ["set", "paused", False],
+    ["tick", 5800], ["reset", 6000, 5900], ["tick", 6100], ["set", "rate", -0.5], ["tick", 6300],
+    ["set", "end", -400], ["tick", 6500], ["tick", 7500], ["tick", 7600],                    # wall clock into a negative end
+]
+
+
+def gen_timer(r, only):
+    """src/timer.js:24-60 through the reference's own class: fixed step, wall clock, pause absorbing into `offset`,
+    end / loop, negative rates, seek / scrub / reset."""
+    if only and only != "timer":
+        return
+    out = r.timer(TIMER_SCRIPT)
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, "timer_script.json")
+    with open(path, "w") as f:
+        json.dump({"ops": TIMER_SCRIPT, "columns": ["time", "dt", "offset", "since", "paused", "now"],
+                   "out": [[repr(float(v)) for v in row] for row in out]}, f, indent=0)
+    print("wrote timer_script.json (%d ops)" % len(TIMER_SCRIPT))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -507,6 +550,8 @@ def main():
     gen_spawn(r, args.only)
     gen_spawn_image(r, args.only)
     gen_geometry(r, args.only)
+    gen_spawn_map(r, args.only)
+    gen_timer(r, args.only)
 
 
 if __name__ == "__main__":

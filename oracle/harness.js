@@ -14,6 +14,11 @@
  *   {kind:'deposit', ...}                -> reference Tendrils.draw(): the particle
  *                                           lines (previous -> current) blended
  *                                           into the flow FBO
+ *   {kind:'spawn_map', ...}              -> reference Particles.spawn(map, pixels, offset) with a
+ *                                           position-dependent map on a non-square staging
+ *                                           array, every ring buffer read back
+ *   {kind:'timer', ...}                  -> a scripted sequence of operations on the reference's
+ *                                           own Timer class (tendrils.timer.constructor)
  *   {kind:'shader', ...}                 -> one full-screen pass of a compiled
  *                                           reference shader string (spawners,
  *                                           optical flow) handed in by python
@@ -233,6 +238,56 @@
     return {out: f32ToB64(readFBO(gl, job.outW, job.outH)), err: gl.getError()};
   }
 
+  // ---- reference Particles.spawn(map, pixels, offset) --------------------------
+  // map(data, x, y) = (a0 + ax*x + ay*y, b0 + bx*x + by*y, x, y): affine in the loop indices, with coefficients that
+  // are exact in fp32 for the sizes used - every staging cell, and so every texel, gets a value that names its (x, y)
+  function runSpawnMap(job) {
+    var T = window.Tendrils, N = job.N;
+    var gl = getGL(job.viewW, job.viewH, T);
+    var t = new T.Tendrils(gl, {});
+    t.resize();
+    t.setup(N);                                   // 2 ring buffers, all inert
+    var P = t.particles, c = job.coef;
+    var map = function (data, x, y) {
+      data[0] = c[0] + c[1] * x + c[2] * y;
+      data[1] = c[3] + c[4] * x + c[5] * y;
+      data[2] = x;
+      data[3] = y;
+    };
+    if (job.pixels) {
+      var w = job.pixels[0], h = job.pixels[1];
+      // an ndarray like particles.pixels (shape [w, h, 4], row-major strides) made by the bundle's own ndarray class
+      var px = new P.pixels.constructor(new Float32Array(w * h * 4), w, h, 4, h * 4, 4, 1, 0);
+      P.spawn(map, px, job.offset || [0, 0]);
+    } else P.spawn(map);
+    var out = [];
+    for (var b = 0; b < P.buffers.length; ++b) {
+      P.buffers[b].bind();
+      out.push(f32ToB64(readFBO(gl, N, N)));
+    }
+    return {out: out, shape: [P.pixels.shape[0], P.pixels.shape[1], P.pixels.shape[2]], err: gl.getError()};
+  }
+
+  // ---- the reference's Timer, scripted ------------------------------------------
+  function runTimer(job) {
+    var T = window.Tendrils;
+    var gl = getGL(4, 4, T);
+    var Timer = new T.Tendrils(gl, {}).timer.constructor;
+    var tm = null, out = [];
+    for (var i = 0; i < job.ops.length; ++i) {
+      var op = job.ops[i];
+      if (op[0] === 'new') tm = new Timer(op[1], op[2]);
+      else if (op[0] === 'set') tm[op[1]] = op[2];
+      else if (op[0] === 'tick') tm.tick(op[1]);
+      else if (op[0] === 'seek') tm.seek(op[1]);
+      else if (op[0] === 'scrub') tm.scrub(op[1]);
+      else if (op[0] === 'reset') tm.reset(op[1], op[2]);
+      else throw new Error('unknown timer op ' + op[0]);
+      out.push([tm.time, tm.dt, tm.offset, tm.since, tm.paused ? 1 : 0, tm.now(op[0] === 'tick' ? op[1] : 12345)]);
+    }
+    return {out: out};
+  }
+
   window.Plotly = {
     version: '2.0.0',
     toImage: function (fig) {
@@ -250,6 +305,8 @@
                  threads: navigator.hardwareConcurrency};
         } else if (job.kind === 'logic') res = runLogic(job);
         else if (job.kind === 'deposit') res = runDeposit(job);
+        else if (job.kind === 'spawn_map') res = runSpawnMap(job);
+        else if (job.kind === 'timer') res = runTimer(job);
         else if (job.kind === 'shader') res = runShader(job);
         else res = {error: 'unknown job kind'};
       } catch (e) {

@@ -110,6 +110,26 @@ class RefRunner:
         w, h = res["flowShape"]
         return _f32(res["out"], (h, w, 4)), res
 
+    # -- reference Particles.spawn(map, pixels, offset) ------------------------------
+    def spawn_map(self, n, coef, pixels=None, offset=None, view=(32, 32)):
+        """Returns the ring buffers ([N,N,4] each) after particles.spawn(map, pixels, offset) with
+        map(data,x,y) = (c0+c1*x+c2*y, c3+c4*x+c5*y, x, y)."""
+        job = {"kind": "spawn_map", "N": int(n), "viewW": int(view[0]), "viewH": int(view[1]), "coef": [float(v) for v in coef]}
+        if pixels is not None:
+            job["pixels"] = [int(pixels[0]), int(pixels[1])]
+            job["offset"] = [int(offset[0]), int(offset[1])] if offset is not None else [0, 0]
+        res = self._run(job)
+        if res.get("err"):
+            raise RuntimeError("GL error %s" % res["err"])
+        return [_f32(o, (n, n, 4)) for o in res["out"]], res
+
+    # -- the reference's Timer class, scripted ---------------------------------------
+    def timer(self, ops):
+        """ops: list of ['new', now, since] | ['set', field, value] | ['tick', now|None] | ['seek', to] | ['scrub', by] |
+        ['reset', now, since]; returns [len(ops), 6] float64: time, dt, offset, since, paused, now(..) after every op."""
+        res = self._run({"kind": "timer", "ops": ops})
+        return np.array(res["out"], dtype=np.float64)
+
     # -- compiled shader strings of demo.js --------------------------------------
     def demo_shaders(self):
         if self._demo_shaders is None:
