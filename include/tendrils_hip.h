@@ -8,8 +8,9 @@
  * 432-457) over WebGL FBO ping-pong.  Each entry point below replaces one of
  * those GL-backed operations; the ctypes binding (tendrils_amd/_capi.py) binds exactly these
  * symbols and the N-API shim (tendrils_amd/csrc/th_napi.cc) all of them except the multi-GPU
- * exchange primitives (th_deposit_emit / _merge / _set_halo, th_flow_device_ptr: the sharded
- * host is the Python one, over torch.distributed) and th_spawn_image_download.
+ * exchange primitives (th_deposit_emit / _merge / _set_halo, th_flow_device_ptr, th_state_device_ptr,
+ * th_stream, th_stats_async: the sharded host is the Python one, over torch.distributed - INTEGRATION.md),
+ * th_spawn_image_download and th_slot_order.
  *
  * Conventions
  *  - plain C, no exceptions across the boundary; every call returns th_status
@@ -261,6 +262,33 @@ th_status th_timer_stop(th_context *ctx, float *elapsed_ms);           /* synchr
  * number of launches since the last read, and resets. */
 th_status th_kernel_timing(th_context *ctx, int32_t enable);
 th_status th_kernel_timing_read(th_context *ctx, float *mean_ms, int32_t *launches);
+/* The context's current texture shapes, for bindings that must size host arrays: state (this context's band),
+ * flow / view, frames (0 x 0 before th_frames_resize). */
+typedef struct th_shapes_info {
+    int32_t state_w, state_h, flow_w, flow_h, frames_w, frames_h;
+} th_shapes_info;
+th_status th_shapes(th_context *ctx, th_shapes_info *out);
+
+/* ---- view pass of Tendrils.draw() (src/index.js:315-337): the particles' lines with the colours of
+ * src/render/index.vert:58-100, blended in primitive order into an RGBA8 image of the drawing buffer's size
+ * (= the flow texture's shape, viewRes).  Same rasteriser as the flow pass (the reference draws both with gl.LINES;
+ * captures: a context without multisampling, lineWidth 1).  sinTerm = sin(time*flowDecay), evaluated by the host: a
+ * uniform-only expression whose value GLSL leaves to the implementation. */
+typedef struct th_render_uniforms {
+    float viewSize[2];
+    float time, speedLimit, flowDecay, speedAlpha, colorMapAlpha, sinTerm;
+    float baseColor[4], flowColor[4];
+} th_render_uniforms;
+th_status th_view_draw(th_context *ctx, const th_render_uniforms *u, uint64_t *fragments);
+/* Tendrils.drawFill / drawFade (src/index.js:342-356): a full-screen colour blended SRC_ALPHA / ONE_MINUS_SRC_ALPHA */
+th_status th_view_fill(th_context *ctx, const float rgba[4]);
+th_status th_view_clear(th_context *ctx);                              /* gl.clear(COLOR_BUFFER_BIT), clear colour 0 */
+th_status th_view_download(th_context *ctx, uint8_t *rgba8);           /* flow-shape RGBA8, row-major */
+/* tendrils.colorMap (src/index.js:94-96: a 1x1 float FBO unless given): RGBA32F, NEAREST, CLAMP_TO_EDGE */
+th_status th_colormap_upload(th_context *ctx, const float *rgba, int32_t w, int32_t h);
+/* th_export_lines with the view pass's vertex colours in place of the flow varyings */
+th_status th_export_view_lines(th_context *ctx, const th_render_uniforms *u, float *lines, uint64_t capacity, uint64_t *count);
+
 /* Slot layout of the ring (build-defined, invisible in every result): how many ring buffers are held in a
  * tile-sorted slot order, integrator passes since the last sort, and the flow taps since then that left the
  * LDS-staged window of their workgroup (served by the global gather instead).  Synchronises. */

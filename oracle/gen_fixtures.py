@@ -491,6 +491,34 @@ def gen_geometry(r, only):
              uniforms=json.dumps(dict(kind="spawn_sample", N=n, samples=6, apply=3, uniforms=un)))
 
 
+def gen_view(r, only):
+    """Tendrils.draw()'s VIEW pass (src/index.js:315-337, src/render/index.vert:58-100) on the reference, for the input
+    states of some of the deposit fixtures: the default framebuffer (RGBA8) read back after draw(), on a context without
+    multisampling (the view's width-1 lines then follow the flow pass's rasteriser).  Stored sparsely."""
+    def case(name, source, uniforms=None, time=None):
+        if only and only not in name:
+            return
+        d = np.load(os.path.join(GOLDEN, source + ".npz"))
+        meta = json.loads(str(d["uniforms"]))
+        cur, prev = d["current"], d["previous"]
+        fw, fh = meta["viewRes"]
+        t = meta["time"] if time is None else time
+        out, res = r.deposit(cur, prev, uniforms=dict(meta.get("overrides", {}), **(uniforms or {})), time=t, view=(fw, fh), want_view=True)
+        view = res["view_out"]
+        idx = np.flatnonzero(view.any(-1)).astype(np.int32)
+        st = res["state"]
+        m = dict(kind="view", source=source, N=meta["N"], viewRes=[fw, fh], viewSize=res["viewSize"], time=t, samples=res["samples"],
+                 render={k: st[k] for k in ("speedLimit", "flowDecay", "speedAlpha", "colorMapAlpha", "baseColor", "flowColor", "lineWidth")})
+        save(name, idx=idx, val=view.reshape(-1, 4)[idx], uniforms=json.dumps(m))
+
+    case("view_isolated_64", "deposit_isolated_64")
+    case("view_overlap_32", "deposit_overlap_32")
+    case("view_nonsquare_32", "deposit_nonsquare_flow_32")
+    case("view_border_48", "deposit_border_48")
+    case("view_colours_32", "deposit_long_lines_32", time=2718.0,
+         uniforms=dict(baseColor=[0.9, 0.4, 0.1, 0.7], flowColor=[0.2, 0.7, 1.0, 0.35], speedAlpha=2.5, flowDecay=0.012))
+
+
 def gen_spawn_map(r, only):
     """Particles.spawn(map, pixels, offset) (src/particles.js:94-117): the [w, h, 4] staging array is filled x-outer /
     y-inner and handed to setPixels - which texel ends up with map(x, y) is what these captures pin."""
@@ -550,6 +578,7 @@ def main():
     gen_spawn(r, args.only)
     gen_spawn_image(r, args.only)
     gen_geometry(r, args.only)
+    gen_view(r, args.only)
     gen_spawn_map(r, args.only)
     gen_timer(r, args.only)
 

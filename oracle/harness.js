@@ -38,10 +38,10 @@
   function f32FromB64(s) { return new Float32Array(b64ToBytes(s).buffer); }
   function f32ToB64(f) { return bytesToB64(new Uint8Array(f.buffer, f.byteOffset, f.byteLength)); }
 
-  function getGL(w, h, T) {
+  function getGL(w, h, T, settings) {
     var c = document.createElement('canvas');
     c.width = w; c.height = h;
-    var gl = c.getContext('webgl', T ? T.glSettings : {preserveDrawingBuffer: true});
+    var gl = c.getContext('webgl', settings || (T ? T.glSettings : {preserveDrawingBuffer: true}));
     if (!gl) throw new Error('no webgl');
     if (!gl.getExtension('OES_texture_float')) throw new Error('no OES_texture_float');
     gl.getExtension('WEBGL_color_buffer_float');
@@ -139,7 +139,9 @@
   // ---- reference Tendrils.draw(): flow deposit ---------------------------------
   function runDeposit(job) {
     var T = window.Tendrils, N = job.N;
-    var gl = getGL(job.viewW, job.viewH, T);
+    // job.view: also return the view render of draw() (the default framebuffer, RGBA8) - on a context without
+    // multisampling, so that the view's lines are rasterised by the same rules as the flow pass's
+    var gl = getGL(job.viewW, job.viewH, T, job.view ? {preserveDrawingBuffer: true, antialias: false, alpha: true, premultipliedAlpha: false} : null);
     var t = new T.Tendrils(gl, {});
     t.resize();
     t.setup(N);
@@ -155,9 +157,16 @@
     gl.enable(gl.BLEND);
     gl.blendFunc(gl.SRC_ALPHA, gl.ONE_MINUS_SRC_ALPHA);
     t.draw();
+    var view = null;
+    if (job.view) {
+      gl.bindFramebuffer(gl.FRAMEBUFFER, null);
+      var px = new Uint8Array(4 * job.viewW * job.viewH);
+      gl.readPixels(0, 0, job.viewW, job.viewH, gl.RGBA, gl.UNSIGNED_BYTE, px);
+      view = bytesToB64(px);
+    }
     t.flow.bind();
     var out = f32ToB64(readFBO(gl, t.flow.shape[0], t.flow.shape[1]));
-    return {out: out, lineWidthRange: Array.prototype.slice.call(gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE)),
+    return {out: out, view: view, samples: gl.getParameter(gl.SAMPLES), lineWidthRange: Array.prototype.slice.call(gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE)),
             lineWidth: gl.getParameter(gl.LINE_WIDTH),
             viewSize: [t.viewSize[0], t.viewSize[1]], viewRes: [t.viewRes[0], t.viewRes[1]],
             flowShape: [t.flow.shape[0], t.flow.shape[1]], state: t.state, err: gl.getError()};

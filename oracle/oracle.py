@@ -77,6 +77,22 @@ class DepositUniforms(C.Structure):
                 ("time", C.c_float), ("speedLimit", C.c_float)]
 
 
+class RenderUniforms(C.Structure):
+    _fields_ = [("speedLimit", C.c_float), ("flowDecay", C.c_float), ("speedAlpha", C.c_float), ("colorMapAlpha", C.c_float),
+                ("sinTerm", C.c_float), ("baseColor", C.c_float * 4), ("flowColor", C.c_float * 4)]
+
+
+def render_uniforms(time, speedLimit=0.01, flowDecay=0.005, speedAlpha=0.000001, colorMapAlpha=0.4,
+                    baseColor=(1, 1, 1, 0.5), flowColor=(1, 1, 1, 0.04), sin_term=None, **_):
+    """defaults: src/index.js:58-65; sin(time*flowDecay) in double, rounded once (what the host mirrors pass down)"""
+    import math
+    r = RenderUniforms(speedLimit=speedLimit, flowDecay=flowDecay, speedAlpha=speedAlpha, colorMapAlpha=colorMapAlpha,
+                       sinTerm=math.sin(float(np.float32(time)) * float(np.float32(flowDecay))) if sin_term is None else sin_term)
+    for k in range(4):
+        r.baseColor[k], r.flowColor[k] = float(baseColor[k]), float(flowColor[k])
+    return r
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -250,6 +266,50 @@ def triangles(positions, shape, view_size=(1.0, 1.0), color=(1.0, 1.0, 1.0, 1.0)
     col = np.asarray(color, np.float32)
     lib().to_triangles(_fp(pos), len(pos) // 6, _fp(vs), _fp(col), _fp(out), int(w), int(h))
     return out
+
+
+def view_render(current, previous, view, time, view_size=(1.0, 1.0), colormap=None, **uniforms):
+    """Tendrils.draw()'s view pass: blends the particle lines into a copy of `view` [vh, vw, 4] uint8.
+    Returns (view_out, fragments)."""
+    current = np.ascontiguousarray(current, np.float32)
+    previous = np.ascontiguousarray(previous, np.float32)
+    out = np.array(view, np.uint8, copy=True, order="C")
+    h, w = current.shape[:2]
+    vh, vw = out.shape[:2]
+    r = render_uniforms(time, **uniforms)
+    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(r.speedLimit))
+    u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+    cm = None if colormap is None else np.ascontiguousarray(colormap, np.float32)
+    L = lib()
+    L.to_view_render.restype = C.c_long
+    n = L.to_view_render(C.byref(u), C.byref(r), _fp(cm) if cm is not None else None, 0 if cm is None else cm.shape[1],
+                         0 if cm is None else cm.shape[0], _fp(current), _fp(previous),
+                         out.ctypes.data_as(C.POINTER(C.c_uint8)), vw, vh)
+    return out, n
+
+
+def view_fill(view, color):
+    out = np.array(view, np.uint8, copy=True, order="C")
+    col = np.asarray(color, np.float32)
+    lib().to_view_fill(out.ctypes.data_as(C.POINTER(C.c_uint8)), out.shape[1], out.shape[0], _fp(col))
+    return out
+
+
+def export_view_lines(current, previous, time, view_size=(1.0, 1.0), colormap=None, **uniforms):
+    """The line list of draw() with the view pass's vertex colours: [n, 12] float32 in stream order."""
+    current = np.ascontiguousarray(current, np.float32)
+    previous = np.ascontiguousarray(previous, np.float32)
+    h, w = current.shape[:2]
+    r = render_uniforms(time, **uniforms)
+    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(r.speedLimit))
+    u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
+    cm = None if colormap is None else np.ascontiguousarray(colormap, np.float32)
+    out = np.empty((w * h, 12), np.float32)
+    L = lib()
+    L.to_export_view_lines.restype = C.c_long
+    n = L.to_export_view_lines(C.byref(u), C.byref(r), _fp(cm) if cm is not None else None, 0 if cm is None else cm.shape[1],
+                               0 if cm is None else cm.shape[0], _fp(current), _fp(previous), _fp(out), w * h)
+    return out[:n].copy()
 
 
 def export_lines(current, previous, time, view_size=(1.0, 1.0), speedLimit=0.01):

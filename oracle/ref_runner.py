@@ -95,11 +95,13 @@ class RefRunner:
         return outs, res
 
     # -- reference Tendrils.draw(): flow deposit ------------------------------------
-    def deposit(self, current, previous, flow=None, uniforms=None, time=0.0, view=(64, 64), view_size=None):
-        """current/previous: [N,N,4] state textures; returns the flow FBO [H,W,4] after draw()."""
+    def deposit(self, current, previous, flow=None, uniforms=None, time=0.0, view=(64, 64), view_size=None, want_view=False):
+        """current/previous: [N,N,4] state textures; returns the flow FBO [H,W,4] after draw() (want_view: and, in
+        res["view_out"], the view render [H,W,4] uint8 of the same draw() on a context without multisampling)."""
         N = current.shape[0]
         job = {"kind": "deposit", "N": N, "viewW": int(view[0]), "viewH": int(view[1]), "state": uniforms or {},
-               "time": float(time), "inputs": {"current": _b64(current, np.float32), "previous": _b64(previous, np.float32)}}
+               "time": float(time), "view": bool(want_view),
+               "inputs": {"current": _b64(current, np.float32), "previous": _b64(previous, np.float32)}}
         if flow is not None:
             job["inputs"]["flow"] = _b64(flow, np.float32)
         if view_size is not None:
@@ -108,6 +110,8 @@ class RefRunner:
         if res.get("err"):
             raise RuntimeError("GL error %s" % res["err"])
         w, h = res["flowShape"]
+        if res.get("view"):
+            res["view_out"] = np.frombuffer(base64.b64decode(res["view"]), dtype=np.uint8).reshape(int(view[1]), int(view[0]), 4).copy()
         return _f32(res["out"], (h, w, 4)), res
 
     # -- reference Particles.spawn(map, pixels, offset) ------------------------------

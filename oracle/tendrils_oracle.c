@@ -537,7 +537,7 @@ void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, 
  *                   them, unclamped); coinciding snapped endpoints give the first vertex's values
  *   blend           SRC_ALPHA, ONE_MINUS_SRC_ALPHA on all four channels, lines in stream order (src/index.js:267-268)
  * ------------------------------------------------------------------------------------------------------------- */
-typedef struct { int live; float px, py; float c[4]; } deposit_vertex;
+typedef struct { int live; float px, py; float c[4]; float uvx, uvy; const float *state; } deposit_vertex;
 
 static void deposit_fetch(const to_deposit_uniforms *u, const float *current, const float *previous,
                           int i, int j, deposit_vertex *v)
@@ -557,6 +557,48 @@ static void deposit_fetch(const to_deposit_uniforms *u, const float *current, co
     v->py = t[1] * u->viewSize[1];
     v->c[0] = t[2]; v->c[1] = t[3]; v->c[2] = u->time;
     v->c[3] = fminf(sqrtf(t[2] * t[2] + t[3] * t[3]) / u->speedLimit, 1.0f);
+    v->uvx = uvx; v->uvy = uvy; v->state = t;
+}
+
+/* The view pass of draw() (src/index.js:333-337) sends the same vertex stream through src/render/index.vert:58-100
+ * instead: position as above, colour = base colour + colour map + flow-aligned colour, alpha scaled by the speed and
+ * a vignette.  Operation order as in the shader; sin(time*flowDecay) is a uniform-only expression whose value is
+ * implementation-defined - the caller evaluates it (sinTerm).  glsl-map: outMin + (outMax-outMin)*(v-inMin)/(inMax-inMin);
+ * mix(a, b, t) = a*(1-t) + b*t; bezier(vec3) and vignette(): src/utils/bezier.glsl:9-13, src/filter/vignette.glsl:5-28. */
+static void render_color(const to_render_uniforms *r, const float *state, float uvx, float uvy, int W, int H,
+                         const float *colormap, int cw, int ch, float *c)
+{
+    const float posx = state[0], posy = state[1];
+    const float velx = state[2] / r->speedLimit, vely = state[3] / r->speedLimit;
+    const float speedRate = fminf((velx * velx + vely * vely) / r->speedAlpha, 1.0f);
+    /* colour map at uv*geomRes/dataRes, geomRes = [W, 2H] */
+    const float mu = uvx * (float)W / (float)W, mv = uvy * (float)(2 * H) / (float)H;
+    const float *mt = colormap ? colormap + 4 * ((size_t)nearest_texel(mv, ch) * cw + nearest_texel(mu, cw)) : NULL;
+    float mapped[4];
+    for (int k = 0; k < 4; ++k) mapped[k] = (mt ? mt[k] : 0.0f) * r->colorMapAlpha;
+    /* flowAxisR/G/B = angleToVec(0), (tau/3), (2 tau/3) as the shader's literals */
+    const float axr[2] = {1.0f, 0.0f}, axg[2] = {-0.5000000000000004f, -0.8660254037844385f}, axb[2] = {-0.4999999999999998f, 0.8660254037844387f};
+    const float al[3] = {velx * axr[0] + vely * axr[1], velx * axg[0] + vely * axg[1], velx * axb[0] + vely * axb[1]};
+    const float gbr[3] = {al[1] * (1.0f - r->flowDecay), al[2] * (1.0f - r->flowDecay), al[0] * (1.0f - r->flowDecay)};
+    float fa[3];
+    for (int k = 0; k < 3; ++k) {
+        const float m = al[k] * (1.0f - r->sinTerm) + gbr[k] * r->sinTerm;
+        fa[k] = 0.0f + (1.0f - 0.0f) * (m - -1.0f) / (1.0f - -1.0f);
+    }
+    const float flw[4] = {r->flowColor[0] * fa[0], r->flowColor[1] * fa[1], r->flowColor[2] * fa[2], r->flowColor[3]};
+    const float *terms[3] = {r->baseColor, mapped, flw};
+    for (int k = 0; k < 4; ++k) c[k] = 0.0f;
+    for (int t = 0; t < 3; ++t) {
+        const float a = terms[t][3];
+        const float pre[4] = {terms[t][0] * a, terms[t][1] * a, terms[t][2] * a, a};
+        for (int k = 0; k < 4; ++k) c[k] = c[k] + fminf(fmaxf(pre[k], 0.0f), 1.0f);       /* clamp(x, min, max) = min(max(x, min), max) */
+    }
+    /* vignette(pos, center = 0, limit = 1, curve = falloff = (0.2, 1, 1)), clamped to fadeRange = (0.2, 1) */
+    const float amount = fminf(1.0f - (sqrtf(posx * posx + posy * posy) / 1.0f), 1.0f);
+    const float ut = 1.0f - amount;
+    const float bz = (0.2f * ut + 1.0f * amount) * ut + (1.0f * ut + 1.0f * amount) * amount;
+    const float vg = fmaxf(0.0f, bz);
+    c[3] = c[3] * (speedRate * fminf(fmaxf(vg, 0.2f), 1.0f));
 }
 
 static inline long ceil_div(long long a, long long b)     /* b > 0 */
@@ -568,8 +610,10 @@ static inline long ceil_div(long long a, long long b)     /* b > 0 */
 
 static inline int snap16(float ndc, float scale, float offset) { return (int)lrintf(ndc * scale + offset); }
 
-long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const float *previous,
-                     float *flow, int fw, int fh, int32_t *coverage)
+/* the rasteriser and the in-order blend; r == NULL: the flow pass into `flow` (RGBA32F), else the view pass into `view`
+ * (RGBA8: the fragment colour is clamped to [0, 1], blended with the stored colour c/255 and stored as round(255 x)) */
+static long deposit_core(const to_deposit_uniforms *u, const to_render_uniforms *r, const float *colormap, int cw, int ch,
+                         const float *current, const float *previous, float *flow, uint8_t *view, int fw, int fh, int32_t *coverage)
 {
     const int W = u->data_w, H = u->data_h;
     const float wx16 = 8.0f * (float)fw, wy16 = 8.0f * (float)fh;          /* 16 * viewport/2 */
@@ -583,6 +627,10 @@ long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const f
             deposit_fetch(u, current, previous, i, 2 * m, &a);
             deposit_fetch(u, current, previous, i, 2 * m + 1, &b);
             if (!a.live || !b.live) continue;                                /* DEVIATION, see above */
+            if (r) {
+                render_color(r, a.state, a.uvx, a.uvy, W, H, colormap, cw, ch, a.c);
+                render_color(r, b.state, b.uvx, b.uvy, W, H, colormap, cw, ch, b.c);
+            }
             const float dx = (0.5f * (float)fw) * (b.px - a.px), dy = (0.5f * (float)fh) * (b.py - a.py);
             if (dx == 0.0f && dy == 0.0f) continue;
             /* fixed-point range: endpoints beyond 1024 half-widths of the view (or non-finite) deposit nothing */
@@ -678,9 +726,19 @@ long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const f
                             const float t = (float)num / (float)den;
                             for (int k = 0; k < 4; ++k) c[k] = a.c[k] + t * (b.c[k] - a.c[k]);
                         }
-                        float *d = flow + 4 * ((size_t)y * fw + x);
-                        const float sa = c[3], da = 1.0f - sa;
-                        for (int k = 0; k < 4; ++k) d[k] = c[k] * sa + d[k] * da;
+                        if (view) {
+                            uint8_t *q = view + 4 * ((size_t)y * fw + x);
+                            for (int k = 0; k < 4; ++k) c[k] = fminf(fmaxf(c[k], 0.0f), 1.0f);
+                            const float sa = c[3], da = 1.0f - sa;
+                            for (int k = 0; k < 4; ++k) {
+                                const float o = c[k] * sa + ((float)q[k] * (1.0f / 255.0f)) * da;
+                                q[k] = (uint8_t)(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
+                            }
+                        } else {
+                            float *d = flow + 4 * ((size_t)y * fw + x);
+                            const float sa = c[3], da = 1.0f - sa;
+                            for (int k = 0; k < 4; ++k) d[k] = c[k] * sa + d[k] * da;
+                        }
                         if (coverage) ++coverage[(size_t)y * fw + x];
                         ++fragments;
                     }
@@ -689,6 +747,32 @@ long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const f
         }
     }
     return fragments;
+}
+
+
+long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const float *previous,
+                     float *flow, int fw, int fh, int32_t *coverage)
+{
+    return deposit_core(u, NULL, NULL, 0, 0, current, previous, flow, NULL, fw, fh, coverage);
+}
+
+long to_view_render(const to_deposit_uniforms *u, const to_render_uniforms *r, const float *colormap, int cw, int ch,
+                    const float *current, const float *previous, uint8_t *view, int vw, int vh)
+{
+    return deposit_core(u, r, colormap, cw, ch, current, previous, NULL, view, vw, vh, NULL);
+}
+
+/* Tendrils.drawFill (src/index.js:350-356): one full-screen quad of `color`, blended like everything else */
+void to_view_fill(uint8_t *view, int vw, int vh, const float *color)
+{
+    float c[4];
+    for (int k = 0; k < 4; ++k) c[k] = fminf(fmaxf(color[k], 0.0f), 1.0f);
+    const float sa = c[3], da = 1.0f - sa;
+    for (size_t i = 0; i < (size_t)vw * vh; ++i)
+        for (int k = 0; k < 4; ++k) {
+            const float o = c[k] * sa + ((float)view[4 * i + k] * (1.0f / 255.0f)) * da;
+            view[4 * i + k] = (uint8_t)(fminf(fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
+        }
 }
 
 
@@ -783,6 +867,13 @@ void to_triangles(const float *positions, int ntri, const float *view_size, cons
  * Lines with an inert vertex or zero length are left out.  Returns the number of lines. */
 long to_export_lines(const to_deposit_uniforms *u, const float *current, const float *previous, float *out, long capacity)
 {
+    return to_export_view_lines(u, NULL, NULL, 0, 0, current, previous, out, capacity);
+}
+
+/* ... and with the view pass's vertex colours (src/render/index.vert:58-100) instead of the flow varyings when r != NULL */
+long to_export_view_lines(const to_deposit_uniforms *u, const to_render_uniforms *r, const float *colormap, int cw, int ch,
+                          const float *current, const float *previous, float *out, long capacity)
+{
     const int W = u->data_w, H = u->data_h;
     long n = 0;
     for (int i = 0; i < W; ++i) {
@@ -792,6 +883,10 @@ long to_export_lines(const to_deposit_uniforms *u, const float *current, const f
             deposit_fetch(u, current, previous, i, 2 * m + 1, &b);
             if (!a.live || !b.live) continue;
             if (a.px == b.px && a.py == b.py) continue;
+            if (r) {
+                render_color(r, a.state, a.uvx, a.uvy, W, H, colormap, cw, ch, a.c);
+                render_color(r, b.state, b.uvx, b.uvy, W, H, colormap, cw, ch, b.c);
+            }
             if (n < capacity) {
                 float *o = out + 12 * n;
                 o[0] = a.px; o[1] = a.py; o[2] = b.px; o[3] = b.py;

@@ -103,6 +103,22 @@ typedef struct to_deposit_uniforms {
 long to_flow_deposit(const to_deposit_uniforms *u, const float *current, const float *previous,
                      float *flow, int fw, int fh, int32_t *coverage);
 
+/* Uniforms of the view pass (src/render/index.vert:10-24; defaults src/index.js:58-65); sinTerm = sin(time*flowDecay)
+ * evaluated by the caller (implementation-defined in GLSL). */
+typedef struct to_render_uniforms {
+    float speedLimit, flowDecay, speedAlpha, colorMapAlpha, sinTerm;
+    float baseColor[4], flowColor[4];
+} to_render_uniforms;
+
+/* The view pass of draw(): the same lines with the render shader's colours, blended in stream order into an RGBA8
+ * image (vw x vh, the drawing buffer); colormap: cw x ch RGBA32F or NULL (= the 1x1 zero texture).  Returns the
+ * number of fragments. */
+long to_view_render(const to_deposit_uniforms *u, const to_render_uniforms *r, const float *colormap, int cw, int ch,
+                    const float *current, const float *previous, uint8_t *view, int vw, int vh);
+void to_view_fill(uint8_t *view, int vw, int vh, const float *color);
+long to_export_view_lines(const to_deposit_uniforms *u, const to_render_uniforms *r, const float *colormap, int cw, int ch,
+                          const float *current, const float *previous, float *out, long capacity);
+
 /* Trail export: the (previous -> current) line list of draw(), 12 floats per line (see the .c file). */
 long to_export_lines(const to_deposit_uniforms *u, const float *current, const float *previous, float *out, long capacity);
 

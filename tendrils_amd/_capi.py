@@ -71,6 +71,17 @@ class Counters(C.Structure):
                 ("sum_speed", C.c_double), ("max_speed", C.c_double)]
 
 
+class RenderUniforms(C.Structure):
+    _fields_ = [("viewSize", C.c_float * 2), ("time", C.c_float), ("speedLimit", C.c_float), ("flowDecay", C.c_float),
+                ("speedAlpha", C.c_float), ("colorMapAlpha", C.c_float), ("sinTerm", C.c_float),
+                ("baseColor", C.c_float * 4), ("flowColor", C.c_float * 4)]
+
+
+class ShapesInfo(C.Structure):
+    _fields_ = [("state_w", C.c_int32), ("state_h", C.c_int32), ("flow_w", C.c_int32), ("flow_h", C.c_int32),
+                ("frames_w", C.c_int32), ("frames_h", C.c_int32)]
+
+
 class SlotOrderInfo(C.Structure):
     _fields_ = [("sorted_buffers", C.c_int32), ("steps_since_sort", C.c_int32), ("window_misses", C.c_uint64),
                 ("sorts", C.c_uint64)]
@@ -127,6 +138,13 @@ PROTOTYPES = {
     "th_kernel_timing": (C.c_int32, [_ctx, C.c_int32]),
     "th_kernel_timing_read": (C.c_int32, [_ctx, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "th_slot_order": (C.c_int32, [_ctx, C.POINTER(SlotOrderInfo)]),
+    "th_shapes": (C.c_int32, [_ctx, C.POINTER(ShapesInfo)]),
+    "th_view_draw": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
+    "th_view_fill": (C.c_int32, [_ctx, _fp]),
+    "th_view_clear": (C.c_int32, [_ctx]),
+    "th_view_download": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),
+    "th_colormap_upload": (C.c_int32, [_ctx, _fp, C.c_int32, C.c_int32]),
+    "th_export_view_lines": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), _fp, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
 _NO_STATUS = {"th_abi_version", "th_last_error"}

@@ -138,6 +138,10 @@ struct th_context {
     float4 *dep_colors = nullptr;
     void *dep_temp = nullptr;
     size_t dep_lines = 0, dep_capacity = 0, dep_temp_bytes = 0;
+    uchar4 *view = nullptr;              // the view pass's RGBA8 drawing buffer (flow shape), lazily allocated
+    int32_t view_w = 0, view_h = 0;
+    float4 *colormap = nullptr;          // tendrils.colorMap (nullptr = the 1x1 zero texture)
+    int32_t cmap_w = 0, cmap_h = 0;
     float4 *image = nullptr;             // PixelSpawner's own buffer (TH_SOURCE_IMAGE)
     int32_t iw = 0, ih = 0;
     unsigned long long *d_respawned = nullptr;   // [0]: particles replaced by respawn passes, [1]: scratch (passes into `targets`)
@@ -509,7 +513,7 @@ th_status th_destroy(th_context *c)
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
     (void)hipFree(c->dep_colors); (void)hipFree(c->dep_temp);
-    (void)hipFree(c->image);
+    (void)hipFree(c->image); (void)hipFree(c->view); (void)hipFree(c->colormap);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
@@ -1228,12 +1232,8 @@ static th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::
     return deposit_scan_total(c, p, total);
 }
 
-th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *lines, uint64_t capacity, uint64_t *count)
+static th_status export_run(th_context *c, th::DepositParams &p, float *lines, uint64_t capacity, uint64_t *count)
 {
-    if (th_status s = use(c)) return s;
-    TH_REQUIRE(count, "null count");
-    th::DepositParams p;
-    if (th_status s = deposit_prepare(c, u, p)) return s;
     th::launch_export_mark(p, c->stream);
     uint32_t total = 0;
     if (th_status s = deposit_scan_total(c, p, &total)) return s;
@@ -1249,6 +1249,15 @@ th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *li
     (void)hipFree(d_out);
     TH_HIP(e);
     return TH_OK;
+}
+
+th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *lines, uint64_t capacity, uint64_t *count)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count, "null count");
+    th::DepositParams p;
+    if (th_status s = deposit_prepare(c, u, p)) return s;
+    return export_run(c, p, lines, capacity, count);
 }
 
 // per-fragment buffers for `total` fragments (grow-only)
@@ -1283,14 +1292,12 @@ static th_status deposit_temp(th_context *c, size_t need)
     return TH_OK;
 }
 
-th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
+// the fragments of the (prepared) pass `p`: count, emit, sort by texel, blend
+static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *fragments)
 {
-    if (th_status s = use(c)) return s;
-    if (c->cfg.height != c->cfg.global_height)
-        return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
-    th::DepositParams p;
     uint32_t total = 0;
-    if (th_status s = deposit_count(c, u, p, &total)) return s;
+    th::launch_deposit_count(p, c->stream);
+    if (th_status s = deposit_scan_total(c, p, &total)) return s;
     if (fragments) *fragments = total;
     if (total == 0) return TH_OK;
     if (th_status s = deposit_reserve(c, total, false)) return s;
@@ -1305,6 +1312,107 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
     return TH_OK;
+}
+
+th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
+    th::DepositParams p;
+    if (th_status s = deposit_prepare(c, u, p)) return s;
+    return deposit_run(c, p, fragments);
+}
+
+// ---- view pass ---------------------------------------------------------------------------------------------
+static th_status view_storage(th_context *c)
+{
+    if (c->view && c->view_w == c->fw && c->view_h == c->fh) return TH_OK;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->view);
+    c->view = nullptr; c->view_w = c->view_h = 0;
+    TH_HIP(hipMalloc((void **)&c->view, (size_t)c->fw * c->fh * sizeof(uchar4)));
+    TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->fw * c->fh * sizeof(uchar4), c->stream));     // a fresh drawing buffer is transparent black
+    c->view_w = c->fw; c->view_h = c->fh;
+    return TH_OK;
+}
+
+static th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositParams &p)
+{
+    TH_REQUIRE(u, "null uniforms");
+    th_deposit_uniforms d{};
+    d.viewSize[0] = u->viewSize[0]; d.viewSize[1] = u->viewSize[1]; d.time = u->time; d.speedLimit = u->speedLimit;
+    if (th_status s = deposit_prepare(c, &d, p)) return s;
+    p.mode = 1;
+    p.flow_decay = u->flowDecay; p.speed_alpha = u->speedAlpha; p.colormap_alpha = u->colorMapAlpha; p.sin_term = u->sinTerm;
+    for (int k = 0; k < 4; ++k) { p.base_color[k] = u->baseColor[k]; p.flow_color[k] = u->flowColor[k]; }
+    p.colormap = c->colormap; p.cw = c->cmap_w; p.ch = c->cmap_h;
+    return TH_OK;
+}
+
+th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "the view pass needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
+    if (th_status s = view_storage(c)) return s;
+    th::DepositParams p;
+    if (th_status s = view_params(c, u, p)) return s;
+    p.view = c->view;
+    return deposit_run(c, p, fragments);
+}
+
+th_status th_view_fill(th_context *c, const float rgba[4])
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba, "null colour");
+    if (th_status s = view_storage(c)) return s;
+    th::launch_view_fill(c->view, (size_t)c->view_w * c->view_h, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+th_status th_view_clear(th_context *c)
+{
+    if (th_status s = use(c)) return s;
+    if (th_status s = view_storage(c)) return s;
+    TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->view_w * c->view_h * sizeof(uchar4), c->stream));
+    return TH_OK;
+}
+
+th_status th_view_download(th_context *c, uint8_t *rgba8)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba8, "null pixels");
+    if (th_status s = view_storage(c)) return s;
+    TH_HIP(hipMemcpyAsync(rgba8, c->view, (size_t)c->view_w * c->view_h * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_colormap_upload(th_context *c, const float *rgba, int32_t w, int32_t h)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(rgba && w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad colour map %dx%d", w, h);
+    if (w != c->cmap_w || h != c->cmap_h) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->colormap);
+        c->colormap = nullptr; c->cmap_w = c->cmap_h = 0;
+        TH_HIP(hipMalloc((void **)&c->colormap, (size_t)w * h * sizeof(float4)));
+        c->cmap_w = w; c->cmap_h = h;
+    }
+    TH_HIP(hipMemcpyAsync(c->colormap, rgba, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_export_view_lines(th_context *c, const th_render_uniforms *u, float *lines, uint64_t capacity, uint64_t *count)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count, "null count");
+    th::DepositParams p;
+    if (th_status s = view_params(c, u, p)) return s;
+    return export_run(c, p, lines, capacity, count);
 }
 
 th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev)
@@ -1511,6 +1619,15 @@ th_status th_kernel_timing_read(th_context *c, float *mean_ms, int32_t *launches
     *launches = (int32_t)(c->kt_used / 2);
     *mean_ms = *launches ? (float)(sum / *launches) : 0.0f;
     c->kt_used = 0;
+    return TH_OK;
+}
+
+th_status th_shapes(th_context *c, th_shapes_info *out)
+{
+    TH_REQUIRE(c && out, "null argument");
+    out->state_w = c->cfg.width; out->state_h = c->cfg.height;
+    out->flow_w = c->fw; out->flow_h = c->fh;
+    out->frames_w = c->frw; out->frames_h = c->frh;
     return TH_OK;
 }
 

@@ -42,6 +42,49 @@ TH_D int dep_nearest(float u, int n)       // NEAREST + CLAMP_TO_EDGE on a float
     return (int)f;
 }
 
+// The view pass's vertex colour (src/render/index.vert:58-100): base colour + colour map + flow-aligned colour, each
+// pre-multiplied and clamped, alpha scaled by the speed and a vignette.  Operation order as in the shader (and in the
+// checker's restatement); sin(time*flowDecay) - a uniform-only expression, implementation-defined in GLSL - comes from
+// the host (sin_term).  glsl-map: outMin + (outMax-outMin)*(v-inMin)/(inMax-inMin); mix(a, b, t) = a*(1-t) + b*t.
+TH_D void dep_render_color(const DepositParams &p, float4 state, float uvx, float uvy, float (&c)[4])
+{
+    const float velx = state.z / p.speed_limit, vely = state.w / p.speed_limit;
+    const float speed_rate = __builtin_fminf((velx * velx + vely * vely) / p.speed_alpha, 1.0f);
+    float mapped[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.colormap) {       // uv*geomRes/dataRes, geomRes = [W, 2H]
+        const float mu = uvx * (float)p.W / (float)p.W, mv = uvy * (float)(2u * p.H) / (float)p.H;
+        const float4 m = p.colormap[(size_t)dep_nearest(mv, p.ch) * p.cw + dep_nearest(mu, p.cw)];
+        mapped[0] = m.x; mapped[1] = m.y; mapped[2] = m.z; mapped[3] = m.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mapped[k] = mapped[k] * p.colormap_alpha;
+    const float al[3] = {velx * 1.0f + vely * 0.0f, velx * -0.5000000000000004f + vely * -0.8660254037844385f,
+                         velx * -0.4999999999999998f + vely * 0.8660254037844387f};
+    const float gbr[3] = {al[1] * (1.0f - p.flow_decay), al[2] * (1.0f - p.flow_decay), al[0] * (1.0f - p.flow_decay)};
+    float flw[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float m = al[k] * (1.0f - p.sin_term) + gbr[k] * p.sin_term;
+        flw[k] = p.flow_color[k] * (0.0f + (1.0f - 0.0f) * (m - -1.0f) / (1.0f - -1.0f));
+    }
+    flw[3] = p.flow_color[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c[k] = 0.0f;
+    auto add = [&](const float *t) {
+        const float a = t[3];
+        const float pre[4] = {t[0] * a, t[1] * a, t[2] * a, a};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = c[k] + __builtin_fminf(__builtin_fmaxf(pre[k], 0.0f), 1.0f);
+    };
+    add(p.base_color); add(mapped); add(flw);
+    // vignette(pos, center = 0, limit = 1, curve = (0.2, 1, 1)) clamped to fadeRange (0.2, 1): src/filter/vignette.glsl:5-28
+    const float amount = __builtin_fminf(1.0f - (__builtin_sqrtf(state.x * state.x + state.y * state.y) / 1.0f), 1.0f);
+    const float ut = 1.0f - amount;
+    const float bz = (0.2f * ut + 1.0f * amount) * ut + (1.0f * ut + 1.0f * amount) * amount;
+    const float vg = __builtin_fmaxf(0.0f, bz);
+    c[3] = c[3] * (speed_rate * __builtin_fminf(__builtin_fmaxf(vg, 0.2f), 1.0f));
+}
+
 // vertex j of column i of the stream Particles.generateLUT([W, 2H]) through src/state/state-at-frame.glsl:12-22
 TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
 {
@@ -63,8 +106,10 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
     v.py = t.y * p.view_y;
-    v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
-    v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
+    if (p.mode == 0) {
+        v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
+        v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
+    } else dep_render_color(p, t, uvx, uvy, v.c);
     return v;
 }
 
@@ -462,6 +507,41 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams 
     }
 }
 
+// the view pass's blend: the RGBA8 drawing buffer - the fragment colour is clamped to [0, 1], blended with the stored
+// colour c/255 and stored as round(255 x), fragment after fragment (what the captured GL does)
+TH_D void dep_blend_rgba8(uchar4 &q, float4 c)
+{
+    c.x = __builtin_fminf(__builtin_fmaxf(c.x, 0.0f), 1.0f); c.y = __builtin_fminf(__builtin_fmaxf(c.y, 0.0f), 1.0f);
+    c.z = __builtin_fminf(__builtin_fmaxf(c.z, 0.0f), 1.0f); c.w = __builtin_fminf(__builtin_fmaxf(c.w, 0.0f), 1.0f);
+    const float sa = c.w, da = 1.0f - sa, k = 1.0f / 255.0f;
+    auto mix8 = [&](float src, unsigned char dst) {
+        const float o = src * sa + ((float)dst * k) * da;
+        return (unsigned char)(__builtin_fminf(__builtin_fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
+    };
+    q = make_uchar4(mix8(c.x, q.x), mix8(c.y, q.y), mix8(c.z, q.z), mix8(c.w, q.w));
+}
+
+__global__ __launch_bounds__(256) void deposit_blend_view_kernel(const DepositParams p, uint32_t total)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t texel = p.keys_sorted[i];
+        if (i > 0 && p.keys_sorted[i - 1] == texel) continue;
+        uchar4 d = p.view[texel];
+        for (uint32_t j = i; j < total && p.keys_sorted[j] == texel; ++j) dep_blend_rgba8(d, p.colors_sorted[j]);
+        p.view[texel] = d;
+    }
+}
+
+// Tendrils.drawFill (src/index.js:350-356): one full-screen quad of `color`, blended like everything else
+__global__ __launch_bounds__(256) void view_fill_kernel(uchar4 *view, size_t n, float4 color)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uchar4 d = view[i];
+        dep_blend_rgba8(d, color);
+        view[i] = d;
+    }
+}
+
 // sharded form: the same walk over fragments sorted by (texel, global stream index)
 __global__ __launch_bounds__(256) void deposit_blend64_kernel(float4 *flow, const unsigned long long *keys, const uint32_t *slots,
                                                               const float4 *colors, uint32_t total)
@@ -742,7 +822,13 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
 {
     launch_deposit_gather_colors(p.colors_sorted, p.colors, p.slots_sorted, total, s);
-    hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
+    if (p.mode == 0) hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
+    else hipLaunchKernelGGL(deposit_blend_view_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
+}
+
+void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t s)
+{
+    if (texels) hipLaunchKernelGGL(view_fill_kernel, dim3(deposit_grid((uint32_t)(texels < 0xffffffffull ? texels : 0xffffffffull))), dim3(256), 0, s, view, texels, color);
 }
 
 }  // namespace th

@@ -112,6 +112,13 @@ struct DepositParams {
     const float4 *halo_lo, *halo_hi;   // row row0-1 / row0+rows of the neighbouring bands: W texels of `cur`, then W of `prev`
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
+    // view pass (mode 1): the vertex colours of src/render/index.vert:58-100, blended into the RGBA8 view buffer
+    int32_t mode;                // 0 = flow pass (varying = vel, time, alpha), 1 = view pass
+    float flow_decay, speed_alpha, colormap_alpha, sin_term;
+    float base_color[4], flow_color[4];
+    const float4 *colormap;      // cw x ch RGBA32F, NEAREST / CLAMP (nullptr = the 1x1 zero texture)
+    int32_t cw, ch;
+    uchar4 *view;
     double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)
     uint32_t *count, *offset;    // per line (row-major, as the threads walk): fragments, first slot in the stream-ordered fragment array
     uint4 *record;               // per line (two uint4): the texels of a line of <= 8 fragments
@@ -162,6 +169,7 @@ void launch_export_write(const DepositParams &p, float *out, hipStream_t stream)
 void launch_triangles(const float *positions, int ntri, float view_x, float view_y, float4 color, TrianglePoly *polys,
                       float4 *img, int w, int h, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
+void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t stream);
 // stable LSD radix sort of (key, u32 value) pairs by key bits [begin_bit, end_bit) (th_sort.hip): the passes ping-pong
 // between the (a) and (b) buffers; returns 0 when the result is in (a), 1 when it is in (b)
 constexpr uint32_t kRadixBits = 8;

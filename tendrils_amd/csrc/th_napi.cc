@@ -234,23 +234,31 @@ napi_value FramesResize(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
-// (ctx, Float32Array) transfers; the caller sizes the array from the shapes it set
-#define CTX_F32(fn_name, th_fn)                                                  \
+// (ctx, Float32Array) transfers: the array must hold what the library will read or write - the size comes from the
+// context's own shapes (th_shapes), not from the caller
+static size_t texture_floats(th_context *c, int which)
+{
+    th_shapes_info s{};
+    if (th_shapes(c, &s) != TH_OK) return (size_t)-1;
+    if (which == 0) return (size_t)s.flow_w * s.flow_h * 4;
+    if (which == 1) return (size_t)s.state_w * s.state_h * 4;
+    return (size_t)s.frames_w * s.frames_h * 4;          // (bytes for the RGBA8 frames)
+}
+#define CTX_F32(fn_name, th_fn, which)                                           \
     napi_value fn_name(napi_env env, napi_callback_info info)                    \
     {                                                                            \
         Args a(env, info);                                                       \
         th_context *c = a.ctx(0);                                                \
         size_t n = 0;                                                            \
         float *px = static_cast<float *>(a.typed(1, napi_float32_array, &n));    \
-        int32_t expect = a.i32(2);                                               \
-        if (!a.ok || n < (size_t)expect) BAD_ARGS(#th_fn);                       \
+        if (!a.ok || n < texture_floats(c, which)) BAD_ARGS(#th_fn);             \
         TH_CALL(#th_fn, th_fn(c, px));                                           \
         return undefined(env);                                                   \
     }
-CTX_F32(FlowUpload, th_flow_upload)
-CTX_F32(FlowDownload, th_flow_download)
-CTX_F32(TargetsUpload, th_targets_upload)
-CTX_F32(TargetsDownload, th_targets_download)
+CTX_F32(FlowUpload, th_flow_upload, 0)
+CTX_F32(FlowDownload, th_flow_download, 0)
+CTX_F32(TargetsUpload, th_targets_upload, 1)
+CTX_F32(TargetsDownload, th_targets_download, 1)
 
 napi_value FramesUpload(napi_env env, napi_callback_info info)
 {
@@ -258,10 +266,92 @@ napi_value FramesUpload(napi_env env, napi_callback_info info)
     th_context *c = a.ctx(0);
     size_t n = 0;
     uint8_t *px = static_cast<uint8_t *>(a.typed(1, napi_uint8_array, &n));
-    int32_t expect = a.i32(2);
-    if (!a.ok || n < (size_t)expect) BAD_ARGS("th_frames_upload");
+    if (!a.ok || n < texture_floats(c, 2)) BAD_ARGS("th_frames_upload");
     TH_CALL("th_frames_upload", th_frames_upload(c, px));
     return undefined(env);
+}
+
+// ---- view pass --------------------------------------------------------------------------------------------
+// viewDraw(ctx, Float32Array(16) th_render_uniforms) -> fragments
+napi_value ViewDraw(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_render_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_view_draw");
+    uint64_t fragments = 0;
+    TH_CALL("th_view_draw", th_view_draw(c, &u, &fragments));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)fragments, &v));
+    return v;
+}
+
+// viewFill(ctx, Float32Array(4) rgba)
+napi_value ViewFill(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    float *rgba = static_cast<float *>(a.typed(1, napi_float32_array, &n));
+    if (!a.ok || n < 4) BAD_ARGS("th_view_fill");
+    TH_CALL("th_view_fill", th_view_fill(c, rgba));
+    return undefined(env);
+}
+
+napi_value ViewClear(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_view_clear");
+    TH_CALL("th_view_clear", th_view_clear(c));
+    return undefined(env);
+}
+
+// viewDownload(ctx) -> Uint8Array (flow shape, RGBA8, row-major)
+napi_value ViewDownload(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_view_download");
+    const size_t bytes = texture_floats(c, 0);       // flow texels x 4 channels, one byte each here
+    napi_value buf, arr;
+    void *data = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, bytes, &data, &buf));
+    TH_CALL("th_view_download", th_view_download(c, static_cast<uint8_t *>(data)));
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, bytes, buf, 0, &arr));
+    return arr;
+}
+
+// colormapUpload(ctx, Float32Array rgba, w, h)
+napi_value ColormapUpload(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    float *px = static_cast<float *>(a.typed(1, napi_float32_array, &n));
+    int32_t w = a.i32(2), h = a.i32(3);
+    if (!a.ok || w <= 0 || h <= 0 || n < (size_t)w * (size_t)h * 4) BAD_ARGS("th_colormap_upload");
+    TH_CALL("th_colormap_upload", th_colormap_upload(c, px, w, h));
+    return undefined(env);
+}
+
+// exportViewLines(ctx, Float32Array(16) th_render_uniforms) -> Float32Array (12 floats per line)
+napi_value ExportViewLines(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_render_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_export_view_lines");
+    uint64_t n = 0;
+    TH_CALL("th_export_view_lines", th_export_view_lines(c, &u, nullptr, 0, &n));
+    napi_value buf, arr;
+    void *data = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 12 * sizeof(float), &data, &buf));
+    if (n) TH_CALL("th_export_view_lines", th_export_view_lines(c, &u, static_cast<float *>(data), n, &n));
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)n * 12, buf, 0, &arr));
+    return arr;
 }
 
 // step(ctx, Float32Array(19) uniforms, target)
@@ -492,6 +582,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
         {"flowDeposit", FlowDeposit}, {"exportLines", ExportLines},
+        {"viewDraw", ViewDraw}, {"viewFill", ViewFill}, {"viewClear", ViewClear}, {"viewDownload", ViewDownload},
+        {"colormapUpload", ColormapUpload}, {"exportViewLines", ExportViewLines},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},
     };

@@ -39,10 +39,10 @@ class FlowTexture {
     this._shape = [wh[0] | 0, wh[1] | 0];
     if (this.owner.particles) native.flowResize(this.owner.particles.handle, this._shape[0], this._shape[1]);
   }
-  setPixels(texels) { native.flowUpload(this.owner.particles.handle, texels, this._shape[0] * this._shape[1] * 4); }
+  setPixels(texels) { native.flowUpload(this.owner.particles.handle, texels); }
   read(out) {
     const px = (out || new Float32Array(this._shape[0] * this._shape[1] * 4));
-    native.flowDownload(this.owner.particles.handle, px, px.length);
+    native.flowDownload(this.owner.particles.handle, px);
     return px;
   }
   clear() { native.flowClear(this.owner.particles.handle); }
@@ -52,10 +52,10 @@ class FlowTexture {
 // tendrils.targets (src/index.js:105,207)
 class TargetsTexture {
   constructor(owner) { this.owner = owner; this.shape = [1, 1]; }
-  setPixels(texels) { native.targetsUpload(this.owner.particles.handle, texels, this.shape[0] * this.shape[1] * 4); }
+  setPixels(texels) { native.targetsUpload(this.owner.particles.handle, texels); }
   read(out) {
     const px = (out || new Float32Array(this.shape[0] * this.shape[1] * 4));
-    native.targetsDownload(this.owner.particles.handle, px, px.length);
+    native.targetsDownload(this.owner.particles.handle, px);
     return px;
   }
   clear() { native.targetsClear(this.owner.particles.handle); }
@@ -87,6 +87,8 @@ class Tendrils {
     this.device = params.device | 0;
     this.mode = params.mode | 0;
     this.stateFormat = params.stateFormat | 0;
+    this.colorMap = (params.colorMap || null);     // { shape: [w, h], data: Float32Array } (null = the 1x1 zero texture)
+    this.renderView = (params.renderView !== false);   // draw() also runs the view pass, as the reference's does
   }
 
   setup(...rest) { this.setupParticles(...rest); this.reset(); return this; }
@@ -114,11 +116,39 @@ class Tendrils {
     this.particles.setup(numBuffers);
     this.targets.shape = shape;
     this.flow.shape = this.flow.shape;            // (re)create on the new context
+    if (this.colorMap) native.colormapUpload(this.particles.handle, this.colorMap.data, this.colorMap.shape[0], this.colorMap.shape[1]);
     return this;
   }
 
   clear() { this.clearView(); this.clearFlow(); return this; }
-  clearView() { return this; }
+  clearView() { native.viewClear(this.particles.handle); return this; }   // src/index.js:215-229 (no extra buffers here)
+
+  drawFade() {                                     // src/index.js:342-348
+    if (this.state.fadeColor[3] > 0) this.drawFill(this.state.fadeColor);
+    return this;
+  }
+
+  drawFill(color = this.state.fadeColor) {         // src/index.js:350-356
+    native.viewFill(this.particles.handle, new Float32Array(color));
+    return this;
+  }
+
+  // th_render_uniforms: viewSize, time, speedLimit, flowDecay, speedAlpha, colorMapAlpha, sin(time*flowDecay) - evaluated
+  // here, on fp32 operands as the shader would: GLSL leaves its value to the implementation -, baseColor, flowColor
+  renderUniforms() {
+    const s = this.state;
+    return new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, s.speedLimit, s.flowDecay, s.speedAlpha,
+      s.colorMapAlpha, Math.sin(Math.fround(this.timer.time) * Math.fround(s.flowDecay)), ...s.baseColor, ...s.flowColor]);
+  }
+
+  // the view buffer: Uint8Array, viewRes[0] x viewRes[1] RGBA8 in readPixels order
+  readView() { return native.viewDownload(this.particles.handle); }
+
+  setColorMap(texels, shape) {                     // tendrils.colorMap (src/index.js:94-96): RGBA32F texels, [w, h]
+    this.colorMap = { shape: [shape[0], shape[1]], data: texels };
+    if (this.particles) native.colormapUpload(this.particles.handle, texels, shape[0], shape[1]);
+    return this;
+  }
   clearFlow() { this.flow.clear(); return this; }   // src/index.js:231-236
   restart() { this.clear(); this.reset(); return this; }
 
@@ -161,14 +191,20 @@ class Tendrils {
 
   // Trail export (build-defined): the (previous -> current) line list this frame's draw() is made of,
   // 12 floats per line: p0.xy, p1.xy (clip space), then both vertices' (vel.x, vel.y, time, alpha).
-  exportLines() {
+  exportLines(view = false) {                      // view: the view pass's vertex colours instead of the flow varyings
+    if (view) return native.exportViewLines(this.particles.handle, this.renderUniforms());
     return native.exportLines(this.particles.handle,
       new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]));
   }
 
-  draw() {                                         // src/index.js:278-340: the flow pass (the view render is outside this build)
+  draw() {                                         // src/index.js:278-340: the flow pass, then the view pass
     this.fragments = native.flowDeposit(this.particles.handle,
       new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]));
+    if (this.renderView) {
+      if (this.state.autoClearView) this.clearView();
+      if (this.state.autoFade) this.drawFade();
+      this.viewFragments = native.viewDraw(this.particles.handle, this.renderUniforms());
+    }
     return this;
   }
 

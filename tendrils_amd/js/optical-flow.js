@@ -37,7 +37,7 @@ class OpticalFlow {
   step() { step(this.buffers); native.framesRotate(this.handle); }     // :60-62
 
   setPixels(pixels) {                              // :64-66, RGBA8 rows in texture order
-    native.framesUpload(this.handle, pixels, this.shape[0] * this.shape[1] * 4);
+    native.framesUpload(this.handle, pixels);
   }
 
   resize(size) {                                   // :68-70

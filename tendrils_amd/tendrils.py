@@ -1,9 +1,11 @@
 """Host mirror of the reference's simulation facade `Tendrils` (src/index.js:84-457) for the
 particle-update path: state uniforms, timer, flow/targets textures, step(), spawn(),
-spawnShader(), resize().  Rendering methods (draw, view buffers, fades) are out of scope
-of this build and are inert no-ops that keep call chains working.
+spawnShader(), resize(), and draw() = the flow pass + the view pass (the particles' lines with the
+render shader's colours into an RGBA8 image of the drawing buffer: `view`, read with read_view()).
+The multi-buffer screen passes (blur / copy shaders, src/screen) are outside this build.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -85,6 +87,27 @@ class FlowTexture:
         return _capi.TH_SOURCE_FLOW
 
 
+class ColorMap:
+    """tendrils.colorMap (src/index.js:94-96): RGBA32F, a 1x1 zero texture until set."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.shape = [1, 1]
+        self._pixels = None
+
+    def set_pixels(self, texels):
+        t = np.ascontiguousarray(texels, np.float32)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self.shape = [t.shape[1], t.shape[0]]
+        self._pixels = t
+        self.bind()
+
+    def bind(self):
+        if self._pixels is not None and self._o.particles is not None:
+            call("th_colormap_upload", self._o.particles._ctx, self._pixels.ctypes.data_as(_capi._fp),
+                 self.shape[0], self.shape[1])
+
+
 class TargetsTexture:
     """tendrils.targets (src/index.js:105,207): RGBA32F at the particle shape."""
 
@@ -124,6 +147,8 @@ class Tendrils:
         self.particles = None
         self.flow = FlowTexture(self)
         self.targets = TargetsTexture(self)
+        self.colorMap = params.get("colorMap") or ColorMap(self)
+        self.renderView = bool(params.get("renderView", True))     # draw() also runs the view pass (as the reference's does)
         self.buffers = []
         self.logicShader = None
         self.uniforms = dict(render={}, update={})
@@ -167,6 +192,9 @@ class Tendrils:
         self.particles.setup(numBuffers)
         self.targets.shape = shape
         self.flow.shape = self.flow.shape          # (re)create on the new context
+        if isinstance(self.colorMap, ColorMap):
+            self.colorMap._o = self
+            self.colorMap.bind()
         return self
 
     # -- clears ---------------------------------------------------------------------
@@ -175,8 +203,37 @@ class Tendrils:
         self.clearFlow()
         return self
 
-    def clearView(self):
+    def clearView(self):                                       # src/index.js:215-229 (no extra buffers here)
+        call("th_view_clear", self.particles._ctx)
         return self
+
+    def drawFade(self):                                        # src/index.js:342-348
+        if self.state["fadeColor"][3] > 0:
+            self.drawFill(self.state["fadeColor"])
+        return self
+
+    def drawFill(self, color=None):                            # src/index.js:350-356
+        col = (C.c_float * 4)(*[float(v) for v in (self.state["fadeColor"] if color is None else color)])
+        call("th_view_fill", self.particles._ctx, col)
+        return self
+
+    def render_uniforms(self):
+        """The view pass's uniforms (src/index.js:284-293 over `state`); sin(time*flowDecay) is evaluated here - as the
+        shader would, in fp32 operands - because GLSL leaves its value to the implementation."""
+        s = self.state
+        u = _capi.RenderUniforms(time=float(self.timer.time), speedLimit=float(s["speedLimit"]), flowDecay=float(s["flowDecay"]),
+                                 speedAlpha=float(s["speedAlpha"]), colorMapAlpha=float(s["colorMapAlpha"]))
+        u.sinTerm = math.sin(float(np.float32(self.timer.time)) * float(np.float32(s["flowDecay"])))
+        u.viewSize[0], u.viewSize[1] = float(self.viewSize[0]), float(self.viewSize[1])
+        for k in range(4):
+            u.baseColor[k], u.flowColor[k] = float(s["baseColor"][k]), float(s["flowColor"][k])
+        return u
+
+    def read_view(self):
+        """The view buffer: [viewRes.y, viewRes.x, 4] uint8 (readPixels order)."""
+        out = np.empty((self.viewRes[1], self.viewRes[0], 4), np.uint8)
+        call("th_view_download", self.particles._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
 
     def clearFlow(self):                                       # src/index.js:231-236
         self.flow.clear()
@@ -225,11 +282,29 @@ class Tendrils:
             self.fragments = draw_sharded(self.dist, self)
         else:
             self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
+        if self.renderView and self.dist is None:             # the view (src/index.js:315-337), straight to the drawing buffer
+            if self.state["autoClearView"]:
+                self.clearView()
+            if self.state["autoFade"]:
+                self.drawFade()
+            n = C.c_uint64(0)
+            u = self.render_uniforms()
+            call("th_view_draw", self.particles._ctx, C.byref(u), C.byref(n))
+            self.view_fragments = int(n.value)
         return self
 
-    def export_lines(self):
-        """Trail export: the (previous -> current) line list this frame's draw() is made of (build-defined)."""
-        return self.particles.export_lines(self.viewSize, self.timer.time, self.state["speedLimit"])
+    def export_lines(self, view=False):
+        """Trail export: the (previous -> current) line list this frame's draw() is made of (build-defined): [n, 12]
+        float32 - p0.xy, p1.xy (clip space), then both vertices' flow varyings, or (view=True) their view colours."""
+        if not view:
+            return self.particles.export_lines(self.viewSize, self.timer.time, self.state["speedLimit"])
+        u = self.render_uniforms()
+        n = C.c_uint64(0)
+        call("th_export_view_lines", self.particles._ctx, C.byref(u), None, 0, C.byref(n))
+        out = np.empty((int(n.value), 12), np.float32)
+        if n.value:
+            call("th_export_view_lines", self.particles._ctx, C.byref(u), out.ctypes.data_as(_capi._fp), n.value, C.byref(n))
+        return out
 
     def resize(self):                                          # src/index.js:393-408
         self.viewRes[0] = self.gl.drawingBufferWidth

@@ -40,15 +40,19 @@ def timed(fn):
 
 for _ in range(5):                      # warm-up: the wake builds up, buffers are sized
     t.timer.tick(); t.step(); t.draw()
-step_ms, draw_ms, frags = [], [], []
+step_ms, draw_ms, view_ms, frags = [], [], [], []
 for _ in range(frames):
     t.timer.tick()
     step_ms.append(timed(t.step))
-    draw_ms.append(timed(t.draw))
+    t.renderView = False
+    draw_ms.append(timed(t.draw))           # the flow pass (what feeds the next step)
     frags.append(t.fragments)
+    t.renderView = True
+    u, n = t.render_uniforms(), C.c_uint64(0)
+    view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))     # the view pass
 stats = t.particles.stats(t.state["speedLimit"])
 print(json.dumps({"particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
-                  "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)),
+                  "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)), "view_ms": float(np.mean(view_ms)),
                   "fragments_per_frame": float(np.mean(frags)), "frames_per_s": 1e3 / float(np.mean(step_ms) + np.mean(draw_ms)),
                   "live": stats["live"], "nan": stats["nan"]}))
 t.dispose()
