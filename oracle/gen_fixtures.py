@@ -526,9 +526,9 @@ def gen_spawn_map(r, only):
         return
     coef = [0.125, 0.0078125, -0.00048828125, -0.25, -0.001953125, 0.015625]        # exact in fp32
     full, _ = r.spawn_map(16, coef)
-    save("spawn_map_full_16", buffers=np.stack(full), coef=np.array(coef), pixels=np.array([16, 16]), offset=np.array([0, 0]))
+    save("mapspawn_full_16", buffers=np.stack(full), coef=np.array(coef), pixels=np.array([16, 16]), offset=np.array([0, 0]))
     part, _ = r.spawn_map(24, coef, pixels=(5, 9), offset=(3, 11))
-    save("spawn_map_rect_24", buffers=np.stack(part), coef=np.array(coef), pixels=np.array([5, 9]), offset=np.array([3, 11]))
+    save("mapspawn_rect_24", buffers=np.stack(part), coef=np.array(coef), pixels=np.array([5, 9]), offset=np.array([3, 11]))
 
 
 TIMER_SCRIPT = [

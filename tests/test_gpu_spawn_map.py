@@ -12,7 +12,7 @@ import pytest
 from helpers import GOLDEN, ROOT, bits_equal
 
 pytestmark = pytest.mark.gpu
-CASES = ["spawn_map_full_16", "spawn_map_rect_24"]
+CASES = ["mapspawn_full_16", "mapspawn_rect_24"]
 
 
 def fixture(name):
