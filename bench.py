@@ -226,6 +226,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
         args.gpus = world
+    if rank != 0:           # one JSON line on the job's stdout: the other ranks' (and their libraries') go nowhere
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     cfg = CONFIGS[args.config]
     state_fmt = args.state or cfg["state"]
     group = cfg["group"]                      # steps per fused launch and per statistics reduction
@@ -536,7 +538,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(line))
+        # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe): push it out first, so
+        # that the JSON line is the last thing on stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 def cpu_baseline(t, width, rows_avail):

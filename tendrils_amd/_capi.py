@@ -151,6 +151,34 @@ _NO_STATUS = {"th_abi_version", "th_last_error"}
 _lib = None
 
 
+def _mapped(name):
+    """paths of the shared objects called `name`* that this process has mapped"""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if os.path.basename(path).startswith(name):
+                    found.add(os.path.realpath(path))
+    except OSError:
+        pass
+    return found
+
+
+def _runtime_order():
+    """PyTorch-ROCm wheels bundle their own ROCm runtime (libamdhip64 / libhsa-runtime64 under torch/lib); this library
+    links the system one.  A process must end up with ONE runtime: the copy that is mapped first serves everybody
+    (same SONAMEs), and that only works in one order - torch's first (the other way round torch finds no devices).  So
+    when torch is installed it is imported before the library is loaded, whatever the caller's import order was;
+    TH_SKIP_TORCH=1 skips that (hosts that never touch torch)."""
+    import importlib.util
+    import sys
+    if os.environ.get("TH_SKIP_TORCH") == "1" or "torch" in sys.modules:
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load():
     """Load the shared library (raises OSError if it was not built) and bind every symbol."""
     global _lib
@@ -158,7 +186,14 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise OSError("%s not found - run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or make -C tendrils_amd/csrc)" % LIB_PATH)
+        _runtime_order()
         lib = C.CDLL(LIB_PATH)
+        for rt in ("libhsa-runtime64", "libamdhip64"):
+            paths = _mapped(rt)
+            if len(paths) > 1:
+                raise OSError("two copies of %s are mapped into this process (%s): device memory and streams cannot be "
+                              "shared between two ROCm runtimes - import torch before anything loads the ROCm runtime, or "
+                              "set TH_SKIP_TORCH=1 and keep torch out of the process" % (rt, ", ".join(sorted(paths))))
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)      # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args

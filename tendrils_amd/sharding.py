@@ -60,8 +60,8 @@ class DeviceCounters:
 
 
 # ---- flow deposit across row-band shards ------------------------------------------------------------------
-# NOTE: torch bundles its own HIP runtime - import torch BEFORE the first call into libtendrils_hip.so (a job that
-# passes `dist` = torch.distributed to Tendrils has done so); loaded the other way round torch finds no devices.
+# (torch bundles its own ROCm runtime: tendrils_amd/_capi.py:load() imports torch before it loads the library and
+# refuses to run with two HSA runtimes mapped, so the order of the caller's imports does not matter.)
 # Tendrils.draw() blends every particle line into the flow texture in the order of ONE vertex stream
 # (src/index.js:295-303); with the particles split into row bands that stream interleaves the bands column by
 # column.  Exact multi-GPU form: every rank rasterises its own lines into fragments keyed

@@ -145,3 +145,58 @@ def test_packed_frame_loop_deposit(oracle):
         flow, _ = oracle.flow_deposit(cur, prev, flow, t.timer.time, view_size=t.viewSize, speedLimit=t.state["speedLimit"])
         assert bits_equal(t.particles.read(0), cur).all() and bits_equal(t.flow.read(), flow).all()
     t.dispose()
+
+
+def test_c5_per_gpu_band_full_size(oracle):
+    """Config C5's per-GPU share at 8 GPUs: a 2048-row band of the 16384^2 packed-state texture (33.5 M particles), 16
+    steps as one fused launch (the configuration's step group).  Size-independent properties over the whole band, the
+    oracle on rows from its first, a middle and its last row, and the second-newest state the ring keeps."""
+    import tendrils_amd as ta
+    from helpers import hashed_state
+    from tendrils_amd.tendrils import View
+    n, rows, row0, steps = 16384, 2048, 6 * 2048, 16
+    fl = seeded_case(64, 5)[1]
+    fl[..., 2] += 86000.0
+    opts = ta.defaults()
+    opts.update(stateFormat=ta.TH_STATE_F16, row0=row0, rows=rows, globalHeight=n)
+    t = ta.Tendrils(View(96, 54), opts)
+    t.resize()
+    t.setup(n)
+    probes = [0, 1000, rows - 2]                       # two rows each
+    kept = {}
+    for r0 in range(0, rows, 256):                     # generated and uploaded in slabs (host memory)
+        slab = unpack_state(pack_state(hashed_state(n, 777, 29, rows=(row0 + r0, row0 + r0 + 256))))
+        for pr in probes:
+            if r0 <= pr < r0 + 256:
+                kept[pr] = slab[pr - r0:pr - r0 + 2].copy()
+        inert_rows = (slab[..., 0] == -1e6) & (slab[..., 1] == -1e6)
+        kept.setdefault("inert", []).append(inert_rows)
+        _capi = __import__("tendrils_amd")._capi
+        _capi.call("th_upload_state", t.particles._ctx, -1, np.ascontiguousarray(slab).ctypes.data_as(_capi._fp), 0, r0, n, 256)
+    t.flow.set_pixels(fl)
+    t.timer.time = 90000.0
+    tm = ta.Timer(0, 0)
+    tm.step, tm.time = t.timer.step, t.timer.time
+    t.step_n(steps)
+    got0, got1 = t.particles.read(0), t.particles.read(1)
+    stats = t.particles.stats(t.state["speedLimit"])
+    t.dispose()
+    inert = np.concatenate(kept["inert"])
+    assert stats["particles"] == n * rows and stats["live"] == int((~inert).sum())
+    # inert particles pass through every step untouched; live ones keep |vel| <= speedLimit (+ one fp16 rounding)
+    assert (got0[inert] == np.array([-1e6, -1e6, 0, 0], np.float32)).all()
+    speed = np.hypot(got0[..., 2], got0[..., 3])[~inert]
+    speed = speed[np.isfinite(speed)]
+    assert speed.max() <= t.state["speedLimit"] * (1 + 2.0 ** -10)
+    cur = {pr: kept[pr] for pr in probes}
+    prev = dict(cur)
+    for _ in range(steps):
+        tm.tick()
+        u = oracle.logic_uniforms(n, n, tm.time, tm.dt, view_size=t.viewSize,
+                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
+        for pr in probes:
+            prev[pr] = cur[pr]
+            cur[pr] = unpack_state(pack_state(oracle.logic_step(u, cur[pr], fl, y0=row0 + pr)))
+    for pr in probes:
+        assert bits_equal(got0[pr:pr + 2], cur[pr]).all(), "rows %d.." % pr
+        assert bits_equal(got1[pr:pr + 2], prev[pr]).all(), "previous state, rows %d.." % pr
