@@ -562,6 +562,84 @@ def gen_timer(r, only):
     print("wrote timer_script.json (%d ops)" % len(TIMER_SCRIPT))
 
 
+ANIMATE_TRACKS = {"tendrils": [], "colour": [], "spawn": [], "calls": []}
+ANIMATE_OUTPUTS = {"tendrils": {"flowWeight": 1, "noiseScale": 2.125, "damping": 0.043, "autoFade": True},
+                   "colour": [1, 1, 1, 0.5], "spawn": {"radius": 1, "speed": 0}, "calls": {}}
+ANIMATE_OPS = [
+    # a start frame on every track, like the demo's tracksStart (src/demo.main.js:928-949)
+    ["track", "tendrils", "to", {"to": {"flowWeight": 1, "noiseScale": 1.5, "forceWeight": 0.017}, "time": 60}],
+    ["track", "colour", "to", {"to": [0, 0, 0, 0.9], "time": 60}],
+    ["track", "spawn", "to", {"to": {"radius": 0.6, "speed": 0.1}, "time": 60}],
+    ["track", "calls", "to", {"call": ["reset"], "time": 60}],
+    ["track", "calls", "to", {"call": ["restart", "dark"], "time": 200}],
+    # eased keyframes: smoothTo (ease joined to the previous curve), flipTo, spans with their null start frame
+    ["track", "tendrils", "smoothTo", {"to": {"flowWeight": 0.2, "noiseScale": 3.25}, "time": 1000, "ease": [0, 0.95, 1]}],
+    ["track", "tendrils", "smoothTo", {"to": {"flowWeight": 0.9, "damping": 0.1}, "time": 1800, "ease": [0, 0.2, 0.7, 1]}],
+    ["track", "tendrils", "flipTo", {"to": {"noiseScale": 0.5, "autoFade": False}, "time": 2600, "ease": [0, -0.3, 1.2, 1]}],
+    ["track", "tendrils", "smoothOver", 300, {"to": {"flowWeight": 2, "forceWeight": 0.03}, "time": 4000, "ease": [0, 1]}],
+    ["track", "tendrils", "easeOver", 250, -0.5, {"to": {"flowWeight": 0.1}, "time": 5000, "ease": [0, 0.1, 0.4, 0.9, 1], "call": ["burst"]}],
+    ["track", "colour", "smoothTo", {"to": [1, 0.5, 0.25, 0.1], "time": 1500, "ease": [0, 0.5, 1]}],
+    ["track", "colour", "over", 400, {"to": [0.2, 0.2, 0.9, 1], "time": 3000}],
+    ["track", "spawn", "flipOver", 500, {"to": {"radius": 0.05, "speed": 0.5}, "time": 2200, "ease": [0, 0.8, 1]}],
+    # playback: before the first frame, through spans, skipping several frames at once, exactly on frames, backwards
+    ["play", 0], ["play", 60], ["play", 61], ["play", 500], ["play", 1000], ["play", 1250.5], ["play", 1799.999],
+    ["play", 2300], ["play", 2600], ["play", 3650], ["play", 3700.25], ["play", 3999], ["play", 4800], ["play", 5000],
+    ["play", 6000], ["play", 4900], ["play", 2000], ["seek", 100], ["play", 150], ["playFrom", 2900, 0], ["playFrom", 1100, 4000],
+    ["seek", 2750], ["play", 2760],
+]
+
+
+def gen_animate(r_unused, only):
+    """src/animate (Player, Timeline, tween) through the reference's own compiled classes, taken out of the demo bundle's
+    module table: a scripted set of tracks and a play / seek sequence; the outputs after every player call."""
+    if only and only != "animate":
+        return
+    r = RefRunner("demo-modules")
+    res = r.animate(ANIMATE_TRACKS, ANIMATE_OPS, ANIMATE_OUTPUTS)
+    os.makedirs(GOLDEN, exist_ok=True)
+    with open(os.path.join(GOLDEN, "animate_script.json"), "w") as f:
+        json.dump({"tracks": ANIMATE_TRACKS, "outputs": ANIMATE_OUTPUTS, "ops": ANIMATE_OPS, "expected": res["out"],
+                   "frames": res["frames"]}, f)
+    print("wrote animate_script.json (%d player calls)" % len(res["out"]))
+
+
+def gen_presets(r_unused, only):
+    """The demo's presets (src/demo.main.js:1483-3238) as DATA: for every preset the literal numbers / booleans / colour
+    arrays its function assigns to `state`, to the reset spawner's uniforms and to the colour proxy (entries computed
+    from other values at run time are left out and listed under "skipped").  Only the values travel - no code."""
+    if only and only != "presets":
+        return
+    import re
+    src = open("/root/reference/src/demo.main.js").read()
+    start = src.index("const presets = {")
+    body = src[start:]
+    heads = [(m.start(), m.group(1)) for m in re.finditer(r"\n    '([^']+)'\(\) \{", body)]
+    end = body.index("\n  };", heads[-1][0])
+    out = {}
+    lit = re.compile(r"^\s*([A-Za-z_][A-Za-z0-9_]*):\s*(-?[0-9.]+(?:e-?[0-9]+)?|true|false|\[[-0-9., ]*\])\s*,?\s*$")
+    for k, (pos, name) in enumerate(heads):
+        block = body[pos:(heads[k + 1][0] if k + 1 < len(heads) else end)]
+        entry, skipped = {}, []
+        for target, key in (("state", "state"), ("resetSpawner.uniforms", "spawn"), ("colorProxy", "colorProxy")):
+            for m in re.finditer(r"Object\.assign\(" + re.escape(target) + r", \{(.*?)\n\s*\}\);", block, re.S):
+                for line in m.group(1).split("\n"):
+                    line = line.split("//")[0]
+                    if not line.strip():
+                        continue
+                    g = lit.match(line)
+                    if g:
+                        entry.setdefault(key, {})[g.group(1)] = json.loads(g.group(2))
+                    elif ":" in line and not line.strip().startswith(("}", "{")):
+                        skipped.append(key + "." + line.strip().split(":")[0])
+        if skipped:
+            entry["skipped"] = skipped
+        out[name] = entry
+    os.makedirs(GOLDEN, exist_ok=True)
+    with open(os.path.join(GOLDEN, "presets.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote presets.json (%d presets)" % len(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -579,6 +657,8 @@ def main():
     gen_spawn_image(r, args.only)
     gen_geometry(r, args.only)
     gen_view(r, args.only)
+    gen_animate(r, args.only)
+    gen_presets(r, args.only)
     gen_spawn_map(r, args.only)
     gen_timer(r, args.only)
 

@@ -30,15 +30,23 @@ def _f32(s, shape):
 
 
 class RefRunner:
-    def __init__(self):
+    def __init__(self, bundle="index"):
+        """bundle "index": docs/js/index.js (the Tendrils library) + harness.js; "demo-modules": docs/js/demo.js with its
+        bootstrap handing out the module loader instead of starting the app (one token of the webpack prologue changed in
+        the /tmp copy) + harness_animate.js - gives access to the compiled animation classes."""
         from kaleido.scopes.plotly import PlotlyScope
 
         self._tmp = tempfile.mkdtemp(prefix="tendrils_oracle_")
         stub = os.path.join(self._tmp, "stub.js")
-        with open(os.path.join(REF, "docs/js/index.js")) as f:
-            bundle = f.read()
-        with open(os.path.join(HERE, "harness.js")) as f:
+        with open(os.path.join(REF, "docs/js/index.js" if bundle == "index" else "docs/js/demo.js")) as f:
+            bundle_text = f.read()
+        if bundle != "index":
+            boot = 't.p="",t(0)}(['
+            assert bundle_text.find(boot) == 405            # the outer bundle's prologue (a nested copy further in stays as it is)
+            bundle_text = bundle_text.replace(boot, 't.p="",t}([', 1)
+        with open(os.path.join(HERE, "harness.js" if bundle == "index" else "harness_animate.js")) as f:
             harness = f.read()
+        bundle = bundle_text
         with open(stub, "w") as f:
             f.write(bundle + "\n" + harness)
         self._scope = PlotlyScope(plotlyjs="file://" + stub)
@@ -113,6 +121,10 @@ class RefRunner:
         if res.get("view"):
             res["view_out"] = np.frombuffer(base64.b64decode(res["view"]), dtype=np.uint8).reshape(int(view[1]), int(view[0]), 4).copy()
         return _f32(res["out"], (h, w, 4)), res
+
+    # -- the reference's Player / Timeline classes, scripted (bundle="demo-modules") ---------------
+    def animate(self, tracks, ops, outputs=None):
+        return self._run({"kind": "animate", "tracks": tracks, "ops": ops, "outputs": outputs or {}})
 
     # -- reference Particles.spawn(map, pixels, offset) ------------------------------
     def spawn_map(self, n, coef, pixels=None, offset=None, view=(32, 32)):
