@@ -188,12 +188,13 @@ def load():
                           "(or make -C tendrils_amd/csrc)" % LIB_PATH)
         _runtime_order()
         lib = C.CDLL(LIB_PATH)
-        for rt in ("libhsa-runtime64", "libamdhip64"):
-            paths = _mapped(rt)
-            if len(paths) > 1:
-                raise OSError("two copies of %s are mapped into this process (%s): device memory and streams cannot be "
-                              "shared between two ROCm runtimes - import torch before anything loads the ROCm runtime, or "
-                              "set TH_SKIP_TORCH=1 and keep torch out of the process" % (rt, ", ".join(sorted(paths))))
+        # (a profiler's preloaded tool library maps the system runtime before Python starts: not this loader's doing)
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        paths = _mapped("libamdhip64")
+        if len(paths) > 1 and not profiled:
+            raise OSError("two copies of the HIP runtime are mapped into this process (%s): streams and events cannot be "
+                          "shared between them - import torch before anything loads the ROCm runtime, or set "
+                          "TH_SKIP_TORCH=1 and keep torch out of the process" % ", ".join(sorted(paths)))
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)      # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
