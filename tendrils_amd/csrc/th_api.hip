@@ -127,6 +127,8 @@ struct th_context {
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
     uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line; scan scratch
     uint4 *dep_record = nullptr;         // per line: the texels of a short line
+    uint32_t *dep_lists = nullptr;       // slow / long line lists (counters first)
+    uint32_t dep_list_cap = 0;
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
     float4 *dep_colors_sorted = nullptr;
@@ -508,7 +510,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
-    (void)hipFree(c->dep_record); (void)hipFree(c->mrg_keys2);
+    (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -1180,11 +1182,12 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     if (c->dep_lines != lines) {
         TH_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_record);
-       
-        c->dep_count = c->dep_offset = c->dep_blocks = nullptr; c->dep_record = nullptr;
+        (void)hipFree(c->dep_lists);
+        c->dep_count = c->dep_offset = c->dep_blocks = c->dep_lists = nullptr; c->dep_record = nullptr;
         TH_HIP(hipMalloc((void **)&c->dep_count, lines * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_offset, lines * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_record, 2 * lines * sizeof(uint4)));
+        TH_HIP(hipMalloc((void **)&c->dep_lists, th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &c->dep_list_cap) * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height) * sizeof(uint32_t)));
         if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 2 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag
         c->dep_lines = lines;
@@ -1206,6 +1209,11 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
     }
     p.count = c->dep_count; p.offset = c->dep_offset; p.record = c->dep_record; p.oob = c->dep_total + 1;
+    p.list_n = c->dep_lists; p.list_cap = c->dep_list_cap;
+    {
+        uint32_t cap = 0;
+        p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
+    }
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
     TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
     return TH_OK;

@@ -124,6 +124,7 @@ TH_D int dep_snap(float ndc, float scale, float offset) { return (int)__builtin_
 
 struct DepositLine {
     bool draws;
+    bool short32;              // snapped endpoints less than 2^14 sixteenths apart: the varying's integers fit 32 bits
     DepositVertex a, b;
     int sx[2], sy[2];          // snapped endpoints (1/16 texel, texel centres at multiples of 16)
     int n;                     // polygon vertices after clipping
@@ -131,10 +132,10 @@ struct DepositLine {
 };
 
 // everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
-TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L)
+TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L)
 {
-    const uint32_t i = id / p.H, m = id - i * p.H;
     L.draws = false;
+    L.short32 = false;
     L.n = 0;
     L.a = dep_fetch(p, i, 2u * m);
     L.b = dep_fetch(p, i, 2u * m + 1u);
@@ -148,6 +149,8 @@ TH_D void dep_setup(const DepositParams &p, uint32_t id, DepositLine &L)
     const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
     L.sx[0] = dep_snap(L.a.px, wx16, x0); L.sy[0] = dep_snap(L.a.py, wy16, y0);
     L.sx[1] = dep_snap(L.b.px, wx16, x0); L.sy[1] = dep_snap(L.b.py, wy16, y0);
+    const int ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0];
+    L.short32 = ex > -(1 << 14) && ex < (1 << 14) && ey > -(1 << 14) && ey < (1 << 14);
     L.draws = true;
 }
 
@@ -249,7 +252,7 @@ TH_D void dep_raster_poly(const DepositParams &p, const int *PX, const int *PY, 
     int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
     if (r0 < 0) r0 = 0;
     if (r1 > p.fh) r1 = p.fh;
-    constexpr int kWindow = 8;
+    constexpr int kWindow = N == 6 ? 4 : 8;
     for (int base = r0; base < r1; base += kWindow) {
         const int top = base + kWindow < r1 ? base + kWindow : r1;
         int left[kWindow], right[kWindow];
@@ -275,13 +278,18 @@ TH_D void dep_raster_poly(const DepositParams &p, const int *PX, const int *PY, 
             const long long DX = X2 - X1, DY = Y2 - Y1;
             // short edges inside a 32768-texel-wide view (every practical case): the same quotient in 32-bit arithmetic
             const bool small = DY < 1024 && DX > -4096 && DX < 4096 && X1 > -(1 << 19) && X1 < (1 << 19);
+            const float rden = __builtin_amdgcn_rcpf((float)(16 * (int)DY));
             for (int y = e0; y < e1; ++y) {
                 long long x;
                 if (small) {
+                    // |num| < 2^30, 16 <= den < 2^14, |quotient| < 2^16: the float estimate of the floor is within one of
+                    // it (relative error of the conversion, v_rcp_f32 and the product < 2^-21), the remainder decides
                     const int num = (int)DX * ((y << 4) - Y1) + X1 * (int)DY, den = 16 * (int)DY;
-                    int q = num / den;
-                    if (num % den > 0) ++q;
-                    x = q;
+                    int q = (int)__builtin_floorf((float)num * rden);
+                    int r = num - q * den;
+                    if (r < 0) { --q; r += den; }
+                    if (r >= den) { ++q; r -= den; }
+                    x = r > 0 ? q + 1 : q;                     // ceil
                 } else x = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
                 if (x < 0) x = 0;
                 if (x > p.fw) x = p.fw;
@@ -294,6 +302,50 @@ TH_D void dep_raster_poly(const DepositParams &p, const int *PX, const int *PY, 
         for (int w = 0; w < kWindow; ++w)
             if (base + w < top)
                 for (int x = left[w]; x < right[w]; ++x) emit(x, base + w);
+    }
+}
+
+// The common case - a hexagon inside the view whose six edges all take the 32-bit division above (whole polygon within
+// 4096 x 1024 sixteenths) - row by row with its six vertices in registers and nothing indexed at run time: per row
+// every edge that crosses it sets its end of the span, in vertex order as above.  Same quotients, same spans.
+TH_D bool dep_hexagon_is_small(const int (&PX)[6], const int (&PY)[6], int &ymin, int &ymax)
+{
+    int xmin = PX[0], xmax = PX[0];
+    ymin = PY[0]; ymax = PY[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) {
+        xmin = PX[k] < xmin ? PX[k] : xmin; xmax = PX[k] > xmax ? PX[k] : xmax;
+        ymin = PY[k] < ymin ? PY[k] : ymin; ymax = PY[k] > ymax ? PY[k] : ymax;
+    }
+    return xmin > -(1 << 19) && xmax < (1 << 19) && xmax - xmin < 4096 && ymax - ymin < 1024;
+}
+
+template <typename Emit>
+TH_D void dep_raster_small_hexagon(const DepositParams &p, const int (&PX)[6], const int (&PY)[6], int ymin, int ymax, Emit emit)
+{
+    int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
+    if (r0 < 0) r0 = 0;
+    if (r1 > p.fh) r1 = p.fh;
+    for (int y = r0; y < r1; ++y) {
+        int left = p.fw, right = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int kn = k == 5 ? 0 : k + 1;
+            const int Xa = PX[k], Ya = PY[k], Xb = PX[kn], Yb = PY[kn];
+            const bool swap = Yb < Ya;
+            const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
+            const bool crosses = y >= ((Y1 + 15) >> 4) && y < ((Y2 + 15) >> 4);        // never for Ya == Yb
+            const int DX = X2 - X1, DY = Y2 - Y1, den = DY > 0 ? 16 * DY : 16;
+            const int num = DX * ((y << 4) - Y1) + X1 * DY;
+            int q = (int)__builtin_floorf((float)num * __builtin_amdgcn_rcpf((float)den));
+            int r = num - q * den;
+            if (r < 0) { --q; r += den; }
+            if (r >= den) { ++q; r -= den; }
+            int x = r > 0 ? q + 1 : q;
+            x = x < 0 ? 0 : (x > p.fw ? p.fw : x);
+            if (crosses) { if (swap) right = x; else left = x; }
+        }
+        for (int x = left; x < right; ++x) emit(x, y);
     }
 }
 
@@ -316,23 +368,35 @@ TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
 // the varying of line L at texel (x, y): linear along the snapped endpoints, extrapolated, unclamped
 TH_D float4 dep_varying(const DepositLine &L, int x, int y)
 {
-    const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
-    if (den == 0) return make_float4(L.a.c[0], L.a.c[1], L.a.c[2], L.a.c[3]);
-    const long long num = ((long long)(x << 4) - L.sx[0]) * ex + ((long long)(y << 4) - L.sy[0]) * ey;
-    const float t = (float)num / (float)den;
+    float t;
+    if (L.short32) {        // the same integers in 32 bits (a fragment lies within a texel of its line): the same floats
+        const int ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
+        if (den == 0) return make_float4(L.a.c[0], L.a.c[1], L.a.c[2], L.a.c[3]);
+        const int num = ((x << 4) - L.sx[0]) * ex + ((y << 4) - L.sy[0]) * ey;
+        t = (float)num / (float)den;
+    } else {
+        const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
+        if (den == 0) return make_float4(L.a.c[0], L.a.c[1], L.a.c[2], L.a.c[3]);
+        const long long num = ((long long)(x << 4) - L.sx[0]) * ex + ((long long)(y << 4) - L.sy[0]) * ey;
+        t = (float)num / (float)den;
+    }
     return make_float4(L.a.c[0] + t * (L.b.c[0] - L.a.c[0]), L.a.c[1] + t * (L.b.c[1] - L.a.c[1]),
                        L.a.c[2] + t * (L.b.c[2] - L.a.c[2]), L.a.c[3] + t * (L.b.c[3] - L.a.c[3]));
 }
 
-constexpr uint32_t kNeedsClip = 0xffffffffu;       // count[] marker between deposit_raster_kernel and its _clipped pass
-constexpr uint32_t kSlowChunk = 4096;              // lines a workgroup of the slow passes sifts at a time
+constexpr uint32_t kNeedsSlow = 0xffffffffu;       // count[] marker between deposit_raster_kernel and its _slow pass
 
-constexpr uint32_t kRecordTexels = 8;             // texels a line's record holds (two uint4 per line)
+constexpr uint32_t kRecordTexels = 8;             // texels a line's record holds (two uint4 per line): x | y << 16
 struct LineRecord { uint32_t n, r[kRecordTexels]; };
-TH_D void rec_add(LineRecord &q, uint32_t texel)
+TH_D void rec_add(LineRecord &q, int x, int y)
 {
+    const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
 #pragma unroll
-    for (uint32_t k = 0; k < kRecordTexels; ++k) if (q.n == k) q.r[k] = texel;      // static indices: the record stays in registers
+    for (uint32_t k = 0; k < kRecordTexels; ++k) {      // static indices and selects: the record stays in registers
+        uint32_t v = q.n == k ? xy : q.r[k];
+        asm volatile("" : "+v"(v));                     // (hipcc would turn the chain into an indexed store to scratch)
+        q.r[k] = v;
+    }
     ++q.n;
 }
 TH_D void rec_store(const DepositParams &p, uint32_t t, const LineRecord &q)
@@ -341,79 +405,96 @@ TH_D void rec_store(const DepositParams &p, uint32_t t, const LineRecord &q)
     if (q.n > 4u) p.record[2u * t + 1u] = make_uint4(q.r[4], q.r[5], q.r[6], q.r[7]);
 }
 
-// pass 1: rasterise every line once: fragment count and (count <= kRecordTexels) the covered texels.  Lines whose hexagon crosses
-// the edge of the view volume are only marked here and done by deposit_raster_clipped_kernel: the clipper's
-// runtime-indexed arrays live in scratch memory, and this way the kernel every line goes through has none.
+// Lines the fast kernels leave to a slower one (hexagons that need clipping or 64-bit edges; lines of more fragments than
+// a record holds) are appended to lists: kDepLists segments with a counter each (one hot counter would serialise the
+// appends of the whole chip; the segment of a line is picked from its 256-line group, so a segment can never receive
+// more than its share of ALL lines: no overflow check), one atomic per wave that has any.  The slow kernels then run on
+// full waves instead of sifting every line for the few.
+constexpr uint32_t kDepLists = 64, kDepListStride = 64;          // counters 256 B apart
+
+TH_D void dep_list_append(const DepositParams &p, uint32_t which, uint32_t group, bool mine, uint32_t t)
+{
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) return;
+    // (the lanes of a wave share their segment: a fast kernel's wave lies inside one group, a slow kernel's workgroup
+    // works through one segment of its input list and appends to the same segment of the other)
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(group) & (kDepLists - 1u);
+    const uint32_t lane = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t first = 0;
+    if (lane == leader) first = atomicAdd(&p.list_n[(which * kDepLists + seg) * kDepListStride], (uint32_t)__builtin_popcountll(m));
+    first = __shfl(first, leader);
+    if (mine) p.lists[((size_t)which * kDepLists + seg) * p.list_cap + first + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+}
+
+// the workgroups of a slow kernel: (segment, part) = (blockIdx % kDepLists, blockIdx / kDepLists)
+template <typename Work>
+TH_D void dep_list_work(const DepositParams &p, uint32_t which, Work work)
+{
+    const uint32_t seg = blockIdx.x & (kDepLists - 1u), part = blockIdx.x / kDepLists, parts = gridDim.x / kDepLists;
+    const uint32_t n = p.list_n[(which * kDepLists + seg) * kDepListStride];
+    const uint32_t *list = p.lists + ((size_t)which * kDepLists + seg) * p.list_cap;
+    for (uint32_t e0 = part * 256u; e0 < n; e0 += parts * 256u) {         // whole waves stay together (the appends ballot)
+        const uint32_t e = e0 + threadIdx.x;
+        work(e < n, e < n ? list[e] : 0u, seg);
+    }
+}
+enum { kListSlow = 0, kListLong = 1 };
+
+// pass 1: rasterise every line once: fragment count and (count <= kRecordTexels) the covered texels.  Workgroups walk
+// the particle texture row-major in pieces of 256 columns of a row (coalesced state reads, no division per line); the
+// line's place in the fragment array is its position in the vertex stream (column-major): the scan below is over
+// that order.  Only the common case is done here, with everything in registers; the rest goes to the slow list.
 __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams p)
 {
-    const uint32_t lines = p.W * p.rows;
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
-        // threads walk the particle texture row-major (coalesced state reads); the line's place in the fragment
-        // array is its position in the vertex stream (column-major): the scan below is over that order
-        const uint32_t row = t / p.W, col = t - row * p.W;
-        const uint32_t id = col * p.H + p.row0 + row;            // position in the whole texture's vertex stream
+    const uint32_t pieces = (p.W + 255u) >> 8, groups = pieces * p.rows;
+    for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const uint32_t row = g / pieces, col = ((g - row * pieces) << 8) + threadIdx.x;
+        const bool have = col < p.W;
+        const uint32_t t = row * p.W + col;
         LineRecord r{};
-        DepositLine L;
-        dep_setup(p, id, L);
-        if (L.draws) {
-            float cx[6], cy[6];
-            const int where = dep_hexagon(p, L, cx, cy);
-            if (where == kHexInside) {
-                int PX[6], PY[6];
-                dep_snap_hexagon(p, cx, cy, PX, PY);
-                dep_raster_poly<6>(p, PX, PY, 6, [&](int x, int y) { rec_add(r, (uint32_t)y * (uint32_t)p.fw + (uint32_t)x); });
-            } else if (where == kHexClip) r.n = kNeedsClip;
-        }
-        p.count[t] = r.n;
-        if (r.n && r.n != kNeedsClip) rec_store(p, t, r);
-    }
-}
-
-// The slow passes concern few lines, spread thinly over the waves: a workgroup first sifts kSlowChunk lines for the
-// ones it has to do (into an LDS list), then works through that list with all its lanes.
-template <typename Want, typename Work>
-TH_D void dep_sift_and_work(const DepositParams &p, Want want, Work work)
-{
-    __shared__ uint32_t list[kSlowChunk];
-    __shared__ uint32_t listed;
-    const uint32_t lines = p.W * p.rows, chunks = (lines + kSlowChunk - 1u) / kSlowChunk;
-    for (uint32_t chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
-        if (threadIdx.x == 0) listed = 0u;
-        __syncthreads();
-        for (uint32_t k = 0; k < kSlowChunk / 256u; ++k) {
-            const uint32_t t = chunk * kSlowChunk + k * 256u + threadIdx.x;
-            const bool mine = t < lines && want(p.count[t]);
-            const unsigned long long m = __ballot(mine);
-            if (m != 0ull) {
-                const uint32_t lane = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
-                uint32_t first = 0;
-                if (lane == leader) first = atomicAdd(&listed, (uint32_t)__builtin_popcountll(m));
-                first = __shfl(first, leader);
-                if (mine) list[first + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+        bool slow = false;
+        if (have) {
+            DepositLine L;
+            dep_setup(p, col, p.row0 + row, L);
+            if (L.draws) {
+                float cx[6], cy[6];
+                const int where = dep_hexagon(p, L, cx, cy);
+                if (where == kHexInside) {
+                    int PX[6], PY[6], ymin, ymax;
+                    dep_snap_hexagon(p, cx, cy, PX, PY);
+                    if (dep_hexagon_is_small(PX, PY, ymin, ymax))
+                        dep_raster_small_hexagon(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
+                    else slow = true;
+                } else if (where == kHexClip) slow = true;
             }
+            p.count[t] = slow ? kNeedsSlow : r.n;
+            if (r.n) rec_store(p, t, r);
         }
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < listed; e += 256u) work(list[e]);
-        __syncthreads();
+        dep_list_append(p, kListSlow, g, slow, t);
+        dep_list_append(p, kListLong, g, r.n > kRecordTexels, t);
     }
 }
 
-__global__ __launch_bounds__(256) void deposit_raster_clipped_kernel(const DepositParams p)
+__global__ __launch_bounds__(256) void deposit_raster_slow_kernel(const DepositParams p)
 {
-    dep_sift_and_work(p, [](uint32_t n) { return n == kNeedsClip; }, [&](uint32_t t) {
-        const uint32_t row = t / p.W, col = t - row * p.W;
-        DepositLine L;
-        dep_setup(p, col * p.H + p.row0 + row, L);
+    dep_list_work(p, kListSlow, [&](bool have, uint32_t t, uint32_t seg) {
         LineRecord r{};
-        dep_raster_line(p, L, [&](int x, int y) { rec_add(r, (uint32_t)y * (uint32_t)p.fw + (uint32_t)x); });
-        p.count[t] = r.n;
-        if (r.n) rec_store(p, t, r);
+        if (have) {
+            const uint32_t row = t / p.W, col = t - row * p.W;
+            DepositLine L;
+            dep_setup(p, col, p.row0 + row, L);
+            dep_raster_line(p, L, [&](int x, int y) { rec_add(r, x, y); });
+            p.count[t] = r.n;
+            if (r.n) rec_store(p, t, r);
+        }
+        dep_list_append(p, kListLong, seg, r.n > kRecordTexels, t);
     });
 }
 
 // one fragment into slot `at` of the stream-ordered fragment array
-TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, uint32_t texel, int x, int y)
+TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, int x, int y)
 {
+    const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
     if (p.keys64) p.keys64[at] = ((unsigned long long)texel << 32) | id;
     else p.keys[at] = texel;                   // (the sort numbers the fragments itself)
     p.colors[at] = dep_varying(L, x, y);
@@ -422,11 +503,10 @@ TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uin
 // pass 3: the fragments of the lines of up to kRecordTexels fragments, from their records, into the lines' slots.  Threads
 // walk patches of kPatchCols x 64 lines, one column per wave: a wave's lines are 64 consecutive positions of the
 // stream, so its fragments form ONE contiguous run of the fragment array (walking row-major, every lane writes
-// somewhere else: 1.2 ms for this pass at C3 against 0.x); the state texels of the patch are read as 16-byte pieces of
-// the rows, shared by the patch's waves through L1 / L2.
-constexpr uint32_t kPatchCols = 4, kPatchRows = 64;
+// somewhere else: 1.2 ms for this pass at C3 against 0.3); a patch reads whole 128-byte lines of the state rows.
+constexpr uint32_t kPatchCols = 8, kPatchRows = 64;
 
-__global__ __launch_bounds__(256) void deposit_emit_kernel(const DepositParams p)
+__global__ __launch_bounds__(kPatchCols * 64) void deposit_emit_kernel(const DepositParams p)
 {
     const uint32_t patches_x = (p.W + kPatchCols - 1) / kPatchCols, patches_y = (p.rows + kPatchRows - 1) / kPatchRows;
     const uint32_t patches = patches_x * patches_y;
@@ -441,27 +521,28 @@ __global__ __launch_bounds__(256) void deposit_emit_kernel(const DepositParams p
         const uint32_t id = col * p.H + p.row0 + row;
         const uint32_t at = p.offset[t];
         DepositLine L;
-        dep_setup(p, id, L);           // vertices and snapped endpoints
+        dep_setup(p, col, p.row0 + row, L);           // vertices and snapped endpoints
         const uint4 ra = p.record[2u * t];
         uint4 rb = make_uint4(0u, 0u, 0u, 0u);
         if (n > 4u) rb = p.record[2u * t + 1u];
-        const uint32_t tex[kRecordTexels] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+        const uint32_t xy[kRecordTexels] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
         for (uint32_t k = 0; k < kRecordTexels; ++k)
-            if (k < n) { const uint32_t y = tex[k] / (uint32_t)p.fw; dep_put(p, L, id, at + k, tex[k], (int)(tex[k] - y * (uint32_t)p.fw), (int)y); }
+            if (k < n) dep_put(p, L, id, at + k, (int)(xy[k] & 0xffffu), (int)(xy[k] >> 16));
     }
 }
 
 // ... and the lines of more fragments than a record holds, rasterised again
 __global__ __launch_bounds__(256) void deposit_emit_long_kernel(const DepositParams p)
 {
-    dep_sift_and_work(p, [](uint32_t n) { return n > kRecordTexels; }, [&](uint32_t t) {
+    dep_list_work(p, kListLong, [&](bool have, uint32_t t, uint32_t) {
+        if (!have) return;
         const uint32_t row = t / p.W, col = t - row * p.W;
         const uint32_t id = col * p.H + p.row0 + row;
         uint32_t at = p.offset[t];
         DepositLine L;
-        dep_setup(p, id, L);
-        dep_raster_line(p, L, [&](int x, int y) { dep_put(p, L, id, at, (uint32_t)y * (uint32_t)p.fw + (uint32_t)x, x, y); ++at; });
+        dep_setup(p, col, p.row0 + row, L);
+        dep_raster_line(p, L, [&](int x, int y) { dep_put(p, L, id, at, x, y); ++at; });
     });
 }
 
@@ -527,7 +608,25 @@ __global__ __launch_bounds__(256) void deposit_blend_view_kernel(const DepositPa
         const uint32_t texel = p.keys_sorted[i];
         if (i > 0 && p.keys_sorted[i - 1] == texel) continue;
         uchar4 d = p.view[texel];
-        for (uint32_t j = i; j < total && p.keys_sorted[j] == texel; ++j) dep_blend_rgba8(d, p.colors_sorted[j]);
+        uint32_t j = i;
+        while (true) {          // as deposit_blend_kernel: four fragments read ahead of the dependent blends
+            float4 c[4];
+            uint32_t k[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
+                c[q] = p.colors_sorted[at];
+                k[q] = p.keys_sorted[at];
+            }
+            bool done = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!done && j + (uint32_t)q < total && k[q] == texel) dep_blend_rgba8(d, c[q]);
+                else done = true;
+            }
+            if (done) break;
+            j += 4u;
+        }
         p.view[texel] = d;
     }
 }
@@ -640,8 +739,7 @@ __global__ __launch_bounds__(256) void export_lines_kernel(const DepositParams p
     const uint32_t lines = p.W * p.rows;
     for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < lines; t += gridDim.x * 256u) {
         const uint32_t row = t / p.W, col = t - row * p.W;
-        const uint32_t id = col * p.H + p.row0 + row;
-        const uint32_t i = id / p.H, m = id - i * p.H;
+        const uint32_t i = col, m = p.row0 + row;
         const DepositVertex a = dep_fetch(p, i, 2u * m), b = dep_fetch(p, i, 2u * m + 1u);
         const bool exists = a.live && b.live && !(a.px == b.px && a.py == b.py);
         if constexpr (WRITE) {
@@ -757,10 +855,21 @@ int deposit_grid(uint32_t n)
 
 uint32_t deposit_scan_words(uint32_t W, uint32_t rows) { return ((rows + kColRows - 1) / kColRows) * W + W; }
 
+// words of the slow / long line lists: counters, then 2 * kDepLists segments of *cap entries
+size_t deposit_list_words(uint32_t W, uint32_t rows, uint32_t *cap)
+{
+    const uint32_t groups = ((W + 255u) >> 8) * rows;
+    *cap = ((groups + kDepLists - 1u) / kDepLists) * 256u;
+    return (size_t)2 * kDepLists * kDepListStride + (size_t)2 * kDepLists * *cap;
+}
+size_t deposit_list_counter_bytes() { return (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t); }
+
 void launch_deposit_count(const DepositParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(deposit_raster_kernel, dim3(deposit_grid(p.W * p.rows)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(deposit_raster_clipped_kernel, dim3(deposit_grid((p.W * p.rows + 15u) / 16u)), dim3(256), 0, s, p);
+    const uint32_t groups = ((p.W + 255u) >> 8) * p.rows;
+    (void)hipMemsetAsync(p.list_n, 0, deposit_list_counter_bytes(), s);
+    hipLaunchKernelGGL(deposit_raster_kernel, dim3(groups < 65536u * 16u ? (groups ? groups : 1u) : 65536u * 16u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_raster_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
 }
 
 // scratch: deposit_scan_words(W, rows) words (row-block partial sums, then the column bases)
@@ -778,8 +887,8 @@ void launch_deposit_scan(const DepositParams &p, uint32_t *scratch, uint32_t *to
 void launch_deposit_scatter(const DepositParams &p, hipStream_t s)
 {
     const uint32_t patches = ((p.W + kPatchCols - 1) / kPatchCols) * ((p.rows + kPatchRows - 1) / kPatchRows);
-    hipLaunchKernelGGL(deposit_emit_kernel, dim3(patches < 65536u * 16u ? (patches ? patches : 1u) : 65536u * 16u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(deposit_emit_long_kernel, dim3(deposit_grid((p.W * p.rows + 15u) / 16u)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(deposit_emit_kernel, dim3(patches < 65536u * 16u ? (patches ? patches : 1u) : 65536u * 16u), dim3(kPatchCols * 64u), 0, s, p);
+    hipLaunchKernelGGL(deposit_emit_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
 }
 
 int deposit_key_bits(const DepositParams &p)

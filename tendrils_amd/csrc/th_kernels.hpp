@@ -121,7 +121,9 @@ struct DepositParams {
     uchar4 *view;
     double inv_x, inv_y;         // 1/(max(W,2)-1), 1/(max(2H,2)-1): Particles.generateLUT (src/particles.js:171-190)
     uint32_t *count, *offset;    // per line (row-major, as the threads walk): fragments, first slot in the stream-ordered fragment array
-    uint4 *record;               // per line (two uint4): the texels of a line of <= 8 fragments
+    uint4 *record;               // per line (two uint4): the texels (x | y << 16) of a line of <= 8 fragments
+    uint32_t *list_n, *lists;    // slow / long line lists (th_deposit.hip: kDepLists segments of list_cap entries each)
+    uint32_t list_cap;
     uint32_t *keys, *slots;      // per fragment (stream order): flow texel, own slot
     uint32_t *keys_sorted, *slots_sorted;   // the same after the stable sort by texel
     float4 *colors;              // per fragment (stream order): interpolated varying
@@ -160,6 +162,7 @@ void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial
 void launch_counter_add(unsigned long long *counter, unsigned long long n, hipStream_t s);
 void launch_optical_flow(const OpticalFlowParams &p, hipStream_t stream);
 uint32_t deposit_scan_words(uint32_t W, uint32_t rows);
+size_t deposit_list_words(uint32_t W, uint32_t rows, uint32_t *cap);
 void launch_deposit_count(const DepositParams &p, hipStream_t stream);
 void launch_deposit_scan(const DepositParams &p, uint32_t *scratch, uint32_t *total, hipStream_t stream);
 void launch_deposit_scatter(const DepositParams &p, hipStream_t stream);
