@@ -557,37 +557,6 @@ TH_D void dep_blend(float4 &d, float4 c)
     d.w = c.w * sa + d.w * da;
 }
 
-// pass 5: fragments sorted by texel (stable: stream order inside a texel); the head of each run blends it
-__global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p, uint32_t total)
-{
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const uint32_t texel = p.keys_sorted[i];
-        if (i > 0 && p.keys_sorted[i - 1] == texel) continue;
-        float4 d = p.flow[texel];
-        // the run's varyings are contiguous (gathered into sorted order): read four ahead of the dependent blends
-        uint32_t j = i;
-        while (true) {
-            float4 c[4];
-            uint32_t k[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
-                c[q] = p.colors_sorted[at];
-                k[q] = p.keys_sorted[at];
-            }
-            bool done = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!done && j + (uint32_t)q < total && k[q] == texel) dep_blend(d, c[q]);
-                else done = true;
-            }
-            if (done) break;
-            j += 4u;
-        }
-        p.flow[texel] = d;
-    }
-}
-
 // the view pass's blend: the RGBA8 drawing buffer - the fragment colour is clamped to [0, 1], blended with the stored
 // colour c/255 and stored as round(255 x), fragment after fragment (what the captured GL does)
 TH_D void dep_blend_rgba8(uchar4 &q, float4 c)
@@ -602,32 +571,116 @@ TH_D void dep_blend_rgba8(uchar4 &q, float4 c)
     q = make_uchar4(mix8(c.x, q.x), mix8(c.y, q.y), mix8(c.z, q.z), mix8(c.w, q.w));
 }
 
-__global__ __launch_bounds__(256) void deposit_blend_view_kernel(const DepositParams p, uint32_t total)
+// pass 5: fragments sorted by texel (stable: stream order inside a texel).  The lane at the head of a texel's run blends
+// its first kShortRun fragments itself, four read ahead of the dependent blends - nearly every run ends there.  What
+// is left of a longer run (the wake makes particles converge: thousands of fragments in one texel are normal after
+// a few dozen frames) is then blended by the whole wave: 64 fragments per coalesced load, the next 64 in flight,
+// every lane doing the same sequential arithmetic on values broadcast with v_readlane - the same operations in the
+// same order, at 64 fragments per memory round trip instead of 4.
+constexpr int kShortRun = 16;
+
+// a fragment's side of the blend (everything that does not depend on the destination), and the destination's
+struct BlendSource { float x, y, z, w, da; };
+TH_D float lane_float(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+TH_D BlendSource source_from_lane(const BlendSource &s, int lane)
 {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const uint32_t texel = p.keys_sorted[i];
-        if (i > 0 && p.keys_sorted[i - 1] == texel) continue;
-        uchar4 d = p.view[texel];
-        uint32_t j = i;
-        while (true) {          // as deposit_blend_kernel: four fragments read ahead of the dependent blends
-            float4 c[4];
-            uint32_t k[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
-                c[q] = p.colors_sorted[at];
-                k[q] = p.keys_sorted[at];
-            }
-            bool done = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!done && j + (uint32_t)q < total && k[q] == texel) dep_blend_rgba8(d, c[q]);
-                else done = true;
-            }
-            if (done) break;
-            j += 4u;
+    return BlendSource{lane_float(s.x, lane), lane_float(s.y, lane), lane_float(s.z, lane), lane_float(s.w, lane), lane_float(s.da, lane)};
+}
+
+struct FlowTarget {                     // dep_blend in two halves
+    using Texel = float4;
+    TH_D static BlendSource source(float4 c) { const float sa = c.w; return BlendSource{c.x * sa, c.y * sa, c.z * sa, c.w * sa, 1.0f - sa}; }
+    TH_D static void apply(float4 &d, const BlendSource &s) { d.x = s.x + d.x * s.da; d.y = s.y + d.y * s.da; d.z = s.z + d.z * s.da; d.w = s.w + d.w * s.da; }
+    TH_D static float4 *plane(const DepositParams &p) { return p.flow; }
+    TH_D static float4 from_lane(float4 d, int lane) { return make_float4(lane_float(d.x, lane), lane_float(d.y, lane), lane_float(d.z, lane), lane_float(d.w, lane)); }
+};
+struct ViewTarget {                     // dep_blend_rgba8 in two halves
+    using Texel = uchar4;
+    TH_D static BlendSource source(float4 c)
+    {
+        c.x = __builtin_fminf(__builtin_fmaxf(c.x, 0.0f), 1.0f); c.y = __builtin_fminf(__builtin_fmaxf(c.y, 0.0f), 1.0f);
+        c.z = __builtin_fminf(__builtin_fmaxf(c.z, 0.0f), 1.0f); c.w = __builtin_fminf(__builtin_fmaxf(c.w, 0.0f), 1.0f);
+        const float sa = c.w;
+        return BlendSource{c.x * sa, c.y * sa, c.z * sa, c.w * sa, 1.0f - sa};
+    }
+    TH_D static void apply(uchar4 &q, const BlendSource &s)
+    {
+        const float k = 1.0f / 255.0f;
+        auto mix8 = [&](float src, unsigned char dst) {
+            const float o = src + ((float)dst * k) * s.da;
+            return (unsigned char)(__builtin_fminf(__builtin_fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
+        };
+        q = make_uchar4(mix8(s.x, q.x), mix8(s.y, q.y), mix8(s.z, q.z), mix8(s.w, q.w));
+    }
+    TH_D static uchar4 *plane(const DepositParams &p) { return p.view; }
+    TH_D static uchar4 from_lane(uchar4 d, int lane) { return __builtin_bit_cast(uchar4, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), lane)); }
+};
+
+template <typename Target>
+__global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p, uint32_t total)
+{
+    using Texel = typename Target::Texel;
+    Texel *plane = Target::plane(p);
+    const uint32_t lane = __lane_id();
+    for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {       // (whole waves stay together)
+        const uint32_t i = base + threadIdx.x;
+        uint32_t texel = 0, j = i;
+        bool head = false, unfinished = false;
+        if (i < total) {
+            texel = p.keys_sorted[i];
+            head = i == 0 || p.keys_sorted[i - 1] != texel;
         }
-        p.view[texel] = d;
+        Texel d{};
+        if (head) {
+            d = plane[texel];
+            bool done = false;
+            for (int round = 0; round < kShortRun / 4 && !done; ++round) {
+                float4 c[4];
+                uint32_t k[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
+                    c[q] = p.colors_sorted[at];
+                    k[q] = p.keys_sorted[at];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!done && j + (uint32_t)q < total && k[q] == texel) Target::apply(d, Target::source(c[q]));
+                    else done = true;
+                }
+                if (!done) j += 4u;
+            }
+            unfinished = !done;
+            if (done) plane[texel] = d;
+        }
+        // the long runs of this wave, one after the other, by all its lanes
+        unsigned long long longs = __ballot(unfinished);
+        while (longs != 0ull) {
+            const int owner = __builtin_ctzll(longs);
+            longs &= longs - 1ull;
+            const uint32_t run_texel = (uint32_t)__builtin_amdgcn_readlane((int)texel, owner);
+            uint32_t at0 = (uint32_t)__builtin_amdgcn_readlane((int)j, owner);
+            Texel rd = Target::from_lane(d, owner);
+            auto fetch = [&](uint32_t first, float4 &c, bool &same) {
+                const uint32_t at = first + lane;
+                const bool in = at < total;
+                c = p.colors_sorted[in ? at : total - 1u];
+                same = in && p.keys_sorted[in ? at : total - 1u] == run_texel;
+            };
+            float4 c, cn;
+            bool same, samen;
+            fetch(at0, c, same);
+            while (true) {
+                fetch(at0 + 64u, cn, samen);              // in flight while this batch is blended
+                const unsigned long long in_run = __ballot(same);
+                const int n = in_run == ~0ull ? 64 : __builtin_ctzll(~in_run);
+                const BlendSource mine = Target::source(c);       // every lane its own fragment's half, then in order
+                for (int q = 0; q < n; ++q) Target::apply(rd, source_from_lane(mine, q));
+                if (n < 64) break;
+                c = cn; same = samen; at0 += 64u;
+            }
+            if (lane == (uint32_t)owner) plane[run_texel] = rd;
+        }
     }
 }
 
@@ -931,8 +984,8 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
 {
     launch_deposit_gather_colors(p.colors_sorted, p.colors, p.slots_sorted, total, s);
-    if (p.mode == 0) hipLaunchKernelGGL(deposit_blend_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
-    else hipLaunchKernelGGL(deposit_blend_view_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
+    if (p.mode == 0) hipLaunchKernelGGL(deposit_blend_kernel<FlowTarget>, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
+    else hipLaunchKernelGGL(deposit_blend_kernel<ViewTarget>, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
 }
 
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t s)

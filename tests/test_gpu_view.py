@@ -79,6 +79,32 @@ def test_view_accumulates_over_frames_with_fade_and_colormap(oracle):
     assert not cleared.any()
 
 
+def test_view_crowded_texels_are_order_exact(oracle):
+    """Hundreds of fragments per view pixel: the per-fragment quantised blend must follow the stream order (runs longer
+    than the lane's share are blended by the whole wave, 64 fragments at a time)."""
+    n, view = 128, (48, 27)
+    rng = np.random.default_rng(78)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.3, 0.3, (n, n, 2)) * [1.0, 27 / 48]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur[rng.random((n, n)) < 0.2] = [-1e6, -1e6, 0, 0]
+    m = dict(viewRes=list(view), viewSize=[1.0, 48 / 27], render=dict(speedLimit=0.01, flowDecay=0.005, speedAlpha=0.5,
+             colorMapAlpha=0.0, baseColor=[1, 0.6, 0.2, 0.07], flowColor=[0.3, 1, 0.8, 0.05]))
+    t = make(m, n)
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.timer.time = 1200.0
+    t.draw()
+    got, frags = t.read_view(), t.view_fragments
+    t.dispose()
+    want, count = oracle.view_render(cur, prev, np.zeros((view[1], view[0], 4), np.uint8), 1200.0, view_size=m["viewSize"], **m["render"])
+    assert frags == count and count > 10000          # ~ 100 fragments per pixel of the crowded centre
+    assert (got == want).all()
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 def test_node_host_view_draw(oracle):
     path = [p for p in golden("view") if "colours" in p][0]
