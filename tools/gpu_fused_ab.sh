@@ -1,0 +1,12 @@
+#!/bin/bash
+# fused kernel: new lib vs libtendrils_hip_old.so on the same box, interleaved
+mkdir -p gpurun_out/r2
+L=tendrils_amd/lib
+cp $L/libtendrils_hip.so /tmp/new.so
+for round in 1 2 3; do
+  for v in new old; do
+    if [ $v = old ]; then cp $L/libtendrils_hip_old.so $L/libtendrils_hip.so; else cp /tmp/new.so $L/libtendrils_hip.so; fi
+    echo "=== $v"; timeout 120 python tools/fused_probe.py --short 2>&1 | grep "back-to-back"
+  done
+done
+cp /tmp/new.so $L/libtendrils_hip.so
