@@ -30,6 +30,9 @@ bound by VALU issue, not by HBM.  The line therefore carries
     step() + draw() frame loop runs).
 PMC numbers come from short child runs of this script under rocprofv3 with launches of the SAME
 length as the timed ones.
+frame_loop (N = 1, c3): the reference's frame loop on the same particles - timer.tick(), step(),
+draw() - after everything else: single-step launch, flow pass and view pass of draw() in ms,
+fragments per draw, and the flow pass's own HBM roofline.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  c3: every rank holds a
 4096-row band of a 4096 x (4096 N) texture (weak scaling).  c4: 8192 x 8192 row-sharded (64 M
@@ -208,6 +211,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json config (default c3: the metric's)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
+    ap.add_argument("--no-frame-loop", action="store_true", help="skip the step() + draw() frame-loop leg")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # PMC child: launches of this length only
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
@@ -535,6 +539,8 @@ def main():
                                        "ms_per_step": wall_every_step / args.steps * 1e3,
                                        "note": "same K steps, one launch and one counter reduction per step"}
 
+    if world == 1 and args.config == "c3" and not args.no_frame_loop and not args.pmc_child:
+        line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
     if rank == 0 and world == 1 and not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(t, width, min(rows, N))
     t.dispose()
@@ -549,6 +555,50 @@ def main():
         except OSError:
             pass
         print(json.dumps(line), flush=True)
+
+
+def frame_loop(t, ctx, state, frames=20):
+    """SURVEY.md 8f-1/8f-2 beside the headline: the reference's frame loop - timer.tick(), step(), draw() - on the same
+    particles: one single-step launch, the flow pass of draw() (the particle lines blended into the flow field in GL
+    primitive order: rasterise, scan, emit, stable sort by texel, gather, blend) and the view pass (the same lines into
+    the RGBA8 view buffer), each timed with a HIP event pair on the context's stream."""
+    from tendrils_amd import _capi
+    ms = C.c_float()
+
+    def timed(fn):
+        _capi.call("th_timer_start", ctx)
+        fn()
+        _capi.call("th_timer_stop", ctx, C.byref(ms))
+        return ms.value
+
+    t.particles.upload_texels(state)
+    t.timer.time = 1000.0
+    keep = t.renderView
+    for _ in range(5):
+        t.timer.tick(); t.step(); t.draw()
+    step_ms, flow_ms, view_ms, frags = [], [], [], []
+    for _ in range(frames):
+        t.timer.tick()
+        step_ms.append(timed(t.step))
+        t.renderView = False
+        flow_ms.append(timed(t.draw))
+        frags.append(t.fragments)
+        t.renderView = True
+        u, n = t.render_uniforms(), C.c_uint64(0)
+        view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))
+    t.renderView = keep
+    lines, f = state.shape[0] * state.shape[1], float(np.mean(frags))
+    # per line: two state texels in the rasterising and in the emitting pass (64 B), count / offset / scan (24 B);
+    # per fragment: key + varying written (20 B), three radix passes over key + position (48 B), gather (36 B), blend (20 B)
+    alg = lines * 88.0 + f * 124.0
+    d = float(np.mean(flow_ms))
+    return {"frames": frames, "step_ms": float(np.mean(step_ms)), "draw_flow_ms": d, "draw_view_ms": float(np.mean(view_ms)),
+            "fragments_per_draw": f, "frames_per_s": 1e3 / (float(np.mean(step_ms)) + d),
+            "roofline": {"bound": "hbm", "kernel": "flow pass of draw() (9 kernels + 3 sort passes)", "achieved": alg / d / 1e6,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / d / 1e6 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_draw": alg,
+                         "achieved_is": "88 B per line + 124 B per fragment (DESIGN.md 3.4) / mean duration of the pass"},
+            "note": "timer.tick(); step(); draw(): one single-step launch + the flow pass; the view pass timed separately"}
 
 
 def cpu_baseline(t, width, rows_avail):

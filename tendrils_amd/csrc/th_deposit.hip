@@ -9,16 +9,17 @@
 // written in the same order and precision as the checker's restatement so that both agree bit for bit.
 //
 // GL blends fragments in primitive order, which a parallel machine has to reconstruct:
-//   1. deposit_raster_kernel: one thread per line (threads walk the particle texture row-major: coalesced state
-//      reads), rasterise ONCE: the line's fragment count and - lines of up to four fragments, nearly all of them:
-//      particles move about a texel per step - the texels themselves go into a 16-byte record per line
+//   1. deposit_raster_kernel: one thread per line (workgroups walk the particle texture row-major: coalesced state
+//      reads), rasterise ONCE: the line's fragment count and - lines of up to eight fragments, nearly all of them:
+//      particles move about a texel per step - the texels themselves go into a 32-byte record per line; the lines
+//      that need clipping or 64-bit edges, and the long ones, are listed for slower kernels
 //   2. exclusive scan of the counts in STREAM order (column-major over the row-major count array: column sums per
 //      64-row block, one small scan, column prefixes) -> every line's first slot: the fragment array is in stream order
 //   3. deposit_emit_kernel: per line, the varying at the recorded texels (only the few long lines are rasterised
 //      again) -> (texel, interpolated varying) in the line's slots
 //   4. stable radix sort of the fragments by texel (th_sort.hip): each texel's fragments end up contiguous and still
 //      in stream order
-//   5. deposit_blend_kernel: the thread at the head of a texel's run walks it and blends sequentially:
+//   5. deposit_blend_kernel: the lane at the head of a texel's run blends it in order (long runs: the whole wave):
 //      dst = src*a + dst*(1-a), exactly GL's order and arithmetic.
 // No step depends on thread scheduling, and the cost does not depend on how crowded single texels are (the
 // wake makes particles converge: thousands of fragments in one texel are normal after a few dozen frames).
