@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 3
+#define TH_ABI_VERSION 4
 
 typedef int32_t th_status;
 enum {
@@ -232,12 +232,18 @@ th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_
 th_status th_export_lines(th_context *ctx, const th_deposit_uniforms *u, float *lines, uint64_t capacity, uint64_t *count);
 
 /* Row-band shards (multi-GPU): the deposit in two steps around one exchange (tendrils_amd/sharding.py).
- *  th_deposit_emit: rasterise THIS context's lines; fragments sorted by key = (flow texel << 32) | global stream
- *    index; *keys_dev = uint64[count], *colors_dev = float4[count] (device, owned by the context, valid until the
- *    next deposit call on it).  The caller routes every fragment to the rank that owns its flow texel.
- *  th_deposit_merge: blend the fragments received for the texels this rank owns (any order) into this context's
- *    flow texture, in (texel, stream index) order - for the owned texels the result is the unsharded deposit's,
- *    bit for bit.  The owners' texel ranges are then all-gathered into every rank's flow (th_flow_device_ptr). */
+ *  th_deposit_set_owners: the number of ranks that own flow texels (contiguous ranges of ceil(texels / world) texels,
+ *    rank by rank; default 1).
+ *  th_deposit_emit: rasterise THIS context's lines; key = owner rank << 56 | flow texel << 32 | global stream index
+ *    of the line; the fragments are parted by owner (one stable radix pass), every part in the band's stream order;
+ *    *keys_dev = uint64[count], *colors_dev = float4[count] (device, owned by the context, valid until the next
+ *    deposit call on it).  The caller sends every part to its owner (all-to-all).
+ *  th_deposit_merge: blend the fragments received for the texels this rank owns - the parts of the source bands one
+ *    after the other, each still in its band's stream order - into this context's flow texture, in (texel, stream
+ *    index) order: a stable sort by texel, then the bands of a texel are merged by stream index as they are blended.
+ *    For the owned texels the result is the unsharded deposit's, bit for bit.  The owners' texel ranges are then
+ *    all-gathered into every rank's flow (th_flow_device_ptr). */
+th_status th_deposit_set_owners(th_context *ctx, int32_t world);
 th_status th_deposit_emit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev);
 th_status th_deposit_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
 /* For texture heights where the fp32 row lookup of the vertex stream (src/state/state-at-frame.glsl:12-22) lands one

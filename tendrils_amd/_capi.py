@@ -126,6 +126,7 @@ PROTOTYPES = {
     "th_export_lines": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), _fp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "th_deposit_emit": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "th_deposit_set_halo": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p]),
+    "th_deposit_set_owners": (C.c_int32, [_ctx, C.c_int32]),
     "th_deposit_merge": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64]),
     "th_flow_device_ptr": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
     "th_stats": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),

@@ -128,6 +128,7 @@ struct th_context {
     uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line; scan scratch
     uint4 *dep_record = nullptr;         // per line: the texels of a short line
     uint32_t *dep_lists = nullptr;       // slow / long line lists (counters first)
+    uint32_t dep_owners = 1;             // th_deposit_set_owners: ranks owning flow texels in the sharded deposit
     uint32_t dep_list_cap = 0;
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
@@ -137,6 +138,7 @@ struct th_context {
     unsigned long long *mrg_keys = nullptr, *mrg_keys2 = nullptr;    // th_deposit_merge scratch (sort ping-pong)
     uint32_t *mrg_vals[2] = {nullptr, nullptr};
     size_t mrg_capacity = 0;
+    float4 *mrg_colors = nullptr;        // the received varyings gathered into texel order
     float4 *dep_colors = nullptr;
     void *dep_temp = nullptr;
     size_t dep_lines = 0, dep_capacity = 0, dep_temp_bytes = 0;
@@ -510,7 +512,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
-    (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2);
+    (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -1423,10 +1425,19 @@ th_status th_export_view_lines(th_context *c, const th_render_uniforms *u, float
     return export_run(c, p, lines, capacity, count);
 }
 
+th_status th_deposit_set_owners(th_context *c, int32_t world)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(world >= 1 && world <= 64, "owner count %d outside [1, 64]", world);
+    c->dep_owners = (uint32_t)world;
+    return TH_OK;
+}
+
 th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev)
 {
     if (th_status s = use(c)) return s;
     TH_REQUIRE(count && keys_dev && colors_dev, "null outputs");
+    TH_REQUIRE((uint64_t)c->fw * c->fh <= (uint64_t)th::kTexelMask + 1u, "the sharded deposit keys hold 24 texel bits: flow %dx%d is too large", c->fw, c->fh);
     th::DepositParams p;
     uint32_t total = 0;
     if (th_status s = deposit_count(c, u, p, &total)) return s;
@@ -1434,17 +1445,23 @@ th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (total == 0) return TH_OK;
     if (th_status s = deposit_reserve(c, total, true)) return s;
     p.keys64 = c->dep_u64[0]; p.slots = c->dep_u32[1]; p.colors = c->dep_colors;
-    // the fragment array is in this band's stream order already: a stable sort on the texel bits alone leaves it
-    // sorted by the whole (texel, stream index) key
-    const int bits = 32 + deposit_texel_bits(c);
-    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 32, bits))) return s;
+    p.owners = c->dep_owners;
+    p.owner_chunk = (uint32_t)(((uint64_t)c->fw * c->fh + p.owners - 1u) / p.owners);
     th::launch_deposit_scatter(p, c->stream);
-    const int in_b = th::launch_radix_sort_u64(c->dep_u64[0], c->dep_u32[1], c->dep_u64[1], c->dep_u32[3], total, 32, bits, c->dep_temp,
-                                               true, c->stream);
-    th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, in_b ? c->dep_u32[3] : c->dep_u32[1], total, c->stream);
+    *keys_dev = c->dep_u64[0]; *colors_dev = c->dep_colors;
+    if (p.owners > 1u) {
+        // the fragment array is in this band's stream order: ONE stable pass on the owner bits parts it by destination
+        // (every part still in stream order); the owners sort by texel
+        int owner_bits = 1;
+        while ((1u << owner_bits) < p.owners) ++owner_bits;
+        if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, th::kOwnerShift, th::kOwnerShift + owner_bits))) return s;
+        const int in_b = th::launch_radix_sort_u64(c->dep_u64[0], c->dep_u32[1], c->dep_u64[1], c->dep_u32[3], total, th::kOwnerShift,
+                                                   th::kOwnerShift + owner_bits, c->dep_temp, true, c->stream);
+        th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, in_b ? c->dep_u32[3] : c->dep_u32[1], total, c->stream);
+        *keys_dev = in_b ? c->dep_u64[1] : c->dep_u64[0]; *colors_dev = c->dep_colors_sorted;
+    }
     TH_HIP(hipGetLastError());
     TH_HIP(hipStreamSynchronize(c->stream));               // the caller hands the buffers to a collective on its own stream
-    *keys_dev = in_b ? c->dep_u64[1] : c->dep_u64[0]; *colors_dev = c->dep_colors_sorted;
     return TH_OK;
 }
 
@@ -1464,23 +1481,32 @@ th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colo
     const uint32_t total = (uint32_t)count;
     if (c->mrg_capacity < total) {
         (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
-        c->mrg_keys = c->mrg_keys2 = nullptr; c->mrg_vals[0] = c->mrg_vals[1] = nullptr; c->mrg_capacity = 0;
+        (void)hipFree(c->mrg_colors);
+        c->mrg_keys = c->mrg_keys2 = nullptr; c->mrg_vals[0] = c->mrg_vals[1] = nullptr; c->mrg_colors = nullptr; c->mrg_capacity = 0;
         const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
         TH_HIP(hipMalloc((void **)&c->mrg_keys, cap * sizeof(unsigned long long)));
         TH_HIP(hipMalloc((void **)&c->mrg_keys2, cap * sizeof(unsigned long long)));
         TH_HIP(hipMalloc((void **)&c->mrg_vals[0], cap * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->mrg_vals[1], cap * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->mrg_colors, cap * sizeof(float4)));
         c->mrg_capacity = cap;
     }
+    // what arrives is one part per source band, every part in that band's stream order: a stable sort by texel (the
+    // owner bits above and the stream index below are left alone), then the blend merges the bands inside each texel
     const int bits = 32 + deposit_texel_bits(c);
-    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 0, bits))) return s;
+    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 32, bits))) return s;
+    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 2 * sizeof(uint32_t)));
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
     // (the sort ping-pongs between its two buffer pairs: the caller's keys are copied, not sorted in place)
     TH_HIP(hipMemcpyAsync(c->mrg_keys, keys_dev, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
-    const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 0, bits, c->dep_temp, true, c->stream);
+    const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 32, bits, c->dep_temp, true, c->stream);
     th::launch_deposit_blend64(c->flow, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
-                               static_cast<const float4 *>(colors_dev), total, c->stream);
+                               static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
     TH_HIP(hipGetLastError());
+    uint32_t too_many = 0;
+    TH_HIP(hipMemcpyAsync(&too_many, c->dep_total, sizeof too_many, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));               // the input buffers may be reused by the caller now
+    if (too_many) return fail(TH_ERR_UNSUPPORTED, "a flow texel received fragments of more than 32 source bands");
     return TH_OK;
 }
 

@@ -496,7 +496,10 @@ __global__ __launch_bounds__(256) void deposit_raster_slow_kernel(const DepositP
 TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, int x, int y)
 {
     const uint32_t texel = (uint32_t)y * (uint32_t)p.fw + (uint32_t)x;
-    if (p.keys64) p.keys64[at] = ((unsigned long long)texel << 32) | id;
+    if (p.keys64) {         // sharded form: owner of the texel | texel | stream index of the line
+        const uint32_t owner = p.owners > 1u ? (texel / p.owner_chunk < p.owners - 1u ? texel / p.owner_chunk : p.owners - 1u) : 0u;
+        p.keys64[at] = ((unsigned long long)owner << kOwnerShift) | ((unsigned long long)texel << 32) | id;
+    }
     else p.keys[at] = texel;                   // (the sort numbers the fragments itself)
     p.colors[at] = dep_varying(L, x, y);
 }
@@ -548,15 +551,6 @@ __global__ __launch_bounds__(256) void deposit_emit_long_kernel(const DepositPar
 }
 
 TH_D void dep_blend_rgba(float4 &d, float4 c) { const float sa = c.w, da = 1.0f - sa; d.x = c.x * sa + d.x * da; d.y = c.y * sa + d.y * da; d.z = c.z * sa + d.z * da; d.w = c.w * sa + d.w * da; }
-
-TH_D void dep_blend(float4 &d, float4 c)
-{
-    const float sa = c.w, da = 1.0f - sa;
-    d.x = c.x * sa + d.x * da;
-    d.y = c.y * sa + d.y * da;
-    d.z = c.z * sa + d.z * da;
-    d.w = c.w * sa + d.w * da;
-}
 
 // the view pass's blend: the RGBA8 drawing buffer - the fragment colour is clamped to [0, 1], blended with the stored
 // colour c/255 and stored as round(255 x), fragment after fragment (what the captured GL does)
@@ -617,19 +611,80 @@ struct ViewTarget {                     // dep_blend_rgba8 in two halves
     TH_D static uchar4 from_lane(uchar4 d, int lane) { return __builtin_bit_cast(uchar4, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), lane)); }
 };
 
+// what the fragments are sorted by.  TexelKeys: the local deposit (the key is the texel, the order inside a run is the
+// stream's).  BandKeys: the sharded deposit - an owner's fragments sorted stably by texel; inside a texel's run the
+// fragments of every source band still follow each other in that band's stream order, band after band: where the
+// stream index falls, the next band begins, and the run has to be merged by stream index.
+struct TexelKeys {
+    const uint32_t *k;
+    static constexpr bool kBands = false;
+    TH_D uint32_t texel(uint32_t at) const { return k[at]; }
+    TH_D void both(uint32_t at, uint32_t &texel, uint32_t &id) const { texel = k[at]; id = 0u; }
+};
+struct BandKeys {
+    const unsigned long long *k;
+    static constexpr bool kBands = true;
+    TH_D uint32_t texel(uint32_t at) const { return (uint32_t)(k[at] >> 32) & kTexelMask; }
+    TH_D void both(uint32_t at, uint32_t &texel, uint32_t &id) const { const unsigned long long v = k[at]; texel = (uint32_t)(v >> 32) & kTexelMask; id = (uint32_t)v; }
+};
+
+// a run made of several bands (BandKeys), by its head lane: short runs by repeated selection of the next stream index,
+// long ones by a merge of up to kMaxBands band cursors
+constexpr int kMaxBands = 32;
 template <typename Target>
-__global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams p, uint32_t total)
+TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, const float4 *colors, uint32_t i, uint32_t total,
+                           uint32_t texel, uint32_t *too_many)
+{
+    uint32_t end = i + 1u, bands = 1u;
+    while (end < total && keys.texel(end) == texel) { bands += (uint32_t)keys.k[end] < (uint32_t)keys.k[end - 1u] ? 1u : 0u; ++end; }
+    typename Target::Texel d = plane[texel];
+    if (end - i <= 16u) {
+        unsigned long long after = 0ull;            // (stream index + 1 of the fragment blended last)
+        for (uint32_t n = i; n < end; ++n) {
+            uint32_t best = i;
+            unsigned long long best_id = ~0ull;
+            for (uint32_t j = i; j < end; ++j) {
+                const unsigned long long id = (uint32_t)keys.k[j];
+                if (id >= after && id < best_id) { best = j; best_id = id; }
+            }
+            Target::apply(d, Target::source(colors[best]));
+            after = best_id + 1ull;
+        }
+    } else if (bands <= (uint32_t)kMaxBands) {
+        uint32_t pos[kMaxBands], lim[kMaxBands];
+        uint32_t nb = 0;
+        pos[0] = i;
+        for (uint32_t j = i + 1u; j < end; ++j)
+            if ((uint32_t)keys.k[j] < (uint32_t)keys.k[j - 1u]) { lim[nb] = j; pos[++nb] = j; }
+        lim[nb++] = end;
+        for (uint32_t n = i; n < end; ++n) {
+            uint32_t best = 0, best_id = 0xffffffffu;
+            bool any = false;
+            for (uint32_t b = 0; b < nb; ++b)
+                if (pos[b] < lim[b]) {
+                    const uint32_t id = (uint32_t)keys.k[pos[b]];
+                    if (!any || id < best_id) { any = true; best = b; best_id = id; }
+                }
+            Target::apply(d, Target::source(colors[pos[best]]));
+            ++pos[best];
+        }
+    } else *too_many = 1u;
+    plane[texel] = d;
+}
+
+template <typename Target, typename Keys>
+__global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Texel *plane, const Keys keys, const float4 *colors,
+                                                            uint32_t total, uint32_t *too_many)
 {
     using Texel = typename Target::Texel;
-    Texel *plane = Target::plane(p);
     const uint32_t lane = __lane_id();
     for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {       // (whole waves stay together)
         const uint32_t i = base + threadIdx.x;
-        uint32_t texel = 0, j = i;
-        bool head = false, unfinished = false;
+        uint32_t texel = 0, j = i, last = 0;
+        bool head = false, unfinished = false, banded = false;
         if (i < total) {
-            texel = p.keys_sorted[i];
-            head = i == 0 || p.keys_sorted[i - 1] != texel;
+            keys.both(i, texel, last);
+            head = i == 0 || keys.texel(i - 1) != texel;
         }
         Texel d{};
         if (head) {
@@ -637,22 +692,24 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams 
             bool done = false;
             for (int round = 0; round < kShortRun / 4 && !done; ++round) {
                 float4 c[4];
-                uint32_t k[4];
+                uint32_t k[4], id[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
-                    c[q] = p.colors_sorted[at];
-                    k[q] = p.keys_sorted[at];
+                    c[q] = colors[at];
+                    keys.both(at, k[q], id[q]);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (!done && j + (uint32_t)q < total && k[q] == texel) Target::apply(d, Target::source(c[q]));
-                    else done = true;
+                    if (!done && j + (uint32_t)q < total && k[q] == texel) {
+                        if (Keys::kBands && id[q] < last) { banded = true; done = true; }
+                        else { Target::apply(d, Target::source(c[q])); last = id[q]; }
+                    } else done = true;
                 }
                 if (!done) j += 4u;
             }
             unfinished = !done;
-            if (done) plane[texel] = d;
+            if (done && !banded) plane[texel] = d;
         }
         // the long runs of this wave, one after the other, by all its lanes
         unsigned long long longs = __ballot(unfinished);
@@ -661,27 +718,37 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(const DepositParams 
             longs &= longs - 1ull;
             const uint32_t run_texel = (uint32_t)__builtin_amdgcn_readlane((int)texel, owner);
             uint32_t at0 = (uint32_t)__builtin_amdgcn_readlane((int)j, owner);
+            uint32_t run_last = (uint32_t)__builtin_amdgcn_readlane((int)last, owner);
             Texel rd = Target::from_lane(d, owner);
-            auto fetch = [&](uint32_t first, float4 &c, bool &same) {
+            auto fetch = [&](uint32_t first, float4 &c, bool &same, uint32_t &id) {
                 const uint32_t at = first + lane;
                 const bool in = at < total;
-                c = p.colors_sorted[in ? at : total - 1u];
-                same = in && p.keys_sorted[in ? at : total - 1u] == run_texel;
+                c = colors[in ? at : total - 1u];
+                uint32_t t;
+                keys.both(in ? at : total - 1u, t, id);
+                same = in && t == run_texel;
             };
             float4 c, cn;
-            bool same, samen;
-            fetch(at0, c, same);
+            bool same, samen, falls = false;
+            uint32_t id = 0, idn = 0;
+            fetch(at0, c, same, id);
             while (true) {
-                fetch(at0 + 64u, cn, samen);              // in flight while this batch is blended
+                fetch(at0 + 64u, cn, samen, idn);              // in flight while this batch is blended
                 const unsigned long long in_run = __ballot(same);
                 const int n = in_run == ~0ull ? 64 : __builtin_ctzll(~in_run);
+                if constexpr (Keys::kBands) {
+                    const uint32_t before = lane ? (uint32_t)__shfl_up((int)id, 1) : run_last;
+                    if (__ballot((int)lane < n && id < before) != 0ull) { falls = true; break; }
+                    if (n) run_last = (uint32_t)__builtin_amdgcn_readlane((int)id, n - 1);
+                }
                 const BlendSource mine = Target::source(c);       // every lane its own fragment's half, then in order
                 for (int q = 0; q < n; ++q) Target::apply(rd, source_from_lane(mine, q));
                 if (n < 64) break;
-                c = cn; same = samen; at0 += 64u;
+                c = cn; same = samen; id = idn; at0 += 64u;
             }
-            if (lane == (uint32_t)owner) plane[run_texel] = rd;
+            if (lane == (uint32_t)owner) { if (falls) banded = true; else plane[run_texel] = rd; }
         }
+        if constexpr (Keys::kBands) if (banded) blend_banded_run<Target>(plane, keys, colors, i, total, texel, too_many);
     }
 }
 
@@ -692,23 +759,6 @@ __global__ __launch_bounds__(256) void view_fill_kernel(uchar4 *view, size_t n, 
         uchar4 d = view[i];
         dep_blend_rgba8(d, color);
         view[i] = d;
-    }
-}
-
-// sharded form: the same walk over fragments sorted by (texel, global stream index)
-__global__ __launch_bounds__(256) void deposit_blend64_kernel(float4 *flow, const unsigned long long *keys, const uint32_t *slots,
-                                                              const float4 *colors, uint32_t total)
-{
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const uint32_t texel = (uint32_t)(keys[i] >> 32);
-        if (i > 0 && (uint32_t)(keys[i - 1] >> 32) == texel) continue;
-        float4 d = flow[texel];
-        uint32_t j = i;
-        do {
-            dep_blend(d, colors[slots[j]]);
-            ++j;
-        } while (j < total && (uint32_t)(keys[j] >> 32) == texel);
-        flow[texel] = d;
     }
 }
 
@@ -976,17 +1026,23 @@ void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t
     if (n) hipLaunchKernelGGL(deposit_gather_colors_kernel, dim3(deposit_grid(n)), dim3(256), 0, s, dst, src, index, n);
 }
 
+// sharded form: colours in arrival order, gathered into the sorted order first (temp: total float4)
 void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
-                            const float4 *colors, uint32_t total, hipStream_t s)
+                            const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t s)
 {
-    if (total) hipLaunchKernelGGL(deposit_blend64_kernel, dim3(deposit_grid(total)), dim3(256), 0, s, flow, keys_sorted, slots_sorted, colors, total);
+    if (!total) return;
+    launch_deposit_gather_colors(colors_sorted, colors, slots_sorted, total, s);
+    hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, BandKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, flow, BandKeys{keys_sorted},
+                       (const float4 *)colors_sorted, total, too_many);
 }
 
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
 {
     launch_deposit_gather_colors(p.colors_sorted, p.colors, p.slots_sorted, total, s);
-    if (p.mode == 0) hipLaunchKernelGGL(deposit_blend_kernel<FlowTarget>, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
-    else hipLaunchKernelGGL(deposit_blend_kernel<ViewTarget>, dim3(deposit_grid(total)), dim3(256), 0, s, p, total);
+    if (p.mode == 0) hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, TexelKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, p.flow,
+                                        TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, total, (uint32_t *)nullptr);
+    else hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, TexelKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, p.view,
+                            TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, total, (uint32_t *)nullptr);
 }
 
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t s)

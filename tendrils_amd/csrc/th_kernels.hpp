@@ -103,6 +103,10 @@ struct SpawnSampleParams {
 };
 
 // flow deposit (th_deposit.hip): draw()'s flow pass
+// key of a fragment in the sharded deposit: 24 texel bits above the 32-bit stream index, the owner rank above them
+constexpr int kOwnerShift = 56;
+constexpr uint32_t kTexelMask = 0xffffffu;
+
 struct DepositParams {
     const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order
     float4 *flow;
@@ -128,7 +132,8 @@ struct DepositParams {
     uint32_t *keys_sorted, *slots_sorted;   // the same after the stable sort by texel
     float4 *colors;              // per fragment (stream order): interpolated varying
     float4 *colors_sorted;       // ... gathered into the sorted order
-    unsigned long long *keys64;  // sharded form: (texel << 32) | global stream index, per fragment
+    unsigned long long *keys64;  // sharded form, per fragment: owner << kOwnerShift | texel << 32 | global stream index
+    uint32_t owners, owner_chunk;    // ranks that own flow texels (contiguous ranges of owner_chunk texels)
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
@@ -184,7 +189,7 @@ int launch_radix_sort_u64(unsigned long long *keys_a, uint32_t *vals_a, unsigned
                           int begin_bit, int end_bit, void *temp, bool iota, hipStream_t stream);
 void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);
 void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
-                            const float4 *colors, uint32_t total, hipStream_t stream);
+                            const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
 void launch_spawn_direct(const SpawnSampleParams &p, hipStream_t stream);

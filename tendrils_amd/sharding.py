@@ -65,9 +65,15 @@ class DeviceCounters:
 # Tendrils.draw() blends every particle line into the flow texture in the order of ONE vertex stream
 # (src/index.js:295-303); with the particles split into row bands that stream interleaves the bands column by
 # column.  Exact multi-GPU form: every rank rasterises its own lines into fragments keyed
-# (flow texel, global stream index) [th_deposit_emit]; an all-to-all sends each fragment to the rank owning that
-# texel (contiguous texel ranges of ceil(texels/world)); the owner blends its texels in key order
-# [th_deposit_merge]; an all-gather of the owned ranges restores the replicated flow texture.
+# (owner rank, flow texel, global stream index) and parts them by owner - contiguous texel ranges of
+# ceil(texels/world) - with one radix pass [th_deposit_emit]; an all-to-all sends every part to its owner; the
+# owner sorts what it received by texel (stably: inside a texel the parts of the source bands follow each other,
+# each in stream order) and merges the bands by stream index as it blends [th_deposit_merge]; an all-gather of the
+# owned ranges restores the replicated flow texture.
+
+OWNER_SHIFT = 56            # th::kOwnerShift: key = owner << 56 | texel << 32 | stream index
+TEXEL_MASK = 0xffffff
+
 
 def device_view(ptr, shape, typestr):
     """Zero-copy torch view of library-owned device memory."""
@@ -85,13 +91,19 @@ def owner_chunk(texels, world):
 
 
 def split_by_owner(keys, texels, world):
-    """keys: int64 tensor sorted by (texel << 32 | stream index).  Returns the per-destination counts (list)."""
+    """keys: int64 tensor parted by owner (th_deposit_emit after set_owners(world)).  Returns the per-destination
+    counts (list)."""
     import torch
-    chunk = owner_chunk(texels, world)
-    bounds = torch.tensor([min(r * chunk, texels) << 32 for r in range(1, world)], dtype=torch.int64, device=keys.device)
-    cuts = torch.searchsorted(keys, bounds).tolist() if world > 1 else []
+    bounds = torch.tensor([r << OWNER_SHIFT for r in range(1, world)], dtype=torch.int64, device=keys.device)
+    cuts = torch.searchsorted(keys, bounds).tolist() if world > 1 else []      # (parted is enough: owner >= r is monotonic)
     edges = [0] + [int(v) for v in cuts] + [int(keys.numel())]
     return [edges[r + 1] - edges[r] for r in range(world)]
+
+
+def set_owners(tendrils, world):
+    """The number of ranks owning flow texels: th_deposit_emit parts its fragments for them."""
+    from . import _capi
+    _capi.call("th_deposit_set_owners", tendrils.particles._ctx, int(world))
 
 
 def emit_fragments(tendrils):
@@ -161,7 +173,7 @@ def draw_sharded(dist, tendrils):
     # edge rows of both state buffers to the neighbouring bands (the fp32 row lookup of the vertex stream can land
     # one row beside a line's own row for some texture heights)
     lo = hi = None
-    if tendrils._state_format == 0:                              # f32 ring (a packed band keeps to its own rows)
+    if tendrils._state_format == 0 and world > 1:                # f32 ring (a packed band keeps to its own rows)
         edges = edge_rows(tendrils)                              # [2 (first, last), 2 (cur, prev), W, 4]
         every = torch.empty((world,) + tuple(edges.shape), dtype=torch.float32, device="cuda")
         dist.all_gather_into_tensor(every, edges)
@@ -169,6 +181,7 @@ def draw_sharded(dist, tendrils):
         hi = every[rank + 1, 0].contiguous() if rank + 1 < world else None
         torch.cuda.synchronize()
     set_halo(tendrils, lo, hi)
+    set_owners(tendrils, world)
     keys, colors = emit_fragments(tendrils)
     send = split_by_owner(keys, texels, world)
     send_t = torch.tensor(send, dtype=torch.int64, device="cuda")

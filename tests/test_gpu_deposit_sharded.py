@@ -55,6 +55,8 @@ def test_sharded_deposit_equals_unsharded(oracle, n, view, world):
         shards.append(make_shard(n, view, row0, rows, cur, prev, base, time))
     texels = fw * fh
     chunk = sharding.owner_chunk(texels, world)
+    for t in shards:
+        sharding.set_owners(t, world)
     emitted = [sharding.emit_fragments(t) for t in shards]
     assert sum(int(k.numel()) for k, _ in emitted) == frags
     sends = [sharding.split_by_owner(k, texels, world) for k, _ in emitted]
@@ -67,7 +69,8 @@ def test_sharded_deposit_equals_unsharded(oracle, n, view, world):
             parts_c.append(colors[lo:lo + sends[s][d]].clone())
         rk, rc = torch.cat(parts_k), torch.cat(parts_c)
         if rk.numel():
-            assert int((rk >> 32).min()) >= d * chunk and int((rk >> 32).max()) < (d + 1) * chunk
+            tx = (rk >> 32) & sharding.TEXEL_MASK
+            assert int(tx.min()) >= d * chunk and int(tx.max()) < (d + 1) * chunk and bool(((rk >> sharding.OWNER_SHIFT) == d).all())
         sharding.merge_fragments(t, rk.contiguous(), rc.contiguous())
     # "all-gather": every shard takes the owners' ranges
     views = [sharding.flow_view(t) for t in shards]

@@ -91,14 +91,19 @@ def _exchange_worker(rank, world, port, texels, out_dir):
     fragments: every rank ends up with exactly the fragments of its texel range."""
     import torch
     import torch.distributed as dist
-    from tendrils_amd.sharding import owner_chunk, split_by_owner
+    from tendrils_amd.sharding import OWNER_SHIFT, TEXEL_MASK, owner_chunk, split_by_owner
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(100 + rank)
     n = 5000 + 700 * rank
     texel = rng.integers(0, texels, n).astype(np.int64)
     ids = (rng.permutation(n).astype(np.int64) * world + rank)          # distinct stream indices across ranks
-    keys = torch.from_numpy(np.sort((texel << 32) | ids))
+    # what th_deposit_emit hands over: owner << 56 | texel << 32 | stream index, parted by owner (one stable pass), every
+    # part in the band's stream order
+    chunk = owner_chunk(texels, world)
+    owner = np.minimum(texel // chunk, world - 1)
+    order = np.lexsort((ids, owner))
+    keys = torch.from_numpy(((owner << OWNER_SHIFT) | (texel << 32) | ids)[order])
     send = split_by_owner(keys, texels, world)
     assert sum(send) == n
     send_t = torch.tensor(send, dtype=torch.int64)
@@ -107,9 +112,9 @@ def _exchange_worker(rank, world, port, texels, out_dir):
     recv = [int(v) for v in recv_t.tolist()]
     rkeys = torch.empty(sum(recv), dtype=torch.int64)
     dist.all_to_all_single(rkeys, keys, recv, send)
-    chunk = owner_chunk(texels, world)
     got = rkeys.numpy()
-    assert ((got >> 32) >= rank * chunk).all() and ((got >> 32) < (rank + 1) * chunk).all()
+    tx = (got >> 32) & TEXEL_MASK
+    assert (tx >= rank * chunk).all() and (tx < (rank + 1) * chunk).all() and ((got >> OWNER_SHIFT) == rank).all()
     np.save(os.path.join(out_dir, "sent_%d.npy" % rank), keys.numpy())
     np.save(os.path.join(out_dir, "recv_%d.npy" % rank), got)
     dist.barrier()
