@@ -737,7 +737,8 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
                 const unsigned long long in_run = __ballot(same);
                 const int n = in_run == ~0ull ? 64 : __builtin_ctzll(~in_run);
                 if constexpr (Keys::kBands) {
-                    const uint32_t before = lane ? (uint32_t)__shfl_up((int)id, 1) : run_last;
+                    const uint32_t up = (uint32_t)__shfl_up((int)id, 1);        // (by every lane: a masked-off source lane reads as 0)
+                    const uint32_t before = lane ? up : run_last;
                     if (__ballot((int)lane < n && id < before) != 0ull) { falls = true; break; }
                     if (n) run_last = (uint32_t)__builtin_amdgcn_readlane((int)id, n - 1);
                 }

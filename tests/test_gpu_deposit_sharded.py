@@ -27,13 +27,17 @@ def make_shard(n, view, row0, rows, st_cur, st_prev, base, time):
     return t
 
 
-@pytest.mark.parametrize("n,view,world", [(64, (96, 54), 2), (128, (48, 27), 4), (64, (80, 60), 3)])
-def test_sharded_deposit_equals_unsharded(oracle, n, view, world):
+@pytest.mark.parametrize("n,view,world,spread", [(64, (96, 54), 2, 0.95), (128, (48, 27), 4, 0.95), (64, (80, 60), 3, 0.95),
+                                                 (128, (48, 27), 4, 0.3), (128, (48, 27), 2, 0.2)])
+def test_sharded_deposit_equals_unsharded(oracle, n, view, world, spread):
+    """spread < 1 crowds the particles into the view's centre: runs of 100+ fragments per texel made of every band's
+    fragments (the owner's merge by stream index: selection for short runs, band cursors for long ones, and the
+    wave-wide walk noticing that a run is not in one piece)."""
     torch = pytest.importorskip("torch")
     from tendrils_amd import sharding
     rng = np.random.default_rng(n + world)
     prev = np.zeros((n, n, 4), np.float32)
-    prev[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, view[1] / view[0]]
+    prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2)) * [1.0, view[1] / view[0]]
     prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
     cur = prev.copy()
     cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
@@ -47,7 +51,7 @@ def test_sharded_deposit_equals_unsharded(oracle, n, view, world):
     base[..., 3] = rng.uniform(0, 1, (fh, fw))
     time = 2500.0
     want, frags, cov = oracle.flow_deposit(cur, prev, base, time, view_size=(1.0, fw / fh), coverage=True)
-    assert cov.max() >= 3
+    assert cov.max() >= (3 if spread > 0.5 else 100)
 
     shards = []
     for r in range(world):
