@@ -502,7 +502,7 @@ def main():
                 "pmc_note": pmc_note}
     roofline.update(head)
     single = rl(single_s, 1, pmc.get("single"))
-    single["kernel"] = "logic_packed_kernel" if packed else "logic_sorted_kernel (tile-sorted slots, LDS-staged flow window; every 8th launch re-sorts) / logic_kernel (texel order)"
+    single["kernel"] = "logic_packed_kernel" if packed else "logic_kernel over tile-sorted slots (gathered taps; every 64th launch re-sorts through logic_sorted_kernel)"
     single["bound"] = "hbm"
     roofline["single_step_kernel"] = single
     roofline["other_mode"] = {"mode": other_mode, "avg_launch_ms": o_ms, "steps_per_launch": launch_len,

@@ -295,7 +295,12 @@ int rebucket_period()
 }
 int resort_period()
 {
-    static const int v = [] { const char *e = getenv("TH_RESORT_STEPS"); int n = e ? atoi(e) : 8; return n > 0 ? n : 8; }();
+    static const int v = [] {
+        const char *e = getenv("TH_RESORT_STEPS"), *m = getenv("TH_SINGLE");
+        const int dflt = (m && !strcmp(m, "window")) ? 8 : 64;       // the LDS window is left after ~8 steps; gathered taps only lose locality
+        int n = e ? atoi(e) : dflt;
+        return n > 0 ? n : dflt;
+    }();
     return v;
 }
 constexpr int kTileShift = 5;            // 32 x 32 texel tiles (th_kernels.hip kTile)
@@ -798,14 +803,11 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     p.u.time = time;
     p.time_dev = time_dev;
 
-    if (plan.decoded)
-        th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, time, time_dev, p.u.flowDecay, c->stream);
-
     // Sorted slots.  The input keeps its order; the output is written either at the same slots or - every
     // resort_period() steps, and when the input is not sorted yet or was sorted for another view / field shape - at
     // the slots of a new sort keyed on the input positions (counted just before the launch).
     int in_order = sorted ? order_of(c, in) : -1, out_order = -1;
-    bool use_sorted = false, scatter = false, count = false;
+    bool use_sorted = false, scatter = false, count = false, gather = false;
     if (sorted) {
         const th::TileGeom g = tile_geom(c, p.u);
         const bool stale = in_order >= 0 && (!same_geom(c->orders[(size_t)in_order].geom, g) ||
@@ -818,6 +820,11 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         }
         scatter = in_order < 0 || c->steps_since_sort >= resort_period();
         use_sorted = true;
+        // between two sorts the pass is the plain grid-stride kernel over the sorted slots (taps gathered from the
+        // decoded plane: a wave's taps fall into one neighbourhood); the chunk kernel with its LDS window counts
+        // and scatters around a re-sort (TH_SINGLE=window: it also does the passes in between, as first built)
+        static const bool window_mode = [] { const char *e = getenv("TH_SINGLE"); return e && !strcmp(e, "window"); }();
+        gather = !window_mode && !scatter && plan.decoded && c->steps_since_sort + 1 < resort_period();
         p.geom = g;
         if (in_order >= 0) {
             const th_context::SlotOrder &o = c->orders[(size_t)in_order];
@@ -834,7 +841,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
             p.use_records = counted ? 1u : 0u;
         } else {
             out_order = in_order;
-            count = c->steps_since_sort + 1 >= resort_period();      // the next pass will re-sort: count for it
+            count = !gather && c->steps_since_sort + 1 >= resort_period();      // the next pass will re-sort: count for it
             if (count) {
                 if (th_status s = sort_storage(c)) return s;
                 p.hist = c->tile_mem;
@@ -844,12 +851,17 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         p.misses = c->tile_mem + kTileWords;
     }
 
+    if (plan.decoded)
+        th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, time, time_dev, p.u.flowDecay, c->stream);
+
     hipEvent_t k0 = nullptr, k1 = nullptr;
     if (timing && c->kernel_timing) {
         if (th_status s = timing_events(c, &k0, &k1)) return s;
         TH_HIP(hipEventRecord(k0, c->stream));
     }
-    if (use_sorted)
+    if (gather) {
+        th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel, c->stream);
+    } else if (use_sorted)
         th::launch_logic_sorted(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, in_order >= 0, scatter, count, c->max_chunks, c->stream);
     else
         th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel,
