@@ -409,7 +409,7 @@ def main():
     k_ms, k_n = timed_kernels(lambda: run_kernel_only(args.steps, launch_len))
     # and the single-step kernel (one Tendrils.step() per launch: what a step() + draw() frame loop runs)
     def singles():
-        for _ in range(32):
+        for _ in range(64):             # one whole re-sort period of the tile-sorted slot order
             t.timer.tick()
             t.step()
     singles()
