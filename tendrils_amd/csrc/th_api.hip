@@ -129,6 +129,9 @@ struct th_context {
     uint4 *dep_record = nullptr;         // per line: the texels of a short line
     uint32_t *dep_lists = nullptr;       // slow / long line lists (counters first)
     uint32_t dep_owners = 1;             // th_deposit_set_owners: ranks owning flow texels in the sharded deposit
+    // the geometry of the last draw pass (fragment counts, offsets, records, the sorted fragment order): the flow pass
+    // and the view pass of one draw() rasterise the same lines at the same resolution
+    struct { bool valid = false; float view_x = 0, view_y = 0; uint32_t total = 0; bool sorted_in_a = false; } drawn;
     uint32_t dep_list_cap = 0;
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
@@ -185,10 +188,13 @@ struct th_context {
 
 namespace {
 
-th_status use(th_context *c)
+// keeps_lines: the entry point leaves the particle state and the per-line / per-fragment buffers of the last draw pass
+// alone, so that a view pass can still reuse the flow pass's geometry (deposit_run)
+th_status use(th_context *c, bool keeps_lines = false)
 {
     if (!c) return fail(TH_ERR_INVALID, "null context");
     TH_HIP(hipSetDevice(c->cfg.device));
+    if (!keeps_lines) c->drawn.valid = false;
     return TH_OK;
 }
 
@@ -1317,19 +1323,34 @@ static th_status deposit_temp(th_context *c, size_t need)
 // the fragments of the (prepared) pass `p`: count, emit, sort by texel, blend
 static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *fragments)
 {
+    // Same state, same view, same resolution as the pass before (the view pass after the flow pass of one draw()): the
+    // lines cover the same texels in the same order - counts, offsets, records and the sorted order of the fragments are
+    // still there, only the varyings differ.  (TH_DRAW_REUSE=0: every pass on its own.)
+    static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
+    const bool reuse = reuse_allowed && c->drawn.valid && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
     uint32_t total = 0;
-    th::launch_deposit_count(p, c->stream);
-    if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    if (reuse) total = c->drawn.total;
+    else {
+        c->drawn.valid = false;
+        th::launch_deposit_count(p, c->stream);
+        if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    }
     if (fragments) *fragments = total;
     if (total == 0) return TH_OK;
-    if (th_status s = deposit_reserve(c, total, false)) return s;
+    if (!reuse) if (th_status s = deposit_reserve(c, total, false)) return s;
     p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
     p.colors = c->dep_colors; p.colors_sorted = c->dep_colors_sorted;
-    const int bits = th::deposit_key_bits(p);
-    if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 0, bits))) return s;
-    th::launch_deposit_scatter(p, c->stream);
-    if (th::launch_radix_sort_u32(p.keys, p.slots, p.keys_sorted, p.slots_sorted, total, 0, bits, c->dep_temp, true, c->stream) == 0) {
-        p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1];        // an even number of passes ends in the (a) buffers
+    if (reuse) {
+        p.keys = nullptr;                        // (the keys are where the sort left them: only the varyings are written)
+        if (c->drawn.sorted_in_a) { p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1]; }
+        th::launch_deposit_scatter(p, c->stream);
+    } else {
+        const int bits = th::deposit_key_bits(p);
+        if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 0, bits))) return s;
+        th::launch_deposit_scatter(p, c->stream);
+        const bool in_a = th::launch_radix_sort_u32(p.keys, p.slots, p.keys_sorted, p.slots_sorted, total, 0, bits, c->dep_temp, true, c->stream) == 0;
+        if (in_a) { p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1]; }        // an even number of passes ends in the (a) buffers
+        c->drawn.valid = true; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total; c->drawn.sorted_in_a = in_a;
     }
     th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
@@ -1374,7 +1395,7 @@ static th_status view_params(th_context *c, const th_render_uniforms *u, th::Dep
 
 th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "the view pass needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
     if (th_status s = view_storage(c)) return s;
@@ -1386,7 +1407,7 @@ th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fra
 
 th_status th_view_fill(th_context *c, const float rgba[4])
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_REQUIRE(rgba, "null colour");
     if (th_status s = view_storage(c)) return s;
     th::launch_view_fill(c->view, (size_t)c->view_w * c->view_h, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), c->stream);
@@ -1396,7 +1417,7 @@ th_status th_view_fill(th_context *c, const float rgba[4])
 
 th_status th_view_clear(th_context *c)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     if (th_status s = view_storage(c)) return s;
     TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->view_w * c->view_h * sizeof(uchar4), c->stream));
     return TH_OK;
@@ -1404,7 +1425,7 @@ th_status th_view_clear(th_context *c)
 
 th_status th_view_download(th_context *c, uint8_t *rgba8)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_REQUIRE(rgba8, "null pixels");
     if (th_status s = view_storage(c)) return s;
     TH_HIP(hipMemcpyAsync(rgba8, c->view, (size_t)c->view_w * c->view_h * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
@@ -1414,7 +1435,7 @@ th_status th_view_download(th_context *c, uint8_t *rgba8)
 
 th_status th_colormap_upload(th_context *c, const float *rgba, int32_t w, int32_t h)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_REQUIRE(rgba && w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad colour map %dx%d", w, h);
     if (w != c->cmap_w || h != c->cmap_h) {
         TH_HIP(hipStreamSynchronize(c->stream));
@@ -1580,7 +1601,7 @@ th_status th_optical_flow(th_context *c, const th_optical_flow_uniforms *u)
 
 th_status th_stats_async(th_context *c, float speed_limit, void **device_counters)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_REQUIRE(!c->ring.empty(), "no state buffers");
     float4 *view = nullptr;
     if (th_status s = unpacked_view(c, c->ring[0], 0, &view)) return s;
@@ -1601,7 +1622,7 @@ th_status th_stats(th_context *c, float speed_limit, th_counters *out)
 
 th_status th_sync(th_context *c)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_HIP(hipStreamSynchronize(c->stream));
     return TH_OK;
 }
@@ -1628,14 +1649,14 @@ th_status th_state_device_ptr(th_context *c, int32_t buffer, void **dptr)
 
 th_status th_timer_start(th_context *c)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_HIP(hipEventRecord(c->ev0, c->stream));
     return TH_OK;
 }
 
 th_status th_timer_stop(th_context *c, float *elapsed_ms)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_REQUIRE(elapsed_ms, "null output");
     TH_HIP(hipEventRecord(c->ev1, c->stream));
     TH_HIP(hipEventSynchronize(c->ev1));
@@ -1645,7 +1666,7 @@ th_status th_timer_stop(th_context *c, float *elapsed_ms)
 
 th_status th_kernel_timing(th_context *c, int32_t enable)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     c->kernel_timing = enable != 0;
     if (!enable) c->kt_used = 0;
     return TH_OK;
@@ -1653,7 +1674,7 @@ th_status th_kernel_timing(th_context *c, int32_t enable)
 
 th_status th_kernel_timing_read(th_context *c, float *mean_ms, int32_t *launches)
 {
-    if (th_status s = use(c)) return s;
+    if (th_status s = use(c, true)) return s;
     TH_REQUIRE(mean_ms && launches, "null output");
     TH_HIP(hipStreamSynchronize(c->stream));
     double sum = 0.0;

@@ -500,7 +500,7 @@ TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uin
         const uint32_t owner = p.owners > 1u ? (texel / p.owner_chunk < p.owners - 1u ? texel / p.owner_chunk : p.owners - 1u) : 0u;
         p.keys64[at] = ((unsigned long long)owner << kOwnerShift) | ((unsigned long long)texel << 32) | id;
     }
-    else p.keys[at] = texel;                   // (the sort numbers the fragments itself)
+    else if (p.keys) p.keys[at] = texel;       // (the sort numbers the fragments itself; no keys: a pass that reuses the sorted order)
     p.colors[at] = dep_varying(L, x, y);
 }
 
