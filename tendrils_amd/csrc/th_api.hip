@@ -814,6 +814,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     // the slots of a new sort keyed on the input positions (counted just before the launch).
     int in_order = sorted ? order_of(c, in) : -1, out_order = -1;
     bool use_sorted = false, scatter = false, count = false, gather = false;
+    static const bool window_mode = [] { const char *e = getenv("TH_SINGLE"); return e && !strcmp(e, "window"); }();
     if (sorted) {
         const th::TileGeom g = tile_geom(c, p.u);
         const bool stale = in_order >= 0 && (!same_geom(c->orders[(size_t)in_order].geom, g) ||
@@ -829,7 +830,6 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         // between two sorts the pass is the plain grid-stride kernel over the sorted slots (taps gathered from the
         // decoded plane: a wave's taps fall into one neighbourhood); the chunk kernel with its LDS window counts
         // and scatters around a re-sort (TH_SINGLE=window: it also does the passes in between, as first built)
-        static const bool window_mode = [] { const char *e = getenv("TH_SINGLE"); return e && !strcmp(e, "window"); }();
         gather = !window_mode && !scatter && plan.decoded && c->steps_since_sort + 1 < resort_period();
         p.geom = g;
         if (in_order >= 0) {
@@ -868,7 +868,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     if (gather) {
         th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel, c->stream);
     } else if (use_sorted)
-        th::launch_logic_sorted(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, in_order >= 0, scatter, count, c->max_chunks, c->stream);
+        th::launch_logic_sorted(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, in_order >= 0, scatter, count, window_mode, c->max_chunks, c->stream);
     else
         th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel,
                          c->stream);

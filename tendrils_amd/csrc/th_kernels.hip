@@ -987,12 +987,15 @@ void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm
 //   COUNT     (in-place passes) also histogram the tiles of the OUTPUT positions - the input of the next pass - and
 //             leave every chunk's table of (tile, count) in p.records, so that a SCATTER pass that follows needs no
 //             counting pass of its own and reserves its slots once per workgroup and tile (p.use_records)
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool IN_TILED, bool SCATTER, bool COUNT>
+//   WINDOW    (tile-sorted input) stage the chunk's tile + halo of the decoded plane in LDS; otherwise the taps are gathered
+//             from the plane (what the counting and re-sorting passes do when the passes in between gather too: by then
+//             most particles have left a window staged for their tile at the last sort)
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool IN_TILED, bool SCATTER, bool COUNT, bool WINDOW = IN_TILED>
 __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams p)
 {
     __shared__ ChunkBins bins;
     __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
-    __shared__ v2f window[IN_TILED ? kTileLW * kTileLW : 1];
+    __shared__ v2f window[WINDOW ? kTileLW * kTileLW : 1];
     const float time = p.time_dev ? *p.time_dev : p.u.time;
     const float4 *lut = smem + (NOISE ? kHashVec : 0);
     const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         }
     }
     if constexpr (NOISE) fill_hash_tables(smem, p.lut);
-    if constexpr (IN_TILED) {
+    if constexpr (WINDOW) {
         if (ch.tile < p.geom.ntiles) {
             const int ty0 = (int)(ch.tile / p.geom.tiles_x), tx0 = (int)(ch.tile - (uint32_t)ty0 * p.geom.tiles_x);
             win.x0 = tx0 * kTile - kTileHalo; win.y0 = ty0 * kTile - kTileHalo;
@@ -1037,7 +1040,7 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
             }
         } else { win.x0 = -0x40000000; win.y0 = -0x40000000; }      // the no-tap class: nothing to stage
     }
-    if constexpr (NOISE || IN_TILED || COUNT) __syncthreads();
+    if constexpr (NOISE || IN_TILED || COUNT) __syncthreads();        // (tables, window, bins; the record-based reservations of SCATTER)
 
     // The chunk is swept 256 slots at a time, two iterations of state loads ahead.  The loads are unconditional - lanes and
     // iterations beyond the chunk read its first slot instead (one line per wave) - because a load under a branch
@@ -1069,7 +1072,7 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         }
         float4 r = st;
         if (valid) {
-            if constexpr (IN_TILED) r = integrate<FAST, NOISE, TARGET, POW2, true, true, true>(p, lut, st, pid, time, &tabs, &win);
+            if constexpr (WINDOW) r = integrate<FAST, NOISE, TARGET, POW2, true, true, true>(p, lut, st, pid, time, &tabs, &win);
             else r = integrate<FAST, NOISE, TARGET, POW2, true, true, false>(p, lut, st, pid, time, &tabs);
             // (scattered runs start at any slot: plain stores, so that L2 can merge the partial lines two runs share)
             if constexpr (SCATTER) { p.out[dst] = r; p.perm_out[dst] = pid; }
@@ -1101,7 +1104,7 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         __syncthreads();
         bins_flush(bins, p.hist, replica_of(c), &p.records[c]);
     }
-    if constexpr (IN_TILED) {
+    if constexpr (WINDOW) {
         if (p.misses) {
             uint32_t m = win.misses;
             m += __shfl_xor(m, 32); m += __shfl_xor(m, 16); m += __shfl_xor(m, 8);
@@ -1112,24 +1115,26 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
 }
 
 template <bool FAST, bool NOISE, bool TARGET>
-static void launch_sorted_p2(const LogicParams &p, bool pow2, bool in_tiled, bool scatter, bool count, uint32_t max_chunks, hipStream_t s)
+static void launch_sorted_p2(const LogicParams &p, bool pow2, bool in_tiled, bool scatter, bool count, bool window, uint32_t max_chunks, hipStream_t s)
 {
     // IN_TILED: an upper bound of the chunk count (the real one lives on the device), rounded up to the 8 XCD groups
     const int grid = in_tiled ? (int)(((max_chunks + 7u) & ~7u)) : tile_grid(p.count);
-#define TH_GO(P2, IT, SC, CN) hipLaunchKernelGGL((logic_sorted_kernel<FAST, NOISE, TARGET, P2, IT, SC, CN>), dim3(grid), dim3(256), 0, s, p)
+#define TH_GO(P2, IT, SC, CN, WN) hipLaunchKernelGGL((logic_sorted_kernel<FAST, NOISE, TARGET, P2, IT, SC, CN, WN>), dim3(grid), dim3(256), 0, s, p)
+#define TH_GO_P2(IT, SC, CN, WN) do { if (pow2) TH_GO(true, IT, SC, CN, WN); else TH_GO(false, IT, SC, CN, WN); } while (0)
     if (in_tiled) {
-        if (scatter) { if (pow2) TH_GO(true, true, true, false); else TH_GO(false, true, true, false); }
-        else if (count) { if (pow2) TH_GO(true, true, false, true); else TH_GO(false, true, false, true); }
-        else { if (pow2) TH_GO(true, true, false, false); else TH_GO(false, true, false, false); }
-    } else { if (pow2) TH_GO(true, false, true, false); else TH_GO(false, false, true, false); }
+        if (scatter) { if (window) TH_GO_P2(true, true, false, true); else TH_GO_P2(true, true, false, false); }
+        else if (count) { if (window) TH_GO_P2(true, false, true, true); else TH_GO_P2(true, false, true, false); }
+        else TH_GO_P2(true, false, false, true);       // (in place without counting: only the window form is used)
+    } else TH_GO_P2(false, true, false, false);
+#undef TH_GO_P2
 #undef TH_GO
 }
 
 void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
-                         bool count, uint32_t max_chunks, hipStream_t s)
+                         bool count, bool window, uint32_t max_chunks, hipStream_t s)
 {
     const bool fast = mode == TH_MODE_FAST;
-#define TH_DISPATCH(F, N, T) launch_sorted_p2<F, N, T>(p, pow2, in_tiled, scatter, count, max_chunks, s)
+#define TH_DISPATCH(F, N, T) launch_sorted_p2<F, N, T>(p, pow2, in_tiled, scatter, count, window, max_chunks, s)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }

@@ -155,7 +155,7 @@ void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t s
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
                         hipStream_t stream);
 void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
-                         bool count, uint32_t max_chunks, hipStream_t stream);
+                         bool count, bool window, uint32_t max_chunks, hipStream_t stream);
 void launch_tile_hist(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scan(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scatter(const TileSortParams &b, hipStream_t stream);
