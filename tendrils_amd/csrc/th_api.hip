@@ -174,6 +174,7 @@ struct th_context {
     std::vector<std::pair<float4 *, int>> buf_order;   // ring buffers held in a sorted order (absent = texel order)
     float4 *spare = nullptr;             // spare state buffer (ensure_identity moves through it)
     uint32_t *tile_mem = nullptr;        // hist | cursor (kSortReplicas x kMaxTileBins words each) | misses
+    th::ChunkRecord *block_records = nullptr;   // per 4096-slot block: tile_hist's table for tile_scatter
     uint32_t max_chunks = 0;
     int steps_since_sort = 0;
     unsigned long long sorts = 0;
@@ -364,6 +365,7 @@ th_status sort_storage(th_context *c)
     TH_HIP(hipMalloc((void **)&c->spare, n * sizeof(float4)));
     TH_HIP(hipMalloc((void **)&c->tile_mem, (kTileWords + 8) * sizeof(uint32_t)));
     TH_HIP(hipMemsetAsync(c->tile_mem, 0, (kTileWords + 8) * sizeof(uint32_t), c->stream));
+    TH_HIP(hipMalloc((void **)&c->block_records, ((n + th::kTileChunk - 1) / th::kTileChunk) * sizeof(th::ChunkRecord)));
     TH_HIP(hipHostMalloc((void **)&c->miss_host, 2 * sizeof(uint32_t)));
     c->miss_host[0] = c->miss_host[1] = 0;
     c->max_chunks = (uint32_t)(n / th::kTileChunk) + th::kMaxTileBins + 8u;
@@ -418,6 +420,7 @@ th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, 
     b.hist = c->tile_mem; b.cursor = c->tile_mem + kTileWords / 2;
     b.chunks = o.chunks; b.nchunks = o.nchunks;
     b.perm_out = o.perm;
+    b.block_records = have_hist ? nullptr : c->block_records;      // (only a tile_hist pass over the same blocks fills them)
     if (!have_hist) {          // (a COUNT pass whose histogram was never used may have left counts behind)
         TH_HIP(hipMemsetAsync(b.hist, 0, kTileWords / 2 * sizeof(uint32_t), c->stream));
         th::launch_tile_hist(b, c->stream);
@@ -533,7 +536,7 @@ th_status th_destroy(th_context *c)
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
     for (th_context::SlotOrder &o : c->orders) { (void)hipFree(o.perm); (void)hipFree(o.chunks); (void)hipFree(o.records); (void)hipFree(o.nchunks); }
-    (void)hipFree(c->spare); (void)hipFree(c->tile_mem);
+    (void)hipFree(c->spare); (void)hipFree(c->tile_mem); (void)hipFree(c->block_records);
     if (c->miss_host) (void)hipHostFree(c->miss_host);
     for (hipEvent_t e : c->kt_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
         if (r.head) bins_count(bins, b.hist, replica_of(blockIdx.x), key, r.length);
     }
     __syncthreads();
-    bins_flush(bins, b.hist, replica_of(blockIdx.x), nullptr);
+    bins_flush(bins, b.hist, replica_of(blockIdx.x), b.block_records ? &b.block_records[blockIdx.x] : nullptr);
 }
 
 // One workgroup: exclusive scan of the histogram (bins = tiles + the no-tap class, summed over the copies) into the
@@ -927,21 +927,36 @@ TH_D uint32_t reserve_slots(ChunkBins &t, uint32_t *cursor, uint32_t rep, uint32
     return __shfl(first, r.head_lane) + r.rank;
 }
 
-// The plain move: state (and particle ids) of slot order `perm_in` (nullptr = texel order) to the sorted slots.
+// The plain move: state (and particle ids) of slot order `perm_in` (nullptr = texel order) to the sorted slots.  With the
+// block's table of (tile, count) from tile_hist_kernel every tile's range is reserved once per workgroup (one atomic each,
+// all in flight together) and the ranks come from LDS; without it - and for tiles that did not fit the table - every
+// wave run waits for its own round trip to the global cursor (16 of them in a row per lane: 0.93 ms at C3 against 0.3).
 __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileSortParams b)
 {
+    __shared__ ChunkBins bins;
+    const bool tabled = b.block_records != nullptr;
+    if (tabled) {
+        if (threadIdx.x < kBinSlots) {
+            const uint32_t k = b.block_records[blockIdx.x].key[threadIdx.x], n = b.block_records[blockIdx.x].count[threadIdx.x];
+            bins.key[threadIdx.x] = k;
+            bins.count[threadIdx.x] = 0u;
+            bins.base[threadIdx.x] = (k != kBinEmpty && n) ? atomicAdd(&b.cursor[replica_of(blockIdx.x) + k], n) : 0u;
+        }
+        __syncthreads();
+    }
     const uint32_t base = blockIdx.x * kTileChunk;
     for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
         const uint32_t s = base + k * 256u + threadIdx.x;
         const bool valid = s < b.count;
         float4 st = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t word = 0, pid = s;
+        uint32_t key = 0, pid = s;
         if (valid) {
             st = load_stream(&b.state[s]);
             if (b.perm_in) pid = __builtin_nontemporal_load(&b.perm_in[s]);
-            word = replica_of(blockIdx.x) + tile_key(b.g, st.x, st.y);
+            key = tile_key(b.g, st.x, st.y);
         }
-        const uint32_t d = reserve_slots(b.cursor, word, valid);
+        const uint32_t d = tabled ? reserve_slots(bins, b.cursor, replica_of(blockIdx.x), key, valid)
+                                  : reserve_slots(b.cursor, replica_of(blockIdx.x) + key, valid);
         if (valid) { b.state_out[d] = st; b.perm_out[d] = pid; }
     }
 }

@@ -74,6 +74,7 @@ struct TileSortParams {
     uint32_t *nchunks;
     float4 *state_out;           // tile_scatter only
     uint32_t *perm_out;
+    ChunkRecord *block_records;  // per 4096-slot block of the input: written by tile_hist, used by tile_scatter (may be null)
 };
 
 struct OpticalFlowParams {
