@@ -855,11 +855,18 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
     bins_clear(bins);
     __syncthreads();
     const uint32_t base = blockIdx.x * kTileChunk;
+    // all 16 positions of a lane first (unconditional, clamped: nothing waits under a branch), then the counting
+    float2 pos[kTileChunk / 256u];
+#pragma unroll
+    for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
+        const uint32_t s = base + k * 256u + threadIdx.x;
+        pos[k] = *reinterpret_cast<const float2 *>(&b.state[s < b.count ? s : b.count - 1u]);
+    }
+#pragma unroll
     for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
         const uint32_t s = base + k * 256u + threadIdx.x;
         const bool valid = s < b.count;
-        uint32_t key = 0;
-        if (valid) { const float4 st = b.state[s]; key = tile_key(b.g, st.x, st.y); }
+        const uint32_t key = valid ? tile_key(b.g, pos[k].x, pos[k].y) : 0u;
         const WaveRuns r = wave_runs(key, valid);
         if (r.head) bins_count(bins, b.hist, replica_of(blockIdx.x), key, r.length);
     }
@@ -945,19 +952,27 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileSortParams 
         __syncthreads();
     }
     const uint32_t base = blockIdx.x * kTileChunk;
-    for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
-        const uint32_t s = base + k * 256u + threadIdx.x;
-        const bool valid = s < b.count;
-        float4 st = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t key = 0, pid = s;
-        if (valid) {
-            st = load_stream(&b.state[s]);
-            if (b.perm_in) pid = __builtin_nontemporal_load(&b.perm_in[s]);
-            key = tile_key(b.g, st.x, st.y);
+    const uint32_t *ids = b.perm_in ? b.perm_in : reinterpret_cast<const uint32_t *>(b.state);     // (texel order: a word read anyway)
+    // four slots of a lane per round, their loads in flight together (unconditional, clamped)
+    constexpr uint32_t kRound = 4;
+    for (uint32_t k0 = 0; k0 < kTileChunk / 256u; k0 += kRound) {
+        float4 st[kRound];
+        uint32_t pid[kRound];
+#pragma unroll
+        for (uint32_t q = 0; q < kRound; ++q) {
+            const uint32_t s = base + (k0 + q) * 256u + threadIdx.x, at = s < b.count ? s : b.count - 1u;
+            st[q] = load_stream(&b.state[at]);
+            pid[q] = __builtin_nontemporal_load(&ids[at]);
         }
-        const uint32_t d = tabled ? reserve_slots(bins, b.cursor, replica_of(blockIdx.x), key, valid)
-                                  : reserve_slots(b.cursor, replica_of(blockIdx.x) + key, valid);
-        if (valid) { b.state_out[d] = st; b.perm_out[d] = pid; }
+#pragma unroll
+        for (uint32_t q = 0; q < kRound; ++q) {
+            const uint32_t s = base + (k0 + q) * 256u + threadIdx.x;
+            const bool valid = s < b.count;
+            const uint32_t key = valid ? tile_key(b.g, st[q].x, st[q].y) : 0u;
+            const uint32_t d = tabled ? reserve_slots(bins, b.cursor, replica_of(blockIdx.x), key, valid)
+                                      : reserve_slots(b.cursor, replica_of(blockIdx.x) + key, valid);
+            if (valid) { b.state_out[d] = st[q]; b.perm_out[d] = b.perm_in ? pid[q] : s; }
+        }
     }
 }
 
