@@ -8,7 +8,7 @@
  * 432-457) over WebGL FBO ping-pong.  Each entry point below replaces one of
  * those GL-backed operations; the ctypes binding (tendrils_amd/_capi.py) binds exactly these
  * symbols and the N-API shim (tendrils_amd/csrc/th_napi.cc) all of them except the multi-GPU
- * exchange primitives (th_deposit_emit / _merge / _set_halo, th_flow_device_ptr, th_state_device_ptr,
+ * exchange primitives (th_deposit_emit / _merge / _set_halo / _set_owners, th_flow_device_ptr, th_state_device_ptr,
  * th_stream, th_stats_async: the sharded host is the Python one, over torch.distributed - INTEGRATION.md),
  * th_spawn_image_download and th_slot_order.
  *
