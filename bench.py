@@ -586,19 +586,25 @@ def frame_loop(t, ctx, state, frames=20):
         t.renderView = True
         u, n = t.render_uniforms(), C.c_uint64(0)
         view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))
+    both_ms = []                          # Tendrils.draw() as it runs with renderView: both passes in one call (th_draw)
+    for _ in range(5):
+        t.timer.tick(); t.step()
+        both_ms.append(timed(t.draw))
     t.renderView = keep
     lines, f = state.shape[0] * state.shape[1], float(np.mean(frags))
     # per line: two state texels in the rasterising and in the emitting pass (64 B), count / offset / scan (24 B);
     # per fragment: key + varying written (20 B), three radix passes over key + position (48 B), gather (36 B), blend (20 B)
     alg = lines * 88.0 + f * 124.0
     d = float(np.mean(flow_ms))
-    return {"frames": frames, "step_ms": float(np.mean(step_ms)), "draw_flow_ms": d, "draw_view_ms": float(np.mean(view_ms)),
+    return {"frames": frames, "step_ms": float(np.mean(step_ms)), "draw_flow_ms": d, "draw_view_ms": float(np.mean(view_ms)), "draw_both_ms": float(np.mean(both_ms)),
             "fragments_per_draw": f, "frames_per_s": 1e3 / (float(np.mean(step_ms)) + d),
             "roofline": {"bound": "hbm", "kernel": "flow pass of draw() (9 kernels + 3 sort passes)", "achieved": alg / d / 1e6,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / d / 1e6 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_draw": alg,
                          "achieved_is": "88 B per line + 124 B per fragment (DESIGN.md 3.4) / mean duration of the pass"},
-            "note": "timer.tick(); step(); draw(): one single-step launch + the flow pass; the view pass timed separately"}
+            "note": "timer.tick(); step(); draw(): one single-step launch + the flow pass; the view pass timed separately "
+                    "(th_view_draw after th_flow_deposit: it reuses the flow pass's rasterisation and sort), and both passes in "
+                    "one call (th_draw, what Tendrils.draw() runs with renderView) over 5 more frames"}
 
 
 def cpu_baseline(t, width, rows_avail):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 4
+#define TH_ABI_VERSION 5
 
 typedef int32_t th_status;
 enum {
@@ -286,6 +286,10 @@ typedef struct th_render_uniforms {
     float baseColor[4], flowColor[4];
 } th_render_uniforms;
 th_status th_view_draw(th_context *ctx, const th_render_uniforms *u, uint64_t *fragments);
+/* Both passes of Tendrils.draw() in one call (src/index.js:278-337: the flow pass, then the view pass): same results as
+ * th_flow_deposit(u) followed by th_view_draw(r), with the lines rasterised and the fragments sorted once.  u and r must
+ * agree in viewSize, time and speedLimit. */
+th_status th_draw(th_context *ctx, const th_deposit_uniforms *u, const th_render_uniforms *r, uint64_t *fragments);
 /* Tendrils.drawFill / drawFade (src/index.js:342-356): a full-screen colour blended SRC_ALPHA / ONE_MINUS_SRC_ALPHA */
 th_status th_view_fill(th_context *ctx, const float rgba[4]);
 th_status th_view_clear(th_context *ctx);                              /* gl.clear(COLOR_BUFFER_BIT), clear colour 0 */

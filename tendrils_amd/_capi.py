@@ -141,6 +141,7 @@ PROTOTYPES = {
     "th_slot_order": (C.c_int32, [_ctx, C.POINTER(SlotOrderInfo)]),
     "th_shapes": (C.c_int32, [_ctx, C.POINTER(ShapesInfo)]),
     "th_view_draw": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
+    "th_draw": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_view_fill": (C.c_int32, [_ctx, _fp]),
     "th_view_clear": (C.c_int32, [_ctx]),
     "th_view_download": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),

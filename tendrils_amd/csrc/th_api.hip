@@ -129,6 +129,7 @@ struct th_context {
     uint4 *dep_record = nullptr;         // per line: the texels of a short line
     uint32_t *dep_lists = nullptr;       // slow / long line lists (counters first)
     uint32_t dep_owners = 1;             // th_deposit_set_owners: ranks owning flow texels in the sharded deposit
+    bool dep_pairs = false;              // the colour buffers hold two varyings per fragment (th_draw)
     // the geometry of the last draw pass (fragment counts, offsets, records, the sorted fragment order): the flow pass
     // and the view pass of one draw() rasterise the same lines at the same resolution
     struct { bool valid = false; float view_x = 0, view_y = 0; uint32_t total = 0; bool sorted_in_a = false; } drawn;
@@ -1292,8 +1293,14 @@ th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *li
 }
 
 // per-fragment buffers for `total` fragments (grow-only)
-static th_status deposit_reserve(th_context *c, uint32_t total, bool wide)
+static th_status deposit_reserve(th_context *c, uint32_t total, bool wide, bool pairs = false)
 {
+    if (pairs && !c->dep_pairs) {                 // two varyings per fragment: the colour buffers at twice the size
+        (void)hipFree(c->dep_colors); c->dep_colors = nullptr;
+        (void)hipFree(c->dep_colors_sorted); c->dep_colors_sorted = nullptr;
+        if (c->dep_capacity) TH_HIP(hipMalloc((void **)&c->dep_colors, 2 * c->dep_capacity * sizeof(float4)));
+        c->dep_pairs = true;
+    }
     if (c->dep_capacity < total) {
         for (uint32_t *&q : c->dep_u32) { (void)hipFree(q); q = nullptr; }
         for (unsigned long long *&q : c->dep_u64) { (void)hipFree(q); q = nullptr; }
@@ -1302,10 +1309,10 @@ static th_status deposit_reserve(th_context *c, uint32_t total, bool wide)
         c->dep_capacity = 0; c->dep_wide = false;
         const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
         for (uint32_t *&q : c->dep_u32) TH_HIP(hipMalloc((void **)&q, cap * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->dep_colors, cap * sizeof(float4)));
+        TH_HIP(hipMalloc((void **)&c->dep_colors, (c->dep_pairs ? 2 : 1) * cap * sizeof(float4)));
         c->dep_capacity = cap;
     }
-    if (!c->dep_colors_sorted) TH_HIP(hipMalloc((void **)&c->dep_colors_sorted, c->dep_capacity * sizeof(float4)));
+    if (!c->dep_colors_sorted) TH_HIP(hipMalloc((void **)&c->dep_colors_sorted, (c->dep_pairs ? 2 : 1) * c->dep_capacity * sizeof(float4)));
     if (wide && !c->dep_wide) {
         for (unsigned long long *&q : c->dep_u64) TH_HIP(hipMalloc((void **)&q, c->dep_capacity * sizeof(unsigned long long)));
         c->dep_wide = true;
@@ -1330,7 +1337,7 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
     // lines cover the same texels in the same order - counts, offsets, records and the sorted order of the fragments are
     // still there, only the varyings differ.  (TH_DRAW_REUSE=0: every pass on its own.)
     static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
-    const bool reuse = reuse_allowed && c->drawn.valid && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
+    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
     uint32_t total = 0;
     if (reuse) total = c->drawn.total;
     else {
@@ -1340,7 +1347,7 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
     }
     if (fragments) *fragments = total;
     if (total == 0) return TH_OK;
-    if (!reuse) if (th_status s = deposit_reserve(c, total, false)) return s;
+    if (!reuse) if (th_status s = deposit_reserve(c, total, false, p.mode == 2)) return s;
     p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
     p.colors = c->dep_colors; p.colors_sorted = c->dep_colors_sorted;
     if (reuse) {
@@ -1383,6 +1390,13 @@ static th_status view_storage(th_context *c)
     return TH_OK;
 }
 
+static void view_fields(th_context *c, const th_render_uniforms *u, th::DepositParams &p)
+{
+    p.flow_decay = u->flowDecay; p.speed_alpha = u->speedAlpha; p.colormap_alpha = u->colorMapAlpha; p.sin_term = u->sinTerm;
+    for (int k = 0; k < 4; ++k) { p.base_color[k] = u->baseColor[k]; p.flow_color[k] = u->flowColor[k]; }
+    p.colormap = c->colormap; p.cw = c->cmap_w; p.ch = c->cmap_h;
+}
+
 static th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositParams &p)
 {
     TH_REQUIRE(u, "null uniforms");
@@ -1390,10 +1404,31 @@ static th_status view_params(th_context *c, const th_render_uniforms *u, th::Dep
     d.viewSize[0] = u->viewSize[0]; d.viewSize[1] = u->viewSize[1]; d.time = u->time; d.speedLimit = u->speedLimit;
     if (th_status s = deposit_prepare(c, &d, p)) return s;
     p.mode = 1;
-    p.flow_decay = u->flowDecay; p.speed_alpha = u->speedAlpha; p.colormap_alpha = u->colorMapAlpha; p.sin_term = u->sinTerm;
-    for (int k = 0; k < 4; ++k) { p.base_color[k] = u->baseColor[k]; p.flow_color[k] = u->flowColor[k]; }
-    p.colormap = c->colormap; p.cw = c->cmap_w; p.ch = c->cmap_h;
+    view_fields(c, u, p);
     return TH_OK;
+}
+
+// Both passes of Tendrils.draw() (src/index.js:278-337) in one: the lines are rasterised, scanned, emitted and sorted once,
+// every fragment carries the flow pass's varying and the view pass's colour side by side, one gather brings both into
+// the sorted order and each target is blended from its half.  The two passes must agree on what they draw: the same
+// viewSize, time and speedLimit (what Tendrils.draw() hands to both); results are those of th_flow_deposit followed
+// by th_view_draw.
+th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(du && ru, "null uniforms");
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "draw on a row-band shard (%d of %d rows): the flow pass goes through th_deposit_emit / th_deposit_merge, the view pass needs the whole texture", c->cfg.height, c->cfg.global_height);
+    TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
+               memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
+               "the two passes of one draw share viewSize, time and speedLimit");
+    if (th_status s = view_storage(c)) return s;
+    th::DepositParams p;
+    if (th_status s = deposit_prepare(c, du, p)) return s;
+    p.mode = 2;
+    view_fields(c, ru, p);
+    p.view = c->view;
+    return deposit_run(c, p, fragments);
 }
 
 th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)

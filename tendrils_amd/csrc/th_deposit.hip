@@ -32,7 +32,8 @@ namespace {
 struct DepositVertex {
     bool live;
     float px, py;      // clip-space position (w = 1)
-    float c[4];        // varying: (vel.x, vel.y, time, min(|vel|/speedLimit, 1))
+    float c[4];        // varying: (vel.x, vel.y, time, min(|vel|/speedLimit, 1)) - or the view pass's colour (mode 1)
+    float c2[4];       // mode 2 (both passes of draw() in one): the view pass's colour beside the flow pass's varying
 };
 
 TH_D int dep_nearest(float u, int n)       // NEAREST + CLAMP_TO_EDGE on a float texture
@@ -107,9 +108,10 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
     v.py = t.y * p.view_y;
-    if (p.mode == 0) {
+    if (p.mode != 1) {
         v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
         v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
+        if (p.mode == 2) dep_render_color(p, t, uvx, uvy, v.c2);
     } else dep_render_color(p, t, uvx, uvy, v.c);
     return v;
 }
@@ -366,23 +368,27 @@ TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
     }
 }
 
-// the varying of line L at texel (x, y): linear along the snapped endpoints, extrapolated, unclamped
-TH_D float4 dep_varying(const DepositLine &L, int x, int y)
+// the varying of line L at texel (x, y): linear along the snapped endpoints, extrapolated, unclamped.  dep_param: the
+// interpolation parameter (false: both endpoints snap to the same point, the first vertex's value is taken)
+TH_D bool dep_param(const DepositLine &L, int x, int y, float &t)
 {
-    float t;
     if (L.short32) {        // the same integers in 32 bits (a fragment lies within a texel of its line): the same floats
         const int ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
-        if (den == 0) return make_float4(L.a.c[0], L.a.c[1], L.a.c[2], L.a.c[3]);
+        if (den == 0) return false;
         const int num = ((x << 4) - L.sx[0]) * ex + ((y << 4) - L.sy[0]) * ey;
         t = (float)num / (float)den;
     } else {
         const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
-        if (den == 0) return make_float4(L.a.c[0], L.a.c[1], L.a.c[2], L.a.c[3]);
+        if (den == 0) return false;
         const long long num = ((long long)(x << 4) - L.sx[0]) * ex + ((long long)(y << 4) - L.sy[0]) * ey;
         t = (float)num / (float)den;
     }
-    return make_float4(L.a.c[0] + t * (L.b.c[0] - L.a.c[0]), L.a.c[1] + t * (L.b.c[1] - L.a.c[1]),
-                       L.a.c[2] + t * (L.b.c[2] - L.a.c[2]), L.a.c[3] + t * (L.b.c[3] - L.a.c[3]));
+    return true;
+}
+TH_D float4 dep_mix(const float (&a)[4], const float (&b)[4], bool along, float t)
+{
+    if (!along) return make_float4(a[0], a[1], a[2], a[3]);
+    return make_float4(a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2]), a[3] + t * (b[3] - a[3]));
 }
 
 constexpr uint32_t kNeedsSlow = 0xffffffffu;       // count[] marker between deposit_raster_kernel and its _slow pass
@@ -501,7 +507,12 @@ TH_D void dep_put(const DepositParams &p, const DepositLine &L, uint32_t id, uin
         p.keys64[at] = ((unsigned long long)owner << kOwnerShift) | ((unsigned long long)texel << 32) | id;
     }
     else if (p.keys) p.keys[at] = texel;       // (the sort numbers the fragments itself; no keys: a pass that reuses the sorted order)
-    p.colors[at] = dep_varying(L, x, y);
+    float t = 0.0f;
+    const bool along = dep_param(L, x, y, t);
+    if (p.mode == 2) {      // both passes' varyings side by side: one gather brings both into the sorted order
+        p.colors[2u * at] = dep_mix(L.a.c, L.b.c, along, t);
+        p.colors[2u * at + 1u] = dep_mix(L.a.c2, L.b.c2, along, t);
+    } else p.colors[at] = dep_mix(L.a.c, L.b.c, along, t);
 }
 
 // pass 3: the fragments of the lines of up to kRecordTexels fragments, from their records, into the lines' slots.  Threads
@@ -672,9 +683,10 @@ TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, 
     plane[texel] = d;
 }
 
+// colors[at * stride]: stride 2 when the two passes' varyings lie side by side (mode 2; `colors` then points at the pass's own)
 template <typename Target, typename Keys>
 __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Texel *plane, const Keys keys, const float4 *colors,
-                                                            uint32_t total, uint32_t *too_many)
+                                                            uint32_t stride, uint32_t total, uint32_t *too_many)
 {
     using Texel = typename Target::Texel;
     const uint32_t lane = __lane_id();
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t at = j + (uint32_t)q < total ? j + (uint32_t)q : total - 1u;
-                    c[q] = colors[at];
+                    c[q] = colors[(size_t)at * stride];
                     keys.both(at, k[q], id[q]);
                 }
 #pragma unroll
@@ -723,7 +735,7 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
             auto fetch = [&](uint32_t first, float4 &c, bool &same, uint32_t &id) {
                 const uint32_t at = first + lane;
                 const bool in = at < total;
-                c = colors[in ? at : total - 1u];
+                c = colors[(size_t)(in ? at : total - 1u) * stride];
                 uint32_t t;
                 keys.both(in ? at : total - 1u, t, id);
                 same = in && t == run_texel;
@@ -766,6 +778,15 @@ __global__ __launch_bounds__(256) void view_fill_kernel(uchar4 *view, size_t n, 
 __global__ __launch_bounds__(256) void deposit_gather_colors_kernel(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[index[i]];
+}
+// pairs of varyings (mode 2): 32 bytes from one random place instead of 16 from two
+__global__ __launch_bounds__(256) void deposit_gather_pairs_kernel(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const size_t from = 2u * (size_t)index[i];
+        const float4 a = src[from], b = src[from + 1u];
+        dst[2u * (size_t)i] = a; dst[2u * (size_t)i + 1u] = b;
+    }
 }
 
 // ---- exclusive scan of the per-line fragment counts in stream order ---------------------------------------------
@@ -1034,16 +1055,25 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
     if (!total) return;
     launch_deposit_gather_colors(colors_sorted, colors, slots_sorted, total, s);
     hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, BandKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, flow, BandKeys{keys_sorted},
-                       (const float4 *)colors_sorted, total, too_many);
+                       (const float4 *)colors_sorted, 1u, total, too_many);
 }
 
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
 {
+    const dim3 grid(deposit_grid(total));
+    if (p.mode == 2) {      // both passes: one gather of the pairs, then each target's blend over its own half
+        hipLaunchKernelGGL(deposit_gather_pairs_kernel, grid, dim3(256), 0, s, p.colors_sorted, (const float4 *)p.colors, (const uint32_t *)p.slots_sorted, total);
+        hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, TexelKeys>), grid, dim3(256), 0, s, p.flow, TexelKeys{p.keys_sorted},
+                           (const float4 *)p.colors_sorted, 2u, total, (uint32_t *)nullptr);
+        hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, TexelKeys>), grid, dim3(256), 0, s, p.view, TexelKeys{p.keys_sorted},
+                           (const float4 *)p.colors_sorted + 1, 2u, total, (uint32_t *)nullptr);
+        return;
+    }
     launch_deposit_gather_colors(p.colors_sorted, p.colors, p.slots_sorted, total, s);
-    if (p.mode == 0) hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, TexelKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, p.flow,
-                                        TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, total, (uint32_t *)nullptr);
-    else hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, TexelKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, p.view,
-                            TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, total, (uint32_t *)nullptr);
+    if (p.mode == 0) hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, TexelKeys>), grid, dim3(256), 0, s, p.flow,
+                                        TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, 1u, total, (uint32_t *)nullptr);
+    else hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, TexelKeys>), grid, dim3(256), 0, s, p.view,
+                            TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, 1u, total, (uint32_t *)nullptr);
 }
 
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t s)

@@ -118,7 +118,7 @@ struct DepositParams {
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
     // view pass (mode 1): the vertex colours of src/render/index.vert:58-100, blended into the RGBA8 view buffer
-    int32_t mode;                // 0 = flow pass (varying = vel, time, alpha), 1 = view pass
+    int32_t mode;                // 0 = flow pass (varying = vel, time, alpha), 1 = view pass, 2 = both (varyings in pairs)
     float flow_decay, speed_alpha, colormap_alpha, sin_term;
     float base_color[4], flow_color[4];
     const float4 *colormap;      // cw x ch RGBA32F, NEAREST / CLAMP (nullptr = the 1x1 zero texture)

@@ -287,6 +287,23 @@ napi_value ViewDraw(napi_env env, napi_callback_info info)
     return v;
 }
 
+// draw(ctx, Float32Array(4) th_deposit_uniforms, Float32Array(16) th_render_uniforms) -> fragments (both passes in one)
+napi_value Draw(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_deposit_uniforms d;
+    th_render_uniforms u;
+    a.uniforms(1, &d);
+    a.uniforms(2, &u);
+    if (!a.ok) BAD_ARGS("th_draw");
+    uint64_t fragments = 0;
+    TH_CALL("th_draw", th_draw(c, &d, &u, &fragments));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)fragments, &v));
+    return v;
+}
+
 // viewFill(ctx, Float32Array(4) rgba)
 napi_value ViewFill(napi_env env, napi_callback_info info)
 {
@@ -582,7 +599,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"framesResize", FramesResize}, {"framesUpload", FramesUpload}, {"framesRotate", FramesRotate},
         {"opticalFlow", OpticalFlow},
         {"flowDeposit", FlowDeposit}, {"exportLines", ExportLines},
-        {"viewDraw", ViewDraw}, {"viewFill", ViewFill}, {"viewClear", ViewClear}, {"viewDownload", ViewDownload},
+        {"viewDraw", ViewDraw}, {"draw", Draw}, {"viewFill", ViewFill}, {"viewClear", ViewClear}, {"viewDownload", ViewDownload},
         {"colormapUpload", ColormapUpload}, {"exportViewLines", ExportViewLines},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},

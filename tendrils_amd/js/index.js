@@ -1,8 +1,8 @@
 'use strict';
 // Mirror of the reference's facade `Tendrils` (src/index.js:84-457) for the particle-update
 // path: state uniforms, timer, flow/targets textures, step(), spawn(), spawnShader(), resize().
-// draw() runs the flow pass (particle lines into the flow field); the view render (view buffers, fades) is out of
-// this build's scope and kept as chainable no-ops.
+// draw() runs the flow pass (particle lines into the flow field) and the view pass (the same lines into the RGBA8 view
+// buffer) in one native call.
 const native = require('./native');
 const { Particles, Program } = require('./particles');
 const { Timer } = require('./timer');
@@ -198,13 +198,15 @@ class Tendrils {
   }
 
   draw() {                                         // src/index.js:278-340: the flow pass, then the view pass
-    this.fragments = native.flowDeposit(this.particles.handle,
-      new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]));
-    if (this.renderView) {
-      if (this.state.autoClearView) this.clearView();
-      if (this.state.autoFade) this.drawFade();
-      this.viewFragments = native.viewDraw(this.particles.handle, this.renderUniforms());
+    const deposit = new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]);
+    if (!this.renderView) {
+      this.fragments = native.flowDeposit(this.particles.handle, deposit);
+      return this;
     }
+    // (the clear and the fade only touch the view buffer; both passes draw the same lines: rasterised and sorted once)
+    if (this.state.autoClearView) this.clearView();
+    if (this.state.autoFade) this.drawFade();
+    this.fragments = this.viewFragments = native.draw(this.particles.handle, deposit, this.renderUniforms());
     return this;
   }
 

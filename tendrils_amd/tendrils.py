@@ -275,22 +275,26 @@ class Tendrils:
         return self
 
     def draw(self):                                            # src/index.js:278-340
-        """The flow pass: particle lines into the flow texture (so that particles respond to each other's
-        wake).  The view render of the reference's draw() (display) is outside this build."""
+        """The flow pass - particle lines into the flow texture, so that particles respond to each other's wake - and,
+        with renderView, the view pass: the same lines into the RGBA8 view buffer (after the clear / fade the state
+        asks for).  Both passes draw the same lines: one call rasterises and sorts them once (th_draw)."""
         if self.dist is not None:          # row-band shard of a torch.distributed job: emit / exchange / merge
             from .sharding import draw_sharded
             self.fragments = draw_sharded(self.dist, self)
-        else:
+            return self
+        if not self.renderView:
             self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
-        if self.renderView and self.dist is None:             # the view (src/index.js:315-337), straight to the drawing buffer
-            if self.state["autoClearView"]:
-                self.clearView()
-            if self.state["autoFade"]:
-                self.drawFade()
-            n = C.c_uint64(0)
-            u = self.render_uniforms()
-            call("th_view_draw", self.particles._ctx, C.byref(u), C.byref(n))
-            self.view_fragments = int(n.value)
+            return self
+        # (the clear and the fade only touch the view buffer: it does not matter that the flow pass comes after them here)
+        if self.state["autoClearView"]:
+            self.clearView()
+        if self.state["autoFade"]:
+            self.drawFade()
+        d = _capi.DepositUniforms(time=float(self.timer.time), speedLimit=float(self.state["speedLimit"]))
+        d.viewSize[0], d.viewSize[1] = float(self.viewSize[0]), float(self.viewSize[1])
+        u, n = self.render_uniforms(), C.c_uint64(0)
+        call("th_draw", self.particles._ctx, C.byref(d), C.byref(u), C.byref(n))
+        self.fragments = self.view_fragments = int(n.value)
         return self
 
     def export_lines(self, view=False):

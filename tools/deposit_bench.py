@@ -40,10 +40,16 @@ def timed(fn):
 
 for _ in range(5):                      # warm-up: the wake builds up, buffers are sized
     t.timer.tick(); t.step(); t.draw()
-step_ms, draw_ms, view_ms, frags = [], [], [], []
+step_ms, draw_ms, view_ms, both_ms, frags = [], [], [], [], []
+both = "--both" in sys.argv              # both passes in one call (Tendrils.draw() with renderView) instead of one after the other
 for _ in range(frames):
     t.timer.tick()
     step_ms.append(timed(t.step))
+    if both:
+        t.renderView = True
+        both_ms.append(timed(t.draw))
+        frags.append(t.fragments)
+        continue
     t.renderView = False
     draw_ms.append(timed(t.draw))           # the flow pass (what feeds the next step)
     frags.append(t.fragments)
@@ -52,7 +58,8 @@ for _ in range(frames):
     view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))     # the view pass
 stats = t.particles.stats(t.state["speedLimit"])
 print(json.dumps({"particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
-                  "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)), "view_ms": float(np.mean(view_ms)),
-                  "fragments_per_frame": float(np.mean(frags)), "frames_per_s": 1e3 / float(np.mean(step_ms) + np.mean(draw_ms)),
+                  "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)) if draw_ms else None, "view_ms": float(np.mean(view_ms)) if view_ms else None,
+                  "draw_both_ms": float(np.mean(both_ms)) if both_ms else None,
+                  "fragments_per_frame": float(np.mean(frags)), "frames_per_s": 1e3 / float(np.mean(step_ms) + (np.mean(both_ms) if both_ms else np.mean(draw_ms))),
                   "live": stats["live"], "nan": stats["nan"]}))
 t.dispose()
