@@ -37,9 +37,17 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const K *keys, uint32_t
     h[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * kRadixBlock;
+    // all 16 keys of a lane first (unconditional, clamped: a load under a branch is awaited before the next is issued)
+    K key[kRadixBlock / 256u];
+#pragma unroll
     for (uint32_t k = 0; k < kRadixBlock / 256u; ++k) {
         const uint32_t i = base + k * 256u + threadIdx.x;
-        if (i < n) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+        key[k] = keys[i < n ? i : n - 1u];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kRadixBlock / 256u; ++k) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        if (i < n) atomicAdd(&h[digit_of(key[k], shift, mask)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < (1u << bits)) counts[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -65,15 +73,20 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K *keys_in, co
     K key[16];
     uint32_t val[16];
     const uint32_t wave_first = wave * 1024u;
+    // (all 32 loads of a lane in flight together: unconditional, clamped - 16 round trips in a row were the pass's time)
+    const uint32_t *vals = vals_in ? vals_in : reinterpret_cast<const uint32_t *>(keys_in);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const uint32_t e = wave_first + (uint32_t)r * 64u + lane;
-        key[r] = K(0); val[r] = 0u;
-        if (e < in_block) {
-            key[r] = keys_in[block_first + e];
-            val[r] = vals_in ? vals_in[block_first + e] : block_first + e;      // no values: the elements' own positions
-            atomicAdd(&wave_hist[wave][digit_of(key[r], shift, mask)], 1u);
-        }
+        const uint32_t at = block_first + (e < in_block ? e : 0u);
+        key[r] = keys_in[at];
+        const uint32_t v = vals[at];
+        val[r] = vals_in ? v : at;                  // no values: the elements' own positions
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t e = wave_first + (uint32_t)r * 64u + lane;
+        if (e < in_block) atomicAdd(&wave_hist[wave][digit_of(key[r], shift, mask)], 1u);
     }
     __syncthreads();
     // block-local layout: digit d starts at digit_start[d]; inside it the waves follow each other
