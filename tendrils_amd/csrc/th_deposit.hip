@@ -801,7 +801,13 @@ __global__ __launch_bounds__(256) void colscan_partial_kernel(const uint32_t *co
     if (col >= W) return;
     const uint32_t r0 = rb * kColRows, r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
     uint32_t s = 0;
-    for (uint32_t r = r0; r < r1; ++r) s += count[(size_t)r * W + col];
+    if (r1 - r0 == kColRows) {              // a full block: all its loads in flight together
+        uint32_t v[kColRows];
+#pragma unroll
+        for (uint32_t k = 0; k < kColRows; ++k) v[k] = count[(size_t)(r0 + k) * W + col];
+#pragma unroll
+        for (uint32_t k = 0; k < kColRows; ++k) s += v[k];
+    } else for (uint32_t r = r0; r < r1; ++r) s += count[(size_t)r * W + col];
     part[(size_t)rb * W + col] = s;
 }
 
@@ -812,7 +818,18 @@ __global__ __launch_bounds__(256) void colscan_prefix_kernel(uint32_t *part, uin
     const uint32_t col = blockIdx.x * 256u + threadIdx.x;
     if (col >= W) return;
     unsigned long long s = 0;
-    for (uint32_t rb = 0; rb < nrb; ++rb) {
+    uint32_t rb = 0;
+    for (; rb + 16u <= nrb; rb += 16u) {            // 16 row blocks at a time, their loads in flight together
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) v[k] = part[(size_t)(rb + k) * W + col];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            part[(size_t)(rb + k) * W + col] = (uint32_t)(s > 0xffffffffull ? 0xffffffffull : s);
+            s += v[k];
+        }
+    }
+    for (; rb < nrb; ++rb) {
         const uint32_t v = part[(size_t)rb * W + col];
         part[(size_t)rb * W + col] = (uint32_t)(s > 0xffffffffull ? 0xffffffffull : s);
         s += v;
@@ -854,7 +871,13 @@ __global__ __launch_bounds__(256) void colscan_offsets_kernel(const uint32_t *co
     if (col >= W) return;
     const uint32_t r0 = rb * kColRows, r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
     uint32_t run = colbase[col] + part[(size_t)rb * W + col];
-    for (uint32_t r = r0; r < r1; ++r) { offset[(size_t)r * W + col] = run; run += count[(size_t)r * W + col]; }
+    if (r1 - r0 == kColRows) {
+        uint32_t v[kColRows];
+#pragma unroll
+        for (uint32_t k = 0; k < kColRows; ++k) v[k] = count[(size_t)(r0 + k) * W + col];
+#pragma unroll
+        for (uint32_t k = 0; k < kColRows; ++k) { offset[(size_t)(r0 + k) * W + col] = run; run += v[k]; }
+    } else for (uint32_t r = r0; r < r1; ++r) { offset[(size_t)r * W + col] = run; run += count[(size_t)r * W + col]; }
 }
 
 // ---- trail export: the line list of draw() (12 floats per line, stream order) ---------------------------------
