@@ -99,11 +99,15 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j)
     const float4 *tex = offset > 0.25f ? p.cur : p.prev;
     int row = dep_nearest(ly, H) - (int)p.row0;              // row-band shard: the band (or its halo rows) must hold the row
     const int col = dep_nearest(uvx, W);
-    float4 t;
-    if (row >= 0 && row < (int)p.rows) t = tex[(size_t)row * W + col];
-    else if (row == -1 && p.halo_lo) t = p.halo_lo[(offset > 0.25f ? 0 : W) + col];
-    else if (row == (int)p.rows && p.halo_hi) t = p.halo_hi[(offset > 0.25f ? 0 : W) + col];
-    else { *p.oob = 1u; t = tex[(size_t)(row < 0 ? 0 : (int)p.rows - 1) * W + col]; }
+    // (one unconditional load from a selected address: a load under a branch is awaited at the join, and the second
+    // vertex's load would only go out after the first had come back)
+    const float4 *from = tex + (size_t)(row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1)) * W + col;
+    if (!(row >= 0 && row < (int)p.rows)) {
+        if (row == -1 && p.halo_lo) from = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
+        else if (row == (int)p.rows && p.halo_hi) from = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
+        else *p.oob = 1u;
+    }
+    const float4 t = *from;
     DepositVertex v;
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
