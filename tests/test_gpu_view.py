@@ -105,6 +105,44 @@ def test_view_crowded_texels_are_order_exact(oracle):
     assert (got == want).all()
 
 
+def test_draw_in_one_call_equals_the_two_passes():
+    """Tendrils.draw() with renderView runs both passes over one rasterisation, one sort and one gather (th_draw); the
+    flow texture and the view buffer must be what th_flow_deposit followed by th_view_draw leave - which reuses the flow
+    pass's geometry - and what the two passes leave when each rasterises for itself (TH_DRAW_REUSE=0 is read once per
+    process: that third way is the golden-fixture test above, which predates both shortcuts)."""
+    import ctypes as C
+    from tendrils_amd import _capi
+    n, view = 128, (96, 54)
+    rng = np.random.default_rng(21)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.6, 0.6, (n, n, 2)) * [1.0, 54 / 96]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.05, .05, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    m = dict(viewRes=list(view), viewSize=[1.0, 96 / 54], render=dict(speedLimit=0.01, flowDecay=0.005, speedAlpha=0.5,
+             colorMapAlpha=0.0, baseColor=[1, 0.7, 0.3, 0.2], flowColor=[0.2, 1, 0.9, 0.1]))
+    out = []
+    for one_call in (True, False):
+        t = make(m, n)
+        t.particles.upload_texels(cur, 0)
+        t.particles.upload_texels(prev, 1)
+        t.timer.time = 900.0
+        if one_call:
+            t.draw()
+        else:
+            t.renderView = False
+            t.draw()                                            # th_flow_deposit
+            u, k = t.render_uniforms(), C.c_uint64(0)
+            _capi.call("th_view_draw", t.particles._ctx, C.byref(u), C.byref(k))
+            assert k.value == t.fragments
+        out.append((t.flow.read(), t.read_view(), t.fragments))
+        t.dispose()
+    assert out[0][2] == out[1][2] > 10000
+    assert bits_equal(out[0][0], out[1][0]).all() and (out[0][1] == out[1][1]).all() and out[0][1].any()
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 def test_node_host_view_draw(oracle):
     path = [p for p in golden("view") if "colours" in p][0]
