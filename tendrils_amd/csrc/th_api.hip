@@ -322,7 +322,6 @@ uint32_t tile_count(const th_context *c, uint32_t *tiles_x)
 }
 bool sorting_possible(const th_context *c)
 {
-    if (c->packed) return false;                                 // packed ring: texel order only
     const size_t flow_texels = (size_t)c->fw * c->fh;
     if (c->texels() < 2 * flow_texels) return false;           // the decoded plane is not used at all
     if ((size_t)tile_count(c, nullptr) + 1 > th::kMaxTileBins) return false;
@@ -397,7 +396,7 @@ th_status ensure_identity(th_context *c, bool *launched = nullptr)
     for (float4 *&b : c->ring) {
         const int o = order_of(c, b);
         if (o < 0) continue;
-        th::launch_unpermute_state(c->spare, b, c->orders[(size_t)o].perm, (uint32_t)c->texels(), c->stream);
+        th::launch_unpermute_state(c->spare, b, c->orders[(size_t)o].perm, (uint32_t)c->texels(), c->packed, c->stream);
         set_order(c, b, -1);
         float4 *t = b; b = c->spare; c->spare = t;
         if (launched) *launched = true;
@@ -422,6 +421,7 @@ th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, 
     b.chunks = o.chunks; b.nchunks = o.nchunks;
     b.perm_out = o.perm;
     b.block_records = have_hist ? nullptr : c->block_records;      // (only a tile_hist pass over the same blocks fills them)
+    b.packed = c->packed ? 1u : 0u;
     if (!have_hist) {          // (a COUNT pass whose histogram was never used may have left counts behind)
         TH_HIP(hipMemsetAsync(b.hist, 0, kTileWords / 2 * sizeof(uint32_t), c->stream));
         th::launch_tile_hist(b, c->stream);
@@ -930,7 +930,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
         // Slot layout of the fused passes: the newest state (ring[0]) may be in a tile-sorted order; both outputs of a
         // pass keep the slots of its input.  (Re)sorted every rebucket_period() steps by a plain move into the other
         // buffer, whose content (state n-1 of the previous call) the pass overwrites anyway.
-        if (plan.may_sort && !c->packed) {
+        if (plan.may_sort) {
             const th::TileGeom g = tile_geom(c, plan.p.u);
             int o = order_of(c, c->ring[0]);
             const bool stale = o >= 0 && (!same_geom(c->orders[(size_t)o].geom, g) || c->orders[(size_t)o].fw != c->fw ||

@@ -13,6 +13,7 @@
 #include "th_kernels.hpp"
 #include "th_math.hpp"
 
+#include <type_traits>
 #include <cstdlib>
 
 namespace th {
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 // Packed ring (TH_STATE_F16): the same fusion on 8-B texels.  The storage quantisation is part of every step
 // (a step reads what the previous one stored), so each intermediate state goes through pack -> unpack in
 // registers: bit-identical to nsteps logic_packed_kernel launches.
-template <bool FAST, bool NOISE, bool TARGET, bool POW2>
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
 __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicParams p)
 {
     __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
@@ -682,16 +683,34 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
     }
     const v2u *in = reinterpret_cast<const v2u *>(p.in);
     v2u *out = reinterpret_cast<v2u *>(p.out), *out_prev = reinterpret_cast<v2u *>(p.out_prev);
-    const uint32_t stride = gridDim.x * 256u;
-    uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    uint32_t idx, stride, end;
+    if constexpr (!BUCKETED) {
+        idx = blockIdx.x * 256u + threadIdx.x;
+        stride = gridDim.x * 256u;
+        end = p.count;
+    } else {            // tile-sorted slots (p.perm), dealt to the 8 XCD groups in eighths like the f32 pass
+        const uint32_t group = blockIdx.x & 7u, rank = blockIdx.x >> 3, per = (p.count + 7u) >> 3;
+        const uint32_t lo = group * per;
+        idx = lo + rank * 256u + threadIdx.x;
+        stride = (gridDim.x >> 3) * 256u;
+        end = lo + per < p.count ? lo + per : p.count;
+    }
     v2u nxt = {0x80008000u, 0u};
-    if (idx < p.count) nxt = __builtin_nontemporal_load(&in[idx]);
-    for (; idx < p.count; idx += stride) {
+    uint32_t npid = idx;
+    if (idx < end) {
+        nxt = __builtin_nontemporal_load(&in[idx]);
+        if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx]);
+    }
+    for (; idx < end; idx += stride) {
         uint2 w = make_uint2(nxt.x, nxt.y), wprev = w;
-        if (idx + stride < p.count) nxt = __builtin_nontemporal_load(&in[idx + stride]);
+        const uint32_t pid = BUCKETED ? npid : idx;
+        if (idx + stride < end) {
+            nxt = __builtin_nontemporal_load(&in[idx + stride]);
+            if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx + stride]);
+        }
         for (uint32_t k = 0; k < p.nsteps; ++k) {
             wprev = w;
-            w = pack_state(integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, unpack_state(w), idx, p.times[k], &tabs));
+            w = pack_state(integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, unpack_state(w), pid, p.times[k], &tabs));
         }
         v2u a = {wprev.x, wprev.y}, b = {w.x, w.y};
         __builtin_nontemporal_store(a, &out_prev[idx]);
@@ -718,9 +737,12 @@ template <bool FAST, bool NOISE, bool TARGET>
 static void launch_fused_p2(const LogicParams &p, bool pow2, bool packed, hipStream_t s)
 {
     if (packed) {
-        const int pgrid = fused_grid(p.count, false);
-        if (pow2) hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, true>), dim3(pgrid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, false>), dim3(pgrid), dim3(256), 0, s, p);
+        const bool sorted = p.perm != nullptr;
+        const int pgrid = fused_grid(p.count, sorted);
+#define TH_GO(P2, BK) hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, P2, BK>), dim3(pgrid), dim3(256), 0, s, p)
+        if (pow2) { if (sorted) TH_GO(true, true); else TH_GO(true, false); }
+        else { if (sorted) TH_GO(false, true); else TH_GO(false, false); }
+#undef TH_GO
         return;
     }
     const bool bucketed = p.perm != nullptr;
@@ -849,6 +871,17 @@ TH_D void bins_flush(const ChunkBins &t, uint32_t *global_hist, uint32_t rep, Ch
     }
 }
 
+// position of slot `at` of a state buffer in either storage format
+template <bool PACKED>
+TH_D float2 slot_position(const float4 *state, uint32_t at)
+{
+    if constexpr (PACKED) {
+        const float4 s = unpack_state(make_uint2(reinterpret_cast<const uint2 *>(state)[at].x, 0u));
+        return make_float2(s.x, s.y);
+    } else return *reinterpret_cast<const float2 *>(&state[at]);
+}
+
+template <bool PACKED>
 __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
 {
     __shared__ ChunkBins bins;
@@ -860,7 +893,7 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
 #pragma unroll
     for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
         const uint32_t s = base + k * 256u + threadIdx.x;
-        pos[k] = *reinterpret_cast<const float2 *>(&b.state[s < b.count ? s : b.count - 1u]);
+        pos[k] = slot_position<PACKED>(b.state, s < b.count ? s : b.count - 1u);
     }
 #pragma unroll
     for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
@@ -938,8 +971,10 @@ TH_D uint32_t reserve_slots(ChunkBins &t, uint32_t *cursor, uint32_t rep, uint32
 // block's table of (tile, count) from tile_hist_kernel every tile's range is reserved once per workgroup (one atomic each,
 // all in flight together) and the ranks come from LDS; without it - and for tiles that did not fit the table - every
 // wave run waits for its own round trip to the global cursor (16 of them in a row per lane: 0.93 ms at C3 against 0.3).
+template <bool PACKED>
 __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileSortParams b)
 {
+    using Texel = std::conditional_t<PACKED, v2u, v4f>;          // 8-byte packed texels or RGBA32F
     __shared__ ChunkBins bins;
     const bool tabled = b.block_records != nullptr;
     if (tabled) {
@@ -952,32 +987,37 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileSortParams 
         __syncthreads();
     }
     const uint32_t base = blockIdx.x * kTileChunk;
-    const uint32_t *ids = b.perm_in ? b.perm_in : reinterpret_cast<const uint32_t *>(b.state);     // (texel order: a word read anyway)
+    const uint32_t *ids = b.perm_in ? b.perm_in : reinterpret_cast<const uint32_t *>(b.state);     // (texel order: a word read anyway;
+                                                                                                      // both formats hold >= count words)
     // four slots of a lane per round, their loads in flight together (unconditional, clamped)
     constexpr uint32_t kRound = 4;
     for (uint32_t k0 = 0; k0 < kTileChunk / 256u; k0 += kRound) {
-        float4 st[kRound];
+        Texel st[kRound];
         uint32_t pid[kRound];
 #pragma unroll
         for (uint32_t q = 0; q < kRound; ++q) {
             const uint32_t s = base + (k0 + q) * 256u + threadIdx.x, at = s < b.count ? s : b.count - 1u;
-            st[q] = load_stream(&b.state[at]);
+            st[q] = __builtin_nontemporal_load(&reinterpret_cast<const Texel *>(b.state)[at]);
             pid[q] = __builtin_nontemporal_load(&ids[at]);
         }
 #pragma unroll
         for (uint32_t q = 0; q < kRound; ++q) {
             const uint32_t s = base + (k0 + q) * 256u + threadIdx.x;
             const bool valid = s < b.count;
-            const uint32_t key = valid ? tile_key(b.g, st[q].x, st[q].y) : 0u;
+            float px, py;
+            if constexpr (PACKED) { const float4 u = unpack_state(make_uint2(st[q].x, 0u)); px = u.x; py = u.y; }
+            else { px = st[q].x; py = st[q].y; }
+            const uint32_t key = valid ? tile_key(b.g, px, py) : 0u;
             const uint32_t d = tabled ? reserve_slots(bins, b.cursor, replica_of(blockIdx.x), key, valid)
                                       : reserve_slots(b.cursor, replica_of(blockIdx.x) + key, valid);
-            if (valid) { b.state_out[d] = st[q]; b.perm_out[d] = b.perm_in ? pid[q] : s; }
+            if (valid) { reinterpret_cast<Texel *>(b.state_out)[d] = st[q]; b.perm_out[d] = b.perm_in ? pid[q] : s; }
         }
     }
 }
 
 // back to texel order: dst[perm[s]] = src[s]
-__global__ __launch_bounds__(256) void unpermute_state_kernel(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n)
+template <typename Texel>
+__global__ __launch_bounds__(256) void unpermute_state_kernel(Texel *dst, const Texel *src, const uint32_t *perm, uint32_t n)
 {
     for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) dst[perm[s]] = src[s];
 }
@@ -986,7 +1026,8 @@ static int tile_grid(uint32_t count) { return (int)((count + kTileChunk - 1) / k
 
 void launch_tile_hist(const TileSortParams &b, hipStream_t s)
 {
-    hipLaunchKernelGGL(tile_hist_kernel, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
+    if (b.packed) hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
 }
 
 void launch_tile_scan(const TileSortParams &b, hipStream_t s)
@@ -996,12 +1037,15 @@ void launch_tile_scan(const TileSortParams &b, hipStream_t s)
 
 void launch_tile_scatter(const TileSortParams &b, hipStream_t s)
 {
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
+    if (b.packed) hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(tile_grid(b.count)), dim3(256), 0, s, b);
 }
 
-void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t s)
+void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t s)
 {
-    hipLaunchKernelGGL(unpermute_state_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, perm, n);
+    if (packed) hipLaunchKernelGGL(unpermute_state_kernel<uint2>, dim3(grid_for(n, 8)), dim3(256), 0, s, reinterpret_cast<uint2 *>(dst),
+                                   reinterpret_cast<const uint2 *>(src), perm, n);
+    else hipLaunchKernelGGL(unpermute_state_kernel<float4>, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, perm, n);
 }
 
 // ---------------------------------------------------------------------------

@@ -75,6 +75,7 @@ struct TileSortParams {
     float4 *state_out;           // tile_scatter only
     uint32_t *perm_out;
     ChunkRecord *block_records;  // per 4096-slot block of the input: written by tile_hist, used by tile_scatter (may be null)
+    uint32_t packed;             // the state is the packed 8-byte form (TH_STATE_F16): state / state_out point at uint2 texels
 };
 
 struct OpticalFlowParams {
@@ -160,7 +161,7 @@ void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target
 void launch_tile_hist(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scan(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scatter(const TileSortParams &b, hipStream_t stream);
-void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, hipStream_t stream);
+void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t stream);
 void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
 void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials, const unsigned long long *respawned,
