@@ -819,7 +819,32 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     int in_order = sorted ? order_of(c, in) : -1, out_order = -1;
     bool use_sorted = false, scatter = false, count = false, gather = false;
     static const bool window_mode = [] { const char *e = getenv("TH_SINGLE"); return e && !strcmp(e, "window"); }();
-    if (sorted) {
+    if (sorted && packed_kernel) {
+        // packed ring: the plain grid-stride kernel over the sorted slots; a re-sort is a plain move of the input
+        // (tile_hist, scan, tile_scatter into the spare buffer, which then takes the input's place in the ring)
+        const th::TileGeom g = tile_geom(c, p.u);
+        const bool stale = in_order >= 0 && (!same_geom(c->orders[(size_t)in_order].geom, g) ||
+                                             c->orders[(size_t)in_order].fw != c->fw || c->orders[(size_t)in_order].fh != c->fh);
+        if (in_order < 0 || stale || c->steps_since_sort >= resort_period()) {
+            int fresh = -1;
+            th::TileSortParams b;
+            if (th_status s = begin_sort(c, g, in, in_order >= 0 ? c->orders[(size_t)in_order].perm : nullptr, &fresh, &b)) return s;
+            b.state_out = c->spare;
+            th::launch_tile_scatter(b, c->stream);
+            TH_HIP(hipGetLastError());
+            clear_graphs(c);               // captured sequences name the ring buffers: one of them changes places with the spare
+            float4 *old = in;
+            for (float4 *&r : c->ring) if (r == old) r = c->spare;
+            c->spare = old;
+            set_order(c, old, -1);
+            in = c->ring[1];
+            set_order(c, in, fresh);
+            p.in = in;
+            in_order = fresh;
+        }
+        p.perm = c->orders[(size_t)in_order].perm;
+        out_order = in_order;
+    } else if (sorted) {
         const th::TileGeom g = tile_geom(c, p.u);
         const bool stale = in_order >= 0 && (!same_geom(c->orders[(size_t)in_order].geom, g) ||
                                              c->orders[(size_t)in_order].fw != c->fw || c->orders[(size_t)in_order].fh != c->fh);
@@ -895,7 +920,7 @@ th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
     TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
     StepPlan plan;
     if (th_status s = plan_step(c, *u, target, plan)) return s;
-    const bool sorted = plan.may_sort && !plan.generic && !c->packed;
+    const bool sorted = plan.may_sort && !plan.generic;
     if (!sorted) if (th_status s = ensure_identity(c)) return s;
     return enqueue_step(c, plan, target, u->time, nullptr, true, sorted);
 }

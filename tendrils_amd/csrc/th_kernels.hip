@@ -525,13 +525,16 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 }
 
 // Packed-state integrator (TH_STATE_F16): same per-particle arithmetic on the decoded texel, 8 B in / 8 B out.
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED>
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB>
 __global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p)
 {
     const float time = p.time_dev ? *p.time_dev : p.u.time;
-    __shared__ float4 lut[NOISE ? kLutSize : 1];
+    __shared__ float4 smem[NOISE ? (PTAB ? kHashVec : 0) + kLutSize : 1];      // (PTAB: sorted slots, as logic_kernel)
+    const float4 *lut = smem + (NOISE && PTAB ? kHashVec : 0);
+    const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
     if constexpr (NOISE) {
-        for (int k = threadIdx.x; k < kLutSize; k += 256) lut[k] = p.lut[k];
+        if constexpr (PTAB) fill_hash_tables(smem, p.lut);
+        else for (int k = threadIdx.x; k < kLutSize; k += 256) smem[k] = p.lut[k];
         __syncthreads();
     }
     const v2u *in = reinterpret_cast<const v2u *>(p.in);
@@ -539,11 +542,14 @@ __global__ __launch_bounds__(256) void logic_packed_kernel(const LogicParams p)
     const uint32_t stride = gridDim.x * 256u;
     uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     v2u nxt = {0x80008000u, 0u};
-    if (idx < p.count) nxt = __builtin_nontemporal_load(&in[idx]);
+    const uint32_t *perm = p.perm;          // tile-sorted slots: the particle of slot s is perm[s] (as logic_kernel)
+    uint32_t pnxt = idx;
+    if (idx < p.count) { nxt = __builtin_nontemporal_load(&in[idx]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx]); }
     for (; idx < p.count; idx += stride) {
         v2u w = nxt;
-        if (idx + stride < p.count) nxt = __builtin_nontemporal_load(&in[idx + stride]);
-        float4 r = integrate<FAST, NOISE, TARGET, POW2, DECODED>(p, lut, unpack_state(make_uint2(w.x, w.y)), idx, time);
+        const uint32_t pid = perm ? pnxt : idx;
+        if (idx + stride < p.count) { nxt = __builtin_nontemporal_load(&in[idx + stride]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx + stride]); }
+        float4 r = integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, unpack_state(make_uint2(w.x, w.y)), pid, time, &tabs);
         uint2 q = pack_state(r);
         v2u qq = {q.x, q.y};
         __builtin_nontemporal_store(qq, &out[idx]);
@@ -580,8 +586,10 @@ static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipSt
 template <bool FAST, bool NOISE, bool TARGET>
 static void launch_packed_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
-    int grid = grid_for(p.count, 8);
-#define TH_GO(P2, DEC) hipLaunchKernelGGL((logic_packed_kernel<FAST, NOISE, TARGET, P2, DEC>), dim3(grid), dim3(256), 0, s, p)
+    // 64 VGPRs in texel order (8 workgroups per CU resident: a grid of 8 per CU), 68 with the hash tables over sorted slots (7)
+    int grid = grid_for(p.count, p.perm ? 20 : 8);
+#define TH_GO(P2, DEC) do { if (p.perm) hipLaunchKernelGGL((logic_packed_kernel<FAST, NOISE, TARGET, P2, DEC, true>), dim3(grid), dim3(256), 0, s, p); \
+                            else hipLaunchKernelGGL((logic_packed_kernel<FAST, NOISE, TARGET, P2, DEC, false>), dim3(grid), dim3(256), 0, s, p); } while (0)
     if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
     else { if (decoded) TH_GO(false, true); else TH_GO(false, false); }
 #undef TH_GO
