@@ -118,7 +118,7 @@ struct th_context {
     int32_t fw = 0, fh = 0;
     float4 *targets = nullptr;
     bool targets_checked = true, targets_nonfinite = false;   // fresh texture = zeros
-    float4 *lut = nullptr;
+    float4 *lut = nullptr, *lut_block = nullptr;      // gradient table (inside lut_block, behind the hash tables)
     uchar4 *frames[2] = {nullptr, nullptr};
     int32_t frw = 0, frh = 0;
     unsigned int *d_flag = nullptr;
@@ -486,10 +486,15 @@ th_status th_create(const th_config *cfg, th_context **out)
         TH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         TH_HIP(hipEventCreate(&c->ev0));
         TH_HIP(hipEventCreate(&c->ev1));
-        TH_HIP(hipMalloc((void **)&c->lut, th::kLutSize * sizeof(float4)));
+        // one block: [hash tables (filled on the device) | gradient table]; c->lut points at the gradient table
+        const size_t hv = (size_t)th::hash_table_vectors();
+        TH_HIP(hipMalloc((void **)&c->lut_block, (hv + th::kLutSize) * sizeof(float4)));
+        c->lut = c->lut_block + hv;
         std::vector<float4> lut(th::kLutSize);
         build_gradient_table(lut.data());
         TH_HIP(hipMemcpy(c->lut, lut.data(), lut.size() * sizeof(float4), hipMemcpyHostToDevice));
+        th::launch_hash_tables(c->lut_block, c->stream);
+        TH_HIP(hipGetLastError());
         TH_HIP(hipMalloc((void **)&c->d_flag, sizeof(unsigned int)));
         TH_HIP(hipMalloc((void **)&c->partials, th::kStatsBlocks * sizeof(th::StatsPartial)));
         TH_HIP(hipMalloc((void **)&c->d_counters, sizeof(th_counters)));
@@ -524,7 +529,7 @@ th_status th_destroy(th_context *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (float4 *b : c->ring) (void)hipFree(b);
-    (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut);
+    (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut_block);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);

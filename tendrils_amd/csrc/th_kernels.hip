@@ -174,13 +174,23 @@ struct HashTables {
     const uint32_t *permA, *permB;
 };
 
+// [permA | permB | gradient table] as one block: computed once per context into global memory (hash_tables_kernel, with
+// permute_int itself), copied into LDS by every workgroup (803 float4: three loads per thread instead of ~100 VALU
+// instructions per thread to evaluate the polynomial - a fused launch has one workgroup per 256 particles)
 TH_D void fill_hash_tables(float4 *smem, const float4 *lut_global)
 {
-    uint32_t *a = reinterpret_cast<uint32_t *>(smem), *b = a + kPermA;
+    const float4 *block = lut_global - kHashVec;        // (LogicParams::lut points at the gradient table inside the block)
+    for (int k = threadIdx.x; k < kHashVec + kLutSize; k += 256) smem[k] = block[k];
+}
+
+__global__ __launch_bounds__(256) void hash_tables_kernel(float4 *block)
+{
+    uint32_t *a = reinterpret_cast<uint32_t *>(block), *b = a + kPermA;
     for (int k = threadIdx.x; k < kPermA; k += 256) a[k] = 4u * (uint32_t)permute_int((float)k);
     for (int k = threadIdx.x; k < kPermB; k += 256) b[k] = 16u * (uint32_t)((int)permute_int((float)k) - kLutMin);
-    for (int k = threadIdx.x; k < kLutSize; k += 256) smem[kHashVec + k] = lut_global[k];
 }
+void launch_hash_tables(float4 *block, hipStream_t s) { hipLaunchKernelGGL(hash_tables_kernel, dim3(1), dim3(256), 0, s, block); }
+int hash_table_vectors() { return kHashVec; }
 
 template <bool FAST>
 TH_D NoiseCorners snoise_corners_tab(float vx, float vy, float vz, float sxy, const HashTables &T)

@@ -33,7 +33,7 @@ struct LogicParams {
     const float4 *flow;      // RGBA32F flow texture, fw x fh
     const float2 *flow_dec;  // flow decoded for this step's time: xy * max(0, 1-(time-z)*decay)
     const float4 *targets;   // RGBA32F targets texture (local rows)
-    const float4 *lut;       // noise gradient table (kLutSize float4)
+    const float4 *lut;       // noise gradient table (kLutSize float4), preceded in memory by the hash tables (hash_table_vectors() float4)
     uint32_t count;          // texels held by this context = width * local rows
     uint32_t width;
     uint32_t log2w;          // valid when pow2 != 0
@@ -163,6 +163,8 @@ void launch_tile_scan(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scatter(const TileSortParams &b, hipStream_t stream);
 void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t stream);
 void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
+void launch_hash_tables(float4 *block, hipStream_t stream);      // the hash tables in front of the gradient table (th_kernels.hip)
+int hash_table_vectors();
 void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials, const unsigned long long *respawned,
                   th_counters *out, hipStream_t stream);
