@@ -7,10 +7,11 @@
  * "logic" shader, driven by `Tendrils.step()/spawnShader()` (src/index.js:248-272,
  * 432-457) over WebGL FBO ping-pong.  Each entry point below replaces one of
  * those GL-backed operations; the ctypes binding (tendrils_amd/_capi.py) binds exactly these
- * symbols and the N-API shim (tendrils_amd/csrc/th_napi.cc) all of them except the multi-GPU
- * exchange primitives (th_deposit_emit / _merge / _set_halo / _set_owners, th_flow_device_ptr, th_state_device_ptr,
- * th_stream, th_stats_async: the sharded host is the Python one, over torch.distributed - INTEGRATION.md),
- * th_spawn_image_download and th_slot_order.
+ * symbols and the N-API shim (tendrils_amd/csrc/th_napi.cc) all of them except th_stream, th_stats_async,
+ * th_spawn_image_download and th_slot_order (the multi-GPU exchange primitives - th_deposit_emit / _merge / _set_halo /
+ * _set_owners, th_flow_device_ptr, th_state_device_ptr - hand device addresses to JS as BigInt; the transport between the
+ * ranks is the host application's: the host that ships with this build for sharded runs is the Python one, over
+ * torch.distributed - INTEGRATION.md).
  *
  * Conventions
  *  - plain C, no exceptions across the boundary; every call returns th_status

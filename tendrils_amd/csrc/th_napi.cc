@@ -536,6 +536,101 @@ napi_value Stats(napi_env env, napi_callback_info info)
     return o;
 }
 
+// ---- multi-GPU exchange primitives (row-band shards): device addresses travel as BigInt; the transport between the
+// ranks' processes is the host application's (the Python host uses torch.distributed / RCCL, tendrils_amd/sharding.py) ----
+bool bigint_ptr(napi_env env, napi_value v, void **out)        // BigInt | null | undefined -> address
+{
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return false;
+    if (t == napi_null || t == napi_undefined) { *out = nullptr; return true; }
+    uint64_t u = 0;
+    bool lossless = false;
+    if (t != napi_bigint || napi_get_value_bigint_uint64(env, v, &u, &lossless) != napi_ok || !lossless) return false;
+    *out = reinterpret_cast<void *>((uintptr_t)u);
+    return true;
+}
+napi_value make_bigint(napi_env env, const void *p)
+{
+    napi_value v = nullptr;
+    napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)p, &v);
+    return v;
+}
+
+// depositSetOwners(ctx, world)
+napi_value DepositSetOwners(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    const int32_t world = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_deposit_set_owners");
+    TH_CALL("th_deposit_set_owners", th_deposit_set_owners(c, world));
+    return undefined(env);
+}
+
+// depositSetHalo(ctx, loAddress | null, hiAddress | null)
+napi_value DepositSetHalo(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    void *lo = nullptr, *hi = nullptr;
+    if (!a.ok || a.argc < 3 || !bigint_ptr(env, a.argv[1], &lo) || !bigint_ptr(env, a.argv[2], &hi)) BAD_ARGS("th_deposit_set_halo");
+    TH_CALL("th_deposit_set_halo", th_deposit_set_halo(c, lo, hi));
+    return undefined(env);
+}
+
+// depositEmit(ctx, Float32Array(4) th_deposit_uniforms) -> { count, keys: address, colors: address }
+napi_value DepositEmit(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_deposit_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_deposit_emit");
+    uint64_t count = 0;
+    void *keys = nullptr, *colors = nullptr;
+    TH_CALL("th_deposit_emit", th_deposit_emit(c, &u, &count, &keys, &colors));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_double(env, (double)count, &v));
+    NAPI_OK(napi_set_named_property(env, o, "count", v));
+    NAPI_OK(napi_set_named_property(env, o, "keys", make_bigint(env, keys)));
+    NAPI_OK(napi_set_named_property(env, o, "colors", make_bigint(env, colors)));
+    return o;
+}
+
+// depositMerge(ctx, keysAddress, colorsAddress, count)
+napi_value DepositMerge(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    void *keys = nullptr, *colors = nullptr;
+    const double count = a.f64(3);
+    if (!a.ok || !bigint_ptr(env, a.argv[1], &keys) || !bigint_ptr(env, a.argv[2], &colors) || count < 0) BAD_ARGS("th_deposit_merge");
+    TH_CALL("th_deposit_merge", th_deposit_merge(c, keys, colors, (uint64_t)count));
+    return undefined(env);
+}
+
+// flowDevicePtr(ctx) / stateDevicePtr(ctx, buffer) -> address
+napi_value FlowDevicePtr(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_flow_device_ptr");
+    void *p = nullptr;
+    TH_CALL("th_flow_device_ptr", th_flow_device_ptr(c, &p));
+    return make_bigint(env, p);
+}
+napi_value StateDevicePtr(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    const int32_t buffer = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_state_device_ptr");
+    void *p = nullptr;
+    TH_CALL("th_state_device_ptr", th_state_device_ptr(c, buffer, &p));
+    return make_bigint(env, p);
+}
+
 napi_value TimerStart(napi_env env, napi_callback_info info)
 {
     Args a(env, info);
@@ -601,6 +696,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"flowDeposit", FlowDeposit}, {"exportLines", ExportLines},
         {"viewDraw", ViewDraw}, {"draw", Draw}, {"viewFill", ViewFill}, {"viewClear", ViewClear}, {"viewDownload", ViewDownload},
         {"colormapUpload", ColormapUpload}, {"exportViewLines", ExportViewLines},
+        {"depositSetOwners", DepositSetOwners}, {"depositSetHalo", DepositSetHalo}, {"depositEmit", DepositEmit},
+        {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},
     };

@@ -27,7 +27,7 @@ def test_addon_loads_and_exports_the_abi():
              "console.log(JSON.stringify({n:Object.keys(a).length,abi:a.abiVersion(),ring:a.TARGET_RING}))")
     assert r.returncode == 0, r.stderr
     info = json.loads(r.stdout)
-    assert info == {"n": 51, "abi": 5, "ring": -1}
+    assert info == {"n": 57, "abi": 5, "ring": -1}
 
 
 def test_timer_matches_reference_semantics():
@@ -250,3 +250,48 @@ def test_js_geometry_spawner(tmp_path, oracle):
     u = oracle.spawn_sample_uniforms(n, n, res["time"], 6, 3, spawnSize=[1, 1], jitter=res["jitter"], speed=0.005,
                                      bias=1e2 / 5e-3, spawnMatrix=[1, 0, 0, 0, 1, 0, 0, 0, 1])
     assert bits_equal(got, oracle.spawn_sample(u, st, fx["out"])).all()
+
+
+@pytest.mark.gpu
+def test_js_exchange_primitives_world_size_1(oracle):
+    """The multi-GPU exchange primitives through the N-API shim (device addresses as BigInt): at one owner, emit followed
+    by merge of the emitted buffers is the flow pass - the flow texture must equal the oracle's deposit bit for bit."""
+    import base64
+    import shutil
+    import subprocess
+    n, view = 40, (96, 54)               # (the state travels on node's command line)
+    rng = np.random.default_rng(31)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.9, 0.9, (n, n, 2)) * [1.0, 54 / 96]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.06, .06, (n, n, 2)).astype(np.float32)
+    script = """
+    const T = require('./tendrils_amd/js');
+    const native = require('./tendrils_amd/js/native');
+    const cfg = JSON.parse(process.argv[1]);
+    const f32 = (b) => new Float32Array(new Uint8Array(Buffer.from(b, 'base64')).buffer);
+    const t = new T.Tendrils({drawingBufferWidth: cfg.view[0], drawingBufferHeight: cfg.view[1]}, {});
+    t.resize(); t.setup(cfg.n);
+    t.particles.uploadTexels(f32(cfg.cur), 0); t.particles.uploadTexels(f32(cfg.prev), 1);
+    t.timer.time = cfg.time;
+    const h = t.particles.handle;
+    native.depositSetOwners(h, 1);
+    native.depositSetHalo(h, null, null);
+    const e = native.depositEmit(h, new Float32Array([t.viewSize[0], t.viewSize[1], t.timer.time, t.state.speedLimit]));
+    if (typeof e.keys !== 'bigint' || typeof native.flowDevicePtr(h) !== 'bigint') throw new Error('addresses are BigInt');
+    native.depositMerge(h, e.keys, e.colors, e.count);
+    const out = {flow: Buffer.from(t.flow.read().buffer).toString('base64'), count: e.count,
+                 state0: native.stateDevicePtr(h, 0) !== native.stateDevicePtr(h, 1)};
+    t.dispose();
+    console.log(JSON.stringify(out));
+    """
+    cfg = dict(n=n, view=list(view), time=800.0,
+               cur=base64.b64encode(cur.tobytes()).decode(), prev=base64.b64encode(prev.tobytes()).decode())
+    r = subprocess.run([shutil.which("node"), "-e", script, json.dumps(cfg)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout)
+    got = np.frombuffer(base64.b64decode(res["flow"]), np.float32).reshape(view[1], view[0], 4)
+    want, frags = oracle.flow_deposit(cur, prev, np.zeros((view[1], view[0], 4), np.float32), 800.0, view_size=(1.0, 96 / 54))
+    assert res["count"] == frags and res["state0"]
+    assert bits_equal(got, want).all()
