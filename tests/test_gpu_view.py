@@ -143,6 +143,46 @@ def test_draw_in_one_call_equals_the_two_passes():
     assert bits_equal(out[0][0], out[1][0]).all() and (out[0][1] == out[1][1]).all() and out[0][1].any()
 
 
+def test_draw_paths_agree_at_scale():
+    """4.2 M particles over a 1080p field (7 M fragments, long runs in the wake of a few frames): draw() in one call, the two
+    passes one after the other (the view pass reusing the flow pass's geometry) and the sharded form's emit + merge at one
+    owner leave the same flow texture, bit for bit; the first two also the same view buffer."""
+    import ctypes as C
+    import tendrils_amd as ta
+    from tendrils_amd import _capi, sharding
+    from tendrils_amd.tendrils import View
+    n, view = 2048, (1920, 1080)
+    rng = np.random.default_rng(5)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2)) * [1.0, 1080 / 1920]
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+    results = []
+    for how in ("one call", "two passes", "emit + merge"):
+        t = ta.Tendrils(View(*view))
+        t.resize()
+        t.setup(n)
+        t.particles.upload_texels(st)
+        t.timer.time = 1000.0
+        t.renderView = how == "one call"
+        for _ in range(3):                                      # a few frames: the wake forms, runs grow
+            t.timer.tick(); t.step()
+            if how == "emit + merge":
+                keys, colors = sharding.emit_fragments(t)
+                sharding.merge_fragments(t, keys, colors)
+                continue
+            t.draw()
+            if how == "two passes":
+                u, k = t.render_uniforms(), C.c_uint64(0)
+                _capi.call("th_view_draw", t.particles._ctx, C.byref(u), C.byref(k))
+                assert k.value == t.fragments
+        results.append((t.flow.read(), t.read_view() if how != "emit + merge" else None, t.particles.read(0)))
+        t.dispose()
+    a, b, c = results
+    assert bits_equal(a[2], b[2]).all() and bits_equal(a[2], c[2]).all()          # the same particles after three closed-loop frames
+    assert bits_equal(a[0], b[0]).all() and bits_equal(a[0], c[0]).all()
+    assert (a[1] == b[1]).all() and a[1].any()
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
 def test_node_host_view_draw(oracle):
     path = [p for p in golden("view") if "colours" in p][0]
