@@ -539,10 +539,18 @@ def main():
                                        "ms_per_step": wall_every_step / args.steps * 1e3,
                                        "note": "same K steps, one launch and one counter reduction per step"}
 
+    # (the side legs must not cost the line: whatever goes wrong in them is reported in their place)
     if world == 1 and args.config == "c3" and not args.no_frame_loop and not args.pmc_child:
-        line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
+        try:
+            line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
+        except Exception as e:            # noqa: BLE001
+            line["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu:
-        line["cpu_baseline"] = cpu_baseline(t, width, min(rows, N))
+        try:
+            line["cpu_baseline"] = cpu_baseline(t, width, min(rows, N))
+        except Exception as e:            # noqa: BLE001
+            line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
+                                    "sample": "failed: %s: %s" % (type(e).__name__, e)}
     t.dispose()
     if dist is not None:
         dist.barrier()
