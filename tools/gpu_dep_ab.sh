@@ -1,9 +1,11 @@
 #!/bin/bash
-# A/B of deposit rasteriser variants on one box: current build, then kWindow = 4 for hexagons (rebuilt on the box)
-mkdir -p gpurun_out/r2
-timeout 300 python -m pytest tests/test_gpu_deposit.py tests/test_gpu_view.py -x -q -m gpu 2>&1 | tail -2
-timeout 250 bash tools/gpu_trace_dep.sh depA
-sed -i 's/constexpr int kWindow = 8;/constexpr int kWindow = N == 6 ? 4 : 8;/' tendrils_amd/csrc/th_deposit.hip
-(cd tendrils_amd/csrc && make 2>&1 | tail -1)
-timeout 300 python -m pytest tests/test_gpu_deposit.py -x -q -m gpu 2>&1 | tail -2
-timeout 250 bash tools/gpu_trace_dep.sh depB
+# draw() (both passes): new lib vs libtendrils_hip_old.so on the same box, interleaved
+L=tendrils_amd/lib
+cp $L/libtendrils_hip.so /tmp/new.so
+for round in 1 2 3; do
+  for v in new old; do
+    if [ $v = old ]; then cp $L/libtendrils_hip_old.so $L/libtendrils_hip.so; else cp /tmp/new.so $L/libtendrils_hip.so; fi
+    echo "=== $v $(timeout 200 python tools/deposit_bench.py 100 --both 2>&1 | tail -1 | grep -o '"draw_both_ms": [0-9.]*') in-view $(timeout 200 python tools/deposit_bench.py 100 --both --in-view 2>&1 | tail -1 | grep -o '"draw_both_ms": [0-9.]*')"
+  done
+done
+cp /tmp/new.so $L/libtendrils_hip.so
