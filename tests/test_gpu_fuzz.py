@@ -92,3 +92,56 @@ def test_random_operation_sequences(oracle, seed):
             prev, cur = cur, oracle.spawn_sample(u, cur, flow)
         check("seed %d op %d (%s)" % (seed, op_index, op))
     t.dispose()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_draws(oracle, seed):
+    """draw() (both passes in one call) on random shapes, views and states against the restatement: lines far longer than
+    a record holds, lines that cross the view's edge or lie outside it, endpoints up to the rasteriser's limit of
+    |clip| = 1024 and beyond (dropped), inert and NaN particles, crowded texels, non-default colours and a colour map."""
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([17, 32, 50, 64, 100]))
+    view = [(96, 54), (64, 64), (33, 47), (120, 50), (16, 9)][int(rng.integers(0, 5))]
+    prev = np.zeros((n, n, 4), np.float32)
+    spread = float(rng.choice([0.2, 1.0, 1.5, 4.0]))
+    prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2)) * [1.0, view[1] / view[0]]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += (rng.uniform(-1, 1, (n, n, 2)) * float(rng.choice([0.02, 0.3, 2.5]))).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    far = rng.random((n, n)) < 0.03
+    cur[far, 0] = rng.choice([-900.0, 700.0, 1023.0, 1500.0, -4000.0], int(far.sum())).astype(np.float32)
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    if seed % 2:
+        cur[0, 0, 1] = np.nan
+        prev[1, 0, 0] = np.inf
+    base = np.zeros((view[1], view[0], 4), np.float32)
+    base[..., :2] = rng.uniform(-.01, .01, (view[1], view[0], 2))
+    base[..., 2] = 800.0
+    cmap = rng.uniform(0, 1, (3, 5, 4)).astype(np.float32) if seed % 3 == 0 else None
+    render = dict(speedLimit=0.01, flowDecay=0.005, speedAlpha=float(rng.choice([1e-6, 0.5])), colorMapAlpha=0.4 if cmap is not None else 0.0,
+                  baseColor=[float(v) for v in rng.uniform(0, 1, 4)], flowColor=[float(v) for v in rng.uniform(0, 1, 4)])
+    view_size = [1.0, view[0] / view[1]] if seed % 4 else [0.8, 1.3]
+    t = ta.Tendrils(View(*view))
+    t.resize()
+    t.setup(n)
+    t.viewSize[:] = view_size
+    for k, v in render.items():
+        t.state[k] = v
+    if cmap is not None:
+        t.colorMap.set_pixels(cmap)
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.flow.set_pixels(base)
+    t.timer.time = 1000.0
+    t.draw()
+    got_flow, got_view, frags = t.flow.read(), t.read_view(), t.fragments
+    t.dispose()
+    want_flow, count = oracle.flow_deposit(cur, prev, base, 1000.0, view_size=view_size, speedLimit=render["speedLimit"])
+    want_view, count2 = oracle.view_render(cur, prev, np.zeros((view[1], view[0], 4), np.uint8), 1000.0, view_size=view_size,
+                                           colormap=cmap, **render)
+    assert frags == count == count2
+    assert bits_equal(got_flow, want_flow).all()
+    assert (got_view == want_view).all()
