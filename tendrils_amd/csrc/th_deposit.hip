@@ -25,6 +25,7 @@
 // wake makes particles converge: thousands of fragments in one texel are normal after a few dozen frames).
 #include "th_kernels.hpp"
 #include "th_math.hpp"
+#include <cstdlib>
 
 namespace th {
 namespace {
@@ -1000,8 +1001,9 @@ __global__ __launch_bounds__(256) void triangle_fill_kernel(const TrianglePoly *
 
 int deposit_grid(uint32_t n)
 {
+    static const uint32_t cap = [] { const char *e = getenv("TH_DEP_GRID"); return e ? (uint32_t)atoi(e) : 16384u; }();      // (8192: 1-2 % slower draws, 65536: the same)
     uint32_t g = (n + 255u) / 256u;
-    return (int)(g < 1u ? 1u : (g > 8192u ? 8192u : g));
+    return (int)(g < 1u ? 1u : (g > cap ? cap : g));
 }
 
 }  // namespace
