@@ -593,11 +593,6 @@ constexpr int kShortRun = 16;
 // a fragment's side of the blend (everything that does not depend on the destination), and the destination's
 struct BlendSource { float x, y, z, w, da; };
 TH_D float lane_float(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
-TH_D BlendSource source_from_lane(const BlendSource &s, int lane)
-{
-    return BlendSource{lane_float(s.x, lane), lane_float(s.y, lane), lane_float(s.z, lane), lane_float(s.w, lane), lane_float(s.da, lane)};
-}
-
 struct FlowTarget {                     // dep_blend in two halves
     using Texel = float4;
     TH_D static BlendSource source(float4 c) { const float sa = c.w; return BlendSource{c.x * sa, c.y * sa, c.z * sa, c.w * sa, 1.0f - sa}; }
@@ -695,6 +690,7 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
 {
     using Texel = typename Target::Texel;
     const uint32_t lane = __lane_id();
+    __shared__ BlendSource staged[256];            // (per wave: its 64 lanes' source halves of the batch being blended)
     for (uint32_t base = blockIdx.x * 256u; base < total; base += gridDim.x * 256u) {       // (whole waves stay together)
         const uint32_t i = base + threadIdx.x;
         uint32_t texel = 0, j = i, last = 0;
@@ -759,8 +755,20 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
                     if (__ballot((int)lane < n && id < before) != 0ull) { falls = true; break; }
                     if (n) run_last = (uint32_t)__builtin_amdgcn_readlane((int)id, n - 1);
                 }
-                const BlendSource mine = Target::source(c);       // every lane its own fragment's half, then in order
-                for (int q = 0; q < n; ++q) Target::apply(rd, source_from_lane(mine, q));
+                // every lane its own fragment's half; then in order, read back from the wave's LDS slots (a broadcast read per
+                // fragment, issued eight ahead: the chain left is the blend's own multiply and add - v_readlane goes through
+                // an SGPR and its wait states, three times as long per fragment on the run that sets a crowded frame's time)
+                staged[threadIdx.x] = Target::source(c);
+                const BlendSource *mine = &staged[threadIdx.x & ~63u];
+                int q = 0;
+                for (; q + 8 <= n; q += 8) {
+                    BlendSource s8[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s8[k] = mine[q + k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) Target::apply(rd, s8[k]);
+                }
+                for (; q < n; ++q) Target::apply(rd, mine[q]);
                 if (n < 64) break;
                 c = cn; same = samen; id = idn; at0 += 64u;
             }
