@@ -668,16 +668,14 @@ TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, 
         for (uint32_t j = i + 1u; j < end; ++j)
             if ((uint32_t)keys.k[j] < (uint32_t)keys.k[j - 1u]) { lim[nb] = j; pos[++nb] = j; }
         lim[nb++] = end;
+        unsigned long long head[kMaxBands];          // stream index at every band's cursor (one past the largest: band exhausted)
+        for (uint32_t b = 0; b < nb; ++b) head[b] = (uint32_t)keys.k[pos[b]];
         for (uint32_t n = i; n < end; ++n) {
-            uint32_t best = 0, best_id = 0xffffffffu;
-            bool any = false;
-            for (uint32_t b = 0; b < nb; ++b)
-                if (pos[b] < lim[b]) {
-                    const uint32_t id = (uint32_t)keys.k[pos[b]];
-                    if (!any || id < best_id) { any = true; best = b; best_id = id; }
-                }
+            uint32_t best = 0;
+            for (uint32_t b = 1; b < nb; ++b) if (head[b] < head[best]) best = b;
             Target::apply(d, Target::source(colors[pos[best]]));
-            ++pos[best];
+            ++pos[best];                              // only the band that moved reads its next key
+            head[best] = pos[best] < lim[best] ? (unsigned long long)(uint32_t)keys.k[pos[best]] : 0x100000000ull;
         }
     } else *too_many = 1u;
     plane[texel] = d;
