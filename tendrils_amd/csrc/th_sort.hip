@@ -60,6 +60,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K *keys_in, co
     constexpr uint32_t D = 1u << kRadixBits;
     __shared__ uint32_t wave_hist[4][D];       // per wave: elements of each digit; then: first slot of (wave, digit) in the block
     __shared__ uint32_t digit_start[D];        // first slot of each digit inside the block
+    __shared__ uint32_t block_base[D];         // this block's first output slot of each digit (one global read per digit, up front:
+                                               // read per element in the output loop it was a dependent round trip per iteration)
     __shared__ K stage_k[kRadixBlock];
     __shared__ uint32_t stage_v[kRadixBlock];
     const uint32_t mask = (1u << bits) - 1u, digits = 1u << bits;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K *keys_in, co
     const uint32_t block_first = blockIdx.x * kRadixBlock;
     const uint32_t in_block = n - block_first < kRadixBlock ? n - block_first : kRadixBlock;
     for (uint32_t i = threadIdx.x; i < 4u * D; i += 256u) (&wave_hist[0][0])[i] = 0u;
+    if (threadIdx.x < digits) block_base[threadIdx.x] = base[(size_t)threadIdx.x * nblocks + blockIdx.x];
     __syncthreads();
 
     // this wave's 1024 consecutive elements, 16 rounds of 64
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K *keys_in, co
     for (uint32_t i = threadIdx.x; i < in_block; i += 256u) {
         const K k = stage_k[i];
         const uint32_t d = digit_of(k, shift, mask);
-        const uint32_t at = base[(size_t)d * nblocks + blockIdx.x] + (i - digit_start[d]);
+        const uint32_t at = block_base[d] + (i - digit_start[d]);
         keys_out[at] = k;
         vals_out[at] = stage_v[i];
     }
