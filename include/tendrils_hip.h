@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 5
+#define TH_ABI_VERSION 6
 
 typedef int32_t th_status;
 enum {
@@ -310,6 +310,15 @@ typedef struct th_slot_order_info {
     uint64_t sorts;              /* sorts so far in this context's life */
 } th_slot_order_info;
 th_status th_slot_order(th_context *ctx, th_slot_order_info *out);
+
+/* Which of the two draw() pipelines th_flow_deposit / th_view_draw / th_draw run through (build-defined, invisible in every
+ * result: both reproduce GL's primitive order bit for bit).  TH_DRAW_STREAM: fragments produced in stream order from
+ * particles in texel order, stable radix sort by texel (th_deposit.hip).  TH_DRAW_BINS: particles walked in whatever slot
+ * order the ring is held in, fragments bucketed by 16 x 16-texel bin of the target and put in order inside each bin
+ * (th_bins.hip) - what lets a step() + draw() frame loop (src/demo.main.js:1082) stay on tile-sorted slots.
+ * TH_DRAW_AUTO (default): bins whenever the integrator steps over sorted slots. */
+enum { TH_DRAW_AUTO = -1, TH_DRAW_STREAM = 0, TH_DRAW_BINS = 1 };
+th_status th_draw_pipeline(th_context *ctx, int32_t which);
 
 #ifdef __cplusplus
 }

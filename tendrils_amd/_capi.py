@@ -140,6 +140,7 @@ PROTOTYPES = {
     "th_kernel_timing_read": (C.c_int32, [_ctx, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "th_slot_order": (C.c_int32, [_ctx, C.POINTER(SlotOrderInfo)]),
     "th_shapes": (C.c_int32, [_ctx, C.POINTER(ShapesInfo)]),
+    "th_draw_pipeline": (C.c_int32, [_ctx, C.c_int32]),
     "th_view_draw": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_draw": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_view_fill": (C.c_int32, [_ctx, _fp]),

@@ -132,8 +132,14 @@ struct th_context {
     bool dep_pairs = false;              // the colour buffers hold two varyings per fragment (th_draw)
     // the geometry of the last draw pass (fragment counts, offsets, records, the sorted fragment order): the flow pass
     // and the view pass of one draw() rasterise the same lines at the same resolution
-    struct { bool valid = false; float view_x = 0, view_y = 0; uint32_t total = 0; bool sorted_in_a = false; } drawn;
+    struct { bool valid = false, binned = false; float view_x = 0, view_y = 0; uint32_t total = 0; bool sorted_in_a = false; } drawn;
     uint32_t dep_list_cap = 0;
+    // binned pipeline (th_bins.hip): fragments per bin | first fragment of every bin (+ 1) | fill cursors
+    uint32_t *bin_mem = nullptr;
+    uint32_t bin_capacity = 0;
+    int lines_local = -1;                // lines_are_local(), cached (-1 = not yet computed)
+    int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
+    long long last_binned_draw = -(1ll << 40);   // total_steps at the last draw over slot order
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
     float4 *dep_colors_sorted = nullptr;
@@ -533,6 +539,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
+    (void)hipFree(c->bin_mem);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -879,6 +886,9 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
             if (th_status s = begin_sort(c, g, in, in_order >= 0 ? c->orders[(size_t)in_order].perm : nullptr, &out_order, &b, counted)) return s;
             p.cursor = b.cursor; p.perm_out = b.perm_out;
             p.use_records = counted ? 1u : 0u;
+            // draws over the slot order are going on (th_bins.hip): the pass moves its INPUT along to the new slots, so
+            // that buffers[0] and buffers[1] - the two ends of every line - stay in one order
+            if (in == c->ring[1] && c->total_steps - c->last_binned_draw <= 2ll * resort_period()) p.in_moved = c->spare;
         } else {
             out_order = in_order;
             count = !gather && c->steps_since_sort + 1 >= resort_period();      // the next pass will re-sort: count for it
@@ -909,6 +919,13 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     if (k1) TH_HIP(hipEventRecord(k1, c->stream));
     TH_HIP(hipGetLastError());
     if (target == TH_TARGET_RING || (target >= 0 && target < (int32_t)c->ring.size())) set_order(c, out, out_order);
+    if (p.in_moved) {                       // the moved copy takes the input's place in the ring
+        clear_graphs(c);
+        float4 *old = c->ring[1];
+        set_order(c, old, -1);
+        c->ring[1] = c->spare; c->spare = old;
+        set_order(c, c->ring[1], out_order);
+    }
     if (c->packed && !packed_kernel)
         if (th_status s = commit_target(c, out, rt)) return s;
     ++c->steps_since_sort; ++c->total_steps;
@@ -1224,13 +1241,85 @@ static int deposit_texel_bits(const th_context *c)
     return bits;
 }
 
-// per-line buffers + parameters
-static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p)
+// ---- which pipeline draws -------------------------------------------------------------------------------------
+// The binned pipeline (th_bins.hip) walks the particles by slot, in whatever order the ring is held; the stream-ordered one
+// (th_deposit.hip) needs texel order.  TH_DRAW=bins / stream forces one (tests); by default the binned pipeline draws
+// whenever the integrator would step over tile-sorted slots (sorting_possible): a step() + draw() frame loop then never
+// leaves the sorted order.
+static int draw_policy()
 {
-    if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
-    c->hold_texel_order_until = c->total_steps + rebucket_period();   // a frame loop of step + draw stays in texel order
+    static const int v = [] { const char *e = getenv("TH_DRAW"); return !e ? -1 : (!strcmp(e, "bins") ? 1 : (!strcmp(e, "stream") ? 0 : -1)); }();
+    return v;
+}
+
+// Does every vertex of every line of this texture shape read the line's OWN particle?  Particles.generateLUT writes the
+// vertex coordinates as i/(W-1), j/(2H-1) (src/particles.js:171-190) and the shader turns them back into a texel with
+// fp32 arithmetic (src/state/state-at-frame.glsl:12-22): for some shapes (W >= 8192; heights such as 100, 1080, 3000)
+// the lookup of a few rows / columns lands one texel beside the line's own.  Same operations as dep_fetch (th_raster.hpp).
+static bool lines_are_local(th_context *c)
+{
+    if (c->lines_local >= 0) return c->lines_local != 0;
+    const int W = c->cfg.width, H = c->cfg.global_height;
+    const double inv_x = 1.0 / (double)((W > 2 ? W : 2) - 1), inv_y = 1.0 / (double)((2 * H > 2 ? 2 * H : 2) - 1);
+    auto nearest = [](float u, int n) { const float f = floorf(u * (float)n); return !(f > 0.0f) ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f); };
+    bool local = true;
+    for (int i = 0; i < W && local; ++i) local = nearest((float)((double)i * inv_x), W) == i;
+    for (int j = 0; j < 2 * H && local; ++j) {
+        const float uvy = (float)((double)j * inv_y), near_index = uvy * (float)H, fl = floorf(near_index);
+        local = nearest(fl / (float)H, H) == j / 2;
+    }
+    c->lines_local = local ? 1 : 0;
+    return local;
+}
+
+static bool draw_uses_bins(th_context *c)
+{
+    const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : draw_policy();
+    if (policy == 0) return false;
+    if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
+    return policy == 1;      // (auto: the stream-ordered pipeline until the binned one is the faster of the two)
+}
+
+// ring[1] into ring[0]'s slot order (through texel order): only when a draw meets the two in different orders - a
+// re-sorting step moves its input along with its output while draws are going on (enqueue_step)
+static th_status align_slot_orders(th_context *c)
+{
+    const int o0 = order_of(c, c->ring[0]), o1 = order_of(c, c->ring[1]);
+    if (o0 == o1) return TH_OK;
+    if (th_status s = sort_storage(c)) return s;
+    clear_graphs(c);
+    float4 *&b = c->ring[1];
+    if (o1 >= 0) {
+        th::launch_unpermute_state(c->spare, b, c->orders[(size_t)o1].perm, (uint32_t)c->texels(), c->packed, c->stream);
+        set_order(c, b, -1);
+        float4 *t = b; b = c->spare; c->spare = t;
+    }
+    if (o0 >= 0) {
+        th::launch_permute_state(c->spare, b, c->orders[(size_t)o0].perm, (uint32_t)c->texels(), c->packed, c->stream);
+        float4 *t = b; b = c->spare; c->spare = t;
+        set_order(c, b, o0);
+    }
+    TH_HIP(hipGetLastError());
+    c->counted.buf = nullptr;
+    return TH_OK;
+}
+
+// per-line buffers + parameters.  want_bins: the caller can run the binned pipeline (*bins tells whether it will)
+static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, bool want_bins = false, bool *bins = nullptr)
+{
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
+    bool use_bins = want_bins && draw_uses_bins(c);
+    if (use_bins && any_sorted(c)) {
+        if (!lines_are_local(c)) use_bins = false;           // a vertex of another particle: only texel order can address it
+        else if (th_status s = align_slot_orders(c)) return s;
+    }
+    if (bins) *bins = use_bins;
+    if (use_bins) c->last_binned_draw = c->total_steps;
+    else {
+        if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
+        c->hold_texel_order_until = c->total_steps + rebucket_period();   // a frame loop of step + draw stays in texel order
+    }
     const size_t lines = c->texels();
     TH_REQUIRE((size_t)c->fw * c->fh > 0 && (uint64_t)c->cfg.width * c->cfg.global_height < (1ull << 32), "bad shapes");
     if (c->dep_lines != lines) {
@@ -1243,7 +1332,7 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         TH_HIP(hipMalloc((void **)&c->dep_record, 2 * lines * sizeof(uint4)));
         TH_HIP(hipMalloc((void **)&c->dep_lists, th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &c->dep_list_cap) * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height) * sizeof(uint32_t)));
-        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 2 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag
+        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 4 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag, [2] largest bin
         c->dep_lines = lines;
     }
     p = th::DepositParams{};
@@ -1269,7 +1358,23 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
     }
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
-    TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 4 * sizeof(uint32_t), c->stream));
+    if (use_bins) {
+        const int o = order_of(c, c->ring[0]);
+        p.perm = o >= 0 ? c->orders[(size_t)o].perm : nullptr;
+        p.bins_x = ((uint32_t)c->fw + (1u << th::kBinShift) - 1u) >> th::kBinShift;
+        p.nbins = p.bins_x * (((uint32_t)c->fh + (1u << th::kBinShift) - 1u) >> th::kBinShift);
+        if (c->bin_capacity < p.nbins) {
+            TH_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->bin_mem); c->bin_mem = nullptr; c->bin_capacity = 0;
+            TH_HIP(hipMalloc((void **)&c->bin_mem, (3 * (size_t)p.nbins + 1) * sizeof(uint32_t)));
+            c->bin_capacity = p.nbins;
+            c->drawn.valid = false;
+        }
+        p.bin_hist = c->bin_mem; p.bin_start = c->bin_mem + c->bin_capacity; p.bin_cursor = p.bin_start + c->bin_capacity + 1;
+        p.id_bits = 1;
+        while (p.id_bits < 32u && (1ull << p.id_bits) < (uint64_t)p.W * p.H) ++p.id_bits;
+    }
     return TH_OK;
 }
 
@@ -1367,7 +1472,7 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
     // lines cover the same texels in the same order - counts, offsets, records and the sorted order of the fragments are
     // still there, only the varyings differ.  (TH_DRAW_REUSE=0: every pass on its own.)
     static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
-    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
+    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && !c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
     uint32_t total = 0;
     if (reuse) total = c->drawn.total;
     else {
@@ -1390,10 +1495,43 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
         th::launch_deposit_scatter(p, c->stream);
         const bool in_a = th::launch_radix_sort_u32(p.keys, p.slots, p.keys_sorted, p.slots_sorted, total, 0, bits, c->dep_temp, true, c->stream) == 0;
         if (in_a) { p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1]; }        // an even number of passes ends in the (a) buffers
-        c->drawn.valid = true; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total; c->drawn.sorted_in_a = in_a;
+        c->drawn.valid = true; c->drawn.binned = false; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total; c->drawn.sorted_in_a = in_a;
     }
     th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+// the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + count per bin, scan, emit, per-bin order + blend
+static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
+{
+    // the view pass right after the flow pass of the same state and view (th_view_draw after th_flow_deposit): the lines'
+    // records, counts and the bins' ranges still stand; only the varyings differ
+    static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
+    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
+    uint32_t total = 0;
+    if (reuse) {
+        total = c->drawn.total;
+        TH_HIP(hipMemcpyAsync(p.bin_cursor, p.bin_start, (size_t)p.nbins * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        c->drawn.valid = false;
+        th::launch_bins_raster(p, c->stream);
+        th::launch_bins_scan(p, c->dep_total, c->stream);
+        uint32_t host[3] = {0, 0, 0};
+        TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));
+        if (host[0] >= (1u << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one draw (2^31 or more)");
+        if (host[2] >= th::kBinsMaxPerBin) return fail(TH_ERR_UNSUPPORTED, "%u fragments in one 16 x 16-texel bin of the target (limit %u)", host[2], th::kBinsMaxPerBin);
+        total = host[0];
+    }
+    if (fragments) *fragments = total;
+    if (total == 0) return TH_OK;
+    if (!reuse) if (th_status s = deposit_reserve(c, total, true, p.mode == 2)) return s;
+    p.frag_keys = c->dep_u64[0]; p.colors = c->dep_colors;
+    th::launch_bins_emit(p, c->stream);
+    th::launch_bins_blend(p, c->stream);
+    TH_HIP(hipGetLastError());
+    c->drawn.valid = true; c->drawn.binned = true; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total;
     return TH_OK;
 }
 
@@ -1403,8 +1541,9 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
     th::DepositParams p;
-    if (th_status s = deposit_prepare(c, u, p)) return s;
-    return deposit_run(c, p, fragments);
+    bool bins = false;
+    if (th_status s = deposit_prepare(c, u, p, true, &bins)) return s;
+    return bins ? deposit_run_bins(c, p, fragments) : deposit_run(c, p, fragments);
 }
 
 // ---- view pass ---------------------------------------------------------------------------------------------
@@ -1427,12 +1566,12 @@ static void view_fields(th_context *c, const th_render_uniforms *u, th::DepositP
     p.colormap = c->colormap; p.cw = c->cmap_w; p.ch = c->cmap_h;
 }
 
-static th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositParams &p)
+static th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositParams &p, bool want_bins = false, bool *bins = nullptr)
 {
     TH_REQUIRE(u, "null uniforms");
     th_deposit_uniforms d{};
     d.viewSize[0] = u->viewSize[0]; d.viewSize[1] = u->viewSize[1]; d.time = u->time; d.speedLimit = u->speedLimit;
-    if (th_status s = deposit_prepare(c, &d, p)) return s;
+    if (th_status s = deposit_prepare(c, &d, p, want_bins, bins)) return s;
     p.mode = 1;
     view_fields(c, u, p);
     return TH_OK;
@@ -1454,11 +1593,12 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
                "the two passes of one draw share viewSize, time and speedLimit");
     if (th_status s = view_storage(c)) return s;
     th::DepositParams p;
-    if (th_status s = deposit_prepare(c, du, p)) return s;
+    bool bins = false;
+    if (th_status s = deposit_prepare(c, du, p, true, &bins)) return s;
     p.mode = 2;
     view_fields(c, ru, p);
     p.view = c->view;
-    return deposit_run(c, p, fragments);
+    return bins ? deposit_run_bins(c, p, fragments) : deposit_run(c, p, fragments);
 }
 
 th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)
@@ -1468,9 +1608,10 @@ th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fra
         return fail(TH_ERR_UNSUPPORTED, "the view pass needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
     if (th_status s = view_storage(c)) return s;
     th::DepositParams p;
-    if (th_status s = view_params(c, u, p)) return s;
+    bool bins = false;
+    if (th_status s = view_params(c, u, p, true, &bins)) return s;
     p.view = c->view;
-    return deposit_run(c, p, fragments);
+    return bins ? deposit_run_bins(c, p, fragments) : deposit_run(c, p, fragments);
 }
 
 th_status th_view_fill(th_context *c, const float rgba[4])
@@ -1596,8 +1737,8 @@ th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colo
     // owner bits above and the stream index below are left alone), then the blend merges the bands inside each texel
     const int bits = 32 + deposit_texel_bits(c);
     if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 32, bits))) return s;
-    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 2 * sizeof(uint32_t)));
-    TH_HIP(hipMemsetAsync(c->dep_total, 0, 2 * sizeof(uint32_t), c->stream));
+    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 4 * sizeof(uint32_t)));
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 4 * sizeof(uint32_t), c->stream));
     // (the sort ping-pongs between its two buffer pairs: the caller's keys are copied, not sorted in place)
     TH_HIP(hipMemcpyAsync(c->mrg_keys, keys_dev, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
     const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 32, bits, c->dep_temp, true, c->stream);
@@ -1763,6 +1904,14 @@ th_status th_shapes(th_context *c, th_shapes_info *out)
     out->state_w = c->cfg.width; out->state_h = c->cfg.height;
     out->flow_w = c->fw; out->flow_h = c->fh;
     out->frames_w = c->frw; out->frames_h = c->frh;
+    return TH_OK;
+}
+
+th_status th_draw_pipeline(th_context *c, int32_t which)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(which == TH_DRAW_AUTO || which == TH_DRAW_STREAM || which == TH_DRAW_BINS, "unknown draw pipeline %d", which);
+    c->draw_pipeline = which;
     return TH_OK;
 }
 

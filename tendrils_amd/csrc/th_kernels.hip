@@ -1040,6 +1040,13 @@ __global__ __launch_bounds__(256) void unpermute_state_kernel(Texel *dst, const 
     for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) dst[perm[s]] = src[s];
 }
 
+// texel order into a slot order: dst[s] = src[perm[s]]
+template <typename Texel>
+__global__ __launch_bounds__(256) void permute_state_kernel(Texel *dst, const Texel *src, const uint32_t *perm, uint32_t n)
+{
+    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) dst[s] = src[perm[s]];
+}
+
 static int tile_grid(uint32_t count) { return (int)((count + kTileChunk - 1) / kTileChunk); }
 
 void launch_tile_hist(const TileSortParams &b, hipStream_t s)
@@ -1064,6 +1071,13 @@ void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm
     if (packed) hipLaunchKernelGGL(unpermute_state_kernel<uint2>, dim3(grid_for(n, 8)), dim3(256), 0, s, reinterpret_cast<uint2 *>(dst),
                                    reinterpret_cast<const uint2 *>(src), perm, n);
     else hipLaunchKernelGGL(unpermute_state_kernel<float4>, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, perm, n);
+}
+
+void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t s)
+{
+    if (packed) hipLaunchKernelGGL(permute_state_kernel<uint2>, dim3(grid_for(n, 8)), dim3(256), 0, s, reinterpret_cast<uint2 *>(dst),
+                                   reinterpret_cast<const uint2 *>(src), perm, n);
+    else hipLaunchKernelGGL(permute_state_kernel<float4>, dim3(grid_for(n, 8)), dim3(256), 0, s, dst, src, perm, n);
 }
 
 // ---------------------------------------------------------------------------
@@ -1167,7 +1181,7 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
             if constexpr (WINDOW) r = integrate<FAST, NOISE, TARGET, POW2, true, true, true>(p, lut, st, pid, time, &tabs, &win);
             else r = integrate<FAST, NOISE, TARGET, POW2, true, true, false>(p, lut, st, pid, time, &tabs);
             // (scattered runs start at any slot: plain stores, so that L2 can merge the partial lines two runs share)
-            if constexpr (SCATTER) { p.out[dst] = r; p.perm_out[dst] = pid; }
+            if constexpr (SCATTER) { p.out[dst] = r; p.perm_out[dst] = pid; if (p.in_moved) p.in_moved[dst] = st; }
             else store_stream(&p.out[dst], r);
         }
         if constexpr (COUNT) {

@@ -52,6 +52,7 @@ struct LogicParams {
     const uint32_t *nchunks;
     uint32_t *cursor;        // SCATTER: rank cursors of the new order (tile_scan_kernel)
     uint32_t *perm_out;      // SCATTER: particle ids of the new order
+    float4 *in_moved;        // SCATTER: (optional) receives the INPUT state at the new slots as well
     uint32_t *misses;        // += taps that left the staged window (nullptr = not counted)
     uint32_t *hist;          // COUNT: histogram of the output positions' tiles
     ChunkRecord *records;    // COUNT: written per chunk; SCATTER with use_records: read per chunk
@@ -136,6 +137,14 @@ struct DepositParams {
     float4 *colors_sorted;       // ... gathered into the sorted order
     unsigned long long *keys64;  // sharded form, per fragment: owner << kOwnerShift | texel << 32 | global stream index
     uint32_t owners, owner_chunk;    // ranks that own flow texels (contiguous ranges of owner_chunk texels)
+    // binned pipeline (th_bins.hip): lines are walked by SLOT - cur / prev in the ring's slot order, perm[slot] = particle
+    // id (nullptr = texel order); count / record / the line lists are indexed by slot; fragments are bucketed by the
+    // 16 x 16-texel bin of the flow field they fall into
+    const uint32_t *perm;
+    uint32_t bins_x, nbins;
+    uint32_t *bin_hist, *bin_start, *bin_cursor;   // fragments per bin; first fragment of every bin (nbins + 1); fill cursors
+    unsigned long long *frag_keys;                 // per fragment, bin-major: (y << 12 | x) << 32 | stream index of the line
+    uint32_t id_bits;                              // bits of a stream index: ceil(log2(W * H))
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
@@ -161,7 +170,8 @@ void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target
 void launch_tile_hist(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scan(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scatter(const TileSortParams &b, hipStream_t stream);
-void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t stream);
+void launch_unpermute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t stream);   // dst[perm[s]] = src[s]
+void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *perm, uint32_t n, bool packed, hipStream_t stream);     // dst[s] = src[perm[s]]
 void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
 void launch_hash_tables(float4 *block, hipStream_t stream);      // the hash tables in front of the gradient table (th_kernels.hip)
 int hash_table_vectors();
@@ -182,6 +192,14 @@ void launch_triangles(const float *positions, int ntri, float view_x, float view
                       float4 *img, int w, int h, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t stream);
+// binned pipeline (th_bins.hip)
+constexpr int kBinShift = 4;                       // 16 x 16 texel bins
+constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits per texel coordinate
+constexpr uint32_t kBinsMaxPerBin = 1u << 24;      // a fragment's position inside its bin rides in 24 key bits while it is sorted
+void launch_bins_raster(const DepositParams &p, hipStream_t stream);                  // count + record per slot, fragments per bin
+void launch_bins_scan(const DepositParams &p, uint32_t *totals, hipStream_t stream);  // totals[0] = fragments, totals[2] = largest bin
+void launch_bins_emit(const DepositParams &p, hipStream_t stream);                    // fragments into their bins
+void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // per bin: sort by (texel, stream index), blend
 // stable LSD radix sort of (key, u32 value) pairs by key bits [begin_bit, end_bit) (th_sort.hip): the passes ping-pong
 // between the (a) and (b) buffers; returns 0 when the result is in (a), 1 when it is in (b)
 constexpr uint32_t kRadixBits = 8;

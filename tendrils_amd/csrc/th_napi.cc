@@ -662,6 +662,17 @@ napi_value KernelTiming(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// drawPipeline(ctx, which): TH_DRAW_AUTO / _STREAM / _BINS
+napi_value DrawPipeline(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t which = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_draw_pipeline");
+    TH_CALL("th_draw_pipeline", th_draw_pipeline(c, which));
+    return undefined(env);
+}
+
 // kernelTimingRead(ctx) -> {meanMs, launches}
 napi_value KernelTimingRead(napi_env env, napi_callback_info info)
 {
@@ -699,7 +710,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"depositSetOwners", DepositSetOwners}, {"depositSetHalo", DepositSetHalo}, {"depositEmit", DepositEmit},
         {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
-        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead},
+        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline},
     };
     for (auto &e : table) {
         napi_value fn;
@@ -710,7 +721,7 @@ napi_value Init(napi_env env, napi_value exports)
     struct { const char *name; int32_t val; } consts[] = {
         {"MODE_EXACT", TH_MODE_EXACT}, {"MODE_FAST", TH_MODE_FAST}, {"STATE_F32", TH_STATE_F32}, {"STATE_F16", TH_STATE_F16},
         {"TARGET_RING", TH_TARGET_RING}, {"TARGET_TARGETS", TH_TARGET_TARGETS}, {"SOURCE_FLOW", TH_SOURCE_FLOW},
-        {"SOURCE_IMAGE", TH_SOURCE_IMAGE},
+        {"SOURCE_IMAGE", TH_SOURCE_IMAGE}, {"DRAW_AUTO", TH_DRAW_AUTO}, {"DRAW_STREAM", TH_DRAW_STREAM}, {"DRAW_BINS", TH_DRAW_BINS},
     };
     for (auto &e : consts) {
         if (napi_create_int32(env, e.val, &v) != napi_ok) return nullptr;

@@ -186,6 +186,11 @@ class Particles:
     def sync(self):
         call("th_sync", self._ctx)
 
+    def draw_pipeline(self, which):
+        """Which of the library's two draw() pipelines runs (build-defined, the results are the same): "auto", "stream"
+        (texel order, stream-ordered stable sort) or "bins" (any slot order, per-bin ordering)."""
+        call("th_draw_pipeline", self._ctx, {"auto": -1, "stream": 0, "bins": 1}[which])
+
     def deposit_flow(self, view_size, time, speed_limit):
         """The flow pass of Tendrils.draw(): (previous -> current) lines blended into the flow texture
         (src/index.js:295-303, src/particles.js:147-158).  Returns the number of fragments."""

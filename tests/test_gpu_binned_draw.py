@@ -1,0 +1,117 @@
+"""The binned draw() pipeline (th_bins.hip: particles walked in slot order, fragments bucketed by 16 x 16-texel bin of the
+target, ordered by (texel, stream index) inside each bin) must reproduce GL's primitive order exactly like the
+stream-ordered one: the draw suites rerun with it forced (in texel order, and over tile-sorted slots re-sorted every few
+steps), both pipelines side by side at BASELINE's C3 size, and crowded targets (bins and single texels of more fragments
+than LDS holds at once) against the CPU restatement."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+SUITES = ["test_gpu_deposit.py", "test_gpu_view.py", "test_gpu_fuzz.py", "test_gpu_scene.py"]
+
+
+def rerun(extra_env):
+    env = dict(os.environ, **extra_env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x"] + [os.path.join(ROOT, "tests", s) for s in SUITES],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_draw_suites_with_bins_forced():
+    if os.environ.get("TH_DRAW"):
+        pytest.skip("already inside a forced-pipeline run")
+    rerun({"TH_DRAW": "bins"})
+
+
+def test_draw_suites_with_bins_over_sorted_slots():
+    if os.environ.get("TH_DRAW"):
+        pytest.skip("already inside a forced-pipeline run")
+    rerun({"TH_DRAW": "bins", "TH_BUCKET": "1", "TH_RESORT_STEPS": "3", "TH_REBUCKET_STEPS": "2"})
+
+
+def make(n, view_res, pipeline):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    t = ta.Tendrils(View(*view_res))
+    t.resize()
+    t.setup(n)
+    t.particles.draw_pipeline(pipeline)
+    return t
+
+
+def test_frame_loop_at_c3_size_bins_equal_stream():
+    """4096^2 particles over a 1920x1080 target: tick(); step(); draw() (both passes) with the default policy - tile-sorted
+    slots, binned pipeline - against the stream-ordered pipeline in texel order: same fragments, same flow field, same view
+    buffer, same particles, bit for bit, frame after frame (the deposited wake steers the next step)."""
+    n, frames = 4096, 4
+    rng = np.random.default_rng(41)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2)).astype(np.float32)
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2)).astype(np.float32)
+    st[rng.random((n, n)) < 0.01] = [-1e6, -1e6, 0, 0]
+    outs = []
+    for pipeline in ("stream", "bins"):
+        t = make(n, (1920, 1080), pipeline)
+        t.particles.upload_texels(st)
+        t.timer.time = 1000.0
+        t.renderView = True
+        frags = []
+        for _ in range(frames):
+            t.timer.tick()
+            t.step()
+            t.draw()
+            frags.append(t.fragments)
+        order = t.particles.slot_order() if hasattr(t.particles, "slot_order") else None
+        outs.append((frags, t.flow.read(), t.read_view(), t.particles.read(0), t.particles.read(1), order))
+        t.dispose()
+    a, b = outs
+    assert a[0] == b[0] and min(a[0]) > 4_000_000
+    assert bits_equal(a[1], b[1]).all()
+    assert (a[2] == b[2]).all() and a[2].any()
+    assert bits_equal(a[3], b[3]).all() and bits_equal(a[4], b[4]).all()
+
+
+def crowded(n, seed, spread):
+    rng = np.random.default_rng(seed)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2))
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.03, .03, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    return cur, prev
+
+
+@pytest.mark.parametrize("n,spread,view", [(256, 0.25, (64, 36)),      # bins of > 4096 fragments: groups of texels
+                                             (512, 0.02, (64, 36))],     # single texels of > 4096 fragments: id windows
+                         ids=["crowded_bins", "giant_texels"])
+def test_crowded_targets_are_order_exact(oracle, n, spread, view):
+    cur, prev = crowded(n, 91, spread)
+    base = np.zeros((view[1], view[0], 4), np.float32)
+    want, frags, cov = oracle.flow_deposit(cur, prev, base, 2500.0, view_size=(1.0, view[0] / view[1]), coverage=True)
+    assert cov.max() > (4096 if spread < 0.1 else 150)
+    for pipeline in ("bins", "stream"):
+        t = make(n, view, pipeline)
+        t.particles.upload_texels(cur, 0)
+        t.particles.upload_texels(prev, 1)
+        t.flow.set_pixels(base)
+        t.timer.time = 2500.0
+        t.draw()
+        got, nf = t.flow.read(), t.fragments
+        t.renderView = True                          # and both targets in one call on top
+        t.draw()
+        view_px = t.read_view()
+        t.dispose()
+        assert nf == frags
+        assert bits_equal(got, want).all(), pipeline
+        if pipeline == "bins":
+            first_view = view_px
+        else:
+            assert (view_px == first_view).all() and view_px.any()

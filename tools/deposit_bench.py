@@ -26,6 +26,7 @@ st = bench.synth_state(0)
 if in_view:
     st[..., 1] *= np.float32(0.56)
 t.particles.upload_texels(st)
+t.particles.draw_pipeline(os.environ.get("TH_PIPE", "auto"))     # "stream" | "bins" | "auto"
 t.timer.time = 1000.0
 ctx = t.particles._ctx
 ms = C.c_float()
@@ -57,7 +58,7 @@ for _ in range(frames):
     u, n = t.render_uniforms(), C.c_uint64(0)
     view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))     # the view pass
 stats = t.particles.stats(t.state["speedLimit"])
-print(json.dumps({"particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
+print(json.dumps({"pipeline": os.environ.get("TH_PIPE", "auto"), "particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
                   "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)) if draw_ms else None, "view_ms": float(np.mean(view_ms)) if view_ms else None,
                   "draw_both_ms": float(np.mean(both_ms)) if both_ms else None,
                   "fragments_per_frame": float(np.mean(frags)), "frames_per_s": 1e3 / float(np.mean(step_ms) + (np.mean(both_ms) if both_ms else np.mean(draw_ms))),
