@@ -132,12 +132,16 @@ struct th_context {
     bool dep_pairs = false;              // the colour buffers hold two varyings per fragment (th_draw)
     // the geometry of the last draw pass (fragment counts, offsets, records, the sorted fragment order): the flow pass
     // and the view pass of one draw() rasterise the same lines at the same resolution
-    struct { bool valid = false, binned = false; float view_x = 0, view_y = 0; uint32_t total = 0; bool sorted_in_a = false; } drawn;
+    struct { bool valid = false, binned = false; float view_x = 0, view_y = 0; uint32_t total = 0, nlarge = 0, nblocks = 0; bool sorted_in_a = false; } drawn;
     uint32_t dep_list_cap = 0;
     // binned pipeline (th_bins.hip): fragments per bin | first fragment of every bin (+ 1) | fill cursors
-    uint32_t *bin_mem = nullptr;
+    uint32_t *bin_mem = nullptr;         // ... | the large bins | first block of each (+ 1)
     uint32_t bin_capacity = 0;
-    int lines_local = -1;                // lines_are_local(), cached (-1 = not yet computed)
+    uint32_t *crowd_mem = nullptr;       // per large bin: fragments per texel, first fragment of every texel, fill cursors
+    uint32_t *block_flags = nullptr;     // per 256-slot block: some line has fragments
+    uint32_t crowd_capacity = 0;
+    int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
+    uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
     long long last_binned_draw = -(1ll << 40);   // total_steps at the last draw over slot order
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
@@ -309,12 +313,7 @@ int rebucket_period()
 }
 int resort_period()
 {
-    static const int v = [] {
-        const char *e = getenv("TH_RESORT_STEPS"), *m = getenv("TH_SINGLE");
-        const int dflt = (m && !strcmp(m, "window")) ? 8 : 64;       // the LDS window is left after ~8 steps; gathered taps only lose locality
-        int n = e ? atoi(e) : dflt;
-        return n > 0 ? n : dflt;
-    }();
+    static const int v = [] { const char *e = getenv("TH_RESORT_STEPS"); int n = e ? atoi(e) : 64; return n > 0 ? n : 64; }();
     return v;
 }
 constexpr int kTileShift = 5;            // 32 x 32 texel tiles (th_kernels.hip kTile)
@@ -330,15 +329,50 @@ bool sorting_possible(const th_context *c)
 {
     const size_t flow_texels = (size_t)c->fw * c->fh;
     if (c->texels() < 2 * flow_texels) return false;           // the decoded plane is not used at all
-    if ((size_t)tile_count(c, nullptr) + 1 > th::kMaxTileBins) return false;
+    if (2 * ((size_t)tile_count(c, nullptr) + 1) > th::kMaxTileBins) return false;     // two sort classes per tile (+ the no-tap pair)
     if (bucket_policy() == 0) return false;
     if (bucket_policy() == 1) return true;
     return c->texels() >= ((size_t)1 << 20) && flow_texels * sizeof(float2) > ((size_t)3 << 20);
 }
 
+// Which rows of the state texture can draw() make lines of, and does every vertex of every line read the line's OWN
+// particle?  Particles.generateLUT writes the vertex coordinates as i/(W-1), j/(2H-1) (src/particles.js:171-190) and the
+// shader turns them back into a texel and a buffer with fp32 arithmetic (src/state/state-at-frame.glsl:12-22): vertex
+// 2m of line m reads `previous` in the lower rows and `current` in the upper ones, vertex 2m+1 `current` - so the lines
+// of the upper half (both vertices the same texel of the same buffer) have no length; and for some shapes (W >= 8192;
+// heights such as 100, 1080, 3000) the lookup of a few rows / columns lands one texel beside the line's own.
+// Same operations as dep_fetch (th_raster.hpp).  Bit m of the table: row m can draw.
+th_status line_rows(th_context *c)
+{
+    if (c->d_row_draws) return TH_OK;
+    const int W = c->cfg.width, H = c->cfg.global_height;
+    const double inv_x = 1.0 / (double)((W > 2 ? W : 2) - 1), inv_y = 1.0 / (double)((2 * H > 2 ? 2 * H : 2) - 1);
+    auto nearest = [](float u, int n) { const float f = floorf(u * (float)n); return !(f > 0.0f) ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f); };
+    bool local = true;
+    for (int i = 0; i < W && local; ++i) local = nearest((float)((double)i * inv_x), W) == i;
+    std::vector<uint32_t> bits(((size_t)H + 31) / 32, 0u);
+    for (int m = 0; m < H; ++m) {
+        int row[2];
+        bool cur[2];
+        for (int v = 0; v < 2; ++v) {
+            const float uvy = (float)((double)(2 * m + v) * inv_y), near_index = uvy * (float)H, fl = floorf(near_index);
+            cur[v] = near_index - fl > 0.25f;
+            row[v] = nearest(fl / (float)H, H);
+            local = local && row[v] == m;
+        }
+        if (!(row[0] == row[1] && cur[0] == cur[1])) bits[(size_t)m >> 5] |= 1u << (m & 31);
+    }
+    TH_HIP(hipMalloc((void **)&c->d_row_draws, bits.size() * sizeof(uint32_t)));
+    TH_HIP(hipMemcpy(c->d_row_draws, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->lines_local = local ? 1 : 0;
+    return TH_OK;
+}
+
 th::TileGeom tile_geom(const th_context *c, const th_logic_uniforms &u)
 {
     th::TileGeom g{};
+    g.width = (uint32_t)c->cfg.width; g.pow2w = is_pow2(g.width) ? 1u : 0u; g.log2w = g.pow2w ? ilog2(g.width) : 0u;
+    g.row0 = (uint32_t)c->cfg.row0; g.row_draws = c->d_row_draws;
     g.view_x = u.viewSize[0]; g.view_y = u.viewSize[1];
     g.half_fw = 0.5f * (float)c->fw; g.half_fh = 0.5f * (float)c->fh;
     g.fwm1 = (float)(c->fw - 1); g.fhm1 = (float)(c->fh - 1);
@@ -366,6 +400,7 @@ bool any_sorted(const th_context *c) { return !c->buf_order.empty(); }
 
 th_status sort_storage(th_context *c)
 {
+    if (th_status s = line_rows(c)) return s;
     if (c->tile_mem) return TH_OK;
     const size_t n = c->texels();
     TH_HIP(hipMalloc((void **)&c->spare, n * sizeof(float4)));
@@ -520,6 +555,7 @@ th_status th_create(const th_config *cfg, th_context **out)
             if (th_status s = alloc_state(c, &b)) return s;
             c->ring.push_back(b);
         }
+        if (th_status s = line_rows(c)) return s;          // (before anything builds a TileGeom)
         TH_HIP(hipStreamSynchronize(c->stream));
         return TH_OK;
     };
@@ -539,7 +575,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
-    (void)hipFree(c->bin_mem);
+    (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->block_flags);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -830,7 +866,6 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     // the slots of a new sort keyed on the input positions (counted just before the launch).
     int in_order = sorted ? order_of(c, in) : -1, out_order = -1;
     bool use_sorted = false, scatter = false, count = false, gather = false;
-    static const bool window_mode = [] { const char *e = getenv("TH_SINGLE"); return e && !strcmp(e, "window"); }();
     if (sorted && packed_kernel) {
         // packed ring: the plain grid-stride kernel over the sorted slots; a re-sort is a plain move of the input
         // (tile_hist, scan, tile_scatter into the spare buffer, which then takes the input's place in the ring)
@@ -869,9 +904,8 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         scatter = in_order < 0 || c->steps_since_sort >= resort_period();
         use_sorted = true;
         // between two sorts the pass is the plain grid-stride kernel over the sorted slots (taps gathered from the
-        // decoded plane: a wave's taps fall into one neighbourhood); the chunk kernel with its LDS window counts
-        // and scatters around a re-sort (TH_SINGLE=window: it also does the passes in between, as first built)
-        gather = !window_mode && !scatter && plan.decoded && c->steps_since_sort + 1 < resort_period();
+        // decoded plane: a wave's taps fall into one neighbourhood); the chunk kernel counts and scatters around a re-sort
+        gather = !scatter && plan.decoded && c->steps_since_sort + 1 < resort_period();
         p.geom = g;
         if (in_order >= 0) {
             const th_context::SlotOrder &o = c->orders[(size_t)in_order];
@@ -898,7 +932,6 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
                 TH_HIP(hipMemsetAsync(p.hist, 0, kTileWords / 2 * sizeof(uint32_t), c->stream));
             }
         }
-        p.misses = c->tile_mem + kTileWords;
     }
 
     if (plan.decoded)
@@ -912,7 +945,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     if (gather) {
         th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel, c->stream);
     } else if (use_sorted)
-        th::launch_logic_sorted(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, in_order >= 0, scatter, count, window_mode, c->max_chunks, c->stream);
+        th::launch_logic_sorted(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, in_order >= 0, scatter, count, c->max_chunks, c->stream);
     else
         th::launch_logic(p, c->cfg.mode, plan.noise, plan.use_targets, plan.pow2, plan.decoded, plan.generic, packed_kernel,
                          c->stream);
@@ -1252,26 +1285,6 @@ static int draw_policy()
     return v;
 }
 
-// Does every vertex of every line of this texture shape read the line's OWN particle?  Particles.generateLUT writes the
-// vertex coordinates as i/(W-1), j/(2H-1) (src/particles.js:171-190) and the shader turns them back into a texel with
-// fp32 arithmetic (src/state/state-at-frame.glsl:12-22): for some shapes (W >= 8192; heights such as 100, 1080, 3000)
-// the lookup of a few rows / columns lands one texel beside the line's own.  Same operations as dep_fetch (th_raster.hpp).
-static bool lines_are_local(th_context *c)
-{
-    if (c->lines_local >= 0) return c->lines_local != 0;
-    const int W = c->cfg.width, H = c->cfg.global_height;
-    const double inv_x = 1.0 / (double)((W > 2 ? W : 2) - 1), inv_y = 1.0 / (double)((2 * H > 2 ? 2 * H : 2) - 1);
-    auto nearest = [](float u, int n) { const float f = floorf(u * (float)n); return !(f > 0.0f) ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f); };
-    bool local = true;
-    for (int i = 0; i < W && local; ++i) local = nearest((float)((double)i * inv_x), W) == i;
-    for (int j = 0; j < 2 * H && local; ++j) {
-        const float uvy = (float)((double)j * inv_y), near_index = uvy * (float)H, fl = floorf(near_index);
-        local = nearest(fl / (float)H, H) == j / 2;
-    }
-    c->lines_local = local ? 1 : 0;
-    return local;
-}
-
 static bool draw_uses_bins(th_context *c)
 {
     const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : draw_policy();
@@ -1311,7 +1324,8 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
     bool use_bins = want_bins && draw_uses_bins(c);
     if (use_bins && any_sorted(c)) {
-        if (!lines_are_local(c)) use_bins = false;           // a vertex of another particle: only texel order can address it
+        if (th_status s = line_rows(c)) return s;
+        if (c->lines_local != 1) use_bins = false;           // a vertex of another particle: only texel order can address it
         else if (th_status s = align_slot_orders(c)) return s;
     }
     if (bins) *bins = use_bins;
@@ -1332,7 +1346,7 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         TH_HIP(hipMalloc((void **)&c->dep_record, 2 * lines * sizeof(uint4)));
         TH_HIP(hipMalloc((void **)&c->dep_lists, th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &c->dep_list_cap) * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height) * sizeof(uint32_t)));
-        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 4 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag, [2] largest bin
+        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 8 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag, [2] largest bin, [3] large bins, [4] their blocks
         c->dep_lines = lines;
     }
     p = th::DepositParams{};
@@ -1358,7 +1372,9 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
     }
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
-    TH_HIP(hipMemsetAsync(c->dep_total, 0, 4 * sizeof(uint32_t), c->stream));
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 8 * sizeof(uint32_t), c->stream));
+    if (th_status s = line_rows(c)) return s;
+    p.row_draws = c->d_row_draws;
     if (use_bins) {
         const int o = order_of(c, c->ring[0]);
         p.perm = o >= 0 ? c->orders[(size_t)o].perm : nullptr;
@@ -1367,11 +1383,18 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         if (c->bin_capacity < p.nbins) {
             TH_HIP(hipStreamSynchronize(c->stream));
             (void)hipFree(c->bin_mem); c->bin_mem = nullptr; c->bin_capacity = 0;
-            TH_HIP(hipMalloc((void **)&c->bin_mem, (3 * (size_t)p.nbins + 1) * sizeof(uint32_t)));
+            (void)hipFree(c->block_flags); c->block_flags = nullptr;
+            const size_t stride = ((size_t)p.nbins + 255) / 256 * 256 + 64;
+            TH_HIP(hipMalloc((void **)&c->bin_mem, (4 * (size_t)p.nbins + 2 + 2 * th::kBinReplicas * stride) * sizeof(uint32_t)));
+            TH_HIP(hipMalloc((void **)&c->block_flags, ((c->texels() + 255) / 256 + 1) * sizeof(uint32_t)));
             c->bin_capacity = p.nbins;
             c->drawn.valid = false;
         }
-        p.bin_hist = c->bin_mem; p.bin_start = c->bin_mem + c->bin_capacity; p.bin_cursor = p.bin_start + c->bin_capacity + 1;
+        p.bin_stride = (uint32_t)(((size_t)c->bin_capacity + 255) / 256 * 256 + 64);
+        p.bin_hist = c->bin_mem; p.bin_start = c->bin_mem + c->bin_capacity;
+        p.large_bins = p.bin_start + c->bin_capacity + 1; p.large_block0 = p.large_bins + c->bin_capacity;
+        p.rep_hist = p.large_block0 + c->bin_capacity + 1; p.rep_cursor = p.rep_hist + (size_t)th::kBinReplicas * p.bin_stride;
+        p.block_flags = c->block_flags;
         p.id_bits = 1;
         while (p.id_bits < 32u && (1ull << p.id_bits) < (uint64_t)p.W * p.H) ++p.id_bits;
     }
@@ -1509,29 +1532,39 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     // records, counts and the bins' ranges still stand; only the varyings differ
     static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
     const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
-    uint32_t total = 0;
+    uint32_t total = 0, nlarge = 0, nblocks = 0;
     if (reuse) {
-        total = c->drawn.total;
-        TH_HIP(hipMemcpyAsync(p.bin_cursor, p.bin_start, (size_t)p.nbins * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        total = c->drawn.total; nlarge = c->drawn.nlarge; nblocks = c->drawn.nblocks;       // (launch_bins_emit resets the fill cursors)
     } else {
         c->drawn.valid = false;
         th::launch_bins_raster(p, c->stream);
         th::launch_bins_scan(p, c->dep_total, c->stream);
-        uint32_t host[3] = {0, 0, 0};
+        uint32_t host[5] = {0, 0, 0, 0, 0};
         TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
         TH_HIP(hipStreamSynchronize(c->stream));
         if (host[0] >= (1u << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one draw (2^31 or more)");
         if (host[2] >= th::kBinsMaxPerBin) return fail(TH_ERR_UNSUPPORTED, "%u fragments in one 16 x 16-texel bin of the target (limit %u)", host[2], th::kBinsMaxPerBin);
-        total = host[0];
+        total = host[0]; nlarge = host[3]; nblocks = host[4];
     }
     if (fragments) *fragments = total;
     if (total == 0) return TH_OK;
     if (!reuse) if (th_status s = deposit_reserve(c, total, true, p.mode == 2)) return s;
+    if (c->crowd_capacity < nlarge) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
+        const uint32_t cap = nlarge + nlarge / 2 + 64;
+        TH_HIP(hipMalloc((void **)&c->crowd_mem, (size_t)cap * th::crowd_words_per_bin() * sizeof(uint32_t)));
+        c->crowd_capacity = cap;
+    }
     p.frag_keys = c->dep_u64[0]; p.colors = c->dep_colors;
+    p.nlarge = nlarge;
+    p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
+    p.crowd_keys = c->dep_u64[1];
     th::launch_bins_emit(p, c->stream);
-    th::launch_bins_blend(p, c->stream);
+    th::launch_bins_blend(p, nblocks, c->stream);
     TH_HIP(hipGetLastError());
     c->drawn.valid = true; c->drawn.binned = true; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total;
+    c->drawn.nlarge = nlarge; c->drawn.nblocks = nblocks;
     return TH_OK;
 }
 
@@ -1737,8 +1770,8 @@ th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colo
     // owner bits above and the stream index below are left alone), then the blend merges the bands inside each texel
     const int bits = 32 + deposit_texel_bits(c);
     if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 32, bits))) return s;
-    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 4 * sizeof(uint32_t)));
-    TH_HIP(hipMemsetAsync(c->dep_total, 0, 4 * sizeof(uint32_t), c->stream));
+    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 8 * sizeof(uint32_t)));
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 8 * sizeof(uint32_t), c->stream));
     // (the sort ping-pongs between its two buffer pairs: the caller's keys are copied, not sorted in place)
     TH_HIP(hipMemcpyAsync(c->mrg_keys, keys_dev, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
     const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 32, bits, c->dep_temp, true, c->stream);

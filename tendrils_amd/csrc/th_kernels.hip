@@ -353,19 +353,10 @@ TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2,
 //   DECODED the flow tap reads the per-step decoded float2 plane (8 B) instead of RGBA32F (16 B)
 // ---------------------------------------------------------------------------
 // One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
-// Workgroup-local copy of a window of the decoded flow plane (logic_sorted_kernel): kTileLW x kTileLW texels around
-// one kTile x kTile tile of the field, staged in LDS.  A tap inside the window is a ds_read_b64; a tap outside it
-// (the particle has drifted further than the halo since the last sort) is the ordinary global gather.
-constexpr int kTileShift = 5, kTile = 1 << kTileShift, kTileHalo = 8, kTileLW = kTile + 2 * kTileHalo;
-struct FlowWindow {
-    const __attribute__((address_space(3))) v2f *lds;
-    int x0, y0;              // flow texel held by lds[0]; rows/columns beyond the field edge hold the clamped texel
-    uint32_t misses;         // taps of this lane that left the window
-};
-
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false, bool WINDOW = false>
+constexpr int kTileShift = 5;            // 32 x 32-texel tiles of the flow field: the key of the tile-sorted slot order
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false>
 TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
-                      const HashTables *tabs = nullptr, FlowWindow *win = nullptr)
+                      const HashTables *tabs = nullptr)
 {
     const th_logic_uniforms &u = p.u;
     float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
@@ -416,22 +407,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     const int texel = ty * p.fw + tx;
     float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
     float4 ft;
-    if constexpr (WINDOW) {
-        // (the LDS read is unconditional and the gather a separate masked load: selecting between an LDS and a global
-        // ADDRESS would turn both into one flat_load, which waits for every outstanding load of the wave)
-        const unsigned lx = (unsigned)(tx - win->x0), ly = (unsigned)(ty - win->y0);
-        const bool inside = lx < (unsigned)kTileLW && ly < (unsigned)kTileLW;
-        const v2f w = win->lds[inside ? ly * kTileLW + lx : 0u];
-        ffx = w.x; ffy = w.y;
-        if (__builtin_expect(!inside, 0)) {
-            const float2 d = p.flow_dec[texel];
-            ffx = d.x; ffy = d.y;
-            // complete the gather INSIDE the branch: a load still pending at the join would make every wave - also the
-            // ones that skipped the branch - wait for vmcnt(0) there, i.e. for its prefetched state texels
-            asm volatile("" : "+v"(ffx), "+v"(ffy));
-            ++win->misses;
-        }
-    } else if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
+    if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
     else ft = p.flow[texel];
 
     float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
@@ -460,7 +436,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
         wxs = (wx * u.dt) * vnw; wys = (wy * u.dt) * vnw;
     }
 
-    if constexpr (!DECODED && !WINDOW) {
+    if constexpr (!DECODED) {
         float k = __builtin_fmaxf(0.0f, 1.0f - ((time - ft.z) * u.flowDecay));
         ffx = ft.x * k; ffy = ft.y * k;
     }
@@ -804,15 +780,21 @@ void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target,
 // Slot order within a tile is whatever the rank atomics produce (it differs from run to run);
 // results do not depend on it: every particle reads only its own texel (src/logic.frag:48,75,85).
 // ---------------------------------------------------------------------------
-TH_D uint32_t tile_key(const TileGeom &g, float px, float py)
+// Sort class of particle `pid` at (px, py): 2 * tile + (its line never draws).  Whether draw() can make a line of a particle
+// at all is a fixed property of its row in the state texture (g.row_draws; th_api.hip: line_rows) - about half of the rows
+// cannot: their two vertices read the same texel of the same buffer (src/state/state-at-frame.glsl:12-22).  Keeping the two
+// kinds apart inside every tile lets the draw passes (th_bins.hip) run whole waves of lines that exist, not half-empty ones.
+TH_D uint32_t tile_key(const TileGeom &g, float px, float py, uint32_t pid)
 {
+    const uint32_t row = g.row0 + (g.pow2w ? pid >> g.log2w : pid / g.width);
+    const uint32_t idle = ((g.row_draws[row >> 5] >> (row & 31u)) & 1u) ^ 1u;
     const bool taps = __builtin_fabsf(px) < __builtin_inff() && __builtin_fabsf(py) < __builtin_inff() &&
                       (px != kInert || py != kInert);
-    if (!taps) return g.ntiles;
+    if (!taps) return 2u * g.ntiles + idle;
     // the tap texel of integrate(): (pos * viewSize + 1) * (0.5 * size), clamped, truncated
     const int tx = (int)__builtin_amdgcn_fmed3f((px * g.view_x + 1.0f) * g.half_fw, 0.0f, g.fwm1);
     const int ty = (int)__builtin_amdgcn_fmed3f((py * g.view_y + 1.0f) * g.half_fh, 0.0f, g.fhm1);
-    return (uint32_t)(ty >> kTileShift) * g.tiles_x + (uint32_t)(tx >> kTileShift);
+    return 2u * ((uint32_t)(ty >> kTileShift) * g.tiles_x + (uint32_t)(tx >> kTileShift)) + idle;
 }
 
 // Runs of equal keys among the valid lanes of a wave (valid lanes are a prefix of the wave).  In sorted input a
@@ -908,16 +890,18 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
     const uint32_t base = blockIdx.x * kTileChunk;
     // all 16 positions of a lane first (unconditional, clamped: nothing waits under a branch), then the counting
     float2 pos[kTileChunk / 256u];
+    uint32_t pid[kTileChunk / 256u];
 #pragma unroll
     for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
-        const uint32_t s = base + k * 256u + threadIdx.x;
-        pos[k] = slot_position<PACKED>(b.state, s < b.count ? s : b.count - 1u);
+        const uint32_t s = base + k * 256u + threadIdx.x, at = s < b.count ? s : b.count - 1u;
+        pos[k] = slot_position<PACKED>(b.state, at);
+        pid[k] = b.perm_in ? b.perm_in[at] : at;
     }
 #pragma unroll
     for (uint32_t k = 0; k < kTileChunk / 256u; ++k) {
         const uint32_t s = base + k * 256u + threadIdx.x;
         const bool valid = s < b.count;
-        const uint32_t key = valid ? tile_key(b.g, pos[k].x, pos[k].y) : 0u;
+        const uint32_t key = valid ? tile_key(b.g, pos[k].x, pos[k].y, pid[k]) : 0u;
         const WaveRuns r = wave_runs(key, valid);
         if (r.head) bins_count(bins, b.hist, replica_of(blockIdx.x), key, r.length);
     }
@@ -931,7 +915,7 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileSortParams b)
 {
     __shared__ uint32_t part_n[1024], part_c[1024];
-    const uint32_t bins = b.g.ntiles + 1u, per = (bins + 1023u) / 1024u;
+    const uint32_t bins = 2u * b.g.ntiles + 2u, per = (bins + 1023u) / 1024u;
     const uint32_t lo = threadIdx.x * per < bins ? threadIdx.x * per : bins, hi = lo + per < bins ? lo + per : bins;
     uint32_t n = 0, c = 0;
     for (uint32_t k = lo; k < hi; ++k) {
@@ -1025,7 +1009,7 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(const TileSortParams 
             float px, py;
             if constexpr (PACKED) { const float4 u = unpack_state(make_uint2(st[q].x, 0u)); px = u.x; py = u.y; }
             else { px = st[q].x; py = st[q].y; }
-            const uint32_t key = valid ? tile_key(b.g, px, py) : 0u;
+            const uint32_t key = valid ? tile_key(b.g, px, py, b.perm_in ? pid[q] : s) : 0u;
             const uint32_t d = tabled ? reserve_slots(bins, b.cursor, replica_of(blockIdx.x), key, valid)
                                       : reserve_slots(b.cursor, replica_of(blockIdx.x) + key, valid);
             if (valid) { reinterpret_cast<Texel *>(b.state_out)[d] = st[q]; b.perm_out[d] = b.perm_in ? pid[q] : s; }
@@ -1093,15 +1077,14 @@ void launch_permute_state(float4 *dst, const float4 *src, const uint32_t *perm, 
 //   COUNT     (in-place passes) also histogram the tiles of the OUTPUT positions - the input of the next pass - and
 //             leave every chunk's table of (tile, count) in p.records, so that a SCATTER pass that follows needs no
 //             counting pass of its own and reserves its slots once per workgroup and tile (p.use_records)
-//   WINDOW    (tile-sorted input) stage the chunk's tile + halo of the decoded plane in LDS; otherwise the taps are gathered
-//             from the plane (what the counting and re-sorting passes do when the passes in between gather too: by then
-//             most particles have left a window staged for their tile at the last sort)
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool IN_TILED, bool SCATTER, bool COUNT, bool WINDOW = IN_TILED>
+// The flow taps are gathered from the decoded plane like the plain passes' in between (round 2 also built an LDS-staged
+// window of the chunk's tile + halo here; gathered taps over the same slot order won the A/B - profiles/HISTORY.md - and
+// the window was removed in round 3).
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool IN_TILED, bool SCATTER, bool COUNT>
 __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams p)
 {
     __shared__ ChunkBins bins;
     __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
-    __shared__ v2f window[WINDOW ? kTileLW * kTileLW : 1];
     const float time = p.time_dev ? *p.time_dev : p.u.time;
     const float4 *lut = smem + (NOISE ? kHashVec : 0);
     const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
@@ -1117,9 +1100,8 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
     } else {
         const uint32_t start = blockIdx.x * kTileChunk;
         if (start >= p.count) return;
-        ch = TileChunk{start, p.count - start < kTileChunk ? p.count - start : kTileChunk, p.geom.ntiles, 0u};
+        ch = TileChunk{start, p.count - start < kTileChunk ? p.count - start : kTileChunk, 0u, 0u};
     }
-    FlowWindow win{(const __attribute__((address_space(3))) v2f *)window, 0, 0, 0u};
     const bool use_records = SCATTER && IN_TILED && p.use_records;
     if constexpr (COUNT) bins_clear(bins);
     if constexpr (SCATTER && IN_TILED) {
@@ -1132,20 +1114,6 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         }
     }
     if constexpr (NOISE) fill_hash_tables(smem, p.lut);
-    if constexpr (WINDOW) {
-        if (ch.tile < p.geom.ntiles) {
-            const int ty0 = (int)(ch.tile / p.geom.tiles_x), tx0 = (int)(ch.tile - (uint32_t)ty0 * p.geom.tiles_x);
-            win.x0 = tx0 * kTile - kTileHalo; win.y0 = ty0 * kTile - kTileHalo;
-            for (int t = threadIdx.x; t < kTileLW * kTileLW; t += 256) {
-                const int ly = t / kTileLW, lx = t - ly * kTileLW;
-                int gx = win.x0 + lx, gy = win.y0 + ly;
-                gx = gx < 0 ? 0 : (gx >= p.fw ? p.fw - 1 : gx);
-                gy = gy < 0 ? 0 : (gy >= p.fh ? p.fh - 1 : gy);
-                const float2 d = p.flow_dec[gy * p.fw + gx];
-                window[t] = v2f{d.x, d.y};
-            }
-        } else { win.x0 = -0x40000000; win.y0 = -0x40000000; }      // the no-tap class: nothing to stage
-    }
     if constexpr (NOISE || IN_TILED || COUNT) __syncthreads();        // (tables, window, bins; the record-based reservations of SCATTER)
 
     // The chunk is swept 256 slots at a time, two iterations of state loads ahead.  The loads are unconditional - lanes and
@@ -1170,7 +1138,7 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         uint32_t dst = slot;
         // (whole waves reach this point together: the rank reservation and the counting are wave-wide operations)
         if constexpr (SCATTER) {
-            const uint32_t key = valid ? tile_key(p.geom, st.x, st.y) : 0u;
+            const uint32_t key = valid ? tile_key(p.geom, st.x, st.y, pid) : 0u;
             // (without a record the histogram came from tile_hist_kernel: copies by the input slot's 4096-block)
             if constexpr (IN_TILED) dst = use_records ? reserve_slots(bins, p.cursor, replica_of(c), key, valid)
                                                       : reserve_slots(p.cursor, replica_of(slot >> 12) + key, valid);
@@ -1178,14 +1146,13 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         }
         float4 r = st;
         if (valid) {
-            if constexpr (WINDOW) r = integrate<FAST, NOISE, TARGET, POW2, true, true, true>(p, lut, st, pid, time, &tabs, &win);
-            else r = integrate<FAST, NOISE, TARGET, POW2, true, true, false>(p, lut, st, pid, time, &tabs);
+            r = integrate<FAST, NOISE, TARGET, POW2, true, true>(p, lut, st, pid, time, &tabs);
             // (scattered runs start at any slot: plain stores, so that L2 can merge the partial lines two runs share)
             if constexpr (SCATTER) { p.out[dst] = r; p.perm_out[dst] = pid; if (p.in_moved) p.in_moved[dst] = st; }
             else store_stream(&p.out[dst], r);
         }
         if constexpr (COUNT) {
-            const uint32_t key = valid ? tile_key(p.geom, r.x, r.y) : 0u;
+            const uint32_t key = valid ? tile_key(p.geom, r.x, r.y, pid) : 0u;
             const WaveRuns w = wave_runs(key, valid);
             if (w.head) bins_count(bins, p.hist, replica_of(c), key, w.length);
         }
@@ -1210,37 +1177,28 @@ __global__ __launch_bounds__(256, 5) void logic_sorted_kernel(const LogicParams 
         __syncthreads();
         bins_flush(bins, p.hist, replica_of(c), &p.records[c]);
     }
-    if constexpr (WINDOW) {
-        if (p.misses) {
-            uint32_t m = win.misses;
-            m += __shfl_xor(m, 32); m += __shfl_xor(m, 16); m += __shfl_xor(m, 8);
-            m += __shfl_xor(m, 4); m += __shfl_xor(m, 2); m += __shfl_xor(m, 1);
-            if ((threadIdx.x & 63u) == 0u && m) atomicAdd(p.misses, m);
-        }
-    }
 }
 
 template <bool FAST, bool NOISE, bool TARGET>
-static void launch_sorted_p2(const LogicParams &p, bool pow2, bool in_tiled, bool scatter, bool count, bool window, uint32_t max_chunks, hipStream_t s)
+static void launch_sorted_p2(const LogicParams &p, bool pow2, bool in_tiled, bool scatter, bool count, uint32_t max_chunks, hipStream_t s)
 {
     // IN_TILED: an upper bound of the chunk count (the real one lives on the device), rounded up to the 8 XCD groups
     const int grid = in_tiled ? (int)(((max_chunks + 7u) & ~7u)) : tile_grid(p.count);
-#define TH_GO(P2, IT, SC, CN, WN) hipLaunchKernelGGL((logic_sorted_kernel<FAST, NOISE, TARGET, P2, IT, SC, CN, WN>), dim3(grid), dim3(256), 0, s, p)
-#define TH_GO_P2(IT, SC, CN, WN) do { if (pow2) TH_GO(true, IT, SC, CN, WN); else TH_GO(false, IT, SC, CN, WN); } while (0)
+#define TH_GO(P2, IT, SC, CN) hipLaunchKernelGGL((logic_sorted_kernel<FAST, NOISE, TARGET, P2, IT, SC, CN>), dim3(grid), dim3(256), 0, s, p)
+#define TH_GO_P2(IT, SC, CN) do { if (pow2) TH_GO(true, IT, SC, CN); else TH_GO(false, IT, SC, CN); } while (0)
     if (in_tiled) {
-        if (scatter) { if (window) TH_GO_P2(true, true, false, true); else TH_GO_P2(true, true, false, false); }
-        else if (count) { if (window) TH_GO_P2(true, false, true, true); else TH_GO_P2(true, false, true, false); }
-        else TH_GO_P2(true, false, false, true);       // (in place without counting: only the window form is used)
-    } else TH_GO_P2(false, true, false, false);
+        if (scatter) TH_GO_P2(true, true, false);
+        else TH_GO_P2(true, false, true);        // (in place: the counting pass before a re-sort; plain passes run logic_kernel)
+    } else TH_GO_P2(false, true, false);
 #undef TH_GO_P2
 #undef TH_GO
 }
 
 void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
-                         bool count, bool window, uint32_t max_chunks, hipStream_t s)
+                         bool count, uint32_t max_chunks, hipStream_t s)
 {
     const bool fast = mode == TH_MODE_FAST;
-#define TH_DISPATCH(F, N, T) launch_sorted_p2<F, N, T>(p, pow2, in_tiled, scatter, count, window, max_chunks, s)
+#define TH_DISPATCH(F, N, T) launch_sorted_p2<F, N, T>(p, pow2, in_tiled, scatter, count, max_chunks, s)
     if (fast) {
         if (noise) { if (target) TH_DISPATCH(true, true, true); else TH_DISPATCH(true, true, false); }
         else { if (target) TH_DISPATCH(true, false, true); else TH_DISPATCH(true, false, false); }

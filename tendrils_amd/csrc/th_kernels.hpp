@@ -13,13 +13,15 @@ constexpr uint32_t kMaxFusedSteps = 32;
 
 // Tile-sorted slot order (th_kernels.hip "Tile-sorted slot order")
 constexpr uint32_t kTileChunk = 4096;        // slots per workgroup (16 per thread), all of one tile
-constexpr uint32_t kMaxTileBins = 8192;      // tiles + 1: larger flow fields keep the texel order
+constexpr uint32_t kMaxTileBins = 8192;      // sort classes (2 per tile + 2): larger flow fields keep the texel order
 constexpr uint32_t kSortReplicas = 64;       // copies of the global sort counters (power of two)
 constexpr uint32_t kBinSlotsLog2 = 6, kBinSlots = 1u << kBinSlotsLog2;   // LDS table of the tiles one workgroup meets
 
-struct TileGeom {                // how a position maps to its flow tile: the tap arithmetic of the integrator
+struct TileGeom {                // how a particle maps to its sort class: the tap arithmetic of the integrator + whether its line can draw
     float view_x, view_y, half_fw, half_fh, fwm1, fhm1;
-    uint32_t tiles_x, ntiles;    // class `ntiles` = particles that tap nothing (inert, NaN / infinite position)
+    uint32_t tiles_x, ntiles;    // classes 2*tile + idle; tile `ntiles` = particles that tap nothing (inert, NaN / infinite position)
+    uint32_t width, log2w, pow2w, row0;      // particle id -> global row of the state texture
+    const uint32_t *row_draws;   // bit per global row: draw() can make a line of the particles of this row
 };
 
 struct TileChunk { uint32_t start, count, tile, pad; };
@@ -53,7 +55,6 @@ struct LogicParams {
     uint32_t *cursor;        // SCATTER: rank cursors of the new order (tile_scan_kernel)
     uint32_t *perm_out;      // SCATTER: particle ids of the new order
     float4 *in_moved;        // SCATTER: (optional) receives the INPUT state at the new slots as well
-    uint32_t *misses;        // += taps that left the staged window (nullptr = not counted)
     uint32_t *hist;          // COUNT: histogram of the output positions' tiles
     ChunkRecord *records;    // COUNT: written per chunk; SCATTER with use_records: read per chunk
     uint32_t use_records;
@@ -137,14 +138,23 @@ struct DepositParams {
     float4 *colors_sorted;       // ... gathered into the sorted order
     unsigned long long *keys64;  // sharded form, per fragment: owner << kOwnerShift | texel << 32 | global stream index
     uint32_t owners, owner_chunk;    // ranks that own flow texels (contiguous ranges of owner_chunk texels)
+    const uint32_t *row_draws;   // bit per global row of the state texture: its lines can draw at all (th_api.hip: line_rows)
     // binned pipeline (th_bins.hip): lines are walked by SLOT - cur / prev in the ring's slot order, perm[slot] = particle
     // id (nullptr = texel order); count / record / the line lists are indexed by slot; fragments are bucketed by the
     // 16 x 16-texel bin of the flow field they fall into
     const uint32_t *perm;
     uint32_t bins_x, nbins;
-    uint32_t *bin_hist, *bin_start, *bin_cursor;   // fragments per bin; first fragment of every bin (nbins + 1); fill cursors
+    uint32_t *bin_hist, *bin_start;                // fragments per bin; first fragment of every bin (nbins + 1)
+    uint32_t *rep_hist, *rep_cursor;               // kBinReplicas copies of the bins' counters, bin_stride words apart: counts (then: first place of the copy in its bin); fill cursors
+    uint32_t bin_stride;
     unsigned long long *frag_keys;                 // per fragment, bin-major: (y << 12 | x) << 32 | stream index of the line
     uint32_t id_bits;                              // bits of a stream index: ceil(log2(W * H))
+    uint32_t *block_flags;                         // per 256-slot block: some line of it has fragments (written by the rasterising pass)
+    // ... bins of more fragments than one workgroup orders in LDS (crowd_*_kernel)
+    uint32_t *large_bins, *large_block0;           // the large bins (in any order); first workgroup block of each (+ 1)
+    uint32_t nlarge;
+    uint32_t *crowd_count, *crowd_start, *crowd_cursor;   // per large bin: fragments per texel (256), first of every texel (257), fill cursors (256)
+    unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 24 | position of its varying in the bin
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
@@ -166,7 +176,7 @@ void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t s
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
                         hipStream_t stream);
 void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
-                         bool count, bool window, uint32_t max_chunks, hipStream_t stream);
+                         bool count, uint32_t max_chunks, hipStream_t stream);
 void launch_tile_hist(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scan(const TileSortParams &b, hipStream_t stream);
 void launch_tile_scatter(const TileSortParams &b, hipStream_t stream);
@@ -194,12 +204,14 @@ void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t st
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t stream);
 // binned pipeline (th_bins.hip)
 constexpr int kBinShift = 4;                       // 16 x 16 texel bins
+constexpr uint32_t kBinReplicas = 32;              // copies of the bins' global counters (th_bins.hip: rep_word)
 constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits per texel coordinate
 constexpr uint32_t kBinsMaxPerBin = 1u << 24;      // a fragment's position inside its bin rides in 24 key bits while it is sorted
 void launch_bins_raster(const DepositParams &p, hipStream_t stream);                  // count + record per slot, fragments per bin
-void launch_bins_scan(const DepositParams &p, uint32_t *totals, hipStream_t stream);  // totals[0] = fragments, totals[2] = largest bin
+void launch_bins_scan(const DepositParams &p, uint32_t *totals, hipStream_t stream);  // totals[0] = fragments, [2] = largest bin, [3] = large bins, [4] = their blocks
 void launch_bins_emit(const DepositParams &p, hipStream_t stream);                    // fragments into their bins
-void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // per bin: sort by (texel, stream index), blend
+void launch_bins_blend(const DepositParams &p, uint32_t nblocks, hipStream_t stream);   // per bin: sort by (texel, stream index), blend
+size_t crowd_words_per_bin();
 // stable LSD radix sort of (key, u32 value) pairs by key bits [begin_bit, end_bit) (th_sort.hip): the passes ping-pong
 // between the (a) and (b) buffers; returns 0 when the result is in (a), 1 when it is in (b)
 constexpr uint32_t kRadixBits = 8;

@@ -71,7 +71,8 @@ TH_D void dep_render_color(const DepositParams &p, float4 state, float uvx, floa
 // `own_row` (local) / `own_at`: the line's own particle - row and index in cur / prev.  The binned pipeline walks SLOTS (cur / prev in
 // the ring's slot order): a vertex that is the line's own particle - every vertex, for shapes whose LUT does not drift
 // off the line's texel (th_api.hip: lines_are_local) - is read at own_at; in texel order own_at is the texel index anyway.
-TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at)
+// `own`: (optional) the own particle's texels of cur and prev, already loaded.
+TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at, const float4 *own = nullptr)
 {
     const int W = (int)p.W, H = (int)p.H;
     const float uvx = (float)((double)i * p.inv_x), uvy = (float)((double)j * p.inv_y);   // Float32Array of JS doubles
@@ -85,14 +86,17 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uin
     // (one unconditional load from a selected address: a load under a branch is awaited at the join, and the second
     // vertex's load would only go out after the first had come back)
     size_t at = (size_t)(row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1)) * W + col;
-    if (row == (int)own_row && col == (int)i) at = own_at;
+    const bool self = row == (int)own_row && col == (int)i;
+    if (self) at = own_at;
     const float4 *from = tex + at;
     if (!(row >= 0 && row < (int)p.rows)) {
         if (row == -1 && p.halo_lo) from = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
         else if (row == (int)p.rows && p.halo_hi) from = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
         else *p.oob = 1u;
     }
-    const float4 t = *from;
+    float4 t;
+    if (own && self) t = offset > 0.25f ? own[0] : own[1];
+    else t = *from;
     DepositVertex v;
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
@@ -124,13 +128,13 @@ struct DepositLine {
 };
 
 // everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
-TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at)
+TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const float4 *own = nullptr)
 {
     L.draws = false;
     L.short32 = false;
     L.n = 0;
-    L.a = dep_fetch(p, i, 2u * m, m - p.row0, own_at);
-    L.b = dep_fetch(p, i, 2u * m + 1u, m - p.row0, own_at);
+    L.a = dep_fetch(p, i, 2u * m, m - p.row0, own_at, own);
+    L.b = dep_fetch(p, i, 2u * m + 1u, m - p.row0, own_at, own);
     if (!L.a.live || !L.b.live) return;                                  // see the header: inert vertex = no line
     const float fw = (float)p.fw, fh = (float)p.fh;
     const float dx = (0.5f * fw) * (L.b.px - L.a.px), dy = (0.5f * fh) * (L.b.py - L.a.py);

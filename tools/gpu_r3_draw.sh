@@ -9,13 +9,13 @@ export TMPDIR=/tmp
 if [ "${1:-}" != "notest" ]; then
   timeout 1700 python -m pytest tests/test_gpu_binned_draw.py -x -q -m gpu 2>&1 | tail -15 | tee $OUT/binned_tests.log
 fi
-for pipe in stream auto; do
+for pipe in stream bins; do
   TH_PIPE=$pipe timeout 300 python tools/deposit_bench.py 60 2>&1 | tail -1 | tee -a $OUT/deposit_bench.log
   TH_PIPE=$pipe timeout 300 python tools/deposit_bench.py 30 --both 2>&1 | tail -1 | tee -a $OUT/deposit_bench.log
 done
-TH_PIPE=auto timeout 300 python tools/deposit_bench.py 60 --in-view 2>&1 | tail -1 | tee -a $OUT/deposit_bench.log
+TH_PIPE=bins timeout 300 python tools/deposit_bench.py 60 --in-view 2>&1 | tail -1 | tee -a $OUT/deposit_bench.log
 cd /tmp
-for pipe in auto; do
+for pipe in bins; do
   D=$OUT/trace_$pipe
   TH_PIPE=$pipe timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $ROOT/tools/deposit_bench.py 30 > $D.log 2>&1
   python3 - $D <<'PY'
