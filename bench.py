@@ -9,17 +9,29 @@ holds.  State, flow and frames are resident in HBM before the timed region start
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode exact|fast] [--config c3|c4|c5]
 
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself: the parent - before it touches
+the GPU - runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's
+JSON line and exits with the child's status.  Under a launcher (WORLD_SIZE set) every process is one rank.
+
 Timed region: W warm-up steps, then an untimed clock pre-roll (>= 50 ms of the same launches,
 disclosed as `preroll_ms`: a GPU that has idled for a few ms runs its first launches ~10 %
-slower, profiles/r2_a_*), barrier + synchronize, EXACTLY K steps, barrier + synchronize; max
-over ranks.
+slower, profiles/r2_a_*), then `--reps` (5) repetitions of: barrier + synchronize, EXACTLY K steps,
+barrier + synchronize; max over ranks per repetition; `value` / `ms_per_step` are the MEDIAN repetition
+(`repetitions` carries all of them and their spread).  Every timed repetition contains the path's
+collective: after every fused launch the statistics pass and - world > 1 - the library's own RCCL
+all-reduce of the counter block (th_stats_allreduce, on the context's stream); `rccl` reports the ranks
+the reduction saw.
 
 Roofline block.  The step loop runs as fused launches (th_step_n: <= 32 steps of a
 particle back to back in registers), which stream 48/n bytes per particle-step instead of 32 and are
 bound by VALU issue, not by HBM.  The line therefore carries
-  * roofline.achieved/peak/frac : the SURVEY.md 8d figure - ALGORITHMIC bytes (32 B x particles x
-    steps of one launch) / mean launch duration, against 8 TB/s.  An equivalent single-step
-    bandwidth, not a physical one (it may exceed 1 for the flow-only uniform set);
+  * roofline.achieved/peak/equivalent_frac : the SURVEY.md 8d figure - ALGORITHMIC bytes (32 B x
+    particles x steps of one launch) / mean launch duration, against 8 TB/s.  An equivalent
+    single-step bandwidth, not a physical one (for a register-resident fused launch it can exceed
+    the peak); roofline.frac is the fraction of the bound the entry NAMES (`bound`): VALU issue for
+    the fused noise-on launch, the larger of physical HBM and VALU for the fused flow-only one,
+    HBM (algorithmic bytes, which a single-step launch really streams) for one step per launch -
+    never above 1;
   * roofline.hbm_physical       : rocprofv3 PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE KiB,
     as MI355X_MICROARCH.md prescribes) / the same duration;
   * roofline.valu               : SQ_INSTS_VALU per launch / duration against the chip's VALU issue
@@ -34,16 +46,25 @@ frame_loop (N = 1, c3): the reference's frame loop on the same particles - timer
 draw() - after everything else: single-step launch, flow pass and view pass of draw() in ms,
 fragments per draw, and the flow pass's own HBM roofline.
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL).  c3: every rank holds a
-4096-row band of a 4096 x (4096 N) texture (weak scaling).  c4: 8192 x 8192 row-sharded (64 M
-particles in all, strong scaling), counters reduced every 16 steps (and, reported beside it, every
-step).  c5: 16384 x 16384 packed fp16 state row-sharded, 16-step fused groups.  Flow replicated; no
-data-path collective; the statistics counters are reduced by small RCCL all-reduces.
+Multi-GPU: one process per GPU.  c3: every rank holds a 4096-row band of a 4096 x (4096 N) texture
+(weak scaling; the N = 1 line is the single-GPU bench).  c4: 8192 x 8192 row-sharded (64 M particles in
+all, strong scaling), counters reduced every 16 steps (and, reported beside it, every step) - also run as
+a second leg of the default c3 invocation (key `c4`), so that a scaling sweep of the driver's command
+carries both curves.  c5: 16384 x 16384 packed fp16 state row-sharded, 16-step fused groups.  Flow
+replicated; no data-path collective; the counter block is reduced by the library's RCCL all-reduce
+(th_comm_init / th_stats_allreduce; torch.distributed only carries the 128-byte id, the barriers and
+the max over ranks of the bench itself).
+
+`--dry-run`: the launcher, the rank plumbing, the timed-region protocol and the collective on CPU
+(gloo), stepping a small band with the CPU restatement - what tests/test_bench_launch.py runs at world
+size 2; it measures nothing.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -202,16 +223,372 @@ def pmc_bytes(c):
     return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(gpus, argv):
+    """`bench.py --gpus N` with no launcher around it: start the N ranks as a child job - from a process that has not
+    touched the GPU (nothing here imports torch) - relay rank 0's JSON line, return the child's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what this pool's driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in child.stdout:
+        text = out.strip()
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        elif text:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc else (0 if line is not None else 1)
+
+
+def median(xs):
+    ys = sorted(xs)
+    return ys[len(ys) // 2] if len(ys) % 2 else 0.5 * (ys[len(ys) // 2 - 1] + ys[len(ys) // 2])
+
+
+def repetition_block(walls, steps):
+    ms = [w / steps * 1e3 for w in walls]
+    mid = median(ms)
+    return {"n": len(ms), "ms_per_step": ms, "median": mid, "min": min(ms), "max": max(ms),
+            "spread": (max(ms) - min(ms)) / mid if mid > 0 else None,
+            "note": "each repetition: barrier + synchronize, K steps, barrier + synchronize; max over ranks; value = median"}
+
+
+class Job:
+    """One rank's share of a configuration: the Tendrils object with its synthetic state and flow, the step loop of the
+    timed region (fused launches + statistics + the counter all-reduce + optical-flow refresh) and its timing."""
+
+    def __init__(self, args, config, rank, local_rank, world, dist, launch_len=None):
+        import tendrils_amd as ta
+        from tendrils_amd import _capi
+        from tendrils_amd.sharding import comm_init, comm_query, shard_rows
+        from tendrils_amd.tendrils import View
+        self.ta, self.capi, self.dist, self.world, self.rank = ta, _capi, dist, world, rank
+        cfg = CONFIGS[config]
+        self.cfg, self.config = cfg, config
+        self.state_fmt = args.state or cfg["state"]
+        self.group = cfg["group"]                    # steps per fused launch and per statistics reduction
+        self.width, self.rows, self.gheight = cfg["width"], cfg["rows"](world), cfg["gheight"](world)
+        self.particles_rank = self.width * self.rows
+        self.launch_len = launch_len or min(self.group, args.steps)
+        opts = ta.defaults()
+        opts.update(device=local_rank, mode=ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT,
+                    row0=shard_rows(self.gheight, world, rank)[0], rows=self.rows, globalHeight=self.gheight,
+                    stateFormat=ta.TH_STATE_F16 if self.state_fmt == "f16" else ta.TH_STATE_F32)
+        t = self.t = ta.Tendrils(View(FLOW_W, FLOW_H), opts)
+        t.resize()                       # viewRes 1920x1080 -> viewSize [1, 1.7778]; flow.shape = viewRes
+        t.setup(self.width)
+        ctx = self.ctx = t.particles._ctx
+        band = 1024                      # generated and uploaded in row bands (bounded host memory at C5)
+        full = synth_state(rank) if config == "c3" else None
+        for r0 in range(0, self.rows, band):
+            r1 = min(self.rows, r0 + band)
+            st = full[r0:r1] if full is not None else synth_rows(self.width, r1 - r0, 12345 + rank * 1000003 + r0)
+            if args.in_view:
+                st = st.copy()
+                st[..., 1] *= np.float32(0.56)
+            _capi.call("th_upload_state", ctx, -1, np.ascontiguousarray(st).ctypes.data_as(_capi._fp), 0, r0, self.width, r1 - r0)
+        full = st = None
+
+        # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
+        self.time0 = 1000.0
+        self.flow_source = "optical-flow(synthetic 1080p frame pair)"
+        self.of = None
+        try:
+            from tendrils_amd.optical_flow import OpticalFlow
+            f0, f1 = synth_frames()
+            of = OpticalFlow(t, uniforms=dict(speed=0.08, offset=0.1, scaleUV=[-1, -1]))   # src/demo.main.js:526-530
+            of.resize([FLOW_W, FLOW_H])
+            of.set_pixels(f0)
+            of.step()
+            of.set_pixels(f1)
+            of.update(dict(speedLimit=t.state["speedLimit"], time=self.time0, viewSize=t.viewSize))
+            of.render()
+            self.of = of
+        except (ImportError, ta.TendrilsHipError):
+            self.flow_source = "synthetic divergence-free field (optical-flow pass unavailable)"
+            t.flow.set_pixels(synth_flow(self.time0))
+        t.timer.time = self.time0
+        # the job's communicator inside the library: the counter all-reduce of the timed region is th_stats_allreduce
+        self.comm = None
+        if dist is not None:
+            comm_init(ctx, dist)
+            self.comm = comm_query(ctx)
+        self.reductions = 0
+        if args.flow_only:
+            t.state["noiseWeight"] = 0
+
+    def sync_all(self):
+        import torch
+        self.t.particles.sync()
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def stats_tick(self):
+        """statistics of buffers[0] and - world > 1 - their reduction over the ranks, both enqueued on the context's
+        stream (the library's RCCL all-reduce: no host sync, no second stream)"""
+        self.capi.call("th_stats_async", self.ctx, C.c_float(self.t.state["speedLimit"]), None)
+        if self.comm is not None:
+            self.capi.call("th_stats_allreduce", self.ctx)
+            self.reductions += 1
+
+    def run(self, k_steps, every=None, refresh=True):
+        # the step loop runs as fused launches (Tendrils.step_n -> th_step_n), `every` steps each; after EVERY launch
+        # (a trailing partial one included): statistics + their reduction over the ranks; after every full group the
+        # optical-flow refresh
+        t, of = self.t, self.of
+        every = min(every or self.group, max(k_steps, 1))
+        done = 0
+        while done < k_steps:
+            n = min(every, k_steps - done)
+            t.step_n(n)
+            done += n
+            self.stats_tick()
+            if of is not None and refresh and done % self.group == 0:      # keep the field alive: re-stamp it from the frame pair (blended)
+                of.update(dict(speedLimit=t.state["speedLimit"], time=t.timer.time, viewSize=t.viewSize))
+                of.render()
+
+    def run_kernel_only(self, k_steps, length):
+        done = 0
+        while done < k_steps:
+            n = min(length, k_steps - done)
+            self.t.step_n(n)
+            done += n
+
+    def timed_kernels(self, fn):
+        """mean launch duration (HIP event pair around every integrator launch on the context's stream)"""
+        ms, n = C.c_float(), C.c_int32()
+        self.capi.call("th_kernel_timing", self.ctx, 1)
+        fn()
+        self.capi.call("th_kernel_timing_read", self.ctx, C.byref(ms), C.byref(n))
+        self.capi.call("th_kernel_timing", self.ctx, 0)
+        return ms.value, n.value
+
+    def preroll(self):
+        """clock pre-roll: the launches of the timed region, untimed, until >= PREROLL_MS have run on the device"""
+        self.sync_all()
+        p0 = time.perf_counter()
+        self.run_kernel_only(self.launch_len, self.launch_len)
+        self.sync_all()
+        est = max(time.perf_counter() - p0, 1e-4)
+        pre_launches = int(min(max(PREROLL_MS * 1e-3 / est, 1), 4096))
+        p0 = time.perf_counter()
+        self.run_kernel_only(pre_launches * self.launch_len, self.launch_len)
+        self.sync_all()
+        return (time.perf_counter() - p0) * 1e3
+
+    def timed_region(self, steps, reps, **kw):
+        """`reps` x [barrier + synchronize, `steps` steps, barrier + synchronize] -> wall seconds of each (this rank)"""
+        walls = []
+        for _ in range(reps):
+            self.sync_all()
+            t0 = time.perf_counter()
+            self.run(steps, **kw)
+            self.sync_all()
+            walls.append(time.perf_counter() - t0)
+        return walls
+
+    def max_over_ranks(self, values):
+        if self.dist is None:
+            return [float(v) for v in values]
+        import torch
+        v = torch.tensor(list(values), dtype=torch.float64, device="cuda")
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in v]
+
+    def global_stats(self):
+        """th_stats_global: the job's counters (local pass + the library's all-reduce + download)"""
+        c = self.capi.Counters()
+        self.capi.call("th_stats_global", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(c))
+        return {k: getattr(c, k) for k, _ in self.capi.Counters._fields_}
+
+    def rccl_block(self, stats, reductions_per_rep):
+        seen = stats["particles"] / float(self.particles_rank)
+        b = {"world": self.world, "nranks_seen": seen, "reductions_per_timed_repetition": reductions_per_rep,
+             "note": "nranks_seen = the all-reduced `particles` counter / this rank's particles: the ranks whose blocks the "
+                     "library's RCCL all-reduce (th_stats_allreduce, on the context's stream) added up; at world 1 the "
+                     "context holds no communicator and the local block is the global one"}
+        if self.comm is not None:
+            b.update(version=self.comm["rccl_version"], in_library=True, rank=self.comm["rank"])
+        return b
+
+    def dispose(self):
+        self.t.dispose()
+
+
+def roofline_entry(job, launch_s, steps_in_launch, counters, bytes_per_step):
+    """roofline entries of one kind of launch"""
+    alg = bytes_per_step * job.particles_rank * steps_in_launch
+    eq = alg / launch_s / 1e9 / HBM_PEAK_GBS
+    e = {"avg_launch_ms": launch_s * 1e3, "steps_per_launch": steps_in_launch,
+         "ms_per_step": launch_s * 1e3 / steps_in_launch,
+         "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "equivalent_frac": eq,
+         "algorithmic_bytes_per_launch": alg}
+    tb = pmc_bytes(counters)
+    e["traffic"] = tb
+    if tb is not None:
+        e["hbm_physical"] = {"achieved": tb / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": tb / launch_s / 1e9 / HBM_PEAK_GBS, "bytes_over_algorithmic": tb / alg}
+    if counters and "SQ_INSTS_VALU" in counters:
+        v = counters["SQ_INSTS_VALU"]
+        e["valu"] = {"wave_insts_per_launch": v, "per_wave_step": v / (job.particles_rank / 64.0 * steps_in_launch),
+                     "achieved": v / launch_s, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": v / launch_s / VALU_PEAK}
+        if "clock_ghz" in counters:      # under the profiler (launches run a few % slower there)
+            e["valu"]["clock_ghz"] = counters["clock_ghz"]
+            e["valu"]["profiled_launch_ms"] = counters.get("profiled_launch_ms")
+            e["valu"]["issue_utilization_at_held_clock"] = counters.get("valu_issue_utilization")
+            e["valu"]["note"] = "peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction; clock_ghz = GRBM_GUI_ACTIVE / 8 / launch " \
+                                "duration and issue_utilization = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), both per " \
+                                "dispatch in the PMC child run: the clock the chip held under this load and the share of its issue " \
+                                "slots the launch used at that clock"
+    if counters and "SQ_LDS_IDX_ACTIVE" in counters and counters["SQ_LDS_IDX_ACTIVE"] > 0:
+        e["lds"] = {"bank_conflict_share": counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]}
+    return e
+
+
+def bind(e, fused):
+    """`bound` and `frac` of an entry: the fraction of the bound it names, never the equivalent bandwidth of a
+    register-resident launch.  One step per launch streams its algorithmic bytes: HBM, frac = algorithmic / peak.
+    A fused launch is bound by whichever of VALU issue and physical HBM traffic it uses more of (PMC child runs);
+    without counters the bound is not known and frac stays null."""
+    if not fused:
+        e["bound"], e["frac"] = "hbm", e["equivalent_frac"]
+        e["frac_is"] = "algorithmic bytes / launch duration / HBM peak (a single-step launch streams them)"
+        return e
+    v = (e.get("valu") or {}).get("frac")
+    h = (e.get("hbm_physical") or {}).get("frac")
+    if v is None and h is None:
+        e["bound"], e["frac"] = "valu", None
+        e["frac_is"] = "unknown: the PMC child runs gave no counters (equivalent_frac is the SURVEY.md 8d figure)"
+    elif h is None or (v is not None and v >= h):
+        e["bound"], e["frac"] = "valu", v
+        e["frac_is"] = "valu.frac: wave64 VALU instructions per second / the chip's issue peak at 2.4 GHz"
+    else:
+        e["bound"], e["frac"] = "hbm", h
+        e["frac_is"] = "hbm_physical.frac: PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) / launch duration / HBM peak"
+    return e
+
+
+def c4_leg(args, rank, local_rank, world, dist):
+    """BASELINE.json config 4 beside the metric's own configuration: 8192 x 8192 particles row-sharded over the ranks
+    (strong scaling: 64 M particles in all, whatever N), counters reduced after every 16-step launch."""
+    job = Job(args, "c4", rank, local_rank, world, dist)
+    job.run(args.warmup)
+    job.preroll()
+    job.reductions = 0
+    walls = job.timed_region(args.steps, max(args.reps // 2, 3))
+    reductions = job.reductions // max(args.reps // 2, 3)
+    walls = job.max_over_ranks(walls)
+    stats = job.global_stats()
+    particles = job.particles_rank * world
+    mid = median(walls)
+    out = {"value": particles * args.steps / mid, "unit": "particle-steps/s", "ms_per_step": mid / args.steps * 1e3,
+           "scaling": "strong", "n_gpus": world, "steps": args.steps, "particles": particles,
+           "particles_per_gpu": job.particles_rank, "repetitions": repetition_block(walls, args.steps),
+           "rccl": job.rccl_block(stats, reductions),
+           "workload": (job.cfg["label"] % "RGBA32F") + ", same flow and uniforms as the headline, fused launches of <= %d steps, "
+                       "statistics + counter all-reduce after every launch" % job.launch_len}
+    job.dispose()
+    return out
+
+
+def dry_run(args, rank, world):
+    """The launcher path, the rank plumbing, the timed-region protocol and the collective on CPU: gloo ranks stepping a
+    small row band each with the CPU restatement (test infrastructure - this measures nothing and says so)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    from tendrils_amd.sharding import reduce_counters, shard_rows
+    n = 48
+    gheight = n * world
+    row0, rows = shard_rows(gheight, world, rank)
+    band = synth_rows(n, rows, 12345 + rank)
+    fl = np.zeros((27, 48, 4), np.float32)
+    fl[..., :2] = np.random.default_rng(5).uniform(-.01, .01, (27, 48, 2))
+    fl[..., 2] = 990.0
+    group = min(4, max(args.steps, 1))
+    tm = {"time": 1000.0}
+
+    def counters(b):
+        live = (b[..., 0] != -1e6) | (b[..., 1] != -1e6)
+        sp = np.hypot(b[..., 2].astype(np.float64), b[..., 3].astype(np.float64))[live]
+        return dict(particles=b.shape[0] * n, live=int(live.sum()), nan=int(np.isnan(b).any(-1).sum()),
+                    capped=int((sp >= 0.01 * (1 - 2 ** -20)).sum()), respawned=0, sum_speed=float(np.nansum(sp)),
+                    max_speed=float(np.nanmax(sp)) if sp.size else 0.0)
+
+    state = {"band": band, "red": None, "reductions": 0}
+
+    def run(k):
+        done = 0
+        while done < k:
+            m = min(group, k - done)
+            for _ in range(m):
+                tm["time"] += 1000.0 / 60.0
+                u = O.logic_uniforms(n, gheight, tm["time"], 1000.0 / 60.0, view_size=(1, 48 / 27))
+                state["band"] = O.logic_step(u, state["band"], fl, y0=row0)
+            done += m
+            state["red"] = reduce_counters(dist, counters(state["band"]))
+            state["reductions"] += 1
+
+    run(args.warmup)
+    walls = []
+    for _ in range(args.reps):
+        dist.barrier()
+        t0 = time.perf_counter()
+        state["reductions"] = 0
+        run(args.steps)
+        dist.barrier()
+        walls.append(time.perf_counter() - t0)
+    v = torch.tensor(walls, dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    walls = [float(x) for x in v]
+    mid = median(walls)
+    line = {"metric": "particle-steps/sec (dry run: CPU restatement over gloo, plumbing only)", "dry_run": True,
+            "value": n * gheight * args.steps / mid, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": mid / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dry run: %d x %d particles per rank, CPU restatement, gloo" % (n, rows)},
+            "repetitions": repetition_block(walls, args.steps),
+            "rccl": {"world": world, "nranks_seen": state["red"]["particles"] / float(rows * n), "backend": "gloo",
+                     "reductions_per_timed_repetition": state["reductions"]},
+            "counters": state["red"]}
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region (value = the median)")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"])
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json config (default c3: the metric's)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
     ap.add_argument("--no-frame-loop", action="store_true", help="skip the step() + draw() frame-loop leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the config-4 leg (8192 x 8192 row-sharded, strong scaling) of a c3 run")
+    ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check: gloo ranks stepping the CPU restatement")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # PMC child: launches of this length only
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
@@ -219,24 +596,25 @@ def main():
     ap.add_argument("--in-view", action="store_true", help="experiment: keep every particle inside the view (|y*viewSize.y| < 1)")
     ap.add_argument("--flow-only", action="store_true", help="noiseWeight = 0 (preset 'Flow Only') in the timed region")
     args = ap.parse_args()
+    args.reps = max(args.reps, 1)
 
     global FLOW_W, FLOW_H
     if args.flow_size:
         FLOW_W, FLOW_H = (int(v) for v in args.flow_size.lower().split("x"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one (before anything touches the GPU) and relay rank 0's line
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        args.gpus = world
+    args.gpus = world
     if rank != 0:           # one JSON line on the job's stdout: the other ranks' (and their libraries') go nowhere
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     cfg = CONFIGS[args.config]
     state_fmt = args.state or cfg["state"]
-    group = cfg["group"]                      # steps per fused launch and per statistics reduction
-    width, rows, gheight = cfg["width"], cfg["rows"](world), cfg["gheight"](world)
-    particles_rank = width * rows
+    group = cfg["group"]
     launch_len = args.pmc_child or min(group, args.steps)
 
     pmc, pmc_note = {}, "not measured"
@@ -257,110 +635,12 @@ def main():
 
     import tendrils_amd as ta
     from tendrils_amd import _capi
-    from tendrils_amd.sharding import DeviceCounters, reduce_counters, shard_rows
-    from tendrils_amd.tendrils import View
 
-    opts = ta.defaults()
-    opts.update(device=local_rank, mode=ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT,
-                row0=shard_rows(gheight, world, rank)[0], rows=rows, globalHeight=gheight,
-                stateFormat=ta.TH_STATE_F16 if state_fmt == "f16" else ta.TH_STATE_F32)
-    t = ta.Tendrils(View(FLOW_W, FLOW_H), opts)
-    t.resize()                       # viewRes 1920x1080 -> viewSize [1, 1.7778]; flow.shape = viewRes
-    t.setup(width)
-    ctx = t.particles._ctx
-    band = 1024                      # generated and uploaded in row bands (bounded host memory at C5)
-    full = synth_state(rank) if args.config == "c3" else None
-    for r0 in range(0, rows, band):
-        r1 = min(rows, r0 + band)
-        st = full[r0:r1] if full is not None else synth_rows(width, r1 - r0, 12345 + rank * 1000003 + r0)
-        if args.in_view:
-            st = st.copy()
-            st[..., 1] *= np.float32(0.56)
-        _capi.call("th_upload_state", ctx, -1, np.ascontiguousarray(st).ctypes.data_as(_capi._fp), 0, r0, width, r1 - r0)
-    full = st = None
-
-    # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
-    time0 = 1000.0
-    flow_source = "optical-flow(synthetic 1080p frame pair)"
-    of = None
-    try:
-        from tendrils_amd.optical_flow import OpticalFlow
-        f0, f1 = synth_frames()
-        of = OpticalFlow(t, uniforms=dict(speed=0.08, offset=0.1, scaleUV=[-1, -1]))   # src/demo.main.js:526-530
-        of.resize([FLOW_W, FLOW_H])
-        of.set_pixels(f0)
-        of.step()
-        of.set_pixels(f1)
-        of.update(dict(speedLimit=t.state["speedLimit"], time=time0, viewSize=t.viewSize))
-        of.render()
-    except (ImportError, ta.TendrilsHipError):
-        of = None
-        flow_source = "synthetic divergence-free field (optical-flow pass unavailable)"
-        t.flow.set_pixels(synth_flow(time0))
-
-    def sync_all():
-        t.particles.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    t.timer.time = time0
-    counters_dev = C.c_void_p()
-    pending, dev_counters, ext_stream = [], None, None
-    if dist is not None:
-        sp = C.c_void_p()
-        _capi.call("th_stream", ctx, C.byref(sp))
-        ext_stream = torch.cuda.ExternalStream(sp.value)
-
-    def stats_tick():
-        """statistics of buffers[0], reduced over the ranks in place by RCCL on the context's stream"""
-        nonlocal pending, dev_counters
-        if pending:        # the context's stream waits (on the device) for the previous reduction before the
-            with torch.cuda.stream(ext_stream):     # counters are overwritten; the host does not block
-                for w in pending:
-                    w.wait()
-        pending = []
-        _capi.call("th_stats_async", ctx, C.c_float(t.state["speedLimit"]), C.byref(counters_dev))
-        if dist is not None:
-            if dev_counters is None:
-                dev_counters = DeviceCounters(counters_dev.value)
-            with torch.cuda.stream(ext_stream):
-                pending = dev_counters.all_reduce_async(dist)
-
-    def run(k_steps, every=None, refresh=True):
-        # the step loop runs as fused launches (Tendrils.step_n -> th_step_n), `every` steps each; between
-        # launches: statistics (+ their RCCL reduction) and the optical-flow refresh (every full group)
-        every = every or group
-        done = 0
-        while done < k_steps:
-            n = min(every, k_steps - done)
-            t.step_n(n)
-            done += n
-            if n == every:
-                stats_tick()
-                if of is not None and refresh and done % group == 0:      # keep the field alive: re-stamp it from the frame pair (blended)
-                    of.update(dict(speedLimit=t.state["speedLimit"], time=t.timer.time, viewSize=t.viewSize))
-                    of.render()
-
-    def run_kernel_only(k_steps, length):
-        done = 0
-        while done < k_steps:
-            n = min(length, k_steps - done)
-            t.step_n(n)
-            done += n
-
-    def timed_kernels(fn):
-        """mean launch duration (HIP event pair around every integrator launch on the context's stream)"""
-        ms, n = C.c_float(), C.c_int32()
-        _capi.call("th_kernel_timing", ctx, 1)
-        fn()
-        _capi.call("th_kernel_timing_read", ctx, C.byref(ms), C.byref(n))
-        _capi.call("th_kernel_timing", ctx, 0)
-        return ms.value, n.value
-
-    if args.flow_only:
-        t.state["noiseWeight"] = 0
+    job = Job(args, args.config, rank, local_rank, world, dist, launch_len=launch_len)
+    t, ctx = job.t, job.ctx
+    width, rows = job.width, job.rows
+    particles_rank = job.particles_rank
+    sync_all, run, run_kernel_only, timed_kernels = job.sync_all, job.run, job.run_kernel_only, job.timed_kernels
 
     if args.pmc_child:
         # PMC child (under rocprofv3): the launches the parent times, nothing else.  Counters are read per kernel.
@@ -373,35 +653,20 @@ def main():
         t.state["noiseWeight"] = 0
         run_kernel_only(3 * L, L)           # (few: see the flow-only leg of the parent)
         sync_all()
-        t.dispose()
+        job.dispose()
         return
 
     run(args.warmup)
-    # clock pre-roll: the launches of the timed region, untimed, until >= PREROLL_MS have run on the device
-    sync_all()
-    p0 = time.perf_counter()
-    run_kernel_only(launch_len, launch_len)
-    sync_all()
-    est = max(time.perf_counter() - p0, 1e-4)
-    pre_launches = int(min(max(PREROLL_MS * 1e-3 / est, 1), 4096))
-    p0 = time.perf_counter()
-    run_kernel_only(pre_launches * launch_len, launch_len)
-    sync_all()
-    preroll_ms = (time.perf_counter() - p0) * 1e3
+    preroll_ms = job.preroll()
 
-    t0 = time.perf_counter()
-    run(args.steps)
-    sync_all()
-    wall = time.perf_counter() - t0
+    job.reductions = 0
+    walls = job.timed_region(args.steps, args.reps)
+    reductions_per_rep = job.reductions // args.reps
 
     # c4: the same K steps with the counters reduced after EVERY step (BASELINE.md config 4 names both cadences)
-    wall_every_step = None
+    walls_every_step = None
     if args.config == "c4":
-        sync_all()
-        t1 = time.perf_counter()
-        run(args.steps, every=1, refresh=False)
-        sync_all()
-        wall_every_step = time.perf_counter() - t1
+        walls_every_step = job.timed_region(args.steps, max(args.reps // 2, 2), every=1, refresh=False)
 
     # kernel-only pass for the roofline: the same K steps in the same launches as the timed region, a HIP event
     # pair around every launch on the context's own stream
@@ -422,11 +687,7 @@ def main():
     _capi.call("th_set_mode", ctx, ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT)
     sync_all()
 
-    if pending:
-        with torch.cuda.stream(ext_stream):
-            for w in pending:
-                w.wait()
-    stats = t.particles.stats(t.state["speedLimit"])
+    stats = job.global_stats()          # (local pass + the library's all-reduce: every rank holds the job's counters)
 
     # second uniform set of BASELINE.md 3: flow only (noiseWeight = 0), same launches, after everything else
     # (it changes the state: without the wander term velocities decay towards 0/0 = NaN, as in the reference)
@@ -443,14 +704,11 @@ def main():
         t.state["noiseWeight"] = keep
         sync_all()
 
-    if dist is not None:
-        tmax = torch.tensor([wall, k_ms / 1e3, s_ms / 1e3, wall_every_step or 0.0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, kern_s, single_s, wes = (float(v) for v in tmax)
-        wall_every_step = wes if wall_every_step is not None else None
-        stats = reduce_counters(dist, stats, device="cuda")
-    else:
-        kern_s, single_s = k_ms / 1e3, s_ms / 1e3
+    walls = job.max_over_ranks(walls)
+    kern_s, single_s = job.max_over_ranks([k_ms / 1e3, s_ms / 1e3])
+    if walls_every_step is not None:
+        walls_every_step = job.max_over_ranks(walls_every_step)
+    wall = median(walls)
 
     particles = particles_rank * world
     packed = state_fmt == "f16"
@@ -461,56 +719,30 @@ def main():
     fused = steps_per_launch > 1
 
     def rl(launch_s, steps_in_launch, counters):
-        """roofline entries of one kind of launch"""
-        alg = bytes_per_step * particles_rank * steps_in_launch
-        e = {"avg_launch_ms": launch_s * 1e3, "steps_per_launch": steps_in_launch,
-             "ms_per_step": launch_s * 1e3 / steps_in_launch,
-             "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / launch_s / 1e9 / HBM_PEAK_GBS,
-             "algorithmic_bytes_per_launch": alg}
-        tb = pmc_bytes(counters)
-        e["traffic"] = tb
-        if tb is not None:
-            e["hbm_physical"] = {"achieved": tb / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": tb / launch_s / 1e9 / HBM_PEAK_GBS, "bytes_over_algorithmic": tb / alg}
-        if counters and "SQ_INSTS_VALU" in counters:
-            v = counters["SQ_INSTS_VALU"]
-            e["valu"] = {"wave_insts_per_launch": v, "per_wave_step": v / (particles_rank / 64.0 * steps_in_launch),
-                         "achieved": v / launch_s, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": v / launch_s / VALU_PEAK}
-            if "clock_ghz" in counters:      # under the profiler (launches run a few % slower there)
-                e["valu"]["clock_ghz"] = counters["clock_ghz"]
-                e["valu"]["profiled_launch_ms"] = counters.get("profiled_launch_ms")
-                e["valu"]["issue_utilization_at_held_clock"] = counters.get("valu_issue_utilization")
-                e["valu"]["note"] = "peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction; clock_ghz = GRBM_GUI_ACTIVE / 8 / launch " \
-                                    "duration and issue_utilization = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), both per " \
-                                    "dispatch in the PMC child run: the clock the chip held under this load and the share of its issue " \
-                                    "slots the launch used at that clock"
-        if counters and "SQ_LDS_IDX_ACTIVE" in counters and counters["SQ_LDS_IDX_ACTIVE"] > 0:
-            e["lds"] = {"bank_conflict_share": counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]}
-        return e
+        return roofline_entry(job, launch_s, steps_in_launch, counters, bytes_per_step)
 
     main_cls = "fused" if fused else "single"
     if args.flow_only:
         main_cls += "_flow_only"
-    head = rl(kern_s, steps_per_launch, pmc.get(main_cls))
+    head = bind(rl(kern_s, steps_per_launch, pmc.get(main_cls)), fused)
     kernel_name = ("logic_fused_packed_kernel" if packed else "logic_fused_kernel") if fused else \
         ("logic_packed_kernel" if packed else "logic_kernel")
-    roofline = {"bound": "valu" if (fused and not args.flow_only) else "hbm", "kernel": kernel_name, "launches": launches,
+    roofline = {"kernel": kernel_name, "launches": launches,
                 "uniform_set": "flow only (noiseWeight = 0)" if args.flow_only else "default (simplex noise on)",
                 "achieved_is": "algorithmic bytes (SURVEY.md 8d: %d B per particle-step) / mean launch duration - an equivalent "
-                               "single-step bandwidth; the fused launch streams 48/n B per particle-step (hbm_physical) and is "
-                               "bound by VALU issue (valu)" % bytes_per_step,
+                               "single-step bandwidth (equivalent_frac = achieved / peak); the fused launch streams 48/n B per "
+                               "particle-step (hbm_physical); frac = the fraction of the bound named in `bound`" % bytes_per_step,
                 "pmc_note": pmc_note}
     roofline.update(head)
-    single = rl(single_s, 1, pmc.get("single"))
+    single = bind(rl(single_s, 1, pmc.get("single")), False)
     single["kernel"] = "logic_packed_kernel" if packed else "logic_kernel over tile-sorted slots (gathered taps; every 64th launch re-sorts through logic_sorted_kernel)"
-    single["bound"] = "hbm"
     roofline["single_step_kernel"] = single
     roofline["other_mode"] = {"mode": other_mode, "avg_launch_ms": o_ms, "steps_per_launch": launch_len,
-                              "achieved": bytes_per_step * particles_rank * launch_len / max(o_ms, 1e-9) / 1e6}
+                              "achieved": bytes_per_step * particles_rank * launch_len / max(o_ms, 1e-9) / 1e6,
+                              "note": "fast mode is toleranced for ONE step only (DESIGN.md 4): not a headline"}
     if f_n:
-        fo = rl(f_ms / 1e3, launch_len, pmc.get("fused_flow_only" if launch_len > 1 else "single_flow_only"))
+        fo = bind(rl(f_ms / 1e3, launch_len, pmc.get("fused_flow_only" if launch_len > 1 else "single_flow_only")), launch_len > 1)
         fo["uniform_set"] = "flow only (noiseWeight = 0)"
-        fo["bound"] = "hbm"
         fo["single_step_kernel_ms"] = fs_ms
         fo["nan_particles_after"] = flow_only_nan
         roofline["flow_only"] = fo
@@ -524,23 +756,25 @@ def main():
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"],
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",     # arithmetic is fp32 in both storage formats
         "preroll_ms": preroll_ms,
+        "repetitions": repetition_block(walls, args.steps),
         "config": {"workload": (cfg["label"] % storage) + ", flow %dx%d from " % (FLOW_W, FLOW_H)
-                               + flow_source + ", reference default uniforms"
+                               + job.flow_source + ", reference default uniforms"
                                + (" with noiseWeight=0 (flow-only)" if args.flow_only else " (simplex noise on)")
                                + ", 60 Hz fixed timer; step loop as fused launches of <= %d steps, statistics "
-                                 "(+ RCCL reduction) every %d steps" % (launch_len, group),
+                                 "(+ the library's RCCL all-reduce of the counters) after every launch" % launch_len,
                    "mode": args.mode, "state_storage": state_fmt, "particles_per_gpu": particles_rank,
                    "parallelism": "row-band shard x%d, flow replicated" % world},
         "roofline": roofline,
+        "rccl": job.rccl_block(stats, reductions_per_rep),
         "counters": stats,
     }
-    if wall_every_step is not None:
-        line["counters_every_step"] = {"value": particles * args.steps / wall_every_step,
-                                       "ms_per_step": wall_every_step / args.steps * 1e3,
+    if walls_every_step is not None:
+        wes = median(walls_every_step)
+        line["counters_every_step"] = {"value": particles * args.steps / wes, "ms_per_step": wes / args.steps * 1e3,
                                        "note": "same K steps, one launch and one counter reduction per step"}
 
     # (the side legs must not cost the line: whatever goes wrong in them is reported in their place)
-    if world == 1 and args.config == "c3" and not args.no_frame_loop and not args.pmc_child:
+    if world == 1 and args.config == "c3" and not args.no_frame_loop:
         try:
             line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
         except Exception as e:            # noqa: BLE001
@@ -551,7 +785,14 @@ def main():
         except Exception as e:            # noqa: BLE001
             line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %s: %s" % (type(e).__name__, e)}
-    t.dispose()
+    job.dispose()
+    if args.config == "c3" and not args.no_c4 and not args.flow_size:
+        # (every rank takes part; a failure on one rank would hang the others in a collective: the leg runs the same
+        # code path as the headline, so what it can still fail on - memory - fails on every rank alike)
+        try:
+            line["c4"] = c4_leg(args, rank, local_rank, world, dist)
+        except Exception as e:            # noqa: BLE001
+            line["c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

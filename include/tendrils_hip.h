@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 6
+#define TH_ABI_VERSION 7
 
 typedef int32_t th_status;
 enum {
@@ -259,6 +259,31 @@ th_status th_stats(th_context *ctx, float speed_limit, th_counters *out);   /* o
 /* enqueue the reduction only; result lands (as th_counters) at the returned device pointer */
 th_status th_stats_async(th_context *ctx, float speed_limit, void **device_counters);
 th_status th_sync(th_context *ctx);
+
+/* -- one process per GPU (BASELINE.json config 4): row-band shards, the flow texture replicated, and ONE
+ * collective on the integrator's path - the statistics block reduced over the ranks (counts and sum_speed added,
+ * max_speed maximised).  The reference has no counterpart (one WebGL context); this is the RCCL all-reduce over xGMI
+ * the north star names, issued by the library on the context's own stream so that any host - a Node process per GPU
+ * through th_napi.cc, the Python host - needs no transport of its own beyond handing rank 0's id to the other ranks
+ * (a file, a socket, an environment variable: 128 bytes).  librccl is bound at run time (the copy the process already
+ * holds, else the system's; TH_RCCL_LIB names another); a single-GPU host never loads it.
+ *  th_comm_unique_id : rank 0 - a fresh id (ncclGetUniqueId)
+ *  th_comm_init      : every rank, collectively - the context joins the communicator as `rank` of `world`
+ *  th_stats_allreduce: the block th_stats_async filled, reduced in place on the context's stream (no host sync; a
+ *                      context without a communicator is a world of one: nothing to do)
+ *  th_stats_global   : th_stats_async + th_stats_allreduce + download; synchronises */
+#define TH_COMM_ID_BYTES 128
+typedef struct th_comm_info {
+    int32_t active;          /* the context holds a communicator */
+    int32_t rank, world;
+    int32_t rccl_version;    /* ncclGetVersion (0: librccl not loadable) */
+} th_comm_info;
+th_status th_comm_unique_id(void *id_out /* TH_COMM_ID_BYTES */);
+th_status th_comm_init(th_context *ctx, const void *id /* TH_COMM_ID_BYTES */, int32_t rank, int32_t world);
+th_status th_comm_destroy(th_context *ctx);
+th_status th_comm_query(th_context *ctx, th_comm_info *out);
+th_status th_stats_allreduce(th_context *ctx);
+th_status th_stats_global(th_context *ctx, float speed_limit, th_counters *out);
 th_status th_stream(th_context *ctx, void **hip_stream);               /* hipStream_t of the context */
 th_status th_state_device_ptr(th_context *ctx, int32_t buffer, void **dptr);
 /* HIP-event timing on the context's own stream (for bench.py / profilers). */

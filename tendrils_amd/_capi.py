@@ -87,6 +87,12 @@ class SlotOrderInfo(C.Structure):
                 ("sorts", C.c_uint64)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("active", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("rccl_version", C.c_int32)]
+
+
+COMM_ID_BYTES = 128         # TH_COMM_ID_BYTES
+
 _ctx = C.c_void_p
 _fp = C.POINTER(C.c_float)
 
@@ -131,6 +137,12 @@ PROTOTYPES = {
     "th_flow_device_ptr": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
     "th_stats": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),
     "th_stats_async": (C.c_int32, [_ctx, C.c_float, C.POINTER(C.c_void_p)]),
+    "th_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "th_comm_init": (C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32]),
+    "th_comm_destroy": (C.c_int32, [_ctx]),
+    "th_comm_query": (C.c_int32, [_ctx, C.POINTER(CommInfo)]),
+    "th_stats_allreduce": (C.c_int32, [_ctx]),
+    "th_stats_global": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),
     "th_sync": (C.c_int32, [_ctx]),
     "th_stream": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
     "th_state_device_ptr": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -194,7 +206,13 @@ def load():
         # (a profiler's preloaded tool library maps the system runtime before Python starts: not this loader's doing)
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
         paths = _mapped("libamdhip64")
-        if len(paths) > 1 and not profiled:
+        import sys
+        if len(paths) > 1 and not profiled and "torch" not in sys.modules:
+            # (a host that never touches torch shares no streams with it: two copies on disk under different names -
+            # a hashed wheel copy, another ROCm - are this host's own business)
+            import warnings
+            warnings.warn("two copies of the HIP runtime are mapped into this process: %s" % ", ".join(sorted(paths)))
+        elif len(paths) > 1 and not profiled:
             raise OSError("two copies of the HIP runtime are mapped into this process (%s): streams and events cannot be "
                           "shared between them - import torch before anything loads the ROCm runtime, or set "
                           "TH_SKIP_TORCH=1 and keep torch out of the process" % ", ".join(sorted(paths)))

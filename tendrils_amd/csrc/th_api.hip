@@ -124,6 +124,8 @@ struct th_context {
     unsigned int *d_flag = nullptr;
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
+    void *comm = nullptr;                // RCCL communicator of the job's ranks (th_comm_init), one rank per context
+    int32_t comm_rank = 0, comm_world = 1;
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
     uint32_t *dep_count = nullptr, *dep_offset = nullptr, *dep_blocks = nullptr, *dep_total = nullptr;   // per line; scan scratch
     uint4 *dep_record = nullptr;         // per line: the texels of a short line
@@ -570,6 +572,7 @@ th_status th_destroy(th_context *c)
     if (!c) return TH_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)th::comm_destroy(c->comm); c->comm = nullptr; }
     for (float4 *b : c->ring) (void)hipFree(b);
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut_block);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
@@ -1857,6 +1860,64 @@ th_status th_stats(th_context *c, float speed_limit, th_counters *out)
 {
     TH_REQUIRE(out, "null output");
     if (th_status s = th_stats_async(c, speed_limit, nullptr)) return s;
+    TH_HIP(hipMemcpyAsync(out, c->d_counters, sizeof *out, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+// ---- one process per GPU: the communicator of the job's ranks and the path's collective (th_comm.hip) --------------------
+th_status th_comm_unique_id(void *id_out)
+{
+    TH_REQUIRE(id_out, "null output");
+    if (th::comm_unique_id(id_out, TH_COMM_ID_BYTES)) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    return TH_OK;
+}
+
+th_status th_comm_init(th_context *c, const void *id, int32_t rank, int32_t world)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(id, "null communicator id");
+    TH_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank %d outside world %d", rank, world);
+    TH_REQUIRE(!c->comm, "the context already holds a communicator (th_comm_destroy first)");
+    if (th::comm_init(&c->comm, id, TH_COMM_ID_BYTES, rank, world)) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    c->comm_rank = rank; c->comm_world = world;
+    return TH_OK;
+}
+
+th_status th_comm_destroy(th_context *c)
+{
+    if (th_status s = use(c, true)) return s;
+    if (!c->comm) return TH_OK;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    const int bad = th::comm_destroy(c->comm);
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    if (bad) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    return TH_OK;
+}
+
+th_status th_comm_query(th_context *c, th_comm_info *out)
+{
+    TH_REQUIRE(c && out, "null argument");
+    *out = th_comm_info{};
+    out->rank = c->comm_rank; out->world = c->comm_world; out->active = c->comm ? 1 : 0;
+    int v = 0;
+    if (th::comm_available(&v) == 0) out->rccl_version = v;
+    return TH_OK;
+}
+
+th_status th_stats_allreduce(th_context *c)
+{
+    if (th_status s = use(c, true)) return s;
+    if (!c->comm) return TH_OK;                    // a single-rank job: the local block is the global one
+    if (th::comm_allreduce_counters(c->comm, c->d_counters, c->stream)) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    return TH_OK;
+}
+
+th_status th_stats_global(th_context *c, float speed_limit, th_counters *out)
+{
+    TH_REQUIRE(out, "null output");
+    if (th_status s = th_stats_async(c, speed_limit, nullptr)) return s;
+    if (th_status s = th_stats_allreduce(c)) return s;
     TH_HIP(hipMemcpyAsync(out, c->d_counters, sizeof *out, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));
     return TH_OK;

@@ -212,6 +212,16 @@ void launch_bins_scan(const DepositParams &p, uint32_t *totals, hipStream_t stre
 void launch_bins_emit(const DepositParams &p, hipStream_t stream);                    // fragments into their bins
 void launch_bins_blend(const DepositParams &p, uint32_t nblocks, hipStream_t stream);   // per bin: sort by (texel, stream index), blend
 size_t crowd_words_per_bin();
+// RCCL side of a context (th_comm.hip; librccl bound at run time).  Every function returns 0 or leaves comm_error().
+const char *comm_error();
+int comm_available(int *version);
+int comm_unique_id(void *out, size_t bytes);
+int comm_init(void **comm, const void *id_bytes, size_t bytes, int rank, int world);
+int comm_destroy(void *comm);
+int comm_allreduce_counters(void *comm, void *counters_dev, hipStream_t stream);
+int comm_allgather_bytes(void *comm, const void *send, void *recv, const size_t *bytes, const size_t *offset, int rank, int world, hipStream_t stream);
+int comm_alltoallv(void *comm, const void *send, const size_t *send_counts, const size_t *send_off, void *recv, const size_t *recv_counts,
+                   const size_t *recv_off, size_t elem, int world, hipStream_t stream);
 // stable LSD radix sort of (key, u32 value) pairs by key bits [begin_bit, end_bit) (th_sort.hip): the passes ping-pong
 // between the (a) and (b) buffers; returns 0 when the result is in (a), 1 when it is in (b)
 constexpr uint32_t kRadixBits = 8;

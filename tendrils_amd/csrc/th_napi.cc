@@ -536,6 +536,96 @@ napi_value Stats(napi_env env, napi_callback_info info)
     return o;
 }
 
+napi_value counters_object(napi_env env, const th_counters &k)
+{
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    const char *names[] = {"particles", "live", "nan", "capped", "respawned", "sumSpeed", "maxSpeed"};
+    double vals[] = {(double)k.particles, (double)k.live, (double)k.nan, (double)k.capped, (double)k.respawned,
+                     k.sum_speed, k.max_speed};
+    for (int i = 0; i < 7; ++i) {
+        NAPI_OK(napi_create_double(env, vals[i], &v));
+        NAPI_OK(napi_set_named_property(env, o, names[i], v));
+    }
+    return o;
+}
+
+// ---- one Node process per GPU (row-band shards): the communicator of the job's ranks.  Rank 0 makes the id, the host
+// application hands its 128 bytes to the other ranks (a file, a socket, an environment variable), every rank joins ----
+// commUniqueId() -> Uint8Array(128)
+napi_value CommUniqueId(napi_env env, napi_callback_info)
+{
+    napi_value buf, arr;
+    void *data = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, TH_COMM_ID_BYTES, &data, &buf));
+    TH_CALL("th_comm_unique_id", th_comm_unique_id(data));
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, TH_COMM_ID_BYTES, buf, 0, &arr));
+    return arr;
+}
+
+// commInit(ctx, id: Uint8Array(128), rank, world)  (collective: returns when every rank has joined)
+napi_value CommInit(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    size_t n = 0;
+    void *id = a.typed(1, napi_uint8_array, &n);
+    int32_t rank = a.i32(2), world = a.i32(3);
+    if (!a.ok || n != TH_COMM_ID_BYTES) BAD_ARGS("th_comm_init");
+    TH_CALL("th_comm_init", th_comm_init(c, id, rank, world));
+    return undefined(env);
+}
+
+napi_value CommDestroy(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_comm_destroy");
+    TH_CALL("th_comm_destroy", th_comm_destroy(c));
+    return undefined(env);
+}
+
+// commQuery(ctx) -> {active, rank, world, rcclVersion}
+napi_value CommQuery(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_comm_query");
+    th_comm_info q{};
+    TH_CALL("th_comm_query", th_comm_query(c, &q));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    const char *names[] = {"active", "rank", "world", "rcclVersion"};
+    int32_t vals[] = {q.active, q.rank, q.world, q.rccl_version};
+    for (int i = 0; i < 4; ++i) {
+        NAPI_OK(napi_create_int32(env, vals[i], &v));
+        NAPI_OK(napi_set_named_property(env, o, names[i], v));
+    }
+    return o;
+}
+
+// statsAllreduce(ctx): the device block of the last statistics pass reduced over the ranks, on the context's stream
+napi_value StatsAllreduce(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_stats_allreduce");
+    TH_CALL("th_stats_allreduce", th_stats_allreduce(c));
+    return undefined(env);
+}
+
+// statsGlobal(ctx, speedLimit) -> the job's counters (every rank gets the same object)
+napi_value StatsGlobal(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    double limit = a.f64(1);
+    if (!a.ok) BAD_ARGS("th_stats_global");
+    th_counters k{};
+    TH_CALL("th_stats_global", th_stats_global(c, (float)limit, &k));
+    return counters_object(env, k);
+}
+
 // ---- multi-GPU exchange primitives (row-band shards): device addresses travel as BigInt; the transport between the
 // ranks' processes is the host application's (the Python host uses torch.distributed / RCCL, tendrils_amd/sharding.py) ----
 bool bigint_ptr(napi_env env, napi_value v, void **out)        // BigInt | null | undefined -> address
@@ -711,6 +801,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline},
+        {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
+        {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
     };
     for (auto &e : table) {
         napi_value fn;

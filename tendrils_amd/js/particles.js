@@ -187,6 +187,16 @@ class Particles {
   sync() { native.sync(this.handle); }
   stats(speedLimit) { return native.stats(this.handle, speedLimit); }
 
+  // -- one Node process per GPU (row-band shards; build-defined: the reference is one WebGL context) --------------
+  // Rank 0 makes the communicator id (Particles.commUniqueId()), the application hands its 128 bytes to the other
+  // ranks (a file, a socket, an environment variable), every rank joins with commInit(id, rank, world); from then on
+  // statsGlobal() is the job's counter block - the library's RCCL all-reduce on the context's stream.
+  static commUniqueId() { return native.commUniqueId(); }
+  commInit(id, rank, world) { native.commInit(this.handle, id, rank | 0, world | 0); return this; }
+  commDestroy() { native.commDestroy(this.handle); return this; }
+  commQuery() { return native.commQuery(this.handle); }
+  statsGlobal(speedLimit) { return native.statsGlobal(this.handle, speedLimit); }
+
   dispose() {
     if (this.handle) { native.destroy(this.handle); this.handle = null; }
   }

@@ -38,25 +38,52 @@ def reduce_counters(dist, counters, device=None):
     return out
 
 
+def share_comm_id(dist, make_id):
+    """The 128-byte communicator id of the job: rank 0 makes it (`make_id()` -> bytes: th_comm_unique_id), every other
+    rank receives it through `dist` - any torch.distributed backend will do (gloo in the CPU tests, nccl on the GPUs):
+    the id is the only thing the library asks the host to carry between the ranks."""
+    box = [bytes(make_id()) if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def comm_id():
+    """th_comm_unique_id -> bytes (a fresh id; meant for rank 0)"""
+    from . import _capi
+    buf = (C.c_ubyte * _capi.COMM_ID_BYTES)()
+    _capi.call("th_comm_unique_id", buf)
+    return bytes(buf)
+
+
+def comm_init(ctx, dist):
+    """Every rank, collectively: the context joins the job's RCCL communicator (th_comm_init), the id travelling from
+    rank 0 through `dist`.  From then on the path's collective - the counter all-reduce - is the library's own
+    (th_stats_allreduce on the context's stream), whatever the host is."""
+    from . import _capi
+    ident = share_comm_id(dist, comm_id)
+    buf = (C.c_ubyte * _capi.COMM_ID_BYTES).from_buffer_copy(ident)
+    _capi.call("th_comm_init", ctx, buf, int(dist.get_rank()), int(dist.get_world_size()))
+
+
+def comm_query(ctx):
+    from . import _capi
+    q = _capi.CommInfo()
+    _capi.call("th_comm_query", ctx, C.byref(q))
+    return {"active": bool(q.active), "rank": q.rank, "world": q.world, "rccl_version": q.rccl_version}
+
+
 class DeviceCounters:
-    """Zero-copy torch views of the context's device-side th_counters block (5 x u64, 2 x f64)
-    so that RCCL can reduce it in place on the context's own stream."""
+    """The context's device-side th_counters block reduced over the ranks in place, on the context's own stream: a thin
+    caller of th_stats_allreduce (the library's RCCL all-reduce; round 2 reduced torch views of the block through
+    torch.distributed)."""
 
-    def __init__(self, dptr):
-        import torch
+    def __init__(self, ctx):
+        self.ctx = ctx
 
-        class _Span:
-            def __init__(self, ptr, n, typestr):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
-                                                 "version": 3, "strides": None}
-        self.counts = torch.as_tensor(_Span(dptr, 5, "<i8"), device="cuda")
-        self.sum_speed = torch.as_tensor(_Span(dptr + 40, 1, "<f8"), device="cuda")
-        self.max_speed = torch.as_tensor(_Span(dptr + 48, 1, "<f8"), device="cuda")
-
-    def all_reduce_async(self, dist):
-        return [dist.all_reduce(self.counts, op=dist.ReduceOp.SUM, async_op=True),
-                dist.all_reduce(self.sum_speed, op=dist.ReduceOp.SUM, async_op=True),
-                dist.all_reduce(self.max_speed, op=dist.ReduceOp.MAX, async_op=True)]
+    def all_reduce_async(self):
+        """enqueue the reduction behind the statistics pass; nothing to wait for on the host (stream order)"""
+        from . import _capi
+        _capi.call("th_stats_allreduce", self.ctx)
 
 
 # ---- flow deposit across row-band shards ------------------------------------------------------------------

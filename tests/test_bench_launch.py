@@ -1,0 +1,55 @@
+"""bench.py's own launcher and rank plumbing on CPU: `--gpus 2` with no launcher around it must start two ranks itself,
+run the timed-region protocol with a collective inside every repetition, and hand back ONE JSON line.  `--dry-run` steps a
+small band per rank with the CPU restatement over gloo (no GPU here); the GPU run shares everything but the stepping."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_self_launch_two_ranks_dry_run(oracle):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "6", "--warmup", "2",
+                        "--reps", "3"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # rank 0's line, relayed by the parent, and nothing else
+    line = json.loads(lines[0])
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2
+    assert line["rccl"]["world"] == 2 and line["rccl"]["nranks_seen"] == 2.0
+    assert line["rccl"]["reductions_per_timed_repetition"] == 2          # 6 steps in launches of 4: one full, one partial
+    assert line["repetitions"]["n"] == 3 and line["repetitions"]["min"] <= line["ms_per_step"] <= line["repetitions"]["max"]
+    assert line["counters"]["particles"] == 2 * 48 * 48
+    assert line["value"] > 0 and line["unit"] == "particle-steps/s"
+
+
+def test_child_failure_is_the_parents_status():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--config", "nope"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip()
+
+
+def test_roofline_fraction_names_its_bound():
+    """`frac` is the fraction of the bound the entry names and never the equivalent bandwidth of a fused launch."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class J:
+        particles_rank = 1 << 24
+    # fused flow-only launch: equivalent bandwidth 2.2 x the peak; counters say VALU 0.34, physical HBM 0.19
+    c = {"FETCH_SIZE": 300e3, "WRITE_SIZE": 200e3, "SQ_INSTS_VALU": 2.55e8}
+    e = bench.bind(bench.roofline_entry(J, 0.61e-3, 20, c, 32), True)
+    assert e["equivalent_frac"] > 1 and e["bound"] == "valu" and 0 < e["frac"] < 1 and e["frac"] == e["valu"]["frac"]
+    # the same launch when its bytes dominate
+    c = {"FETCH_SIZE": 1.2e6, "WRITE_SIZE": 1.0e6, "SQ_INSTS_VALU": 1e7}
+    e = bench.bind(bench.roofline_entry(J, 0.61e-3, 20, c, 32), True)
+    assert e["bound"] == "hbm" and e["frac"] == e["hbm_physical"]["frac"] < 1
+    # no counters: unknown, not a number above 1
+    e = bench.bind(bench.roofline_entry(J, 0.61e-3, 20, None, 32), True)
+    assert e["frac"] is None and e["equivalent_frac"] > 1
+    # one step per launch streams its algorithmic bytes
+    e = bench.bind(bench.roofline_entry(J, 0.134e-3, 1, None, 32), False)
+    assert e["bound"] == "hbm" and e["frac"] == e["equivalent_frac"] < 1

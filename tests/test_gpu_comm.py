@@ -1,0 +1,87 @@
+"""The library's own RCCL side (th_comm.hip) on one GPU: a world of one rank through ctypes and through the Node host -
+id, collective init, the counter all-reduce on the context's stream, teardown.  (World sizes above one need more than one
+GPU: bench.py --gpus N runs them; the id exchange between ranks is covered on CPU in tests/test_sharding_gloo.py.)"""
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make(n=128):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    t = ta.Tendrils(View(96, 54))
+    t.resize()
+    t.setup(n)
+    rng = np.random.default_rng(3)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.02, .02, (n, n, 2))
+    st[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    t.particles.upload_texels(st)
+    return t
+
+
+def test_world_of_one_through_the_c_abi():
+    from tendrils_amd import _capi
+    from tendrils_amd.sharding import comm_id, comm_query
+    t = make()
+    ctx = t.particles._ctx
+    assert comm_query(ctx)["active"] is False
+    local = t.particles.stats(0.01)
+    # without a communicator the global block is the local one
+    g = _capi.Counters()
+    _capi.call("th_stats_global", ctx, C.c_float(0.01), C.byref(g))
+    assert {k: getattr(g, k) for k, _ in _capi.Counters._fields_} == local
+    ident = comm_id()
+    buf = (C.c_ubyte * _capi.COMM_ID_BYTES).from_buffer_copy(ident)
+    _capi.call("th_comm_init", ctx, buf, 0, 1)
+    q = comm_query(ctx)
+    assert q["active"] and q["rank"] == 0 and q["world"] == 1 and q["rccl_version"] > 0
+    with pytest.raises(_capi.TendrilsHipError):           # one communicator per context
+        _capi.call("th_comm_init", ctx, buf, 0, 1)
+    for _ in range(3):                                     # the reduction rides the context's stream behind the pass
+        t.timer.tick()
+        t.step()
+        _capi.call("th_stats_async", ctx, C.c_float(0.01), None)
+        _capi.call("th_stats_allreduce", ctx)
+    _capi.call("th_stats_global", ctx, C.c_float(0.01), C.byref(g))
+    assert {k: getattr(g, k) for k, _ in _capi.Counters._fields_} == t.particles.stats(0.01)
+    _capi.call("th_comm_destroy", ctx)
+    assert comm_query(ctx)["active"] is False
+    with pytest.raises(_capi.TendrilsHipError):
+        _capi.call("th_comm_init", ctx, buf, 1, 1)          # rank outside the world
+    t.dispose()
+
+
+def test_world_of_one_from_the_node_host():
+    node = shutil.which("node")
+    if node is None or not os.path.exists(os.path.join(ROOT, "tendrils_amd", "lib", "tendrils_hip.node")):
+        pytest.skip("no Node host here")
+    script = """
+const { Particles } = require('./tendrils_amd/js/particles');
+const p = new Particles(null, { shape: [64, 64] });
+p.setup(2);
+p.spawn((d) => { d[0] = 0.25; d[1] = -0.5; d[2] = 0.003; d[3] = 0.004; });
+const id = Particles.commUniqueId();
+const before = p.commQuery();
+p.commInit(id, 0, 1);
+const q = p.commQuery();
+const g = p.statsGlobal(0.01), l = p.stats(0.01);
+p.commDestroy();
+console.log(JSON.stringify({ idBytes: id.length, before, q, g, l, after: p.commQuery() }));
+p.dispose();
+"""
+    r = subprocess.run([node, "-e", script], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["idBytes"] == 128 and out["before"]["active"] == 0 and out["after"]["active"] == 0
+    assert out["q"]["active"] == 1 and out["q"]["world"] == 1 and out["q"]["rcclVersion"] > 0
+    assert out["g"] == out["l"] and out["g"]["live"] == 64 * 64 and abs(out["g"]["sumSpeed"] - 64 * 64 * 0.005) < 1e-3

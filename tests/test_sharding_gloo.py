@@ -127,3 +127,30 @@ def test_fragment_exchange_by_texel_owner(tmp_path):
     sent = np.concatenate([np.load(tmp_path / ("sent_%d.npy" % r)) for r in range(world)])
     recv = np.concatenate([np.load(tmp_path / ("recv_%d.npy" % r)) for r in range(world)])
     assert np.array_equal(np.sort(sent), np.sort(recv))                  # nothing lost, nothing duplicated
+
+
+def _id_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tendrils_amd.sharding import comm_id, share_comm_id
+    made = []
+
+    def make():
+        made.append(1)
+        return comm_id()              # th_comm_unique_id (ncclGetUniqueId needs no GPU)
+    ident = share_comm_id(dist, make)
+    assert len(made) == (1 if rank == 0 else 0)          # only rank 0 makes an id
+    with open(os.path.join(out_dir, "id_%d.bin" % rank), "wb") as f:
+        f.write(ident)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_communicator_id_travels_from_rank_0(tmp_path):
+    """The only thing the library asks the host to carry between the ranks: rank 0's 128-byte id (th_comm_unique_id),
+    handed to every rank before the collective th_comm_init."""
+    world = 2
+    mp.spawn(_id_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ids = [open(tmp_path / ("id_%d.bin" % r), "rb").read() for r in range(world)]
+    assert len(ids[0]) == 128 and ids[0] == ids[1] and any(ids[0])
