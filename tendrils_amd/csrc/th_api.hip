@@ -136,12 +136,18 @@ struct th_context {
     // and the view pass of one draw() rasterise the same lines at the same resolution
     struct { bool valid = false, binned = false; float view_x = 0, view_y = 0; uint32_t total = 0, nlarge = 0, nblocks = 0; bool sorted_in_a = false; } drawn;
     uint32_t dep_list_cap = 0;
-    // binned pipeline (th_bins.hip): fragments per bin | first fragment of every bin (+ 1) | fill cursors
-    uint32_t *bin_mem = nullptr;         // ... | the large bins | first block of each (+ 1)
+    // binned pipeline (th_bins.hip): the bins' cursors | the large bins | first block of each (+ 1) | first regrouped key of each (+ 1)
+    uint32_t *bin_mem = nullptr;
     uint32_t bin_capacity = 0;
-    uint32_t *crowd_mem = nullptr;       // per large bin: fragments per texel, first fragment of every texel, fill cursors
-    uint32_t *block_flags = nullptr;     // per 256-slot block: some line has fragments
+    uint32_t *chunk_table = nullptr;     // per list x kBinMaxPages: the pages a list has grown by
+    unsigned long long *bins_keys = nullptr;   // the page store: (bins x kBinReplicas + bins_pool) pages of kBinPage places - keys (~0 = empty) ...
+    float4 *bins_colors = nullptr;       // ... and varyings (two per place once a th_draw has run)
+    uint32_t bins_pool = 0, bins_store_bins = 0;
+    bool bins_pairs = false;
+    uint32_t *crowd_mem = nullptr;       // per large bin: fragments per texel, first fragment of every texel, fill cursors, long runs
     uint32_t crowd_capacity = 0;
+    unsigned long long *crowd_keys = nullptr;  // the large bins' fragments regrouped by texel
+    size_t crowd_keys_cap = 0;
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
@@ -578,7 +584,8 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
-    (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->block_flags);
+    (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -1378,6 +1385,8 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     TH_HIP(hipMemsetAsync(c->dep_total, 0, 8 * sizeof(uint32_t), c->stream));
     if (th_status s = line_rows(c)) return s;
     p.row_draws = c->d_row_draws;
+    static const uint32_t exp_flags = [] { const char *e = getenv("TH_EXP"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
+    p.exp = exp_flags;
     if (use_bins) {
         const int o = order_of(c, c->ring[0]);
         p.perm = o >= 0 ? c->orders[(size_t)o].perm : nullptr;
@@ -1386,20 +1395,19 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
         if (c->bin_capacity < p.nbins) {
             TH_HIP(hipStreamSynchronize(c->stream));
             (void)hipFree(c->bin_mem); c->bin_mem = nullptr; c->bin_capacity = 0;
-            (void)hipFree(c->block_flags); c->block_flags = nullptr;
-            const size_t stride = ((size_t)p.nbins + 255) / 256 * 256 + 64;
-            TH_HIP(hipMalloc((void **)&c->bin_mem, (4 * (size_t)p.nbins + 2 + 2 * th::kBinReplicas * stride) * sizeof(uint32_t)));
-            TH_HIP(hipMalloc((void **)&c->block_flags, ((c->texels() + 255) / 256 + 1) * sizeof(uint32_t)));
+            (void)hipFree(c->chunk_table); c->chunk_table = nullptr;
+            const size_t stride = ((size_t)p.nbins + 255) / 256 * 256 + 64;      // (the lists' cursors of one bin on different memory channels)
+            TH_HIP(hipMalloc((void **)&c->bin_mem, (th::kBinReplicas * stride + 2 * (size_t)p.nbins + 2) * sizeof(uint32_t)));
+            const size_t table = (size_t)p.nbins * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t);
+            TH_HIP(hipMalloc((void **)&c->chunk_table, table));
+            TH_HIP(hipMemsetAsync(c->chunk_table, 0, table, c->stream));        // (every reader of a list leaves its entries empty)
             c->bin_capacity = p.nbins;
-            c->drawn.valid = false;
         }
         p.bin_stride = (uint32_t)(((size_t)c->bin_capacity + 255) / 256 * 256 + 64);
-        p.bin_hist = c->bin_mem; p.bin_start = c->bin_mem + c->bin_capacity;
-        p.large_bins = p.bin_start + c->bin_capacity + 1; p.large_block0 = p.large_bins + c->bin_capacity;
-        p.rep_hist = p.large_block0 + c->bin_capacity + 1; p.rep_cursor = p.rep_hist + (size_t)th::kBinReplicas * p.bin_stride;
-        p.block_flags = c->block_flags;
-        p.id_bits = 1;
-        while (p.id_bits < 32u && (1ull << p.id_bits) < (uint64_t)p.W * p.H) ++p.id_bits;
+        p.bin_cursor = c->bin_mem; p.large_bins = c->bin_mem + (size_t)th::kBinReplicas * p.bin_stride;
+        p.large_key0 = p.large_bins + c->bin_capacity;
+        p.page_table = c->chunk_table;
+        p.totals = c->dep_total;
     }
     return TH_OK;
 }
@@ -1528,46 +1536,71 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
     return TH_OK;
 }
 
-// the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + count per bin, scan, emit, per-bin order + blend
+// the chunk store of the binned pipeline: nbins + pool chunks of keys (all empty) and varyings
+static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool pairs)
+{
+    if (c->bins_keys && c->bins_store_bins == nbins && c->bins_pool >= pool && (c->bins_pairs || !pairs)) return TH_OK;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors);
+    c->bins_keys = nullptr; c->bins_colors = nullptr;
+    pool = pool > c->bins_pool ? pool : c->bins_pool;
+    pairs = pairs || c->bins_pairs;
+    c->bins_pool = 0; c->bins_store_bins = 0;
+    const size_t places = ((size_t)nbins * th::kBinReplicas + pool) * th::kBinPage;
+    TH_REQUIRE(places < ((size_t)1 << 32), "the binned draw's chunk store would hold 2^32 places or more");
+    TH_HIP(hipMalloc((void **)&c->bins_keys, places * sizeof(unsigned long long)));
+    TH_HIP(hipMalloc((void **)&c->bins_colors, places * (pairs ? 2 : 1) * sizeof(float4)));
+    TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, places * sizeof(unsigned long long), c->stream));
+    c->bins_pool = pool; c->bins_store_bins = nbins; c->bins_pairs = pairs;
+    return TH_OK;
+}
+
+constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
+
+// the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + emit into the bins, plan, per-bin order + blend
 static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
 {
-    // the view pass right after the flow pass of the same state and view (th_view_draw after th_flow_deposit): the lines'
-    // records, counts and the bins' ranges still stand; only the varyings differ
-    static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
-    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
-    uint32_t total = 0, nlarge = 0, nblocks = 0;
-    if (reuse) {
-        total = c->drawn.total; nlarge = c->drawn.nlarge; nblocks = c->drawn.nblocks;       // (launch_bins_emit resets the fill cursors)
-    } else {
-        c->drawn.valid = false;
-        th::launch_bins_raster(p, c->stream);
-        th::launch_bins_scan(p, c->dep_total, c->stream);
-        uint32_t host[5] = {0, 0, 0, 0, 0};
+    c->drawn.valid = false;
+    uint32_t host[th::kTotWords];
+    for (int attempt = 0;; ++attempt) {
+        const uint32_t pool = c->bins_pool ? c->bins_pool : (p.nbins * 8u > 16384u ? p.nbins * 8u : 16384u);
+        if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
+        p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
+        if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
+        th::launch_bins_fused(p, c->stream);
         TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
         TH_HIP(hipStreamSynchronize(c->stream));
-        if (host[0] >= (1u << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one draw (2^31 or more)");
-        if (host[2] >= th::kBinsMaxPerBin) return fail(TH_ERR_UNSUPPORTED, "%u fragments in one 16 x 16-texel bin of the target (limit %u)", host[2], th::kBinsMaxPerBin);
-        total = host[0]; nlarge = host[3]; nblocks = host[4];
+        const uint32_t flags = host[th::kTotFlags];
+        if (flags == 0) break;
+        // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
+        // outgrew its chunk table or a line its reservation, left to the stream-ordered pipeline
+        TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
+        TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t), c->stream));
+        if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) return kRetryInStreamOrder;
+        const uint32_t want = host[th::kTotPool] + host[th::kTotPool] / 4 + 64;
+        if (th_status s = bins_store(c, p.nbins, want, p.mode == 2)) return s;
     }
+    const uint32_t total = host[th::kTotFragments], nlarge = host[th::kTotLarge];
     if (fragments) *fragments = total;
-    if (total == 0) return TH_OK;
-    if (!reuse) if (th_status s = deposit_reserve(c, total, true, p.mode == 2)) return s;
+    if (host[th::kTotCrowdKeys] == 0xffffffffu) return fail(TH_ERR_UNSUPPORTED, "too many fragments in crowded bins for one draw (2^32 or more places)");
     if (c->crowd_capacity < nlarge) {
-        TH_HIP(hipStreamSynchronize(c->stream));
         (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
         const uint32_t cap = nlarge + nlarge / 2 + 64;
         TH_HIP(hipMalloc((void **)&c->crowd_mem, (size_t)cap * th::crowd_words_per_bin() * sizeof(uint32_t)));
         c->crowd_capacity = cap;
     }
-    p.frag_keys = c->dep_u64[0]; p.colors = c->dep_colors;
+    if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
+        (void)hipFree(c->crowd_keys); c->crowd_keys = nullptr; c->crowd_keys_cap = 0;
+        const size_t cap = (size_t)host[th::kTotCrowdKeys] + host[th::kTotCrowdKeys] / 4 + 4096;
+        TH_HIP(hipMalloc((void **)&c->crowd_keys, cap * sizeof(unsigned long long)));
+        c->crowd_keys_cap = cap;
+    }
     p.nlarge = nlarge;
     p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
-    p.crowd_keys = c->dep_u64[1];
-    th::launch_bins_emit(p, c->stream);
-    th::launch_bins_blend(p, nblocks, c->stream);
+    p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257;
+    p.crowd_keys = c->crowd_keys;
+    th::launch_bins_blend(p, c->stream);           // (every list's cursor counts: empty places are skipped as they are met)
     TH_HIP(hipGetLastError());
-    c->drawn.valid = true; c->drawn.binned = true; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total;
-    c->drawn.nlarge = nlarge; c->drawn.nblocks = nblocks;
     return TH_OK;
 }
 
@@ -1576,10 +1609,14 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     if (th_status s = use(c)) return s;
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
-    th::DepositParams p;
-    bool bins = false;
-    if (th_status s = deposit_prepare(c, u, p, true, &bins)) return s;
-    return bins ? deposit_run_bins(c, p, fragments) : deposit_run(c, p, fragments);
+    for (int pass = 0;; ++pass) {            // (a binned pass that gives up before blending is repeated in stream order)
+        th::DepositParams p;
+        bool bins = false;
+        if (th_status s = deposit_prepare(c, u, p, pass == 0, &bins)) return s;
+        if (!bins) return deposit_run(c, p, fragments);
+        const th_status s = deposit_run_bins(c, p, fragments);
+        if (s != kRetryInStreamOrder) return s;
+    }
 }
 
 // ---- view pass ---------------------------------------------------------------------------------------------
@@ -1628,13 +1665,17 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
                memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
                "the two passes of one draw share viewSize, time and speedLimit");
     if (th_status s = view_storage(c)) return s;
-    th::DepositParams p;
-    bool bins = false;
-    if (th_status s = deposit_prepare(c, du, p, true, &bins)) return s;
-    p.mode = 2;
-    view_fields(c, ru, p);
-    p.view = c->view;
-    return bins ? deposit_run_bins(c, p, fragments) : deposit_run(c, p, fragments);
+    for (int pass = 0;; ++pass) {
+        th::DepositParams p;
+        bool bins = false;
+        if (th_status s = deposit_prepare(c, du, p, pass == 0, &bins)) return s;
+        p.mode = 2;
+        view_fields(c, ru, p);
+        p.view = c->view;
+        if (!bins) return deposit_run(c, p, fragments);
+        const th_status s = deposit_run_bins(c, p, fragments);
+        if (s != kRetryInStreamOrder) return s;
+    }
 }
 
 th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)
@@ -1643,11 +1684,15 @@ th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fra
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "the view pass needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
     if (th_status s = view_storage(c)) return s;
-    th::DepositParams p;
-    bool bins = false;
-    if (th_status s = view_params(c, u, p, true, &bins)) return s;
-    p.view = c->view;
-    return bins ? deposit_run_bins(c, p, fragments) : deposit_run(c, p, fragments);
+    for (int pass = 0;; ++pass) {
+        th::DepositParams p;
+        bool bins = false;
+        if (th_status s = view_params(c, u, p, pass == 0, &bins)) return s;
+        p.view = c->view;
+        if (!bins) return deposit_run(c, p, fragments);
+        const th_status s = deposit_run_bins(c, p, fragments);
+        if (s != kRetryInStreamOrder) return s;
+    }
 }
 
 th_status th_view_fill(th_context *c, const float rgba[4])

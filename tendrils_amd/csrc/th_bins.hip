@@ -6,19 +6,27 @@
 // Same lines, same rasteriser, same varyings, same blend arithmetic as th_deposit.hip (th_raster.hpp); what differs is how
 // GL's primitive order is reconstructed.  The stream-ordered pipeline produces the fragments in stream order and sorts
 // them stably by texel with three global radix passes + a gather.  Here the order is restored where the fragments
-// meet - inside one 16 x 16-texel bin of the target, in LDS:
-//   1. bins_raster_kernel: one thread per SLOT (coalesced state reads whatever the order): rasterise once, keep the
-//      covered texels of a line of <= 8 fragments in its record, count the fragments of every bin (per workgroup in an
-//      LDS table, one global atomic per workgroup and bin)
-//   2. bins_scan_kernel: exclusive scan over the bins -> every bin's range of the fragment array
-//   3. bins_emit_kernel: per slot, the varyings at the recorded texels; a workgroup reserves its share of every bin it
-//      meets with one atomic and writes (texel, stream index) keys + varyings there - in whatever order: the
-//      arrival order inside a bin is not defined
-//   4. bins_blend_kernel: one workgroup per bin: its fragments grouped by texel (LDS counting sort), every texel's
-//      run ordered by the stream index of its line (short runs: rank by counting; long ones: bitonic sort) and blended
-//      in that order by the texel's thread - dst = src*a + dst*(1-a), fragment after fragment, GL's order and arithmetic.
-//      Bins of more than kBinCap fragments go through LDS in groups of texels; a single texel of more than kBinCap
-//      fragments in windows of its stream indices.
+// meet - inside one 16 x 16-texel bin of the target, in LDS - and a line is touched ONCE:
+//   1. bins_fused_kernel: one thread per SLOT (coalesced state reads whatever the order): the line is rasterised and
+//      every covered texel's fragment - (texel, stream index) key + varying(s) - goes straight into the bin it falls
+//      into.  No counting pass: a bin is kBinReplicas LISTS of PAGES of kBinPage places (page 0 of list r of bin b is
+//      page b * kBinReplicas + r - a bin's first pages lie side by side - further pages come from a pool as a list
+//      grows); a line reserves an upper bound of its fragments per bin - from the bounding box of its snapped hexagon,
+//      before it is rasterised - the reservations of a workgroup's lines are added up in an LDS table, ONE global atomic
+//      per (workgroup, bin) moves the cursor of the list the workgroup uses (a crowded bin is met by thousands of
+//      workgroups, and device-wide atomics on one cache line are served one after the other at the memory side - a
+//      thousand of them set the time of a whole pass - hence the lists, their cursors kept bin_stride words apart), and the
+//      workgroup whose reservation crosses into a new page takes that page from the pool and publishes it.  Places
+//      reserved and not used stay empty (key ~0: every reader of a key leaves ~0 behind, so the store starts every
+//      pass empty).
+//      bins_slow_kernel: the few lines that cross the view's edge or a third bin, one place at a time.
+//   2. bins_plan_kernel / crowd_plan_kernel: the bins of more than kBinCap places ("large").
+//   3. bins_blend_kernel: one workgroup per bin of up to kBinCap places: its fragments grouped by texel (LDS counting sort), every
+//      texel's run ordered by the stream index of its line (short runs: rank by counting; long ones: bitonic sort) and
+//      blended in that order by the texel's thread - dst = src*a + dst*(1-a), fragment after fragment, GL's order and
+//      arithmetic.
+//      crowd_*_kernel: the large bins get one more level of the same scheme (regrouped by texel, then a wave or a
+//      workgroup per texel).
 // The stream index of a line is a pure function of its particle id, so the result is the stream-ordered pipeline's, and
 // the restatement's, bit for bit, whatever the slot order and whatever the atomics did.
 #include "th_kernels.hpp"
@@ -28,74 +36,77 @@ namespace th {
 namespace {
 
 constexpr uint32_t kBinSide = 1u << kBinShift, kBinTexels = kBinSide * kBinSide;      // 256 texels = one per thread
-constexpr uint32_t kBinCap = 4096;           // fragments ordered in LDS at a time
+constexpr uint32_t kPageShift = 8;
+static_assert(kBinPage == 1u << kPageShift && kBinPage * kBinReplicas == kBinCap, "page size");
 constexpr uint32_t kRankMaxRun = 256;        // runs up to this length are ordered by counting, longer ones by the bitonic network
 constexpr uint32_t kOwnRun = 64;             // runs up to this length are blended by their texel's thread alone
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr uint32_t kNoPlace = 0xffffffffu;
 
 TH_D uint32_t bin_of(const DepositParams &p, uint32_t x, uint32_t y) { return (y >> kBinShift) * p.bins_x + (x >> kBinShift); }
+TH_D void bins_flag(const DepositParams &p, uint32_t what) { atomicOr(&p.totals[kTotFlags], what); }
 
-// ---- wave-wide bin arithmetic -------------------------------------------------------------------------------------
-// In the tile-sorted order the lines of a wave fall into the same few bins.  The lanes of every distinct bin are found with
-// one ballot round per bin, their fragments counted and numbered with ballots and population counts alone - no LDS, no
-// barrier - and the leader lane of the bin goes to the global counter once for all of them.
-constexpr uint32_t kNoBin = 0xffffffffu;
-
-// The bins' global counters are kept in kBinReplicas copies p.bin_stride words apart, and a slot always uses the copy of
-// its 64-slot group: a crowded bin is met by thousands of waves, and device-wide atomics on ONE word are served one after
-// the other at the memory side (every XCD has its own L2) - a thousand of them set the time of a whole pass.  The scan
-// (bins_replica_kernel) lays the copies of a bin out one after the other inside the bin's range.
-TH_D uint32_t *rep_word(uint32_t *base, const DepositParams &p, uint32_t slot, uint32_t bin)
+// ---- pages ---------------------------------------------------------------------------------------------------------------
+// Place `v` (a virtual index handed out by the list's cursor) of list `list` = bin * kBinReplicas + r -> position in the
+// key / varying arrays.  The page a place lies in was taken from the pool by whoever's reservation contained the page's
+// FIRST place - a thread that had moved the cursor before this one and publishes the page right after, without waiting for
+// anybody: the wait below always ends.
+// (WAIT: inside the pass that hands the pages out - a relaxed device-scope load per try: only the entry's own value is
+// needed, nothing else is published with it, and an acquire would empty the caches at every fragment; readers of later
+// launches load plainly)
+template <bool WAIT>
+TH_D uint32_t page_of(const DepositParams &p, uint32_t list, uint32_t pn)
 {
-    return base + (size_t)((slot >> 6) & (kBinReplicas - 1u)) * p.bin_stride + bin;
+    if (pn == 0u) return list;
+    if (pn >= kBinMaxPages) return kNoPlace;
+    uint32_t *slot = &p.page_table[(size_t)list * kBinMaxPages + pn];
+    if constexpr (!WAIT) return *slot;
+    uint32_t id = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (id == 0u) {
+        __builtin_amdgcn_s_sleep(2);
+        id = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return id;                                      // (kNoPlace: the pool was exhausted - flagged by the allocator)
 }
-
-// raster: the lanes' `c` fragments (<= kRecordTexels each) of `bin` (kNoBin: none) added to the bins' counts
-TH_D void wave_bin_count(const DepositParams &p, uint32_t s, uint32_t bin, uint32_t c)
+template <bool WAIT = false>
+TH_D uint32_t place_of(const DepositParams &p, uint32_t list, uint32_t v)
 {
-    const uint32_t lane = __lane_id();
-    unsigned long long todo = __ballot(bin != kNoBin);
-    while (todo != 0ull) {
-        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-        const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)leader);
-        const bool mine = bin == lb;
-        uint32_t total = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kRecordTexels; ++j) total += (uint32_t)__builtin_popcountll(__ballot(mine && c > j));
-        if (lane == leader) atomicAdd(rep_word(p.rep_hist, p, s, lb), total);
-        todo &= ~__ballot(mine);
+    const uint32_t id = page_of<WAIT>(p, list, v >> kPageShift);
+    return id == kNoPlace ? kNoPlace : (id << kPageShift) | (v & (kBinPage - 1u));
+}
+// the pages that start inside the reservation [base, base + n) of `list` (n >= 1): taken from the pool and published
+TH_D void pages_open(const DepositParams &p, uint32_t list, uint32_t base, uint32_t n)
+{
+    uint32_t pn = (base + kBinPage - 1u) >> kPageShift;
+    if (pn == 0u) pn = 1u;
+    const uint32_t last = (base + n - 1u) >> kPageShift;
+    for (; pn <= last; ++pn) {
+        if (pn >= kBinMaxPages) { bins_flag(p, kBinsBinFull); break; }
+        const uint32_t k = atomicAdd(&p.totals[kTotPool], 1u);
+        uint32_t id = p.nbins * kBinReplicas + k;
+        if (k >= p.pool_pages) { id = kNoPlace; bins_flag(p, kBinsPoolExhausted); }
+        __hip_atomic_store(&p.page_table[(size_t)list * kBinMaxPages + pn], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-
-// emit: slot[j] = place in the bin's range of the lane's j-th fragment of `bin` (j < c).  The wave's fragments of one bin
-// form ONE contiguous run, numbered j-major: the j-th fragments of all lanes follow each other, so a store of "fragment j"
-// writes consecutive places (the arrival order inside a bin is free).  One atomic per bin, all bins' atomics in flight together.
-TH_D void wave_bin_slots(const DepositParams &p, uint32_t s, uint32_t bin, uint32_t c, uint32_t (&slot)[kRecordTexels])
+// a reader is done with list `list` of `n` places: its table entries are left empty for the next pass
+TH_D void pages_forget(const DepositParams &p, uint32_t list, uint32_t n, uint32_t tid, uint32_t threads)
 {
-    const uint32_t lane = __lane_id();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned long long todo = __ballot(bin != kNoBin);
-    uint32_t total = 0, my_leader = lane;
-#pragma unroll
-    for (uint32_t j = 0; j < kRecordTexels; ++j) slot[j] = 0u;
-    while (todo != 0ull) {
-        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-        const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)leader);
-        const bool mine = bin == lb;
-        uint32_t off = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kRecordTexels; ++j) {
-            const unsigned long long m = __ballot(mine && c > j);
-            if (mine) slot[j] = off + (uint32_t)__builtin_popcountll(m & below);
-            off += (uint32_t)__builtin_popcountll(m);
-        }
-        if (mine) { total = off; my_leader = leader; }
-        todo &= ~__ballot(mine);
-    }
-    uint32_t base = 0;
-    if (bin != kNoBin && lane == my_leader) base = atomicAdd(rep_word(p.rep_cursor, p, s, bin), total);
-    base = (uint32_t)__shfl((int)base, (int)my_leader);
-#pragma unroll
-    for (uint32_t j = 0; j < kRecordTexels; ++j) slot[j] += base;
+    const uint32_t pages = (n + kBinPage - 1u) >> kPageShift;
+    for (uint32_t pn = 1u + tid; pn < pages && pn < kBinMaxPages; pn += threads) p.page_table[(size_t)list * kBinMaxPages + pn] = 0u;
+}
+TH_D uint32_t *list_cursor(const DepositParams &p, uint32_t bin, uint32_t r) { return p.bin_cursor + (size_t)r * p.bin_stride + bin; }
+
+// one fragment into place `at` (kNoPlace: nowhere - the pass is flagged and repeated)
+TH_D void bins_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, int x, int y)
+{
+    if (at == kNoPlace) return;
+    p.frag_keys[at] = ((unsigned long long)(((uint32_t)y << 12) | (uint32_t)x) << 32) | id;
+    float t = 0.0f;
+    const bool along = dep_param(L, x, y, t);
+    if (p.mode == 2) {
+        p.colors[2u * (size_t)at] = dep_mix(L.a.c, L.b.c, along, t);
+        p.colors[2u * (size_t)at + 1u] = dep_mix(L.a.c2, L.b.c2, along, t);
+    } else p.colors[at] = dep_mix(L.a.c, L.b.c, along, t);
 }
 
 // slot s: its particle's texel (col, row) and whether draw() can make a line of it at all (th_api.hip: line_rows)
@@ -107,80 +118,82 @@ TH_D bool slot_particle(const DepositParams &p, uint32_t s, uint32_t &col, uint3
     const uint32_t g = p.row0 + row;
     return (p.row_draws[g >> 5] >> (g & 31u)) & 1u;
 }
-// the line of slot s
-TH_D void slot_line(const DepositParams &p, uint32_t s, uint32_t &col, uint32_t &row, DepositLine &L)
+
+// ---- the reservations of a workgroup's lines, by bin ----------------------------------------------------------------------
+constexpr uint32_t kResv = 2048;             // LDS table entries: >= 4 bins x 256 lines, so linear probing always finds a free one
+struct Reservations {
+    uint32_t tag[kResv];                     // bin + 1 (0: free)
+    uint32_t sum[kResv];                     // places reserved by the workgroup's lines; after the flush: the first of them
+    uint32_t frags;                          // fragments written by the workgroup
+    uint32_t any;
+};
+// n places of `bin` for the calling line -> entry << 20 | offset inside the workgroup's share
+TH_D uint32_t resv_take(Reservations &t, uint32_t bin, uint32_t n)
 {
-    slot_particle(p, s, col, row);
-    dep_setup(p, col, p.row0 + row, L, s);
-}
-// The slots of a workgroup of the two big passes: in the tile-sorted order the particles whose lines can draw lie apart from
-// the others inside every tile (th_kernels.hip: tile_key), so most workgroups meet only one kind: whole waves of lines that
-// exist - or nothing to do at all.  Returns false when no slot of the workgroup draws.
-// (`which`: a kernel's calls use different words - a second call must not reset what a straggler of the first still reads)
-TH_D bool workgroup_draws(bool mine, int which)
-{
-    __shared__ uint32_t any[2];
-    if (threadIdx.x == 0u) any[which] = 0u;
-    __syncthreads();
-    if (mine && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(mine)))) any[which] = 1u;
-    __syncthreads();
-    return any[which] != 0u;
+    uint32_t h = (bin * 2654435761u) >> 21;
+    for (;;) {
+        const uint32_t old = atomicCAS(&t.tag[h], 0u, bin + 1u);
+        if (old == 0u || old == bin + 1u) break;
+        h = (h + 1u) & (kResv - 1u);
+    }
+    return (h << 20) | atomicAdd(&t.sum[h], n);
 }
 
 // The fragments of a line of up to kRecordTexels fragments, by bin.  A line is about a texel long: nearly always all of its
-// fragments fall into one bin (b0), sometimes into two (b1); the table is asked once per bin, not once per fragment.
-// Fragments of a third bin (`others`) go to the global counters one by one.
+// fragments fall into one bin (b0), sometimes into two (b1); fragments of a third bin (`others`) take their places one by one.
 struct LineBins { uint32_t bin[kRecordTexels], b0, b1, c0, c1, others; };
 TH_D LineBins line_bins(const DepositParams &p, const uint32_t (&xy)[kRecordTexels], uint32_t n)
 {
     LineBins q;
-    q.b0 = q.b1 = kNoBin; q.c0 = q.c1 = 0u;
+    q.b0 = q.b1 = kNoPlace; q.c0 = q.c1 = 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < kRecordTexels; ++k) q.bin[k] = k < n ? bin_of(p, xy[k] & 0xffffu, xy[k] >> 16) : kNoBin;
+    for (uint32_t k = 0; k < kRecordTexels; ++k) q.bin[k] = k < n ? bin_of(p, xy[k] & 0xffffu, xy[k] >> 16) : kNoPlace;
     q.b0 = q.bin[0];
 #pragma unroll
     for (uint32_t k = 0; k < kRecordTexels; ++k) {
         const bool in0 = k < n && q.bin[k] == q.b0;
         q.c0 += in0 ? 1u : 0u;
-        if (k < n && !in0 && q.b1 == kNoBin) q.b1 = q.bin[k];
+        if (k < n && !in0 && q.b1 == kNoPlace) q.b1 = q.bin[k];
     }
 #pragma unroll
-    for (uint32_t k = 0; k < kRecordTexels; ++k) q.c1 += (k < n && q.bin[k] == q.b1 && q.b1 != kNoBin) ? 1u : 0u;
+    for (uint32_t k = 0; k < kRecordTexels; ++k) q.c1 += (k < n && q.bin[k] == q.b1 && q.b1 != kNoPlace) ? 1u : 0u;
     q.others = n - q.c0 - q.c1;
     return q;
 }
 
-// (called by whole waves; n = 0 for lanes without a line to count)
-TH_D void count_record(const DepositParams &p, uint32_t s, const uint32_t (&xy)[kRecordTexels], uint32_t n)
+// one place of list `list`, straight from its cursor (the odd fragment: slow lines, a line's third bin)
+TH_D uint32_t place_single(const DepositParams &p, uint32_t bin, uint32_t rep)
 {
-    const LineBins q = line_bins(p, xy, n);
-    wave_bin_count(p, s, n ? q.b0 : kNoBin, q.c0);
-    wave_bin_count(p, s, q.c1 ? q.b1 : kNoBin, q.c1);
-    if (q.others) {
-#pragma unroll
-        for (uint32_t k = 0; k < kRecordTexels; ++k)
-            if (k < n && q.bin[k] != q.b0 && q.bin[k] != q.b1) atomicAdd(rep_word(p.rep_hist, p, s, q.bin[k]), 1u);
-    }
+    const uint32_t v = atomicAdd(list_cursor(p, bin, rep), 1u);
+    if (v == 0xffffffffu) { bins_flag(p, kBinsBinFull); return kNoPlace; }
+    if (v && (v & (kBinPage - 1u)) == 0u) pages_open(p, bin * kBinReplicas + rep, v, 1u);
+    return place_of<true>(p, bin * kBinReplicas + rep, v);
 }
 
-// pass 1: every slot's line rasterised once (the common case: a small hexagon inside the view, all in registers; the
-// rest through the slow list).  Lines of more than kRecordTexels fragments are counted by bins_count_long_kernel.
-__global__ __launch_bounds__(256) void bins_raster_kernel(const DepositParams p)
+// pass 1.  Per slot: the line set up, classified, and - the common case: a small hexagon inside the view, all in registers -
+// rasterised into a record of <= kRecordTexels texels; its places reserved per bin, exactly; its fragments written.
+__global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
 {
+    __shared__ Reservations t;
     const uint32_t s = blockIdx.x * 256u + threadIdx.x, slots = p.W * p.rows;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);
-    if (!workgroup_draws(can, 0)) {
-        if (s < slots) p.count[s] = 0u;
-        if (threadIdx.x == 0u) p.block_flags[blockIdx.x] = 0u;
-        return;
-    }
+    // In the tile-sorted order the particles whose lines can draw lie apart from the others inside every tile
+    // (th_kernels.hip: tile_key): most workgroups meet only one kind - whole waves of lines that exist, or nothing to do.
+    if (threadIdx.x == 0u) { t.any = 0u; t.frags = 0u; }
+    for (uint32_t e = threadIdx.x; e < kResv; e += 256u) { t.tag[e] = 0u; t.sum[e] = 0u; }
+    __syncthreads();
+    if (can && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(can)))) t.any = 1u;
+    __syncthreads();
+    if (t.any == 0u) return;
+
     float4 own[2];                                      // (both ends of the line, before anything else)
     if (can) { own[0] = p.cur[s]; own[1] = p.prev[s]; }
+    DepositLine L;
+    L.draws = false;
     LineRecord r{};
     bool slow = false;
     if (can) {
-        DepositLine L;
         dep_setup(p, col, p.row0 + row, L, s, own);
         if (L.draws) {
             float cx[6], cy[6];
@@ -188,180 +201,104 @@ __global__ __launch_bounds__(256) void bins_raster_kernel(const DepositParams p)
             if (where == kHexInside) {
                 int PX[6], PY[6], ymin, ymax;
                 dep_snap_hexagon(p, cx, cy, PX, PY);
-                if (dep_hexagon_is_small(PX, PY, ymin, ymax))
-                    dep_raster_small_hexagon(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
-                else slow = true;
+                if (dep_hexagon_is_small(PX, PY, ymin, ymax)) {
+                    if (p.exp & 4u) dep_raster_small_hexagon(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
+                    else dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
+                } else slow = true;
             } else if (where == kHexClip) slow = true;
         }
-        if (r.n) rec_store(p, s, r);
     }
-    if (s < slots) p.count[s] = slow ? kNeedsSlow : r.n;        // (one store per wave: whole lines)
-    count_record(p, s, r.r, r.n <= kRecordTexels ? r.n : 0u);
+    if (r.n > kRecordTexels) { slow = true; r.n = 0u; }      // more fragments than a record holds: fragment by fragment
+    const uint32_t n = r.n;
+    const LineBins q = line_bins(p, r.r, n);
+    uint32_t took0 = 0, took1 = 0;
+    if (n) took0 = resv_take(t, q.b0, q.c0);
+    if (q.c1) took1 = resv_take(t, q.b1, q.c1);
     dep_list_append(p, kListSlow, blockIdx.x, slow, s);
-    dep_list_append(p, kListLong, blockIdx.x, r.n > kRecordTexels, s);
-    const bool busy = workgroup_draws(slow || r.n != 0u, 1);
-    if (threadIdx.x == 0u) p.block_flags[blockIdx.x] = busy ? 1u : 0u;     // the emitting pass skips the blocks without fragments
+    __syncthreads();
+    // the workgroup's share of every bin it met: one atomic each on the cursor of the workgroup's list of that bin; the
+    // pages that start inside it are taken from the pool
+    const uint32_t rep = blockIdx.x & (kBinReplicas - 1u);
+    for (uint32_t e = threadIdx.x; e < kResv; e += 256u) {
+        const uint32_t tag = t.tag[e];
+        if (tag == 0u) continue;
+        const uint32_t m = t.sum[e], base = atomicAdd(list_cursor(p, tag - 1u, rep), m);
+        t.sum[e] = base;
+        if (base + m < base) bins_flag(p, kBinsBinFull);
+        else if (((base + m - 1u) >> kPageShift) != (base >> kPageShift) || (base & (kBinPage - 1u)) == 0u) pages_open(p, (tag - 1u) * kBinReplicas + rep, base, m);
+    }
+    __syncthreads();
+    if (n) {
+        // a line's <= 8 places of a bin lie in one page or two: both looked up once, all lookups in flight together
+        const uint32_t v0 = t.sum[took0 >> 20] + (took0 & 0xfffffu), v1 = q.c1 ? t.sum[took1 >> 20] + (took1 & 0xfffffu) : 0u;
+        const uint32_t l0 = q.b0 * kBinReplicas + rep, l1 = (q.c1 ? q.b1 : q.b0) * kBinReplicas + rep;
+        const uint32_t pa0 = v0 >> kPageShift, pb0 = (v0 + q.c0 - 1u) >> kPageShift, pa1 = v1 >> kPageShift, pb1 = (v1 + (q.c1 ? q.c1 - 1u : 0u)) >> kPageShift;
+        const uint32_t ga0 = page_of<true>(p, l0, pa0), gb0 = pb0 != pa0 ? page_of<true>(p, l0, pb0) : ga0;
+        const uint32_t ga1 = q.c1 ? page_of<true>(p, l1, pa1) : 0u, gb1 = (q.c1 && pb1 != pa1) ? page_of<true>(p, l1, pb1) : ga1;
+        const uint32_t id = col * p.H + p.row0 + row;
+        uint32_t i0 = 0, i1 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kRecordTexels; ++k)
+            if (k < n) {
+                const uint32_t x = r.r[k] & 0xffffu, y = r.r[k] >> 16;
+                uint32_t at;
+                if (q.bin[k] == q.b0) { const uint32_t v = v0 + i0++, g = (v >> kPageShift) == pa0 ? ga0 : gb0; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
+                else if (q.bin[k] == q.b1) { const uint32_t v = v1 + i1++, g = (v >> kPageShift) == pa1 ? ga1 : gb1; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
+                else at = place_single(p, q.bin[k], rep);
+                bins_put(p, L, id, at, (int)x, (int)y);
+            }
+    }
+    // fragments of the pass: one atomic per workgroup
+    uint32_t written = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) written += __shfl_xor(written, o);
+    if (__lane_id() == 0u && written) atomicAdd(&t.frags, written);
+    __syncthreads();
+    if (threadIdx.x == 0u && t.frags) atomicAdd(&p.totals[kTotFragments], t.frags);
 }
 
-__global__ __launch_bounds__(256) void bins_raster_slow_kernel(const DepositParams p)
+// ... and the lines of the slow list (hexagons that cross the view's edge or need 64-bit edges, lines of more fragments than
+// a record holds): one place at a time from the lists' cursors
+__global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
 {
     dep_list_work(p, kListSlow, [&](bool have, uint32_t s, uint32_t seg) {
-        LineRecord r{};
+        const uint32_t rep = seg & (kBinReplicas - 1u);
+        uint32_t written = 0;
         if (have) {
             uint32_t col, row;
+            slot_particle(p, s, col, row);
             DepositLine L;
-            slot_line(p, s, col, row, L);
-            dep_raster_line(p, L, [&](int x, int y) { rec_add(r, x, y); });
-            p.count[s] = r.n;
-            if (r.n) rec_store(p, s, r);
-            if (r.n <= kRecordTexels) {
-#pragma unroll
-                for (uint32_t k = 0; k < kRecordTexels; ++k)
-                    if (k < r.n) atomicAdd(rep_word(p.rep_hist, p, s, bin_of(p, r.r[k] & 0xffffu, r.r[k] >> 16)), 1u);
-            }
+            dep_setup(p, col, p.row0 + row, L, s);
+            const uint32_t id = col * p.H + p.row0 + row;
+            dep_raster_line(p, L, [&](int x, int y) {
+                bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
+                ++written;
+            });
         }
-        dep_list_append(p, kListLong, seg, r.n > kRecordTexels, s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) written += __shfl_xor(written, o);
+        if (__lane_id() == 0u && written) atomicAdd(&p.totals[kTotFragments], written);
     });
 }
 
-// ... and the fragments of the long lines (more than a record holds), rasterised again
-__global__ __launch_bounds__(256) void bins_count_long_kernel(const DepositParams p)
+// the places handed out in bin b (all its lists; saturated)
+TH_D uint32_t bin_places(const DepositParams &p, uint32_t b)
 {
-    dep_list_work(p, kListLong, [&](bool have, uint32_t s, uint32_t) {
-        if (!have) return;
-        uint32_t col, row;
-        DepositLine L;
-        slot_line(p, s, col, row, L);
-        dep_raster_line(p, L, [&](int x, int y) { atomicAdd(rep_word(p.rep_hist, p, s, bin_of(p, (uint32_t)x, (uint32_t)y)), 1u); });
-    });
-}
-
-// pass 2a: every bin's copies added up (-> bin_hist) and laid out one after the other (rep_hist becomes the first place of
-// every copy inside its bin's range)
-__global__ __launch_bounds__(256) void bins_replica_kernel(const DepositParams p)
-{
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b >= p.nbins) return;
-    uint32_t h[kBinReplicas], run = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < kBinReplicas; ++r) h[r] = p.rep_hist[(size_t)r * p.bin_stride + b];
-#pragma unroll
-    for (uint32_t r = 0; r < kBinReplicas; ++r) {
-        p.rep_hist[(size_t)r * p.bin_stride + b] = run;
-        run = run + h[r] < run ? 0xffffffffu : run + h[r];         // (saturating: a count beyond 2^32 must be seen)
-    }
-    p.bin_hist[b] = run;
-}
-// ... and after the scan: every copy's fill cursor = first fragment of the bin + first place of the copy
-__global__ __launch_bounds__(256) void bins_cursor_kernel(const DepositParams p)
-{
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b >= p.nbins) return;
-    const uint32_t start = p.bin_start[b];
-#pragma unroll
-    for (uint32_t r = 0; r < kBinReplicas; ++r) p.rep_cursor[(size_t)r * p.bin_stride + b] = start + p.rep_hist[(size_t)r * p.bin_stride + b];
-}
-
-// pass 2: one workgroup: exclusive scan of the bins' fragment counts (64-bit sums, saturated: a total beyond 2^32 must
-// be seen) -> bin_start (nbins + 1), the fill cursors, totals[0] = fragments, totals[2] = the largest bin
-__global__ __launch_bounds__(1024) void bins_scan_kernel(const DepositParams p, uint32_t *totals)
-{
-    __shared__ unsigned long long part[1024];
-    __shared__ uint32_t most[1024];
-    const uint32_t per = (p.nbins + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per < p.nbins ? threadIdx.x * per : p.nbins, hi = lo + per < p.nbins ? lo + per : p.nbins;
     unsigned long long n = 0;
-    uint32_t m = 0;
-    for (uint32_t b = lo; b < hi; ++b) { const uint32_t h = p.bin_hist[b]; n += h; m = h > m ? h : m; }
-    part[threadIdx.x] = n; most[threadIdx.x] = m;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        unsigned long long a = 0;
-        uint32_t am = 0;
-        if (threadIdx.x >= off) { a = part[threadIdx.x - off]; am = most[threadIdx.x - off]; }
-        __syncthreads();
-        part[threadIdx.x] += a; most[threadIdx.x] = most[threadIdx.x] > am ? most[threadIdx.x] : am;
-        __syncthreads();
-    }
-    unsigned long long run = part[threadIdx.x] - n;
-    for (uint32_t b = lo; b < hi; ++b) {
-        const uint32_t at = (uint32_t)(run > 0xffffffffull ? 0xffffffffull : run), h = p.bin_hist[b];
-        p.bin_start[b] = at;
-        run += h;
-        if (h > kBinCap) p.large_bins[atomicAdd(&totals[3], 1u)] = b;       // (in whatever order)
-    }
-    if (threadIdx.x == 1023u) {
-        const uint32_t total = (uint32_t)(part[1023] > 0xffffffffull ? 0xffffffffull : part[1023]);
-        p.bin_start[p.nbins] = total;
-        totals[0] = total; totals[2] = most[1023];
-    }
-}
-
-// one fragment into slot `at` of the bin-major fragment array
-TH_D void bins_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, int x, int y)
-{
-    p.frag_keys[at] = ((unsigned long long)(((uint32_t)y << 12) | (uint32_t)x) << 32) | id;
-    float t = 0.0f;
-    const bool along = dep_param(L, x, y, t);
-    if (p.mode == 2) {
-        p.colors[2u * (size_t)at] = dep_mix(L.a.c, L.b.c, along, t);
-        p.colors[2u * (size_t)at + 1u] = dep_mix(L.a.c2, L.b.c2, along, t);
-    } else p.colors[at] = dep_mix(L.a.c, L.b.c, along, t);
-}
-
-// pass 3: the fragments of the lines of up to kRecordTexels fragments, from their records, into their bins.  Wave by
-// wave, no LDS, no barrier: the fragments of a wave in one bin are written as one contiguous run (wave_bin_slots); the
-// few fragments of a line beyond its first bin (a line crossing a bin's edge) take their places one by one.
-__global__ __launch_bounds__(256) void bins_emit_kernel(const DepositParams p)
-{
-    if (p.block_flags[blockIdx.x] == 0u) return;         // (uniform: no fragments in this block's lines)
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x, slots = p.W * p.rows, at = s < slots ? s : slots - 1u;
-    // everything a line needs, in flight together (unconditional, clamped)
-    uint32_t n = p.count[at];
-    const uint4 ra = p.record[2u * at], rb = p.record[2u * at + 1u];
-    float4 own[2] = {p.cur[at], p.prev[at]};
-    uint32_t col = 0, row = 0;
-    slot_particle(p, at, col, row);
-    if (s >= slots || n > kRecordTexels) n = 0u;
-    const uint32_t xy[kRecordTexels] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    const LineBins q = line_bins(p, xy, n);
-    uint32_t slot[kRecordTexels];
-    wave_bin_slots(p, s, n ? q.b0 : kNoBin, q.c0, slot);
-    if (!n) return;
-    DepositLine L;
-    dep_setup(p, col, p.row0 + row, L, s, own);
-    const uint32_t id = col * p.H + p.row0 + row;
-    uint32_t j = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kRecordTexels; ++k)
-        if (k < n) {
-            const uint32_t x = xy[k] & 0xffffu, y = xy[k] >> 16;
-            uint32_t to;
-            if (q.bin[k] == q.b0) {
-                to = slot[0];
-#pragma unroll
-                for (uint32_t e = 1; e < kRecordTexels; ++e) to = j == e ? slot[e] : to;      // (selects: the places stay in registers)
-                ++j;
-            } else to = atomicAdd(rep_word(p.rep_cursor, p, s, q.bin[k]), 1u);
-            bins_put(p, L, id, to, (int)x, (int)y);
-        }
+    for (uint32_t r = 0; r < kBinReplicas; ++r) n += *list_cursor(p, b, r);
+    return n > 0xffffffffull ? 0xffffffffu : (uint32_t)n;
 }
 
-__global__ __launch_bounds__(256) void bins_emit_long_kernel(const DepositParams p)
+// pass 2: the bins of more places than one workgroup orders in LDS
+__global__ __launch_bounds__(256) void bins_plan_kernel(const DepositParams p)
 {
-    dep_list_work(p, kListLong, [&](bool have, uint32_t s, uint32_t) {
-        if (!have) return;
-        uint32_t col, row;
-        DepositLine L;
-        slot_line(p, s, col, row, L);
-        const uint32_t id = col * p.H + p.row0 + row;
-        dep_raster_line(p, L, [&](int x, int y) {
-            bins_put(p, L, id, atomicAdd(rep_word(p.rep_cursor, p, s, bin_of(p, (uint32_t)x, (uint32_t)y)), 1u), x, y);
-        });
-    });
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= p.nbins) return;
+    if (bin_places(p, b) > kBinCap) p.large_bins[atomicAdd(&p.totals[kTotLarge], 1u)] = b;       // (in whatever order)
 }
 
-// ---- pass 4: one workgroup per bin -----------------------------------------------------------------------------
+// ---- pass 3: one workgroup per bin -----------------------------------------------------------------------------
 TH_D uint32_t key_local(unsigned long long k) { return (uint32_t)((k >> 40) & 0xf0u) | (uint32_t)((k >> 32) & 0xfu); }   // (y & 15) << 4 | (x & 15)
 // sort key of a fragment while a crowded bin is ordered: texel inside the bin (8 bits) | stream index (32) | position in the
 // bin's range of the fragment array (24 bits: where its varying lies)
@@ -411,6 +348,7 @@ struct BinShared {
     uint32_t cnt[kBinTexels], first[kBinTexels + 1u];        // fragments per texel (then: fill cursors); first fragment of every texel
     BlendSource stage_a[256], stage_b[MODE == 2 ? 256 : 1];  // a long run's sources, 256 at a time (b: the view pass's beside the flow pass's)
     uint32_t misc[8];
+    uint32_t lists[kBinReplicas + 1u];                       // first place of every list of the bin when its lists are walked one after the other
     TH_D uint32_t *sid() { return pool; }
     TH_D uint32_t *osrc() { return pool + kBinCap; }
     TH_D unsigned long long *skey() { return reinterpret_cast<unsigned long long *>(pool); }     // kCrowdCap keys = 4096 words
@@ -525,39 +463,42 @@ TH_D void bin_bitonic(BinShared<MODE> &s, uint32_t m)
     __syncthreads();
 }
 
-// every key of the bin: body(key, position); a thread's loads of one round of 16 are issued together (unconditional, clamped)
-template <typename Body>
-TH_D void for_keys(const unsigned long long *keys, uint32_t n, Body body)
+// every fragment among n places (place(f) = where place f of the walk lies): body(key, f) (empty places skipped); a
+// thread's loads of one round are issued together (unconditional, clamped)
+template <typename PlaceAt, typename Body>
+TH_D void for_keys(const unsigned long long *keys, PlaceAt place, uint32_t n, Body body)
 {
     constexpr uint32_t kPer = 8;
     for (uint32_t c0 = 0; c0 < n; c0 += kPer * 256u) {
         unsigned long long k[kPer];
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = c0 + q * 256u + threadIdx.x; k[q] = keys[f < n ? f : n - 1u]; }
+        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = c0 + q * 256u + threadIdx.x; k[q] = keys[place(f < n ? f : n - 1u)]; }
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = c0 + q * 256u + threadIdx.x; if (f < n) body(k[q], f); }
+        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = c0 + q * 256u + threadIdx.x; if (f < n && k[q] != kEmptyKey) body(k[q], f); }
     }
 }
 
 // One texel's fragments when they do not fit LDS at once: windows [lo, hi) of its stream indices (distinct inside one
 // texel: a line covers a texel at most once), each small enough to be sorted in LDS, in rising order; the texel's thread
 // (`owner`) carries the destination from window to window.  for_texel(body) hands every fragment's sort key to body -
-// stream index in bits 24..55, position of its varying in bits 0..23.
-template <int MODE, typename ForTexel>
-TH_D void blend_texel_windows(BinShared<MODE> &s, const DepositParams &p, uint32_t begin, uint32_t owner, BinTexel<MODE> &d, ForTexel for_texel)
+// stream index above the PB position bits, which place() turns into the place of the varying.
+template <int MODE, int PB, typename PlaceAt, typename ForTexel>
+TH_D void blend_texel_windows(BinShared<MODE> &s, const DepositParams &p, uint32_t owner, BinTexel<MODE> &d, PlaceAt place, ForTexel for_texel)
 {
     const uint32_t t = threadIdx.x;
     unsigned long long *skey = s.skey();
     uint16_t *order = s.order();
     uint32_t *hist = s.hist();
     unsigned long long lo = 0ull;
-    uint32_t shift = p.id_bits > 10u ? p.id_bits - 10u : 0u;
+    uint32_t id_bits = 1;                           // bits of a stream index: ceil(log2(W * H))
+    while (id_bits < 32u && (1ull << id_bits) < (unsigned long long)p.W * p.H) ++id_bits;
+    uint32_t shift = id_bits > 10u ? id_bits - 10u : 0u;
     while (true) {
         for (uint32_t k = t; k < 1024u; k += 256u) hist[k] = 0u;
         if (t == 0u) s.misc[0] = 0u;
         __syncthreads();
         for_texel([&](unsigned long long k) {
-            const unsigned long long id = (k >> 24) & 0xffffffffull;
+            const unsigned long long id = (k >> PB) & 0xffffffffull;
             if (id >= lo) {
                 const unsigned long long bkt = (id - lo) >> shift;
                 atomicAdd(&hist[bkt < 1023ull ? (uint32_t)bkt : 1023u], 1u);
@@ -577,31 +518,32 @@ TH_D void blend_texel_windows(BinShared<MODE> &s, const DepositParams &p, uint32
         // (bucket 1023 also holds everything beyond it: taken only together with all the others = the rest of the run)
         const unsigned long long hi = nb == 1024u ? 0x100000000ull : lo + ((unsigned long long)nb << shift);
         for_texel([&](unsigned long long k) {
-            const unsigned long long id = (k >> 24) & 0xffffffffull;
+            const unsigned long long id = (k >> PB) & 0xffffffffull;
             if (id >= lo && id < hi) skey[atomicAdd(&s.misc[0], 1u)] = k;
         });
         __syncthreads();
         bin_bitonic(s, m);
-        bin_blend_long<MODE>(s, p, begin, m, owner, d, [&](uint32_t j) { return (uint32_t)(skey[order[j]] & 0xffffffull); });
+        bin_blend_long<MODE>(s, p, 0u, m, owner, d, [&](uint32_t j) { return place((uint32_t)(skey[order[j]] & ((1ull << PB) - 1ull))); });
         if (rest == 0u) break;
         lo = hi;
     }
 }
 
-// A bin of up to kBinCap fragments with a run longer than kRankMaxRun (bins of MORE fragments are spread over many
-// workgroups: crowd_*_kernel below): batches of whole texels that fit kCrowdCap sort keys, each ordered in LDS; a texel
+// A bin of one chunk with a run longer than kRankMaxRun (bins of more chunks are spread over many workgroups:
+// crowd_*_kernel below): batches of whole texels that fit kCrowdCap sort keys, each ordered in LDS; a texel
 // that does not fit alone goes in windows of its stream indices.
-template <int MODE>
-TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned long long *keys, uint32_t begin, uint32_t n,
+template <int MODE, typename PlaceAt>
+TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned long long *keys, PlaceAt place, uint32_t n,
                       BinTexel<MODE> &d, bool &touched)
 {
     const uint32_t t = threadIdx.x;
+    constexpr uint32_t begin = 0u;                 // (the sources are places)
     unsigned long long *skey = s.skey();
     uint16_t *order = s.order();
-    auto src_at = [&](uint32_t base) { return [&, base](uint32_t j) { return (uint32_t)(skey[order[base + j]] & 0xffffffull); }; };
+    auto src_at = [&](uint32_t base) { return [&, base](uint32_t j) { return place((uint32_t)(skey[order[base + j]] & 0xffffffull)); }; };
     s.cnt[t] = 0u;
     __syncthreads();
-    for_keys(keys, n, [&](unsigned long long k, uint32_t) { atomicAdd(&s.cnt[key_local(k)], 1u); });
+    for_keys(keys, place, n, [&](unsigned long long k, uint32_t) { atomicAdd(&s.cnt[key_local(k)], 1u); });
     __syncthreads();
     bin_scan_counts(s);
     uint32_t t0 = 0;
@@ -614,7 +556,7 @@ TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned
             if (m) {
                 if (t >= t0 && t < t1) s.cnt[t] = 0u;
                 __syncthreads();
-                for_keys(keys, n, [&](unsigned long long k, uint32_t f) {
+                for_keys(keys, place, n, [&](unsigned long long k, uint32_t f) {
                     const uint32_t lt = key_local(k);
                     if (lt >= t0 && lt < t1) skey[s.first[lt] - base + atomicAdd(&s.cnt[lt], 1u)] = sort_key(k, f);
                 });
@@ -647,8 +589,8 @@ TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned
         }
         // texel t0 alone holds more than kCrowdCap fragments
         if (t == t0) touched = true;
-        blend_texel_windows<MODE>(s, p, begin, t0, d, [&](auto body) {
-            for_keys(keys, n, [&](unsigned long long k, uint32_t f) { if (key_local(k) == t0) body(sort_key(k, f)); });
+        blend_texel_windows<MODE, 24>(s, p, t0, d, place, [&](auto body) {
+            for_keys(keys, place, n, [&](unsigned long long k, uint32_t f) { if (key_local(k) == t0) body(sort_key(k, f)); });
         });
         ++t0;
     }
@@ -658,10 +600,23 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
 {
     __shared__ BinShared<MODE> s;
-    const uint32_t b = blockIdx.x, begin = p.bin_start[b], n = p.bin_start[b + 1u] - begin;
-    if (n == 0u || n > kBinCap) return;              // (bins of more than kBinCap fragments: crowd_*_kernel)
-    const uint32_t t = threadIdx.x;
-    const unsigned long long *keys = p.frag_keys + begin;
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (t == 0u) {
+        uint32_t run = 0;
+        for (uint32_t r = 0; r < kBinReplicas; ++r) { s.lists[r] = run; const uint32_t c = *list_cursor(p, b, r); run = run + c < run ? 0xffffffffu : run + c; }
+        s.lists[kBinReplicas] = run;
+    }
+    __syncthreads();
+    const uint32_t n = s.lists[kBinReplicas];        // (places handed out: some may be empty)
+    if (n == 0u || n > kBinCap) return;              // (bins of more places: crowd_*_kernel)
+    // place f of the bin's lists walked one after the other
+    auto place = [&](uint32_t f) {
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < kBinReplicas; ++q) r += f >= s.lists[q] ? 1u : 0u;
+        return place_of(p, b * kBinReplicas + r, f - s.lists[r]);
+    };
+    unsigned long long *keys = p.frag_keys;
     const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
     const uint32_t x = (bx << kBinShift) + (t & (kBinSide - 1u)), y = (by << kBinShift) + (t >> kBinShift);
     const bool inside = x < (uint32_t)p.fw && y < (uint32_t)p.fh;
@@ -670,21 +625,23 @@ __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
     if (inside) d.load(p, texel);
     bool touched = false;
 
+    constexpr uint32_t kPer = kBinCap / 256u;
+    uint32_t at[kPer];                               // where the thread's places lie
     bool crowded = false;
     {
         // The common case.  A thread's <= 16 keys stay in registers from the count to the ranking: counted per texel, the
         // runs laid out by the scan, every fragment's stream index dropped into its texel's run (in whatever order the LDS
         // atomics hand out), then every fragment ranks itself inside its run by counting the smaller indices - its place
-        // in GL's order - and leaves its position there for the texel's thread.
-        constexpr uint32_t kPer = kBinCap / 256u;
+        // in GL's order - and leaves the place of its varying there for the texel's thread.
         unsigned long long k[kPer];
-        uint32_t at[kPer];
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; k[q] = keys[f < n ? f : n - 1u]; }
+        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; at[q] = place(f < n ? f : n - 1u); }
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) k[q] = keys[at[q]];
         s.cnt[t] = 0u;
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) if (q * 256u + t < n) atomicAdd(&s.cnt[key_local(k[q])], 1u);
+        for (uint32_t q = 0; q < kPer; ++q) if (q * 256u + t < n && k[q] != kEmptyKey) atomicAdd(&s.cnt[key_local(k[q])], 1u);
         __syncthreads();
         const uint32_t mine = s.cnt[t];
         const uint32_t longest = bin_scan_counts(s);
@@ -693,92 +650,120 @@ __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
             s.cnt[t] = 0u;
             __syncthreads();
             uint32_t *sid = s.sid(), *osrc = s.osrc();
+            uint32_t to[kPer];
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
-                if (q * 256u + t < n) {
+                if (q * 256u + t < n && k[q] != kEmptyKey) {
                     const uint32_t lt = key_local(k[q]);
-                    at[q] = s.first[lt] + atomicAdd(&s.cnt[lt], 1u);
-                    sid[at[q]] = (uint32_t)k[q];
+                    to[q] = s.first[lt] + atomicAdd(&s.cnt[lt], 1u);
+                    sid[to[q]] = (uint32_t)k[q];
                 }
             __syncthreads();
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
-                if (q * 256u + t < n) {
+                if (q * 256u + t < n && k[q] != kEmptyKey) {
                     const uint32_t lt = key_local(k[q]), id = (uint32_t)k[q], r0 = s.first[lt], r1 = s.first[lt + 1u];
                     uint32_t rank = 0;
                     for (uint32_t j = r0; j < r1; ++j) rank += sid[j] < id ? 1u : 0u;
-                    osrc[r0 + rank] = q * 256u + t;
+                    osrc[r0 + rank] = at[q];
                 }
             __syncthreads();
             const uint32_t r0 = s.first[t];
             auto src_at = [&](uint32_t base) { return [osrc, base](uint32_t j) { return osrc[base + j]; }; };
-            if (mine && mine <= kOwnRun) { touched = true; bin_blend_own<MODE>(p, begin, mine, d, src_at(r0)); }
+            if (mine && mine <= kOwnRun) { touched = true; bin_blend_own<MODE>(p, 0u, mine, d, src_at(r0)); }
             if (longest > kOwnRun)
                 for (uint32_t lt = 0; lt < kBinTexels; ++lt) {
                     const uint32_t l = s.first[lt + 1u] - s.first[lt];
                     if (l <= kOwnRun) continue;
                     if (t == lt) touched = true;
-                    bin_blend_long<MODE>(s, p, begin, l, lt, d, src_at(s.first[lt]));
+                    bin_blend_long<MODE>(s, p, 0u, l, lt, d, src_at(s.first[lt]));
                 }
         }
     }
-    if (crowded) bin_crowded<MODE>(s, p, keys, begin, n, d, touched);
+    if (crowded) { bin_crowded<MODE>(s, p, keys, place, n, d, touched); __syncthreads(); }
     if (inside && touched) d.store(p, texel);
+    // the pages the bin's lists grew by are forgotten for the next pass
+    for (uint32_t r = 0; r < kBinReplicas; ++r) if (s.lists[r + 1u] - s.lists[r] > kBinPage) pages_forget(p, b * kBinReplicas + r, s.lists[r + 1u] - s.lists[r], t, 256u);
 }
 
 
-// ---- bins of more than kBinCap fragments: many workgroups per bin ------------------------------------------------------
+// ---- bins of more than kBinCap places: many workgroups per bin ---------------------------------------------------------------
 // The wake makes particles converge: after a few dozen frames a few hundred bins hold a third of all fragments (tens of
 // thousands each, a thousand in single texels).  Those bins get one more level of the same scheme: their fragments are
-// regrouped by TEXEL - a counting sort over the 256 texels of the bin, kCrowdBlock fragments per workgroup, exact ranges
-// from a per-bin scan - and then every texel's run is ordered by stream index and blended by a workgroup of its own.
-//   crowd_plan_kernel     workgroup blocks of the large bins: first block of every large bin (prefix over the list)
-//   crowd_hist_kernel     fragments per texel of every large bin
-//   crowd_scan_kernel     every texel's range inside its bin
-//   crowd_scatter_kernel  (stream index << 24 | position of the varying) of every fragment into its texel's range
-//   crowd_blend_kernel    one workgroup per texel of a large bin: order the run in LDS (windows of stream indices when it
-//                         does not fit), blend
-constexpr uint32_t kCrowdBlock = 4096;
+// regrouped by TEXEL - a counting sort over the 256 texels of the bin, one workgroup per list of the bin, exact ranges from
+// a per-bin scan - and then every texel's run is ordered by stream index and blended by a wave (or, the longest, a
+// workgroup) of its own.
+//   crowd_plan_kernel        regrouped-key ranges of the large bins (prefix over the list)
+//   crowd_hist_kernel        fragments per texel of every large bin
+//   crowd_scan_kernel        every texel's range inside its bin; the list of the long runs
+//   crowd_scatter_kernel     (stream index << 32 | place of the varying) of every fragment into its texel's range; the
+//                            places and the lists' pages are left empty
+//   crowd_blend_wave_kernel  one wave per texel: order the run in LDS, blend
+//   crowd_blend_kernel       one workgroup per texel of the long list (windows of stream indices when a run does not fit LDS)
+constexpr uint32_t kWaveRun = 256;           // runs up to this length are ordered and blended by ONE wave
 
-__global__ __launch_bounds__(1024) void crowd_plan_kernel(const DepositParams p, uint32_t *totals)
+__global__ __launch_bounds__(1024) void crowd_plan_kernel(const DepositParams p)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t nlarge = totals[3], per = (nlarge + 1023u) / 1024u;
+    __shared__ unsigned long long kpart[1024];
+    const uint32_t nlarge = p.totals[kTotLarge], per = (nlarge + 1023u) / 1024u;
     const uint32_t lo = threadIdx.x * per < nlarge ? threadIdx.x * per : nlarge, hi = lo + per < nlarge ? lo + per : nlarge;
-    uint32_t n = 0;
-    for (uint32_t i = lo; i < hi; ++i) n += (p.bin_hist[p.large_bins[i]] + kCrowdBlock - 1u) / kCrowdBlock;
-    part[threadIdx.x] = n;
+    unsigned long long kn = 0;
+    for (uint32_t i = lo; i < hi; ++i) kn += bin_places(p, p.large_bins[i]);
+    kpart[threadIdx.x] = kn;
     __syncthreads();
     for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t a = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        const unsigned long long ka = threadIdx.x >= off ? kpart[threadIdx.x - off] : 0ull;
         __syncthreads();
-        part[threadIdx.x] += a;
+        kpart[threadIdx.x] += ka;
         __syncthreads();
     }
-    uint32_t run = part[threadIdx.x] - n;
-    for (uint32_t i = lo; i < hi; ++i) { p.large_block0[i] = run; run += (p.bin_hist[p.large_bins[i]] + kCrowdBlock - 1u) / kCrowdBlock; }
-    if (threadIdx.x == 1023u) { p.large_block0[nlarge] = part[1023]; totals[4] = part[1023]; }
+    unsigned long long krun = kpart[threadIdx.x] - kn;
+    for (uint32_t i = lo; i < hi; ++i) {
+        p.large_key0[i] = (uint32_t)(krun > 0xffffffffull ? 0xffffffffull : krun);
+        krun += bin_places(p, p.large_bins[i]);
+    }
+    if (threadIdx.x == 1023u) p.totals[kTotCrowdKeys] = (uint32_t)(kpart[1023] > 0xffffffffull ? 0xffffffffull : kpart[1023]);      // (saturated: the host refuses it)
 }
 
-// block -> (large bin i, first fragment of the block inside the bin)
-TH_D void crowd_block(const DepositParams &p, uint32_t block, uint32_t &i, uint32_t &first)
+// workgroup block -> (large bin i, one of its lists, the places handed out in it)
+TH_D void crowd_block(const DepositParams &p, uint32_t block, uint32_t &i, uint32_t &list, uint32_t &n)
 {
-    uint32_t lo = 0, hi = p.nlarge;                 // the last i with large_block0[i] <= block
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (p.large_block0[mid] <= block) lo = mid; else hi = mid; }
-    i = lo;
-    first = (block - p.large_block0[lo]) * kCrowdBlock;
+    i = block / kBinReplicas;
+    const uint32_t r = block - i * kBinReplicas, b = p.large_bins[i];
+    list = b * kBinReplicas + r;
+    n = *list_cursor(p, b, r);
+}
+// the fragments of a list in rounds of kBinCap places: round(keys of the thread, their places, first index, places in the round)
+template <typename Round>
+TH_D void crowd_rounds(const DepositParams &p, uint32_t list, uint32_t n, Round round)
+{
+    constexpr uint32_t kPer = kBinCap / 256u;
+    for (uint32_t f0 = 0; f0 < n; f0 += kBinCap) {
+        const uint32_t m = n - f0 < kBinCap ? n - f0 : kBinCap;
+        uint32_t at[kPer];
+        unsigned long long k[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + threadIdx.x; at[q] = place_of(p, list, f0 + (f < m ? f : m - 1u)); }
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) k[q] = at[q] == kNoPlace ? kEmptyKey : p.frag_keys[at[q]];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) if (q * 256u + threadIdx.x >= m) k[q] = kEmptyKey;
+        round(k, at, m);
+    }
 }
 
 __global__ __launch_bounds__(256) void crowd_hist_kernel(const DepositParams p)
 {
     __shared__ uint32_t hist[kBinTexels];
-    uint32_t i, first;
-    crowd_block(p, blockIdx.x, i, first);
-    const uint32_t b = p.large_bins[i], begin = p.bin_start[b], n = p.bin_start[b + 1u] - begin;
-    const uint32_t m = n - first < kCrowdBlock ? n - first : kCrowdBlock;
+    uint32_t i, list, n;
+    crowd_block(p, blockIdx.x, i, list, n);
+    if (n == 0u) return;
     hist[threadIdx.x] = 0u;
     __syncthreads();
-    for_keys(p.frag_keys + begin + first, m, [&](unsigned long long k, uint32_t) { atomicAdd(&hist[key_local(k)], 1u); });
+    crowd_rounds(p, list, n, [&](const unsigned long long (&k)[kBinCap / 256u], const uint32_t (&)[kBinCap / 256u], uint32_t) {
+#pragma unroll
+        for (uint32_t q = 0; q < kBinCap / 256u; ++q) if (k[q] != kEmptyKey) atomicAdd(&hist[key_local(k[q])], 1u);
+    });
     __syncthreads();
     if (hist[threadIdx.x]) atomicAdd(&p.crowd_count[(size_t)i * kBinTexels + threadIdx.x], hist[threadIdx.x]);
 }
@@ -799,113 +784,178 @@ __global__ __launch_bounds__(256) void crowd_scan_kernel(const DepositParams p)
     p.crowd_start[(size_t)i * (kBinTexels + 1u) + t] = start;
     p.crowd_cursor[(size_t)i * kBinTexels + t] = start;
     if (t == 255u) p.crowd_start[(size_t)i * (kBinTexels + 1u) + 256u] = before + incl;
+    if (mine > kWaveRun) p.crowd_long[atomicAdd(&p.totals[kTotLong], 1u)] = (i << 8) | t;       // (in whatever order)
 }
 
 __global__ __launch_bounds__(256) void crowd_scatter_kernel(const DepositParams p)
 {
     __shared__ uint32_t hist[kBinTexels], base[kBinTexels];
-    uint32_t i, first;
-    crowd_block(p, blockIdx.x, i, first);
-    const uint32_t b = p.large_bins[i], begin = p.bin_start[b], n = p.bin_start[b + 1u] - begin;
-    const uint32_t m = n - first < kCrowdBlock ? n - first : kCrowdBlock, t = threadIdx.x;
-    constexpr uint32_t kPer = kCrowdBlock / 256u;
-    unsigned long long k[kPer];
-    const unsigned long long *keys = p.frag_keys + begin + first;
+    uint32_t i, list, n;
+    crowd_block(p, blockIdx.x, i, list, n);
+    if (n == 0u) return;
+    const uint32_t t = threadIdx.x;
+    unsigned long long *out = p.crowd_keys + p.large_key0[i];
+    crowd_rounds(p, list, n, [&](const unsigned long long (&k)[kBinCap / 256u], const uint32_t (&at)[kBinCap / 256u], uint32_t m) {
+        hist[t] = 0u;
+        __syncthreads();
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; k[q] = keys[f < m ? f : m - 1u]; }
-    hist[t] = 0u;
-    __syncthreads();
+        for (uint32_t q = 0; q < kBinCap / 256u; ++q) if (k[q] != kEmptyKey) atomicAdd(&hist[key_local(k[q])], 1u);
+        __syncthreads();
+        base[t] = hist[t] ? atomicAdd(&p.crowd_cursor[(size_t)i * kBinTexels + t], hist[t]) : 0u;
+        hist[t] = 0u;
+        __syncthreads();
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) if (q * 256u + t < m) atomicAdd(&hist[key_local(k[q])], 1u);
-    __syncthreads();
-    base[t] = hist[t] ? atomicAdd(&p.crowd_cursor[(size_t)i * kBinTexels + t], hist[t]) : 0u;
-    hist[t] = 0u;
-    __syncthreads();
-    unsigned long long *out = p.crowd_keys + begin;
-#pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q)
-        if (q * 256u + t < m) {
-            const uint32_t lt = key_local(k[q]);
-            out[base[lt] + atomicAdd(&hist[lt], 1u)] = ((k[q] & 0xffffffffull) << 24) | (first + q * 256u + t);
+        for (uint32_t q = 0; q < kBinCap / 256u; ++q) {
+            if (k[q] != kEmptyKey) {
+                const uint32_t lt = key_local(k[q]);
+                out[base[lt] + atomicAdd(&hist[lt], 1u)] = ((k[q] & 0xffffffffull) << 32) | at[q];
+            }
         }
+        __syncthreads();
+    });
+    pages_forget(p, list, n, t, 256u);
 }
 
+// the texels of the long list (runs of more than kWaveRun fragments), a workgroup each
 template <int MODE>
 __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p)
 {
     __shared__ BinShared<MODE> s;
-    const uint32_t i = blockIdx.x >> 8, lt = blockIdx.x & 255u, t = threadIdx.x;
-    const uint32_t b = p.large_bins[i], begin = p.bin_start[b];
+    const uint32_t t = threadIdx.x, nlong = p.totals[kTotLong];
+    for (uint32_t e = blockIdx.x; e < nlong; e += gridDim.x) {
+        const uint32_t entry = p.crowd_long[e], i = entry >> 8, lt = entry & 255u;
+        const uint32_t b = p.large_bins[i];
+        const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
+        const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
+        const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
+        const uint32_t texel = y * (uint32_t)p.fw + x;            // (a texel with fragments lies inside the target)
+        const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
+        BinTexel<MODE> d{};
+        if (t == 0u) d.load(p, texel);
+        unsigned long long *skey = s.skey();
+        uint16_t *order = s.order();
+        if (len <= kCrowdCap) {
+            for (uint32_t f = t; f < len; f += 256u) skey[f] = run[f];
+            __syncthreads();
+            bin_bitonic(s, len);
+            bin_blend_long<MODE>(s, p, 0u, len, 0u, d, [&](uint32_t j) { return (uint32_t)(skey[order[j]] & 0xffffffffull); });
+        } else {
+            blend_texel_windows<MODE, 32>(s, p, 0u, d, [](uint32_t at) { return at; }, [&](auto body) { for (uint32_t f = t; f < len; f += 256u) body(run[f]); });
+        }
+        if (t == 0u) d.store(p, texel);
+        __syncthreads();
+    }
+}
+
+// One WAVE per texel of a large bin: runs of up to kWaveRun fragments - nearly all of them (the typical texel of a crowded
+// bin holds a few dozen).  No workgroup barrier anywhere: a wave loads its run's keys into its own LDS strip, every lane
+// ranks its (<= 4) keys by counting the smaller ones (all lanes read the same key at a time: a broadcast, no bank
+// conflicts; stream indices inside a texel are distinct: a line covers a texel at most once), leaves every fragment's
+// place at its rank, and then the run is blended 64 fragments at a time: every lane fetches one varying and turns it
+// into its side of the blend (64 gathers in flight, the next batch's issued before this batch's chain), and ALL lanes
+// apply the 64 sources in order to their own copy of the destination (read back as LDS broadcasts) - the same operations
+// in the same order as one thread would do them, without a divergent tail; lane 0 stores.
+template <int MODE>
+__global__ __launch_bounds__(256) void crowd_blend_wave_kernel(const DepositParams p)
+{
+    __shared__ unsigned long long keys[4][kWaveRun];
+    __shared__ uint32_t ord[4][kWaveRun];
+    __shared__ BlendSource stage_a[4][64], stage_b[MODE == 2 ? 4 : 1][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gt = blockIdx.x * 4u + wave, i = gt >> 8, lt = gt & 255u;
+    if (i >= p.nlarge) return;
     const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
-    if (len == 0u) return;
+    if (len == 0u || len > kWaveRun) return;                  // (the long ones: crowd_blend_kernel)
+    const uint32_t b = p.large_bins[i];
     const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
     const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
-    const uint32_t texel = y * (uint32_t)p.fw + x;            // (a texel with fragments lies inside the target)
-    const unsigned long long *run = p.crowd_keys + begin + r0;
+    const uint32_t texel = y * (uint32_t)p.fw + x;
+    const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
     BinTexel<MODE> d{};
-    if (t == 0u) d.load(p, texel);
-    unsigned long long *skey = s.skey();
-    uint16_t *order = s.order();
-    if (len <= kCrowdCap) {
-        for_keys(run, len, [&](unsigned long long k, uint32_t f) { skey[f] = k; });
-        __syncthreads();
-        if (len <= kRankMaxRun) {
-            if (t < len) {
-                const unsigned long long k = skey[t];
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < len; ++j) rank += skey[j] < k ? 1u : 0u;
-                order[rank] = (uint16_t)t;
-            }
-            __syncthreads();
-        } else bin_bitonic(s, len);
-        bin_blend_long<MODE>(s, p, begin, len, 0u, d, [&](uint32_t j) { return (uint32_t)(skey[order[j]] & 0xffffffull); });
-    } else {
-        blend_texel_windows<MODE>(s, p, begin, 0u, d, [&](auto body) { for_keys(run, len, [&](unsigned long long k, uint32_t) { body(k); }); });
+    d.load(p, texel);                                          // (every lane: its own copy)
+    constexpr uint32_t kPer = kWaveRun / 64u;
+    unsigned long long mine[kPer];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; mine[q] = run[f < len ? f : len - 1u]; }
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) keys[wave][f] = mine[q]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank[kPer];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) rank[q] = 0u;
+    const uint32_t groups = (len + 63u) >> 6;                 // (uniform) key groups of 64 that exist
+    for (uint32_t j = 0; j < len; ++j) {
+        const unsigned long long k = keys[wave][j];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) if (q < groups) rank[q] += k < mine[q] ? 1u : 0u;
     }
-    if (t == 0u) d.store(p, texel);
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) ord[wave][rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float4 c0, c1;
+    fetch_colors<MODE>(p, (size_t)ord[wave][lane < len ? lane : len - 1u], c0, c1);
+    for (uint32_t j0 = 0; j0 < len; j0 += 64u) {
+        if constexpr (MODE == 1) stage_a[wave][lane] = ViewTarget::source(c0);
+        else stage_a[wave][lane] = FlowTarget::source(c0);
+        if constexpr (MODE == 2) stage_b[wave][lane] = ViewTarget::source(c1);
+        const uint32_t nx = j0 + 64u + lane;                   // the next batch's varyings, before this batch's chain
+        if (j0 + 64u < len) fetch_colors<MODE>(p, (size_t)ord[wave][nx < len ? nx : len - 1u], c0, c1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = len - j0 < 64u ? len - j0 : 64u;
+        uint32_t e = 0;
+        for (; e + 8u <= n; e += 8u) {
+            BlendSource a[8], bb[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) { a[u] = stage_a[wave][e + u]; if constexpr (MODE == 2) bb[u] = stage_b[wave][e + u]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                if constexpr (MODE == 1) ViewTarget::apply(d.v, a[u]);
+                else FlowTarget::apply(d.f, a[u]);
+                if constexpr (MODE == 2) ViewTarget::apply(d.v, bb[u]);
+            }
+        }
+        for (; e < n; ++e) {
+            if constexpr (MODE == 1) ViewTarget::apply(d.v, stage_a[wave][e]);
+            else FlowTarget::apply(d.f, stage_a[wave][e]);
+            if constexpr (MODE == 2) ViewTarget::apply(d.v, stage_b[wave][e]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // (the stage is rewritten by the next batch)
+    }
+    if (lane == 0u) d.store(p, texel);
 }
 
 }  // namespace
 
-static uint32_t slot_blocks(const DepositParams &p) { const uint32_t n = (p.W * p.rows + 255u) / 256u; return n ? n : 1u; }
-
-void launch_bins_raster(const DepositParams &p, hipStream_t s)
+void launch_bins_fused(const DepositParams &p, hipStream_t s)
 {
+    const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
     (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
-    (void)hipMemsetAsync(p.rep_hist, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(bins_raster_kernel, dim3(slot_blocks(p)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_raster_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_count_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
+    (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(bins_fused_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }
 
-void launch_bins_scan(const DepositParams &p, uint32_t *totals, hipStream_t s)
+// p.nlarge: the large bins, as the plan counted them (totals[kTotLarge])
+void launch_bins_blend(const DepositParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(bins_replica_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, s, p, totals);
-    hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p, totals);
-}
-
-void launch_bins_emit(const DepositParams &p, hipStream_t s)
-{
-    hipLaunchKernelGGL(bins_cursor_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_emit_kernel, dim3(slot_blocks(p)), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_emit_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
-}
-
-// p.nlarge / nblocks: the large bins and their kCrowdBlock-fragment blocks, as the scan counted them (totals[3], totals[4])
-void launch_bins_blend(const DepositParams &p, uint32_t nblocks, hipStream_t s)
-{
-    if (p.nlarge) {         // regroup the large bins by texel first: the two blend kernels then overlap at the tail
+    if (p.nlarge) {         // regroup the large bins by texel
         (void)hipMemsetAsync(p.crowd_count, 0, (size_t)p.nlarge * kBinTexels * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(crowd_hist_kernel, dim3(nblocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(crowd_hist_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
         hipLaunchKernelGGL(crowd_scan_kernel, dim3(p.nlarge), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(crowd_scatter_kernel, dim3(nblocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(crowd_scatter_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
     }
-#define TH_GO(M) do { if (p.nlarge) hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(p.nlarge * kBinTexels), dim3(256), 0, s, p); \
+#define TH_GO(M) do { if (p.nlarge) { hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(1024), dim3(256), 0, s, p); \
+                                        hipLaunchKernelGGL(crowd_blend_wave_kernel<M>, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p); } \
                       hipLaunchKernelGGL(bins_blend_kernel<M>, dim3(p.nbins), dim3(256), 0, s, p); } while (0)
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO
 }
-size_t crowd_words_per_bin() { return 3u * kBinTexels + 1u; }
+size_t crowd_words_per_bin() { return 4u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list
 
 }  // namespace th

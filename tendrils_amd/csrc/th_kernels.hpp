@@ -140,21 +140,23 @@ struct DepositParams {
     uint32_t owners, owner_chunk;    // ranks that own flow texels (contiguous ranges of owner_chunk texels)
     const uint32_t *row_draws;   // bit per global row of the state texture: its lines can draw at all (th_api.hip: line_rows)
     // binned pipeline (th_bins.hip): lines are walked by SLOT - cur / prev in the ring's slot order, perm[slot] = particle
-    // id (nullptr = texel order); count / record / the line lists are indexed by slot; fragments are bucketed by the
-    // 16 x 16-texel bin of the flow field they fall into
+    // id (nullptr = texel order); fragments go straight from the rasteriser into the 16 x 16-texel bin of the target they
+    // fall into.  A bin is kBinReplicas lists of pages of kBinPage places: page 0 of list r of bin b is page
+    // b * kBinReplicas + r, further pages come from a pool.
     const uint32_t *perm;
     uint32_t bins_x, nbins;
-    uint32_t *bin_hist, *bin_start;                // fragments per bin; first fragment of every bin (nbins + 1)
-    uint32_t *rep_hist, *rep_cursor;               // kBinReplicas copies of the bins' counters, bin_stride words apart: counts (then: first place of the copy in its bin); fill cursors
-    uint32_t bin_stride;
-    unsigned long long *frag_keys;                 // per fragment, bin-major: (y << 12 | x) << 32 | stream index of the line
-    uint32_t id_bits;                              // bits of a stream index: ceil(log2(W * H))
-    uint32_t *block_flags;                         // per 256-slot block: some line of it has fragments (written by the rasterising pass)
-    // ... bins of more fragments than one workgroup orders in LDS (crowd_*_kernel)
-    uint32_t *large_bins, *large_block0;           // the large bins (in any order); first workgroup block of each (+ 1)
+    uint32_t *bin_cursor, bin_stride;              // per list (r * bin_stride + bin): places handed out so far (virtual indices inside the list)
+    uint32_t *page_table;                          // per list x kBinMaxPages: page id of the list's n-th page, n >= 1 (0: not handed out yet)
+    uint32_t pool_pages;                           // pages in the pool: ids nbins * kBinReplicas .. + pool_pages - 1
+    uint32_t *totals;                              // device words (th_bins.hip: kTot*)
+    unsigned long long *frag_keys;                 // per place, chunk-major: (y << 12 | x) << 32 | stream index of the line; ~0 = empty
+    // ... bins of more places than one workgroup orders in LDS (crowd_*_kernel)
+    uint32_t *large_bins, *large_key0;             // the large bins (in any order); first regrouped key of each (+ 1)
     uint32_t nlarge;
     uint32_t *crowd_count, *crowd_start, *crowd_cursor;   // per large bin: fragments per texel (256), first of every texel (257), fill cursors (256)
-    unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 24 | position of its varying in the bin
+    unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 32 | place of its varying
+    uint32_t *crowd_long;                          // texels of large bins whose runs one wave does not order (large bin << 8 | texel)
+    uint32_t exp;                                  // experiment switches (TH_EXP, th_api.hip); 0 = the product
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
@@ -204,13 +206,16 @@ void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t st
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t stream);
 // binned pipeline (th_bins.hip)
 constexpr int kBinShift = 4;                       // 16 x 16 texel bins
-constexpr uint32_t kBinReplicas = 32;              // copies of the bins' global counters (th_bins.hip: rep_word)
+constexpr uint32_t kBinCap = 4096;                 // places of a bin that one workgroup orders in LDS
+constexpr uint32_t kBinReplicas = 16;              // lists per bin (th_bins.hip)
+constexpr uint32_t kBinPage = 256;                 // places per page
+constexpr uint32_t kBinMaxPages = 128;             // pages one list can grow to (half a million places per bin)
 constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits per texel coordinate
-constexpr uint32_t kBinsMaxPerBin = 1u << 24;      // a fragment's position inside its bin rides in 24 key bits while it is sorted
-void launch_bins_raster(const DepositParams &p, hipStream_t stream);                  // count + record per slot, fragments per bin
-void launch_bins_scan(const DepositParams &p, uint32_t *totals, hipStream_t stream);  // totals[0] = fragments, [2] = largest bin, [3] = large bins, [4] = their blocks
-void launch_bins_emit(const DepositParams &p, hipStream_t stream);                    // fragments into their bins
-void launch_bins_blend(const DepositParams &p, uint32_t nblocks, hipStream_t stream);   // per bin: sort by (texel, stream index), blend
+// totals[]: device words of one pass
+enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotBlocks = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWords = 8 };
+enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
+void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
+void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // per bin: order by (texel, stream index), blend
 size_t crowd_words_per_bin();
 // RCCL side of a context (th_comm.hip; librccl bound at run time).  Every function returns 0 or leaves comm_error().
 const char *comm_error();

@@ -345,6 +345,53 @@ TH_D void dep_raster_small_hexagon(const DepositParams &p, const int (&PX)[6], c
     }
 }
 
+// ... the same spans with TWO divisions per row instead of six: every row of a polygon whose vertices run once up and once
+// down in y is crossed by exactly one edge going up and one going down (half-open row ranges [ceil(Y1/16), ceil(Y2/16)):
+// the edges of a chain take the rows in turn), so the row first selects its two edges - in vertex order, a later edge
+// over an earlier one, as the span assignment above does - and then divides.  Same quotients, same spans.
+template <typename Emit>
+TH_D void dep_raster_small_hexagon2(const DepositParams &p, const int (&PX)[6], const int (&PY)[6], int ymin, int ymax, Emit emit)
+{
+    int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
+    if (r0 < 0) r0 = 0;
+    if (r1 > p.fh) r1 = p.fh;
+    int X1[6], Y1[6], DX[6], DY[6], e0[6], en[6];
+    bool up[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int kn = k == 5 ? 0 : k + 1;
+        const int Xa = PX[k], Ya = PY[k], Xb = PX[kn], Yb = PY[kn];
+        const bool swap = Yb < Ya;
+        up[k] = !swap;
+        X1[k] = swap ? Xb : Xa; Y1[k] = swap ? Yb : Ya;
+        DX[k] = (swap ? Xa : Xb) - X1[k]; DY[k] = (swap ? Ya : Yb) - Y1[k];
+        e0[k] = (Y1[k] + 15) >> 4; en[k] = ((Y1[k] + DY[k] + 15) >> 4) - e0[k];           // rows [e0, e0 + en); none for Ya == Yb
+    }
+    auto ceil_at = [&](int y, int x1, int y1, int dx, int dy) {
+        const int den = dy > 0 ? 16 * dy : 16;
+        const int num = dx * ((y << 4) - y1) + x1 * dy;
+        int q = (int)__builtin_floorf((float)num * __builtin_amdgcn_rcpf((float)den));
+        int r = num - q * den;
+        if (r < 0) { --q; r += den; }
+        if (r >= den) { ++q; r -= den; }
+        int x = r > 0 ? q + 1 : q;
+        return x < 0 ? 0 : (x > p.fw ? p.fw : x);
+    };
+    for (int y = r0; y < r1; ++y) {
+        int lx = 0, ly = 0, ldx = 0, ldy = 0, rx = 0, ry = 0, rdx = 0, rdy = 0;
+        bool hl = false, hr = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const bool crosses = (unsigned)(y - e0[k]) < (unsigned)en[k];
+            const bool l = crosses && up[k], r = crosses && !up[k];
+            lx = l ? X1[k] : lx; ly = l ? Y1[k] : ly; ldx = l ? DX[k] : ldx; ldy = l ? DY[k] : ldy; hl = hl || l;
+            rx = r ? X1[k] : rx; ry = r ? Y1[k] : ry; rdx = r ? DX[k] : rdx; rdy = r ? DY[k] : rdy; hr = hr || r;
+        }
+        const int left = hl ? ceil_at(y, lx, ly, ldx, ldy) : p.fw, right = hr ? ceil_at(y, rx, ry, rdx, rdy) : 0;
+        for (int x = left; x < right; ++x) emit(x, y);
+    }
+}
+
 // a line, whichever way it has to go: straight from its hexagon, or clipped first
 template <typename Emit>
 TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
