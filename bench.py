@@ -809,8 +809,8 @@ def main():
 def frame_loop(t, ctx, state, frames=20):
     """SURVEY.md 8f-1/8f-2 beside the headline: the reference's frame loop - timer.tick(), step(), draw() - on the same
     particles: one single-step launch, the flow pass of draw() (the particle lines blended into the flow field in GL
-    primitive order: rasterise, scan, emit, stable sort by texel, gather, blend) and the view pass (the same lines into
-    the RGBA8 view buffer), each timed with a HIP event pair on the context's stream."""
+    primitive order) and the view pass (the same lines into the RGBA8 view buffer), each timed with a HIP event pair
+    on the context's stream."""
     from tendrils_amd import _capi
     ms = C.c_float()
 
@@ -841,19 +841,31 @@ def frame_loop(t, ctx, state, frames=20):
         both_ms.append(timed(t.draw))
     t.renderView = keep
     lines, f = state.shape[0] * state.shape[1], float(np.mean(frags))
-    # per line: two state texels in the rasterising and in the emitting pass (64 B), count / offset / scan (24 B);
-    # per fragment: key + varying written (20 B), three radix passes over key + position (48 B), gather (36 B), blend (20 B)
-    alg = lines * 88.0 + f * 124.0
+    texels = FLOW_W * FLOW_H
+    # the binned pipeline (th_bins.hip; what `auto` runs over tile-sorted slots).  Per slot: the particle id (4 B); per line that
+    # can draw (half of the rows: state-at-frame.glsl reads `current` twice in the others): two state texels (32 B); per
+    # fragment: key + varying written (24 B) and read once where its bin is put in order (24 B); the target read and written (32 B
+    # per texel).  Round 2's pipeline (three radix passes + a gather between emit and blend) moved 88 B per line + 124 B per
+    # fragment: its model is kept beside for the comparison across rounds.
+    alg = lines * 4.0 + lines * 0.5 * 32.0 + f * 48.0 + texels * 32.0
+    alg_r2 = lines * 88.0 + f * 124.0
     d = float(np.mean(flow_ms))
     return {"frames": frames, "step_ms": float(np.mean(step_ms)), "draw_flow_ms": d, "draw_view_ms": float(np.mean(view_ms)), "draw_both_ms": float(np.mean(both_ms)),
             "fragments_per_draw": f, "frames_per_s": 1e3 / (float(np.mean(step_ms)) + d),
-            "roofline": {"bound": "hbm", "kernel": "flow pass of draw() (9 kernels + 3 sort passes)", "achieved": alg / d / 1e6,
+            "frame_ms_reference_loop": float(np.mean(step_ms)) + float(np.mean(both_ms)),
+            "pipeline": "binned (th_bins.hip): particles stay in the integrator's tile-sorted slot order; one fused rasterise + emit pass into "
+                        "16x16-texel bins of the target, per-bin ordering by (texel, stream index) and blending in LDS",
+            "roofline": {"bound": "hbm", "kernel": "flow pass of draw(): bins_fused_kernel + per-bin blend kernels", "achieved": alg / d / 1e6,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / d / 1e6 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_draw": alg,
-                         "achieved_is": "88 B per line + 124 B per fragment (DESIGN.md 3.4) / mean duration of the pass"},
-            "note": "timer.tick(); step(); draw(): one single-step launch + the flow pass; the view pass timed separately "
-                    "(th_view_draw after th_flow_deposit: it reuses the flow pass's rasterisation and sort), and both passes in "
-                    "one call (th_draw, what Tendrils.draw() runs with renderView) over 5 more frames"}
+                         "achieved_is": "4 B per slot + 32 B per drawable line + 48 B per fragment + 32 B per target texel / mean duration of the pass "
+                                        "(the pass is bound by the rasteriser's integer arithmetic and by latency, not by bytes: DESIGN.md 3.4)",
+                         "r2_model": {"algorithmic_bytes_per_draw": alg_r2, "achieved": alg_r2 / d / 1e6, "frac": alg_r2 / d / 1e6 / HBM_PEAK_GBS,
+                                      "note": "round 2's byte model (88 B per line + 124 B per fragment: what the stream-ordered pipeline moves) over "
+                                              "this round's duration - comparable with round 2's frame_loop.roofline.frac"}},
+            "note": "timer.tick(); step(); draw(): one single-step launch over tile-sorted slots + the flow pass; the view pass timed separately "
+                    "(th_view_draw after th_flow_deposit: a full pass of its own in the binned pipeline), and both passes in one call "
+                    "(th_draw, what Tendrils.draw() runs with renderView: one rasterisation, two varyings per fragment) over 5 more frames"}
 
 
 def cpu_baseline(t, width, rows_avail):

@@ -1300,7 +1300,10 @@ static bool draw_uses_bins(th_context *c)
     const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : draw_policy();
     if (policy == 0) return false;
     if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
-    return policy == 1;      // (auto: the stream-ordered pipeline until the binned one is the faster of the two)
+    if (policy == 1) return true;
+    // auto: wherever the integrator steps over tile-sorted slots the frame loop - step(); draw() - stays on them (the
+    // binned pipeline takes particles in any order and is the faster of the two there: DESIGN.md 3.4)
+    return sorting_possible(c);
 }
 
 // ring[1] into ring[0]'s slot order (through texel order): only when a draw meets the two in different orders - a
@@ -1544,7 +1547,7 @@ static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool p
     (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors);
     c->bins_keys = nullptr; c->bins_colors = nullptr;
     pool = pool > c->bins_pool ? pool : c->bins_pool;
-    pairs = pairs || c->bins_pairs;
+    pairs = true;           // (room for both varyings of a th_draw from the start: growing the store later costs a frame)
     c->bins_pool = 0; c->bins_store_bins = 0;
     const size_t places = ((size_t)nbins * th::kBinReplicas + pool) * th::kBinPage;
     TH_REQUIRE(places < ((size_t)1 << 32), "the binned draw's chunk store would hold 2^32 places or more");

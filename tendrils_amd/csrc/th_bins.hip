@@ -124,7 +124,6 @@ constexpr uint32_t kResv = 2048;             // LDS table entries: >= 4 bins x 2
 struct Reservations {
     uint32_t tag[kResv];                     // bin + 1 (0: free)
     uint32_t sum[kResv];                     // places reserved by the workgroup's lines; after the flush: the first of them
-    uint32_t frags;                          // fragments written by the workgroup
     uint32_t any;
 };
 // n places of `bin` for the calling line -> entry << 20 | offset inside the workgroup's share
@@ -175,17 +174,22 @@ TH_D uint32_t place_single(const DepositParams &p, uint32_t bin, uint32_t rep)
 __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
 {
     __shared__ Reservations t;
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x, slots = p.W * p.rows;
+    const uint32_t slots = p.W * p.rows, blocks = (slots + 255u) / 256u;
+    // (the workgroups walk the blocks of 256 slots with the stride of the grid: a grid of a few workgroups per CU stays
+    // resident for the whole pass instead of 65 536 short-lived ones waiting to be dispatched)
+    for (uint32_t block = blockIdx.x; block < blocks; block += gridDim.x) {
+    const uint32_t s = block * 256u + threadIdx.x;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);
     // In the tile-sorted order the particles whose lines can draw lie apart from the others inside every tile
-    // (th_kernels.hip: tile_key): most workgroups meet only one kind - whole waves of lines that exist, or nothing to do.
-    if (threadIdx.x == 0u) { t.any = 0u; t.frags = 0u; }
+    // (th_kernels.hip: tile_key): most blocks meet only one kind - whole waves of lines that exist, or nothing to do.
+    __syncthreads();                                    // (the block before is done with the table)
+    if (threadIdx.x == 0u) t.any = 0u;
     for (uint32_t e = threadIdx.x; e < kResv; e += 256u) { t.tag[e] = 0u; t.sum[e] = 0u; }
     __syncthreads();
     if (can && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(can)))) t.any = 1u;
     __syncthreads();
-    if (t.any == 0u) return;
+    if (t.any == 0u) continue;
 
     float4 own[2];                                      // (both ends of the line, before anything else)
     if (can) { own[0] = p.cur[s]; own[1] = p.prev[s]; }
@@ -214,11 +218,11 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
     uint32_t took0 = 0, took1 = 0;
     if (n) took0 = resv_take(t, q.b0, q.c0);
     if (q.c1) took1 = resv_take(t, q.b1, q.c1);
-    dep_list_append(p, kListSlow, blockIdx.x, slow, s);
+    dep_list_append(p, kListSlow, block, slow, s);
     __syncthreads();
-    // the workgroup's share of every bin it met: one atomic each on the cursor of the workgroup's list of that bin; the
+    // the block's share of every bin it met: one atomic each on the cursor of the block's list of that bin; the
     // pages that start inside it are taken from the pool
-    const uint32_t rep = blockIdx.x & (kBinReplicas - 1u);
+    const uint32_t rep = block & (kBinReplicas - 1u);
     for (uint32_t e = threadIdx.x; e < kResv; e += 256u) {
         const uint32_t tag = t.tag[e];
         if (tag == 0u) continue;
@@ -248,13 +252,7 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
                 bins_put(p, L, id, at, (int)x, (int)y);
             }
     }
-    // fragments of the pass: one atomic per workgroup
-    uint32_t written = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) written += __shfl_xor(written, o);
-    if (__lane_id() == 0u && written) atomicAdd(&t.frags, written);
-    __syncthreads();
-    if (threadIdx.x == 0u && t.frags) atomicAdd(&p.totals[kTotFragments], t.frags);
+    }
 }
 
 // ... and the lines of the slow list (hexagons that cross the view's edge or need 64-bit edges, lines of more fragments than
@@ -263,7 +261,6 @@ __global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
 {
     dep_list_work(p, kListSlow, [&](bool have, uint32_t s, uint32_t seg) {
         const uint32_t rep = seg & (kBinReplicas - 1u);
-        uint32_t written = 0;
         if (have) {
             uint32_t col, row;
             slot_particle(p, s, col, row);
@@ -272,12 +269,8 @@ __global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
             const uint32_t id = col * p.H + p.row0 + row;
             dep_raster_line(p, L, [&](int x, int y) {
                 bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
-                ++written;
             });
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) written += __shfl_xor(written, o);
-        if (__lane_id() == 0u && written) atomicAdd(&p.totals[kTotFragments], written);
     });
 }
 
@@ -290,12 +283,21 @@ TH_D uint32_t bin_places(const DepositParams &p, uint32_t b)
     return n > 0xffffffffull ? 0xffffffffu : (uint32_t)n;
 }
 
-// pass 2: the bins of more places than one workgroup orders in LDS
+// pass 2: the bins of more places than one workgroup orders in LDS; the fragments of the pass (every place handed out holds
+// one: no hot counter in the pass itself)
 __global__ __launch_bounds__(256) void bins_plan_kernel(const DepositParams p)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b >= p.nbins) return;
-    if (bin_places(p, b) > kBinCap) p.large_bins[atomicAdd(&p.totals[kTotLarge], 1u)] = b;       // (in whatever order)
+    const uint32_t n = b < p.nbins ? bin_places(p, b) : 0u;
+    if (n > kBinCap) p.large_bins[atomicAdd(&p.totals[kTotLarge], 1u)] = b;       // (in whatever order)
+    unsigned long long sum = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (__lane_id() == 0u && sum) {
+        const unsigned long long cap = 0xffffffffull;
+        const uint32_t old = atomicAdd(&p.totals[kTotFragments], (uint32_t)(sum > cap ? cap : sum));
+        if ((unsigned long long)old + sum > cap) bins_flag(p, kBinsBinFull);
+    }
 }
 
 // ---- pass 3: one workgroup per bin -----------------------------------------------------------------------------
@@ -935,7 +937,8 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
     (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
     (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(bins_fused_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    const uint32_t per_cu = (p.exp >> 8) & 0xffu, grid = per_cu ? 256u * per_cu : blocks;     // (experiment: a resident grid; slower)
+    hipLaunchKernelGGL(bins_fused_kernel, dim3(blocks < grid ? (blocks ? blocks : 1u) : grid), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
