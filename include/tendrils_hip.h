@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 7
+#define TH_ABI_VERSION 8
 
 typedef int32_t th_status;
 enum {
@@ -253,6 +253,14 @@ th_status th_deposit_merge(th_context *ctx, const void *keys_dev, const void *co
  * by the caller, read by the next th_deposit_emit; NULL = none).  Without them such a lookup fails the emit. */
 th_status th_deposit_set_halo(th_context *ctx, const void *lo_dev, const void *hi_dev);
 th_status th_flow_device_ptr(th_context *ctx, void **dptr);
+/* Best-sample spawning from the PARTICLE texture (spawnData = particles.buffers[k], src/demo.main.js:433-441) reads arbitrary
+ * particles: on a row-band shard th_spawn_sample / th_spawn_direct read them from a copy of the WHOLE texture
+ * (width x global_height RGBA32F) of ring buffer `buffer`, valid until that buffer is written again:
+ *  th_state_gather    : every rank, collectively (needs th_comm_init; balanced bands): all-gather over RCCL on the context's stream
+ *  th_state_gather_ptr: the copy's device address, for a host that fills it by its own means (another transport, several
+ *                       contexts on one device). */
+th_status th_state_gather(th_context *ctx, int32_t buffer);
+th_status th_state_gather_ptr(th_context *ctx, int32_t buffer, void **dptr);
 
 /* -- statistics, sync, interop ---------------------------------------------- */
 th_status th_stats(th_context *ctx, float speed_limit, th_counters *out);   /* of buffers[0]; synchronises */
@@ -324,6 +332,13 @@ th_status th_view_download(th_context *ctx, uint8_t *rgba8);           /* flow-s
 th_status th_colormap_upload(th_context *ctx, const float *rgba, int32_t w, int32_t h);
 /* th_export_lines with the view pass's vertex colours in place of the flow varyings */
 th_status th_export_view_lines(th_context *ctx, const th_render_uniforms *u, float *lines, uint64_t capacity, uint64_t *count);
+/* The view pass of a row-band shard (src/index.js:315-337), the same way: th_view_emit = this band's fragments with the render
+ * shader's colours (src/render/index.vert:58-100), parted by owner; th_view_merge = the owner's fragments blended into
+ * this context's view buffer in (texel, stream index) order - for the owned texels the unsharded view pass byte for byte;
+ * th_view_device_ptr = the RGBA8 view buffer (flow shape) whose owned ranges the ranks then gather. */
+th_status th_view_emit(th_context *ctx, const th_render_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev);
+th_status th_view_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
+th_status th_view_device_ptr(th_context *ctx, void **dptr);
 
 /* Slot layout of the ring (build-defined, invisible in every result): how many ring buffers are held in a
  * tile-sorted slot order, integrator passes since the last sort, and the flow taps since then that left the

@@ -135,6 +135,11 @@ PROTOTYPES = {
     "th_deposit_set_owners": (C.c_int32, [_ctx, C.c_int32]),
     "th_deposit_merge": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64]),
     "th_flow_device_ptr": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
+    "th_view_emit": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "th_view_merge": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "th_view_device_ptr": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
+    "th_state_gather": (C.c_int32, [_ctx, C.c_int32]),
+    "th_state_gather_ptr": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_void_p)]),
     "th_stats": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),
     "th_stats_async": (C.c_int32, [_ctx, C.c_float, C.POINTER(C.c_void_p)]),
     "th_comm_unique_id": (C.c_int32, [C.c_void_p]),

@@ -124,6 +124,8 @@ struct th_context {
     unsigned int *d_flag = nullptr;
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
+    float4 *gathered = nullptr;          // row-band shard: a copy of the WHOLE particle texture (th_state_gather / _ptr) ...
+    const void *gathered_of = nullptr;   // ... of this ring buffer, for the spawners that sample arbitrary particles
     void *comm = nullptr;                // RCCL communicator of the job's ranks (th_comm_init), one rank per context
     int32_t comm_rank = 0, comm_world = 1;
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
@@ -585,7 +587,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
     (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
-    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys);
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->gathered);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -1193,12 +1195,17 @@ static th_status spawn_from_data(th_context *c, const th_spawn_sample_uniforms *
         TH_REQUIRE(c->image, "no spawn image (call th_spawn_image_upload)");
         p.data = c->image; p.dw = c->iw; p.dh = c->ih;
     } else if (source >= 0 && source < (int32_t)c->ring.size()) {
-        if (c->cfg.height != c->cfg.global_height)
-            return fail(TH_ERR_UNSUPPORTED, "sampling the particle texture needs the whole texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
         float4 *data = nullptr;
-        if (source == 1) data = particles;
+        if (c->cfg.height != c->cfg.global_height) {
+            // a row-band shard: the pass samples ARBITRARY particles (src/demo.main.js:433-441) - from the copy of the whole
+            // texture the ranks gathered beforehand (th_state_gather, or a host's own transport through th_state_gather_ptr)
+            TH_REQUIRE(c->gathered && c->gathered_of == (const void *)c->ring[(size_t)source],
+                       "sampling the particle texture on a row-band shard (%d of %d rows) reads every band: gather buffer %d first (th_state_gather / th_state_gather_ptr)",
+                       c->cfg.height, c->cfg.global_height, source);
+            data = c->gathered;
+        } else if (source == 1) data = particles;
         else if (th_status s = unpacked_view(c, c->ring[source], 2, &data)) return s;
-        p.data = data; p.dw = c->cfg.width; p.dh = c->cfg.height;
+        p.data = data; p.dw = c->cfg.width; p.dh = c->cfg.global_height;
     } else return fail(TH_ERR_INVALID, "bad spawnData source %d", source);
     p.count = (uint32_t)c->texels(); p.width = (uint32_t)c->cfg.width; p.row0 = (uint32_t)c->cfg.row0;
     p.wf = (float)c->cfg.width; p.hf = (float)c->cfg.global_height;
@@ -1663,7 +1670,7 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
     if (th_status s = use(c)) return s;
     TH_REQUIRE(du && ru, "null uniforms");
     if (c->cfg.height != c->cfg.global_height)
-        return fail(TH_ERR_UNSUPPORTED, "draw on a row-band shard (%d of %d rows): the flow pass goes through th_deposit_emit / th_deposit_merge, the view pass needs the whole texture", c->cfg.height, c->cfg.global_height);
+        return fail(TH_ERR_UNSUPPORTED, "draw on a row-band shard (%d of %d rows): the passes go through th_deposit_emit / th_deposit_merge and th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
     TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
                memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
                "the two passes of one draw share viewSize, time and speedLimit");
@@ -1685,7 +1692,7 @@ th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fra
 {
     if (th_status s = use(c, true)) return s;
     if (c->cfg.height != c->cfg.global_height)
-        return fail(TH_ERR_UNSUPPORTED, "the view pass needs the whole particle texture on this context (row-band shard holds %d of %d rows)", c->cfg.height, c->cfg.global_height);
+        return fail(TH_ERR_UNSUPPORTED, "view pass on a row-band shard (%d of %d rows): use th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
     if (th_status s = view_storage(c)) return s;
     for (int pass = 0;; ++pass) {
         th::DepositParams p;
@@ -1759,14 +1766,9 @@ th_status th_deposit_set_owners(th_context *c, int32_t world)
     return TH_OK;
 }
 
-th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev)
+// the (counted) fragments of this band's lines, keyed (owner, texel, global stream index) and parted by owner
+static th_status emit_parted(th_context *c, th::DepositParams &p, uint32_t total, uint64_t *count, void **keys_dev, void **colors_dev)
 {
-    if (th_status s = use(c)) return s;
-    TH_REQUIRE(count && keys_dev && colors_dev, "null outputs");
-    TH_REQUIRE((uint64_t)c->fw * c->fh <= (uint64_t)th::kTexelMask + 1u, "the sharded deposit keys hold 24 texel bits: flow %dx%d is too large", c->fw, c->fh);
-    th::DepositParams p;
-    uint32_t total = 0;
-    if (th_status s = deposit_count(c, u, p, &total)) return s;
     *count = total; *keys_dev = nullptr; *colors_dev = nullptr;
     if (total == 0) return TH_OK;
     if (th_status s = deposit_reserve(c, total, true)) return s;
@@ -1791,6 +1793,31 @@ th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t 
     return TH_OK;
 }
 
+th_status th_deposit_emit(th_context *c, const th_deposit_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count && keys_dev && colors_dev, "null outputs");
+    TH_REQUIRE((uint64_t)c->fw * c->fh <= (uint64_t)th::kTexelMask + 1u, "the sharded deposit keys hold 24 texel bits: flow %dx%d is too large", c->fw, c->fh);
+    th::DepositParams p;
+    uint32_t total = 0;
+    if (th_status s = deposit_count(c, u, p, &total)) return s;
+    return emit_parted(c, p, total, count, keys_dev, colors_dev);
+}
+
+// the view pass of a row-band shard: the same lines with the render shader's colours
+th_status th_view_emit(th_context *c, const th_render_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count && keys_dev && colors_dev, "null outputs");
+    TH_REQUIRE((uint64_t)c->fw * c->fh <= (uint64_t)th::kTexelMask + 1u, "the sharded deposit keys hold 24 texel bits: view %dx%d is too large", c->fw, c->fh);
+    th::DepositParams p;
+    if (th_status s = view_params(c, u, p)) return s;
+    th::launch_deposit_count(p, c->stream);
+    uint32_t total = 0;
+    if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    return emit_parted(c, p, total, count, keys_dev, colors_dev);
+}
+
 th_status th_deposit_set_halo(th_context *c, const void *lo_dev, const void *hi_dev)
 {
     TH_REQUIRE(c, "null context");
@@ -1799,9 +1826,8 @@ th_status th_deposit_set_halo(th_context *c, const void *lo_dev, const void *hi_
     return TH_OK;
 }
 
-th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
+static th_status merge_parted(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count, bool into_view)
 {
-    if (th_status s = use(c)) return s;
     if (count == 0) return TH_OK;
     TH_REQUIRE(keys_dev && colors_dev && count < (1ull << 31), "bad fragment buffers");
     const uint32_t total = (uint32_t)count;
@@ -1826,13 +1852,39 @@ th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colo
     // (the sort ping-pongs between its two buffer pairs: the caller's keys are copied, not sorted in place)
     TH_HIP(hipMemcpyAsync(c->mrg_keys, keys_dev, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
     const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 32, bits, c->dep_temp, true, c->stream);
-    th::launch_deposit_blend64(c->flow, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
-                               static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
+    if (into_view)
+        th::launch_view_blend64(c->view, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
+                                static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
+    else
+        th::launch_deposit_blend64(c->flow, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
+                                   static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
     TH_HIP(hipGetLastError());
     uint32_t too_many = 0;
     TH_HIP(hipMemcpyAsync(&too_many, c->dep_total, sizeof too_many, hipMemcpyDeviceToHost, c->stream));
     TH_HIP(hipStreamSynchronize(c->stream));               // the input buffers may be reused by the caller now
-    if (too_many) return fail(TH_ERR_UNSUPPORTED, "a flow texel received fragments of more than 32 source bands");
+    if (too_many) return fail(TH_ERR_UNSUPPORTED, "a texel received fragments of more than 32 source bands");
+    return TH_OK;
+}
+
+th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
+{
+    if (th_status s = use(c)) return s;
+    return merge_parted(c, keys_dev, colors_dev, count, false);
+}
+
+th_status th_view_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
+{
+    if (th_status s = use(c, true)) return s;
+    if (th_status s = view_storage(c)) return s;
+    return merge_parted(c, keys_dev, colors_dev, count, true);
+}
+
+th_status th_view_device_ptr(th_context *c, void **dptr)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(dptr, "null output");
+    if (th_status s = view_storage(c)) return s;
+    *dptr = c->view;
     return TH_OK;
 }
 
@@ -1950,6 +2002,50 @@ th_status th_comm_query(th_context *c, th_comm_info *out)
     out->rank = c->comm_rank; out->world = c->comm_world; out->active = c->comm ? 1 : 0;
     int v = 0;
     if (th::comm_available(&v) == 0) out->rccl_version = v;
+    return TH_OK;
+}
+
+// ---- row-band shards: the whole particle texture on every rank, for the spawners that sample arbitrary particles ----------
+static th_status gather_storage(th_context *c, int32_t buffer)
+{
+    TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer %d (ring has %zu)", buffer, c->ring.size());
+    if (!c->gathered) TH_HIP(hipMalloc((void **)&c->gathered, (size_t)c->cfg.width * c->cfg.global_height * sizeof(float4)));
+    c->gathered_of = nullptr;
+    return TH_OK;
+}
+
+th_status th_state_gather_ptr(th_context *c, int32_t buffer, void **dptr)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(dptr, "null output");
+    if (th_status s = gather_storage(c, buffer)) return s;
+    c->gathered_of = c->ring[(size_t)buffer];
+    *dptr = c->gathered;
+    return TH_OK;
+}
+
+th_status th_state_gather(th_context *c, int32_t buffer)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(c->comm, "th_state_gather needs the job's communicator (th_comm_init)");
+    if (th_status s = gather_storage(c, buffer)) return s;
+    if (th_status s = ensure_identity(c)) return s;          // bands travel in texel order
+    // the bands of sharding.shard_rows: contiguous, balanced (the first H % world ranks hold one row more)
+    const int world = c->comm_world, H = c->cfg.global_height, base = H / world, extra = H % world;
+    std::vector<size_t> bytes((size_t)world), offset((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        const int rows = base + (r < extra ? 1 : 0), row0 = r * base + (r < extra ? r : extra);
+        bytes[(size_t)r] = (size_t)rows * c->cfg.width * sizeof(float4);
+        offset[(size_t)r] = (size_t)row0 * c->cfg.width * sizeof(float4);
+        if (r == c->comm_rank)
+            TH_REQUIRE(rows == c->cfg.height && row0 == c->cfg.row0, "this context holds rows %d..%d, rank %d of %d balanced bands holds %d..%d",
+                       c->cfg.row0, c->cfg.row0 + c->cfg.height, r, world, row0, row0 + rows);
+    }
+    float4 *data = nullptr;
+    if (th_status s = unpacked_view(c, c->ring[(size_t)buffer], 2, &data)) return s;
+    if (th::comm_allgather_bytes(c->comm, data, c->gathered, bytes.data(), offset.data(), c->comm_rank, world, c->stream))
+        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    c->gathered_of = c->ring[(size_t)buffer];
     return TH_OK;
 }
 

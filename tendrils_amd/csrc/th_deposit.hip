@@ -617,6 +617,16 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
                        (const float4 *)colors_sorted, 1u, total, too_many);
 }
 
+// ... and the view pass of a row-band shard: the same merge into the RGBA8 view buffer
+void launch_view_blend64(uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
+                         const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t s)
+{
+    if (!total) return;
+    launch_deposit_gather_colors(colors_sorted, colors, slots_sorted, total, s);
+    hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, BandKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, view, BandKeys{keys_sorted},
+                       (const float4 *)colors_sorted, 1u, total, too_many);
+}
+
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
 {
     const dim3 grid(deposit_grid(total));

@@ -721,6 +721,72 @@ napi_value StateDevicePtr(napi_env env, napi_callback_info info)
     return make_bigint(env, p);
 }
 
+// viewEmit(ctx, Float32Array th_render_uniforms) -> { count, keys: address, colors: address }  (row-band shard: the view pass's fragments)
+napi_value ViewEmit(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_render_uniforms u;
+    a.uniforms(1, &u);
+    if (!a.ok) BAD_ARGS("th_view_emit");
+    uint64_t count = 0;
+    void *keys = nullptr, *colors = nullptr;
+    TH_CALL("th_view_emit", th_view_emit(c, &u, &count, &keys, &colors));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_double(env, (double)count, &v));
+    NAPI_OK(napi_set_named_property(env, o, "count", v));
+    NAPI_OK(napi_set_named_property(env, o, "keys", make_bigint(env, keys)));
+    NAPI_OK(napi_set_named_property(env, o, "colors", make_bigint(env, colors)));
+    return o;
+}
+
+// viewMerge(ctx, keysAddress, colorsAddress, count)
+napi_value ViewMerge(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    void *keys = nullptr, *colors = nullptr;
+    const double count = a.f64(3);
+    if (!a.ok || !bigint_ptr(env, a.argv[1], &keys) || !bigint_ptr(env, a.argv[2], &colors) || count < 0) BAD_ARGS("th_view_merge");
+    TH_CALL("th_view_merge", th_view_merge(c, keys, colors, (uint64_t)count));
+    return undefined(env);
+}
+
+// viewDevicePtr(ctx) -> address of the RGBA8 view buffer
+napi_value ViewDevicePtr(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_view_device_ptr");
+    void *p = nullptr;
+    TH_CALL("th_view_device_ptr", th_view_device_ptr(c, &p));
+    return make_bigint(env, p);
+}
+
+// stateGather(ctx, buffer): the whole particle texture of ring buffer `buffer` on every rank (RCCL all-gather; needs commInit)
+napi_value StateGather(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    const int32_t buffer = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_state_gather");
+    TH_CALL("th_state_gather", th_state_gather(c, buffer));
+    return undefined(env);
+}
+
+// stateGatherPtr(ctx, buffer) -> address of that copy, for a host with its own transport
+napi_value StateGatherPtr(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    const int32_t buffer = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_state_gather_ptr");
+    void *p = nullptr;
+    TH_CALL("th_state_gather_ptr", th_state_gather_ptr(c, buffer, &p));
+    return make_bigint(env, p);
+}
+
 napi_value TimerStart(napi_env env, napi_callback_info info)
 {
     Args a(env, info);
@@ -803,6 +869,8 @@ napi_value Init(napi_env env, napi_value exports)
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline},
         {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
+        {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"viewDevicePtr", ViewDevicePtr},
+        {"stateGather", StateGather}, {"stateGatherPtr", StateGatherPtr},
     };
     for (auto &e : table) {
         napi_value fn;

@@ -190,9 +190,79 @@ def flow_view(tendrils):
     return device_view(ptr.value, (fw * fh, 4), "<f4")
 
 
-def draw_sharded(dist, tendrils):
-    """Tendrils.draw() (flow pass) for a row-band shard of a torch.distributed job (backend nccl = RCCL).
-    One exchange step: fragment all-to-all by flow-texel owner, then an all-gather of the owned flow ranges."""
+def emit_view_fragments(tendrils):
+    """th_view_emit on this rank's context -> (keys int64[n], colors float32[n, 4]) views (or empty tensors): the view
+    pass's fragments of this band's lines, parted by owner like the flow pass's."""
+    import torch
+    from . import _capi
+    u = tendrils.render_uniforms()
+    n, kp, cp = C.c_uint64(0), C.c_void_p(), C.c_void_p()
+    _capi.call("th_view_emit", tendrils.particles._ctx, C.byref(u), C.byref(n), C.byref(kp), C.byref(cp))
+    if n.value == 0:
+        return torch.empty(0, dtype=torch.int64, device="cuda"), torch.empty((0, 4), dtype=torch.float32, device="cuda")
+    return device_view(kp.value, (n.value,), "<i8"), device_view(cp.value, (n.value, 4), "<f4")
+
+
+def merge_view_fragments(tendrils, keys, colors):
+    from . import _capi
+    if keys.numel():
+        assert keys.is_contiguous() and colors.is_contiguous()
+        _capi.call("th_view_merge", tendrils.particles._ctx, C.c_void_p(keys.data_ptr()), C.c_void_p(colors.data_ptr()),
+                   C.c_uint64(keys.numel()))
+
+
+def view_view(tendrils):
+    """the context's RGBA8 view buffer as a [texels, 4] uint8 tensor"""
+    from . import _capi
+    fw, fh = tendrils.flow.shape
+    ptr = C.c_void_p()
+    _capi.call("th_view_device_ptr", tendrils.particles._ctx, C.byref(ptr))
+    return device_view(ptr.value, (fw * fh, 4), "|u1")
+
+
+def gather_state(tendrils, buffer=0):
+    """Row-band shard: the whole particle texture of ring buffer `buffer` on every rank (th_state_gather: the library's RCCL
+    all-gather; needs sharding.comm_init), for the spawners that sample arbitrary particles (src/demo.main.js:433-441)."""
+    from . import _capi
+    index = buffer.index if hasattr(buffer, "index") else int(buffer)
+    _capi.call("th_state_gather", tendrils.particles._ctx, index)
+
+
+def _exchange(dist, keys, colors, texels):
+    """the owners' all-to-all: every part of (keys, colors) to its owner; returns what this rank received"""
+    import torch
+    world = dist.get_world_size()
+    send = split_by_owner(keys, texels, world)
+    send_t = torch.tensor(send, dtype=torch.int64, device="cuda")
+    recv_t = torch.empty_like(send_t)
+    dist.all_to_all_single(recv_t, send_t)
+    recv = [int(v) for v in recv_t.tolist()]
+    rkeys = torch.empty(sum(recv), dtype=torch.int64, device="cuda")
+    rcolors = torch.empty((sum(recv), 4), dtype=torch.float32, device="cuda")
+    dist.all_to_all_single(rkeys, keys.contiguous(), recv, send)
+    dist.all_to_all_single(rcolors, colors.contiguous(), recv, send)
+    torch.cuda.synchronize()
+    return rkeys, rcolors
+
+
+def _gather_owned(dist, plane, texels):
+    """every owner's texel range of `plane` ([texels, k]) to every rank (equal chunks: the tail padded)"""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    chunk = owner_chunk(texels, world)
+    mine = torch.zeros((chunk, plane.shape[1]), dtype=plane.dtype, device="cuda")
+    lo, hi = min(rank * chunk, texels), min((rank + 1) * chunk, texels)
+    mine[:hi - lo] = plane[lo:hi]
+    gathered = torch.empty((world * chunk, plane.shape[1]), dtype=plane.dtype, device="cuda")
+    dist.all_gather_into_tensor(gathered, mine)
+    plane.copy_(gathered[:texels])
+    torch.cuda.synchronize()
+
+
+def draw_sharded(dist, tendrils, view=False):
+    """Tendrils.draw() for a row-band shard of a torch.distributed job (backend nccl = RCCL): the flow pass and - `view` -
+    the view pass (after the clear / fade the caller applied to its copy of the view buffer, the same on every rank).
+    One exchange step per pass: fragment all-to-all by texel owner, then an all-gather of the owned ranges."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     fw, fh = tendrils.flow.shape
@@ -210,25 +280,13 @@ def draw_sharded(dist, tendrils):
     set_halo(tendrils, lo, hi)
     set_owners(tendrils, world)
     keys, colors = emit_fragments(tendrils)
-    send = split_by_owner(keys, texels, world)
-    send_t = torch.tensor(send, dtype=torch.int64, device="cuda")
-    recv_t = torch.empty_like(send_t)
-    dist.all_to_all_single(recv_t, send_t)
-    recv = [int(v) for v in recv_t.tolist()]
-    rkeys = torch.empty(sum(recv), dtype=torch.int64, device="cuda")
-    rcolors = torch.empty((sum(recv), 4), dtype=torch.float32, device="cuda")
-    dist.all_to_all_single(rkeys, keys.contiguous(), recv, send)
-    dist.all_to_all_single(rcolors, colors.contiguous(), recv, send)
-    torch.cuda.synchronize()
+    fragments = int(keys.numel())
+    rkeys, rcolors = _exchange(dist, keys, colors, texels)
     merge_fragments(tendrils, rkeys, rcolors)
-    # owned ranges -> every rank's flow texture (equal chunks: pad the tail)
-    chunk = owner_chunk(texels, world)
-    flow = flow_view(tendrils)
-    mine = torch.zeros((chunk, 4), dtype=torch.float32, device="cuda")
-    lo, hi = min(rank * chunk, texels), min((rank + 1) * chunk, texels)
-    mine[:hi - lo] = flow[lo:hi]
-    gathered = torch.empty((world * chunk, 4), dtype=torch.float32, device="cuda")
-    dist.all_gather_into_tensor(gathered, mine)
-    flow.copy_(gathered[:texels])
-    torch.cuda.synchronize()
-    return int(keys.numel())
+    _gather_owned(dist, flow_view(tendrils), texels)
+    if view:
+        keys, colors = emit_view_fragments(tendrils)
+        rkeys, rcolors = _exchange(dist, keys, colors, texels)
+        merge_view_fragments(tendrils, rkeys, rcolors)
+        _gather_owned(dist, view_view(tendrils), texels)
+    return fragments

@@ -278,9 +278,15 @@ class Tendrils:
         """The flow pass - particle lines into the flow texture, so that particles respond to each other's wake - and,
         with renderView, the view pass: the same lines into the RGBA8 view buffer (after the clear / fade the state
         asks for).  Both passes draw the same lines: one call rasterises and sorts them once (th_draw)."""
-        if self.dist is not None:          # row-band shard of a torch.distributed job: emit / exchange / merge
+        if self.dist is not None:          # row-band shard of a torch.distributed job: emit / exchange / merge, pass by pass
             from .sharding import draw_sharded
-            self.fragments = draw_sharded(self.dist, self)
+            if self.renderView:            # (every rank holds the whole view buffer: the clear / fade are the same everywhere)
+                if self.state["autoClearView"]:
+                    self.clearView()
+                if self.state["autoFade"]:
+                    self.drawFade()
+            self.fragments = draw_sharded(self.dist, self, view=self.renderView)
+            self.view_fragments = self.fragments if self.renderView else 0
             return self
         if not self.renderView:
             self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])

@@ -85,3 +85,31 @@ p.dispose();
     assert out["idBytes"] == 128 and out["before"]["active"] == 0 and out["after"]["active"] == 0
     assert out["q"]["active"] == 1 and out["q"]["world"] == 1 and out["q"]["rcclVersion"] > 0
     assert out["g"] == out["l"] and out["g"]["live"] == 64 * 64 and abs(out["g"]["sumSpeed"] - 64 * 64 * 0.005) < 1e-3
+
+
+def test_state_gather_over_the_librarys_communicator():
+    """th_state_gather (the whole particle texture on every rank, for the spawners that sample arbitrary particles) over a
+    world of one: the copy equals the band, and a particle-texture best-sample pass on the 'shard' equals the plain one."""
+    import torch
+    from tendrils_amd import _capi, sharding
+    from tendrils_amd.sharding import comm_id
+    from tendrils_amd.spawn import PixelSpawner, data_sample_frag
+    from helpers import bits_equal
+    outs = []
+    for gathered in (False, True):
+        t = make(96)
+        ctx = t.particles._ctx
+        if gathered:
+            buf = (C.c_ubyte * _capi.COMM_ID_BYTES).from_buffer_copy(comm_id())
+            _capi.call("th_comm_init", ctx, buf, 0, 1)
+            sharding.gather_state(t, 0)
+            ptr = C.c_void_p()
+            _capi.call("th_state_gather_ptr", ctx, 0, C.byref(ptr))      # (the same buffer: what the gather left there)
+            copy = sharding.device_view(ptr.value, (96, 96, 4), "<f4").cpu().numpy()
+            assert bits_equal(copy, t.particles.read(0)).all()
+        sp = PixelSpawner(None, dict(shader=data_sample_frag(), buffer=t.particles.buffers[0], spawnSize=[0.8, 0.8], speed=0.01, bias=0.3))
+        t.timer.time = 480.0
+        sp.spawn(t)
+        outs.append(t.particles.read(0))
+        t.dispose()
+    assert bits_equal(outs[0], outs[1]).all()

@@ -125,6 +125,17 @@ def test_draw_sharded_through_rccl_world_size_1(oracle):
         assert sharding.draw_sharded(dist, t) == frags
         assert bits_equal(t.flow.read(), want).all()
         t.dispose()
+        # ... and Tendrils.draw() of a sharded job with renderView: flow pass + view pass, against the local th_draw
+        local = make_shard(n, view, 0, n, cur, prev, base, 700.0)
+        local.draw()
+        t = make_shard(n, view, 0, n, cur, prev, base, 700.0)
+        t.dist = dist
+        t.draw()
+        assert t.fragments == local.fragments == frags and t.view_fragments == frags
+        assert bits_equal(t.flow.read(), local.flow.read()).all()
+        assert (t.read_view() == local.read_view()).all() and t.read_view().any()
+        t.dispose()
+        local.dispose()
     finally:
         dist.destroy_process_group()
 
@@ -199,3 +210,117 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BUCKET="1", TH_RESORT_STEPS="2", PYTHONPATH=ROOT),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("n,view,world", [(64, (96, 54), 2), (128, (48, 27), 3)])
+def test_sharded_view_pass_equals_unsharded(n, view, world):
+    """The view pass of draw() on row-band shards (th_view_emit / th_view_merge, the owners' exchange by hand as above):
+    every shard's view buffer ends up byte-identical to the unsharded th_view_draw - crowded texels with fragments of every
+    band included - also on top of an earlier frame (a translucent fade in between)."""
+    torch = pytest.importorskip("torch")
+    from tendrils_amd import sharding
+    rng = np.random.default_rng(7 * n + world)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.5, 0.5, (n, n, 2)) * [1.0, view[1] / view[0]]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    fw, fh = view
+    base = np.zeros((fh, fw, 4), np.float32)
+    time = 2500.0
+
+    def frame(t):
+        """what Tendrils.draw() does to the view before its lines: the fade"""
+        t.state["autoClearView"] = False
+        t.state["autoFade"] = True
+        t.drawFade()
+
+    whole = make_shard(n, view, 0, n, cur, prev, base, time)
+    shards = []
+    for r in range(world):
+        row0, rows = sharding.shard_rows(n, world, r)
+        shards.append(make_shard(n, view, row0, rows, cur, prev, base, time))
+    texels = fw * fh
+    chunk = sharding.owner_chunk(texels, world)
+    for t in shards:
+        sharding.set_owners(t, world)
+    import ctypes as C
+    from tendrils_amd import _capi
+    for rep in range(2):                       # the second frame blends over the first one's pixels
+        frame(whole)
+        u, nf = whole.render_uniforms(), C.c_uint64(0)
+        _capi.call("th_view_draw", whole.particles._ctx, C.byref(u), C.byref(nf))
+        want = whole.read_view()
+        for t in shards:
+            frame(t)
+        emitted = [sharding.emit_view_fragments(t) for t in shards]
+        assert sum(int(k.numel()) for k, _ in emitted) == nf.value > 1000
+        sends = [sharding.split_by_owner(k, texels, world) for k, _ in emitted]
+        for d, t in enumerate(shards):
+            parts_k, parts_c = [], []
+            for s, (keys, colors) in enumerate(emitted):
+                lo = sum(sends[s][:d])
+                parts_k.append(keys[lo:lo + sends[s][d]].clone())
+                parts_c.append(colors[lo:lo + sends[s][d]].clone())
+            sharding.merge_view_fragments(t, torch.cat(parts_k).contiguous(), torch.cat(parts_c).contiguous())
+        views = [sharding.view_view(t) for t in shards]
+        owned = [views[d][min(d * chunk, texels):min((d + 1) * chunk, texels)].clone() for d in range(world)]
+        for v in views:
+            v.copy_(torch.cat(owned))
+        torch.cuda.synchronize()
+        for t in shards:
+            got = t.read_view()
+            assert (got == want).all() and got.any()
+    for t in shards + [whole]:
+        t.dispose()
+
+
+def test_particle_texture_sampling_on_shards_equals_unsharded():
+    """Best-sample spawning from the PARTICLE texture (src/demo.main.js:433-441) reads arbitrary particles: a row-band shard
+    reads them from a copy of the whole texture (th_state_gather_ptr, filled here by hand - th_state_gather is the same
+    copy over RCCL); every band comes out as the band of the unsharded pass, bit for bit.  Without the copy: an error that
+    says what to do."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    import tendrils_amd as ta
+    from tendrils_amd import _capi, sharding
+    from tendrils_amd.spawn import PixelSpawner, data_sample_frag
+    n, view, world = 96, (64, 36), 3
+    rng = np.random.default_rng(19)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.02, .02, (n, n, 2)) * (rng.random((n, n, 1)) < 0.5)
+    base = np.zeros((36, 64, 4), np.float32)
+
+    def spawn(t):
+        sp = PixelSpawner(None, dict(shader=data_sample_frag(), buffer=t.particles.buffers[0], spawnSize=[0.8, 0.8], speed=0.01, bias=0.3))
+        sp.jitter = [0.003, 0.002]
+        t.timer.time = 480.0
+        sp.spawn(t)
+
+    whole = make_shard(n, view, 0, n, st, st, base, 500.0)
+    spawn(whole)
+    want = whole.particles.read(0)
+    assert not bits_equal(want, st).all()
+    whole.dispose()
+    shards = []
+    for r in range(world):
+        row0, rows = sharding.shard_rows(n, world, r)
+        shards.append((row0, rows, make_shard(n, view, row0, rows, st, st, base, 500.0)))
+    with pytest.raises(ta.TendrilsHipError) as e:
+        spawn(shards[1][2])
+    assert "th_state_gather" in str(e.value)
+    full = torch.from_numpy(st).cuda().contiguous()
+    for row0, rows, t in shards:
+        t2 = make_shard(n, view, row0, rows, st, st, base, 500.0)        # (the failed attempt above ticked the timer)
+        ptr = C.c_void_p()
+        _capi.call("th_state_gather_ptr", t2.particles._ctx, 0, C.byref(ptr))
+        sharding.device_view(ptr.value, (n, n, 4), "<f4").copy_(full)
+        torch.cuda.synchronize()
+        spawn(t2)
+        got = t2.particles.read(0)
+        assert bits_equal(got, want[row0:row0 + rows]).all()
+        t2.dispose()
+        t.dispose()
