@@ -786,7 +786,10 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %s: %s" % (type(e).__name__, e)}
     job.dispose()
-    if args.config == "c3" and not args.no_c4 and not args.flow_size:
+    if under_profiler and args.config == "c3" and not args.no_c4:
+        # (a kernel-trace of this command should average the headline's launches, not mix them with config 4's)
+        line["c4"] = {"skipped": "under a profiler: run without it (or --config c4) for the config-4 leg"}
+    elif args.config == "c3" and not args.no_c4 and not args.flow_size:
         # (every rank takes part; a failure on one rank would hang the others in a collective: the leg runs the same
         # code path as the headline, so what it can still fail on - memory - fails on every rank alike)
         try:

@@ -293,6 +293,9 @@ th_status th_comm_query(th_context *ctx, th_comm_info *out);
 th_status th_stats_allreduce(th_context *ctx);
 th_status th_stats_global(th_context *ctx, float speed_limit, th_counters *out);
 th_status th_stream(th_context *ctx, void **hip_stream);               /* hipStream_t of the context */
+/* Device address of ring buffer `buffer` (RGBA32F / packed texels in texel order; valid until the ring rotates or re-sorts).
+ * The call itself invalidates the line geometry th_view_draw would reuse from the last th_flow_deposit; a host that WRITES
+ * through the address later must hand out the address again (or call any state entry point) before the next th_view_draw. */
 th_status th_state_device_ptr(th_context *ctx, int32_t buffer, void **dptr);
 /* HIP-event timing on the context's own stream (for bench.py / profilers). */
 th_status th_timer_start(th_context *ctx);

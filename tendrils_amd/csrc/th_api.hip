@@ -1395,8 +1395,6 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     TH_HIP(hipMemsetAsync(c->dep_total, 0, 8 * sizeof(uint32_t), c->stream));
     if (th_status s = line_rows(c)) return s;
     p.row_draws = c->d_row_draws;
-    static const uint32_t exp_flags = [] { const char *e = getenv("TH_EXP"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
-    p.exp = exp_flags;
     if (use_bins) {
         const int o = order_of(c, c->ring[0]);
         p.perm = o >= 0 ? c->orders[(size_t)o].perm : nullptr;
@@ -1761,7 +1759,9 @@ th_status th_export_view_lines(th_context *c, const th_render_uniforms *u, float
 th_status th_deposit_set_owners(th_context *c, int32_t world)
 {
     TH_REQUIRE(c, "null context");
-    TH_REQUIRE(world >= 1 && world <= 64, "owner count %d outside [1, 64]", world);
+    // (the owner's merge walks up to 32 source bands per texel - th_deposit.hip: kMaxBands: more ranks than that could only be
+    // refused after the blend had begun)
+    TH_REQUIRE(world >= 1 && world <= 32, "owner count %d outside [1, 32]", world);
     c->dep_owners = (uint32_t)world;
     return TH_OK;
 }
@@ -2091,6 +2091,8 @@ th_status th_state_device_ptr(th_context *c, int32_t buffer, void **dptr)
     if (moved) TH_HIP(hipStreamSynchronize(c->stream));
     TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
     *dptr = c->ring[buffer];
+    // (use() above dropped the geometry a view pass would reuse from the last flow pass: whoever holds this address may write
+    // the state behind the library's back - after such a write, call any state entry point, or th_sync, before th_view_draw)
     return TH_OK;
 }
 

@@ -206,8 +206,7 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
                 int PX[6], PY[6], ymin, ymax;
                 dep_snap_hexagon(p, cx, cy, PX, PY);
                 if (dep_hexagon_is_small(PX, PY, ymin, ymax)) {
-                    if (p.exp & 4u) dep_raster_small_hexagon(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
-                    else dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
+                    dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
                 } else slow = true;
             } else if (where == kHexClip) slow = true;
         }
@@ -937,8 +936,9 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
     (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
     (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
-    const uint32_t per_cu = (p.exp >> 8) & 0xffu, grid = per_cu ? 256u * per_cu : blocks;     // (experiment: a resident grid; slower)
-    hipLaunchKernelGGL(bins_fused_kernel, dim3(blocks < grid ? (blocks ? blocks : 1u) : grid), dim3(256), 0, s, p);
+    // (one short workgroup per 256 slots: a resident grid of 4 / 8 / 16 workgroups per CU walking the blocks was 1.08 / 0.86 /
+    // 0.84 ms against 0.68-0.76, profiles/r3_b_*)
+    hipLaunchKernelGGL(bins_fused_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);

@@ -156,7 +156,6 @@ struct DepositParams {
     uint32_t *crowd_count, *crowd_start, *crowd_cursor;   // per large bin: fragments per texel (256), first of every texel (257), fill cursors (256)
     unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 32 | place of its varying
     uint32_t *crowd_long;                          // texels of large bins whose runs one wave does not order (large bin << 8 | texel)
-    uint32_t exp;                                  // experiment switches (TH_EXP, th_api.hip); 0 = the product
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)

@@ -1,5 +1,7 @@
 #!/bin/bash
 # same-box comparison of several library builds: interleaved rounds. usage: gpu_abn.sh MODE lib1 lib2 ...
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 MODE=$1; shift
 for r in 1 2 3; do
   for lib in "$@"; do

@@ -1,5 +1,7 @@
 #!/bin/bash
 # draw(): new lib vs libtendrils_hip_old.so on the same box, interleaved; 300 frames (the wake has formed: long runs)
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 L=tendrils_amd/lib
 cp $L/libtendrils_hip.so /tmp/new.so
 timeout 600 python -m pytest tests/test_gpu_deposit.py tests/test_gpu_view.py tests/test_gpu_fuzz.py tests/test_gpu_deposit_sharded.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2

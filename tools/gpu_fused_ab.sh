@@ -1,5 +1,7 @@
 #!/bin/bash
 # whole-job bench line + fused probe: new lib vs libtendrils_hip_old.so on the same box, interleaved
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p gpurun_out/r2
 L=tendrils_amd/lib
 cp $L/libtendrils_hip.so /tmp/new.so

@@ -1,5 +1,7 @@
 #!/bin/bash
 # regime matrix: layout x arithmetic x data distribution (per-launch logic_kernel ms)
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for data in "" "--in-view"; do
  for b in 0 1; do
   for m in "--mode exact" "--mode fast" "--flow-only --steps 40 --warmup 4"; do

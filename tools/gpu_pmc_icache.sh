@@ -1,5 +1,7 @@
 #!/bin/bash
 # instruction-fetch counters of the single-step probe
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2/pmc_icache
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

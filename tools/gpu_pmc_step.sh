@@ -1,5 +1,7 @@
 #!/bin/bash
 # PMC passes over the single-step probe. usage: gpu_pmc_step.sh TAG [env...]
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-x}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2/pmc_$TAG
 mkdir -p $OUT

@@ -1,4 +1,6 @@
 #!/bin/bash
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p gpurun_out/r2
 cd /tmp && export TMPDIR=/tmp
 PROBE_STEPS=32 TH_RESORT_STEPS=8 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2/trace_sorted -- python3 $GRAFT_REPO_ROOT/tools/step_probe.py > $GRAFT_REPO_ROOT/gpurun_out/r2/trace_sorted.log 2>&1

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round-2 evidence for the single-step launch: loop timings, kernel trace, PMC passes
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p gpurun_out/r2
 O=gpurun_out/r2/r2_e_single_step.txt
 {

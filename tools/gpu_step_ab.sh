@@ -1,5 +1,7 @@
 #!/bin/bash
 # single-step kernel: new lib vs libtendrils_hip_old.so on the same box
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p gpurun_out/r2
 L=tendrils_amd/lib
 timeout 400 python -m pytest tests/test_gpu_bucketed.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -3

@@ -1,4 +1,6 @@
 #!/bin/bash
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-dep}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2/trace_$TAG
 mkdir -p $OUT

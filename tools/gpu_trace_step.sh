@@ -1,5 +1,7 @@
 #!/bin/bash
 # kernel-trace stats of the single-step probe: gpu_trace_step.sh TAG [probe args]
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2/trace_$TAG
 mkdir -p $OUT

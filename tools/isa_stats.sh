@@ -1,5 +1,7 @@
 #!/bin/bash
 # ISA of one kernel (default: the exact fused integrator) and an instruction histogram of its step loop
+set -u
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 K=${1:-_ZN2th18logic_fused_kernelILb0ELb1ELb0ELb1ELb0EEEvNS_11LogicParamsE}
 cd "$(dirname "$0")/../tendrils_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I../../include -S --cuda-device-only -o /tmp/th_kernels.s th_kernels.hip 2>/dev/null
