@@ -1343,10 +1343,12 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
     bool use_bins = want_bins && draw_uses_bins(c);
-    if (use_bins && any_sorted(c)) {
+    if (use_bins) {
+        // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
+        // another particle (line_rows) keep to the stream-ordered pipeline in texel order
         if (th_status s = line_rows(c)) return s;
-        if (c->lines_local != 1) use_bins = false;           // a vertex of another particle: only texel order can address it
-        else if (th_status s = align_slot_orders(c)) return s;
+        if (c->lines_local != 1) use_bins = false;
+        else if (any_sorted(c)) { if (th_status s = align_slot_orders(c)) return s; }
     }
     if (bins) *bins = use_bins;
     if (use_bins) c->last_binned_draw = c->total_steps;

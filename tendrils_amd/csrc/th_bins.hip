@@ -120,20 +120,21 @@ TH_D bool slot_particle(const DepositParams &p, uint32_t s, uint32_t &col, uint3
 }
 
 // ---- the reservations of a workgroup's lines, by bin ----------------------------------------------------------------------
-constexpr uint32_t kResv = 2048;             // LDS table entries: >= 4 bins x 256 lines, so linear probing always finds a free one
+template <uint32_t N>                       // (a power of two)
 struct Reservations {
-    uint32_t tag[kResv];                     // bin + 1 (0: free)
-    uint32_t sum[kResv];                     // places reserved by the workgroup's lines; after the flush: the first of them
+    uint32_t tag[N];                         // bin + 1 (0: free)
+    uint32_t sum[N];                         // places reserved by the workgroup's lines; after the flush: the first of them
     uint32_t any;
 };
 // n places of `bin` for the calling line -> entry << 20 | offset inside the workgroup's share
-TH_D uint32_t resv_take(Reservations &t, uint32_t bin, uint32_t n)
+template <uint32_t N>
+TH_D uint32_t resv_take(Reservations<N> &t, uint32_t bin, uint32_t n)
 {
-    uint32_t h = (bin * 2654435761u) >> 21;
+    uint32_t h = ((bin * 2654435761u) >> 8) & (N - 1u);
     for (;;) {
         const uint32_t old = atomicCAS(&t.tag[h], 0u, bin + 1u);
         if (old == 0u || old == bin + 1u) break;
-        h = (h + 1u) & (kResv - 1u);
+        h = (h + 1u) & (N - 1u);
     }
     return (h << 20) | atomicAdd(&t.sum[h], n);
 }
@@ -171,21 +172,23 @@ TH_D uint32_t place_single(const DepositParams &p, uint32_t bin, uint32_t rep)
 
 // pass 1.  Per slot: the line set up, classified, and - the common case: a small hexagon inside the view, all in registers -
 // rasterised into a record of <= kRecordTexels texels; its places reserved per bin, exactly; its fragments written.
-__global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
+template <uint32_t BS>
+__global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 {
-    __shared__ Reservations t;
-    const uint32_t slots = p.W * p.rows, blocks = (slots + 255u) / 256u;
+    constexpr uint32_t kTab = BS * 8u;          // table entries: >= 2 bins per line and some air, so linear probing always finds a free one soon
+    __shared__ Reservations<kTab> t;
+    const uint32_t slots = p.W * p.rows, blocks = (slots + BS - 1u) / BS;
     // (the workgroups walk the blocks of 256 slots with the stride of the grid: a grid of a few workgroups per CU stays
     // resident for the whole pass instead of 65 536 short-lived ones waiting to be dispatched)
     for (uint32_t block = blockIdx.x; block < blocks; block += gridDim.x) {
-    const uint32_t s = block * 256u + threadIdx.x;
+    const uint32_t s = block * BS + threadIdx.x;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);
     // In the tile-sorted order the particles whose lines can draw lie apart from the others inside every tile
     // (th_kernels.hip: tile_key): most blocks meet only one kind - whole waves of lines that exist, or nothing to do.
     __syncthreads();                                    // (the block before is done with the table)
     if (threadIdx.x == 0u) t.any = 0u;
-    for (uint32_t e = threadIdx.x; e < kResv; e += 256u) { t.tag[e] = 0u; t.sum[e] = 0u; }
+    for (uint32_t e = threadIdx.x; e < kTab; e += BS) { t.tag[e] = 0u; t.sum[e] = 0u; }
     __syncthreads();
     if (can && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(can)))) t.any = 1u;
     __syncthreads();
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
     LineRecord r{};
     bool slow = false;
     if (can) {
-        dep_setup(p, col, p.row0 + row, L, s, own);
+        dep_setup(p, col, p.row0 + row, L, s, own, false);          // (the varyings: once the line is known to cover a texel)
         if (L.draws) {
             float cx[6], cy[6];
             const int where = dep_hexagon(p, L, cx, cy);
@@ -211,18 +214,20 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
             } else if (where == kHexClip) slow = true;
         }
     }
-    if (r.n > kRecordTexels) { slow = true; r.n = 0u; }      // more fragments than a record holds: fragment by fragment
+    const bool lengthy = r.n > kRecordTexels;                // more fragments than a record holds: the long list
+    if (lengthy) r.n = 0u;
     const uint32_t n = r.n;
     const LineBins q = line_bins(p, r.r, n);
     uint32_t took0 = 0, took1 = 0;
     if (n) took0 = resv_take(t, q.b0, q.c0);
     if (q.c1) took1 = resv_take(t, q.b1, q.c1);
     dep_list_append(p, kListSlow, block, slow, s);
+    dep_list_append(p, kListLong, block, lengthy, s);
     __syncthreads();
     // the block's share of every bin it met: one atomic each on the cursor of the block's list of that bin; the
     // pages that start inside it are taken from the pool
     const uint32_t rep = block & (kBinReplicas - 1u);
-    for (uint32_t e = threadIdx.x; e < kResv; e += 256u) {
+    for (uint32_t e = threadIdx.x; e < kTab; e += BS) {
         const uint32_t tag = t.tag[e];
         if (tag == 0u) continue;
         const uint32_t m = t.sum[e], base = atomicAdd(list_cursor(p, tag - 1u, rep), m);
@@ -239,6 +244,9 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
         const uint32_t ga0 = page_of<true>(p, l0, pa0), gb0 = pb0 != pa0 ? page_of<true>(p, l0, pb0) : ga0;
         const uint32_t ga1 = q.c1 ? page_of<true>(p, l1, pa1) : 0u, gb1 = (q.c1 && pb1 != pa1) ? page_of<true>(p, l1, pb1) : ga1;
         const uint32_t id = col * p.H + p.row0 + row;
+        // (bins run on contexts whose every vertex reads the line's own particle: th_api.hip, lines_local)
+        dep_vertex_colors(p, L.a.from_cur ? own[0] : own[1], L.a);
+        dep_vertex_colors(p, L.b.from_cur ? own[0] : own[1], L.b);
         uint32_t i0 = 0, i1 = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kRecordTexels; ++k)
@@ -254,8 +262,10 @@ __global__ __launch_bounds__(256) void bins_fused_kernel(const DepositParams p)
     }
 }
 
-// ... and the lines of the slow list (hexagons that cross the view's edge or need 64-bit edges, lines of more fragments than
-// a record holds): one place at a time from the lists' cursors
+// ... and the lines of the slow list (hexagons that cross the view's edge or need 64-bit edges: clipped, scan-converted with
+// run-time indexed edges): one place at a time from the lists' cursors.  (Counting a line's fragments per bin first and
+// reserving them together - two rasterisations, one round trip - was slower: 115 against 92 us; the pass is bound by the
+// general rasteriser, not by its atomics.)
 __global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
 {
     dep_list_work(p, kListSlow, [&](bool have, uint32_t s, uint32_t seg) {
@@ -267,6 +277,30 @@ __global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
             dep_setup(p, col, p.row0 + row, L, s);
             const uint32_t id = col * p.H + p.row0 + row;
             dep_raster_line(p, L, [&](int x, int y) {
+                bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
+            });
+        }
+    });
+}
+
+// ... and the lines of the long list: small hexagons inside the view like the rest, only with more fragments than a record
+// holds - the same register-resident rasteriser, every fragment straight to a place of its own
+__global__ __launch_bounds__(256) void bins_long_kernel(const DepositParams p)
+{
+    dep_list_work(p, kListLong, [&](bool have, uint32_t s, uint32_t seg) {
+        const uint32_t rep = seg & (kBinReplicas - 1u);
+        if (have) {
+            uint32_t col, row;
+            slot_particle(p, s, col, row);
+            DepositLine L;
+            dep_setup(p, col, p.row0 + row, L, s);
+            const uint32_t id = col * p.H + p.row0 + row;
+            float cx[6], cy[6];
+            int PX[6], PY[6], ymin, ymax;
+            dep_hexagon(p, L, cx, cy);                       // (inside and small: the fused pass said so)
+            dep_snap_hexagon(p, cx, cy, PX, PY);
+            dep_hexagon_is_small(PX, PY, ymin, ymax);
+            dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) {
                 bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
             });
         }
@@ -936,9 +970,11 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
     (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
     (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
-    // (one short workgroup per 256 slots: a resident grid of 4 / 8 / 16 workgroups per CU walking the blocks was 1.08 / 0.86 /
-    // 0.84 ms against 0.68-0.76, profiles/r3_b_*)
-    hipLaunchKernelGGL(bins_fused_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    // (one short workgroup per 256 slots.  Measured and not kept, profiles/r3_b_fused_pass_experiments.txt: a resident grid of
+    // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
+    // per SIMD instead of 4)
+    hipLaunchKernelGGL(bins_fused_kernel<256u>, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);

@@ -14,6 +14,8 @@ struct DepositVertex {
     float px, py;      // clip-space position (w = 1)
     float c[4];        // varying: (vel.x, vel.y, time, min(|vel|/speedLimit, 1)) - or the view pass's colour (mode 1)
     float c2[4];       // mode 2 (both passes of draw() in one): the view pass's colour beside the flow pass's varying
+    bool from_cur;     // the vertex reads `current` (else `previous`)
+    float uvx, uvy;    // its coordinates in the vertex stream (the colour map is looked up there)
 };
 
 TH_D int dep_nearest(float u, int n)       // NEAREST + CLAMP_TO_EDGE on a float texture
@@ -72,7 +74,18 @@ TH_D void dep_render_color(const DepositParams &p, float4 state, float uvx, floa
 // the ring's slot order): a vertex that is the line's own particle - every vertex, for shapes whose LUT does not drift
 // off the line's texel (th_api.hip: lines_are_local) - is read at own_at; in texel order own_at is the texel index anyway.
 // `own`: (optional) the own particle's texels of cur and prev, already loaded.
-TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at, const float4 *own = nullptr)
+// the varyings of a vertex from its state texel `t` (dep_fetch computes them unless told to leave them for later: a pass that
+// rasterises first needs them only for the lines that cover a texel at all)
+TH_D void dep_vertex_colors(const DepositParams &p, float4 t, DepositVertex &v)
+{
+    if (p.mode != 1) {
+        v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
+        v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
+        if (p.mode == 2) dep_render_color(p, t, v.uvx, v.uvy, v.c2);
+    } else dep_render_color(p, t, v.uvx, v.uvy, v.c);
+}
+
+TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at, const float4 *own = nullptr, bool colors = true)
 {
     const int W = (int)p.W, H = (int)p.H;
     const float uvx = (float)((double)i * p.inv_x), uvy = (float)((double)j * p.inv_y);   // Float32Array of JS doubles
@@ -101,11 +114,8 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uin
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
     v.py = t.y * p.view_y;
-    if (p.mode != 1) {
-        v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
-        v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
-        if (p.mode == 2) dep_render_color(p, t, uvx, uvy, v.c2);
-    } else dep_render_color(p, t, uvx, uvy, v.c);
+    v.from_cur = offset > 0.25f; v.uvx = uvx; v.uvy = uvy;
+    if (colors) dep_vertex_colors(p, t, v);
     return v;
 }
 
@@ -128,13 +138,13 @@ struct DepositLine {
 };
 
 // everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
-TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const float4 *own = nullptr)
+TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const float4 *own = nullptr, bool colors = true)
 {
     L.draws = false;
     L.short32 = false;
     L.n = 0;
-    L.a = dep_fetch(p, i, 2u * m, m - p.row0, own_at, own);
-    L.b = dep_fetch(p, i, 2u * m + 1u, m - p.row0, own_at, own);
+    L.a = dep_fetch(p, i, 2u * m, m - p.row0, own_at, own, colors);
+    L.b = dep_fetch(p, i, 2u * m + 1u, m - p.row0, own_at, own, colors);
     if (!L.a.live || !L.b.live) return;                                  // see the header: inert vertex = no line
     const float fw = (float)p.fw, fh = (float)p.fh;
     const float dx = (0.5f * fw) * (L.b.px - L.a.px), dy = (0.5f * fh) * (L.b.py - L.a.py);
@@ -367,11 +377,13 @@ TH_D void dep_raster_small_hexagon2(const DepositParams &p, const int (&PX)[6], 
         DX[k] = (swap ? Xa : Xb) - X1[k]; DY[k] = (swap ? Ya : Yb) - Y1[k];
         e0[k] = (Y1[k] + 15) >> 4; en[k] = ((Y1[k] + DY[k] + 15) >> 4) - e0[k];           // rows [e0, e0 + en); none for Ya == Yb
     }
+    // (every factor fits 24 bits here - |dx| < 4096, |16 y - y1| < 2048, |x1| < 2^19, dy < 1024, |q| < 2^16, den < 2^14 -
+    // and every product 31: the 24-bit multiplier gives the same integers at the full VALU rate, v_mul_lo_u32 at a quarter)
     auto ceil_at = [&](int y, int x1, int y1, int dx, int dy) {
         const int den = dy > 0 ? 16 * dy : 16;
-        const int num = dx * ((y << 4) - y1) + x1 * dy;
+        const int num = __mul24(dx, (y << 4) - y1) + __mul24(x1, dy);
         int q = (int)__builtin_floorf((float)num * __builtin_amdgcn_rcpf((float)den));
-        int r = num - q * den;
+        int r = num - __mul24(q, den);
         if (r < 0) { --q; r += den; }
         if (r >= den) { ++q; r -= den; }
         int x = r > 0 ? q + 1 : q;
@@ -413,9 +425,10 @@ TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
 TH_D bool dep_param(const DepositLine &L, int x, int y, float &t)
 {
     if (L.short32) {        // the same integers in 32 bits (a fragment lies within a texel of its line): the same floats
-        const int ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
+        // (|ex|, |ey| < 2^14 and a fragment within a texel of its line: 24-bit factors, 30-bit sums)
+        const int ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = __mul24(ex, ex) + __mul24(ey, ey);
         if (den == 0) return false;
-        const int num = ((x << 4) - L.sx[0]) * ex + ((y << 4) - L.sy[0]) * ey;
+        const int num = __mul24((x << 4) - L.sx[0], ex) + __mul24((y << 4) - L.sy[0], ey);
         t = (float)num / (float)den;
     } else {
         const long long ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = ex * ex + ey * ey;
