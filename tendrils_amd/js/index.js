@@ -87,6 +87,8 @@ class Tendrils {
     this.device = params.device | 0;
     this.mode = params.mode | 0;
     this.stateFormat = params.stateFormat | 0;
+    // a row band of a larger texture (one process per GPU: DESIGN.md 6): rows [row0, row0 + rows) of globalHeight
+    this.band = { row0: params.row0 | 0, rows: params.rows | 0, globalHeight: params.globalHeight | 0 };
     this.colorMap = (params.colorMap || null);     // { shape: [w, h], data: Float32Array } (null = the 1x1 zero texture)
     this.renderView = (params.renderView !== false);   // draw() also runs the view pass, as the reference's does
   }
@@ -101,7 +103,7 @@ class Tendrils {
 
   setupParticles(rootNum = this.state.rootNum, numBuffers = 2) {   // src/index.js:186-210
     this.state.rootNum = rootNum;
-    const shape = [rootNum, rootNum];
+    const shape = [rootNum, this.band.rows || rootNum];
 
     if (this.particles) this.particles.dispose();
     this.particles = new Particles(this.gl, {
@@ -110,7 +112,9 @@ class Tendrils {
       logic: new Program('logic'),
       device: this.device,
       mode: this.mode,
-      stateFormat: this.stateFormat
+      stateFormat: this.stateFormat,
+      row0: this.band.row0,
+      globalHeight: this.band.globalHeight || (this.band.rows ? rootNum : 0)
     });
     this.logicShader = this.particles.logic;
     this.particles.setup(numBuffers);

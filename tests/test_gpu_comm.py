@@ -76,7 +76,13 @@ p.commInit(id, 0, 1);
 const q = p.commQuery();
 const g = p.statsGlobal(0.01), l = p.stats(0.01);
 p.commDestroy();
-console.log(JSON.stringify({ idBytes: id.length, before, q, g, l, after: p.commQuery() }));
+const { Tendrils } = require('./tendrils_amd/js');
+const t = new Tendrils({ drawingBufferWidth: 32, drawingBufferHeight: 18 }, { rows: 16, row0: 32, globalHeight: 64 });   // a row band of a 64 x 64 texture
+t.resize();
+t.setup(64);
+const band = { shape: t.particles.shape, live: t.particles.stats(0.01).particles };
+t.dispose();
+console.log(JSON.stringify({ idBytes: id.length, before, q, g, l, after: p.commQuery(), band }));
 p.dispose();
 """
     r = subprocess.run([node, "-e", script], cwd=ROOT, capture_output=True, text=True, timeout=300)
@@ -85,6 +91,7 @@ p.dispose();
     assert out["idBytes"] == 128 and out["before"]["active"] == 0 and out["after"]["active"] == 0
     assert out["q"]["active"] == 1 and out["q"]["world"] == 1 and out["q"]["rcclVersion"] > 0
     assert out["g"] == out["l"] and out["g"]["live"] == 64 * 64 and abs(out["g"]["sumSpeed"] - 64 * 64 * 0.005) < 1e-3
+    assert out["band"] == {"shape": [64, 16], "live": 64 * 16}
 
 
 def test_state_gather_over_the_librarys_communicator():
