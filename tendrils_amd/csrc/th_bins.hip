@@ -172,11 +172,24 @@ TH_D uint32_t place_single(const DepositParams &p, uint32_t bin, uint32_t rep)
 
 // pass 1.  Per slot: the line set up, classified, and - the common case: a small hexagon inside the view, all in registers -
 // rasterised into a record of <= kRecordTexels texels; its places reserved per bin, exactly; its fragments written.
-template <uint32_t BS>
+// a line's hexagon and its record while the wave's rows are dealt to its lanes (LDS, one per line of the workgroup)
+constexpr uint32_t kMaxRowsDealt = 16;       // lines of more rows (none of ordinary length: a line is <= 10 texels long) walk their own rows
+struct LineStage {
+    int PX[6], PY[6];
+    int r0;                                  // first row
+    uint32_t first;                          // first of the line's (line, row) pairs among the wave's
+    uint32_t n;                              // fragments so far
+    uint32_t rec[kRecordTexels];
+    uint32_t pad;                            // (24 words: 16-byte aligned fields)
+};
+
+template <uint32_t BS, bool DEAL>
 __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 {
-    constexpr uint32_t kTab = BS * 8u;          // table entries: >= 2 bins per line and some air, so linear probing always finds a free one soon
+    constexpr uint32_t kTab = BS * 4u;          // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly), half full at most
     __shared__ Reservations<kTab> t;
+    __shared__ LineStage stage[DEAL ? BS : 1u];
+    __shared__ uint8_t owner[DEAL ? BS / 64u : 1u][DEAL ? 64u * kMaxRowsDealt : 1u];     // per wave: the line (lane) of every dealt row
     const uint32_t slots = p.W * p.rows, blocks = (slots + BS - 1u) / BS;
     // (the workgroups walk the blocks of 256 slots with the stride of the grid: a grid of a few workgroups per CU stays
     // resident for the whole pass instead of 65 536 short-lived ones waiting to be dispatched)
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     L.draws = false;
     LineRecord r{};
     bool slow = false;
+    uint32_t dealt = 0;                                 // rows of this line handed to the wave's lanes
     if (can) {
         dep_setup(p, col, p.row0 + row, L, s, own, false);          // (the varyings: once the line is known to cover a texel)
         if (L.draws) {
@@ -209,9 +223,55 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
                 int PX[6], PY[6], ymin, ymax;
                 dep_snap_hexagon(p, cx, cy, PX, PY);
                 if (dep_hexagon_is_small(PX, PY, ymin, ymax)) {
-                    dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
+                    int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
+                    r0 = r0 < 0 ? 0 : r0; r1 = r1 > p.fh ? p.fh : r1;
+                    if (DEAL && r1 - r0 <= (int)kMaxRowsDealt) {
+                        dealt = r1 > r0 ? (uint32_t)(r1 - r0) : 0u;
+                        LineStage &g = stage[threadIdx.x];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) { g.PX[k] = PX[k]; g.PY[k] = PY[k]; }
+                        g.r0 = r0;
+                    } else dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
                 } else slow = true;
             } else if (where == kHexClip) slow = true;
+        }
+    }
+    if constexpr (DEAL) {
+        // The rows of the wave's lines, dealt evenly to its lanes: a lane rasterises ONE row of some line per round (two
+        // divisions), whatever the lengths of the lines - walking its own line's rows, a wave runs as many rounds as its
+        // longest line has rows with most lanes idle.  Wave-private LDS, no workgroup barrier.
+        const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+        uint32_t incl = dealt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((int)lane >= o) incl += up; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63), first = incl - dealt;
+        stage[threadIdx.x].first = first; stage[threadIdx.x].n = 0u;
+        for (uint32_t k = 0; k < dealt; ++k) owner[wave][first + k] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
+            const uint32_t g = g0 + lane;
+            if (g < total) {
+                LineStage &q = stage[(wave << 6) + owner[wave][g]];
+                int QX[6], QY[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { QX[k] = q.PX[k]; QY[k] = q.PY[k]; }
+                const int y = q.r0 + (int)(g - q.first);
+                int left, right;
+                dep_hexagon_row_span(p, QX, QY, y, left, right);
+                if (right > left) {
+                    uint32_t at = atomicAdd(&q.n, (uint32_t)(right - left));
+                    for (int x = left; x < right && at < kRecordTexels; ++x, ++at) q.rec[at] = (uint32_t)x | ((uint32_t)y << 16);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (dealt) {
+            const LineStage &q = stage[threadIdx.x];
+            r.n = q.n;
+#pragma unroll
+            for (uint32_t k = 0; k < kRecordTexels; ++k) r.r[k] = q.rec[k];
         }
     }
     const bool lengthy = r.n > kRecordTexels;                // more fragments than a record holds: the long list
@@ -227,13 +287,22 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     // the block's share of every bin it met: one atomic each on the cursor of the block's list of that bin; the
     // pages that start inside it are taken from the pool
     const uint32_t rep = block & (kBinReplicas - 1u);
-    for (uint32_t e = threadIdx.x; e < kTab; e += BS) {
-        const uint32_t tag = t.tag[e];
-        if (tag == 0u) continue;
-        const uint32_t m = t.sum[e], base = atomicAdd(list_cursor(p, tag - 1u, rep), m);
-        t.sum[e] = base;
-        if (base + m < base) bins_flag(p, kBinsBinFull);
-        else if (((base + m - 1u) >> kPageShift) != (base >> kPageShift) || (base & (kBinPage - 1u)) == 0u) pages_open(p, (tag - 1u) * kBinReplicas + rep, base, m);
+    {
+        // (a thread's atomics go out together: one round trip to the memory side, not one per entry)
+        constexpr uint32_t kPer = kTab / BS;
+        uint32_t tag[kPer], m[kPer], base[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) { tag[q] = t.tag[q * BS + threadIdx.x]; m[q] = t.sum[q * BS + threadIdx.x]; }
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) base[q] = tag[q] ? atomicAdd(list_cursor(p, tag[q] - 1u, rep), m[q]) : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            if (tag[q] == 0u) continue;
+            t.sum[q * BS + threadIdx.x] = base[q];
+            if (base[q] + m[q] < base[q]) bins_flag(p, kBinsBinFull);
+            else if (((base[q] + m[q] - 1u) >> kPageShift) != (base[q] >> kPageShift) || (base[q] & (kBinPage - 1u)) == 0u)
+                pages_open(p, (tag[q] - 1u) * kBinReplicas + rep, base[q], m[q]);
+        }
     }
     __syncthreads();
     if (n) {
@@ -973,7 +1042,9 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // (one short workgroup per 256 slots.  Measured and not kept, profiles/r3_b_fused_pass_experiments.txt: a resident grid of
     // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
     // per SIMD instead of 4)
-    hipLaunchKernelGGL(bins_fused_kernel<256u>, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    static const bool deal = [] { const char *e = getenv("TH_FUSED_DEAL"); return !e || atoi(e) != 0; }();     // (A/B: rows dealt to the wave's lanes)
+    if (deal) hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((bins_fused_kernel<256u, false>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);

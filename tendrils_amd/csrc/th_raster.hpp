@@ -404,6 +404,39 @@ TH_D void dep_raster_small_hexagon2(const DepositParams &p, const int (&PX)[6], 
     }
 }
 
+// ... and ONE row of it: the span [left, right) of row y of the small hexagon (the same edge selection, the same
+// quotients).  For passes that deal a wave's (line, row) pairs evenly to its lanes instead of letting every lane walk
+// the rows of its own line - a wave then runs as many rows as its lines have, not 64 times as many as its longest line.
+TH_D void dep_hexagon_row_span(const DepositParams &p, const int (&PX)[6], const int (&PY)[6], int y, int &left, int &right)
+{
+    int lx = 0, ly = 0, ldx = 0, ldy = 0, rx = 0, ry = 0, rdx = 0, rdy = 0;
+    bool hl = false, hr = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int kn = k == 5 ? 0 : k + 1;
+        const int Xa = PX[k], Ya = PY[k], Xb = PX[kn], Yb = PY[kn];
+        const bool swap = Yb < Ya;
+        const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, DX = (swap ? Xa : Xb) - X1, DY = (swap ? Ya : Yb) - Y1;
+        const int e0 = (Y1 + 15) >> 4, en = ((Y1 + DY + 15) >> 4) - e0;
+        const bool crosses = (unsigned)(y - e0) < (unsigned)en;
+        const bool l = crosses && !swap, r = crosses && swap;
+        lx = l ? X1 : lx; ly = l ? Y1 : ly; ldx = l ? DX : ldx; ldy = l ? DY : ldy; hl = hl || l;
+        rx = r ? X1 : rx; ry = r ? Y1 : ry; rdx = r ? DX : rdx; rdy = r ? DY : rdy; hr = hr || r;
+    }
+    auto ceil_at = [&](int x1, int y1, int dx, int dy) {
+        const int den = dy > 0 ? 16 * dy : 16;
+        const int num = __mul24(dx, (y << 4) - y1) + __mul24(x1, dy);
+        int q = (int)__builtin_floorf((float)num * __builtin_amdgcn_rcpf((float)den));
+        int r = num - __mul24(q, den);
+        if (r < 0) { --q; r += den; }
+        if (r >= den) { ++q; r -= den; }
+        int x = r > 0 ? q + 1 : q;
+        return x < 0 ? 0 : (x > p.fw ? p.fw : x);
+    };
+    left = hl ? ceil_at(lx, ly, ldx, ldy) : p.fw;
+    right = hr ? ceil_at(rx, ry, rdx, rdy) : 0;
+}
+
 // a line, whichever way it has to go: straight from its hexagon, or clipped first
 template <typename Emit>
 TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
