@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 8
+#define TH_ABI_VERSION 9
 
 typedef int32_t th_status;
 enum {
@@ -339,6 +339,11 @@ th_status th_export_view_lines(th_context *ctx, const th_render_uniforms *u, flo
  * shader's colours (src/render/index.vert:58-100), parted by owner; th_view_merge = the owner's fragments blended into
  * this context's view buffer in (texel, stream index) order - for the owned texels the unsharded view pass byte for byte;
  * th_view_device_ptr = the RGBA8 view buffer (flow shape) whose owned ranges the ranks then gather. */
+/* Tendrils.draw() of a row-band shard with the exchange issued by the LIBRARY over its own communicator (every rank,
+ * collectively; needs th_comm_init; balanced bands, <= 32 ranks): edge rows to the neighbours, then per pass emit ->
+ * fragment all-to-all by texel owner -> merge -> all-gather of the owned ranges, all on the context's stream (ncclSend /
+ * ncclRecv groups, ncclAllGather).  r = NULL: the flow pass only.  Same results as the primitives above driven by a host. */
+th_status th_draw_sharded(th_context *ctx, const th_deposit_uniforms *u, const th_render_uniforms *r, uint64_t *fragments);
 th_status th_view_emit(th_context *ctx, const th_render_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev);
 th_status th_view_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
 th_status th_view_device_ptr(th_context *ctx, void **dptr);

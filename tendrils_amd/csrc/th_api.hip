@@ -124,6 +124,12 @@ struct th_context {
     unsigned int *d_flag = nullptr;
     th::StatsPartial *partials = nullptr;
     th_counters *d_counters = nullptr;
+    // th_draw_sharded: the neighbours' edge rows, the owners' counts, what this rank received
+    float4 *x_halo = nullptr;            // [lo: cur row, prev row | hi: cur row, prev row], `width` texels each
+    unsigned long long *x_counts = nullptr;   // device: bounds (33) | send counts (32) | recv counts (32)
+    unsigned long long *x_keys = nullptr;
+    float4 *x_colors = nullptr;
+    size_t x_capacity = 0;
     float4 *gathered = nullptr;          // row-band shard: a copy of the WHOLE particle texture (th_state_gather / _ptr) ...
     const void *gathered_of = nullptr;   // ... of this ring buffer, for the spawners that sample arbitrary particles
     void *comm = nullptr;                // RCCL communicator of the job's ranks (th_comm_init), one rank per context
@@ -588,6 +594,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
     (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
     (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->gathered);
+    (void)hipFree(c->x_halo); (void)hipFree(c->x_counts); (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
@@ -1879,6 +1886,99 @@ th_status th_view_merge(th_context *c, const void *keys_dev, const void *colors_
     if (th_status s = use(c, true)) return s;
     if (th_status s = view_storage(c)) return s;
     return merge_parted(c, keys_dev, colors_dev, count, true);
+}
+
+// ---- draw() of a row-band shard, the exchange issued by the library over its own communicator ---------------------------------
+// One pass: this band's fragments parted by owner -> all-to-all -> the owner's merge -> all-gather of the owned ranges.
+static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
+{
+    const int world = c->comm_world, rank = c->comm_rank;
+    const bool view = ru != nullptr;
+    uint64_t count = 0;
+    void *keys = nullptr, *colors = nullptr;
+    if (th_status s = view ? th_view_emit(c, ru, &count, &keys, &colors) : th_deposit_emit(c, du, &count, &keys, &colors)) return s;
+    if (fragments) *fragments = count;
+    // every owner's share of what this rank emitted, and of what it will receive
+    unsigned long long *bounds = c->x_counts, *sendc = c->x_counts + 33, *recvc = c->x_counts + 65;
+    std::vector<unsigned long long> hb((size_t)world + 1, 0ull);
+    if (count) {
+        th::launch_owner_bounds(static_cast<const unsigned long long *>(keys), (uint32_t)count, (uint32_t)world, bounds, c->stream);
+        TH_HIP(hipMemcpyAsync(hb.data(), bounds, ((size_t)world + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));
+    }
+    std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
+    std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
+    for (int r = 0; r < world; ++r) { scount[(size_t)r] = (size_t)(hb[(size_t)r + 1] - hb[(size_t)r]); soff[(size_t)r] = (size_t)hb[(size_t)r]; hs[(size_t)r] = scount[(size_t)r]; idx[(size_t)r] = (size_t)r; }
+    TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    if (th::comm_alltoallv(c->comm, sendc, one.data(), idx.data(), recvc, one.data(), idx.data(), sizeof(unsigned long long), world, c->stream))
+        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    TH_HIP(hipMemcpyAsync(hr.data(), recvc, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    size_t total = 0;
+    for (int r = 0; r < world; ++r) { rcount[(size_t)r] = (size_t)hr[(size_t)r]; roff[(size_t)r] = total; total += rcount[(size_t)r]; }
+    TH_REQUIRE(total < ((size_t)1 << 31), "too many fragments for one owner");
+    if (c->x_capacity < total) {
+        (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
+        c->x_keys = nullptr; c->x_colors = nullptr; c->x_capacity = 0;
+        const size_t cap = total + total / 4 + 1024;
+        TH_HIP(hipMalloc((void **)&c->x_keys, cap * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->x_colors, cap * sizeof(float4)));
+        c->x_capacity = cap;
+    }
+    if (th::comm_alltoallv(c->comm, keys, scount.data(), soff.data(), c->x_keys, rcount.data(), roff.data(), sizeof(unsigned long long), world, c->stream) ||
+        th::comm_alltoallv(c->comm, colors, scount.data(), soff.data(), c->x_colors, rcount.data(), roff.data(), sizeof(float4), world, c->stream))
+        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    if (th_status s = view ? th_view_merge(c, c->x_keys, c->x_colors, total) : th_deposit_merge(c, c->x_keys, c->x_colors, total)) return s;
+    // the owners' texel ranges of the target to every rank, in place
+    const size_t texels = (size_t)c->fw * c->fh, chunk = (texels + (size_t)world - 1) / (size_t)world, elem = view ? sizeof(uchar4) : sizeof(float4);
+    std::vector<size_t> gb((size_t)world), go((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        const size_t lo = std::min(texels, (size_t)r * chunk), hi = std::min(texels, ((size_t)r + 1) * chunk);
+        gb[(size_t)r] = (hi - lo) * elem; go[(size_t)r] = lo * elem;
+    }
+    char *plane = view ? reinterpret_cast<char *>(c->view) : reinterpret_cast<char *>(c->flow);
+    if (th::comm_allgather_bytes(c->comm, plane + go[(size_t)rank], plane, gb.data(), go.data(), rank, world, c->stream))
+        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    return TH_OK;
+}
+
+th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(du, "null uniforms");
+    TH_REQUIRE(c->comm, "th_draw_sharded needs the job's communicator (th_comm_init)");
+    TH_REQUIRE(c->comm_world <= 32, "the owners' merge handles up to 32 ranks");
+    const int world = c->comm_world, rank = c->comm_rank, W = c->cfg.width;
+    if (!c->x_counts) TH_HIP(hipMalloc((void **)&c->x_counts, 97 * sizeof(unsigned long long)));
+    // the neighbouring bands' edge rows of both state buffers (the fp32 row lookup of the vertex stream can land one row
+    // beside a line's own row for some texture heights): my first row to the rank below, my last row to the rank above
+    c->halo_lo = c->halo_hi = nullptr;
+    if (world > 1 && !c->packed) {
+        if (th_status s = ensure_identity(c)) return s;
+        if (!c->x_halo) TH_HIP(hipMalloc((void **)&c->x_halo, (size_t)4 * W * sizeof(float4)));
+        std::vector<size_t> sc((size_t)world, 0), so((size_t)world, 0), rc((size_t)world, 0), ro((size_t)world, 0);
+        for (int b = 0; b < 2; ++b) {           // ring buffer b: one exchange each (the rows lie in different allocations)
+            const float4 *state = c->ring[(size_t)b];
+            std::fill(sc.begin(), sc.end(), 0); std::fill(rc.begin(), rc.end(), 0);
+            // to rank - 1: my first row (its `hi`); to rank + 1: my last row (its `lo`).  Offsets are in rows of W texels from `state`.
+            if (rank > 0) { sc[(size_t)rank - 1] = 1; so[(size_t)rank - 1] = 0; rc[(size_t)rank - 1] = 1; ro[(size_t)rank - 1] = (size_t)b; }
+            if (rank + 1 < world) { sc[(size_t)rank + 1] = 1; so[(size_t)rank + 1] = (size_t)c->cfg.height - 1; rc[(size_t)rank + 1] = 1; ro[(size_t)rank + 1] = 2 + (size_t)b; }
+            if (th::comm_alltoallv(c->comm, state, sc.data(), so.data(), c->x_halo, rc.data(), ro.data(), (size_t)W * sizeof(float4), world, c->stream))
+                return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+        }
+        c->halo_lo = rank > 0 ? c->x_halo : nullptr;
+        c->halo_hi = rank + 1 < world ? c->x_halo + (size_t)2 * W : nullptr;
+    }
+    c->dep_owners = (uint32_t)world;
+    if (th_status s = sharded_pass(c, du, nullptr, fragments)) return s;
+    if (ru) {
+        TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
+                   memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
+                   "the two passes of one draw share viewSize, time and speedLimit");
+        if (th_status s = sharded_pass(c, nullptr, ru, nullptr)) return s;
+    }
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
 }
 
 th_status th_view_device_ptr(th_context *c, void **dptr)

@@ -617,6 +617,21 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
                        (const float4 *)colors_sorted, 1u, total, too_many);
 }
 
+// first fragment of every owner's part of keys parted by owner (bounds[r] = first key with owner >= r; bounds[world] = n)
+__global__ void owner_bounds_kernel(const unsigned long long *keys, uint32_t n, uint32_t world, unsigned long long *bounds)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > world) return;
+    const unsigned long long want = (unsigned long long)r << kOwnerShift;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < want) lo = mid + 1u; else hi = mid; }
+    bounds[r] = r == world ? n : lo;
+}
+void launch_owner_bounds(const unsigned long long *keys, uint32_t n, uint32_t world, unsigned long long *bounds, hipStream_t s)
+{
+    hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys, n, world, bounds);
+}
+
 // ... and the view pass of a row-band shard: the same merge into the RGBA8 view buffer
 void launch_view_blend64(uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                          const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t s)

@@ -238,6 +238,7 @@ int launch_radix_sort_u64(unsigned long long *keys_a, uint32_t *vals_a, unsigned
 void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);
 void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                             const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);
+void launch_owner_bounds(const unsigned long long *keys, uint32_t n, uint32_t world, unsigned long long *bounds, hipStream_t stream);   // world <= 32
 void launch_view_blend64(uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                          const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);

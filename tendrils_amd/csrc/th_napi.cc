@@ -764,6 +764,26 @@ napi_value ViewDevicePtr(napi_env env, napi_callback_info info)
     return make_bigint(env, p);
 }
 
+// drawSharded(ctx, Float32Array th_deposit_uniforms, Float32Array th_render_uniforms | null) -> fragments of this rank
+// (Tendrils.draw() of a row-band shard, the exchange issued by the library over its communicator: collective)
+napi_value DrawSharded(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_deposit_uniforms du;
+    th_render_uniforms ru;
+    a.uniforms(1, &du);
+    napi_valuetype t = napi_undefined;
+    const bool view = a.argc > 2 && napi_typeof(env, a.argv[2], &t) == napi_ok && t != napi_null && t != napi_undefined;
+    if (view) a.uniforms(2, &ru);
+    if (!a.ok) BAD_ARGS("th_draw_sharded");
+    uint64_t n = 0;
+    TH_CALL("th_draw_sharded", th_draw_sharded(c, &du, view ? &ru : nullptr, &n));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)n, &v));
+    return v;
+}
+
 // stateGather(ctx, buffer): the whole particle texture of ring buffer `buffer` on every rank (RCCL all-gather; needs commInit)
 napi_value StateGather(napi_env env, napi_callback_info info)
 {
@@ -870,7 +890,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
         {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"viewDevicePtr", ViewDevicePtr},
-        {"stateGather", StateGather}, {"stateGatherPtr", StateGatherPtr},
+        {"stateGather", StateGather}, {"stateGatherPtr", StateGatherPtr}, {"drawSharded", DrawSharded},
     };
     for (auto &e : table) {
         napi_value fn;

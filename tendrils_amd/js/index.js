@@ -203,6 +203,17 @@ class Tendrils {
 
   draw() {                                         // src/index.js:278-340: the flow pass, then the view pass
     const deposit = new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]);
+    if (this.band.rows && this.band.rows !== (this.band.globalHeight || this.state.rootNum)) {
+      // a row band of a larger texture (one process per GPU): the passes' exchange is the library's, over the communicator
+      // the ranks joined with particles.commInit() - every rank calls draw() together
+      if (this.renderView) {
+        if (this.state.autoClearView) this.clearView();
+        if (this.state.autoFade) this.drawFade();
+      }
+      this.fragments = native.drawSharded(this.particles.handle, deposit, this.renderView ? this.renderUniforms() : null);
+      this.viewFragments = this.renderView ? this.fragments : 0;
+      return this;
+    }
     if (!this.renderView) {
       this.fragments = native.flowDeposit(this.particles.handle, deposit);
       return this;

@@ -290,3 +290,15 @@ def draw_sharded(dist, tendrils, view=False):
         merge_view_fragments(tendrils, rkeys, rcolors)
         _gather_owned(dist, view_view(tendrils), texels)
     return fragments
+
+
+def draw_sharded_native(tendrils, view=False):
+    """The same draw() with the exchange issued by the LIBRARY over its own communicator (th_draw_sharded; needs
+    sharding.comm_init): what a Node process per GPU calls as drawSharded - no torch.distributed in the data path."""
+    from . import _capi
+    d = _capi.DepositUniforms(time=float(tendrils.timer.time), speedLimit=float(tendrils.state["speedLimit"]))
+    d.viewSize[0], d.viewSize[1] = float(tendrils.viewSize[0]), float(tendrils.viewSize[1])
+    n = C.c_uint64(0)
+    u = tendrils.render_uniforms() if view else None
+    _capi.call("th_draw_sharded", tendrils.particles._ctx, C.byref(d), C.byref(u) if view else None, C.byref(n))
+    return int(n.value)

@@ -288,6 +288,19 @@ class Tendrils:
             self.fragments = draw_sharded(self.dist, self, view=self.renderView)
             self.view_fragments = self.fragments if self.renderView else 0
             return self
+        row0, rows, gh = self._band
+        if rows and rows != (gh or self.state["rootNum"]):
+            # a row band without a torch.distributed host: the exchange is the library's, over the communicator the ranks
+            # joined with sharding.comm_init() (th_draw_sharded; what the Node host runs) - every rank calls draw() together
+            from .sharding import draw_sharded_native
+            if self.renderView:
+                if self.state["autoClearView"]:
+                    self.clearView()
+                if self.state["autoFade"]:
+                    self.drawFade()
+            self.fragments = draw_sharded_native(self, view=self.renderView)
+            self.view_fragments = self.fragments if self.renderView else 0
+            return self
         if not self.renderView:
             self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
             return self

@@ -120,3 +120,31 @@ def test_state_gather_over_the_librarys_communicator():
         outs.append(t.particles.read(0))
         t.dispose()
     assert bits_equal(outs[0], outs[1]).all()
+
+
+def test_draw_sharded_by_the_library_world_of_one(oracle):
+    """th_draw_sharded - edge rows, emit, fragment all-to-all, merge, all-gather, all issued by the library on its own
+    communicator (ncclSend / ncclRecv groups) - at world size 1 (one GPU): both passes against the local th_draw."""
+    from tendrils_amd import _capi, sharding
+    from tendrils_amd.sharding import comm_id
+    from helpers import bits_equal
+    outs = []
+    for native in (False, True):
+        t = make(96)
+        for _ in range(3):
+            t.timer.tick()
+            t.step()
+        if native:
+            buf = (C.c_ubyte * _capi.COMM_ID_BYTES).from_buffer_copy(comm_id())
+            _capi.call("th_comm_init", t.particles._ctx, buf, 0, 1)
+            t.state["autoClearView"] = False
+            t.drawFade()
+            frags = sharding.draw_sharded_native(t, view=True)
+        else:
+            t.draw()
+            frags = t.fragments
+        outs.append((frags, t.flow.read(), t.read_view()))
+        t.dispose()
+    assert outs[0][0] == outs[1][0] > 100
+    assert bits_equal(outs[0][1], outs[1][1]).all()
+    assert (outs[0][2] == outs[1][2]).all() and outs[0][2].any()

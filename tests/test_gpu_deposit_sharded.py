@@ -96,7 +96,15 @@ def test_shard_draw_points_to_the_exchange():
     t.resize()
     t.setup(64)
     with pytest.raises(ta.TendrilsHipError) as e:
-        t.draw()
+        t.draw()                                   # a shard's draw() is collective: it needs the job's communicator ...
+    assert "th_comm_init" in str(e.value)
+    from tendrils_amd import _capi
+    import ctypes as C
+    n = C.c_uint64(0)
+    u = _capi.DepositUniforms(time=1.0, speedLimit=0.01)
+    u.viewSize[0] = u.viewSize[1] = 1.0
+    with pytest.raises(ta.TendrilsHipError) as e:  # ... and the single-context entry points say where the exchange lives
+        _capi.call("th_flow_deposit", t.particles._ctx, C.byref(u), C.byref(n))
     assert e.value.status == 4 and "th_deposit_emit" in str(e.value)
     t.dispose()
 
