@@ -1580,7 +1580,9 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     c->drawn.valid = false;
     uint32_t host[th::kTotWords];
     for (int attempt = 0;; ++attempt) {
-        const uint32_t pool = c->bins_pool ? c->bins_pool : (p.nbins * 8u > 16384u ? p.nbins * 8u : 16384u);
+        // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
+        static const uint32_t pool0 = [] { const char *e = getenv("TH_BINS_POOL"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
+        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 8u > 16384u ? p.nbins * 8u : 16384u));
         if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
         p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));

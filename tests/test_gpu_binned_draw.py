@@ -115,3 +115,42 @@ def test_crowded_targets_are_order_exact(oracle, n, spread, view):
             first_view = view_px
         else:
             assert (view_px == first_view).all() and view_px.any()
+
+
+def test_pool_growth_and_overfull_bins_fall_back_exactly(oracle):
+    """The binned pass hands pages out from a pool sized from experience: a pool that runs dry is grown and the pass repeated
+    before anything is blended (TH_BINS_POOL=8 forces it), and a bin that outgrows its lists (more than half a million
+    fragments in 16 x 16 texels) leaves the draw to the stream-ordered pipeline - both with the exact result."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests"); sys.path.insert(0, %r + "/oracle")
+import oracle as O
+import tendrils_amd as ta
+from tendrils_amd.tendrils import View
+from helpers import bits_equal
+def run(n, spread, view, seed):
+    rng = np.random.default_rng(seed)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2))
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.03, .03, (n, n, 2)).astype(np.float32)
+    base = np.zeros((view[1], view[0], 4), np.float32)
+    want, frags = O.flow_deposit(cur, prev, base, 2500.0, view_size=(1.0, view[0] / view[1]))
+    t = ta.Tendrils(View(*view)); t.resize(); t.setup(n)
+    t.particles.draw_pipeline("bins")
+    t.particles.upload_texels(cur, 0); t.particles.upload_texels(prev, 1)
+    t.flow.set_pixels(base); t.timer.time = 2500.0; t.renderView = False
+    t.draw()
+    assert t.fragments == frags, (t.fragments, frags)
+    assert bits_equal(t.flow.read(), want).all()
+    t.draw()                                  # (and again: the store is clean after a repeated / abandoned pass)
+    t.dispose()
+    return frags
+print(run(256, 0.2, (96, 54), 5))            # a few bins, hundreds of fragments per list, a pool of 8 pages: grown, pass repeated
+print(run(1536, 0.004, (64, 36), 6))         # 1.2 M drawable lines inside one bin: the bin outgrows its lists
+''' % (ROOT, ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BINS_POOL="8"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = (int(v) for v in r.stdout.split()[-2:])
+    assert a > 20_000 and b > 600_000, (a, b)
