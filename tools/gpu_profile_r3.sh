@@ -4,7 +4,7 @@ set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_r3
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 ARGS="--gpus 1 --steps 20 --warmup 5 --no-cpu --no-traffic"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
