@@ -1582,7 +1582,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     for (int attempt = 0;; ++attempt) {
         // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
         static const uint32_t pool0 = [] { const char *e = getenv("TH_BINS_POOL"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
-        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 8u > 16384u ? p.nbins * 8u : 16384u));
+        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 16u > 16384u ? p.nbins * 16u : 16384u));
         if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
         p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
@@ -1596,7 +1596,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
         TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t), c->stream));
         if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) return kRetryInStreamOrder;
-        const uint32_t want = host[th::kTotPool] + host[th::kTotPool] / 4 + 64;
+        const uint32_t want = 2u * host[th::kTotPool] + 64;      // (generously: growing the store costs a frame's worth of time)
         if (th_status s = bins_store(c, p.nbins, want, p.mode == 2)) return s;
     }
     const uint32_t total = host[th::kTotFragments], nlarge = host[th::kTotLarge];
@@ -1604,13 +1604,13 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     if (host[th::kTotCrowdKeys] == 0xffffffffu) return fail(TH_ERR_UNSUPPORTED, "too many fragments in crowded bins for one draw (2^32 or more places)");
     if (c->crowd_capacity < nlarge) {
         (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
-        const uint32_t cap = nlarge + nlarge / 2 + 64;
+        const uint32_t cap = 2u * nlarge + 256;
         TH_HIP(hipMalloc((void **)&c->crowd_mem, (size_t)cap * th::crowd_words_per_bin() * sizeof(uint32_t)));
         c->crowd_capacity = cap;
     }
     if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
         (void)hipFree(c->crowd_keys); c->crowd_keys = nullptr; c->crowd_keys_cap = 0;
-        const size_t cap = (size_t)host[th::kTotCrowdKeys] + host[th::kTotCrowdKeys] / 4 + 4096;
+        const size_t cap = 2 * (size_t)host[th::kTotCrowdKeys] + ((size_t)1 << 20);
         TH_HIP(hipMalloc((void **)&c->crowd_keys, cap * sizeof(unsigned long long)));
         c->crowd_keys_cap = cap;
     }
