@@ -87,6 +87,10 @@ class SlotOrderInfo(C.Structure):
                 ("sorts", C.c_uint64)]
 
 
+class DrawInfo(C.Structure):
+    _fields_ = [("pipeline", C.c_int32), ("reserved", C.c_int32), ("fragments", C.c_uint64), ("crowded_fragments", C.c_uint64)]
+
+
 class CommInfo(C.Structure):
     _fields_ = [("active", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("rccl_version", C.c_int32)]
 
@@ -159,6 +163,7 @@ PROTOTYPES = {
     "th_slot_order": (C.c_int32, [_ctx, C.POINTER(SlotOrderInfo)]),
     "th_shapes": (C.c_int32, [_ctx, C.POINTER(ShapesInfo)]),
     "th_draw_pipeline": (C.c_int32, [_ctx, C.c_int32]),
+    "th_draw_query": (C.c_int32, [_ctx, C.POINTER(DrawInfo)]),
     "th_view_draw": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_draw": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_view_fill": (C.c_int32, [_ctx, _fp]),

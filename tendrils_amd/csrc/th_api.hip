@@ -159,6 +159,10 @@ struct th_context {
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
+    th_draw_info last_draw{};            // th_draw_query
+    // auto policy: the binned pipeline while the target is not crowded (th_api.hip: draw_uses_bins)
+    long long draws = 0, stream_until = 0;
+    int crowded_streak = 0, stream_spell = 0;
     long long last_binned_draw = -(1ll << 40);   // total_steps at the last draw over slot order
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
@@ -1309,14 +1313,24 @@ static int draw_policy()
     return v;
 }
 
+// Which pipeline a draw pass takes.  auto: wherever the integrator steps over tile-sorted slots the frame loop - step(); draw() -
+// stays on them: the binned pipeline takes particles in any order and wins while the target is not crowded (first ~60 frames
+// at C3: 1.7 against 2.3 ms per draw with both passes).  Once the wake has made the particles converge most fragments lie in
+// texels with hundreds and thousands of them, restoring GL's order per texel means sorting them by stream index, and the
+// stream-ordered pipeline - which gets that order for free from walking particles in texel order - is ahead (2.3 against
+// 2.8 ms; profiles/r3_b_fused_pass_experiments.txt).  So auto watches the share of a binned pass's fragments that fell into
+// bins of more than 4096: above kCrowdedShare three passes in a row, the next kStreamSpell passes (doubling, up to 4096)
+// go to the stream-ordered pipeline, then the binned one is tried again.
+constexpr double kCrowdedShare = 0.5;
+constexpr int kStreamSpell = 256;
+
 static bool draw_uses_bins(th_context *c)
 {
     const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : draw_policy();
     if (policy == 0) return false;
     if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
     if (policy == 1) return true;
-    // auto: wherever the integrator steps over tile-sorted slots the frame loop - step(); draw() - stays on them (the
-    // binned pipeline takes particles in any order and is the faster of the two there: DESIGN.md 3.4)
+    if (c->draws < c->stream_until) return false;
     return sorting_possible(c);
 }
 
@@ -1349,6 +1363,7 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
 {
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
+    if (want_bins) ++c->draws;
     bool use_bins = want_bins && draw_uses_bins(c);
     if (use_bins) {
         // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
@@ -1532,6 +1547,7 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
         if (th_status s = deposit_scan_total(c, p, &total)) return s;
     }
     if (fragments) *fragments = total;
+    c->last_draw.pipeline = TH_DRAW_STREAM; c->last_draw.fragments = total; c->last_draw.crowded_fragments = 0;
     if (total == 0) return TH_OK;
     if (!reuse) if (th_status s = deposit_reserve(c, total, false, p.mode == 2)) return s;
     p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
@@ -1601,6 +1617,17 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     }
     const uint32_t total = host[th::kTotFragments], nlarge = host[th::kTotLarge];
     if (fragments) *fragments = total;
+    c->last_draw.pipeline = TH_DRAW_BINS; c->last_draw.fragments = total; c->last_draw.crowded_fragments = host[th::kTotCrowdKeys];
+    {   // (auto policy: see draw_uses_bins)
+        const bool crowded = total > 0 && (double)host[th::kTotCrowdKeys] > kCrowdedShare * (double)total;
+        c->crowded_streak = crowded ? c->crowded_streak + 1 : 0;
+        if (!crowded) c->stream_spell = 0;
+        if (c->crowded_streak >= 3 || (crowded && c->stream_spell > 0)) {
+            c->stream_spell = c->stream_spell ? std::min(2 * c->stream_spell, 4096) : kStreamSpell;
+            c->stream_until = c->draws + c->stream_spell;
+            c->crowded_streak = 0;
+        }
+    }
     if (host[th::kTotCrowdKeys] == 0xffffffffu) return fail(TH_ERR_UNSUPPORTED, "too many fragments in crowded bins for one draw (2^32 or more places)");
     if (c->crowd_capacity < nlarge) {
         (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
@@ -2248,6 +2275,13 @@ th_status th_shapes(th_context *c, th_shapes_info *out)
     out->state_w = c->cfg.width; out->state_h = c->cfg.height;
     out->flow_w = c->fw; out->flow_h = c->fh;
     out->frames_w = c->frw; out->frames_h = c->frh;
+    return TH_OK;
+}
+
+th_status th_draw_query(th_context *c, th_draw_info *out)
+{
+    TH_REQUIRE(c && out, "null argument");
+    *out = c->last_draw;
     return TH_OK;
 }
 

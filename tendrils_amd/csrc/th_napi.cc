@@ -849,6 +849,25 @@ napi_value DrawPipeline(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// drawQuery(ctx) -> {pipeline, fragments, crowdedFragments} of the last draw pass
+napi_value DrawQuery(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_draw_query");
+    th_draw_info q{};
+    TH_CALL("th_draw_query", th_draw_query(c, &q));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_int32(env, q.pipeline, &v));
+    NAPI_OK(napi_set_named_property(env, o, "pipeline", v));
+    NAPI_OK(napi_create_double(env, (double)q.fragments, &v));
+    NAPI_OK(napi_set_named_property(env, o, "fragments", v));
+    NAPI_OK(napi_create_double(env, (double)q.crowded_fragments, &v));
+    NAPI_OK(napi_set_named_property(env, o, "crowdedFragments", v));
+    return o;
+}
+
 // kernelTimingRead(ctx) -> {meanMs, launches}
 napi_value KernelTimingRead(napi_env env, napi_callback_info info)
 {
@@ -886,7 +905,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"depositSetOwners", DepositSetOwners}, {"depositSetHalo", DepositSetHalo}, {"depositEmit", DepositEmit},
         {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
-        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline},
+        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline}, {"drawQuery", DrawQuery},
         {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
         {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"viewDevicePtr", ViewDevicePtr},

@@ -154,3 +154,42 @@ print(run(1536, 0.004, (64, 36), 6))         # 1.2 M drawable lines inside one b
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     a, b = (int(v) for v in r.stdout.split()[-2:])
     assert a > 20_000 and b > 600_000, (a, b)
+
+
+def test_auto_policy_leaves_a_crowded_target_to_the_stream_ordered_pipeline():
+    """TH_DRAW_AUTO watches the share of a binned pass's fragments that fell into bins of more than 4096 (th_draw_query): three
+    crowded passes in a row and the following passes go to the stream-ordered pipeline - with the same results as a context
+    that used it all along, bit for bit (TH_BUCKET=1: sorted slots, hence the binned pipeline, at this small size)."""
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import tendrils_amd as ta
+from tendrils_amd import _capi
+from tendrils_amd.tendrils import View
+from helpers import bits_equal
+n, view = 512, (96, 54)
+rng = np.random.default_rng(3)
+st = np.zeros((n, n, 4), np.float32)
+st[..., :2] = rng.uniform(-0.12, 0.12, (n, n, 2))            # everybody inside a few bins of the target
+st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+outs = []
+for pipeline in ("auto", "stream"):
+    t = ta.Tendrils(View(*view)); t.resize(); t.setup(n)
+    t.particles.upload_texels(st)
+    t.particles.draw_pipeline(pipeline)
+    t.timer.time = 1000.0
+    t.state["noiseWeight"] = 0.0005
+    info, used, share = _capi.DrawInfo(), [], []
+    for _ in range(8):
+        t.timer.tick(); t.step(); t.draw()
+        _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
+        used.append(info.pipeline); share.append(info.crowded_fragments / max(info.fragments, 1))
+    outs.append((used, share, t.flow.read(), t.read_view(), t.particles.read(0)))
+    t.dispose()
+(a_used, a_share, *a), (s_used, s_share, *s) = outs
+print(a_used, [round(v, 2) for v in a_share], s_used)
+assert a_used[:3] == [1, 1, 1] and min(a_share[:3]) > 0.5 and a_used[3:] == [0] * 5 and s_used == [0] * 8
+assert bits_equal(a[0], s[0]).all() and (a[1] == s[1]).all() and a[1].any() and bits_equal(a[2], s[2]).all()
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BUCKET="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

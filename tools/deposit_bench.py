@@ -41,7 +41,8 @@ def timed(fn):
 
 for _ in range(5):                      # warm-up: the wake builds up, buffers are sized
     t.timer.tick(); t.step(); t.draw()
-step_ms, draw_ms, view_ms, both_ms, frags = [], [], [], [], []
+step_ms, draw_ms, view_ms, both_ms, frags, pipes, crowded = [], [], [], [], [], [], []
+info = _capi.DrawInfo()
 both = "--both" in sys.argv              # both passes in one call (Tendrils.draw() with renderView) instead of one after the other
 for _ in range(frames):
     t.timer.tick()
@@ -50,6 +51,8 @@ for _ in range(frames):
         t.renderView = True
         both_ms.append(timed(t.draw))
         frags.append(t.fragments)
+        _capi.call("th_draw_query", ctx, C.byref(info))
+        pipes.append(info.pipeline); crowded.append(info.crowded_fragments / max(info.fragments, 1))
         continue
     t.renderView = False
     draw_ms.append(timed(t.draw))           # the flow pass (what feeds the next step)
@@ -57,6 +60,10 @@ for _ in range(frames):
     t.renderView = True
     u, n = t.render_uniforms(), C.c_uint64(0)
     view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))     # the view pass
+if os.environ.get("TH_BENCH_TRACE") and both_ms:        # how the frame changes as the wake crowds the particles: averages per 50 frames
+    for k in range(0, len(both_ms), 50):
+        print("frames %4d-%4d  step %.3f  draw(both) %.3f  fragments %.2f M  binned %3d%%  crowded share %.2f" % (k, min(k + 50, len(both_ms)) - 1, np.mean(step_ms[k:k + 50]),
+              np.mean(both_ms[k:k + 50]), np.mean(frags[k:k + 50]) / 1e6, 100 * np.mean(pipes[k:k + 50]), np.mean(crowded[k:k + 50])))
 stats = t.particles.stats(t.state["speedLimit"])
 print(json.dumps({"pipeline": os.environ.get("TH_PIPE", "auto"), "particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
                   "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)) if draw_ms else None, "view_ms": float(np.mean(view_ms)) if view_ms else None,
