@@ -156,6 +156,8 @@ struct th_context {
     uint32_t crowd_capacity = 0;
     unsigned long long *crowd_keys = nullptr;  // the large bins' fragments regrouped by texel
     size_t crowd_keys_cap = 0;
+    hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
+    hipEvent_t forked = nullptr, joined = nullptr;
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
@@ -598,6 +600,9 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
     (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
     (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->gathered);
+    if (c->forked) (void)hipEventDestroy(c->forked);
+    if (c->joined) (void)hipEventDestroy(c->joined);
+    if (c->side) (void)hipStreamDestroy(c->side);
     (void)hipFree(c->x_halo); (void)hipFree(c->x_counts); (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
@@ -1643,9 +1648,25 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     }
     p.nlarge = nlarge;
     p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
-    p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257;
+    p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257; p.crowd_giant = p.crowd_long + (size_t)c->crowd_capacity * 256;
     p.crowd_keys = c->crowd_keys;
+    th::launch_bins_regroup(p, c->stream);
+    static const bool overlap = [] { const char *e = getenv("TH_BINS_SIDE"); return !e || atoi(e) != 0; }();     // (A/B)
+    if (nlarge && overlap) {
+        // the long runs on a stream of their own, beside the bins' and the short runs' blend (disjoint texels): the walk of
+        // the longest run - one thread, one fragment after the other - overlaps with everything else instead of following it
+        if (!c->side) {
+            TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
+            TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
+        }
+        TH_HIP(hipEventRecord(c->forked, c->stream));
+        TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
+        th::launch_bins_blend_long(p, c->side);
+        TH_HIP(hipEventRecord(c->joined, c->side));
+    } else th::launch_bins_blend_long(p, c->stream);
     th::launch_bins_blend(p, c->stream);           // (every list's cursor counts: empty places are skipped as they are met)
+    if (nlarge && overlap) TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
     TH_HIP(hipGetLastError());
     return TH_OK;
 }

@@ -805,6 +805,7 @@ __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
 //   crowd_blend_wave_kernel  one wave per texel: order the run in LDS, blend
 //   crowd_blend_kernel       one workgroup per texel of the long list (windows of stream indices when a run does not fit LDS)
 constexpr uint32_t kWaveRun = 256;           // runs up to this length are ordered and blended by ONE wave
+constexpr uint32_t kGiantRun = 1024;         // longer runs are listed apart and started first: the longest run's walk is the critical path of the blend
 
 __global__ __launch_bounds__(1024) void crowd_plan_kernel(const DepositParams p)
 {
@@ -888,7 +889,8 @@ __global__ __launch_bounds__(256) void crowd_scan_kernel(const DepositParams p)
     p.crowd_start[(size_t)i * (kBinTexels + 1u) + t] = start;
     p.crowd_cursor[(size_t)i * kBinTexels + t] = start;
     if (t == 255u) p.crowd_start[(size_t)i * (kBinTexels + 1u) + 256u] = before + incl;
-    if (mine > kWaveRun) p.crowd_long[atomicAdd(&p.totals[kTotLong], 1u)] = (i << 8) | t;       // (in whatever order)
+    if (mine > kGiantRun) p.crowd_giant[atomicAdd(&p.totals[kTotGiant], 1u)] = (i << 8) | t;       // (in whatever order)
+    else if (mine > kWaveRun) p.crowd_long[atomicAdd(&p.totals[kTotLong], 1u)] = (i << 8) | t;
 }
 
 __global__ __launch_bounds__(256) void crowd_scatter_kernel(const DepositParams p)
@@ -922,12 +924,12 @@ __global__ __launch_bounds__(256) void crowd_scatter_kernel(const DepositParams 
 
 // the texels of the long list (runs of more than kWaveRun fragments), a workgroup each
 template <int MODE>
-__global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p)
+__global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p, const uint32_t *list, const uint32_t *count)
 {
     __shared__ BinShared<MODE> s;
-    const uint32_t t = threadIdx.x, nlong = p.totals[kTotLong];
+    const uint32_t t = threadIdx.x, nlong = *count;
     for (uint32_t e = blockIdx.x; e < nlong; e += gridDim.x) {
-        const uint32_t entry = p.crowd_long[e], i = entry >> 8, lt = entry & 255u;
+        const uint32_t entry = list[e], i = entry >> 8, lt = entry & 255u;
         const uint32_t b = p.large_bins[i];
         const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
         const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
@@ -1052,20 +1054,34 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
 }
 
 // p.nlarge: the large bins, as the plan counted them (totals[kTotLarge])
+void launch_bins_regroup(const DepositParams &p, hipStream_t s)
+{
+    if (!p.nlarge) return;
+    (void)hipMemsetAsync(p.crowd_count, 0, (size_t)p.nlarge * kBinTexels * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(crowd_hist_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crowd_scan_kernel, dim3(p.nlarge), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crowd_scatter_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
+}
+
+// the runs a wave does not order, a workgroup each: the giants first (a run of ten thousand fragments is walked by one thread
+// for a few hundred microseconds: started last it would be the tail of the whole draw).  The caller may put this on a stream of
+// its own beside launch_bins_blend: the texels are disjoint.
+void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
+{
+    if (!p.nlarge) return;
+#define TH_GO(M) do { hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(256), dim3(256), 0, s, p, (const uint32_t *)p.crowd_giant, (const uint32_t *)(p.totals + kTotGiant)); \
+                      hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(1024), dim3(256), 0, s, p, (const uint32_t *)p.crowd_long, (const uint32_t *)(p.totals + kTotLong)); } while (0)
+    if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
+#undef TH_GO
+}
+
 void launch_bins_blend(const DepositParams &p, hipStream_t s)
 {
-    if (p.nlarge) {         // regroup the large bins by texel
-        (void)hipMemsetAsync(p.crowd_count, 0, (size_t)p.nlarge * kBinTexels * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(crowd_hist_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(crowd_scan_kernel, dim3(p.nlarge), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(crowd_scatter_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
-    }
-#define TH_GO(M) do { if (p.nlarge) { hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(1024), dim3(256), 0, s, p); \
-                                        hipLaunchKernelGGL(crowd_blend_wave_kernel<M>, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p); } \
+#define TH_GO(M) do { if (p.nlarge) hipLaunchKernelGGL(crowd_blend_wave_kernel<M>, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p); \
                       hipLaunchKernelGGL(bins_blend_kernel<M>, dim3(p.nbins), dim3(256), 0, s, p); } while (0)
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO
 }
-size_t crowd_words_per_bin() { return 4u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list
+size_t crowd_words_per_bin() { return 5u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list, the giants' list
 
 }  // namespace th

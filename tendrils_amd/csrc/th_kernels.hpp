@@ -155,7 +155,7 @@ struct DepositParams {
     uint32_t nlarge;
     uint32_t *crowd_count, *crowd_start, *crowd_cursor;   // per large bin: fragments per texel (256), first of every texel (257), fill cursors (256)
     unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 32 | place of its varying
-    uint32_t *crowd_long;                          // texels of large bins whose runs one wave does not order (large bin << 8 | texel)
+    uint32_t *crowd_long, *crowd_giant;            // texels of large bins whose runs one wave does not order (large bin << 8 | texel): up to kGiantRun fragments / more
 };
 
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
@@ -211,10 +211,12 @@ constexpr uint32_t kBinPage = 256;                 // places per page
 constexpr uint32_t kBinMaxPages = 128;             // pages one list can grow to (half a million places per bin)
 constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits per texel coordinate
 // totals[]: device words of one pass
-enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotBlocks = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWords = 8 };
+enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWords = 8 };
 enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
-void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // per bin: order by (texel, stream index), blend
+void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
+void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs of more fragments than a wave orders (the longest first)
+void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // every other run, bin by bin / wave by wave: order by (texel, stream index), blend
 size_t crowd_words_per_bin();
 // RCCL side of a context (th_comm.hip; librccl bound at run time).  Every function returns 0 or leaves comm_error().
 const char *comm_error();
