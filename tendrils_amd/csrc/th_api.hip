@@ -155,6 +155,7 @@ struct th_context {
     uint32_t *crowd_mem = nullptr;       // per large bin: fragments per texel, first fragment of every texel, fill cursors, long runs
     uint32_t crowd_capacity = 0;
     unsigned long long *crowd_keys = nullptr;  // the large bins' fragments regrouped by texel
+    uint32_t *crowd_sorted = nullptr;          // ... their places, run by run in blend order
     size_t crowd_keys_cap = 0;
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
@@ -599,7 +600,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
     (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
-    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->gathered);
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); (void)hipFree(c->gathered);
     if (c->forked) (void)hipEventDestroy(c->forked);
     if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -1319,14 +1320,15 @@ static int draw_policy()
 }
 
 // Which pipeline a draw pass takes.  auto: wherever the integrator steps over tile-sorted slots the frame loop - step(); draw() -
-// stays on them: the binned pipeline takes particles in any order and wins while the target is not crowded (first ~60 frames
-// at C3: 1.7 against 2.3 ms per draw with both passes).  Once the wake has made the particles converge most fragments lie in
-// texels with hundreds and thousands of them, restoring GL's order per texel means sorting them by stream index, and the
-// stream-ordered pipeline - which gets that order for free from walking particles in texel order - is ahead (2.3 against
-// 2.8 ms; profiles/r3_b_fused_pass_experiments.txt).  So auto watches the share of a binned pass's fragments that fell into
-// bins of more than 4096: above kCrowdedShare three passes in a row, the next kStreamSpell passes (doubling, up to 4096)
-// go to the stream-ordered pipeline, then the binned one is tried again.
-constexpr double kCrowdedShare = 0.5;
+// stays on them: the binned pipeline takes particles in any order.  It is ahead while the target is not crowded (first ~60
+// frames at C3: 1.7 against 2.3 ms per draw with both passes) and level with the stream-ordered pipeline once the wake has made
+// the particles converge (70-76 % of all fragments in bins of more than 4096, in texels with hundreds and thousands of them:
+// 2.0-2.7 ms either way; profiles/r3_b_fused_pass_experiments.txt) - restoring GL's order per texel then means sorting most
+// fragments by stream index, an order the stream-ordered pipeline gets for free from walking particles in texel order.  Beyond
+// that, auto hands over: when more than kCrowdedShare of a binned pass's fragments fell into large bins three passes in a row,
+// the next kStreamSpell passes (doubling, up to 4096, while it stays so) go to the stream-ordered pipeline, then the binned one
+// is tried again.
+constexpr double kCrowdedShare = 0.8;
 constexpr int kStreamSpell = 256;
 
 static bool draw_uses_bins(th_context *c)
@@ -1641,15 +1643,16 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         c->crowd_capacity = cap;
     }
     if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
-        (void)hipFree(c->crowd_keys); c->crowd_keys = nullptr; c->crowd_keys_cap = 0;
+        (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); c->crowd_keys = nullptr; c->crowd_sorted = nullptr; c->crowd_keys_cap = 0;
         const size_t cap = 2 * (size_t)host[th::kTotCrowdKeys] + ((size_t)1 << 20);
         TH_HIP(hipMalloc((void **)&c->crowd_keys, cap * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->crowd_sorted, cap * sizeof(uint32_t)));
         c->crowd_keys_cap = cap;
     }
     p.nlarge = nlarge;
     p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
     p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257; p.crowd_giant = p.crowd_long + (size_t)c->crowd_capacity * 256;
-    p.crowd_keys = c->crowd_keys;
+    p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted;
     th::launch_bins_regroup(p, c->stream);
     static const bool overlap = [] { const char *e = getenv("TH_BINS_SIDE"); return !e || atoi(e) != 0; }();     // (A/B)
     if (nlarge && overlap) {

@@ -39,7 +39,7 @@ constexpr uint32_t kBinSide = 1u << kBinShift, kBinTexels = kBinSide * kBinSide;
 constexpr uint32_t kPageShift = 8;
 static_assert(kBinPage == 1u << kPageShift && kBinPage * kBinReplicas == kBinCap, "page size");
 constexpr uint32_t kRankMaxRun = 256;        // runs up to this length are ordered by counting, longer ones by the bitonic network
-constexpr uint32_t kOwnRun = 64;             // runs up to this length are blended by their texel's thread alone
+constexpr uint32_t kOwnRun = 256;            // runs up to this length are blended by their texel's thread alone (64 texels of a wave side by side: a chain per lane, nothing redundant)
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kNoPlace = 0xffffffffu;
 
@@ -802,7 +802,8 @@ __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
 //   crowd_scan_kernel        every texel's range inside its bin; the list of the long runs
 //   crowd_scatter_kernel     (stream index << 32 | place of the varying) of every fragment into its texel's range; the
 //                            places and the lists' pages are left empty
-//   crowd_blend_wave_kernel  one wave per texel: order the run in LDS, blend
+//   crowd_sort_kernel        one wave per texel: its run of up to kWaveRun fragments ordered (rank by counting)
+//   crowd_walk_kernel        one LANE per texel: the ordered run blended, 64 texels of a wave side by side
 //   crowd_blend_kernel       one workgroup per texel of the long list (windows of stream indices when a run does not fit LDS)
 constexpr uint32_t kWaveRun = 256;           // runs up to this length are ordered and blended by ONE wave
 constexpr uint32_t kGiantRun = 1024;         // longer runs are listed apart and started first: the longest run's walk is the critical path of the blend
@@ -953,36 +954,29 @@ __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p,
     }
 }
 
-// One WAVE per texel of a large bin: runs of up to kWaveRun fragments - nearly all of them (the typical texel of a crowded
-// bin holds a few dozen).  No workgroup barrier anywhere: a wave loads its run's keys into its own LDS strip, every lane
-// ranks its (<= 4) keys by counting the smaller ones (all lanes read the same key at a time: a broadcast, no bank
-// conflicts; stream indices inside a texel are distinct: a line covers a texel at most once), leaves every fragment's
-// place at its rank, and then the run is blended 64 fragments at a time: every lane fetches one varying and turns it
-// into its side of the blend (64 gathers in flight, the next batch's issued before this batch's chain), and ALL lanes
-// apply the 64 sources in order to their own copy of the destination (read back as LDS broadcasts) - the same operations
-// in the same order as one thread would do them, without a divergent tail; lane 0 stores.
-template <int MODE>
-__global__ __launch_bounds__(256) void crowd_blend_wave_kernel(const DepositParams p)
+// The runs of up to kWaveRun fragments in two steps.  crowd_sort_kernel: one WAVE per texel orders its run (rank by counting,
+// every lane its <= 4 keys against all of the run's, read from LDS as broadcasts) and leaves the places of the varyings in blend order - tens of thousands of independent waves.
+// crowd_walk_kernel: 64 texels per wave, a LANE per texel, every lane walking the run of its own texel - 64 chains side by
+// side.  With one wave per texel for the whole job every lane applies every fragment to its own copy of the destination: 64
+// times the chain's arithmetic, and the chain (the view target's clamp, convert and round per channel on top of the flow
+// target's multiply and add) is most of that kernel once runs are a hundred fragments long; a lane per texel for the whole job
+// orders 64 runs one after the other per wave and waits for each.
+__global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
 {
-    __shared__ unsigned long long keys[4][kWaveRun];
-    __shared__ uint32_t ord[4][kWaveRun];
-    __shared__ BlendSource stage_a[4][64], stage_b[MODE == 2 ? 4 : 1][64];
+    constexpr uint32_t CAP = kWaveRun;
+    __shared__ unsigned long long keys[4][CAP];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gt = blockIdx.x * 4u + wave, i = gt >> 8, lt = gt & 255u;
     if (i >= p.nlarge) return;
     const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
-    if (len == 0u || len > kWaveRun) return;                  // (the long ones: crowd_blend_kernel)
-    const uint32_t b = p.large_bins[i];
-    const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
-    const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
-    const uint32_t texel = y * (uint32_t)p.fw + x;
+    if (len == 0u || len > CAP) return;                       // (longer ones: crowd_blend_kernel)
     const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
-    BinTexel<MODE> d{};
-    d.load(p, texel);                                          // (every lane: its own copy)
-    constexpr uint32_t kPer = kWaveRun / 64u;
+    uint32_t *sorted = p.crowd_sorted + p.large_key0[i] + r0;
+    constexpr uint32_t kPer = CAP / 64u;
     unsigned long long mine[kPer];
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; mine[q] = run[f < len ? f : len - 1u]; }
+    if (len == 1u) { if (lane == 0u) sorted[0] = (uint32_t)(mine[0] & 0xffffffffull); return; }
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) keys[wave][f] = mine[q]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -997,41 +991,25 @@ __global__ __launch_bounds__(256) void crowd_blend_wave_kernel(const DepositPara
         for (uint32_t q = 0; q < kPer; ++q) if (q < groups) rank[q] += k < mine[q] ? 1u : 0u;
     }
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) ord[wave][rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float4 c0, c1;
-    fetch_colors<MODE>(p, (size_t)ord[wave][lane < len ? lane : len - 1u], c0, c1);
-    for (uint32_t j0 = 0; j0 < len; j0 += 64u) {
-        if constexpr (MODE == 1) stage_a[wave][lane] = ViewTarget::source(c0);
-        else stage_a[wave][lane] = FlowTarget::source(c0);
-        if constexpr (MODE == 2) stage_b[wave][lane] = ViewTarget::source(c1);
-        const uint32_t nx = j0 + 64u + lane;                   // the next batch's varyings, before this batch's chain
-        if (j0 + 64u < len) fetch_colors<MODE>(p, (size_t)ord[wave][nx < len ? nx : len - 1u], c0, c1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t n = len - j0 < 64u ? len - j0 : 64u;
-        uint32_t e = 0;
-        for (; e + 8u <= n; e += 8u) {
-            BlendSource a[8], bb[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u) { a[u] = stage_a[wave][e + u]; if constexpr (MODE == 2) bb[u] = stage_b[wave][e + u]; }
-#pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u) {
-                if constexpr (MODE == 1) ViewTarget::apply(d.v, a[u]);
-                else FlowTarget::apply(d.f, a[u]);
-                if constexpr (MODE == 2) ViewTarget::apply(d.v, bb[u]);
-            }
-        }
-        for (; e < n; ++e) {
-            if constexpr (MODE == 1) ViewTarget::apply(d.v, stage_a[wave][e]);
-            else FlowTarget::apply(d.f, stage_a[wave][e]);
-            if constexpr (MODE == 2) ViewTarget::apply(d.v, stage_b[wave][e]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                       // (the stage is rewritten by the next batch)
-    }
-    if (lane == 0u) d.store(p, texel);
+    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) sorted[rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
+{
+    const uint32_t lane = threadIdx.x, i = blockIdx.x >> 2, lt = ((blockIdx.x & 3u) << 6) + lane;
+    if (i >= p.nlarge) return;
+    const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
+    if (len == 0u || len > kWaveRun) return;                  // (longer runs: crowd_blend_kernel, sources by the workgroup)
+    const uint32_t b = p.large_bins[i];
+    const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
+    const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
+    const uint32_t texel = y * (uint32_t)p.fw + x;
+    BinTexel<MODE> d{};
+    d.load(p, texel);
+    const uint32_t *sorted = p.crowd_sorted + p.large_key0[i] + r0;
+    bin_blend_own<MODE>(p, 0u, len, d, [sorted](uint32_t j) { return sorted[j]; });
+    d.store(p, texel);
 }
 
 }  // namespace
@@ -1063,9 +1041,9 @@ void launch_bins_regroup(const DepositParams &p, hipStream_t s)
     hipLaunchKernelGGL(crowd_scatter_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
 }
 
-// the runs a wave does not order, a workgroup each: the giants first (a run of ten thousand fragments is walked by one thread
-// for a few hundred microseconds: started last it would be the tail of the whole draw).  The caller may put this on a stream of
-// its own beside launch_bins_blend: the texels are disjoint.
+// the runs a wave does not order (more than kWaveRun fragments), a workgroup each, the giants first: a run of ten thousand
+// fragments is walked by one thread for a few hundred microseconds - the caller puts this on a stream of its own beside
+// launch_bins_blend (disjoint texels), so that the walk overlaps with everything else instead of following it.
 void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;
@@ -1077,7 +1055,12 @@ void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
 
 void launch_bins_blend(const DepositParams &p, hipStream_t s)
 {
-#define TH_GO(M) do { if (p.nlarge) hipLaunchKernelGGL(crowd_blend_wave_kernel<M>, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p); \
+    // every run of up to kWaveRun fragments ordered by a wave of its own ...  (Up to kGiantRun - the 257..1024 class through a
+    // 16-keys-per-lane instantiation over the list - was slower: a lane walking a thousand fragments holds its wave: 2.60
+    // against 2.28 ms per crowded draw.)
+    if (p.nlarge) hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p);
+    // ... and walked by a lane of its own; the bins of up to kBinCap places
+#define TH_GO(M) do { if (p.nlarge) hipLaunchKernelGGL(crowd_walk_kernel<M>, dim3(p.nlarge * 4u), dim3(64), 0, s, p); \
                       hipLaunchKernelGGL(bins_blend_kernel<M>, dim3(p.nbins), dim3(256), 0, s, p); } while (0)
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO

@@ -155,6 +155,7 @@ struct DepositParams {
     uint32_t nlarge;
     uint32_t *crowd_count, *crowd_start, *crowd_cursor;   // per large bin: fragments per texel (256), first of every texel (257), fill cursors (256)
     unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 32 | place of its varying
+    uint32_t *crowd_sorted;                        // ... and the places alone, every texel's run in blend order (crowd_blend_lanes_kernel)
     uint32_t *crowd_long, *crowd_giant;            // texels of large bins whose runs one wave does not order (large bin << 8 | texel): up to kGiantRun fragments / more
 };
 

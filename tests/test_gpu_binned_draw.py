@@ -170,7 +170,7 @@ from helpers import bits_equal
 n, view = 512, (96, 54)
 rng = np.random.default_rng(3)
 st = np.zeros((n, n, 4), np.float32)
-st[..., :2] = rng.uniform(-0.12, 0.12, (n, n, 2))            # everybody inside a few bins of the target
+st[..., :2] = rng.uniform(-0.12, 0.12, (n, n, 2))            # everybody inside a few bins of the target (share ~1)
 st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
 outs = []
 for pipeline in ("auto", "stream"):
@@ -188,7 +188,7 @@ for pipeline in ("auto", "stream"):
     t.dispose()
 (a_used, a_share, *a), (s_used, s_share, *s) = outs
 print(a_used, [round(v, 2) for v in a_share], s_used)
-assert a_used[:3] == [1, 1, 1] and min(a_share[:3]) > 0.5 and a_used[3:] == [0] * 5 and s_used == [0] * 8
+assert a_used[:3] == [1, 1, 1] and min(a_share[:3]) > 0.8 and a_used[3:] == [0] * 5 and s_used == [0] * 8
 assert bits_equal(a[0], s[0]).all() and (a[1] == s[1]).all() and a[1].any() and bits_equal(a[2], s[2]).all()
 ''' % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BUCKET="1"), capture_output=True, text=True, timeout=900)
