@@ -852,16 +852,20 @@ def frame_loop(t, ctx, state, frames=20):
     # fragment: its model is kept beside for the comparison across rounds.
     alg = lines * 4.0 + lines * 0.5 * 32.0 + f * 48.0 + texels * 32.0
     alg_r2 = lines * 88.0 + f * 124.0
-    d = float(np.mean(flow_ms))
-    return {"frames": frames, "step_ms": float(np.mean(step_ms)), "draw_flow_ms": d, "draw_view_ms": float(np.mean(view_ms)), "draw_both_ms": float(np.mean(both_ms)),
-            "fragments_per_draw": f, "frames_per_s": 1e3 / (float(np.mean(step_ms)) + d),
-            "frame_ms_reference_loop": float(np.mean(step_ms)) + float(np.mean(both_ms)),
+    # medians over the frames (a frame in which a store grows - a hipMalloc inside the pass - would otherwise own the mean);
+    # the slowest frame is reported beside
+    d, s_ms, b_ms = float(np.median(flow_ms)), float(np.median(step_ms)), float(np.median(both_ms))
+    return {"frames": frames, "step_ms": s_ms, "draw_flow_ms": d, "draw_view_ms": float(np.median(view_ms)), "draw_both_ms": b_ms,
+            "slowest_frame": {"step_ms": float(np.max(step_ms)), "draw_flow_ms": float(np.max(flow_ms)), "draw_view_ms": float(np.max(view_ms)),
+                              "draw_both_ms": float(np.max(both_ms))},
+            "fragments_per_draw": f, "frames_per_s": 1e3 / (s_ms + d),
+            "frame_ms_reference_loop": s_ms + b_ms,
             "pipeline": "binned (th_bins.hip): particles stay in the integrator's tile-sorted slot order; one fused rasterise + emit pass into "
                         "16x16-texel bins of the target, per-bin ordering by (texel, stream index) and blending in LDS",
             "roofline": {"bound": "hbm", "kernel": "flow pass of draw(): bins_fused_kernel + per-bin blend kernels", "achieved": alg / d / 1e6,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / d / 1e6 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_draw": alg,
-                         "achieved_is": "4 B per slot + 32 B per drawable line + 48 B per fragment + 32 B per target texel / mean duration of the pass "
+                         "achieved_is": "4 B per slot + 32 B per drawable line + 48 B per fragment + 32 B per target texel / median duration of the pass "
                                         "(the pass is bound by the rasteriser's integer arithmetic and by latency, not by bytes: DESIGN.md 3.4)",
                          "r2_model": {"algorithmic_bytes_per_draw": alg_r2, "achieved": alg_r2 / d / 1e6, "frac": alg_r2 / d / 1e6 / HBM_PEAK_GBS,
                                       "note": "round 2's byte model (88 B per line + 124 B per fragment: what the stream-ordered pipeline moves) over "
