@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 10
+#define TH_ABI_VERSION 11
 
 typedef int32_t th_status;
 enum {
@@ -219,11 +219,26 @@ th_status th_optical_flow(th_context *ctx, const th_optical_flow_uniforms *u);
 
 /* -- flow deposit: the flow pass of Tendrils.draw() (src/index.js:278-303) ----- */
 /* Renders every particle's (previous -> current) line (buffers[1] -> buffers[0]) into the flow texture as
- * (vel, time, min(|vel|/speedLimit, 1)), alpha-blended in the reference's primitive order (width-1 lines: the GL the
- * reference was captured on clamps flowWidth to 1).  fragments (optional) receives the number of fragments blended;
+ * (vel, time, min(|vel|/speedLimit, 1)), alpha-blended in the reference's primitive order, with the context's line width
+ * (th_line_width below; 1 unless the host widened the range).  fragments (optional) receives the number of fragments blended;
  * the call synchronises once (the fragment lists are sized from a device count).
  * Needs the whole particle texture on this context (a row-band shard: th_deposit_emit / th_deposit_merge below). */
 th_status th_flow_deposit(th_context *ctx, const th_deposit_uniforms *u, uint64_t *fragments);
+/* gl.lineWidth (src/index.js:302: flowWidth before the flow pass, :336: lineWidth before the view pass): context state
+ * like the GL's, kept per pass because th_draw / th_draw_sharded run both passes in one call (the reference sets the width
+ * between them); every later pass of that kind draws its lines with clamp(width, range).  th_line_width_range is what
+ * gl.getParameter(ALIASED_LINE_WIDTH_RANGE) reports, chosen by the host: [1, 1] by default - the range of the GL the
+ * reference was captured on, so that flowWidth = 5 draws width-1 lines as it does there and every capture of the
+ * reference keeps pinning the result - up to [1, TH_MAX_LINE_WIDTH] for the picture of a GL that honours the width (a wide line = the width-1
+ * construction with its endpoint diamonds scaled: `width` texels across in the minor direction, OpenGL ES 2.0 3.4.2.1;
+ * unpinned - no GL within reach draws one).  width <= 0 or NaN: TH_ERR_INVALID, state unchanged (GL: INVALID_VALUE). */
+#define TH_MAX_LINE_WIDTH 64.0f
+#define TH_PASS_FLOW 0      /* th_flow_deposit, th_deposit_emit, the flow pass of th_draw / th_draw_sharded */
+#define TH_PASS_VIEW 1      /* th_view_draw, th_view_emit, the view pass of th_draw / th_draw_sharded */
+th_status th_line_width(th_context *ctx, int32_t pass, float width);
+th_status th_line_width_range(th_context *ctx, float lo, float hi);         /* 0 < lo <= 1 <= hi <= TH_MAX_LINE_WIDTH */
+/* width = as set, drawn = after the clamp, range[2]; any pointer may be NULL */
+th_status th_line_width_query(th_context *ctx, int32_t pass, float *width, float *drawn, float *range);
 
 /* Trail export (build-defined; the reference never reads its lines back): the line list draw() hands to GL - same
  * vertex stream, pairing and frame choice as the flow pass (src/state/state-at-frame.glsl:12-22, read by both
@@ -324,8 +339,8 @@ typedef struct th_render_uniforms {
 } th_render_uniforms;
 th_status th_view_draw(th_context *ctx, const th_render_uniforms *u, uint64_t *fragments);
 /* Both passes of Tendrils.draw() in one call (src/index.js:278-337: the flow pass, then the view pass): same results as
- * th_flow_deposit(u) followed by th_view_draw(r), with the lines rasterised and the fragments sorted once.  u and r must
- * agree in viewSize, time and speedLimit. */
+ * th_flow_deposit(u) followed by th_view_draw(r), with the lines rasterised and the fragments sorted once when both passes
+ * draw with the same width.  u and r must agree in viewSize, time and speedLimit. */
 th_status th_draw(th_context *ctx, const th_deposit_uniforms *u, const th_render_uniforms *r, uint64_t *fragments);
 /* Tendrils.drawFill / drawFade (src/index.js:342-356): a full-screen colour blended SRC_ALPHA / ONE_MINUS_SRC_ALPHA */
 th_status th_view_fill(th_context *ctx, const float rgba[4]);

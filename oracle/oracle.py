@@ -74,7 +74,7 @@ _lib = None
 
 class DepositUniforms(C.Structure):
     _fields_ = [("data_w", C.c_int32), ("data_h", C.c_int32), ("viewSize", C.c_float * 2),
-                ("time", C.c_float), ("speedLimit", C.c_float)]
+                ("time", C.c_float), ("speedLimit", C.c_float), ("lineWidth", C.c_float)]
 
 
 class RenderUniforms(C.Structure):
@@ -230,16 +230,17 @@ def spawn_sample(u, particles, spawn_data, y0=0):
     return out
 
 
-def flow_deposit(current, previous, flow, time, view_size=(1.0, 1.0), speedLimit=0.01, coverage=False):
+def flow_deposit(current, previous, flow, time, view_size=(1.0, 1.0), speedLimit=0.01, coverage=False, line_width=1.0):
     """Tendrils.draw()'s flow pass: blends the particle lines into a copy of `flow` [fh, fw, 4].
-    Returns (flow_out, fragments[, per-texel fragment counts])."""
+    Returns (flow_out, fragments[, per-texel fragment counts]).  line_width: the width the GL draws with (after its
+    clamp to ALIASED_LINE_WIDTH_RANGE; 1 on the captured GL - wider lines are unpinned, see tendrils_oracle.c)."""
     current = np.ascontiguousarray(current, np.float32)
     previous = np.ascontiguousarray(previous, np.float32)
     out = np.array(flow, np.float32, copy=True, order="C")
     h, w = current.shape[:2]
     assert previous.shape == current.shape and current.shape[2] == 4 and out.shape[2] == 4
     fh, fw = out.shape[:2]
-    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(speedLimit))
+    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(speedLimit), lineWidth=float(line_width))
     u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
     cov = np.zeros((fh, fw), np.int32) if coverage else None
     n = lib().to_flow_deposit(C.byref(u), _fp(current), _fp(previous), _fp(out), fw, fh,
@@ -277,7 +278,7 @@ def view_render(current, previous, view, time, view_size=(1.0, 1.0), colormap=No
     h, w = current.shape[:2]
     vh, vw = out.shape[:2]
     r = render_uniforms(time, **uniforms)
-    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(r.speedLimit))
+    u = DepositUniforms(data_w=w, data_h=h, time=float(time), speedLimit=float(r.speedLimit), lineWidth=float(uniforms.get("line_width", 1.0)))
     u.viewSize[0], u.viewSize[1] = float(view_size[0]), float(view_size[1])
     cm = None if colormap is None else np.ascontiguousarray(colormap, np.float32)
     L = lib()

@@ -533,6 +533,13 @@ void to_spawn_sample(const to_spawn_sample_uniforms *u, const float *particles, 
  *                   to the view volume in clip space, vertices snapped to 1/16 px, scan-converted with ceil() edges:
  *                   texel centres with left <= x < right (reproduces the captured coverage texel for texel: ties,
  *                   sub-texel lines and lines crossing the view's edge included)
+ *   WIDE LINES      (UNPINNED: no GL within reach draws them - the captured one clamps every width to 1.)  A line of
+ *                   width w is the same construction with the endpoint diamonds scaled by w (|dx|+|dy| <= w/2 px):
+ *                   the hexagon then measures exactly w texels across in the line's minor direction, which is what
+ *                   the GL specification asks of a non-antialiased wide line (OpenGL ES 2.0 3.4.2.1: a column of w
+ *                   fragments per step in the major direction), and it is the captured rasteriser's own shape with its
+ *                   one constant (the diamond's half-diagonal) multiplied - w = 1 is bit for bit the pinned case.  The
+ *                   varying is projected on the line as before, so it is constant across the line's width.
  *   interpolation   the varying is linear along the SNAPPED endpoints (orthogonal projection, extrapolated beyond
  *                   them, unclamped); coinciding snapped endpoints give the first vertex's values
  *   blend           SRC_ALPHA, ONE_MINUS_SRC_ALPHA on all four channels, lines in stream order (src/index.js:267-268)
@@ -618,7 +625,8 @@ static long deposit_core(const to_deposit_uniforms *u, const to_render_uniforms 
     const int W = u->data_w, H = u->data_h;
     const float wx16 = 8.0f * (float)fw, wy16 = 8.0f * (float)fh;          /* 16 * viewport/2 */
     const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;                         /* texel centres at integer*16 */
-    const float hx = 0.5f / (0.5f * (float)fw), hy = 0.5f / (0.5f * (float)fh);   /* half a texel in NDC */
+    const float lw = u->lineWidth > 0.0f ? u->lineWidth : 1.0f;
+    const float hx = (0.5f * lw) / (0.5f * (float)fw), hy = (0.5f * lw) / (0.5f * (float)fh);   /* half the diamond (half a texel x width) in NDC */
     long fragments = 0;
     enum { SPAN = 64 };
     for (int i = 0; i < W; ++i) {

@@ -91,11 +91,14 @@ void to_triangles(const float *positions, int ntri, const float *view_size, cons
 /* Flow deposit: the particle lines of Tendrils.draw() (src/index.js:278-303) rendered into the flow FBO with the
  * flow shader (src/flow/index.vert -> vert/main.vert:10-17, apply/state.glsl:5-16; index.frag).
  * data_w/data_h = particle texture shape; the vertex stream is Particles.generateLUT(geomShape = [w, 2h])
- * (src/particles.js:171-190, src/index.js:195-197) drawn as gl.LINES with lineWidth clamped to 1. */
+ * (src/particles.js:171-190, src/index.js:195-197) drawn as gl.LINES.  lineWidth = the width the GL draws with, i.e.
+ * gl.lineWidth(flowWidth / lineWidth) (src/index.js:302,336) AFTER the clamp to ALIASED_LINE_WIDTH_RANGE - [1, 1] on the GL
+ * every fixture was captured on, so 1 wherever a capture pins the result (0 is taken as 1). */
 typedef struct to_deposit_uniforms {
     int32_t data_w, data_h;
     float viewSize[2];
     float time, speedLimit;
+    float lineWidth;
 } to_deposit_uniforms;
 
 /* Blends every line in stream order into flow (fw x fh RGBA32F); returns the number of fragments.

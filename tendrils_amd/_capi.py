@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("TH_LIB") or os.path.join(HERE, "lib", "libtendrils_hi
 TH_OK = 0
 TH_MODE_EXACT, TH_MODE_FAST = 0, 1
 TH_STATE_F32, TH_STATE_F16 = 0, 1
+TH_PASS_FLOW, TH_PASS_VIEW = 0, 1
+TH_MAX_LINE_WIDTH = 64.0
 TH_TARGET_RING, TH_TARGET_TARGETS, TH_SOURCE_FLOW, TH_SOURCE_IMAGE = -1, -2, -3, -4
 INERT = -1000000.0
 
@@ -164,6 +166,9 @@ PROTOTYPES = {
     "th_shapes": (C.c_int32, [_ctx, C.POINTER(ShapesInfo)]),
     "th_draw_pipeline": (C.c_int32, [_ctx, C.c_int32]),
     "th_draw_query": (C.c_int32, [_ctx, C.POINTER(DrawInfo)]),
+    "th_line_width": (C.c_int32, [_ctx, C.c_int32, C.c_float]),
+    "th_line_width_range": (C.c_int32, [_ctx, C.c_float, C.c_float]),
+    "th_line_width_query": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "th_view_draw": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_draw": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_view_fill": (C.c_int32, [_ctx, _fp]),

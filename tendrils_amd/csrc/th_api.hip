@@ -142,7 +142,8 @@ struct th_context {
     bool dep_pairs = false;              // the colour buffers hold two varyings per fragment (th_draw)
     // the geometry of the last draw pass (fragment counts, offsets, records, the sorted fragment order): the flow pass
     // and the view pass of one draw() rasterise the same lines at the same resolution
-    struct { bool valid = false, binned = false; float view_x = 0, view_y = 0; uint32_t total = 0, nlarge = 0, nblocks = 0; bool sorted_in_a = false; } drawn;
+    float line_width[2] = {1.0f, 1.0f}, line_range[2] = {1.0f, 1.0f};     // th_line_width (per pass: TH_PASS_FLOW, TH_PASS_VIEW) / th_line_width_range
+    struct { bool valid = false, binned = false; float view_x = 0, view_y = 0, line_half = 0; uint32_t total = 0, nlarge = 0, nblocks = 0; bool sorted_in_a = false; } drawn;
     uint32_t dep_list_cap = 0;
     // binned pipeline (th_bins.hip): the bins' cursors | the large bins | first block of each (+ 1) | first regrouped key of each (+ 1)
     uint32_t *bin_mem = nullptr;
@@ -1331,6 +1332,12 @@ static int draw_policy()
 constexpr double kCrowdedShare = 0.8;
 constexpr int kStreamSpell = 256;
 
+static float drawn_line_width(const th_context *c, int pass)
+{
+    const float w = c->line_width[pass];
+    return w < c->line_range[0] ? c->line_range[0] : (w > c->line_range[1] ? c->line_range[1] : w);
+}
+
 static bool draw_uses_bins(th_context *c)
 {
     const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : draw_policy();
@@ -1338,6 +1345,9 @@ static bool draw_uses_bins(th_context *c)
     if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
     if (policy == 1) return true;
     if (c->draws < c->stream_until) return false;
+    // (lines wider than 2 cover more texels than a line's record holds: nearly all of them would leave the fused pass
+    // for the long list, one atomic per fragment - the stream-ordered pipeline counts and scans instead)
+    if (drawn_line_width(c, TH_PASS_FLOW) > 2.0f || drawn_line_width(c, TH_PASS_VIEW) > 2.0f) return false;
     return sorting_possible(c);
 }
 
@@ -1412,6 +1422,7 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     p.row0 = (uint32_t)c->cfg.row0; p.rows = (uint32_t)c->cfg.height;
     p.fw = c->fw; p.fh = c->fh;
     p.view_x = u->viewSize[0]; p.view_y = u->viewSize[1]; p.time = u->time; p.speed_limit = u->speedLimit;
+    p.line_half = 0.5f * drawn_line_width(c, TH_PASS_FLOW);       // (view_params: the view pass's)
     {
         const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.global_height > 2 ? 2 * c->cfg.global_height : 2;
         p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
@@ -1545,7 +1556,8 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
     // lines cover the same texels in the same order - counts, offsets, records and the sorted order of the fragments are
     // still there, only the varyings differ.  (TH_DRAW_REUSE=0: every pass on its own.)
     static const bool reuse_allowed = [] { const char *e = getenv("TH_DRAW_REUSE"); return !e || atoi(e) != 0; }();
-    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && !c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y;
+    const bool reuse = reuse_allowed && p.mode != 2 && c->drawn.valid && !c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y &&
+                       c->drawn.line_half == p.line_half;
     uint32_t total = 0;
     if (reuse) total = c->drawn.total;
     else {
@@ -1569,7 +1581,7 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
         th::launch_deposit_scatter(p, c->stream);
         const bool in_a = th::launch_radix_sort_u32(p.keys, p.slots, p.keys_sorted, p.slots_sorted, total, 0, bits, c->dep_temp, true, c->stream) == 0;
         if (in_a) { p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1]; }        // an even number of passes ends in the (a) buffers
-        c->drawn.valid = true; c->drawn.binned = false; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.total = total; c->drawn.sorted_in_a = in_a;
+        c->drawn.valid = true; c->drawn.binned = false; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.line_half = p.line_half; c->drawn.total = total; c->drawn.sorted_in_a = in_a;
     }
     th::launch_deposit_blend(p, total, c->stream);
     TH_HIP(hipGetLastError());
@@ -1716,6 +1728,7 @@ static th_status view_params(th_context *c, const th_render_uniforms *u, th::Dep
     d.viewSize[0] = u->viewSize[0]; d.viewSize[1] = u->viewSize[1]; d.time = u->time; d.speedLimit = u->speedLimit;
     if (th_status s = deposit_prepare(c, &d, p, want_bins, bins)) return s;
     p.mode = 1;
+    p.line_half = 0.5f * drawn_line_width(c, TH_PASS_VIEW);
     view_fields(c, u, p);
     return TH_OK;
 }
@@ -1734,6 +1747,10 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
     TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
                memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
                "the two passes of one draw share viewSize, time and speedLimit");
+    if (drawn_line_width(c, TH_PASS_FLOW) != drawn_line_width(c, TH_PASS_VIEW)) {       // two widths: two rasterisations
+        if (th_status s = th_flow_deposit(c, du, fragments)) return s;
+        return th_view_draw(c, ru, nullptr);
+    }
     if (th_status s = view_storage(c)) return s;
     for (int pass = 0;; ++pass) {
         th::DepositParams p;
@@ -2306,6 +2323,34 @@ th_status th_draw_query(th_context *c, th_draw_info *out)
 {
     TH_REQUIRE(c && out, "null argument");
     *out = c->last_draw;
+    return TH_OK;
+}
+
+th_status th_line_width(th_context *c, int32_t pass, float width)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(pass == TH_PASS_FLOW || pass == TH_PASS_VIEW, "unknown pass %d", pass);
+    TH_REQUIRE(width > 0.0f, "line width %g (gl.lineWidth: INVALID_VALUE, the width stays %g)", (double)width, (double)c->line_width[pass]);
+    c->line_width[pass] = width;
+    return TH_OK;
+}
+
+th_status th_line_width_range(th_context *c, float lo, float hi)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(lo > 0.0f && lo <= 1.0f && hi >= 1.0f && hi <= th::kMaxLineWidth, "line width range [%g, %g]: need 0 < lo <= 1 <= hi <= %g",
+               (double)lo, (double)hi, (double)th::kMaxLineWidth);
+    c->line_range[0] = lo; c->line_range[1] = hi;
+    return TH_OK;
+}
+
+th_status th_line_width_query(th_context *c, int32_t pass, float *width, float *drawn, float *range)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(pass == TH_PASS_FLOW || pass == TH_PASS_VIEW, "unknown pass %d", pass);
+    if (width) *width = c->line_width[pass];
+    if (drawn) *drawn = drawn_line_width(c, pass);
+    if (range) { range[0] = c->line_range[0]; range[1] = c->line_range[1]; }
     return TH_OK;
 }
 

@@ -111,6 +111,8 @@ struct SpawnSampleParams {
 constexpr int kOwnerShift = 56;
 constexpr uint32_t kTexelMask = 0xffffffu;
 
+constexpr float kMaxLineWidth = 64.0f;      // th_line_width_range's upper end (TH_MAX_LINE_WIDTH): dep_param's 32-bit arithmetic holds up to it
+
 struct DepositParams {
     const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order
     float4 *flow;
@@ -120,6 +122,7 @@ struct DepositParams {
     const float4 *halo_lo, *halo_hi;   // row row0-1 / row0+rows of the neighbouring bands: W texels of `cur`, then W of `prev`
     int32_t fw, fh;              // flow texture shape
     float view_x, view_y, time, speed_limit;
+    float line_half;             // half the width the lines are drawn with, in texels (th_line_width after the clamp to its range; 0.5 = width 1)
     // view pass (mode 1): the vertex colours of src/render/index.vert:58-100, blended into the RGBA8 view buffer
     int32_t mode;                // 0 = flow pass (varying = vel, time, alpha), 1 = view pass, 2 = both (varyings in pairs)
     float flow_decay, speed_alpha, colormap_alpha, sin_term;

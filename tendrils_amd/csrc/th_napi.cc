@@ -868,6 +868,53 @@ napi_value DrawQuery(napi_env env, napi_callback_info info)
     return o;
 }
 
+// lineWidth(ctx, pass, width): gl.lineWidth before the flow (0) / view (1) pass; lineWidthRange(ctx, lo, hi): what
+// ALIASED_LINE_WIDTH_RANGE reports on this context
+napi_value LineWidth(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t pass = a.i32(1);
+    double w = a.f64(2);
+    if (!a.ok) BAD_ARGS("th_line_width");
+    TH_CALL("th_line_width", th_line_width(c, pass, (float)w));
+    return undefined(env);
+}
+
+napi_value LineWidthRange(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    double lo = a.f64(1), hi = a.f64(2);
+    if (!a.ok) BAD_ARGS("th_line_width_range");
+    TH_CALL("th_line_width_range", th_line_width_range(c, (float)lo, (float)hi));
+    return undefined(env);
+}
+
+// lineWidthQuery(ctx, pass) -> {width, drawn, range: [lo, hi]}
+napi_value LineWidthQuery(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t pass = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_line_width_query");
+    float w = 0, d = 0, r[2] = {0, 0};
+    TH_CALL("th_line_width_query", th_line_width_query(c, pass, &w, &d, r));
+    napi_value o, v, arr;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_double(env, w, &v));
+    NAPI_OK(napi_set_named_property(env, o, "width", v));
+    NAPI_OK(napi_create_double(env, d, &v));
+    NAPI_OK(napi_set_named_property(env, o, "drawn", v));
+    NAPI_OK(napi_create_array_with_length(env, 2, &arr));
+    for (uint32_t k = 0; k < 2; ++k) {
+        NAPI_OK(napi_create_double(env, r[k], &v));
+        NAPI_OK(napi_set_element(env, arr, k, v));
+    }
+    NAPI_OK(napi_set_named_property(env, o, "range", arr));
+    return o;
+}
+
 // kernelTimingRead(ctx) -> {meanMs, launches}
 napi_value KernelTimingRead(napi_env env, napi_callback_info info)
 {
@@ -906,6 +953,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline}, {"drawQuery", DrawQuery},
+        {"lineWidth", LineWidth}, {"lineWidthRange", LineWidthRange}, {"lineWidthQuery", LineWidthQuery},
         {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
         {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"viewDevicePtr", ViewDevicePtr},

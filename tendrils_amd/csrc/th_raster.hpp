@@ -160,7 +160,12 @@ TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine 
     L.draws = true;
 }
 
-// The width-1 line as the hexagon of its two endpoint diamonds, in clip space (six vertices, statically indexed).
+// The line as the hexagon of its two endpoint diamonds, in clip space (six vertices, statically indexed).  Width 1 (every
+// pinned case: the captured GL clamps gl.lineWidth to 1): diamonds of half a texel.  A wider line (th_line_width on a
+// context whose th_line_width_range lets it through; unpinned) is the same construction with the diamonds scaled by the
+// width: the hexagon then measures `width` texels across in the line's minor direction, as the GL specification asks of a
+// non-antialiased wide line, and everything downstream (clipping, snapping, scan conversion, the varying projected on
+// the line) is the same code.
 // Returns kHexInside when all of it lies inside the view volume (it is rasterised as it stands), kHexOutside when all
 // six vertices are beyond ONE of the four planes (the clipper would then leave nothing: 44 % of the lines of the C3
 // bench, whose particles are spread over twice the view's height), else kHexClip.
@@ -169,7 +174,7 @@ TH_D int dep_hexagon(const DepositParams &p, const DepositLine &L, float (&cx)[6
 {
     const float fw = (float)p.fw, fh = (float)p.fh;
     const float dx = (0.5f * fw) * (L.b.px - L.a.px), dy = (0.5f * fh) * (L.b.py - L.a.py);
-    const float hx = 0.5f / (0.5f * fw), hy = 0.5f / (0.5f * fh);      // half a texel in clip space
+    const float hx = p.line_half / (0.5f * fw), hy = p.line_half / (0.5f * fh);      // half the diamond (half a texel x width) in clip space
     const DepositVertex *vv[2] = {&L.a, &L.b};
 #define TH_L(n, k) do { cx[n] = vv[k]->px - hx; cy[n] = vv[k]->py; } while (0)
 #define TH_T(n, k) do { cx[n] = vv[k]->px; cy[n] = vv[k]->py + hy; } while (0)
@@ -457,8 +462,8 @@ TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
 // interpolation parameter (false: both endpoints snap to the same point, the first vertex's value is taken)
 TH_D bool dep_param(const DepositLine &L, int x, int y, float &t)
 {
-    if (L.short32) {        // the same integers in 32 bits (a fragment lies within a texel of its line): the same floats
-        // (|ex|, |ey| < 2^14 and a fragment within a texel of its line: 24-bit factors, 30-bit sums)
+    if (L.short32) {        // the same integers in 32 bits (a fragment lies within half the line's width + a texel of its line): the same floats
+        // (|ex|, |ey| < 2^14 and a fragment within 33 texels of its line - widths up to kMaxLineWidth: 24-bit factors, 30-bit sums)
         const int ex = L.sx[1] - L.sx[0], ey = L.sy[1] - L.sy[0], den = __mul24(ex, ex) + __mul24(ey, ey);
         if (den == 0) return false;
         const int num = __mul24((x << 4) - L.sx[0], ex) + __mul24((y << 4) - L.sy[0], ey);

@@ -91,6 +91,9 @@ class Tendrils {
     this.band = { row0: params.row0 | 0, rows: params.rows | 0, globalHeight: params.globalHeight | 0 };
     this.colorMap = (params.colorMap || null);     // { shape: [w, h], data: Float32Array } (null = the 1x1 zero texture)
     this.renderView = (params.renderView !== false);   // draw() also runs the view pass, as the reference's does
+    // what gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE) reports here: [1, 1] like the GL the reference was captured on
+    // (flowWidth: 5 then draws width-1 lines, as it does there); up to [1, 64] for the picture of a GL that honours widths
+    this.lineWidthRange = (params.lineWidthRange || [1, 1]);
   }
 
   setup(...rest) { this.setupParticles(...rest); this.reset(); return this; }
@@ -121,7 +124,16 @@ class Tendrils {
     this.targets.shape = shape;
     this.flow.shape = this.flow.shape;            // (re)create on the new context
     if (this.colorMap) native.colormapUpload(this.particles.handle, this.colorMap.data, this.colorMap.shape[0], this.colorMap.shape[1]);
+    native.lineWidthRange(this.particles.handle, this.lineWidthRange[0], this.lineWidthRange[1]);
     return this;
+  }
+
+  // gl.lineWidth(Math.max(0, flowWidth)) before the flow pass, gl.lineWidth(Math.max(0, lineWidth)) before the view pass
+  // (src/index.js:302,336); a width of 0 is GL's INVALID_VALUE: the width of that pass stays what it was
+  lineWidths() {
+    const flow = Math.max(0, this.state.flowWidth), view = Math.max(0, this.state.lineWidth);
+    if (flow > 0) native.lineWidth(this.particles.handle, 0, flow);
+    if (view > 0) native.lineWidth(this.particles.handle, 1, view);
   }
 
   clear() { this.clearView(); this.clearFlow(); return this; }
@@ -203,6 +215,7 @@ class Tendrils {
 
   draw() {                                         // src/index.js:278-340: the flow pass, then the view pass
     const deposit = new Float32Array([this.viewSize[0], this.viewSize[1], this.timer.time, this.state.speedLimit]);
+    this.lineWidths();
     if (this.band.rows && this.band.rows !== (this.band.globalHeight || this.state.rootNum)) {
       // a row band of a larger texture (one process per GPU): the passes' exchange is the library's, over the communicator
       // the ranks joined with particles.commInit() - every rank calls draw() together
@@ -218,7 +231,8 @@ class Tendrils {
       this.fragments = native.flowDeposit(this.particles.handle, deposit);
       return this;
     }
-    // (the clear and the fade only touch the view buffer; both passes draw the same lines: rasterised and sorted once)
+    // (the clear and the fade only touch the view buffer; both passes draw the same lines: rasterised and sorted once
+    // when they draw them with the same width)
     if (this.state.autoClearView) this.clearView();
     if (this.state.autoFade) this.drawFade();
     this.fragments = this.viewFragments = native.draw(this.particles.handle, deposit, this.renderUniforms());

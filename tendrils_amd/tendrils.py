@@ -160,6 +160,9 @@ class Tendrils:
         self._state_format = int(params.get("stateFormat", _capi.TH_STATE_F32))
         self._band = (int(params.get("row0", 0)), params.get("rows"), int(params.get("globalHeight", 0)))
         self.dist = params.get("dist")           # torch.distributed module of a row-band-sharded job (draw() exchanges)
+        # what gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE) reports here: [1, 1] like the GL the reference was captured on
+        # (flowWidth: 5 then draws width-1 lines, as it does there); up to [1, 64] for the picture of a GL that honours widths
+        self.lineWidthRange = tuple(params.get("lineWidthRange", (1, 1)))
 
     # -- setup ---------------------------------------------------------------------
     def setup(self, *rest):                                   # src/index.js:149-154
@@ -195,7 +198,17 @@ class Tendrils:
         if isinstance(self.colorMap, ColorMap):
             self.colorMap._o = self
             self.colorMap.bind()
+        call("th_line_width_range", self.particles._ctx, float(self.lineWidthRange[0]), float(self.lineWidthRange[1]))
         return self
+
+    def line_widths(self):
+        """gl.lineWidth(Math.max(0, flowWidth)) before the flow pass, gl.lineWidth(Math.max(0, lineWidth)) before the view
+        pass (src/index.js:302,336); a width of 0 is GL's INVALID_VALUE: the width of that pass stays what it was."""
+        flow, view = max(0.0, float(self.state["flowWidth"])), max(0.0, float(self.state["lineWidth"]))
+        if flow > 0:
+            call("th_line_width", self.particles._ctx, _capi.TH_PASS_FLOW, flow)
+        if view > 0:
+            call("th_line_width", self.particles._ctx, _capi.TH_PASS_VIEW, view)
 
     # -- clears ---------------------------------------------------------------------
     def clear(self):
@@ -277,7 +290,9 @@ class Tendrils:
     def draw(self):                                            # src/index.js:278-340
         """The flow pass - particle lines into the flow texture, so that particles respond to each other's wake - and,
         with renderView, the view pass: the same lines into the RGBA8 view buffer (after the clear / fade the state
-        asks for).  Both passes draw the same lines: one call rasterises and sorts them once (th_draw)."""
+        asks for).  Both passes draw the same lines: one call rasterises and sorts them once (th_draw) when they draw them
+        with the same width."""
+        self.line_widths()
         if self.dist is not None:          # row-band shard of a torch.distributed job: emit / exchange / merge, pass by pass
             from .sharding import draw_sharded
             if self.renderView:            # (every rank holds the whole view buffer: the clear / fade are the same everywhere)

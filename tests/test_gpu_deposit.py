@@ -37,7 +37,7 @@ def gpu_deposit(cur, prev, base, time, view_res, view_size, speed_limit):
 
 
 @pytest.mark.parametrize("path", golden("deposit"), ids=lambda p: p.split("/")[-1][:-4])
-def test_deposit_reference_capture_and_oracle(oracle, path):
+def test_deposit_bit_exact_to_oracle_reference_coverage_exact_values_toleranced(oracle, path):
     fx = load(path)
     m, base, ref = deposit_inputs(fx)
     got, frags = gpu_deposit(fx["current"], fx["previous"], base, m["time"], m["viewRes"], m["viewSize"], m["speedLimit"])

@@ -19,7 +19,7 @@ def make(n, view=(96, 54)):
 
 
 @pytest.mark.parametrize("path", [p for p in golden("spawn") if "ball" in p], ids=lambda p: p.split("/")[-1][:-4])
-def test_spawn_ball(oracle, path):
+def test_spawn_ball_bit_exact_to_oracle_statistical_to_reference(oracle, path):
     from tendrils_amd.spawn import spawnBall
     fx = load(path)
     m = fx["meta"]
@@ -35,7 +35,7 @@ def test_spawn_ball(oracle, path):
 
 
 @pytest.mark.parametrize("path", [p for p in golden("spawn") if "sample" in p and "image" not in p and "geometry" not in p], ids=lambda p: p.split("/")[-1][:-4])
-def test_spawn_sample(oracle, path):
+def test_spawn_sample_bit_exact_to_oracle_statistical_to_reference(oracle, path):
     from tendrils_amd.spawn import PixelSpawner, data_sample_frag, flow_sample_frag
     fx = load(path)
     m = fx["meta"]

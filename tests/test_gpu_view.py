@@ -29,7 +29,7 @@ def make(m, n):
 
 
 @pytest.mark.parametrize("path", golden("view"), ids=lambda p: p.split("/")[-1][:-4])
-def test_view_draw_equals_oracle_and_reference(oracle, path):
+def test_view_draw_byte_exact_to_oracle_reference_coverage_exact_colours_toleranced(oracle, path):
     m, cur, prev, ref = view_fixture(path)
     t = make(m, cur.shape[0])
     t.particles.upload_texels(cur, 0)

@@ -19,7 +19,12 @@ bench.N = N
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 in_view = "--in-view" in sys.argv
 
-t = ta.Tendrils(View(1920, 1080))
+opts = ta.defaults()
+WIDTH = float(os.environ.get("TH_WIDTH", "0"))     # > 0: a GL that honours gl.lineWidth - flowWidth = lineWidth = TH_WIDTH
+if WIDTH > 0:
+    opts["lineWidthRange"] = (1, 64)
+    opts["state"]["flowWidth"] = opts["state"]["lineWidth"] = WIDTH
+t = ta.Tendrils(View(1920, 1080), opts)
 t.resize()
 t.setup(N)
 st = bench.synth_state(0)
