@@ -442,19 +442,21 @@ TH_D void apply_colors(BinTexel<MODE> &d, float4 c0, float4 c1)
 
 // LDS of a bin's workgroup.  `pool` is used two ways:
 //   the common case (a bin of <= kBinCap fragments, no run longer than kRankMaxRun): sid = stream index of every fragment,
-//     grouped by texel | osrc = the fragments' positions (where their varyings lie) in blend order        (2 x kBinCap words)
+//     grouped by texel, and then - once every fragment knows its rank - in the same words osrc = the fragments' positions
+//     (where their varyings lie) in blend order                                                            (kBinCap words)
 //   crowded bins: skey = 64-bit sort keys of a batch of <= kCrowdCap fragments | order = blend order as indices into skey |
-//     hist = the id histogram of a texel too crowded for one batch
+//     hist = the id histogram of a texel too crowded for one batch                                  (3 x kCrowdCap words)
+// (24 KB + the stages: five workgroups per CU for one target, four for both - the pass waits on its loads, not on arithmetic)
 constexpr uint32_t kCrowdCap = 2048;
 template <int MODE>
 struct BinShared {
-    uint32_t pool[2u * kBinCap];
+    uint32_t pool[3u * kCrowdCap];
     uint32_t cnt[kBinTexels], first[kBinTexels + 1u];        // fragments per texel (then: fill cursors); first fragment of every texel
     BlendSource stage_a[256], stage_b[MODE == 2 ? 256 : 1];  // a long run's sources, 256 at a time (b: the view pass's beside the flow pass's)
     uint32_t misc[8];
     uint32_t lists[kBinReplicas + 1u];                       // first place of every list of the bin when its lists are walked one after the other
     TH_D uint32_t *sid() { return pool; }
-    TH_D uint32_t *osrc() { return pool + kBinCap; }
+    TH_D uint32_t *osrc() { return pool; }
     TH_D unsigned long long *skey() { return reinterpret_cast<unsigned long long *>(pool); }     // kCrowdCap keys = 4096 words
     TH_D uint16_t *order() { return reinterpret_cast<uint16_t *>(pool + 2u * kCrowdCap); }         // kCrowdCap indices = 1024 words
     TH_D uint32_t *hist() { return pool + 2u * kCrowdCap + kCrowdCap; }                             // 1024 buckets
@@ -701,7 +703,7 @@ TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
+__global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(const DepositParams p)
 {
     __shared__ BinShared<MODE> s;
     const uint32_t b = blockIdx.x, t = threadIdx.x;
@@ -737,15 +739,27 @@ __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
         // runs laid out by the scan, every fragment's stream index dropped into its texel's run (in whatever order the LDS
         // atomics hand out), then every fragment ranks itself inside its run by counting the smaller indices - its place
         // in GL's order - and leaves the place of its varying there for the texel's thread.
-        unsigned long long k[kPer];
+        // (per fragment a thread keeps: the place of its varying, its stream index, its texel inside the bin - four to a word;
+        // then its rank, likewise)
+        uint32_t id[kPer], lts[kPer / 4u] = {}, ranks[kPer / 4u] = {}, have = 0u;
+        {
+            unsigned long long k[kPer];
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; at[q] = place(f < n ? f : n - 1u); }
+            for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; at[q] = place(f < n ? f : n - 1u); }
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) k[q] = keys[at[q]];
+            for (uint32_t q = 0; q < kPer; ++q) k[q] = keys[at[q]];
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; ++q) {
+                id[q] = (uint32_t)k[q];
+                lts[q >> 2] |= key_local(k[q]) << ((q & 3u) * 8u);
+                have |= (q * 256u + t < n && k[q] != kEmptyKey) ? 1u << q : 0u;
+            }
+        }
+        auto lt_of = [&](uint32_t q) { return (lts[q >> 2] >> ((q & 3u) * 8u)) & 0xffu; };
         s.cnt[t] = 0u;
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) if (q * 256u + t < n && k[q] != kEmptyKey) atomicAdd(&s.cnt[key_local(k[q])], 1u);
+        for (uint32_t q = 0; q < kPer; ++q) if (have >> q & 1u) atomicAdd(&s.cnt[lt_of(q)], 1u);
         __syncthreads();
         const uint32_t mine = s.cnt[t];
         const uint32_t longest = bin_scan_counts(s);
@@ -754,23 +768,22 @@ __global__ __launch_bounds__(256) void bins_blend_kernel(const DepositParams p)
             s.cnt[t] = 0u;
             __syncthreads();
             uint32_t *sid = s.sid(), *osrc = s.osrc();
-            uint32_t to[kPer];
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
-                if (q * 256u + t < n && k[q] != kEmptyKey) {
-                    const uint32_t lt = key_local(k[q]);
-                    to[q] = s.first[lt] + atomicAdd(&s.cnt[lt], 1u);
-                    sid[to[q]] = (uint32_t)k[q];
-                }
+                if (have >> q & 1u) { const uint32_t lt = lt_of(q); sid[s.first[lt] + atomicAdd(&s.cnt[lt], 1u)] = id[q]; }
             __syncthreads();
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
-                if (q * 256u + t < n && k[q] != kEmptyKey) {
-                    const uint32_t lt = key_local(k[q]), id = (uint32_t)k[q], r0 = s.first[lt], r1 = s.first[lt + 1u];
-                    uint32_t rank = 0;
-                    for (uint32_t j = r0; j < r1; ++j) rank += sid[j] < id ? 1u : 0u;
-                    osrc[r0 + rank] = at[q];
+                if (have >> q & 1u) {
+                    const uint32_t lt = lt_of(q), r0 = s.first[lt], r1 = s.first[lt + 1u];
+                    uint32_t rank = 0;                  // (< kRankMaxRun = 256: a byte)
+                    for (uint32_t j = r0; j < r1; ++j) rank += sid[j] < id[q] ? 1u : 0u;
+                    ranks[q >> 2] |= rank << ((q & 3u) * 8u);
                 }
+            __syncthreads();                            // (every stream index has been read: the words now take the places)
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; ++q)
+                if (have >> q & 1u) osrc[s.first[lt_of(q)] + ((ranks[q >> 2] >> ((q & 3u) * 8u)) & 0xffu)] = at[q];
             __syncthreads();
             const uint32_t r0 = s.first[t];
             auto src_at = [&](uint32_t base) { return [osrc, base](uint32_t j) { return osrc[base + j]; }; };
