@@ -160,6 +160,7 @@ struct th_context {
     size_t crowd_keys_cap = 0;
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
+    uint32_t *bins_totals_host = nullptr;      // (pinned) the binned pass's totals, read back over the side stream
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
@@ -605,6 +606,7 @@ th_status th_destroy(th_context *c)
     if (c->forked) (void)hipEventDestroy(c->forked);
     if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->bins_totals_host) (void)hipHostFree(c->bins_totals_host);
     (void)hipFree(c->x_halo); (void)hipFree(c->x_counts); (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
@@ -1607,13 +1609,26 @@ static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool p
     return TH_OK;
 }
 
+constexpr double kEarlyBlendShare = 0.5;            // (of a draw's fragments in crowded bins: see deposit_run_bins)
 constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
 
 // the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + emit into the bins, plan, per-bin order + blend
 static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
 {
     c->drawn.valid = false;
-    uint32_t host[th::kTotWords];
+    if (!c->side) {
+        TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
+        TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
+        TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    uint32_t *host = c->bins_totals_host;
+    // Which comes first behind the emitting pass: the ordinary bins' blend - it needs nothing from the host and covers the
+    // read-back - or, on a crowded target, the crowded bins' kernels: their long runs (walked by one thread each, on the
+    // side stream) are then the longest chain of the draw and must start as early as they can.  Decided by the last draw.
+    static const int early_env = [] { const char *e = getenv("TH_BINS_EARLY"); return e ? atoi(e) : -1; }();       // (A/B)
+    const bool early = early_env >= 0 ? early_env != 0
+                                      : !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
     for (int attempt = 0;; ++attempt) {
         // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
         static const uint32_t pool0 = [] { const char *e = getenv("TH_BINS_POOL"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
@@ -1622,8 +1637,13 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
         th::launch_bins_fused(p, c->stream);
-        TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
-        TH_HIP(hipStreamSynchronize(c->stream));
+        // the totals come back over the side stream while the ordinary bins are already being blended (the kernel looks at the
+        // pass's flags itself): the host's round trip - it sizes the crowded bins' launches - costs the GPU nothing
+        TH_HIP(hipEventRecord(c->forked, c->stream));
+        if (early) th::launch_bins_blend(p, c->stream);
+        TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
+        TH_HIP(hipMemcpyAsync(host, c->dep_total, th::kTotWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
+        TH_HIP(hipStreamSynchronize(c->side));
         const uint32_t flags = host[th::kTotFlags];
         if (flags == 0) break;
         // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
@@ -1668,19 +1688,15 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     th::launch_bins_regroup(p, c->stream);
     static const bool overlap = [] { const char *e = getenv("TH_BINS_SIDE"); return !e || atoi(e) != 0; }();     // (A/B)
     if (nlarge && overlap) {
-        // the long runs on a stream of their own, beside the bins' and the short runs' blend (disjoint texels): the walk of
-        // the longest run - one thread, one fragment after the other - overlaps with everything else instead of following it
-        if (!c->side) {
-            TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-            TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
-            TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
-        }
+        // the long runs on a stream of their own, beside the short runs' blend (disjoint texels): the walk of the longest
+        // run - one thread, one fragment after the other - overlaps with everything else instead of following it
         TH_HIP(hipEventRecord(c->forked, c->stream));
         TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
         th::launch_bins_blend_long(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
     } else th::launch_bins_blend_long(p, c->stream);
-    th::launch_bins_blend(p, c->stream);           // (every list's cursor counts: empty places are skipped as they are met)
+    th::launch_bins_blend_crowd(p, c->stream);
+    if (!early) th::launch_bins_blend(p, c->stream);
     if (nlarge && overlap) TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
     TH_HIP(hipGetLastError());
     return TH_OK;

@@ -707,6 +707,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
 {
     __shared__ BinShared<MODE> s;
     const uint32_t b = blockIdx.x, t = threadIdx.x;
+    // (the pass is launched before the host has seen the emitting pass's flags - its read-back hides under this kernel: a
+    // pass that ran out of pages or of room in a bin is repeated before anything is blended)
+    if (p.totals[kTotFlags] != 0u) return;
     if (t == 0u) {
         uint32_t run = 0;
         for (uint32_t r = 0; r < kBinReplicas; ++r) { s.lists[r] = run; const uint32_t c = *list_cursor(p, b, r); run = run + c < run ? 0xffffffffu : run + c; }
@@ -1066,17 +1069,26 @@ void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
 #undef TH_GO
 }
 
-void launch_bins_blend(const DepositParams &p, hipStream_t s)
+void launch_bins_blend_crowd(const DepositParams &p, hipStream_t s)
 {
+    if (!p.nlarge) return;
     // every run of up to kWaveRun fragments ordered by a wave of its own ...  (Up to kGiantRun - the 257..1024 class through a
     // 16-keys-per-lane instantiation over the list - was slower: a lane walking a thousand fragments holds its wave: 2.60
     // against 2.28 ms per crowded draw.)
-    if (p.nlarge) hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p);
-    // ... and walked by a lane of its own; the bins of up to kBinCap places
-#define TH_GO(M) do { if (p.nlarge) hipLaunchKernelGGL(crowd_walk_kernel<M>, dim3(p.nlarge * 4u), dim3(64), 0, s, p); \
-                      hipLaunchKernelGGL(bins_blend_kernel<M>, dim3(p.nbins), dim3(256), 0, s, p); } while (0)
-    if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
-#undef TH_GO
+    hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p);
+    // ... and walked by a lane of its own
+    if (p.mode == 0) hipLaunchKernelGGL(crowd_walk_kernel<0>, dim3(p.nlarge * 4u), dim3(64), 0, s, p);
+    else if (p.mode == 1) hipLaunchKernelGGL(crowd_walk_kernel<1>, dim3(p.nlarge * 4u), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(crowd_walk_kernel<2>, dim3(p.nlarge * 4u), dim3(64), 0, s, p);
+}
+
+// the bins of up to kBinCap places, a workgroup each.  Needs nothing from the host: launched right behind launch_bins_fused,
+// it covers the read-back of the pass's totals (the kernel returns at once when the pass raised a flag)
+void launch_bins_blend(const DepositParams &p, hipStream_t s)
+{
+    if (p.mode == 0) hipLaunchKernelGGL(bins_blend_kernel<0>, dim3(p.nbins), dim3(256), 0, s, p);
+    else if (p.mode == 1) hipLaunchKernelGGL(bins_blend_kernel<1>, dim3(p.nbins), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bins_blend_kernel<2>, dim3(p.nbins), dim3(256), 0, s, p);
 }
 size_t crowd_words_per_bin() { return 5u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list, the giants' list
 

@@ -220,7 +220,8 @@ enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
 void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
 void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs of more fragments than a wave orders (the longest first)
-void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // every other run, bin by bin / wave by wave: order by (texel, stream index), blend
+void launch_bins_blend_crowd(const DepositParams &p, hipStream_t stream);             // their other runs, a wave each: order by stream index, blend
+void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // the bins one workgroup orders: by (texel, stream index), blend (needs no host value)
 size_t crowd_words_per_bin();
 // RCCL side of a context (th_comm.hip; librccl bound at run time).  Every function returns 0 or leaves comm_error().
 const char *comm_error();
