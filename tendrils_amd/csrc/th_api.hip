@@ -161,6 +161,7 @@ struct th_context {
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
     uint32_t *bins_totals_host = nullptr;      // (pinned) the binned pass's totals, read back over the side stream
+    void *pinned = nullptr;                    // (pinned, kPinnedBytes) small read-backs: a pageable hipMemcpyAsync costs ~0.15 ms per call
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
@@ -607,6 +608,7 @@ th_status th_destroy(th_context *c)
     if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->bins_totals_host) (void)hipHostFree(c->bins_totals_host);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipFree(c->x_halo); (void)hipFree(c->x_counts); (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
     for (uint32_t *q : c->dep_u32) (void)hipFree(q);
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
@@ -1464,13 +1466,24 @@ static th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th
     return TH_OK;
 }
 
+// a few words from the device to the host, through pinned memory, with the stream's work before them finished
+constexpr size_t kPinnedBytes = 1024;
+static th_status read_back(th_context *c, void *host, const void *dev, size_t bytes)
+{
+    TH_REQUIRE(bytes <= kPinnedBytes, "read_back of %zu bytes", bytes);
+    if (!c->pinned) TH_HIP(hipHostMalloc(&c->pinned, kPinnedBytes, hipHostMallocDefault));
+    TH_HIP(hipMemcpyAsync(c->pinned, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    memcpy(host, c->pinned, bytes);
+    return TH_OK;
+}
+
 // scan of p.count (filled by the caller's marking pass) -> p.offset, total (one sync); reports band violations
 static th_status deposit_scan_total(th_context *c, const th::DepositParams &p, uint32_t *total)
 {
     th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
     uint32_t host[2] = {0, 0};
-    TH_HIP(hipMemcpyAsync(host, c->dep_total, sizeof host, hipMemcpyDeviceToHost, c->stream));
-    TH_HIP(hipStreamSynchronize(c->stream));
+    if (th_status s = read_back(c, host, c->dep_total, sizeof host)) return s;
     if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d) and no halo row was supplied (th_deposit_set_halo)", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
     if (host[0] >= (1u << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one draw (2^31 or more)");
     *total = host[0];
@@ -1955,8 +1968,7 @@ static th_status merge_parted(th_context *c, const void *keys_dev, const void *c
                                    static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
     TH_HIP(hipGetLastError());
     uint32_t too_many = 0;
-    TH_HIP(hipMemcpyAsync(&too_many, c->dep_total, sizeof too_many, hipMemcpyDeviceToHost, c->stream));
-    TH_HIP(hipStreamSynchronize(c->stream));               // the input buffers may be reused by the caller now
+    if (th_status s = read_back(c, &too_many, c->dep_total, sizeof too_many)) return s;        // (a sync: the input buffers may be reused by the caller now)
     if (too_many) return fail(TH_ERR_UNSUPPORTED, "a texel received fragments of more than 32 source bands");
     return TH_OK;
 }
@@ -1989,8 +2001,7 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     std::vector<unsigned long long> hb((size_t)world + 1, 0ull);
     if (count) {
         th::launch_owner_bounds(static_cast<const unsigned long long *>(keys), (uint32_t)count, (uint32_t)world, bounds, c->stream);
-        TH_HIP(hipMemcpyAsync(hb.data(), bounds, ((size_t)world + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        TH_HIP(hipStreamSynchronize(c->stream));
+        if (th_status s = read_back(c, hb.data(), bounds, ((size_t)world + 1) * sizeof(unsigned long long))) return s;
     }
     std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
     std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
@@ -1998,8 +2009,7 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     if (th::comm_alltoallv(c->comm, sendc, one.data(), idx.data(), recvc, one.data(), idx.data(), sizeof(unsigned long long), world, c->stream))
         return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
-    TH_HIP(hipMemcpyAsync(hr.data(), recvc, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    TH_HIP(hipStreamSynchronize(c->stream));
+    if (th_status s = read_back(c, hr.data(), recvc, (size_t)world * sizeof(unsigned long long))) return s;
     size_t total = 0;
     for (int r = 0; r < world; ++r) { rcount[(size_t)r] = (size_t)hr[(size_t)r]; roff[(size_t)r] = total; total += rcount[(size_t)r]; }
     TH_REQUIRE(total < ((size_t)1 << 31), "too many fragments for one owner");
@@ -2148,9 +2158,7 @@ th_status th_stats(th_context *c, float speed_limit, th_counters *out)
 {
     TH_REQUIRE(out, "null output");
     if (th_status s = th_stats_async(c, speed_limit, nullptr)) return s;
-    TH_HIP(hipMemcpyAsync(out, c->d_counters, sizeof *out, hipMemcpyDeviceToHost, c->stream));
-    TH_HIP(hipStreamSynchronize(c->stream));
-    return TH_OK;
+    return read_back(c, out, c->d_counters, sizeof *out);
 }
 
 // ---- one process per GPU: the communicator of the job's ranks and the path's collective (th_comm.hip) --------------------
@@ -2250,9 +2258,7 @@ th_status th_stats_global(th_context *c, float speed_limit, th_counters *out)
     TH_REQUIRE(out, "null output");
     if (th_status s = th_stats_async(c, speed_limit, nullptr)) return s;
     if (th_status s = th_stats_allreduce(c)) return s;
-    TH_HIP(hipMemcpyAsync(out, c->d_counters, sizeof *out, hipMemcpyDeviceToHost, c->stream));
-    TH_HIP(hipStreamSynchronize(c->stream));
-    return TH_OK;
+    return read_back(c, out, c->d_counters, sizeof *out);
 }
 
 th_status th_sync(th_context *c)
