@@ -355,13 +355,22 @@ th_status th_export_view_lines(th_context *ctx, const th_render_uniforms *u, flo
  * this context's view buffer in (texel, stream index) order - for the owned texels the unsharded view pass byte for byte;
  * th_view_device_ptr = the RGBA8 view buffer (flow shape) whose owned ranges the ranks then gather. */
 /* Tendrils.draw() of a row-band shard with the exchange issued by the LIBRARY over its own communicator (every rank,
- * collectively; needs th_comm_init; balanced bands, <= 32 ranks): edge rows to the neighbours, then per pass emit ->
- * fragment all-to-all by texel owner -> merge -> all-gather of the owned ranges, all on the context's stream (ncclSend /
- * ncclRecv groups, ncclAllGather).  r = NULL: the flow pass only.  Same results as the primitives above driven by a host. */
+ * collectively; needs th_comm_init; balanced bands, <= 32 ranks): edge rows to the neighbours, then emit -> fragment
+ * all-to-all by texel owner -> merge -> all-gather of the owned ranges, all on the context's stream (ncclSend / ncclRecv
+ * groups, ncclAllGather) - once for both passes (th_draw_emit / th_draw_merge below) when they draw with the same line
+ * width, else pass by pass.  r = NULL: the flow pass only.  Same results as the primitives driven by a host. */
 th_status th_draw_sharded(th_context *ctx, const th_deposit_uniforms *u, const th_render_uniforms *r, uint64_t *fragments);
 th_status th_view_emit(th_context *ctx, const th_render_uniforms *u, uint64_t *count, void **keys_dev, void **colors_dev);
 th_status th_view_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
 th_status th_view_device_ptr(th_context *ctx, void **dptr);
+/* Both passes of a row-band shard's draw() over ONE rasterisation and ONE exchange (src/index.js:278-337; what th_draw is to
+ * th_flow_deposit + th_view_draw): th_draw_emit = this band's fragments, every one with the flow pass's varying and the view
+ * pass's colour side by side (colors: 2 x float4 per fragment), parted by owner; th_draw_merge = the owner's fragments
+ * blended into the flow texture and the view buffer.  Needs both passes to draw with the same line width (else:
+ * TH_ERR_INVALID, use the per-pass primitives); u and r must agree in viewSize, time and speedLimit.  th_draw_sharded goes
+ * this way whenever it can. */
+th_status th_draw_emit(th_context *ctx, const th_deposit_uniforms *u, const th_render_uniforms *r, uint64_t *count, void **keys_dev, void **colors_dev);
+th_status th_draw_merge(th_context *ctx, const void *keys_dev, const void *colors_dev, uint64_t count);
 
 /* Slot layout of the ring (build-defined, invisible in every result): how many ring buffers are held in a
  * tile-sorted slot order, integrator passes since the last sort, and the flow taps since then that left the

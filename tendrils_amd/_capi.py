@@ -143,6 +143,8 @@ PROTOTYPES = {
     "th_flow_device_ptr": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
     "th_view_emit": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "th_view_merge": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "th_draw_emit": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(RenderUniforms), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "th_draw_merge": (C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64]),
     "th_draw_sharded": (C.c_int32, [_ctx, C.POINTER(DepositUniforms), C.POINTER(RenderUniforms), C.POINTER(C.c_uint64)]),
     "th_view_device_ptr": (C.c_int32, [_ctx, C.POINTER(C.c_void_p)]),
     "th_state_gather": (C.c_int32, [_ctx, C.c_int32]),

@@ -161,6 +161,7 @@ struct th_context {
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
     uint32_t *bins_totals_host = nullptr;      // (pinned) the binned pass's totals, read back over the side stream
+    bool mrg_pairs = false, x_pairs = false;   // the merge / exchange colour buffers hold two varyings per fragment (th_draw_emit / _merge)
     void *pinned = nullptr;                    // (pinned, kPinnedBytes) small read-backs: a pageable hipMemcpyAsync costs ~0.15 ms per call
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
@@ -1879,7 +1880,8 @@ static th_status emit_parted(th_context *c, th::DepositParams &p, uint32_t total
 {
     *count = total; *keys_dev = nullptr; *colors_dev = nullptr;
     if (total == 0) return TH_OK;
-    if (th_status s = deposit_reserve(c, total, true)) return s;
+    const bool pairs = p.mode == 2;                  // th_draw_emit: two varyings per fragment, side by side
+    if (th_status s = deposit_reserve(c, total, true, pairs)) return s;
     p.keys64 = c->dep_u64[0]; p.slots = c->dep_u32[1]; p.colors = c->dep_colors;
     p.owners = c->dep_owners;
     p.owner_chunk = (uint32_t)(((uint64_t)c->fw * c->fh + p.owners - 1u) / p.owners);
@@ -1893,7 +1895,8 @@ static th_status emit_parted(th_context *c, th::DepositParams &p, uint32_t total
         if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, th::kOwnerShift, th::kOwnerShift + owner_bits))) return s;
         const int in_b = th::launch_radix_sort_u64(c->dep_u64[0], c->dep_u32[1], c->dep_u64[1], c->dep_u32[3], total, th::kOwnerShift,
                                                    th::kOwnerShift + owner_bits, c->dep_temp, true, c->stream);
-        th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, in_b ? c->dep_u32[3] : c->dep_u32[1], total, c->stream);
+        if (pairs) th::launch_deposit_gather_pairs(c->dep_colors_sorted, c->dep_colors, in_b ? c->dep_u32[3] : c->dep_u32[1], total, c->stream);
+        else th::launch_deposit_gather_colors(c->dep_colors_sorted, c->dep_colors, in_b ? c->dep_u32[3] : c->dep_u32[1], total, c->stream);
         *keys_dev = in_b ? c->dep_u64[1] : c->dep_u64[0]; *colors_dev = c->dep_colors_sorted;
     }
     TH_HIP(hipGetLastError());
@@ -1926,6 +1929,29 @@ th_status th_view_emit(th_context *c, const th_render_uniforms *u, uint64_t *cou
     return emit_parted(c, p, total, count, keys_dev, colors_dev);
 }
 
+// both passes of a row-band shard's draw() in one: every fragment with the flow pass's varying and the view pass's colour
+// side by side (32 bytes), rasterised, parted and - by the host or th_draw_sharded - exchanged once
+th_status th_draw_emit(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *count, void **keys_dev, void **colors_dev)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(du && ru && count && keys_dev && colors_dev, "null argument");
+    TH_REQUIRE((uint64_t)c->fw * c->fh <= (uint64_t)th::kTexelMask + 1u, "the sharded deposit keys hold 24 texel bits: target %dx%d is too large", c->fw, c->fh);
+    TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
+               memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
+               "the two passes of one draw share viewSize, time and speedLimit");
+    TH_REQUIRE(drawn_line_width(c, TH_PASS_FLOW) == drawn_line_width(c, TH_PASS_VIEW),
+               "the two passes draw their lines %g and %g wide: th_deposit_emit and th_view_emit rasterise them apart",
+               (double)drawn_line_width(c, TH_PASS_FLOW), (double)drawn_line_width(c, TH_PASS_VIEW));
+    th::DepositParams p;
+    if (th_status s = deposit_prepare(c, du, p)) return s;
+    p.mode = 2;
+    view_fields(c, ru, p);
+    th::launch_deposit_count(p, c->stream);
+    uint32_t total = 0;
+    if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    return emit_parted(c, p, total, count, keys_dev, colors_dev);
+}
+
 th_status th_deposit_set_halo(th_context *c, const void *lo_dev, const void *hi_dev)
 {
     TH_REQUIRE(c, "null context");
@@ -1934,11 +1960,18 @@ th_status th_deposit_set_halo(th_context *c, const void *lo_dev, const void *hi_
     return TH_OK;
 }
 
-static th_status merge_parted(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count, bool into_view)
+// target: 0 = the flow texture, 1 = the view buffer, 2 = both (the fragments carry pairs of varyings: th_draw_emit)
+static th_status merge_parted(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count, int target)
 {
     if (count == 0) return TH_OK;
     TH_REQUIRE(keys_dev && colors_dev && count < (1ull << 31), "bad fragment buffers");
     const uint32_t total = (uint32_t)count;
+    const bool into_view = target == 1;
+    if (target == 2 && !c->mrg_pairs) {               // room for two varyings per fragment from now on
+        (void)hipFree(c->mrg_colors); c->mrg_colors = nullptr;
+        if (c->mrg_capacity) TH_HIP(hipMalloc((void **)&c->mrg_colors, 2 * c->mrg_capacity * sizeof(float4)));
+        c->mrg_pairs = true;
+    }
     if (c->mrg_capacity < total) {
         (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
         (void)hipFree(c->mrg_colors);
@@ -1948,7 +1981,7 @@ static th_status merge_parted(th_context *c, const void *keys_dev, const void *c
         TH_HIP(hipMalloc((void **)&c->mrg_keys2, cap * sizeof(unsigned long long)));
         TH_HIP(hipMalloc((void **)&c->mrg_vals[0], cap * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->mrg_vals[1], cap * sizeof(uint32_t)));
-        TH_HIP(hipMalloc((void **)&c->mrg_colors, cap * sizeof(float4)));
+        TH_HIP(hipMalloc((void **)&c->mrg_colors, (c->mrg_pairs ? 2 : 1) * cap * sizeof(float4)));
         c->mrg_capacity = cap;
     }
     // what arrives is one part per source band, every part in that band's stream order: a stable sort by texel (the
@@ -1960,7 +1993,10 @@ static th_status merge_parted(th_context *c, const void *keys_dev, const void *c
     // (the sort ping-pongs between its two buffer pairs: the caller's keys are copied, not sorted in place)
     TH_HIP(hipMemcpyAsync(c->mrg_keys, keys_dev, (size_t)total * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
     const int in_b = th::launch_radix_sort_u64(c->mrg_keys, c->mrg_vals[0], c->mrg_keys2, c->mrg_vals[1], total, 32, bits, c->dep_temp, true, c->stream);
-    if (into_view)
+    if (target == 2)
+        th::launch_draw_blend64(c->flow, c->view, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
+                                static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
+    else if (into_view)
         th::launch_view_blend64(c->view, in_b ? c->mrg_keys2 : c->mrg_keys, in_b ? c->mrg_vals[1] : c->mrg_vals[0],
                                 static_cast<const float4 *>(colors_dev), c->mrg_colors, total, c->dep_total, c->stream);
     else
@@ -1976,25 +2012,35 @@ static th_status merge_parted(th_context *c, const void *keys_dev, const void *c
 th_status th_deposit_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
 {
     if (th_status s = use(c)) return s;
-    return merge_parted(c, keys_dev, colors_dev, count, false);
+    return merge_parted(c, keys_dev, colors_dev, count, 0);
 }
 
 th_status th_view_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
 {
     if (th_status s = use(c, true)) return s;
     if (th_status s = view_storage(c)) return s;
-    return merge_parted(c, keys_dev, colors_dev, count, true);
+    return merge_parted(c, keys_dev, colors_dev, count, 1);
+}
+
+th_status th_draw_merge(th_context *c, const void *keys_dev, const void *colors_dev, uint64_t count)
+{
+    if (th_status s = use(c, true)) return s;
+    if (th_status s = view_storage(c)) return s;
+    return merge_parted(c, keys_dev, colors_dev, count, 2);
 }
 
 // ---- draw() of a row-band shard, the exchange issued by the library over its own communicator ---------------------------------
 // One pass: this band's fragments parted by owner -> all-to-all -> the owner's merge -> all-gather of the owned ranges.
+// du alone: the flow pass; ru alone: the view pass; both: both passes over one rasterisation and one exchange (two all-gathers)
 static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
 {
     const int world = c->comm_world, rank = c->comm_rank;
-    const bool view = ru != nullptr;
+    const bool view = ru != nullptr, both = ru != nullptr && du != nullptr;
+    const size_t color_bytes = both ? 2 * sizeof(float4) : sizeof(float4);
     uint64_t count = 0;
     void *keys = nullptr, *colors = nullptr;
-    if (th_status s = view ? th_view_emit(c, ru, &count, &keys, &colors) : th_deposit_emit(c, du, &count, &keys, &colors)) return s;
+    if (th_status s = both ? th_draw_emit(c, du, ru, &count, &keys, &colors)
+                           : (view ? th_view_emit(c, ru, &count, &keys, &colors) : th_deposit_emit(c, du, &count, &keys, &colors))) return s;
     if (fragments) *fragments = count;
     // every owner's share of what this rank emitted, and of what it will receive
     unsigned long long *bounds = c->x_counts, *sendc = c->x_counts + 33, *recvc = c->x_counts + 65;
@@ -2013,28 +2059,34 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     size_t total = 0;
     for (int r = 0; r < world; ++r) { rcount[(size_t)r] = (size_t)hr[(size_t)r]; roff[(size_t)r] = total; total += rcount[(size_t)r]; }
     TH_REQUIRE(total < ((size_t)1 << 31), "too many fragments for one owner");
-    if (c->x_capacity < total) {
+    if (c->x_capacity < total || (both && !c->x_pairs)) {
         (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
         c->x_keys = nullptr; c->x_colors = nullptr; c->x_capacity = 0;
-        const size_t cap = total + total / 4 + 1024;
+        c->x_pairs = c->x_pairs || both;
+        const size_t cap = std::max(total, c->x_capacity) + total / 4 + 1024;
         TH_HIP(hipMalloc((void **)&c->x_keys, cap * sizeof(unsigned long long)));
-        TH_HIP(hipMalloc((void **)&c->x_colors, cap * sizeof(float4)));
+        TH_HIP(hipMalloc((void **)&c->x_colors, (c->x_pairs ? 2 : 1) * cap * sizeof(float4)));
         c->x_capacity = cap;
     }
     if (th::comm_alltoallv(c->comm, keys, scount.data(), soff.data(), c->x_keys, rcount.data(), roff.data(), sizeof(unsigned long long), world, c->stream) ||
-        th::comm_alltoallv(c->comm, colors, scount.data(), soff.data(), c->x_colors, rcount.data(), roff.data(), sizeof(float4), world, c->stream))
+        th::comm_alltoallv(c->comm, colors, scount.data(), soff.data(), c->x_colors, rcount.data(), roff.data(), color_bytes, world, c->stream))
         return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
-    if (th_status s = view ? th_view_merge(c, c->x_keys, c->x_colors, total) : th_deposit_merge(c, c->x_keys, c->x_colors, total)) return s;
-    // the owners' texel ranges of the target to every rank, in place
-    const size_t texels = (size_t)c->fw * c->fh, chunk = (texels + (size_t)world - 1) / (size_t)world, elem = view ? sizeof(uchar4) : sizeof(float4);
-    std::vector<size_t> gb((size_t)world), go((size_t)world);
-    for (int r = 0; r < world; ++r) {
-        const size_t lo = std::min(texels, (size_t)r * chunk), hi = std::min(texels, ((size_t)r + 1) * chunk);
-        gb[(size_t)r] = (hi - lo) * elem; go[(size_t)r] = lo * elem;
+    if (th_status s = both ? th_draw_merge(c, c->x_keys, c->x_colors, total)
+                           : (view ? th_view_merge(c, c->x_keys, c->x_colors, total) : th_deposit_merge(c, c->x_keys, c->x_colors, total))) return s;
+    // the owners' texel ranges of the target(s) to every rank, in place
+    const size_t texels = (size_t)c->fw * c->fh, chunk = (texels + (size_t)world - 1) / (size_t)world;
+    for (int plane_of = 0; plane_of < 2; ++plane_of) {          // 0: the flow texture, 1: the view buffer
+        if (plane_of == 0 ? (view && !both) : !view) continue;
+        const size_t elem = plane_of ? sizeof(uchar4) : sizeof(float4);
+        std::vector<size_t> gb((size_t)world), go((size_t)world);
+        for (int r = 0; r < world; ++r) {
+            const size_t lo = std::min(texels, (size_t)r * chunk), hi = std::min(texels, ((size_t)r + 1) * chunk);
+            gb[(size_t)r] = (hi - lo) * elem; go[(size_t)r] = lo * elem;
+        }
+        char *plane = plane_of ? reinterpret_cast<char *>(c->view) : reinterpret_cast<char *>(c->flow);
+        if (th::comm_allgather_bytes(c->comm, plane + go[(size_t)rank], plane, gb.data(), go.data(), rank, world, c->stream))
+            return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
     }
-    char *plane = view ? reinterpret_cast<char *>(c->view) : reinterpret_cast<char *>(c->flow);
-    if (th::comm_allgather_bytes(c->comm, plane + go[(size_t)rank], plane, gb.data(), go.data(), rank, world, c->stream))
-        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
     return TH_OK;
 }
 
@@ -2066,12 +2118,18 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
         c->halo_hi = rank + 1 < world ? c->x_halo + (size_t)2 * W : nullptr;
     }
     c->dep_owners = (uint32_t)world;
-    if (th_status s = sharded_pass(c, du, nullptr, fragments)) return s;
     if (ru) {
         TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
                    memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
                    "the two passes of one draw share viewSize, time and speedLimit");
-        if (th_status s = sharded_pass(c, nullptr, ru, nullptr)) return s;
+        if (th_status s = view_storage(c)) return s;
+    }
+    if (ru && drawn_line_width(c, TH_PASS_FLOW) == drawn_line_width(c, TH_PASS_VIEW)) {
+        // both passes draw the same lines: one rasterisation, one sort, one exchange of fragments carrying both varyings
+        if (th_status s = sharded_pass(c, du, ru, fragments)) return s;
+    } else {
+        if (th_status s = sharded_pass(c, du, nullptr, fragments)) return s;
+        if (ru) if (th_status s = sharded_pass(c, nullptr, ru, nullptr)) return s;
     }
     TH_HIP(hipStreamSynchronize(c->stream));
     return TH_OK;

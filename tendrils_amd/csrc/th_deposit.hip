@@ -167,7 +167,7 @@ struct BandKeys {
 // long ones by a merge of up to kMaxBands band cursors
 constexpr int kMaxBands = 32;
 template <typename Target>
-TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, const float4 *colors, uint32_t i, uint32_t total,
+TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, const float4 *colors, uint32_t stride, uint32_t i, uint32_t total,
                            uint32_t texel, uint32_t *too_many)
 {
     uint32_t end = i + 1u, bands = 1u;
@@ -182,7 +182,7 @@ TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, 
                 const unsigned long long id = (uint32_t)keys.k[j];
                 if (id >= after && id < best_id) { best = j; best_id = id; }
             }
-            Target::apply(d, Target::source(colors[best]));
+            Target::apply(d, Target::source(colors[(size_t)best * stride]));
             after = best_id + 1ull;
         }
     } else if (bands <= (uint32_t)kMaxBands) {
@@ -197,7 +197,7 @@ TH_D void blend_banded_run(typename Target::Texel *plane, const BandKeys &keys, 
         for (uint32_t n = i; n < end; ++n) {
             uint32_t best = 0;
             for (uint32_t b = 1; b < nb; ++b) if (head[b] < head[best]) best = b;
-            Target::apply(d, Target::source(colors[pos[best]]));
+            Target::apply(d, Target::source(colors[(size_t)pos[best] * stride]));
             ++pos[best];                              // only the band that moved reads its next key
             head[best] = pos[best] < lim[best] ? (unsigned long long)(uint32_t)keys.k[pos[best]] : 0x100000000ull;
         }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
             }
             if (lane == (uint32_t)owner) { if (falls) banded = true; else plane[run_texel] = rd; }
         }
-        if constexpr (Keys::kBands) if (banded) blend_banded_run<Target>(plane, keys, colors, i, total, texel, too_many);
+        if constexpr (Keys::kBands) if (banded) blend_banded_run<Target>(plane, keys, colors, stride, i, total, texel, too_many);
     }
 }
 
@@ -615,6 +615,24 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
     launch_deposit_gather_colors(colors_sorted, colors, slots_sorted, total, s);
     hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, BandKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, flow, BandKeys{keys_sorted},
                        (const float4 *)colors_sorted, 1u, total, too_many);
+}
+
+void launch_deposit_gather_pairs(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(deposit_gather_pairs_kernel, dim3(deposit_grid(n)), dim3(256), 0, s, dst, src, index, n);
+}
+
+// ... both passes of a draw() in one merge: the fragments carry the flow pass's varying and the view pass's colour side by
+// side (th_draw_emit); one gather of the pairs, then each target's blend over its own half - as launch_deposit_blend does
+void launch_draw_blend64(float4 *flow, uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
+                         const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t s)
+{
+    if (!total) return;
+    launch_deposit_gather_pairs(colors_sorted, colors, slots_sorted, total, s);
+    hipLaunchKernelGGL((deposit_blend_kernel<FlowTarget, BandKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, flow, BandKeys{keys_sorted},
+                       (const float4 *)colors_sorted, 2u, total, too_many);
+    hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, BandKeys>), dim3(deposit_grid(total)), dim3(256), 0, s, view, BandKeys{keys_sorted},
+                       (const float4 *)colors_sorted + 1, 2u, total, too_many);
 }
 
 // first fragment of every owner's part of keys parted by owner (bounds[r] = first key with owner >= r; bounds[world] = n)

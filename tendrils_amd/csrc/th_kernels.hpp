@@ -248,6 +248,9 @@ void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted,
 void launch_owner_bounds(const unsigned long long *keys, uint32_t n, uint32_t world, unsigned long long *bounds, hipStream_t stream);   // world <= 32
 void launch_view_blend64(uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                          const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);
+void launch_deposit_gather_pairs(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);
+void launch_draw_blend64(float4 *flow, uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
+                         const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);   // both targets from pairs of varyings
 void launch_spawn_ball(const SpawnBallParams &p, hipStream_t stream);
 void launch_spawn_sample(const SpawnSampleParams &p, hipStream_t stream);
 void launch_spawn_direct(const SpawnSampleParams &p, hipStream_t stream);

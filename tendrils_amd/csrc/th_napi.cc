@@ -753,6 +753,41 @@ napi_value ViewMerge(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// drawEmit(ctx, Float32Array th_deposit_uniforms, Float32Array th_render_uniforms) -> { count, keys: address, colors: address }
+// (row-band shard: both passes' fragments in one - colors holds 2 x float4 per fragment)
+napi_value DrawEmit(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    th_deposit_uniforms d;
+    th_render_uniforms u;
+    a.uniforms(1, &d);
+    a.uniforms(2, &u);
+    if (!a.ok) BAD_ARGS("th_draw_emit");
+    uint64_t count = 0;
+    void *keys = nullptr, *colors = nullptr;
+    TH_CALL("th_draw_emit", th_draw_emit(c, &d, &u, &count, &keys, &colors));
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    NAPI_OK(napi_create_double(env, (double)count, &v));
+    NAPI_OK(napi_set_named_property(env, o, "count", v));
+    NAPI_OK(napi_set_named_property(env, o, "keys", make_bigint(env, keys)));
+    NAPI_OK(napi_set_named_property(env, o, "colors", make_bigint(env, colors)));
+    return o;
+}
+
+// drawMerge(ctx, keysAddress, colorsAddress, count)
+napi_value DrawMerge(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    void *keys = nullptr, *colors = nullptr;
+    const double count = a.f64(3);
+    if (!a.ok || !bigint_ptr(env, a.argv[1], &keys) || !bigint_ptr(env, a.argv[2], &colors) || count < 0) BAD_ARGS("th_draw_merge");
+    TH_CALL("th_draw_merge", th_draw_merge(c, keys, colors, (uint64_t)count));
+    return undefined(env);
+}
+
 // viewDevicePtr(ctx) -> address of the RGBA8 view buffer
 napi_value ViewDevicePtr(napi_env env, napi_callback_info info)
 {
@@ -956,7 +991,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"lineWidth", LineWidth}, {"lineWidthRange", LineWidthRange}, {"lineWidthQuery", LineWidthQuery},
         {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
-        {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"viewDevicePtr", ViewDevicePtr},
+        {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"drawEmit", DrawEmit}, {"drawMerge", DrawMerge}, {"viewDevicePtr", ViewDevicePtr},
         {"stateGather", StateGather}, {"stateGatherPtr", StateGatherPtr}, {"drawSharded", DrawSharded},
     };
     for (auto &e : table) {

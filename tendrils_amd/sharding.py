@@ -211,6 +211,38 @@ def merge_view_fragments(tendrils, keys, colors):
                    C.c_uint64(keys.numel()))
 
 
+def emit_draw_fragments(tendrils):
+    """th_draw_emit -> (keys int64[n], colors float32[n, 8]): both passes' fragments of this band's lines in one - the flow
+    pass's varying and the view pass's colour side by side -, parted by owner.  Needs both passes to draw with one line width."""
+    import torch
+    from . import _capi
+    d = _capi.DepositUniforms(time=float(tendrils.timer.time), speedLimit=float(tendrils.state["speedLimit"]))
+    d.viewSize[0], d.viewSize[1] = float(tendrils.viewSize[0]), float(tendrils.viewSize[1])
+    u = tendrils.render_uniforms()
+    n, kp, cp = C.c_uint64(0), C.c_void_p(), C.c_void_p()
+    _capi.call("th_draw_emit", tendrils.particles._ctx, C.byref(d), C.byref(u), C.byref(n), C.byref(kp), C.byref(cp))
+    if n.value == 0:
+        return torch.empty(0, dtype=torch.int64, device="cuda"), torch.empty((0, 8), dtype=torch.float32, device="cuda")
+    return device_view(kp.value, (n.value,), "<i8"), device_view(cp.value, (n.value, 8), "<f4")
+
+
+def merge_draw_fragments(tendrils, keys, colors):
+    from . import _capi
+    if keys.numel():
+        assert keys.is_contiguous() and colors.is_contiguous() and colors.shape[-1] == 8
+        _capi.call("th_draw_merge", tendrils.particles._ctx, C.c_void_p(keys.data_ptr()), C.c_void_p(colors.data_ptr()),
+                   C.c_uint64(keys.numel()))
+
+
+def same_line_widths(tendrils):
+    """both passes of draw() draw their lines equally wide (after the clamp to the context's range)"""
+    from . import _capi
+    d0, d1 = C.c_float(), C.c_float()
+    _capi.call("th_line_width_query", tendrils.particles._ctx, _capi.TH_PASS_FLOW, None, C.byref(d0), None)
+    _capi.call("th_line_width_query", tendrils.particles._ctx, _capi.TH_PASS_VIEW, None, C.byref(d1), None)
+    return d0.value == d1.value
+
+
 def view_view(tendrils):
     """the context's RGBA8 view buffer as a [texels, 4] uint8 tensor"""
     from . import _capi
@@ -238,7 +270,7 @@ def _exchange(dist, keys, colors, texels):
     dist.all_to_all_single(recv_t, send_t)
     recv = [int(v) for v in recv_t.tolist()]
     rkeys = torch.empty(sum(recv), dtype=torch.int64, device="cuda")
-    rcolors = torch.empty((sum(recv), 4), dtype=torch.float32, device="cuda")
+    rcolors = torch.empty((sum(recv), colors.shape[1]), dtype=torch.float32, device="cuda")     # (4, or 8: both passes' varyings)
     dist.all_to_all_single(rkeys, keys.contiguous(), recv, send)
     dist.all_to_all_single(rcolors, colors.contiguous(), recv, send)
     torch.cuda.synchronize()
@@ -279,6 +311,15 @@ def draw_sharded(dist, tendrils, view=False):
         torch.cuda.synchronize()
     set_halo(tendrils, lo, hi)
     set_owners(tendrils, world)
+    if view and same_line_widths(tendrils):
+        # both passes draw the same lines: one rasterisation, one exchange of fragments carrying both varyings, two all-gathers
+        keys, colors = emit_draw_fragments(tendrils)
+        fragments = int(keys.numel())
+        rkeys, rcolors = _exchange(dist, keys, colors, texels)
+        merge_draw_fragments(tendrils, rkeys, rcolors)
+        _gather_owned(dist, flow_view(tendrils), texels)
+        _gather_owned(dist, view_view(tendrils), texels)
+        return fragments
     keys, colors = emit_fragments(tendrils)
     fragments = int(keys.numel())
     rkeys, rcolors = _exchange(dist, keys, colors, texels)

@@ -285,6 +285,77 @@ def test_sharded_view_pass_equals_unsharded(n, view, world):
         t.dispose()
 
 
+@pytest.mark.parametrize("n,view,world", [(64, (96, 54), 2), (128, (48, 27), 3), (96, (80, 60), 4)])
+def test_sharded_draw_in_one_pass_equals_unsharded(n, view, world):
+    """Both passes of draw() on row-band shards over ONE rasterisation and ONE exchange (th_draw_emit / th_draw_merge:
+    fragments carrying the flow pass's varying and the view pass's colour side by side; the owners' exchange by hand as
+    above): every shard's flow texture and view buffer end up identical to the unsharded th_draw, frame after frame."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from tendrils_amd import _capi, sharding
+    rng = np.random.default_rng(11 * n + world)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.6, 0.6, (n, n, 2)) * [1.0, view[1] / view[0]]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    fw, fh = view
+    base = np.zeros((fh, fw, 4), np.float32)
+    base[..., 2] = 2400.0
+    base[..., 3] = rng.uniform(0, 1, (fh, fw))
+    time = 2500.0
+    whole = make_shard(n, view, 0, n, cur, prev, base, time)
+    shards = []
+    for r in range(world):
+        row0, rows = sharding.shard_rows(n, world, r)
+        shards.append(make_shard(n, view, row0, rows, cur, prev, base, time))
+    texels = fw * fh
+    chunk = sharding.owner_chunk(texels, world)
+    for t in shards + [whole]:
+        t.state["autoClearView"] = False
+        t.state["autoFade"] = True
+    for t in shards:
+        sharding.set_owners(t, world)
+    for rep in range(2):                       # the second frame blends over the first one's texels and pixels
+        whole.renderView = True
+        whole.draw()
+        want_flow, want_view = whole.flow.read(), whole.read_view()
+        for t in shards:
+            t.drawFade()
+            t.line_widths()
+        emitted = [sharding.emit_draw_fragments(t) for t in shards]
+        assert all(c.shape[1] == 8 for _, c in emitted)
+        assert sum(int(k.numel()) for k, _ in emitted) == whole.fragments > 1000
+        sends = [sharding.split_by_owner(k, texels, world) for k, _ in emitted]
+        for d, t in enumerate(shards):
+            parts_k, parts_c = [], []
+            for s, (keys, colors) in enumerate(emitted):
+                lo = sum(sends[s][:d])
+                parts_k.append(keys[lo:lo + sends[s][d]].clone())
+                parts_c.append(colors[lo:lo + sends[s][d]].clone())
+            sharding.merge_draw_fragments(t, torch.cat(parts_k).contiguous(), torch.cat(parts_c).contiguous())
+        for plane_of in (sharding.flow_view, sharding.view_view):
+            planes = [plane_of(t) for t in shards]
+            owned = [planes[d][min(d * chunk, texels):min((d + 1) * chunk, texels)].clone() for d in range(world)]
+            for v in planes:
+                v.copy_(torch.cat(owned))
+        torch.cuda.synchronize()
+        for t in shards:
+            assert bits_equal(t.flow.read(), want_flow).all()
+            got = t.read_view()
+            assert (got == want_view).all() and got.any()
+    # two widths: the passes cannot share a rasterisation, and the entry point says so
+    t = shards[0]
+    _capi.call("th_line_width_range", t.particles._ctx, 1.0, 8.0)
+    _capi.call("th_line_width", t.particles._ctx, _capi.TH_PASS_FLOW, 3.0)
+    with pytest.raises(_capi.TendrilsHipError, match="th_deposit_emit and th_view_emit"):
+        sharding.emit_draw_fragments(t)
+    for t in shards + [whole]:
+        t.dispose()
+
+
 def test_particle_texture_sampling_on_shards_equals_unsharded():
     """Best-sample spawning from the PARTICLE texture (src/demo.main.js:433-441) reads arbitrary particles: a row-band shard
     reads them from a copy of the whole texture (th_state_gather_ptr, filled here by hand - th_state_gather is the same
