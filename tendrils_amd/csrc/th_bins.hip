@@ -506,6 +506,35 @@ TH_D void bin_blend_own(const DepositParams &p, uint32_t begin, uint32_t len, Bi
     }
 }
 
+// ... the same walk for a run whose positions come from global memory (crowd_walk_kernel: src_at is a load): two dependent
+// round trips per batch - position, then varying - taken out of the chain: while a batch is blended, the next batch's
+// varyings and the positions of the batch after it are already on their way
+template <int MODE, typename SrcAt>
+TH_D void bin_blend_own_ahead(const DepositParams &p, uint32_t begin, uint32_t len, BinTexel<MODE> &d, SrcAt src_at)
+{
+    constexpr uint32_t kAhead = MODE == 2 ? 4u : 8u;
+    uint32_t src[kAhead];
+    float4 c0[kAhead], c1[kAhead];
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(q < len ? q : len - 1u);
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE>(p, (size_t)begin + src[q], c0[q], c1[q]);
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(kAhead + q < len ? kAhead + q : len - 1u);
+    for (uint32_t j0 = 0; j0 < len; j0 += kAhead) {
+        float4 n0[kAhead], n1[kAhead];
+        uint32_t after[kAhead];
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE>(p, (size_t)begin + src[q], n0[q], n1[q]);      // (clamped positions: always valid)
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) { const uint32_t j = j0 + 2u * kAhead + q; after[q] = src_at(j < len ? j : len - 1u); }
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply_colors<MODE>(d, c0[q], c1[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) { c0[q] = n0[q]; c1[q] = n1[q]; src[q] = after[q]; }
+    }
+}
+
 // a long run by the whole workgroup: every thread turns one fragment's varying into its side of the blend (256 loads in
 // flight), the texel's thread applies them in order
 template <int MODE, typename SrcAt>
@@ -1024,7 +1053,7 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
     BinTexel<MODE> d{};
     d.load(p, texel);
     const uint32_t *sorted = p.crowd_sorted + p.large_key0[i] + r0;
-    bin_blend_own<MODE>(p, 0u, len, d, [sorted](uint32_t j) { return sorted[j]; });
+    bin_blend_own_ahead<MODE>(p, 0u, len, d, [sorted](uint32_t j) { return sorted[j]; });
     d.store(p, texel);
 }
 
