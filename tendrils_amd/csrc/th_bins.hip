@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p,
 __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
 {
     constexpr uint32_t CAP = kWaveRun;
-    __shared__ unsigned long long keys[4][CAP];
+    __shared__ uint32_t ids[4][CAP];                 // (the stream indices alone order a texel's run: a line covers a texel at most once)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gt = blockIdx.x * 4u + wave, i = gt >> 8, lt = gt & 255u;
     if (i >= p.nlarge) return;
@@ -1022,8 +1022,9 @@ __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; mine[q] = run[f < len ? f : len - 1u]; }
     if (len == 1u) { if (lane == 0u) sorted[0] = (uint32_t)(mine[0] & 0xffffffffull); return; }
+    uint32_t id[kPer];
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) keys[wave][f] = mine[q]; }
+    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; id[q] = (uint32_t)(mine[q] >> 32); if (f < len) ids[wave][f] = id[q]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     uint32_t rank[kPer];
@@ -1031,9 +1032,9 @@ __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
     for (uint32_t q = 0; q < kPer; ++q) rank[q] = 0u;
     const uint32_t groups = (len + 63u) >> 6;                 // (uniform) key groups of 64 that exist
     for (uint32_t j = 0; j < len; ++j) {
-        const unsigned long long k = keys[wave][j];
+        const uint32_t k = ids[wave][j];
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) if (q < groups) rank[q] += k < mine[q] ? 1u : 0u;
+        for (uint32_t q = 0; q < kPer; ++q) if (q < groups) rank[q] += k < id[q] ? 1u : 0u;
     }
 #pragma unroll
     for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) sorted[rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
