@@ -413,16 +413,16 @@ TH_D unsigned long long sort_key(unsigned long long k, uint32_t f) { return ((un
 template <int MODE>
 struct BinTexel {
     float4 f;
-    uchar4 v;
+    float4 v;           // (the RGBA8 texel unpacked: ViewTarget::apply_unpacked)
     TH_D void load(const DepositParams &p, uint32_t texel)
     {
         if constexpr (MODE != 1) f = p.flow[texel];
-        if constexpr (MODE != 0) v = p.view[texel];
+        if constexpr (MODE != 0) v = ViewTarget::unpack(p.view[texel]);
     }
     TH_D void store(const DepositParams &p, uint32_t texel) const
     {
         if constexpr (MODE != 1) p.flow[texel] = f;
-        if constexpr (MODE != 0) p.view[texel] = v;
+        if constexpr (MODE != 0) p.view[texel] = ViewTarget::pack(v);
     }
 };
 
@@ -436,8 +436,8 @@ template <int MODE>
 TH_D void apply_colors(BinTexel<MODE> &d, float4 c0, float4 c1)
 {
     if constexpr (MODE == 0) FlowTarget::apply(d.f, FlowTarget::source(c0));
-    else if constexpr (MODE == 1) ViewTarget::apply(d.v, ViewTarget::source(c0));
-    else { FlowTarget::apply(d.f, FlowTarget::source(c0)); ViewTarget::apply(d.v, ViewTarget::source(c1)); }
+    else if constexpr (MODE == 1) ViewTarget::apply_unpacked(d.v, ViewTarget::source(c0));
+    else { FlowTarget::apply(d.f, FlowTarget::source(c0)); ViewTarget::apply_unpacked(d.v, ViewTarget::source(c1)); }
 }
 
 // LDS of a bin's workgroup.  `pool` is used two ways:
@@ -560,15 +560,15 @@ TH_D void bin_blend_long(BinShared<MODE> &s, const DepositParams &p, uint32_t be
                 for (uint32_t e = 0; e < 8u; ++e) { a[e] = s.stage_a[q + e]; if constexpr (MODE == 2) b[e] = s.stage_b[q + e]; }
 #pragma unroll
                 for (uint32_t e = 0; e < 8u; ++e) {
-                    if constexpr (MODE == 1) ViewTarget::apply(d.v, a[e]);
+                    if constexpr (MODE == 1) ViewTarget::apply_unpacked(d.v, a[e]);
                     else FlowTarget::apply(d.f, a[e]);
-                    if constexpr (MODE == 2) ViewTarget::apply(d.v, b[e]);
+                    if constexpr (MODE == 2) ViewTarget::apply_unpacked(d.v, b[e]);
                 }
             }
             for (; q < n; ++q) {
-                if constexpr (MODE == 1) ViewTarget::apply(d.v, s.stage_a[q]);
+                if constexpr (MODE == 1) ViewTarget::apply_unpacked(d.v, s.stage_a[q]);
                 else FlowTarget::apply(d.f, s.stage_a[q]);
-                if constexpr (MODE == 2) ViewTarget::apply(d.v, s.stage_b[q]);
+                if constexpr (MODE == 2) ViewTarget::apply_unpacked(d.v, s.stage_b[q]);
             }
         }
         __syncthreads();

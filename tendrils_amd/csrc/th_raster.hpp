@@ -590,6 +590,21 @@ struct ViewTarget {                     // dep_blend_rgba8 in two halves
         };
         q = make_uchar4(mix8(s.x, q.x), mix8(s.y, q.y), mix8(s.z, q.z), mix8(s.w, q.w));
     }
+    // ... with the texel held as four integer-valued floats while a run is blended into it: the same arithmetic, the round trip
+    // through bytes (convert, pack, unpack, convert) taken out of the dependent chain - the byte the cast gives for a
+    // non-negative x is floor(x), and the float of that byte is floor(x) again.  (The chain of one texel's run is what a
+    // crowded frame waits for: thousands of fragments applied one after the other.)
+    TH_D static float4 unpack(uchar4 q) { return make_float4((float)q.x, (float)q.y, (float)q.z, (float)q.w); }
+    TH_D static uchar4 pack(float4 f) { return make_uchar4((unsigned char)f.x, (unsigned char)f.y, (unsigned char)f.z, (unsigned char)f.w); }
+    TH_D static void apply_unpacked(float4 &q, const BlendSource &s)
+    {
+        const float k = 1.0f / 255.0f;
+        auto mix8 = [&](float src, float dst) {
+            const float o = src + (dst * k) * s.da;
+            return __builtin_floorf(__builtin_fminf(__builtin_fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
+        };
+        q = make_float4(mix8(s.x, q.x), mix8(s.y, q.y), mix8(s.z, q.z), mix8(s.w, q.w));
+    }
     TH_D static uchar4 *plane(const DepositParams &p) { return p.view; }
     TH_D static uchar4 from_lane(uchar4 d, int lane) { return __builtin_bit_cast(uchar4, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), lane)); }
 };
