@@ -1640,9 +1640,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     // Which comes first behind the emitting pass: the ordinary bins' blend - it needs nothing from the host and covers the
     // read-back - or, on a crowded target, the crowded bins' kernels: their long runs (walked by one thread each, on the
     // side stream) are then the longest chain of the draw and must start as early as they can.  Decided by the last draw.
-    static const int early_env = [] { const char *e = getenv("TH_BINS_EARLY"); return e ? atoi(e) : -1; }();       // (A/B)
-    const bool early = early_env >= 0 ? early_env != 0
-                                      : !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
+    const bool early = !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
     for (int attempt = 0;; ++attempt) {
         // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
         static const uint32_t pool0 = [] { const char *e = getenv("TH_BINS_POOL"); return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u; }();
@@ -1700,18 +1698,17 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257; p.crowd_giant = p.crowd_long + (size_t)c->crowd_capacity * 256;
     p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted;
     th::launch_bins_regroup(p, c->stream);
-    static const bool overlap = [] { const char *e = getenv("TH_BINS_SIDE"); return !e || atoi(e) != 0; }();     // (A/B)
-    if (nlarge && overlap) {
+    if (nlarge) {
         // the long runs on a stream of their own, beside the short runs' blend (disjoint texels): the walk of the longest
         // run - one thread, one fragment after the other - overlaps with everything else instead of following it
         TH_HIP(hipEventRecord(c->forked, c->stream));
         TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
         th::launch_bins_blend_long(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
-    } else th::launch_bins_blend_long(p, c->stream);
+    }
     th::launch_bins_blend_crowd(p, c->stream);
     if (!early) th::launch_bins_blend(p, c->stream);
-    if (nlarge && overlap) TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
+    if (nlarge) TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
     TH_HIP(hipGetLastError());
     return TH_OK;
 }

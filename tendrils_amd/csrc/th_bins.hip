@@ -1068,9 +1068,8 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // (one short workgroup per 256 slots.  Measured and not kept, profiles/r3_b_fused_pass_experiments.txt: a resident grid of
     // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
     // per SIMD instead of 4)
-    static const bool deal = [] { const char *e = getenv("TH_FUSED_DEAL"); return !e || atoi(e) != 0; }();     // (A/B: rows dealt to the wave's lanes)
-    if (deal) hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((bins_fused_kernel<256u, false>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
+    hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);

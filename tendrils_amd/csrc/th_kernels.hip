@@ -559,9 +559,7 @@ template <bool FAST, bool NOISE, bool TARGET>
 static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
     // 7 workgroups per CU are resident: 2048 workgroups (8 per CU) ran as 1792 + a second round of 256; 20 per CU ends evenly
-    int grid = grid_for(p.count, 20);
-    static const int grid_env = [] { const char *e = getenv("TH_STEP_GRID"); return e ? atoi(e) : 0; }();
-    if (grid_env > 0 && (int)((p.count + 255) / 256) >= grid_env) grid = grid_env;
+    const int grid = grid_for(p.count, 20);
 #define TH_GO(P2, DEC) do { if (p.perm) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true>), dim3(grid), dim3(256), 0, s, p); \
                             else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, false>), dim3(grid), dim3(256), 0, s, p); } while (0)
     if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
@@ -716,14 +714,12 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
 // is issue-bound and runs 5 workgroups per CU (82 VGPRs): a persistent grid of 2048 workgroups left the CUs
 // unevenly loaded at the end of the pass (1280 resident + a 768-workgroup second round); with one short
 // workgroup per 256 slots the dispatcher keeps every CU full until the last few (C3, exact: 0.098 -> 0.086 ms per
-// step, profiles/r2_a_grid_sweep.txt).  TH_FUSED_GRID overrides the workgroup count (experiments).
+// step, profiles/r2_a_grid_sweep.txt).
 static int fused_grid(uint32_t count, bool bucketed)
 {
-    static const int grid_env = [] { const char *e = getenv("TH_FUSED_GRID"); return e ? atoi(e) : 0; }();
     const uint32_t blocks = (count + 255u) / 256u;
     // bucketed: 8 XCD groups, group g = blockIdx % 8 sweeps its eighth of the slots
-    uint32_t grid = bucketed ? 8u * ((((count + 7u) >> 3) + 255u) / 256u) : blocks;
-    if (grid_env > 0 && blocks >= (uint32_t)grid_env) grid = (uint32_t)grid_env & ~7u;
+    const uint32_t grid = bucketed ? 8u * ((((count + 7u) >> 3) + 255u) / 256u) : blocks;
     return (int)(grid ? grid : 1u);
 }
 

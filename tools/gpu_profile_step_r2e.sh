@@ -7,7 +7,6 @@ O=gpurun_out/r2/r2_e_single_step.txt
 {
 echo "# tools/step_probe.py at C3 (4096^2 particles, flow 1920x1080, exact, default uniforms unless noted); same box"
 echo "## default: gathered taps over tile-sorted slots, re-sort every 64"; PROBE_STEPS=256 timeout 120 python tools/step_probe.py 2>&1 | grep "single step"
-echo "## TH_SINGLE=window: LDS-staged flow window, re-sort every 8"; TH_SINGLE=window PROBE_STEPS=256 timeout 120 python tools/step_probe.py 2>&1 | grep "single step"
 echo "## TH_BUCKET=0: texel order"; TH_BUCKET=0 PROBE_STEPS=128 timeout 120 python tools/step_probe.py 2>&1 | grep "single step"
 for R in 16 32 128; do echo "## default, TH_RESORT_STEPS=$R"; TH_RESORT_STEPS=$R PROBE_STEPS=256 timeout 120 python tools/step_probe.py 2>&1 | grep "single step" | tail -1; done
 echo "## default, flow-only"; PROBE_STEPS=128 timeout 120 python tools/step_probe.py --flow-only 2>&1 | grep "single step" | tail -1
