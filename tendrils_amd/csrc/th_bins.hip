@@ -38,6 +38,7 @@ namespace {
 constexpr uint32_t kBinSide = 1u << kBinShift, kBinTexels = kBinSide * kBinSide;      // 256 texels = one per thread
 constexpr uint32_t kPageShift = 8;
 static_assert(kBinPage == 1u << kPageShift && kBinPage * kBinReplicas == kBinCap, "page size");
+static_assert(sizeof(BlendSource) == 5 * sizeof(float), "bin_blend_long reads a source's components as five floats side by side");
 constexpr uint32_t kRankMaxRun = 256;        // runs up to this length are ordered by counting, longer ones by the bitonic network
 constexpr uint32_t kOwnRun = 256;            // runs up to this length are blended by their texel's thread alone (64 texels of a wave side by side: a chain per lane, nothing redundant)
 constexpr unsigned long long kEmptyKey = ~0ull;
@@ -454,6 +455,7 @@ struct BinShared {
     uint32_t cnt[kBinTexels], first[kBinTexels + 1u];        // fragments per texel (then: fill cursors); first fragment of every texel
     BlendSource stage_a[256], stage_b[MODE == 2 ? 256 : 1];  // a long run's sources, 256 at a time (b: the view pass's beside the flow pass's)
     uint32_t misc[8];
+    float chan[8];                                           // a long run's destination, a channel per lane (bin_blend_long)
     uint32_t lists[kBinReplicas + 1u];                       // first place of every list of the bin when its lists are walked one after the other
     TH_D uint32_t *sid() { return pool; }
     TH_D uint32_t *osrc() { return pool; }
@@ -536,43 +538,63 @@ TH_D void bin_blend_own_ahead(const DepositParams &p, uint32_t begin, uint32_t l
 }
 
 // a long run by the whole workgroup: every thread turns one fragment's varying into its side of the blend (256 loads in
-// flight), the texel's thread applies them in order
+// flight); then the destination's CHANNELS are applied side by side, a lane each - lanes 0-3 of the workgroup the flow
+// texel's four floats, lanes 4-7 the view texel's four bytes (as integer-valued floats) - instead of one thread doing all
+// eight one after the other: the same operations on every channel in the same order, a quarter of the instructions per
+// fragment in the one wave that everything else waits for (the texel's thread hands its value over through LDS and takes
+// it back at the end)
 template <int MODE, typename SrcAt>
 TH_D void bin_blend_long(BinShared<MODE> &s, const DepositParams &p, uint32_t begin, uint32_t len, uint32_t owner, BinTexel<MODE> &d, SrcAt src_at)
 {
+    const uint32_t t = threadIdx.x;
+    const bool flow_lane = t < 4u;
+    const bool channel = t < 8u && (MODE == 2 || (MODE == 0) == flow_lane);
+    if (t == owner) {
+        if constexpr (MODE != 1) { s.chan[0] = d.f.x; s.chan[1] = d.f.y; s.chan[2] = d.f.z; s.chan[3] = d.f.w; }
+        if constexpr (MODE != 0) { s.chan[4] = d.v.x; s.chan[5] = d.v.y; s.chan[6] = d.v.z; s.chan[7] = d.v.w; }
+    }
+    float comp = 0.0f;
     for (uint32_t j0 = 0; j0 < len; j0 += 256u) {
-        const uint32_t j = j0 + threadIdx.x;
+        const uint32_t j = j0 + t;
         if (j < len) {
             float4 c0, c1;
             fetch_colors<MODE>(p, (size_t)begin + src_at(j), c0, c1);
-            if constexpr (MODE == 1) s.stage_a[threadIdx.x] = ViewTarget::source(c0);
-            else s.stage_a[threadIdx.x] = FlowTarget::source(c0);
-            if constexpr (MODE == 2) s.stage_b[threadIdx.x] = ViewTarget::source(c1);
+            if constexpr (MODE == 1) s.stage_a[t] = ViewTarget::source(c0);
+            else s.stage_a[t] = FlowTarget::source(c0);
+            if constexpr (MODE == 2) s.stage_b[t] = ViewTarget::source(c1);
         }
         __syncthreads();
-        if (threadIdx.x == owner) {
-            // (sources read eight ahead of the dependent blends: the chain left is the blend's own multiply and add)
+        if (channel) {
+            if (j0 == 0u) comp = s.chan[t];
+            // this lane's component of every source, and the source's 1 - alpha: {x, y, z, w, da} lie side by side
+            const float *mine = reinterpret_cast<const float *>((MODE == 2 && !flow_lane) ? s.stage_b : s.stage_a) + (t & 3u);
+            const float *das = reinterpret_cast<const float *>((MODE == 2 && !flow_lane) ? s.stage_b : s.stage_a) + 4u;
             const uint32_t n = len - j0 < 256u ? len - j0 : 256u;
-            uint32_t q = 0;
-            for (; q + 8u <= n; q += 8u) {
-                BlendSource a[8], b[8];
-#pragma unroll
-                for (uint32_t e = 0; e < 8u; ++e) { a[e] = s.stage_a[q + e]; if constexpr (MODE == 2) b[e] = s.stage_b[q + e]; }
-#pragma unroll
-                for (uint32_t e = 0; e < 8u; ++e) {
-                    if constexpr (MODE == 1) ViewTarget::apply_unpacked(d.v, a[e]);
-                    else FlowTarget::apply(d.f, a[e]);
-                    if constexpr (MODE == 2) ViewTarget::apply_unpacked(d.v, b[e]);
+            auto apply = [&](float src, float da) {
+                if (MODE != 1 && flow_lane) comp = src + comp * da;                                   // FlowTarget::apply, one channel
+                else {                                                                                // ViewTarget::apply_unpacked, one channel
+                    const float o = src + (comp * (1.0f / 255.0f)) * da;
+                    comp = __builtin_floorf(__builtin_fminf(__builtin_fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
                 }
+            };
+            uint32_t q = 0;
+            for (; q + 8u <= n; q += 8u) {      // (sources read eight ahead of the dependent blends)
+                float sv[8], da[8];
+#pragma unroll
+                for (uint32_t e = 0; e < 8u; ++e) { sv[e] = mine[(q + e) * 5u]; da[e] = das[(q + e) * 5u]; }
+#pragma unroll
+                for (uint32_t e = 0; e < 8u; ++e) apply(sv[e], da[e]);
             }
-            for (; q < n; ++q) {
-                if constexpr (MODE == 1) ViewTarget::apply_unpacked(d.v, s.stage_a[q]);
-                else FlowTarget::apply(d.f, s.stage_a[q]);
-                if constexpr (MODE == 2) ViewTarget::apply_unpacked(d.v, s.stage_b[q]);
-            }
+            for (; q < n; ++q) apply(mine[q * 5u], das[q * 5u]);
+            if (j0 + 256u >= len) s.chan[t] = comp;
         }
         __syncthreads();
     }
+    if (t == owner) {
+        if constexpr (MODE != 1) d.f = make_float4(s.chan[0], s.chan[1], s.chan[2], s.chan[3]);
+        if constexpr (MODE != 0) d.v = make_float4(s.chan[4], s.chan[5], s.chan[6], s.chan[7]);
+    }
+    __syncthreads();            // (the words are free for the next run's texel)
 }
 
 // bitonic network over skey[0, P) (P a power of two >= m, the tail padded with ~0); then order = identity
