@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
             const uint32_t run_texel = (uint32_t)__builtin_amdgcn_readlane((int)texel, owner);
             uint32_t at0 = (uint32_t)__builtin_amdgcn_readlane((int)j, owner);
             uint32_t run_last = (uint32_t)__builtin_amdgcn_readlane((int)last, owner);
-            Texel rd = Target::from_lane(d, owner);
+            // the destination, a channel per lane (lane & 3; every group of four lanes does the same: nothing diverges)
+            float rc = Target::channel(Target::from_lane(d, owner), lane & 3u);
             auto fetch = [&](uint32_t first, float4 &c, bool &same, uint32_t &id) {
                 const uint32_t at = first + lane;
                 const bool in = at < total;
@@ -281,19 +282,21 @@ __global__ __launch_bounds__(256) void deposit_blend_kernel(typename Target::Tex
                 // fragment, issued eight ahead: the chain left is the blend's own multiply and add - v_readlane goes through
                 // an SGPR and its wait states, three times as long per fragment on the run that sets a crowded frame's time)
                 staged[threadIdx.x] = Target::source(c);
-                const BlendSource *mine = &staged[threadIdx.x & ~63u];
+                const float *mine = reinterpret_cast<const float *>(&staged[threadIdx.x & ~63u]);      // {x, y, z, w, da} side by side
+                const float *comp = mine + (lane & 3u), *das = mine + 4;
                 int q = 0;
                 for (; q + 8 <= n; q += 8) {
-                    BlendSource s8[8];
+                    float s8[8], d8[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) s8[k] = mine[q + k];
+                    for (int k = 0; k < 8; ++k) { s8[k] = comp[(q + k) * 5]; d8[k] = das[(q + k) * 5]; }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) Target::apply(rd, s8[k]);
+                    for (int k = 0; k < 8; ++k) Target::apply_channel(rc, s8[k], d8[k]);
                 }
-                for (; q < n; ++q) Target::apply(rd, mine[q]);
+                for (; q < n; ++q) Target::apply_channel(rc, comp[q * 5], das[q * 5]);
                 if (n < 64) break;
                 c = cn; same = samen; id = idn; at0 += 64u;
             }
+            const Texel rd = Target::from_channels(lane_float(rc, 0), lane_float(rc, 1), lane_float(rc, 2), lane_float(rc, 3));
             if (lane == (uint32_t)owner) { if (falls) banded = true; else plane[run_texel] = rd; }
         }
         if constexpr (Keys::kBands) if (banded) blend_banded_run<Target>(plane, keys, colors, stride, i, total, texel, too_many);

@@ -558,8 +558,9 @@ TH_D void dep_blend_rgba8(uchar4 &q, float4 c)
 // its first kShortRun fragments itself, four read ahead of the dependent blends - nearly every run ends there.  What
 // is left of a longer run (the wake makes particles converge: thousands of fragments in one texel are normal after
 // a few dozen frames) is then blended by the whole wave: 64 fragments per coalesced load, the next 64 in flight,
-// every lane doing the same sequential arithmetic on values broadcast with v_readlane - the same operations in the
-// same order, at 64 fragments per memory round trip instead of 4.
+// every lane turning its own fragment into its side of the blend, and the destination's four channels applied side by
+// side, a lane each - the same operations in the same order, at 64 fragments per memory round trip instead of 4 and a
+// quarter of the chain's instructions.
 constexpr int kShortRun = 16;
 
 // a fragment's side of the blend (everything that does not depend on the destination), and the destination's
@@ -569,6 +570,10 @@ struct FlowTarget {                     // dep_blend in two halves
     using Texel = float4;
     TH_D static BlendSource source(float4 c) { const float sa = c.w; return BlendSource{c.x * sa, c.y * sa, c.z * sa, c.w * sa, 1.0f - sa}; }
     TH_D static void apply(float4 &d, const BlendSource &s) { d.x = s.x + d.x * s.da; d.y = s.y + d.y * s.da; d.z = s.z + d.z * s.da; d.w = s.w + d.w * s.da; }
+    // one channel of the blend (apply(), component by component): what a lane does when a long run's channels are applied side by side
+    TH_D static float channel(float4 d, uint32_t c) { return c == 0u ? d.x : (c == 1u ? d.y : (c == 2u ? d.z : d.w)); }
+    TH_D static void apply_channel(float &d, float src, float da) { d = src + d * da; }
+    TH_D static float4 from_channels(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
     TH_D static float4 *plane(const DepositParams &p) { return p.flow; }
     TH_D static float4 from_lane(float4 d, int lane) { return make_float4(lane_float(d.x, lane), lane_float(d.y, lane), lane_float(d.z, lane), lane_float(d.w, lane)); }
 };
@@ -605,6 +610,13 @@ struct ViewTarget {                     // dep_blend_rgba8 in two halves
         };
         q = make_float4(mix8(s.x, q.x), mix8(s.y, q.y), mix8(s.z, q.z), mix8(s.w, q.w));
     }
+    TH_D static float channel(uchar4 q, uint32_t c) { return (float)(c == 0u ? q.x : (c == 1u ? q.y : (c == 2u ? q.z : q.w))); }
+    TH_D static void apply_channel(float &q, float src, float da)          // (apply_unpacked, one channel)
+    {
+        const float o = src + (q * (1.0f / 255.0f)) * da;
+        q = __builtin_floorf(__builtin_fminf(__builtin_fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
+    }
+    TH_D static uchar4 from_channels(float x, float y, float z, float w) { return make_uchar4((unsigned char)x, (unsigned char)y, (unsigned char)z, (unsigned char)w); }
     TH_D static uchar4 *plane(const DepositParams &p) { return p.view; }
     TH_D static uchar4 from_lane(uchar4 d, int lane) { return __builtin_bit_cast(uchar4, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), lane)); }
 };
