@@ -1065,7 +1065,9 @@ __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
 template <int MODE>
 __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
 {
-    const uint32_t lane = threadIdx.x, i = blockIdx.x >> 2, lt = ((blockIdx.x & 3u) << 6) + lane;
+    // four lanes per texel, a channel each (of the flow texel and / or of the view texel): 16 runs side by side per wave, every
+    // run's chain a quarter as long as with a lane per texel doing all channels (the pass is bound by its longest chains)
+    const uint32_t lane = threadIdx.x, c = lane & 3u, i = blockIdx.x >> 4, lt = ((blockIdx.x & 15u) << 4) + (lane >> 2);
     if (i >= p.nlarge) return;
     const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
     if (len == 0u || len > kWaveRun) return;                  // (longer runs: crowd_blend_kernel, sources by the workgroup)
@@ -1073,11 +1075,54 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
     const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
     const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
     const uint32_t texel = y * (uint32_t)p.fw + x;
-    BinTexel<MODE> d{};
-    d.load(p, texel);
+    float f = 0.0f, v = 0.0f;                                 // this lane's channel of the two destinations
+    if constexpr (MODE != 1) f = reinterpret_cast<const float *>(p.flow + texel)[c];
+    if constexpr (MODE != 0) v = (float)reinterpret_cast<const unsigned char *>(p.view + texel)[c];
     const uint32_t *sorted = p.crowd_sorted + p.large_key0[i] + r0;
-    bin_blend_own_ahead<MODE>(p, 0u, len, d, [sorted](uint32_t j) { return sorted[j]; });
-    d.store(p, texel);
+    const float *colors = reinterpret_cast<const float *>(p.colors);
+    constexpr uint32_t kAhead = 8u, kFloats = MODE == 2 ? 8u : 4u;
+    struct Piece { float c0, a0, c1, a1; };                   // the lane's component and the alpha of the fragment's varying(s)
+    auto fetch = [&](uint32_t place) {
+        const float *at = colors + (size_t)place * kFloats;
+        Piece q{};
+        q.c0 = at[c]; q.a0 = at[3];
+        if constexpr (MODE == 2) { q.c1 = at[4u + c]; q.a1 = at[7]; }
+        return q;
+    };
+    auto apply = [&](const Piece &q) {
+        if constexpr (MODE != 1) {                            // FlowTarget::source + apply, one channel
+            const float sa = q.a0;
+            FlowTarget::apply_channel(f, q.c0 * sa, 1.0f - sa);
+        }
+        if constexpr (MODE != 0) {                            // ViewTarget::source + apply_unpacked, one channel
+            const float cc = MODE == 1 ? q.c0 : q.c1, ca = MODE == 1 ? q.a0 : q.a1;
+            const float col = __builtin_fminf(__builtin_fmaxf(cc, 0.0f), 1.0f), sa = __builtin_fminf(__builtin_fmaxf(ca, 0.0f), 1.0f);
+            ViewTarget::apply_channel(v, col * sa, 1.0f - sa);
+        }
+    };
+    // (as bin_blend_own_ahead: while a batch is applied, the next batch's varyings and the positions of the batch after it are in flight)
+    uint32_t src[kAhead];
+    Piece cur[kAhead];
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; ++q) src[q] = sorted[q < len ? q : len - 1u];
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; ++q) cur[q] = fetch(src[q]);
+#pragma unroll
+    for (uint32_t q = 0; q < kAhead; ++q) src[q] = sorted[kAhead + q < len ? kAhead + q : len - 1u];
+    for (uint32_t j0 = 0; j0 < len; j0 += kAhead) {
+        Piece nxt[kAhead];
+        uint32_t after[kAhead];
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) nxt[q] = fetch(src[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) { const uint32_t j = j0 + 2u * kAhead + q; after[q] = sorted[j < len ? j : len - 1u]; }
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply(cur[q]);
+#pragma unroll
+        for (uint32_t q = 0; q < kAhead; ++q) { cur[q] = nxt[q]; src[q] = after[q]; }
+    }
+    if constexpr (MODE != 1) reinterpret_cast<float *>(p.flow + texel)[c] = f;
+    if constexpr (MODE != 0) reinterpret_cast<unsigned char *>(p.view + texel)[c] = (unsigned char)v;
 }
 
 }  // namespace
@@ -1128,9 +1173,9 @@ void launch_bins_blend_crowd(const DepositParams &p, hipStream_t s)
     // against 2.28 ms per crowded draw.)
     hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p);
     // ... and walked by a lane of its own
-    if (p.mode == 0) hipLaunchKernelGGL(crowd_walk_kernel<0>, dim3(p.nlarge * 4u), dim3(64), 0, s, p);
-    else if (p.mode == 1) hipLaunchKernelGGL(crowd_walk_kernel<1>, dim3(p.nlarge * 4u), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(crowd_walk_kernel<2>, dim3(p.nlarge * 4u), dim3(64), 0, s, p);
+    if (p.mode == 0) hipLaunchKernelGGL(crowd_walk_kernel<0>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
+    else if (p.mode == 1) hipLaunchKernelGGL(crowd_walk_kernel<1>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(crowd_walk_kernel<2>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
 }
 
 // the bins of up to kBinCap places, a workgroup each.  Needs nothing from the host: launched right behind launch_bins_fused,
