@@ -508,33 +508,59 @@ TH_D void bin_blend_own(const DepositParams &p, uint32_t begin, uint32_t len, Bi
     }
 }
 
-// ... the same walk for a run whose positions come from global memory (crowd_walk_kernel: src_at is a load): two dependent
-// round trips per batch - position, then varying - taken out of the chain: while a batch is blended, the next batch's
-// varyings and the positions of the batch after it are already on their way
+// A run of one texel walked by FOUR lanes, a channel each (of the flow texel and / or of the view texel; c = the lane's
+// channel): the same operations per channel in the same order as a thread doing all channels, a quarter of the chain.
+// The destination is read from and written to the target(s) directly.  While a batch is applied, the next batch's varyings
+// and the positions of the batch after it are in flight.
 template <int MODE, typename SrcAt>
-TH_D void bin_blend_own_ahead(const DepositParams &p, uint32_t begin, uint32_t len, BinTexel<MODE> &d, SrcAt src_at)
+TH_D void quad_walk(const DepositParams &p, uint32_t texel, uint32_t len, uint32_t c, SrcAt src_at)
 {
-    constexpr uint32_t kAhead = MODE == 2 ? 4u : 8u;
+    float f = 0.0f, v = 0.0f;                                 // this lane's channel of the two destinations
+    if constexpr (MODE != 1) f = reinterpret_cast<const float *>(p.flow + texel)[c];
+    if constexpr (MODE != 0) v = (float)reinterpret_cast<const unsigned char *>(p.view + texel)[c];
+    const float *colors = reinterpret_cast<const float *>(p.colors);
+    constexpr uint32_t kAhead = 8u, kFloats = MODE == 2 ? 8u : 4u;
+    struct Piece { float c0, a0, c1, a1; };                   // the lane's component and the alpha of the fragment's varying(s)
+    auto fetch = [&](uint32_t place) {
+        const float *at = colors + (size_t)place * kFloats;
+        Piece q{};
+        q.c0 = at[c]; q.a0 = at[3];
+        if constexpr (MODE == 2) { q.c1 = at[4u + c]; q.a1 = at[7]; }
+        return q;
+    };
+    auto apply = [&](const Piece &q) {
+        if constexpr (MODE != 1) {                            // FlowTarget::source + apply, one channel
+            const float sa = q.a0;
+            FlowTarget::apply_channel(f, q.c0 * sa, 1.0f - sa);
+        }
+        if constexpr (MODE != 0) {                            // ViewTarget::source + apply_unpacked, one channel
+            const float cc = MODE == 1 ? q.c0 : q.c1, ca = MODE == 1 ? q.a0 : q.a1;
+            const float col = __builtin_fminf(__builtin_fmaxf(cc, 0.0f), 1.0f), sa = __builtin_fminf(__builtin_fmaxf(ca, 0.0f), 1.0f);
+            ViewTarget::apply_channel(v, col * sa, 1.0f - sa);
+        }
+    };
     uint32_t src[kAhead];
-    float4 c0[kAhead], c1[kAhead];
+    Piece cur[kAhead];
 #pragma unroll
     for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(q < len ? q : len - 1u);
 #pragma unroll
-    for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE>(p, (size_t)begin + src[q], c0[q], c1[q]);
+    for (uint32_t q = 0; q < kAhead; ++q) cur[q] = fetch(src[q]);
 #pragma unroll
     for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(kAhead + q < len ? kAhead + q : len - 1u);
     for (uint32_t j0 = 0; j0 < len; j0 += kAhead) {
-        float4 n0[kAhead], n1[kAhead];
+        Piece nxt[kAhead];
         uint32_t after[kAhead];
 #pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE>(p, (size_t)begin + src[q], n0[q], n1[q]);      // (clamped positions: always valid)
+        for (uint32_t q = 0; q < kAhead; ++q) nxt[q] = fetch(src[q]);
 #pragma unroll
         for (uint32_t q = 0; q < kAhead; ++q) { const uint32_t j = j0 + 2u * kAhead + q; after[q] = src_at(j < len ? j : len - 1u); }
 #pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply_colors<MODE>(d, c0[q], c1[q]);
+        for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply(cur[q]);
 #pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) { c0[q] = n0[q]; c1[q] = n1[q]; src[q] = after[q]; }
+        for (uint32_t q = 0; q < kAhead; ++q) { cur[q] = nxt[q]; src[q] = after[q]; }
     }
+    if constexpr (MODE != 1) reinterpret_cast<float *>(p.flow + texel)[c] = f;
+    if constexpr (MODE != 0) reinterpret_cast<unsigned char *>(p.view + texel)[c] = (unsigned char)v;
 }
 
 // a long run by the whole workgroup: every thread turns one fragment's varying into its side of the blend (256 loads in
@@ -1075,54 +1101,8 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
     const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
     const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
     const uint32_t texel = y * (uint32_t)p.fw + x;
-    float f = 0.0f, v = 0.0f;                                 // this lane's channel of the two destinations
-    if constexpr (MODE != 1) f = reinterpret_cast<const float *>(p.flow + texel)[c];
-    if constexpr (MODE != 0) v = (float)reinterpret_cast<const unsigned char *>(p.view + texel)[c];
     const uint32_t *sorted = p.crowd_sorted + p.large_key0[i] + r0;
-    const float *colors = reinterpret_cast<const float *>(p.colors);
-    constexpr uint32_t kAhead = 8u, kFloats = MODE == 2 ? 8u : 4u;
-    struct Piece { float c0, a0, c1, a1; };                   // the lane's component and the alpha of the fragment's varying(s)
-    auto fetch = [&](uint32_t place) {
-        const float *at = colors + (size_t)place * kFloats;
-        Piece q{};
-        q.c0 = at[c]; q.a0 = at[3];
-        if constexpr (MODE == 2) { q.c1 = at[4u + c]; q.a1 = at[7]; }
-        return q;
-    };
-    auto apply = [&](const Piece &q) {
-        if constexpr (MODE != 1) {                            // FlowTarget::source + apply, one channel
-            const float sa = q.a0;
-            FlowTarget::apply_channel(f, q.c0 * sa, 1.0f - sa);
-        }
-        if constexpr (MODE != 0) {                            // ViewTarget::source + apply_unpacked, one channel
-            const float cc = MODE == 1 ? q.c0 : q.c1, ca = MODE == 1 ? q.a0 : q.a1;
-            const float col = __builtin_fminf(__builtin_fmaxf(cc, 0.0f), 1.0f), sa = __builtin_fminf(__builtin_fmaxf(ca, 0.0f), 1.0f);
-            ViewTarget::apply_channel(v, col * sa, 1.0f - sa);
-        }
-    };
-    // (as bin_blend_own_ahead: while a batch is applied, the next batch's varyings and the positions of the batch after it are in flight)
-    uint32_t src[kAhead];
-    Piece cur[kAhead];
-#pragma unroll
-    for (uint32_t q = 0; q < kAhead; ++q) src[q] = sorted[q < len ? q : len - 1u];
-#pragma unroll
-    for (uint32_t q = 0; q < kAhead; ++q) cur[q] = fetch(src[q]);
-#pragma unroll
-    for (uint32_t q = 0; q < kAhead; ++q) src[q] = sorted[kAhead + q < len ? kAhead + q : len - 1u];
-    for (uint32_t j0 = 0; j0 < len; j0 += kAhead) {
-        Piece nxt[kAhead];
-        uint32_t after[kAhead];
-#pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) nxt[q] = fetch(src[q]);
-#pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) { const uint32_t j = j0 + 2u * kAhead + q; after[q] = sorted[j < len ? j : len - 1u]; }
-#pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply(cur[q]);
-#pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) { cur[q] = nxt[q]; src[q] = after[q]; }
-    }
-    if constexpr (MODE != 1) reinterpret_cast<float *>(p.flow + texel)[c] = f;
-    if constexpr (MODE != 0) reinterpret_cast<unsigned char *>(p.view + texel)[c] = (unsigned char)v;
+    quad_walk<MODE>(p, texel, len, c, [sorted](uint32_t j) { return sorted[j]; });
 }
 
 }  // namespace
