@@ -678,7 +678,7 @@ TH_D void blend_texel_windows(BinShared<MODE> &s, const DepositParams &p, uint32
     uint32_t shift = id_bits > 10u ? id_bits - 10u : 0u;
     while (true) {
         for (uint32_t k = t; k < 1024u; k += 256u) hist[k] = 0u;
-        if (t == 0u) s.misc[0] = 0u;
+        if (t < 3u) s.misc[t] = 0u;
         __syncthreads();
         for_texel([&](unsigned long long k) {
             const unsigned long long id = (k >> PB) & 0xffffffffull;
@@ -688,14 +688,28 @@ TH_D void blend_texel_windows(BinShared<MODE> &s, const DepositParams &p, uint32
             }
         });
         __syncthreads();
-        if (t == 0u) {
-            uint32_t acc = 0, k = 0, rest = 0;
-            while (k < 1024u && acc + hist[k] <= kCrowdCap) { acc += hist[k]; ++k; }
-            for (uint32_t q = k; q < 1024u; ++q) rest += hist[q];
-            s.misc[1] = k; s.misc[2] = acc; s.misc[3] = rest;
+        {
+            // the window: the leading buckets whose running total stays within kCrowdCap.  Every thread its four buckets,
+            // a scan of the workgroup over them (one thread walking the 1024 words took ~30 us per window - of a chain
+            // that is the draw's critical path)
+            const uint32_t lane = t & 63u, wave = t >> 6;
+            const uint32_t h0 = hist[4u * t], h1 = hist[4u * t + 1u], h2 = hist[4u * t + 2u], h3 = hist[4u * t + 3u];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((int)lane >= o) incl += up; }
+            if (lane == 63u) s.misc[4u + wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (uint32_t w = 0; w < 4u; ++w) { const uint32_t v = s.misc[4u + w]; total += v; before += w < wave ? v : 0u; }
+            const uint32_t a0 = before + incl - mine + h0, a1 = a0 + h1, a2 = a1 + h2, a3 = a2 + h3;
+            const uint32_t within = (a0 <= kCrowdCap ? 1u : 0u) + (a1 <= kCrowdCap ? 1u : 0u) + (a2 <= kCrowdCap ? 1u : 0u) + (a3 <= kCrowdCap ? 1u : 0u);
+            const uint32_t reach = a3 <= kCrowdCap ? a3 : (a2 <= kCrowdCap ? a2 : (a1 <= kCrowdCap ? a1 : (a0 <= kCrowdCap ? a0 : 0u)));
+            if (within) { atomicAdd(&s.misc[1], within); atomicMax(&s.misc[2], reach); }       // (the running total never falls: the buckets within the cap are the leading ones)
+            if (t == 0u) s.misc[3] = total;
         }
         __syncthreads();
-        const uint32_t nb = s.misc[1], m = s.misc[2], rest = s.misc[3];
+        const uint32_t nb = s.misc[1], m = s.misc[2], rest = s.misc[3] - m;
         __syncthreads();
         if (nb == 0u) { shift = shift > 4u ? shift - 4u : 0u; continue; }     // the first bucket alone is too large: finer buckets
         // (bucket 1023 also holds everything beyond it: taken only together with all the others = the rest of the run)
