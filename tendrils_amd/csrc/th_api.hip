@@ -160,6 +160,8 @@ struct th_context {
     size_t crowd_keys_cap = 0;
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
+    hipStream_t side2 = nullptr;               // ... and the crowded bins' short runs beside both
+    hipEvent_t joined2 = nullptr;
     uint32_t *bins_totals_host = nullptr;      // (pinned) the binned pass's totals, read back over the side stream
     bool mrg_pairs = false, x_pairs = false;   // the merge / exchange colour buffers hold two varyings per fragment (th_draw_emit / _merge)
     void *pinned = nullptr;                    // (pinned, kPinnedBytes) small read-backs: a pageable hipMemcpyAsync costs ~0.15 ms per call
@@ -608,6 +610,8 @@ th_status th_destroy(th_context *c)
     if (c->forked) (void)hipEventDestroy(c->forked);
     if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->joined2) (void)hipEventDestroy(c->joined2);
+    if (c->side2) (void)hipStreamDestroy(c->side2);
     if (c->bins_totals_host) (void)hipHostFree(c->bins_totals_host);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipFree(c->x_halo); (void)hipFree(c->x_counts); (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
@@ -1634,6 +1638,8 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
         TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
+        TH_HIP(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+        TH_HIP(hipEventCreateWithFlags(&c->joined2, hipEventDisableTiming));
         TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
     }
     uint32_t *host = c->bins_totals_host;
@@ -1699,16 +1705,19 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted;
     th::launch_bins_regroup(p, c->stream);
     if (nlarge) {
-        // the long runs on a stream of their own, beside the short runs' blend (disjoint texels): the walk of the longest
-        // run - one thread, one fragment after the other - overlaps with everything else instead of following it
+        // the long runs on a stream of their own, the crowded bins' short runs on another, beside the ordinary bins' blend
+        // (disjoint texels, kernels that wait on chains and loads rather than fill the chip): the walk of the longest run -
+        // one fragment after the other - overlaps with everything else instead of following it
         TH_HIP(hipEventRecord(c->forked, c->stream));
         TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
         th::launch_bins_blend_long(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
+        TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));
+        th::launch_bins_blend_crowd(p, c->side2);
+        TH_HIP(hipEventRecord(c->joined2, c->side2));
     }
-    th::launch_bins_blend_crowd(p, c->stream);
     if (!early) th::launch_bins_blend(p, c->stream);
-    if (nlarge) TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
+    if (nlarge) { TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0)); }
     TH_HIP(hipGetLastError());
     return TH_OK;
 }
