@@ -19,7 +19,8 @@
 //      workgroup whose reservation crosses into a new page takes that page from the pool and publishes it.  Places
 //      reserved and not used stay empty (key ~0: every reader of a key leaves ~0 behind, so the store starts every
 //      pass empty).
-//      bins_slow_kernel: the few lines that cross the view's edge or a third bin, one place at a time.
+//      bins_listed_kernel: the few lines that cross the view's edge (clipped) and the lines of more fragments than a record
+//      holds, one place at a time.
 //   2. bins_plan_kernel / crowd_plan_kernel: the bins of more than kBinCap places ("large").
 //   3. bins_blend_kernel: one workgroup per bin of up to kBinCap places: its fragments grouped by texel (LDS counting sort), every
 //      texel's run ordered by the stream index of its line (short runs: rank by counting; long ones: bitonic sort) and
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 // run-time indexed edges): one place at a time from the lists' cursors.  (Counting a line's fragments per bin first and
 // reserving them together - two rasterisations, one round trip - was slower: 115 against 92 us; the pass is bound by the
 // general rasteriser, not by its atomics.)
-__global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
+TH_D void bins_slow_lines(const DepositParams &p, uint32_t block, uint32_t blocks)
 {
     dep_list_work(p, kListSlow, [&](bool have, uint32_t s, uint32_t seg) {
         const uint32_t rep = seg & (kBinReplicas - 1u);
@@ -350,12 +351,12 @@ __global__ __launch_bounds__(256) void bins_slow_kernel(const DepositParams p)
                 bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
             });
         }
-    });
+    }, block, blocks);
 }
 
 // ... and the lines of the long list: small hexagons inside the view like the rest, only with more fragments than a record
 // holds - the same register-resident rasteriser, every fragment straight to a place of its own
-__global__ __launch_bounds__(256) void bins_long_kernel(const DepositParams p)
+TH_D void bins_long_lines(const DepositParams &p, uint32_t block, uint32_t blocks)
 {
     dep_list_work(p, kListLong, [&](bool have, uint32_t s, uint32_t seg) {
         const uint32_t rep = seg & (kBinReplicas - 1u);
@@ -374,7 +375,15 @@ __global__ __launch_bounds__(256) void bins_long_kernel(const DepositParams p)
                 bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
             });
         }
-    });
+    }, block, blocks);
+}
+
+// both lists in one launch, half of the grid each: two small grids that wait on their loads and atomics, side by side
+__global__ __launch_bounds__(256) void bins_listed_kernel(const DepositParams p)
+{
+    const uint32_t half = gridDim.x >> 1;
+    if (blockIdx.x < half) bins_long_lines(p, blockIdx.x, half);
+    else bins_slow_lines(p, blockIdx.x - half, half);
 }
 
 // the places handed out in bin b (all its lists; saturated)
@@ -1131,8 +1140,7 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // per SIMD instead of 4)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
     hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_long_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_slow_kernel, dim3(kDepLists * 8u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }

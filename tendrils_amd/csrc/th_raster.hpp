@@ -524,11 +524,12 @@ TH_D void dep_list_append(const DepositParams &p, uint32_t which, uint32_t group
     if (mine) p.lists[((size_t)which * kDepLists + seg) * p.list_cap + first + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
 }
 
-// the workgroups of a slow kernel: (segment, part) = (blockIdx % kDepLists, blockIdx / kDepLists)
+// the workgroups of a slow kernel: (segment, part) = (block % kDepLists, block / kDepLists) of `blocks` workgroups (by
+// default the whole grid)
 template <typename Work>
-TH_D void dep_list_work(const DepositParams &p, uint32_t which, Work work)
+TH_D void dep_list_work(const DepositParams &p, uint32_t which, Work work, uint32_t block = blockIdx.x, uint32_t blocks = gridDim.x)
 {
-    const uint32_t seg = blockIdx.x & (kDepLists - 1u), part = blockIdx.x / kDepLists, parts = gridDim.x / kDepLists;
+    const uint32_t seg = block & (kDepLists - 1u), part = block / kDepLists, parts = blocks / kDepLists;
     const uint32_t n = p.list_n[(which * kDepLists + seg) * kDepListStride];
     const uint32_t *list = p.lists + ((size_t)which * kDepLists + seg) * p.list_cap;
     for (uint32_t e0 = part * 256u; e0 < n; e0 += parts * 256u) {         // whole waves stay together (the appends ballot)
