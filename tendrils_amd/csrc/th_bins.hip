@@ -919,8 +919,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
 //   crowd_scatter_kernel     (stream index << 32 | place of the varying) of every fragment into its texel's range; the
 //                            places and the lists' pages are left empty
 //   crowd_sort_kernel        one wave per texel: its run of up to kWaveRun fragments ordered (rank by counting)
-//   crowd_walk_kernel        one LANE per texel: the ordered run blended, 64 texels of a wave side by side
-//   crowd_blend_kernel       one workgroup per texel of the long list (windows of stream indices when a run does not fit LDS)
+//   crowd_walk_kernel        FOUR lanes per texel, a channel each: the ordered run blended, 16 texels of a wave side by side
+//   crowd_blend_kernel       one workgroup per texel of the long list (windows of stream indices when a run does not fit LDS):
+//                            sources staged by all threads, the destination's channels applied side by side, a lane each
 constexpr uint32_t kWaveRun = 256;           // runs up to this length are ordered and blended by ONE wave
 constexpr uint32_t kGiantRun = 1024;         // longer runs are listed apart and started first: the longest run's walk is the critical path of the blend
 
@@ -1072,11 +1073,12 @@ __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p,
 
 // The runs of up to kWaveRun fragments in two steps.  crowd_sort_kernel: one WAVE per texel orders its run (rank by counting,
 // every lane its <= 4 keys against all of the run's, read from LDS as broadcasts) and leaves the places of the varyings in blend order - tens of thousands of independent waves.
-// crowd_walk_kernel: 64 texels per wave, a LANE per texel, every lane walking the run of its own texel - 64 chains side by
-// side.  With one wave per texel for the whole job every lane applies every fragment to its own copy of the destination: 64
-// times the chain's arithmetic, and the chain (the view target's clamp, convert and round per channel on top of the flow
-// target's multiply and add) is most of that kernel once runs are a hundred fragments long; a lane per texel for the whole job
-// orders 64 runs one after the other per wave and waits for each.
+// crowd_walk_kernel: 16 texels per wave, FOUR lanes per texel - a channel of the destination(s) each -, every quad walking the
+// run of its own texel: 16 chains side by side, each a quarter as long as one thread's doing all channels.  With one wave per
+// texel for the whole job every lane applies every fragment to its own copy of the destination: 64 times the chain's
+// arithmetic, and the chain (the view target's clamp, convert and round per channel on top of the flow target's multiply
+// and add) is most of that kernel once runs are a hundred fragments long; a lane per texel for the whole job orders 64 runs
+// one after the other per wave and waits for each.
 __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
 {
     constexpr uint32_t CAP = kWaveRun;
