@@ -2,6 +2,8 @@
 uniform changes) on random shapes, mirrored operation by operation on the CPU restatement.  Everything must stay
 bit-identical - this is what shakes out interactions (ring parity after odd step_n, slot layout transitions around
 draw(), TARGET / NOISE specialisations, non power-of-two textures, inert and NaN particles)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -94,7 +96,7 @@ def test_random_operation_sequences(oracle, seed):
     t.dispose()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TH_FUZZ_DRAWS", "24"))))        # (TH_FUZZ_DRAWS: longer one-off runs)
 def test_random_draws(oracle, seed):
     """draw() (both passes in one call) on random shapes, views and states against the restatement: lines far longer than
     a record holds, lines that cross the view's edge or lie outside it, endpoints up to the rasteriser's limit of
@@ -124,7 +126,12 @@ def test_random_draws(oracle, seed):
     render = dict(speedLimit=0.01, flowDecay=0.005, speedAlpha=float(rng.choice([1e-6, 0.5])), colorMapAlpha=0.4 if cmap is not None else 0.0,
                   baseColor=[float(v) for v in rng.uniform(0, 1, 4)], flowColor=[float(v) for v in rng.uniform(0, 1, 4)])
     view_size = [1.0, view[0] / view[1]] if seed % 4 else [0.8, 1.3]
-    t = ta.Tendrils(View(*view))
+    # seeds from 16 on: a context that honours gl.lineWidth, the two passes with widths of their own
+    widths = (float(rng.choice([1, 2, 3.5, 7])), float(rng.choice([1, 1.5, 4]))) if seed >= 16 else (1.0, 1.0)
+    opts = ta.defaults()
+    opts["lineWidthRange"] = (1, 64) if seed >= 16 else (1, 1)
+    t = ta.Tendrils(View(*view), opts)
+    t.state["flowWidth"], t.state["lineWidth"] = (widths if seed >= 16 else (5, 1))
     t.resize()
     t.setup(n)
     t.viewSize[:] = view_size
@@ -139,9 +146,9 @@ def test_random_draws(oracle, seed):
     t.draw()
     got_flow, got_view, frags = t.flow.read(), t.read_view(), t.fragments
     t.dispose()
-    want_flow, count = oracle.flow_deposit(cur, prev, base, 1000.0, view_size=view_size, speedLimit=render["speedLimit"])
+    want_flow, count = oracle.flow_deposit(cur, prev, base, 1000.0, view_size=view_size, speedLimit=render["speedLimit"], line_width=widths[0])
     want_view, count2 = oracle.view_render(cur, prev, np.zeros((view[1], view[0], 4), np.uint8), 1000.0, view_size=view_size,
-                                           colormap=cmap, **render)
-    assert frags == count == count2
+                                           colormap=cmap, line_width=widths[1], **render)
+    assert frags == count and (widths[0] != widths[1] or count == count2)
     assert bits_equal(got_flow, want_flow).all()
     assert (got_view == want_view).all()
