@@ -1071,6 +1071,89 @@ __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p,
     }
 }
 
+// The long list (kWaveRun < fragments <= kGiantRun) by ONE WAVE per run, four runs per workgroup side by side: the run's keys
+// ordered by a bitonic network in the wave's own LDS words - no workgroup barrier between its steps: a workgroup per run spent
+// most of its time in the 55 barriers of a thousand-key sort -, then 64 sources staged at a time (the next 64 varyings in
+// flight meanwhile) and the destination's channels applied by lanes 0-7 as in bin_blend_long.
+template <int MODE>
+__global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositParams p, const uint32_t *list, const uint32_t *count)
+{
+    __shared__ unsigned long long skeys[4][kGiantRun];
+    __shared__ BlendSource stage_a[4][2][64], stage_b[4][MODE == 2 ? 2 : 1][MODE == 2 ? 64 : 1];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nlong = *count;
+    unsigned long long *skey = skeys[wave];
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    for (uint32_t e = blockIdx.x * 4u + wave; e < nlong; e += gridDim.x * 4u) {
+        const uint32_t entry = list[e], i = entry >> 8, lt = entry & 255u;
+        const uint32_t b = p.large_bins[i];
+        const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
+        const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
+        const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
+        const uint32_t texel = y * (uint32_t)p.fw + x;            // (a texel with fragments lies inside the target)
+        const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
+        // the keys (stream index << 32 | place of the varying), padded to a power of two, ordered
+        uint32_t P = 512u;
+        while (P < len) P <<= 1;
+        for (uint32_t f = lane; f < P; f += 64u) skey[f] = f < len ? run[f] : ~0ull;
+        wave_sync();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t q = lane; q < (P >> 1); q += 64u) {
+                    const uint32_t lo = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), hi = lo | j;
+                    const unsigned long long a = skey[lo], c = skey[hi];
+                    const bool up = (lo & k) == 0u;
+                    if ((a > c) == up) { skey[lo] = c; skey[hi] = a; }
+                }
+                wave_sync();
+            }
+        // the destination, a channel per lane: lanes 0-3 the flow texel's floats, 4-7 the view texel's bytes
+        const bool flow_lane = lane < 4u;
+        const bool channel = lane < 8u && (MODE == 2 || (MODE == 0) == flow_lane);
+        float comp = 0.0f;
+        if (channel) {
+            if (MODE != 1 && flow_lane) comp = reinterpret_cast<const float *>(p.flow + texel)[lane & 3u];
+            else comp = (float)reinterpret_cast<const unsigned char *>(p.view + texel)[lane & 3u];
+        }
+        auto fetch = [&](uint32_t j0, float4 &c0, float4 &c1) {
+            const uint32_t j = j0 + lane;
+            fetch_colors<MODE>(p, (size_t)(uint32_t)(skey[j < len ? j : len - 1u] & 0xffffffffull), c0, c1);
+        };
+        float4 c0, c1;
+        fetch(0u, c0, c1);
+        uint32_t buf = 0;
+        for (uint32_t j0 = 0; j0 < len; j0 += 64u, buf ^= 1u) {
+            if constexpr (MODE == 1) stage_a[wave][buf][lane] = ViewTarget::source(c0);
+            else stage_a[wave][buf][lane] = FlowTarget::source(c0);
+            if constexpr (MODE == 2) stage_b[wave][buf][lane] = ViewTarget::source(c1);
+            if (j0 + 64u < len) fetch(j0 + 64u, c0, c1);              // in flight while this batch is applied
+            wave_sync();
+            if (channel) {
+                const BlendSource *from = (MODE == 2 && !flow_lane) ? stage_b[wave][MODE == 2 ? buf : 0u] : stage_a[wave][buf];
+                const float *mine = reinterpret_cast<const float *>(from) + (lane & 3u), *das = reinterpret_cast<const float *>(from) + 4u;
+                const uint32_t n = len - j0 < 64u ? len - j0 : 64u;
+                auto apply = [&](float src, float da) {
+                    if (MODE != 1 && flow_lane) FlowTarget::apply_channel(comp, src, da);
+                    else ViewTarget::apply_channel(comp, src, da);
+                };
+                uint32_t q = 0;
+                for (; q + 8u <= n; q += 8u) {
+                    float sv[8], da[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; ++k) { sv[k] = mine[(q + k) * 5u]; da[k] = das[(q + k) * 5u]; }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; ++k) apply(sv[k], da[k]);
+                }
+                for (; q < n; ++q) apply(mine[q * 5u], das[q * 5u]);
+            }
+        }
+        if (channel) {
+            if (MODE != 1 && flow_lane) reinterpret_cast<float *>(p.flow + texel)[lane & 3u] = comp;
+            else reinterpret_cast<unsigned char *>(p.view + texel)[lane & 3u] = (unsigned char)comp;
+        }
+        wave_sync();                                              // (the words are free for the wave's next run)
+    }
+}
+
 // The runs of up to kWaveRun fragments in two steps.  crowd_sort_kernel: one WAVE per texel orders its run (rank by counting,
 // every lane its <= 4 keys against all of the run's, read from LDS as broadcasts) and leaves the places of the varyings in blend order - tens of thousands of independent waves.
 // crowd_walk_kernel: 16 texels per wave, FOUR lanes per texel - a channel of the destination(s) each -, every quad walking the
@@ -1164,7 +1247,7 @@ void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;
 #define TH_GO(M) do { hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(256), dim3(256), 0, s, p, (const uint32_t *)p.crowd_giant, (const uint32_t *)(p.totals + kTotGiant)); \
-                      hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(1024), dim3(256), 0, s, p, (const uint32_t *)p.crowd_long, (const uint32_t *)(p.totals + kTotLong)); } while (0)
+                      hipLaunchKernelGGL(crowd_blend_waves_kernel<M>, dim3(1024), dim3(256), 0, s, p, (const uint32_t *)p.crowd_long, (const uint32_t *)(p.totals + kTotLong)); } while (0)
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO
 }
