@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositPar
         const uint32_t texel = y * (uint32_t)p.fw + x;            // (a texel with fragments lies inside the target)
         const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
         // the keys (stream index << 32 | place of the varying), padded to a power of two, ordered
-        uint32_t P = 512u;
+        uint32_t P = 64u;
         while (P < len) P <<= 1;
         for (uint32_t f = lane; f < P; f += 64u) skey[f] = f < len ? run[f] : ~0ull;
         wave_sync();
