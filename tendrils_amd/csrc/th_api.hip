@@ -161,7 +161,7 @@ struct th_context {
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
     hipStream_t side2 = nullptr;               // ... and the crowded bins' short runs beside both
-    hipEvent_t joined2 = nullptr;
+    hipEvent_t joined2 = nullptr, regrouped = nullptr;
     uint32_t *bins_totals_host = nullptr;      // (pinned) the binned pass's totals, read back over the side stream
     bool mrg_pairs = false, x_pairs = false;   // the merge / exchange colour buffers hold two varyings per fragment (th_draw_emit / _merge)
     void *pinned = nullptr;                    // (pinned, kPinnedBytes) small read-backs: a pageable hipMemcpyAsync costs ~0.15 ms per call
@@ -611,6 +611,7 @@ th_status th_destroy(th_context *c)
     if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->joined2) (void)hipEventDestroy(c->joined2);
+    if (c->regrouped) (void)hipEventDestroy(c->regrouped);
     if (c->side2) (void)hipStreamDestroy(c->side2);
     if (c->bins_totals_host) (void)hipHostFree(c->bins_totals_host);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -1640,6 +1641,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
         TH_HIP(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
         TH_HIP(hipEventCreateWithFlags(&c->joined2, hipEventDisableTiming));
+        TH_HIP(hipEventCreateWithFlags(&c->regrouped, hipEventDisableTiming));
         TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
     }
     uint32_t *host = c->bins_totals_host;
@@ -1703,16 +1705,17 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
     p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257; p.crowd_giant = p.crowd_long + (size_t)c->crowd_capacity * 256;
     p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted;
-    th::launch_bins_regroup(p, c->stream);
     if (nlarge) {
-        // the long runs on a stream of their own, the crowded bins' short runs on another, beside the ordinary bins' blend
-        // (disjoint texels, kernels that wait on chains and loads rather than fill the chip): the walk of the longest run -
-        // one fragment after the other - overlaps with everything else instead of following it
-        TH_HIP(hipEventRecord(c->forked, c->stream));
-        TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
+        // The crowded bins on two streams of their own, beside the ordinary bins' blend (disjoint texels, kernels that wait on
+        // chains and loads rather than fill the chip): their fragments regrouped by texel, then the long runs on one stream -
+        // the walk of the longest run, one fragment after the other, overlaps with everything else instead of following it -
+        // and the short runs on the other.
+        TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan: the ordinary bins' blend need not be waited for)
+        th::launch_bins_regroup(p, c->side2);
+        TH_HIP(hipEventRecord(c->regrouped, c->side2));
+        TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
         th::launch_bins_blend_long(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
-        TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));
         th::launch_bins_blend_crowd(p, c->side2);
         TH_HIP(hipEventRecord(c->joined2, c->side2));
     }
