@@ -1162,38 +1162,64 @@ __global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositPar
 // arithmetic, and the chain (the view target's clamp, convert and round per channel on top of the flow target's multiply
 // and add) is most of that kernel once runs are a hundred fragments long; a lane per texel for the whole job orders 64 runs
 // one after the other per wave and waits for each.
-__global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
+// a run of up to 64 W fragments ordered by the LANES lanes [first, first + LANES) of a wave (W keys per lane... K keys each):
+// rank by counting over the run's stream indices in `ids` (LDS words of those lanes alone)
+template <uint32_t LANES, uint32_t K>
+TH_D void lanes_rank_sort(const unsigned long long *run, uint32_t *sorted, uint32_t len, uint32_t *ids, uint32_t sl, uint32_t trips)
 {
-    constexpr uint32_t CAP = kWaveRun;
-    __shared__ uint32_t ids[4][CAP];                 // (the stream indices alone order a texel's run: a line covers a texel at most once)
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t gt = blockIdx.x * 4u + wave, i = gt >> 8, lt = gt & 255u;
-    if (i >= p.nlarge) return;
-    const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
-    if (len == 0u || len > CAP) return;                       // (longer ones: crowd_blend_kernel)
-    const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
-    uint32_t *sorted = p.crowd_sorted + p.large_key0[i] + r0;
-    constexpr uint32_t kPer = CAP / 64u;
-    unsigned long long mine[kPer];
+    unsigned long long mine[K];
+    uint32_t id[K], rank[K];
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; mine[q] = run[f < len ? f : len - 1u]; }
-    if (len == 1u) { if (lane == 0u) sorted[0] = (uint32_t)(mine[0] & 0xffffffffull); return; }
-    uint32_t id[kPer];
-#pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; id[q] = (uint32_t)(mine[q] >> 32); if (f < len) ids[wave][f] = id[q]; }
+    for (uint32_t q = 0; q < K; ++q) {
+        const uint32_t f = q * LANES + sl;
+        mine[q] = len ? run[f < len ? f : len - 1u] : 0ull;
+        id[q] = (uint32_t)(mine[q] >> 32);            // (the stream indices alone order a texel's run: a line covers a texel at most once)
+        rank[q] = 0u;
+        if (f < len) ids[f] = id[q];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    uint32_t rank[kPer];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (`trips`: the longest run of the wave's groups - every lane goes round as often, a group past its own run counts nothing)
+    for (uint32_t j = 0; j < trips; ++j) {
+        const uint32_t k = ids[j < len ? j : 0u];
+        const bool in = j < len;
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) rank[q] = 0u;
-    const uint32_t groups = (len + 63u) >> 6;                 // (uniform) key groups of 64 that exist
-    for (uint32_t j = 0; j < len; ++j) {
-        const uint32_t k = ids[wave][j];
-#pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) if (q < groups) rank[q] += k < id[q] ? 1u : 0u;
+        for (uint32_t q = 0; q < K; ++q) rank[q] += (in && k < id[q]) ? 1u : 0u;
     }
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 64u + lane; if (f < len) sorted[rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
+    for (uint32_t q = 0; q < K; ++q) { const uint32_t f = q * LANES + sl; if (f < len) sorted[rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
+}
+
+// Four texels per wave.  Most runs of a crowded bin are a few dozen fragments long: a wave per texel spent its time waiting
+// for three dependent loads to order thirty keys.  When all four runs have at most 64 fragments, 16 lanes take each (4 keys a
+// lane); otherwise the wave takes them one after the other (4 keys a lane, up to kWaveRun).
+__global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
+{
+    static_assert(kWaveRun == 256u, "four keys per lane");
+    __shared__ uint32_t ids[4][kWaveRun];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, sub = lane >> 4, sl = lane & 15u;
+    const uint32_t g = blockIdx.x * 4u + wave, i = g >> 6, lt0 = (g & 63u) << 2;          // texels lt0 .. lt0 + 3 of large bin i
+    if (i >= p.nlarge) return;
+    const uint32_t *start = p.crowd_start + (size_t)i * (kBinTexels + 1u) + lt0;
+    const uint32_t r0 = start[sub];
+    uint32_t len = start[sub + 1u] - r0;
+    if (len > kWaveRun) len = 0u;                                      // (longer ones: the long list's kernels)
+    uint32_t longest = len;
+    longest = max(longest, (uint32_t)__shfl_xor((int)longest, 16));
+    longest = max(longest, (uint32_t)__shfl_xor((int)longest, 32));
+    if (longest == 0u) return;
+    const size_t key0 = p.large_key0[i];
+    if (longest <= 64u) {
+        lanes_rank_sort<16u, 4u>(p.crowd_keys + key0 + r0, p.crowd_sorted + key0 + r0, len, ids[wave] + sub * 64u, sl, longest);
+        return;
+    }
+    for (uint32_t q = 0; q < 4u; ++q) {
+        const uint32_t qr0 = (uint32_t)__shfl((int)r0, (int)(q << 4)), qlen = (uint32_t)__shfl((int)len, (int)(q << 4));
+        if (qlen == 0u) continue;
+        lanes_rank_sort<64u, 4u>(p.crowd_keys + key0 + qr0, p.crowd_sorted + key0 + qr0, qlen, ids[wave], lane, qlen);
+        __builtin_amdgcn_wave_barrier();                              // (everybody is done with the words before the next run's)
+    }
 }
 
 template <int MODE>
@@ -1258,7 +1284,7 @@ void launch_bins_blend_crowd(const DepositParams &p, hipStream_t s)
     // every run of up to kWaveRun fragments ordered by a wave of its own ...  (Up to kGiantRun - the 257..1024 class through a
     // 16-keys-per-lane instantiation over the list - was slower: a lane walking a thousand fragments holds its wave: 2.60
     // against 2.28 ms per crowded draw.)
-    hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 4u)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 16u)), dim3(256), 0, s, p);
     // ... and walked by a lane of its own
     if (p.mode == 0) hipLaunchKernelGGL(crowd_walk_kernel<0>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
     else if (p.mode == 1) hipLaunchKernelGGL(crowd_walk_kernel<1>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
