@@ -846,7 +846,16 @@ def frame_loop(t, ctx, state, frames=20):
     # ... and the same loop once the wake has crowded the target (the reference's loop runs for minutes: after ~60 frames
     # at this size most fragments fall into texels with hundreds and thousands of them, and a draw waits for the
     # longest run of one texel): `settle` more frames untimed, then 50 timed
-    settle = 250
+    def wall(n):
+        """n frames of the loop as a host runs it - no event, no sync but the draw's own read-back - against the wall clock"""
+        _capi.call("th_sync", ctx)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            t.timer.tick(); t.step(); t.draw()
+        _capi.call("th_sync", ctx)
+        return (time.perf_counter() - t0) / n * 1e3
+    wall_ms = wall(20)
+    settle = 230
     for _ in range(settle):
         t.timer.tick(); t.step(); t.draw()
     c_step, c_both, c_frags = [], [], []
@@ -855,7 +864,8 @@ def frame_loop(t, ctx, state, frames=20):
         c_step.append(timed(t.step))
         c_both.append(timed(t.draw))
         c_frags.append(t.fragments)
-    crowded = {"after_frames": 5 + frames + 5 + settle, "frames": 50, "step_ms": float(np.median(c_step)), "draw_both_ms": float(np.median(c_both)),
+    crowded = {"after_frames": 5 + frames + 5 + 20 + settle, "frames": 50, "step_ms": float(np.median(c_step)), "draw_both_ms": float(np.median(c_both)),
+               "wall_ms_per_frame": wall(50),
                "slowest_frame": {"step_ms": float(np.max(c_step)), "draw_both_ms": float(np.max(c_both))},
                "fragments_per_draw": float(np.mean(c_frags)),
                "frame_ms_reference_loop": float(np.median(c_step)) + float(np.median(c_both))}
@@ -877,6 +887,7 @@ def frame_loop(t, ctx, state, frames=20):
                               "draw_both_ms": float(np.max(both_ms))},
             "fragments_per_draw": f, "frames_per_s": 1e3 / (s_ms + d),
             "frame_ms_reference_loop": s_ms + b_ms,
+            "wall_ms_per_frame": wall_ms,
             "crowded": crowded,
             "pipeline": "binned (th_bins.hip): particles stay in the integrator's tile-sorted slot order; one fused rasterise + emit pass into "
                         "16x16-texel bins of the target, per-bin ordering by (texel, stream index) and blending in LDS",
@@ -890,7 +901,8 @@ def frame_loop(t, ctx, state, frames=20):
                                               "this round's duration - comparable with round 2's frame_loop.roofline.frac"}},
             "note": "timer.tick(); step(); draw(): one single-step launch over tile-sorted slots + the flow pass; the view pass timed separately "
                     "(th_view_draw after th_flow_deposit: a full pass of its own in the binned pipeline), and both passes in one call "
-                    "(th_draw, what Tendrils.draw() runs with renderView: one rasterisation, two varyings per fragment) over 5 more frames"}
+                    "(th_draw, what Tendrils.draw() runs with renderView: one rasterisation, two varyings per fragment) over 5 more frames; "
+                    "wall_ms_per_frame: the loop as a host runs it (no events, no sync but the draw's own read-back) against the wall clock, 20 frames"}
 
 
 def cpu_baseline(t, width, rows_avail):
