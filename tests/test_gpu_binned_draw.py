@@ -78,6 +78,42 @@ def test_frame_loop_at_c3_size_bins_equal_stream():
     assert bits_equal(a[3], b[3]).all() and bits_equal(a[4], b[4]).all()
 
 
+def test_loop_on_a_crowded_target_bins_equal_stream():
+    """A million particles over a 160 x 90 target: every texel holds a run of dozens of fragments from the first frame on,
+    hundreds and thousands (the long list, the giants, their windows) once the wake has pulled the particles together.  30
+    frames of tick(); step(); draw() with both passes: the binned pipeline over tile-sorted slots against the stream-ordered
+    one in texel order - fragments, flow field, view buffer and particles bit for bit, frame after frame."""
+    import ctypes as C
+    from tendrils_amd import _capi
+    n, frames = 1024, 30
+    rng = np.random.default_rng(77)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2)).astype(np.float32) * np.float32(0.7)
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2)).astype(np.float32)
+    outs = []
+    for pipeline in ("stream", "bins"):
+        t = make(n, (160, 90), pipeline)
+        t.particles.upload_texels(st)
+        t.timer.time = 1000.0
+        t.renderView = True
+        frags, crowd = [], []
+        for _ in range(frames):
+            t.timer.tick()
+            t.step()
+            t.draw()
+            frags.append(t.fragments)
+        info = _capi.DrawInfo()
+        _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
+        outs.append((frags, t.flow.read(), t.read_view(), t.particles.read(0), int(info.crowded_fragments)))
+        t.dispose()
+    a, b = outs
+    assert a[0] == b[0] and min(a[0]) > 100_000
+    assert b[4] > 0.3 * b[0][-1]                     # (the crowded bins' kernels did run: a third of the last draw's fragments and more)
+    assert bits_equal(a[1], b[1]).all()
+    assert (a[2] == b[2]).all() and a[2].any()
+    assert bits_equal(a[3], b[3]).all()
+
+
 def crowded(n, seed, spread):
     rng = np.random.default_rng(seed)
     prev = np.zeros((n, n, 4), np.float32)
