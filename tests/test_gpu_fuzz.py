@@ -17,7 +17,7 @@ def oracle_uniforms(oracle, t, n):
                                  **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TH_FUZZ_OPS", "6"))))           # (TH_FUZZ_OPS: longer one-off runs)
 def test_random_operation_sequences(oracle, seed):
     import tendrils_amd as ta
     from tendrils_amd.spawn import PixelSpawner, flow_sample_frag, spawnBall
