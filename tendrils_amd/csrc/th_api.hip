@@ -115,6 +115,7 @@ struct th_context {
     float4 *tmp[3] = {nullptr, nullptr, nullptr};   // f32 staging for the non-hot operations on a packed ring
     float4 *flow = nullptr;
     float2 *flow_dec = nullptr;          // per-step decoded plane (launch_flow_decode)
+    float *flow3 = nullptr;              // the flow texels' x, y, z alone (fused passes: th_step_n packs them once per call)
     int32_t fw = 0, fh = 0;
     float4 *targets = nullptr;
     bool targets_checked = true, targets_nonfinite = false;   // fresh texture = zeros
@@ -601,7 +602,7 @@ th_status th_destroy(th_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)th::comm_destroy(c->comm); c->comm = nullptr; }
     for (float4 *b : c->ring) (void)hipFree(b);
-    (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->targets); (void)hipFree(c->lut_block);
+    (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->flow3); (void)hipFree(c->targets); (void)hipFree(c->lut_block);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
@@ -715,7 +716,8 @@ th_status th_flow_resize(th_context *c, int32_t w, int32_t h)
     clear_graphs(c);
     TH_HIP(hipFree(c->flow));
     TH_HIP(hipFree(c->flow_dec));
-    c->flow = nullptr; c->flow_dec = nullptr;
+    (void)hipFree(c->flow3);
+    c->flow = nullptr; c->flow_dec = nullptr; c->flow3 = nullptr;
     TH_HIP(hipMalloc((void **)&c->flow, (size_t)w * h * sizeof(float4)));
     TH_HIP(hipMalloc((void **)&c->flow_dec, (size_t)w * h * sizeof(float2)));
     TH_HIP(hipMemsetAsync(c->flow, 0, (size_t)w * h * sizeof(float4), c->stream));
@@ -1069,11 +1071,21 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 c->ring[0] = other; c->ring[1] = cur;
             }
         } else if (th_status s = ensure_identity(c)) return s;
+        // The field does not change inside the call.  Without the noise the pass waits for its taps (a dependent gather per
+        // step): the field's x, y, z packed 12 B apart once per call - three quarters of the footprint, and the band one
+        // XCD taps fits its L2 (0.574 -> 0.546 ms per 20-step launch at C3; with the noise on the pass is bound by its
+        // arithmetic and the packing pass only costs: 1.829 against 1.818 + 0.01)
+        const bool pack3 = !plan.noise;
+        if (pack3) {
+            if (!c->flow3) TH_HIP(hipMalloc((void **)&c->flow3, (size_t)c->fw * c->fh * 3 * sizeof(float)));
+            th::launch_flow_pack3(c->flow, c->flow3, (size_t)c->fw * c->fh, c->stream);
+        }
         {
             int32_t done = 0;
             while (done < n) {
                 const int32_t m = std::min<int32_t>(n - done, (int32_t)th::kMaxFusedSteps);
                 th::LogicParams p = plan.p;
+                p.flow3 = pack3 ? c->flow3 : nullptr;
                 float4 *cur = c->ring[0], *other = c->ring[1];
                 const int order = order_of(c, cur);
                 p.in = cur;

@@ -408,6 +408,7 @@ TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32
     float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
     float4 ft;
     if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
+    else if (p.flow3) { const float *f3 = p.flow3 + 3u * (uint32_t)texel; ft = make_float4(f3[0], f3[1], f3[2], 0.0f); }     // (uniform branch)
     else ft = p.flow[texel];
 
     float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
@@ -1218,6 +1219,20 @@ __global__ __launch_bounds__(256) void flow_decode_kernel(const float4 *flow, fl
         float k = __builtin_fmaxf(0.0f, 1.0f - ((time - f.z) * decay));
         dec[i] = make_float2(f.x * k, f.y * k);
     }
+}
+
+// the flow texels' x, y, z alone, 12 B apart (LogicParams::flow3)
+__global__ __launch_bounds__(256) void flow_pack3_kernel(const float4 *flow, float *xyz, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float4 f = flow[i];
+        xyz[3 * i] = f.x; xyz[3 * i + 1] = f.y; xyz[3 * i + 2] = f.z;
+    }
+}
+void launch_flow_pack3(const float4 *flow, float *xyz, size_t n, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(flow_pack3_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, flow, xyz, n);
 }
 
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,

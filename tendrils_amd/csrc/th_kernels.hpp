@@ -34,6 +34,8 @@ struct LogicParams {
     float4 *out;             // ring buffers[0] or an explicit target
     const float4 *flow;      // RGBA32F flow texture, fw x fh
     const float2 *flow_dec;  // flow decoded for this step's time: xy * max(0, 1-(time-z)*decay)
+    const float *flow3;      // (fused passes) the flow texels' x, y, z alone, 12 B apart: three quarters of the field's footprint in the
+                             // XCDs' L2s - the band one XCD taps (a sorted eighth of the slots) then fits its 4 MB; nullptr: p.flow
     const float4 *targets;   // RGBA32F targets texture (local rows)
     const float4 *lut;       // noise gradient table (kLutSize float4), preceded in memory by the hash tables (hash_table_vectors() float4)
     uint32_t count;          // texels held by this context = width * local rows
@@ -178,6 +180,7 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
 void launch_logic_fused(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool packed, hipStream_t stream);
 void launch_pack_state(void *dst, const float4 *src, uint32_t n, hipStream_t stream);      // f32 texels -> TH_STATE_F16
 void launch_unpack_state(float4 *dst, const void *src, uint32_t n, hipStream_t stream);
+void launch_flow_pack3(const float4 *flow, float *xyz, size_t n, hipStream_t stream);
 void launch_flow_decode(const float4 *flow, float2 *dec, size_t n, float time, const float *time_dev, float decay,
                         hipStream_t stream);
 void launch_logic_sorted(const LogicParams &p, int mode, bool noise, bool target, bool pow2, bool in_tiled, bool scatter,
