@@ -562,9 +562,11 @@ def gen_timer(r, only):
     print("wrote timer_script.json (%d ops)" % len(TIMER_SCRIPT))
 
 
-ANIMATE_TRACKS = {"tendrils": [], "colour": [], "spawn": [], "calls": []}
-ANIMATE_OUTPUTS = {"tendrils": {"flowWeight": 1, "noiseScale": 2.125, "damping": 0.043, "autoFade": True},
-                   "colour": [1, 1, 1, 0.5], "spawn": {"radius": 1, "speed": 0}, "calls": {}}
+# in alphabetical order: the job reaches the page with its keys sorted (kaleido's JSON encoder), and the order of the
+# tracks is the order in which a player call visits them - visible in the call log when two tracks fire in one call
+ANIMATE_TRACKS = {"calls": [], "colour": [], "spawn": [], "tendrils": []}
+ANIMATE_OUTPUTS = {"calls": {}, "colour": [1, 1, 1, 0.5], "spawn": {"radius": 1, "speed": 0},
+                   "tendrils": {"autoFade": True, "damping": 0.043, "flowWeight": 1, "noiseScale": 2.125}}
 ANIMATE_OPS = [
     # a start frame on every track, like the demo's tracksStart (src/demo.main.js:928-949)
     ["track", "tendrils", "to", {"to": {"flowWeight": 1, "noiseScale": 1.5, "forceWeight": 0.017}, "time": 60}],
@@ -586,6 +588,25 @@ ANIMATE_OPS = [
     ["play", 2300], ["play", 2600], ["play", 3650], ["play", 3700.25], ["play", 3999], ["play", 4800], ["play", 5000],
     ["play", 6000], ["play", 4900], ["play", 2000], ["seek", 100], ["play", 150], ["playFrom", 2900, 0], ["playFrom", 1100, 4000],
     ["seek", 2750], ["play", 2760],
+    # editing while the playhead stands inside the timeline (the demo's `keyframe()` adds a frame at the current track time,
+    # src/demo.main.js:1267-1274; <backspace> removes the one before it, :3472-3474), then playing on
+    ["track", "tendrils", "smoothTo", {"to": {"flowWeight": 0.5, "damping": 0.2}, "time": 2760, "ease": [0, 0.95, 1]}],
+    ["play", 2770], ["play", 2800], ["play", 3690], ["play", 3705],
+    ["track", "tendrils", "to", {"to": {"noiseScale": 7}, "time": 3600}], ["play", 3710], ["play", 4100],
+    ["track", "colour", "spliceAt", 2000], ["play", 4200], ["playFrom", 1800, 0],
+    ["track", "spawn", "spliceSpan", 600, 1500], ["playFrom", 2500, 0],
+    ["track", "tendrils", "spliceAt", 4500, 1], ["track", "tendrils", "spliceIndex", 2], ["playFrom", 5200, 0],
+    ["track", "colour", "over", 0, {"to": [0.5, 0.5, 0.5, 0.5], "time": 3000}], ["playFrom", 3000, 2900], ["play", 3001],
+    ["track", "spawn", "easeTo", 0.25, {"to": {"radius": 2}, "time": 100, "ease": [0, 0.3, 0.6, 0.8, 0.9, 1]}], ["playFrom", 90, 0],
+    # return values of the timeline's queries, on the timelines as they stand now
+    ["query", "tendrils", "gapAt", 3650], ["query", "tendrils", "gapAt", 60], ["query", "tendrils", "gapAt", -1e9],
+    ["query", "tendrils", "gapAt", 1e9], ["query", "tendrils", "indexOf", {"time": 1800}], ["query", "tendrils", "indexOf", {"time": 1e9}],
+    ["query", "tendrils", "indexOf", {"time": 59}], ["query", "colour", "spanGapAt", 2800], ["query", "colour", "spanGapAt", 3000],
+    ["query", "tendrils", "minFrame", {"to": {"flowWeight": 0.9, "damping": 0.3, "noiseScale": 0.5}, "time": 2000}],
+    ["query", "tendrils", "minFrame", {"flowWeight": 1, "time": 7}, 30, [0, 1]], ["query", "tendrils", "minFrame", {"to": {"noiseScale": 7}, "time": 1e9}],
+    ["query", "spawn", "start"], ["query", "spawn", "end"], ["query", "spawn", "duration"], ["query", "calls", "valid"],
+    ["query", "spawn", "splice", 0, 0], ["query", "spawn", "spliceIndex", 3], ["query", "spawn", "spliceIndex", -1],
+    ["query", "spawn", "gapAt", 500], ["playFrom", 2300, 0],
 ]
 
 
@@ -599,8 +620,66 @@ def gen_animate(r_unused, only):
     os.makedirs(GOLDEN, exist_ok=True)
     with open(os.path.join(GOLDEN, "animate_script.json"), "w") as f:
         json.dump({"tracks": ANIMATE_TRACKS, "outputs": ANIMATE_OUTPUTS, "ops": ANIMATE_OPS, "expected": res["out"],
-                   "frames": res["frames"]}, f)
+                   "frames": res["frames"], "queries": res["queries"], "player": {k: res[k] for k in ("start", "end", "duration")}}, f)
     print("wrote animate_script.json (%d player calls)" % len(res["out"]))
+
+
+def scene_colour(proxy, name, preset):
+    """The demo's colour proxy (src/demo.main.js:1335-1354): a preset assigns `<name>Color` (0..255) and / or `<name>Alpha`
+    to a proxy that keeps everything else, and the state colour is then [r / 255, g / 255, b / 255, alpha]."""
+    cp = preset.get("colorProxy", {})
+    if name + "Color" in cp:
+        proxy[name + "Color"] = list(cp[name + "Color"])
+    if name + "Alpha" in cp:
+        proxy[name + "Alpha"] = cp[name + "Alpha"]
+    return (name + "Color" in cp) or (name + "Alpha" in cp)
+
+
+def gen_scene(r_unused, only):
+    """preset "Flow" set at once, then keyframes easing into "Turbulence" (reached at frame 12 over 10 frames)
+    and into "Wings" (frame 24, ease joined to the one before) on the reference's own Player, 24 frames of the demo's loop
+    body on the reference's own Tendrils.  Stores the script, the state object after every frame, the particle texture of
+    every frame and flow + view of five frames."""
+    name = "scene_flow_turbulence_wings_64"
+    if only and only not in name and only != "scene":
+        return
+    table = json.load(open(os.path.join(GOLDEN, "presets.json")))
+    n, view, frames, time0, step = 64, (96, 54), 24, 1000.0, 1000 / 60
+    rng = np.random.default_rng(41)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, 0.55]
+    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+    defaults = {"baseColor": [1, 1, 1, 0.5], "flowColor": [1, 1, 1, 0.04], "fadeColor": [0.1333, 0.1333, 0.1333, 0]}
+    proxy = {}
+    for c in ("base", "flow", "fade"):
+        proxy[c + "Color"] = [v * 255 for v in defaults[c + "Color"][:3]]
+        proxy[c + "Alpha"] = defaults[c + "Color"][3]
+
+    def colours(preset, only_named):
+        out = {}
+        for c in ("base", "flow", "fade"):
+            if scene_colour(proxy, c, preset) or not only_named:
+                out[c + "Color"] = [v / 255 for v in proxy[c + "Color"]] + [proxy[c + "Alpha"]]
+        return out
+    first = table["Flow"]
+    colors0 = colours(first, False)
+    script = [dict(preset="Turbulence", time=time0 + 12 * step, duration=10 * step, ease=[0, 0.95, 1]),
+              dict(preset="Wings", time=time0 + 24 * step, duration=0, ease=[0, 0.2, 1])]
+    ops = []
+    for k in script:
+        p = table[k["preset"]]
+        tracks = dict(tendrils=dict(p.get("state", {})), **colours(p, True))
+        for tr, to in tracks.items():
+            frame = {"to": to, "time": k["time"], "ease": list(k["ease"])}
+            ops.append(["track", tr, "smoothOver", k["duration"], frame] if k["duration"] else ["track", tr, "smoothTo", frame])
+    r = RefRunner("demo-modules")
+    grab = [0, 7, 11, 15, 23]
+    res = r.scene(st, ops, state0=first.get("state", {}), colors0=colors0, time0=time0, frames=frames, view=view, grab=grab)
+    assert res["samples"] == 0
+    meta = dict(kind="scene", N=n, frames=frames, viewRes=list(view), viewSize=res["viewSize"], time0=time0, times=res["times"],
+                dts=res["dts"], first="Flow", script=script, ops=ops, colors0=colors0, grab=grab, states=res["states"])
+    save(name, state=st, out=res["particles"], flows=np.stack([res["flows"][g] for g in grab]),
+         views=np.stack([res["views"][g] for g in grab]), uniforms=json.dumps(meta))
 
 
 def gen_presets(r_unused, only):
@@ -659,6 +738,7 @@ def main():
     gen_view(r, args.only)
     gen_animate(r, args.only)
     gen_presets(r, args.only)
+    gen_scene(r, args.only)
     gen_spawn_map(r, args.only)
     gen_timer(r, args.only)
 

@@ -126,6 +126,24 @@ class RefRunner:
     def animate(self, tracks, ops, outputs=None):
         return self._run({"kind": "animate", "tracks": tracks, "ops": ops, "outputs": outputs or {}})
 
+    def scene(self, particles, ops, state0=None, colors0=None, time0=0.0, frames=24, view=(96, 54), grab=()):
+        """bundle="demo-modules": the reference's Player (tracks tendrils / baseColor / flowColor / fadeColor writing into
+        tendrils.state, as src/demo.main.js:836-857) keyframed by `ops`, then `frames` x [timer.tick(); player.play(time);
+        step(); draw()] of the reference's Tendrils.  Returns per frame: time, dt, the whole state object, the particle
+        texture; flow [H,W,4] f32 and view [H,W,4] u8 for the frames in `grab`."""
+        n = particles.shape[0]
+        res = self._run({"kind": "scene", "N": n, "viewW": int(view[0]), "viewH": int(view[1]), "state0": state0 or {},
+                         "colors0": colors0 or {}, "particles": _b64(particles, np.float32), "time0": float(time0),
+                         "frames": int(frames), "ops": ops, "grab": [int(g) for g in grab]})
+        if res.get("err"):
+            raise RuntimeError("GL error %s" % res["err"])
+        fw, fh = res["flowShape"]
+        res["particles"] = np.stack([_f32(p, (n, n, 4)) for p in res["particles"]])
+        res["flows"] = {int(k): _f32(v, (fh, fw, 4)) for k, v in res["flows"].items()}
+        res["views"] = {int(k): np.frombuffer(base64.b64decode(v), dtype=np.uint8).reshape(int(view[1]), int(view[0]), 4).copy()
+                        for k, v in res["views"].items()}
+        return res
+
     # -- reference Particles.spawn(map, pixels, offset) ------------------------------
     def spawn_map(self, n, coef, pixels=None, offset=None, view=(32, 32)):
         """Returns the ring buffers ([N,N,4] each) after particles.spawn(map, pixels, offset) with

@@ -101,6 +101,19 @@ if (spec.kind === 'logic') {
   sp.spawn(t);
   save('out_0.bin', t.particles.read(0));
   fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ time: t.timer.time, jitter: sp.jitter, moved }));
+} else if (spec.kind === 'scene') {               // presets keyframed by js/scenes.js while step() + draw() run
+  const { Scene } = require(path.join(root, 'tendrils_amd', 'js', 'scenes'));
+  const scene = new Scene(t).preset(spec.table[spec.first]);
+  for (const k of spec.script) scene.keyframe(spec.table[k.preset], k.time, k.duration, k.ease);
+  t.timer.time = spec.time0;
+  const states = [], times = [];
+  scene.run(spec.frames, (k, tn) => {
+    times.push(tn.timer.time);
+    states.push(JSON.parse(JSON.stringify(tn.state)));
+    save(`state_${k}.bin`, tn.particles.read(0));
+    if (spec.grab.includes(k)) { save(`flow_${k}.bin`, tn.flow.read()); save(`view_${k}.bin`, tn.readView()); }
+  });
+  fs.writeFileSync(path.join(dir, 'result.json'), JSON.stringify({ times, states }));
 } else {
   throw new Error('unknown case kind ' + spec.kind);
 }

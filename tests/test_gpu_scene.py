@@ -1,41 +1,75 @@
-"""Scene replay (tendrils_amd/scenes.py): presets from the fixture table keyframed into `tendrils.state` by the Player
-while step() + draw() run; the state must follow the tracks and the view must fill."""
+"""Scene replay on the GPU against frames captured from the REFERENCE: its own Player driving its own
+Tendrils - preset "Flow", then keyframes easing into "Turbulence" and "Wings" over 24 frames of tick / play / step / draw
+(oracle/gen_fixtures.py:gen_scene -> tests/golden/scene_flow_turbulence_wings_64.npz).  The same script runs through
+tendrils_amd/scenes.py and through the Node host's js/scenes.js: the state object must follow the reference's double for
+double, the particle texture, the flow field and the view image within tests/test_scene_script.py:scene_close."""
 import json
 import os
+import shutil
+import subprocess
 
 import numpy as np
 import pytest
 
-from helpers import GOLDEN
+from helpers import GOLDEN, ROOT
+from test_scene_script import FX, META, TABLE, check_states, scene_close
 
 pytestmark = pytest.mark.gpu
 
 
-def test_two_presets_eased_over_a_short_run():
+def test_python_scene_against_the_reference_frames():
+    import copy
     import tendrils_amd as ta
-    from tendrils_amd.scenes import Scene, apply_preset, preset_targets
-    from tendrils_amd.spawn.ball import spawnBall
+    from tendrils_amd.scenes import Scene
     from tendrils_amd.tendrils import View
-    table = json.load(open(os.path.join(GOLDEN, "presets.json")))
-    assert len(table) >= 30 and "Flow" in table and "Wings" in table
-    t = ta.Tendrils(View(96, 54))
+    t = ta.Tendrils(View(*META["viewRes"]))
     t.resize()
-    t.setup(64)
-    apply_preset(t, table["Flow"])
-    assert t.state["colorMapAlpha"] == 0 and t.state["flowColor"][:3] == [1.0, 1.0, 1.0] and t.state["baseColor"][3] == 0
-    scene = Scene(t)
-    end = 24 * t.timer.step
-    scene.keyframe(table["Wings"], time=end, duration=0.75 * end, ease=[0, 0.95, 1])
-    seen = []
-    scene.run(24, each=lambda k, tn: seen.append((tn.state["flowDecay"], tn.state["baseColor"][3], tn.view_fragments)),
-              spawner=spawnBall(None, dict(uniforms=dict(radius=0.25, speed=0.01))))
-    view = t.read_view()
-    stats = t.particles.stats(t.state["speedLimit"])
+    t.setup(META["N"])
+    assert list(t.viewSize) == META["viewSize"]
+    scene = Scene(t).preset(TABLE[META["first"]])
+    for k in META["script"]:
+        scene.keyframe(TABLE[k["preset"]], k["time"], k["duration"], k["ease"])
+    t.particles.upload_texels(FX["state"])
+    t.timer.time = META["time0"]
+    hosts, states, flows, views = [], [], [], []
+
+    def each(k, tn):
+        assert tn.timer.time == META["times"][k]
+        hosts.append(copy.deepcopy(tn.state))
+        states.append(tn.particles.read(0))
+        if k in META["grab"]:
+            flows.append(tn.flow.read())
+            views.append(tn.read_view())
+    scene.run(META["frames"], each=each)
     t.dispose()
-    want = preset_targets(table["Wings"], t.state)
-    assert t.state["flowDecay"] == want["tendrils"]["flowDecay"] == 0          # the last frame lands on the keyframe
-    assert t.state["baseColor"] == want["baseColor"] and t.state["baseColor"][3] == 0.8
-    decay = [s[0] for s in seen]
-    assert decay[0] == 0.005 and all(a >= b for a, b in zip(decay, decay[1:])) and decay[-1] == 0      # eased, monotonic here
-    assert 0 < seen[10][1] < 0.8                                                # the colour track moves too
-    assert stats["live"] == 64 * 64 and seen[-1][2] > 0 and view.any()
+    check_states(hosts)
+    scene_close(states, flows, views)
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+def test_node_scene_against_the_reference_frames(tmp_path):
+    FX["state"].astype(np.float32).tofile(tmp_path / "state.bin")
+    spec = dict(kind="scene", N=META["N"], viewRes=META["viewRes"], inputs={"state": "state.bin"}, time0=META["time0"],
+                frames=META["frames"], grab=META["grab"], first=META["first"], script=META["script"], table=TABLE)
+    (tmp_path / "case.json").write_text(json.dumps(spec))
+    r = subprocess.run([shutil.which("node"), os.path.join(ROOT, "tests", "js", "run_case.js"), str(tmp_path / "case.json")],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    res = json.loads((tmp_path / "result.json").read_text())
+    assert res["times"] == META["times"]
+    check_states(res["states"])
+    n, (fw, fh) = META["N"], META["viewRes"]
+    states = [np.fromfile(tmp_path / ("state_%d.bin" % k), np.float32).reshape(n, n, 4) for k in range(META["frames"])]
+    flows = [np.fromfile(tmp_path / ("flow_%d.bin" % k), np.float32).reshape(fh, fw, 4) for k in META["grab"]]
+    views = [np.fromfile(tmp_path / ("view_%d.bin" % k), np.uint8).reshape(fh, fw, 4) for k in META["grab"]]
+    scene_close(states, flows, views)
+
+
+def test_replay_tool_runs(tmp_path):
+    """tools/replay_scene.py: the batch renderer over the preset table writes its frames."""
+    out = str(tmp_path / "scene")
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "replay_scene.py"), os.path.join(GOLDEN, "presets.json"), "Flow",
+                        "Turbulence", "Wings", "--frames", "24", "--every", "12", "--root", "64", "--view", "96x54", "--out", out],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(out + "_0012.ppm") == os.path.getsize(out + "_0024.ppm") == len(b"P6 96 54 255\n") + 96 * 54 * 3

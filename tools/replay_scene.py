@@ -10,7 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tendrils_amd as ta  # noqa: E402
-from tendrils_amd.scenes import Scene, apply_preset  # noqa: E402
+from tendrils_amd.scenes import Scene  # noqa: E402
 from tendrils_amd.spawn.ball import spawnBall  # noqa: E402
 from tendrils_amd.tendrils import View  # noqa: E402
 
@@ -29,8 +29,7 @@ w, h = (int(v) for v in args.view.split("x"))
 t = ta.Tendrils(View(w, h))
 t.resize()
 t.setup(args.root)
-apply_preset(t, table[args.presets[0]])
-scene = Scene(t)
+scene = Scene(t).preset(table[args.presets[0]])
 span = args.frames * t.timer.step / max(len(args.presets) - 1, 1)
 for k, name in enumerate(args.presets[1:], 1):
     scene.keyframe(table[name], time=k * span, duration=0.6 * span, ease=[0, 0.95, 1])
