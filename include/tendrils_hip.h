@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 11
+#define TH_ABI_VERSION 12
 
 typedef int32_t th_status;
 enum {
@@ -297,11 +297,18 @@ th_status th_sync(th_context *ctx);
  *  th_stats_global   : th_stats_async + th_stats_allreduce + download; synchronises */
 #define TH_COMM_ID_BYTES 128
 typedef struct th_comm_info {
-    int32_t active;          /* the context holds a communicator */
+    int32_t active;          /* the context holds a communicator: 1 = RCCL, 2 = in-process (th_comm_loopback_id); 0 = none */
     int32_t rank, world;
     int32_t rccl_version;    /* ncclGetVersion (0: librccl not loadable) */
 } th_comm_info;
 th_status th_comm_unique_id(void *id_out /* TH_COMM_ID_BYTES */);
+/* An id of an IN-PROCESS world instead: the ranks are contexts of one process (on one device or several), each driven by a
+ * host thread of its own, and the exchanges are device-to-device copies around a host-side rendezvous (th_loopback.hip).
+ * Everything above the byte transport - which fragments go to which owner, bands, owned ranges, the agreement on failures
+ * - is the code an RCCL job runs; this is how it is exercised with more ranks than a box has GPUs.  th_comm_init tells the
+ * two kinds of id apart by itself.  A collective that the other ranks do not join within TH_LOOPBACK_TIMEOUT_MS
+ * (default 120 000) fails instead of hanging. */
+th_status th_comm_loopback_id(void *id_out /* TH_COMM_ID_BYTES */);
 th_status th_comm_init(th_context *ctx, const void *id /* TH_COMM_ID_BYTES */, int32_t rank, int32_t world);
 th_status th_comm_destroy(th_context *ctx);
 th_status th_comm_query(th_context *ctx, th_comm_info *out);
@@ -400,6 +407,29 @@ typedef struct th_draw_info {
     uint64_t fragments, crowded_fragments;
 } th_draw_info;
 th_status th_draw_query(th_context *ctx, th_draw_info *out);
+
+/* Per-context switches between equivalent paths (build-defined; no switch changes a result - the parity suites rerun under
+ * each, tests/conftest.py).  A context starts from the environment variables of the same names, read by th_create
+ * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL,
+ * TH_FRAME_FUSE; TH_DRAW=stream|bins sets what TH_DRAW_AUTO means).
+ *   TH_OPT_BUCKET          tile-sorted slot order never (0) / always (1) / when it pays (-1, default)
+ *   TH_OPT_RESORT_STEPS    re-sort period of single-step launches (default 64)
+ *   TH_OPT_REBUCKET_STEPS  ... of fused th_step_n launches (default 256)
+ *   TH_OPT_FUSE            temporal fusion in th_step_n (default 1)
+ *   TH_OPT_GRAPH           captured hipGraphs in th_step_n where it does not fuse (default 1)
+ *   TH_OPT_FORCE_GENERIC   every step through the reference-order kernel (default 0)
+ *   TH_OPT_DRAW_REUSE      the stream-ordered view pass reuses the flow pass's rasterisation and sort (default 1)
+ *   TH_OPT_BINS_POOL       first size, in pages, of the binned pipeline's page pool (default 0: by the target's size)
+ *   TH_OPT_FRAME_FUSE      th_step immediately followed by th_draw / th_flow_deposit runs as one pass over the slots where
+ *                          both would run on tile-sorted slots (default 1)
+ *   TH_OPT_INJECT_FAILURE  (tests) the next th_draw_sharded of THIS context fails on its own at stage 1 (its edge rows; packed rings), 2
+ *                          (rasterising its lines) or 3 (making room for what it owns); the switch resets itself.  What is
+ *                          tested: every other rank of the job returns an error too instead of waiting in a collective */
+enum { TH_OPT_BUCKET = 0, TH_OPT_RESORT_STEPS = 1, TH_OPT_REBUCKET_STEPS = 2, TH_OPT_FUSE = 3, TH_OPT_GRAPH = 4,
+       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_FRAME_FUSE = 8,
+       TH_OPT_INJECT_FAILURE = 9 };
+th_status th_option_set(th_context *ctx, int32_t option, int64_t value);
+th_status th_option_get(th_context *ctx, int32_t option, int64_t *value);
 
 #ifdef __cplusplus
 }

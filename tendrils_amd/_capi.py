@@ -152,6 +152,7 @@ PROTOTYPES = {
     "th_stats": (C.c_int32, [_ctx, C.c_float, C.POINTER(Counters)]),
     "th_stats_async": (C.c_int32, [_ctx, C.c_float, C.POINTER(C.c_void_p)]),
     "th_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "th_comm_loopback_id": (C.c_int32, [C.c_void_p]),
     "th_comm_init": (C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32]),
     "th_comm_destroy": (C.c_int32, [_ctx]),
     "th_comm_query": (C.c_int32, [_ctx, C.POINTER(CommInfo)]),
@@ -168,6 +169,8 @@ PROTOTYPES = {
     "th_shapes": (C.c_int32, [_ctx, C.POINTER(ShapesInfo)]),
     "th_draw_pipeline": (C.c_int32, [_ctx, C.c_int32]),
     "th_draw_query": (C.c_int32, [_ctx, C.POINTER(DrawInfo)]),
+    "th_option_set": (C.c_int32, [_ctx, C.c_int32, C.c_int64]),
+    "th_option_get": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int64)]),
     "th_line_width": (C.c_int32, [_ctx, C.c_int32, C.c_float]),
     "th_line_width_range": (C.c_int32, [_ctx, C.c_float, C.c_float]),
     "th_line_width_query": (C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -1,0 +1,577 @@
+// th_draw.hip - Tendrils.draw() (src/index.js:278-337): the flow pass, the view pass, both in one call, the trail export;
+// which pipeline draws (binned over sorted slots, th_bins.hip / stream-ordered in texel order, th_deposit.hip + th_sort.hip).
+#include "th_ctx.hpp"
+
+using namespace thi;
+
+namespace thi {
+
+// ---- flow deposit ------------------------------------------------------------------------------------------
+int deposit_texel_bits(const th_context *c)
+{
+    const uint64_t texels = (uint64_t)c->fw * c->fh;
+    int bits = 1;
+    while (bits < 32 && (1ull << bits) < texels) ++bits;
+    return bits;
+}
+
+// ---- which pipeline draws -------------------------------------------------------------------------------------
+// The binned pipeline (th_bins.hip) walks the particles by slot, in whatever order the ring is held; the stream-ordered one
+// (th_deposit.hip) needs texel order.  th_draw_pipeline (or TH_DRAW=bins / stream at th_create) forces one; by default the binned pipeline draws
+// whenever the integrator would step over tile-sorted slots (sorting_possible): a step() + draw() frame loop then never
+// leaves the sorted order.
+// Which pipeline a draw pass takes.  auto: wherever the integrator steps over tile-sorted slots the frame loop - step(); draw() -
+// stays on them: the binned pipeline takes particles in any order.  It is ahead while the target is not crowded (first ~60
+// frames at C3: 1.7 against 2.3 ms per draw with both passes) and level with the stream-ordered pipeline once the wake has made
+// the particles converge (70-76 % of all fragments in bins of more than 4096, in texels with hundreds and thousands of them:
+// 2.0-2.7 ms either way; profiles/r3_b_fused_pass_experiments.txt) - restoring GL's order per texel then means sorting most
+// fragments by stream index, an order the stream-ordered pipeline gets for free from walking particles in texel order.  Beyond
+// that, auto hands over: when more than kCrowdedShare of a binned pass's fragments fell into large bins three passes in a row,
+// the next kStreamSpell passes (doubling, up to 4096, while it stays so) go to the stream-ordered pipeline, then the binned one
+// is tried again.
+constexpr double kCrowdedShare = 0.8;
+constexpr int kStreamSpell = 256;
+
+float drawn_line_width(const th_context *c, int pass)
+{
+    const float w = c->line_width[pass];
+    return w < c->line_range[0] ? c->line_range[0] : (w > c->line_range[1] ? c->line_range[1] : w);
+}
+
+static bool draw_uses_bins(th_context *c)
+{
+    const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : c->opt.draw;
+    if (policy == 0) return false;
+    if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
+    if (policy == 1) return true;
+    if (c->draws < c->stream_until) return false;
+    // (lines wider than 2 cover more texels than a line's record holds: nearly all of them would leave the fused pass
+    // for the long list, one atomic per fragment - the stream-ordered pipeline counts and scans instead)
+    if (drawn_line_width(c, TH_PASS_FLOW) > 2.0f || drawn_line_width(c, TH_PASS_VIEW) > 2.0f) return false;
+    return sorting_possible(c);
+}
+
+// per-line buffers + parameters.  want_bins: the caller can run the binned pipeline (*bins tells whether it will)
+th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, bool want_bins, bool *bins)
+{
+    TH_REQUIRE(u, "null uniforms");
+    TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
+    if (want_bins) ++c->draws;
+    bool use_bins = want_bins && draw_uses_bins(c);
+    if (use_bins) {
+        // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
+        // another particle (line_rows) keep to the stream-ordered pipeline in texel order
+        if (th_status s = line_rows(c)) return s;
+        if (c->lines_local != 1) use_bins = false;
+        else if (any_sorted(c)) { if (th_status s = align_slot_orders(c)) return s; }
+    }
+    if (bins) *bins = use_bins;
+    if (use_bins) c->last_binned_draw = c->total_steps;
+    else {
+        if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
+        c->hold_texel_order_until = c->total_steps + c->opt.rebucket_steps;   // a frame loop of step + draw stays in texel order
+    }
+    const size_t lines = c->texels();
+    TH_REQUIRE((size_t)c->fw * c->fh > 0 && (uint64_t)c->cfg.width * c->cfg.global_height < (1ull << 32), "bad shapes");
+    if (c->dep_lines != lines) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_record);
+        (void)hipFree(c->dep_lists);
+        c->dep_count = c->dep_offset = c->dep_blocks = c->dep_lists = nullptr; c->dep_record = nullptr;
+        TH_HIP(hipMalloc((void **)&c->dep_count, lines * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_offset, lines * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_record, 2 * lines * sizeof(uint4)));
+        TH_HIP(hipMalloc((void **)&c->dep_lists, th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &c->dep_list_cap) * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height) * sizeof(uint32_t)));
+        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 8 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag, [2] largest bin, [3] large bins, [4] their blocks
+        c->dep_lines = lines;
+    }
+    p = th::DepositParams{};
+    {   // a packed ring is read through f32 views (what the stored texels decode to)
+        float4 *cur = nullptr, *prev = nullptr;
+        if (th_status s = unpacked_view(c, c->ring[0], 0, &cur)) return s;
+        if (th_status s = unpacked_view(c, c->ring[1], 1, &prev)) return s;
+        p.cur = cur; p.prev = prev;
+    }
+    p.flow = c->flow;
+    p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.global_height;
+    p.row0 = (uint32_t)c->cfg.row0; p.rows = (uint32_t)c->cfg.height;
+    p.fw = c->fw; p.fh = c->fh;
+    p.view_x = u->viewSize[0]; p.view_y = u->viewSize[1]; p.time = u->time; p.speed_limit = u->speedLimit;
+    p.line_half = 0.5f * drawn_line_width(c, TH_PASS_FLOW);       // (view_params: the view pass's)
+    {
+        const int lw = c->cfg.width > 2 ? c->cfg.width : 2, lh = 2 * c->cfg.global_height > 2 ? 2 * c->cfg.global_height : 2;
+        p.inv_x = 1.0 / (double)(lw - 1); p.inv_y = 1.0 / (double)(lh - 1);
+    }
+    p.count = c->dep_count; p.offset = c->dep_offset; p.record = c->dep_record; p.oob = c->dep_total + 1;
+    p.list_n = c->dep_lists; p.list_cap = c->dep_list_cap;
+    {
+        uint32_t cap = 0;
+        p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
+    }
+    p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, 8 * sizeof(uint32_t), c->stream));
+    if (th_status s = line_rows(c)) return s;
+    p.row_draws = c->d_row_draws;
+    if (use_bins) {
+        const int o = order_of(c, c->ring[0]);
+        p.perm = o >= 0 ? c->orders[(size_t)o].perm : nullptr;
+        p.bins_x = ((uint32_t)c->fw + (1u << th::kBinShift) - 1u) >> th::kBinShift;
+        p.nbins = p.bins_x * (((uint32_t)c->fh + (1u << th::kBinShift) - 1u) >> th::kBinShift);
+        if (c->bin_capacity < p.nbins) {
+            TH_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->bin_mem); c->bin_mem = nullptr; c->bin_capacity = 0;
+            (void)hipFree(c->chunk_table); c->chunk_table = nullptr;
+            const size_t stride = ((size_t)p.nbins + 255) / 256 * 256 + 64;      // (the lists' cursors of one bin on different memory channels)
+            TH_HIP(hipMalloc((void **)&c->bin_mem, (th::kBinReplicas * stride + 2 * (size_t)p.nbins + 2) * sizeof(uint32_t)));
+            const size_t table = (size_t)p.nbins * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t);
+            TH_HIP(hipMalloc((void **)&c->chunk_table, table));
+            TH_HIP(hipMemsetAsync(c->chunk_table, 0, table, c->stream));        // (every reader of a list leaves its entries empty)
+            c->bin_capacity = p.nbins;
+        }
+        p.bin_stride = (uint32_t)(((size_t)c->bin_capacity + 255) / 256 * 256 + 64);
+        p.bin_cursor = c->bin_mem; p.large_bins = c->bin_mem + (size_t)th::kBinReplicas * p.bin_stride;
+        p.large_key0 = p.large_bins + c->bin_capacity;
+        p.page_table = c->chunk_table;
+        p.totals = c->dep_total;
+    }
+    return TH_OK;
+}
+
+// scan of p.count (filled by the caller's marking pass) -> p.offset, total (one sync); reports band violations
+th_status deposit_scan_total(th_context *c, const th::DepositParams &p, uint32_t *total)
+{
+    th::launch_deposit_scan(p, c->dep_blocks, c->dep_total, c->stream);
+    uint32_t host[2] = {0, 0};
+    if (th_status s = read_back(c, host, c->dep_total, sizeof host)) return s;
+    if (host[1]) return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d) and no halo row was supplied (th_deposit_set_halo)", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
+    if (host[0] >= (1u << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one draw (2^31 or more)");
+    *total = host[0];
+    return TH_OK;
+}
+
+// counts this context's fragments
+th_status deposit_count(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, uint32_t *total)
+{
+    if (th_status s = deposit_prepare(c, u, p)) return s;
+    th::launch_deposit_count(p, c->stream);
+    return deposit_scan_total(c, p, total);
+}
+
+// per-fragment buffers for `total` fragments (grow-only)
+th_status deposit_reserve(th_context *c, uint32_t total, bool wide, bool pairs)
+{
+    if (pairs && !c->dep_pairs) {                 // two varyings per fragment: the colour buffers at twice the size
+        (void)hipFree(c->dep_colors); c->dep_colors = nullptr;
+        (void)hipFree(c->dep_colors_sorted); c->dep_colors_sorted = nullptr;
+        if (c->dep_capacity) TH_HIP(hipMalloc((void **)&c->dep_colors, 2 * c->dep_capacity * sizeof(float4)));
+        c->dep_pairs = true;
+    }
+    if (c->dep_capacity < total) {
+        for (uint32_t *&q : c->dep_u32) { (void)hipFree(q); q = nullptr; }
+        for (unsigned long long *&q : c->dep_u64) { (void)hipFree(q); q = nullptr; }
+        (void)hipFree(c->dep_colors); c->dep_colors = nullptr;
+        (void)hipFree(c->dep_colors_sorted); c->dep_colors_sorted = nullptr;
+        c->dep_capacity = 0; c->dep_wide = false;
+        const size_t cap = (size_t)total + (size_t)total / 4 + 1024;
+        for (uint32_t *&q : c->dep_u32) TH_HIP(hipMalloc((void **)&q, cap * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->dep_colors, (c->dep_pairs ? 2 : 1) * cap * sizeof(float4)));
+        c->dep_capacity = cap;
+    }
+    if (!c->dep_colors_sorted) TH_HIP(hipMalloc((void **)&c->dep_colors_sorted, (c->dep_pairs ? 2 : 1) * c->dep_capacity * sizeof(float4)));
+    if (wide && !c->dep_wide) {
+        for (unsigned long long *&q : c->dep_u64) TH_HIP(hipMalloc((void **)&q, c->dep_capacity * sizeof(unsigned long long)));
+        c->dep_wide = true;
+    }
+    return TH_OK;
+}
+
+th_status deposit_temp(th_context *c, size_t need)
+{
+    if (c->dep_temp_bytes < need) {
+        (void)hipFree(c->dep_temp); c->dep_temp = nullptr; c->dep_temp_bytes = 0;
+        TH_HIP(hipMalloc(&c->dep_temp, need + need / 4));
+        c->dep_temp_bytes = need + need / 4;
+    }
+    return TH_OK;
+}
+
+// ---- view pass ---------------------------------------------------------------------------------------------
+th_status view_storage(th_context *c)
+{
+    if (c->view && c->view_w == c->fw && c->view_h == c->fh) return TH_OK;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->view);
+    c->view = nullptr; c->view_w = c->view_h = 0;
+    TH_HIP(hipMalloc((void **)&c->view, (size_t)c->fw * c->fh * sizeof(uchar4)));
+    TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->fw * c->fh * sizeof(uchar4), c->stream));     // a fresh drawing buffer is transparent black
+    c->view_w = c->fw; c->view_h = c->fh;
+    return TH_OK;
+}
+
+void view_fields(th_context *c, const th_render_uniforms *u, th::DepositParams &p)
+{
+    p.flow_decay = u->flowDecay; p.speed_alpha = u->speedAlpha; p.colormap_alpha = u->colorMapAlpha; p.sin_term = u->sinTerm;
+    for (int k = 0; k < 4; ++k) { p.base_color[k] = u->baseColor[k]; p.flow_color[k] = u->flowColor[k]; }
+    p.colormap = c->colormap; p.cw = c->cmap_w; p.ch = c->cmap_h;
+}
+
+th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositParams &p, bool want_bins, bool *bins)
+{
+    TH_REQUIRE(u, "null uniforms");
+    th_deposit_uniforms d{};
+    d.viewSize[0] = u->viewSize[0]; d.viewSize[1] = u->viewSize[1]; d.time = u->time; d.speedLimit = u->speedLimit;
+    if (th_status s = deposit_prepare(c, &d, p, want_bins, bins)) return s;
+    p.mode = 1;
+    p.line_half = 0.5f * drawn_line_width(c, TH_PASS_VIEW);
+    view_fields(c, u, p);
+    return TH_OK;
+}
+
+}  // namespace thi
+
+static th_status export_run(th_context *c, th::DepositParams &p, float *lines, uint64_t capacity, uint64_t *count)
+{
+    th::launch_export_mark(p, c->stream);
+    uint32_t total = 0;
+    if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    *count = total;
+    if (!lines || total == 0) return TH_OK;                  // size query
+    TH_REQUIRE(capacity >= total, "line buffer holds %llu of %u lines", (unsigned long long)capacity, total);
+    float *d_out = nullptr;
+    TH_HIP(hipMalloc((void **)&d_out, (size_t)total * 12 * sizeof(float)));
+    th::launch_export_write(p, d_out, c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(lines, d_out, (size_t)total * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    TH_HIP(e);
+    return TH_OK;
+}
+
+// the fragments of the (prepared) pass `p`: count, emit, sort by texel, blend
+static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *fragments)
+{
+    // Same state, same view, same resolution as the pass before (the view pass after the flow pass of one draw()): the
+    // lines cover the same texels in the same order - counts, offsets, records and the sorted order of the fragments are
+    // still there, only the varyings differ.  (TH_DRAW_REUSE=0: every pass on its own.)
+    const bool reuse = c->opt.draw_reuse && p.mode != 2 && c->drawn.valid && !c->drawn.binned && c->drawn.view_x == p.view_x && c->drawn.view_y == p.view_y &&
+                       c->drawn.line_half == p.line_half;
+    uint32_t total = 0;
+    if (reuse) total = c->drawn.total;
+    else {
+        c->drawn.valid = false;
+        th::launch_deposit_count(p, c->stream);
+        if (th_status s = deposit_scan_total(c, p, &total)) return s;
+    }
+    if (fragments) *fragments = total;
+    c->last_draw.pipeline = TH_DRAW_STREAM; c->last_draw.fragments = total; c->last_draw.crowded_fragments = 0;
+    if (total == 0) return TH_OK;
+    if (!reuse) if (th_status s = deposit_reserve(c, total, false, p.mode == 2)) return s;
+    p.keys = c->dep_u32[0]; p.slots = c->dep_u32[1]; p.keys_sorted = c->dep_u32[2]; p.slots_sorted = c->dep_u32[3];
+    p.colors = c->dep_colors; p.colors_sorted = c->dep_colors_sorted;
+    if (reuse) {
+        p.keys = nullptr;                        // (the keys are where the sort left them: only the varyings are written)
+        if (c->drawn.sorted_in_a) { p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1]; }
+        th::launch_deposit_scatter(p, c->stream);
+    } else {
+        const int bits = th::deposit_key_bits(p);
+        if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 0, bits))) return s;
+        th::launch_deposit_scatter(p, c->stream);
+        const bool in_a = th::launch_radix_sort_u32(p.keys, p.slots, p.keys_sorted, p.slots_sorted, total, 0, bits, c->dep_temp, true, c->stream) == 0;
+        if (in_a) { p.keys_sorted = c->dep_u32[0]; p.slots_sorted = c->dep_u32[1]; }        // an even number of passes ends in the (a) buffers
+        c->drawn.valid = true; c->drawn.binned = false; c->drawn.view_x = p.view_x; c->drawn.view_y = p.view_y; c->drawn.line_half = p.line_half; c->drawn.total = total; c->drawn.sorted_in_a = in_a;
+    }
+    th::launch_deposit_blend(p, total, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+// the chunk store of the binned pipeline: nbins + pool chunks of keys (all empty) and varyings
+static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool pairs)
+{
+    if (c->bins_keys && c->bins_store_bins == nbins && c->bins_pool >= pool && (c->bins_pairs || !pairs)) return TH_OK;
+    TH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors);
+    c->bins_keys = nullptr; c->bins_colors = nullptr;
+    pool = pool > c->bins_pool ? pool : c->bins_pool;
+    pairs = true;           // (room for both varyings of a th_draw from the start: growing the store later costs a frame)
+    c->bins_pool = 0; c->bins_store_bins = 0;
+    const size_t places = ((size_t)nbins * th::kBinReplicas + pool) * th::kBinPage;
+    TH_REQUIRE(places < ((size_t)1 << 32), "the binned draw's chunk store would hold 2^32 places or more");
+    TH_HIP(hipMalloc((void **)&c->bins_keys, places * sizeof(unsigned long long)));
+    TH_HIP(hipMalloc((void **)&c->bins_colors, places * (pairs ? 2 : 1) * sizeof(float4)));
+    TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, places * sizeof(unsigned long long), c->stream));
+    c->bins_pool = pool; c->bins_store_bins = nbins; c->bins_pairs = pairs;
+    return TH_OK;
+}
+
+constexpr double kEarlyBlendShare = 0.5;            // (of a draw's fragments in crowded bins: see deposit_run_bins)
+constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
+
+// the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + emit into the bins, plan, per-bin order + blend
+static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
+{
+    c->drawn.valid = false;
+    if (!c->side) {
+        TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
+        TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
+        TH_HIP(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+        TH_HIP(hipEventCreateWithFlags(&c->joined2, hipEventDisableTiming));
+        TH_HIP(hipEventCreateWithFlags(&c->regrouped, hipEventDisableTiming));
+        TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    uint32_t *host = c->bins_totals_host;
+    // Which comes first behind the emitting pass: the ordinary bins' blend - it needs nothing from the host and covers the
+    // read-back - or, on a crowded target, the crowded bins' kernels: their long runs (walked by one thread each, on the
+    // side stream) are then the longest chain of the draw and must start as early as they can.  Decided by the last draw.
+    const bool early = !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
+    for (int attempt = 0;; ++attempt) {
+        // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
+        const uint32_t pool0 = c->opt.bins_pool;
+        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 16u > 16384u ? p.nbins * 16u : 16384u));
+        if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
+        p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
+        if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
+        th::launch_bins_fused(p, c->stream);
+        // the totals come back over the side stream while the ordinary bins are already being blended (the kernel looks at the
+        // pass's flags itself): the host's round trip - it sizes the crowded bins' launches - costs the GPU nothing
+        TH_HIP(hipEventRecord(c->forked, c->stream));
+        if (early) th::launch_bins_blend(p, c->stream);
+        TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
+        TH_HIP(hipMemcpyAsync(host, c->dep_total, th::kTotWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
+        TH_HIP(hipStreamSynchronize(c->side));
+        const uint32_t flags = host[th::kTotFlags];
+        if (flags == 0) break;
+        // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
+        // outgrew its chunk table or a line its reservation, left to the stream-ordered pipeline
+        TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
+        TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t), c->stream));
+        if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) return kRetryInStreamOrder;
+        const uint32_t want = 2u * host[th::kTotPool] + 64;      // (generously: growing the store costs a frame's worth of time)
+        if (th_status s = bins_store(c, p.nbins, want, p.mode == 2)) return s;
+    }
+    const uint32_t total = host[th::kTotFragments], nlarge = host[th::kTotLarge];
+    if (fragments) *fragments = total;
+    c->last_draw.pipeline = TH_DRAW_BINS; c->last_draw.fragments = total; c->last_draw.crowded_fragments = host[th::kTotCrowdKeys];
+    {   // (auto policy: see draw_uses_bins)
+        const bool crowded = total > 0 && (double)host[th::kTotCrowdKeys] > kCrowdedShare * (double)total;
+        c->crowded_streak = crowded ? c->crowded_streak + 1 : 0;
+        if (!crowded) c->stream_spell = 0;
+        if (c->crowded_streak >= 3 || (crowded && c->stream_spell > 0)) {
+            c->stream_spell = c->stream_spell ? std::min(2 * c->stream_spell, 4096) : kStreamSpell;
+            c->stream_until = c->draws + c->stream_spell;
+            c->crowded_streak = 0;
+        }
+    }
+    if (host[th::kTotCrowdKeys] == 0xffffffffu) return fail(TH_ERR_UNSUPPORTED, "too many fragments in crowded bins for one draw (2^32 or more places)");
+    if (c->crowd_capacity < nlarge) {
+        (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
+        const uint32_t cap = 2u * nlarge + 256;
+        TH_HIP(hipMalloc((void **)&c->crowd_mem, (size_t)cap * th::crowd_words_per_bin() * sizeof(uint32_t)));
+        c->crowd_capacity = cap;
+    }
+    if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
+        (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); c->crowd_keys = nullptr; c->crowd_sorted = nullptr; c->crowd_keys_cap = 0;
+        const size_t cap = 2 * (size_t)host[th::kTotCrowdKeys] + ((size_t)1 << 20);
+        TH_HIP(hipMalloc((void **)&c->crowd_keys, cap * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->crowd_sorted, cap * sizeof(uint32_t)));
+        c->crowd_keys_cap = cap;
+    }
+    p.nlarge = nlarge;
+    p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
+    p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257; p.crowd_giant = p.crowd_long + (size_t)c->crowd_capacity * 256;
+    p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted;
+    if (nlarge) {
+        // The crowded bins on two streams of their own, beside the ordinary bins' blend (disjoint texels, kernels that wait on
+        // chains and loads rather than fill the chip): their fragments regrouped by texel, then the long runs on one stream -
+        // the walk of the longest run, one fragment after the other, overlaps with everything else instead of following it -
+        // and the short runs on the other.
+        TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan: the ordinary bins' blend need not be waited for)
+        th::launch_bins_regroup(p, c->side2);
+        TH_HIP(hipEventRecord(c->regrouped, c->side2));
+        TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
+        th::launch_bins_blend_long(p, c->side);
+        TH_HIP(hipEventRecord(c->joined, c->side));
+        th::launch_bins_blend_crowd(p, c->side2);
+        TH_HIP(hipEventRecord(c->joined2, c->side2));
+    }
+    if (!early) th::launch_bins_blend(p, c->stream);
+    if (nlarge) { TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0)); }
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+extern "C" {
+
+th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *lines, uint64_t capacity, uint64_t *count)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count, "null count");
+    th::DepositParams p;
+    if (th_status s = deposit_prepare(c, u, p)) return s;
+    return export_run(c, p, lines, capacity, count);
+}
+
+th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
+    for (int pass = 0;; ++pass) {            // (a binned pass that gives up before blending is repeated in stream order)
+        th::DepositParams p;
+        bool bins = false;
+        if (th_status s = deposit_prepare(c, u, p, pass == 0, &bins)) return s;
+        if (!bins) return deposit_run(c, p, fragments);
+        const th_status s = deposit_run_bins(c, p, fragments);
+        if (s != kRetryInStreamOrder) return s;
+    }
+}
+
+// Both passes of Tendrils.draw() (src/index.js:278-337) in one: the lines are rasterised, scanned, emitted and sorted once,
+// every fragment carries the flow pass's varying and the view pass's colour side by side, one gather brings both into
+// the sorted order and each target is blended from its half.  The two passes must agree on what they draw: the same
+// viewSize, time and speedLimit (what Tendrils.draw() hands to both); results are those of th_flow_deposit followed
+// by th_view_draw.
+th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(du && ru, "null uniforms");
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "draw on a row-band shard (%d of %d rows): the passes go through th_deposit_emit / th_deposit_merge and th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
+    TH_REQUIRE(memcmp(du->viewSize, ru->viewSize, sizeof du->viewSize) == 0 && memcmp(&du->time, &ru->time, sizeof du->time) == 0 &&
+               memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
+               "the two passes of one draw share viewSize, time and speedLimit");
+    if (drawn_line_width(c, TH_PASS_FLOW) != drawn_line_width(c, TH_PASS_VIEW)) {       // two widths: two rasterisations
+        if (th_status s = th_flow_deposit(c, du, fragments)) return s;
+        return th_view_draw(c, ru, nullptr);
+    }
+    if (th_status s = view_storage(c)) return s;
+    for (int pass = 0;; ++pass) {
+        th::DepositParams p;
+        bool bins = false;
+        if (th_status s = deposit_prepare(c, du, p, pass == 0, &bins)) return s;
+        p.mode = 2;
+        view_fields(c, ru, p);
+        p.view = c->view;
+        if (!bins) return deposit_run(c, p, fragments);
+        const th_status s = deposit_run_bins(c, p, fragments);
+        if (s != kRetryInStreamOrder) return s;
+    }
+}
+
+th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)
+{
+    if (th_status s = use(c, true)) return s;
+    if (c->cfg.height != c->cfg.global_height)
+        return fail(TH_ERR_UNSUPPORTED, "view pass on a row-band shard (%d of %d rows): use th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
+    if (th_status s = view_storage(c)) return s;
+    for (int pass = 0;; ++pass) {
+        th::DepositParams p;
+        bool bins = false;
+        if (th_status s = view_params(c, u, p, pass == 0, &bins)) return s;
+        p.view = c->view;
+        if (!bins) return deposit_run(c, p, fragments);
+        const th_status s = deposit_run_bins(c, p, fragments);
+        if (s != kRetryInStreamOrder) return s;
+    }
+}
+
+th_status th_view_fill(th_context *c, const float rgba[4])
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(rgba, "null colour");
+    if (th_status s = view_storage(c)) return s;
+    th::launch_view_fill(c->view, (size_t)c->view_w * c->view_h, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+th_status th_view_clear(th_context *c)
+{
+    if (th_status s = use(c, true)) return s;
+    if (th_status s = view_storage(c)) return s;
+    TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->view_w * c->view_h * sizeof(uchar4), c->stream));
+    return TH_OK;
+}
+
+th_status th_view_download(th_context *c, uint8_t *rgba8)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(rgba8, "null pixels");
+    if (th_status s = view_storage(c)) return s;
+    TH_HIP(hipMemcpyAsync(rgba8, c->view, (size_t)c->view_w * c->view_h * sizeof(uchar4), hipMemcpyDeviceToHost, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_colormap_upload(th_context *c, const float *rgba, int32_t w, int32_t h)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(rgba && w > 0 && h > 0 && (uint64_t)w * h < (1ull << 28), "bad colour map %dx%d", w, h);
+    if (w != c->cmap_w || h != c->cmap_h) {
+        TH_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->colormap);
+        c->colormap = nullptr; c->cmap_w = c->cmap_h = 0;
+        TH_HIP(hipMalloc((void **)&c->colormap, (size_t)w * h * sizeof(float4)));
+        c->cmap_w = w; c->cmap_h = h;
+    }
+    TH_HIP(hipMemcpyAsync(c->colormap, rgba, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    return TH_OK;
+}
+
+th_status th_export_view_lines(th_context *c, const th_render_uniforms *u, float *lines, uint64_t capacity, uint64_t *count)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(count, "null count");
+    th::DepositParams p;
+    if (th_status s = view_params(c, u, p)) return s;
+    return export_run(c, p, lines, capacity, count);
+}
+
+th_status th_draw_query(th_context *c, th_draw_info *out)
+{
+    TH_REQUIRE(c && out, "null argument");
+    *out = c->last_draw;
+    return TH_OK;
+}
+
+th_status th_line_width(th_context *c, int32_t pass, float width)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(pass == TH_PASS_FLOW || pass == TH_PASS_VIEW, "unknown pass %d", pass);
+    TH_REQUIRE(width > 0.0f, "line width %g (gl.lineWidth: INVALID_VALUE, the width stays %g)", (double)width, (double)c->line_width[pass]);
+    c->line_width[pass] = width;
+    return TH_OK;
+}
+
+th_status th_line_width_range(th_context *c, float lo, float hi)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(lo > 0.0f && lo <= 1.0f && hi >= 1.0f && hi <= th::kMaxLineWidth, "line width range [%g, %g]: need 0 < lo <= 1 <= hi <= %g",
+               (double)lo, (double)hi, (double)th::kMaxLineWidth);
+    c->line_range[0] = lo; c->line_range[1] = hi;
+    return TH_OK;
+}
+
+th_status th_line_width_query(th_context *c, int32_t pass, float *width, float *drawn, float *range)
+{
+    TH_REQUIRE(c, "null context");
+    TH_REQUIRE(pass == TH_PASS_FLOW || pass == TH_PASS_VIEW, "unknown pass %d", pass);
+    if (width) *width = c->line_width[pass];
+    if (drawn) *drawn = drawn_line_width(c, pass);
+    if (range) { range[0] = c->line_range[0]; range[1] = c->line_range[1]; }
+    return TH_OK;
+}
+
+th_status th_draw_pipeline(th_context *c, int32_t which)
+{
+    if (th_status s = use(c)) return s;
+    TH_REQUIRE(which == TH_DRAW_AUTO || which == TH_DRAW_STREAM || which == TH_DRAW_BINS, "unknown draw pipeline %d", which);
+    c->draw_pipeline = which;
+    return TH_OK;
+}
+
+}  // extern "C"

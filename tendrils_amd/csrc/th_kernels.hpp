@@ -1,6 +1,7 @@
 // th_kernels.hpp - launch parameter blocks shared by th_kernels.hip (device)
 // and th_api.hip (host).
 #pragma once
+#include <string>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -226,16 +227,34 @@ void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);        
 void launch_bins_blend_crowd(const DepositParams &p, hipStream_t stream);             // their other runs, a wave each: order by stream index, blend
 void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // the bins one workgroup orders: by (texel, stream index), blend (needs no host value)
 size_t crowd_words_per_bin();
-// RCCL side of a context (th_comm.hip; librccl bound at run time).  Every function returns 0 or leaves comm_error().
+// How a context's ranks exchange bytes.  th_shard.hip does the path's arithmetic - which fragments go to which owner, where
+// the bands and the owned texel ranges lie - and hands plain (pointer, count, offset) lists to one of two transports:
+//   rccl      one process per GPU, RCCL over xGMI (th_comm.hip; librccl bound at run time) - the product's;
+//   loopback  the ranks are contexts of ONE process, each driven by its own host thread, device-to-device copies and a
+//             host-side rendezvous (th_loopback.hip) - so that the exchange logic runs with more ranks than a box has GPUs.
+// Every function returns 0 or leaves comm_error().  All of them are collective: every rank of the communicator calls.
+struct Transport {
+    const char *name;
+    int (*destroy)(void *comm);
+    // th_counters in place: [0, 40) five u64 counts (sum), [40, 48) sum_speed (sum), [48, 56) max_speed (max)
+    int (*allreduce_counters)(void *comm, void *counters_dev, hipStream_t stream);
+    // every rank's bytes[r] bytes at `send` land at recv + offset[r] on every rank (parts may differ in size)
+    int (*allgather_bytes)(void *comm, const void *send, void *recv, const size_t *bytes, const size_t *offset, int rank, int world, hipStream_t stream);
+    // send_counts[r] elements of `elem` bytes from send + send_off[r] * elem to rank r, and likewise received
+    int (*alltoallv)(void *comm, const void *send, const size_t *send_counts, const size_t *send_off, void *recv, const size_t *recv_counts,
+                     const size_t *recv_off, size_t elem, int world, hipStream_t stream);
+    // a device word per rank -> the largest of them on every rank, in place
+    int (*allreduce_max_u32)(void *comm, uint32_t *word_dev, hipStream_t stream);
+};
 const char *comm_error();
+int comm_fail(const std::string &why);               // records comm_error(), returns 1
 int comm_available(int *version);
-int comm_unique_id(void *out, size_t bytes);
-int comm_init(void **comm, const void *id_bytes, size_t bytes, int rank, int world);
-int comm_destroy(void *comm);
-int comm_allreduce_counters(void *comm, void *counters_dev, hipStream_t stream);
-int comm_allgather_bytes(void *comm, const void *send, void *recv, const size_t *bytes, const size_t *offset, int rank, int world, hipStream_t stream);
-int comm_alltoallv(void *comm, const void *send, const size_t *send_counts, const size_t *send_off, void *recv, const size_t *recv_counts,
-                   const size_t *recv_off, size_t elem, int world, hipStream_t stream);
+int comm_unique_id(void *out, size_t bytes);         // rccl: ncclGetUniqueId
+int loopback_unique_id(void *out, size_t bytes);     // a fresh in-process world
+bool loopback_id(const void *id_bytes);
+// joins the communicator `id` names - an RCCL one or an in-process one - as `rank` of `world`
+int comm_init(void **comm, const Transport **transport, const void *id_bytes, size_t bytes, int rank, int world);
+int loopback_init(void **comm, const Transport **transport, const void *id_bytes, size_t bytes, int rank, int world);
 // stable LSD radix sort of (key, u32 value) pairs by key bits [begin_bit, end_bit) (th_sort.hip): the passes ping-pong
 // between the (a) and (b) buffers; returns 0 when the result is in (a), 1 when it is in (b)
 constexpr uint32_t kRadixBits = 8;

@@ -563,6 +563,17 @@ napi_value CommUniqueId(napi_env env, napi_callback_info)
     return arr;
 }
 
+// commLoopbackId() -> Uint8Array(128): the id of an in-process world (th_comm_loopback_id)
+napi_value CommLoopbackId(napi_env env, napi_callback_info)
+{
+    napi_value buf, arr;
+    void *data = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, TH_COMM_ID_BYTES, &data, &buf));
+    TH_CALL("th_comm_loopback_id", th_comm_loopback_id(data));
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, TH_COMM_ID_BYTES, buf, 0, &arr));
+    return arr;
+}
+
 // commInit(ctx, id: Uint8Array(128), rank, world)  (collective: returns when every rank has joined)
 napi_value CommInit(napi_env env, napi_callback_info info)
 {
@@ -884,6 +895,25 @@ napi_value DrawPipeline(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// option(ctx, which[, value]) -> the switch's value (set first when `value` is given): th_option_set / th_option_get
+napi_value Option(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t which = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_option_get");
+    if (a.argc > 2) {
+        double value = a.f64(2);
+        if (!a.ok) BAD_ARGS("th_option_set");
+        TH_CALL("th_option_set", th_option_set(c, which, (int64_t)value));
+    }
+    int64_t out = 0;
+    TH_CALL("th_option_get", th_option_get(c, which, &out));
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)out, &v));
+    return v;
+}
+
 // drawQuery(ctx) -> {pipeline, fragments, crowdedFragments} of the last draw pass
 napi_value DrawQuery(napi_env env, napi_callback_info info)
 {
@@ -987,9 +1017,9 @@ napi_value Init(napi_env env, napi_value exports)
         {"depositSetOwners", DepositSetOwners}, {"depositSetHalo", DepositSetHalo}, {"depositEmit", DepositEmit},
         {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
-        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline}, {"drawQuery", DrawQuery},
+        {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline}, {"drawQuery", DrawQuery}, {"option", Option},
         {"lineWidth", LineWidth}, {"lineWidthRange", LineWidthRange}, {"lineWidthQuery", LineWidthQuery},
-        {"commUniqueId", CommUniqueId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
+        {"commUniqueId", CommUniqueId}, {"commLoopbackId", CommLoopbackId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
         {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"drawEmit", DrawEmit}, {"drawMerge", DrawMerge}, {"viewDevicePtr", ViewDevicePtr},
         {"stateGather", StateGather}, {"stateGatherPtr", StateGatherPtr}, {"drawSharded", DrawSharded},
@@ -1004,6 +1034,9 @@ napi_value Init(napi_env env, napi_value exports)
         {"MODE_EXACT", TH_MODE_EXACT}, {"MODE_FAST", TH_MODE_FAST}, {"STATE_F32", TH_STATE_F32}, {"STATE_F16", TH_STATE_F16},
         {"TARGET_RING", TH_TARGET_RING}, {"TARGET_TARGETS", TH_TARGET_TARGETS}, {"SOURCE_FLOW", TH_SOURCE_FLOW},
         {"SOURCE_IMAGE", TH_SOURCE_IMAGE}, {"DRAW_AUTO", TH_DRAW_AUTO}, {"DRAW_STREAM", TH_DRAW_STREAM}, {"DRAW_BINS", TH_DRAW_BINS},
+        {"OPT_BUCKET", TH_OPT_BUCKET}, {"OPT_RESORT_STEPS", TH_OPT_RESORT_STEPS}, {"OPT_REBUCKET_STEPS", TH_OPT_REBUCKET_STEPS},
+        {"OPT_FUSE", TH_OPT_FUSE}, {"OPT_GRAPH", TH_OPT_GRAPH}, {"OPT_FORCE_GENERIC", TH_OPT_FORCE_GENERIC},
+        {"OPT_DRAW_REUSE", TH_OPT_DRAW_REUSE}, {"OPT_BINS_POOL", TH_OPT_BINS_POOL}, {"OPT_FRAME_FUSE", TH_OPT_FRAME_FUSE},
     };
     for (auto &e : consts) {
         if (napi_create_int32(env, e.val, &v) != napi_ok) return nullptr;

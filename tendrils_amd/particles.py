@@ -191,6 +191,18 @@ class Particles:
         (texel order, stream-ordered stable sort) or "bins" (any slot order, per-bin ordering)."""
         call("th_draw_pipeline", self._ctx, {"auto": -1, "stream": 0, "bins": 1}[which])
 
+    OPTIONS = dict(bucket=0, resort_steps=1, rebucket_steps=2, fuse=3, graph=4, force_generic=5, draw_reuse=6, bins_pool=7,
+                   frame_fuse=8, inject_failure=9)
+
+    def option(self, name, value=None):
+        """A switch between equivalent paths of the library (th_option_set / _get; no switch changes a result): returns the
+        current value, sets `value` first if given."""
+        if value is not None:
+            call("th_option_set", self._ctx, self.OPTIONS[name], int(value))
+        out = C.c_int64(0)
+        call("th_option_get", self._ctx, self.OPTIONS[name], C.byref(out))
+        return out.value
+
     def deposit_flow(self, view_size, time, speed_limit):
         """The flow pass of Tendrils.draw(): (previous -> current) lines blended into the flow texture
         (src/index.js:295-303, src/particles.js:147-158).  Returns the number of fragments."""

@@ -55,6 +55,22 @@ def comm_id():
     return bytes(buf)
 
 
+def loopback_id():
+    """th_comm_loopback_id -> bytes: the id of an in-process world (contexts of ONE process, a host thread per rank) - the
+    exchange logic with more ranks than the box has GPUs; th_comm_init takes it like an RCCL id"""
+    from . import _capi
+    buf = (C.c_ubyte * _capi.COMM_ID_BYTES)()
+    _capi.call("th_comm_loopback_id", buf)
+    return bytes(buf)
+
+
+def comm_join(ctx, ident, rank, world):
+    """th_comm_init with an id the caller carries itself"""
+    from . import _capi
+    buf = (C.c_ubyte * _capi.COMM_ID_BYTES).from_buffer_copy(ident)
+    _capi.call("th_comm_init", ctx, buf, int(rank), int(world))
+
+
 def comm_init(ctx, dist):
     """Every rank, collectively: the context joins the job's RCCL communicator (th_comm_init), the id travelling from
     rank 0 through `dist`.  From then on the path's collective - the counter all-reduce - is the library's own

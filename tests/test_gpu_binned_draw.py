@@ -1,40 +1,14 @@
 """The binned draw() pipeline (th_bins.hip: particles walked in slot order, fragments bucketed by 16 x 16-texel bin of the
 target, ordered by (texel, stream index) inside each bin) must reproduce GL's primitive order exactly like the
-stream-ordered one: the draw suites rerun with it forced (in texel order, and over tile-sorted slots re-sorted every few
-steps), both pipelines side by side at BASELINE's C3 size, and crowded targets (bins and single texels of more fragments
+stream-ordered one: the draw suites run with it forced (in texel order, and over tile-sorted slots re-sorted every few
+steps: the "bins" / "bins-on-sorted" variants of tests/conftest.py), both pipelines side by side at BASELINE's C3 size, and crowded targets (bins and single texels of more fragments
 than LDS holds at once) against the CPU restatement."""
-import os
-import subprocess
-import sys
-
 import numpy as np
 import pytest
 
-from helpers import ROOT, bits_equal
+from helpers import bits_equal
 
 pytestmark = pytest.mark.gpu
-
-SUITES = ["test_gpu_deposit.py", "test_gpu_view.py", "test_gpu_fuzz.py", "test_gpu_scene.py"]
-
-
-def rerun(extra_env):
-    env = dict(os.environ, **extra_env)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x"] + [os.path.join(ROOT, "tests", s) for s in SUITES],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-
-
-def test_draw_suites_with_bins_forced():
-    if os.environ.get("TH_DRAW"):
-        pytest.skip("already inside a forced-pipeline run")
-    rerun({"TH_DRAW": "bins"})
-
-
-def test_draw_suites_with_bins_over_sorted_slots():
-    if os.environ.get("TH_DRAW"):
-        pytest.skip("already inside a forced-pipeline run")
-    rerun({"TH_DRAW": "bins", "TH_BUCKET": "1", "TH_RESORT_STEPS": "3", "TH_REBUCKET_STEPS": "2"})
-
 
 def make(n, view_res, pipeline):
     import tendrils_amd as ta
@@ -153,79 +127,77 @@ def test_crowded_targets_are_order_exact(oracle, n, spread, view):
             assert (view_px == first_view).all() and view_px.any()
 
 
-def test_pool_growth_and_overfull_bins_fall_back_exactly(oracle):
+def test_pool_growth_and_overfull_bins_fall_back_exactly(oracle, monkeypatch):
     """The binned pass hands pages out from a pool sized from experience: a pool that runs dry is grown and the pass repeated
     before anything is blended (TH_BINS_POOL=8 forces it), and a bin that outgrows its lists (more than half a million
     fragments in 16 x 16 texels) leaves the draw to the stream-ordered pipeline - both with the exact result."""
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests"); sys.path.insert(0, %r + "/oracle")
-import oracle as O
-import tendrils_amd as ta
-from tendrils_amd.tendrils import View
-from helpers import bits_equal
-def run(n, spread, view, seed):
-    rng = np.random.default_rng(seed)
-    prev = np.zeros((n, n, 4), np.float32)
-    prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2))
-    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
-    cur = prev.copy()
-    cur[..., :2] += rng.uniform(-.03, .03, (n, n, 2)).astype(np.float32)
-    base = np.zeros((view[1], view[0], 4), np.float32)
-    want, frags = O.flow_deposit(cur, prev, base, 2500.0, view_size=(1.0, view[0] / view[1]))
-    t = ta.Tendrils(View(*view)); t.resize(); t.setup(n)
-    t.particles.draw_pipeline("bins")
-    t.particles.upload_texels(cur, 0); t.particles.upload_texels(prev, 1)
-    t.flow.set_pixels(base); t.timer.time = 2500.0; t.renderView = False
-    t.draw()
-    assert t.fragments == frags, (t.fragments, frags)
-    assert bits_equal(t.flow.read(), want).all()
-    t.draw()                                  # (and again: the store is clean after a repeated / abandoned pass)
-    t.dispose()
-    return frags
-print(run(256, 0.2, (96, 54), 5))            # a few bins, hundreds of fragments per list, a pool of 8 pages: grown, pass repeated
-print(run(1536, 0.004, (64, 36), 6))         # 1.2 M drawable lines inside one bin: the bin outgrows its lists
-''' % (ROOT, ROOT, ROOT)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BINS_POOL="8"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    a, b = (int(v) for v in r.stdout.split()[-2:])
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    monkeypatch.setenv("TH_BINS_POOL", "8")              # (a context's switches start from the environment it is created in)
+
+    def run(n, spread, view, seed):
+        rng = np.random.default_rng(seed)
+        prev = np.zeros((n, n, 4), np.float32)
+        prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2))
+        prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+        cur = prev.copy()
+        cur[..., :2] += rng.uniform(-.03, .03, (n, n, 2)).astype(np.float32)
+        base = np.zeros((view[1], view[0], 4), np.float32)
+        want, frags = oracle.flow_deposit(cur, prev, base, 2500.0, view_size=(1.0, view[0] / view[1]))
+        t = ta.Tendrils(View(*view))
+        t.resize()
+        t.setup(n)
+        assert t.particles.option("bins_pool") == 8
+        t.particles.draw_pipeline("bins")
+        t.particles.upload_texels(cur, 0)
+        t.particles.upload_texels(prev, 1)
+        t.flow.set_pixels(base)
+        t.timer.time = 2500.0
+        t.renderView = False
+        t.draw()
+        assert t.fragments == frags, (t.fragments, frags)
+        assert bits_equal(t.flow.read(), want).all()
+        t.draw()                                  # (and again: the store is clean after a repeated / abandoned pass)
+        t.dispose()
+        return frags
+    a = run(256, 0.2, (96, 54), 5)               # a few bins, hundreds of fragments per list, a pool of 8 pages: grown, pass repeated
+    b = run(1536, 0.004, (64, 36), 6)            # 1.2 M drawable lines inside one bin: the bin outgrows its lists
     assert a > 20_000 and b > 600_000, (a, b)
 
 
 def test_auto_policy_leaves_a_crowded_target_to_the_stream_ordered_pipeline():
     """TH_DRAW_AUTO watches the share of a binned pass's fragments that fell into bins of more than 4096 (th_draw_query): three
     crowded passes in a row and the following passes go to the stream-ordered pipeline - with the same results as a context
-    that used it all along, bit for bit (TH_BUCKET=1: sorted slots, hence the binned pipeline, at this small size)."""
-    code = r'''
-import sys, ctypes as C, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
-import tendrils_amd as ta
-from tendrils_amd import _capi
-from tendrils_amd.tendrils import View
-from helpers import bits_equal
-n, view = 512, (96, 54)
-rng = np.random.default_rng(3)
-st = np.zeros((n, n, 4), np.float32)
-st[..., :2] = rng.uniform(-0.12, 0.12, (n, n, 2))            # everybody inside a few bins of the target (share ~1)
-st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
-outs = []
-for pipeline in ("auto", "stream"):
-    t = ta.Tendrils(View(*view)); t.resize(); t.setup(n)
-    t.particles.upload_texels(st)
-    t.particles.draw_pipeline(pipeline)
-    t.timer.time = 1000.0
-    t.state["noiseWeight"] = 0.0005
-    info, used, share = _capi.DrawInfo(), [], []
-    for _ in range(8):
-        t.timer.tick(); t.step(); t.draw()
-        _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
-        used.append(info.pipeline); share.append(info.crowded_fragments / max(info.fragments, 1))
-    outs.append((used, share, t.flow.read(), t.read_view(), t.particles.read(0)))
-    t.dispose()
-(a_used, a_share, *a), (s_used, s_share, *s) = outs
-print(a_used, [round(v, 2) for v in a_share], s_used)
-assert a_used[:3] == [1, 1, 1] and min(a_share[:3]) > 0.8 and a_used[3:] == [0] * 5 and s_used == [0] * 8
-assert bits_equal(a[0], s[0]).all() and (a[1] == s[1]).all() and a[1].any() and bits_equal(a[2], s[2]).all()
-''' % (ROOT, ROOT)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BUCKET="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    that used it all along, bit for bit (option bucket = 1: sorted slots, hence the binned pipeline, at this small size)."""
+    import ctypes as C
+    import tendrils_amd as ta
+    from tendrils_amd import _capi
+    from tendrils_amd.tendrils import View
+    n, view = 512, (96, 54)
+    rng = np.random.default_rng(3)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.12, 0.12, (n, n, 2))            # everybody inside a few bins of the target (share ~1)
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+    outs = []
+    for pipeline in ("auto", "stream"):
+        t = ta.Tendrils(View(*view))
+        t.resize()
+        t.setup(n)
+        t.particles.option("bucket", 1)
+        t.particles.upload_texels(st)
+        t.particles.draw_pipeline(pipeline)
+        t.timer.time = 1000.0
+        t.state["noiseWeight"] = 0.0005
+        info, used, share = _capi.DrawInfo(), [], []
+        for _ in range(8):
+            t.timer.tick()
+            t.step()
+            t.draw()
+            _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
+            used.append(info.pipeline)
+            share.append(info.crowded_fragments / max(info.fragments, 1))
+        outs.append((used, share, t.flow.read(), t.read_view(), t.particles.read(0)))
+        t.dispose()
+    (a_used, a_share, *a), (s_used, s_share, *s) = outs
+    assert a_used[:3] == [1, 1, 1] and min(a_share[:3]) > 0.8 and a_used[3:] == [0] * 5 and s_used == [0] * 8, (a_used, a_share)
+    assert bits_equal(a[0], s[0]).all() and (a[1] == s[1]).all() and a[1].any() and bits_equal(a[2], s[2]).all()

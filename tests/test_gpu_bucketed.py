@@ -1,7 +1,7 @@
-"""The XCD-affine bucketed slot layout must be invisible in the results: rerun the integrator
-parity tests in a child process with bucketing forced on (TH_BUCKET=1) and a 2-step re-sort
-period, so that sorting, re-sorting, the permuted launch and the un-permute on read-back are all
-exercised against the golden vectors and the oracle."""
+"""The tile-sorted slot layout must be invisible in the results.  The integrator, optical-flow, spawn, deposit and fuzz suites
+run once more with it forced on and a 2-step re-sort period (the "bucket" variant of tests/conftest.py): sorting,
+re-sorting, the permuted launch and the un-permute on read-back against the golden vectors and the oracle.  Here: the
+sizes at which the default policy sorts by itself."""
 import os
 import subprocess
 import sys
@@ -11,20 +11,6 @@ import pytest
 from helpers import ROOT
 
 pytestmark = pytest.mark.gpu
-
-
-def test_parity_suite_with_bucketing_forced():
-    if os.environ.get("TH_BUCKET") == "1":
-        pytest.skip("already inside the forced-bucketing run")
-    env = dict(os.environ, TH_BUCKET="1", TH_REBUCKET_STEPS="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x",
-                        os.path.join(ROOT, "tests", "test_gpu_logic_parity.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_optical_flow.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_spawn.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_deposit.py"),
-                        os.path.join(ROOT, "tests", "test_gpu_fuzz.py")],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 def test_auto_bucketing_at_c3_size_is_bit_identical(oracle):

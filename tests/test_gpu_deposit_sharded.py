@@ -184,40 +184,42 @@ def test_band_edge_lookup_needs_and_uses_halo_rows(oracle):
 
 def test_edge_rows_after_a_sorted_step_are_current():
     """sharding.edge_rows reads the band's first and last state rows through torch views of library memory: when the
-    step left the slots tile-sorted (TH_BUCKET=1 forces it), th_state_device_ptr first restores texel order on the
+    step left the slots tile-sorted (option bucket = 1 forces it), th_state_device_ptr first restores texel order on the
     context's own stream - the rows handed to the neighbours must be the restored ones, not a buffer still being written
-    (stream race).  Run in a child process: the layout switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    from helpers import ROOT
-    code = r"""
-import numpy as np, torch
-import tendrils_amd as ta
-from tendrils_amd import sharding
-from tendrils_amd.tendrils import View
-n, rows = 256, 64
-opts = ta.defaults(); opts.update(row0=64, rows=rows, globalHeight=n)
-t = ta.Tendrils(View(64, 36), opts); t.resize(); t.setup(n)
-rng = np.random.default_rng(3)
-st = np.empty((rows, n, 4), np.float32)
-st[..., :2] = rng.uniform(-1, 1, (rows, n, 2)); st[..., 2:] = rng.uniform(-.01, .01, (rows, n, 2))
-t.particles.upload_texels(st)
-fl = np.zeros((36, 64, 4), np.float32); fl[..., :2] = rng.uniform(-.01, .01, (36, 64, 2)); fl[..., 2] = 990.0
-t.flow.set_pixels(fl); t.timer.time = 1000.0
-for k in range(5):
-    t.timer.tick(); t.step()
-    info = ta._capi.SlotOrderInfo(); ta._capi.call("th_slot_order", t.particles._ctx, __import__("ctypes").byref(info))
-    assert info.sorted_buffers > 0, "the step was expected to leave sorted slots"
-    e = sharding.edge_rows(t).cpu().numpy()
-    cur, prev = t.particles.read(0), t.particles.read(1)
-    assert (e[0, 0] == cur[0]).all() and (e[1, 0] == cur[-1]).all() and (e[0, 1] == prev[0]).all() and (e[1, 1] == prev[-1]).all(), k
-t.dispose()
-print("ok")
-"""
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, TH_BUCKET="1", TH_RESORT_STEPS="2", PYTHONPATH=ROOT),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    (stream race)."""
+    import ctypes as C
+    pytest.importorskip("torch")
+    import tendrils_amd as ta
+    from tendrils_amd import sharding
+    from tendrils_amd.tendrils import View
+    n, rows = 256, 64
+    opts = ta.defaults()
+    opts.update(row0=64, rows=rows, globalHeight=n)
+    t = ta.Tendrils(View(64, 36), opts)
+    t.resize()
+    t.setup(n)
+    t.particles.option("bucket", 1)
+    t.particles.option("resort_steps", 2)
+    rng = np.random.default_rng(3)
+    st = np.empty((rows, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (rows, n, 2))
+    st[..., 2:] = rng.uniform(-.01, .01, (rows, n, 2))
+    t.particles.upload_texels(st)
+    fl = np.zeros((36, 64, 4), np.float32)
+    fl[..., :2] = rng.uniform(-.01, .01, (36, 64, 2))
+    fl[..., 2] = 990.0
+    t.flow.set_pixels(fl)
+    t.timer.time = 1000.0
+    for k in range(5):
+        t.timer.tick()
+        t.step()
+        info = ta._capi.SlotOrderInfo()
+        ta._capi.call("th_slot_order", t.particles._ctx, C.byref(info))
+        assert info.sorted_buffers > 0, "the step was expected to leave sorted slots"
+        e = sharding.edge_rows(t).cpu().numpy()
+        cur, prev = t.particles.read(0), t.particles.read(1)
+        assert (e[0, 0] == cur[0]).all() and (e[1, 0] == cur[-1]).all() and (e[0, 1] == prev[0]).all() and (e[1, 1] == prev[-1]).all(), k
+    t.dispose()
 
 
 @pytest.mark.parametrize("n,view,world", [(64, (96, 54), 2), (128, (48, 27), 3)])

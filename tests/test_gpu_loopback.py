@@ -1,0 +1,194 @@
+"""The sharded draw()'s exchange logic with MORE THAN ONE RANK on one GPU.  RCCL refuses two ranks on one device, so the
+ranks here are contexts of this process joined by the in-process transport (th_comm_loopback_id; th_loopback.hip), each
+driven by a thread of its own - everything above the byte transport is the code an RCCL job runs (th_shard.hip): the
+owners' bounds, the count exchange, the fragment all-to-all, the merge, the all-gather of owned texel ranges that are NOT
+all the same size (the path RCCL serves with grouped broadcasts), the edge-row exchange, the agreement on rank-local
+failures.  Every rank's flow texture and view buffer must equal the unsharded draw() bit for bit."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def inputs(n, view, seed, spread=0.9):
+    rng = np.random.default_rng(seed)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2)) * [1.0, view[1] / view[0]]
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.08, .08, (n, n, 2)).astype(np.float32)
+    cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    fw, fh = view
+    base = np.zeros((fh, fw, 4), np.float32)
+    base[..., :2] = rng.uniform(-.01, .01, (fh, fw, 2))
+    base[..., 2] = 2400.0
+    base[..., 3] = rng.uniform(0, 1, (fh, fw))
+    return cur, prev, base
+
+
+def make(n, view, cur, prev, base, band=None, fmt="f32"):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    opts = ta.defaults()
+    row0, rows = band if band else (0, n)
+    opts.update(row0=row0, rows=rows, globalHeight=n, stateFormat=ta._capi.TH_STATE_F16 if fmt == "f16" else ta._capi.TH_STATE_F32)
+    t = ta.Tendrils(View(*view), opts)
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(cur[row0:row0 + rows], 0)
+    t.particles.upload_texels(prev[row0:row0 + rows], 1)
+    t.flow.set_pixels(base)
+    t.timer.time = 2500.0
+    t.state["baseColor"] = [1, 0.7, 0.3, 0.2]
+    t.state["flowColor"] = [0.2, 1, 0.9, 0.1]
+    return t
+
+
+def in_threads(world, body):
+    """body(rank) on a thread per rank (a ctypes call releases the GIL: the ranks really meet inside the library)"""
+    out, err = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            out[r] = body(r)
+        except BaseException as e:          # noqa: BLE001 - handed to the main thread
+            err[r] = e
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not any(th.is_alive() for th in threads), "a rank is still waiting inside a collective"
+    return out, err
+
+
+def world_of(n, view, world, cur, prev, base, fmt="f32"):
+    from tendrils_amd import sharding
+    ident = sharding.loopback_id()
+    shards = [make(n, view, cur, prev, base, sharding.shard_rows(n, world, r), fmt) for r in range(world)]
+    _, err = in_threads(world, lambda r: sharding.comm_join(shards[r].particles._ctx, ident, r, world))
+    assert err == [None] * world, err
+    assert all(sharding.comm_query(t.particles._ctx)["world"] == world for t in shards)
+    return shards
+
+
+@pytest.mark.parametrize("n,view,world,fmt", [(64, (96, 54), 2, "f32"), (100, (50, 27), 3, "f32"), (128, (50, 27), 4, "f32"),
+                                              (100, (50, 27), 4, "f16"), (64, (96, 54), 2, "f16")])
+def test_draw_sharded_over_loopback_equals_unsharded(n, view, world, fmt):
+    """n = 100: bands of 34 / 33 / 33 rows, and a height whose vertex lookup lands one row beside a line's own - the edge
+    rows of the neighbours are needed (f16: through the f32 views of the packed ring).  50 x 27 texels over 3 or 4 owners:
+    the last owner's range is shorter than the others' (the unequal all-gather)."""
+    from tendrils_amd import sharding
+    cur, prev, base = inputs(n, view, 7 * n + world)
+    one = make(n, view, cur, prev, base, None, fmt)
+    if fmt == "f16":                               # what the packed texels decode to is what everybody draws
+        cur, prev = one.particles.read(0), one.particles.read(1)
+    one.draw()
+    want_flow, want_view, want_frags = one.flow.read(), one.read_view(), one.fragments
+    one.dispose()
+    assert want_frags > 1000 and want_view.any()
+    shards = world_of(n, view, world, cur, prev, base, fmt)
+    for frame in range(2):                         # (the second draw: grown buffers are reused, the agreement of the first call is not repeated)
+        frags, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+        assert err == [None] * world, err
+        if frame == 0:
+            assert sum(frags) == want_frags
+            for t in shards:
+                assert bits_equal(t.flow.read(), want_flow).all()
+                assert (t.read_view() == want_view).all()
+    for t in shards:
+        t.dispose()
+
+
+def test_gather_and_counters_over_loopback_with_unequal_bands():
+    """th_state_gather (bands of 34 / 33 / 33 rows: parts of different sizes) and the counter all-reduce"""
+    from tendrils_amd import _capi, sharding
+    n, view, world = 100, (50, 27), 3
+    cur, prev, base = inputs(n, view, 11)
+    one = make(n, view, cur, prev, base)
+    want = one.particles.stats(0.01)
+    one.dispose()
+    shards = world_of(n, view, world, cur, prev, base)
+
+    def body(r):
+        ctx = shards[r].particles._ctx
+        _capi.call("th_state_gather", ctx, 0)
+        p = C.c_void_p()
+        _capi.call("th_state_gather_ptr", ctx, 0, C.byref(p))            # (the same copy: its address)
+        g = _capi.Counters()
+        _capi.call("th_stats_global", ctx, C.c_float(0.01), C.byref(g))
+        return {k: getattr(g, k) for k, _ in _capi.Counters._fields_}
+    got, err = in_threads(world, body)
+    assert err == [None] * world, err
+    for g in got:
+        assert {k: v for k, v in g.items() if k != "sum_speed"} == {k: v for k, v in want.items() if k != "sum_speed"}
+        assert abs(g["sum_speed"] - want["sum_speed"]) <= 1e-9 * want["sum_speed"]        # (a sum of three partial sums)
+    assert got[0] == got[1] == got[2]
+    for t in shards:                                # every rank holds the whole texture
+        whole = sharding.device_view(_ptr(t), (n, n, 4), "<f4")
+        assert bits_equal(whole.cpu().numpy(), cur).all()
+        t.dispose()
+
+
+def _ptr(t):
+    from tendrils_amd import _capi
+    p = C.c_void_p()
+    _capi.call("th_state_gather_ptr", t.particles._ctx, 0, C.byref(p))
+    return p.value
+
+
+@pytest.mark.parametrize("stage,fmt", [(2, "f32"), (3, "f32"), (1, "f16")])
+def test_a_rank_local_failure_ends_the_draw_on_every_rank(stage, fmt):
+    """One rank fails on its own (TH_OPT_INJECT_FAILURE: while preparing its edge rows / rasterising / making room): it reports
+    its error, every other rank reports that a peer failed - nobody is left waiting in a collective, nothing is blended -
+    and the next draw of the same world works."""
+    import tendrils_amd as ta
+    from tendrils_amd import sharding
+    n, view, world, bad = 64, (96, 54), 3, 1
+    cur, prev, base = inputs(n, view, 5)
+    one = make(n, view, cur, prev, base, None, fmt)
+    if fmt == "f16":
+        cur, prev = one.particles.read(0), one.particles.read(1)
+    one.draw()
+    want_flow, want_view = one.flow.read(), one.read_view()
+    one.dispose()
+    shards = world_of(n, view, world, cur, prev, base, fmt)
+    _, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))      # (first call: fixed buffers agreed)
+    assert err == [None] * world, err
+    for t in shards:                                # back to the start
+        t.flow.set_pixels(base)
+        t.clearView()
+    shards[bad].particles.option("inject_failure", stage)
+    _, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+    assert all(isinstance(e, ta.TendrilsHipError) for e in err), err
+    assert "injected failure" in str(err[bad])
+    for r in range(world):
+        if r != bad:
+            assert "rank %d failed" % bad in str(err[r]), str(err[r])
+    for t in shards:
+        assert bits_equal(t.flow.read(), base).all() and not t.read_view().any()
+    assert shards[bad].particles.option("inject_failure") == 0
+    _, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+    assert err == [None] * world, err
+    for t in shards:
+        assert bits_equal(t.flow.read(), want_flow).all() and (t.read_view() == want_view).all()
+        t.dispose()
+
+
+def test_a_collective_nobody_else_joins_times_out(monkeypatch):
+    import tendrils_amd as ta
+    from tendrils_amd import _capi
+    monkeypatch.setenv("TH_LOOPBACK_TIMEOUT_MS", "300")
+    cur, prev, base = inputs(64, (96, 54), 2)
+    shards = world_of(64, (96, 54), 2, cur, prev, base)
+    with pytest.raises(ta.TendrilsHipError) as e:
+        _capi.call("th_stats_global", shards[0].particles._ctx, C.c_float(0.01), C.byref(_capi.Counters()))
+    assert "did not arrive" in str(e.value)
+    for t in shards:
+        t.dispose()

@@ -108,8 +108,7 @@ def test_view_crowded_texels_are_order_exact(oracle):
 def test_draw_in_one_call_equals_the_two_passes():
     """Tendrils.draw() with renderView runs both passes over one rasterisation, one sort and one gather (th_draw); the
     flow texture and the view buffer must be what th_flow_deposit followed by th_view_draw leave - which reuses the flow
-    pass's geometry - and what the two passes leave when each rasterises for itself (TH_DRAW_REUSE=0 is read once per
-    process: that third way is the golden-fixture test above, which predates both shortcuts)."""
+    pass's geometry - and what the two passes leave when each rasterises for itself (option draw_reuse = 0)."""
     import ctypes as C
     from tendrils_amd import _capi
     n, view = 128, (96, 54)
@@ -124,14 +123,16 @@ def test_draw_in_one_call_equals_the_two_passes():
     m = dict(viewRes=list(view), viewSize=[1.0, 96 / 54], render=dict(speedLimit=0.01, flowDecay=0.005, speedAlpha=0.5,
              colorMapAlpha=0.0, baseColor=[1, 0.7, 0.3, 0.2], flowColor=[0.2, 1, 0.9, 0.1]))
     out = []
-    for one_call in (True, False):
+    for how in ("one call", "two passes", "two passes, no reuse"):
         t = make(m, n)
         t.particles.upload_texels(cur, 0)
         t.particles.upload_texels(prev, 1)
         t.timer.time = 900.0
-        if one_call:
+        if how == "one call":
             t.draw()
         else:
+            if how.endswith("no reuse"):
+                t.particles.option("draw_reuse", 0)
             t.renderView = False
             t.draw()                                            # th_flow_deposit
             u, k = t.render_uniforms(), C.c_uint64(0)
@@ -139,8 +140,9 @@ def test_draw_in_one_call_equals_the_two_passes():
             assert k.value == t.fragments
         out.append((t.flow.read(), t.read_view(), t.fragments))
         t.dispose()
-    assert out[0][2] == out[1][2] > 10000
-    assert bits_equal(out[0][0], out[1][0]).all() and (out[0][1] == out[1][1]).all() and out[0][1].any()
+    assert out[0][2] == out[1][2] == out[2][2] > 10000
+    for other in out[1:]:
+        assert bits_equal(out[0][0], other[0]).all() and (out[0][1] == other[1]).all() and out[0][1].any()
 
 
 def test_draw_paths_agree_at_scale():
