@@ -70,7 +70,7 @@ th_status use(th_context *c, bool keeps_lines)
 {
     if (!c) return fail(TH_ERR_INVALID, "null context");
     TH_HIP(hipSetDevice(c->cfg.device));
-    if (!keeps_lines) c->drawn.valid = false;
+    if (!keeps_lines) { c->drawn.valid = false; c->fused_stats.valid = false; }
     return TH_OK;
 }
 
@@ -271,7 +271,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
     (void)hipFree(c->dep_colors); (void)hipFree(c->dep_temp);
     (void)hipFree(c->image); (void)hipFree(c->view); (void)hipFree(c->colormap);
-    (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
+    (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->fused_parts); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
     for (th_context::SlotOrder &o : c->orders) { (void)hipFree(o.perm); (void)hipFree(o.chunks); (void)hipFree(o.records); (void)hipFree(o.nchunks); }
@@ -498,6 +498,14 @@ th_status th_stats_async(th_context *c, float speed_limit, void **device_counter
     TH_REQUIRE(!c->ring.empty(), "no state buffers");
     float4 *view = nullptr;
     if (th_status s = unpacked_view(c, c->ring[0], 0, &view)) return s;
+    if (c->fused_stats.valid && c->fused_stats.buf == c->ring[0] && memcmp(&c->fused_stats.limit, &speed_limit, sizeof speed_limit) == 0) {
+        // the launch that wrote this state took its statistics on the way (th_step_n): only the fold is left
+        const uint32_t n = c->fused_stats.nparts;
+        th::launch_stats_fold(c->fused_parts, n, c->fused_parts + n, c->texels(), c->d_respawned, c->d_counters, c->stream);
+        TH_HIP(hipGetLastError());
+        if (device_counters) *device_counters = c->d_counters;
+        return TH_OK;
+    }
     th::launch_stats(view, c->texels(), speed_limit, c->partials, c->d_respawned, c->d_counters, c->stream);
     TH_HIP(hipGetLastError());
     if (device_counters) *device_counters = c->d_counters;

@@ -85,6 +85,11 @@ struct th_context {
     int32_t frw = 0, frh = 0;
     unsigned int *d_flag = nullptr;
     th::StatsPartial *partials = nullptr;
+    // the statistics a fused th_step_n launch took of the state it wrote (LogicParams::stats_part): valid while ring[0] is
+    // that buffer and nothing has written it (use() without keeps_lines drops them)
+    th::StatsPartial *fused_parts = nullptr;
+    uint32_t fused_parts_cap = 0;
+    struct { bool valid = false; const float4 *buf = nullptr; float limit = 0.0f; uint32_t nparts = 0; } fused_stats;
     th_counters *d_counters = nullptr;
     // th_draw_sharded: the neighbours' edge rows, the owners' counts, what this rank received
     float4 *x_halo = nullptr;            // [lo: cur row, prev row | hi: cur row, prev row], `width` texels each

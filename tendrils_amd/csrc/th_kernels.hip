@@ -616,7 +616,44 @@ void launch_logic(const LogicParams &p, int mode, bool noise, bool target, bool 
 // ---------------------------------------------------------------------------
 constexpr bool kFusedPermTable = true;      // hash stages through the LDS tables (snoise_corners_tab)
 
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
+// The statistics of th_stats (stats_kernel below: same classification, same arithmetic per particle) taken by the launch that
+// has the state in registers: a lane's share, then one StatsPartial per workgroup (plain store; folded in a fixed order by
+// launch_stats_fold) - instead of a pass that reads the whole state again (268 MB at C3).
+// Nothing of it lives in registers across integrate(), no LDS, no barrier: right after its stores a wave reduces its 64
+// particles' share and lane 0 stores it as the wave's own partial (a workgroup's tail - barrier, fold by one thread, store -
+// cost 3 % of a launch of 65 536 short workgroups).  `first`: the wave's first round overwrites, later rounds add.
+TH_D void stats_take(StatsPartial *slot, const float4 &v, float limit, bool first)
+{
+
+    const float cap = limit * (1.0f - 9.5367431640625e-07f);
+    const bool is_live = v.x != kInert || v.y != kInert;
+    const bool is_nan = (v.x != v.x) || (v.y != v.y) || (v.z != v.z) || (v.w != v.w);
+    const float sp = __builtin_sqrtf(v.z * v.z + v.w * v.w);
+    const bool fin = is_live && !is_nan && sp <= 3.4028234e38f;
+    StatsPartial t;
+    t.live = __builtin_popcountll(__ballot(is_live)); t.nan = __builtin_popcountll(__ballot(is_nan));
+    t.capped = __builtin_popcountll(__ballot(fin && sp >= cap));
+    double sum = fin ? (double)sp : 0.0;
+    float mx = fin ? sp : 0.0f;
+    // (through the LDS crossbar: this launch is bound by VALU issue, and the same reduction on the VALU's data-parallel
+    // path - row scans, row broadcasts - cost twice as much: profiles/r4_b_fused_statistics.txt)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o);
+        const float om = __shfl_xor(mx, o); mx = om > mx ? om : mx;
+    }
+    if (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(true))) {
+        t.sum_speed = sum; t.max_speed = (double)mx;
+        if (!first) {
+            const StatsPartial o = *slot;
+            t.live += o.live; t.nan += o.nan; t.capped += o.capped; t.sum_speed += o.sum_speed;
+            t.max_speed = o.max_speed > t.max_speed ? o.max_speed : t.max_speed;
+        }
+        *slot = t;
+    }
+}
+
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED, bool STATS>
 __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 {
     // one LDS block: [permA | permB | gradient table], the hash tables first so that their reads need no base offset
@@ -641,6 +678,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
     }
     float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t npid = idx;
+    [[maybe_unused]] bool first = true;
     if (idx < end) {
         nxt = load_stream(&p.in[idx]);
         if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx]);
@@ -658,7 +696,9 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
         }
         store_stream(&p.out_prev[idx], prev);
         store_stream(&p.out[idx], st);
+        if constexpr (STATS) { stats_take(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], st, p.u.speedLimit, first); first = false; }
     }
+    // (a wave that met no particle leaves the zeros launch_logic_fused's memset put in its partial)
 }
 
 // Packed ring (TH_STATE_F16): the same fusion on 8-B texels.  The storage quantisation is part of every step
@@ -738,7 +778,11 @@ static void launch_fused_p2(const LogicParams &p, bool pow2, bool packed, hipStr
     }
     const bool bucketed = p.perm != nullptr;
     const int grid = fused_grid(p.count, bucketed);
-#define TH_GO(P2, BK) hipLaunchKernelGGL((logic_fused_kernel<FAST, NOISE, TARGET, P2, BK>), dim3(grid), dim3(256), 0, s, p)
+#define TH_GO(P2, BK)                                                                                                         \
+    do {                                                                                                                      \
+        if (p.stats_part) hipLaunchKernelGGL((logic_fused_kernel<FAST, NOISE, TARGET, P2, BK, true>), dim3(grid), dim3(256), 0, s, p);   \
+        else hipLaunchKernelGGL((logic_fused_kernel<FAST, NOISE, TARGET, P2, BK, false>), dim3(grid), dim3(256), 0, s, p);               \
+    } while (0)
     if (pow2) { if (bucketed) TH_GO(true, true); else TH_GO(true, false); }
     else { if (bucketed) TH_GO(false, true); else TH_GO(false, false); }
 #undef TH_GO
@@ -1691,6 +1735,44 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *par
         }
         *out = c;
     }
+}
+
+// 256 partials -> 1, per workgroup (the first level of launch_stats_fold)
+__global__ __launch_bounds__(256) void stats_fold_parts_kernel(const StatsPartial *part, uint32_t nparts, StatsPartial *out)
+{
+    __shared__ StatsPartial sh[4];
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    StatsPartial a = k < nparts ? part[k] : StatsPartial{0, 0, 0, 0.0, 0.0};
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a.live += __shfl_xor(a.live, o); a.nan += __shfl_xor(a.nan, o); a.capped += __shfl_xor(a.capped, o);
+        a.sum_speed += __shfl_xor(a.sum_speed, o);
+        const double om = __shfl_xor(a.max_speed, o); a.max_speed = om > a.max_speed ? om : a.max_speed;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        StatsPartial t = sh[0];
+        for (int w = 1; w < 4; ++w) {
+            t.live += sh[w].live; t.nan += sh[w].nan; t.capped += sh[w].capped;
+            t.sum_speed += sh[w].sum_speed; t.max_speed = sh[w].max_speed > t.max_speed ? sh[w].max_speed : t.max_speed;
+        }
+        out[blockIdx.x] = t;
+    }
+}
+
+uint32_t fused_stats_parts(uint32_t count, bool sorted) { return 4u * (uint32_t)fused_grid(count, sorted); }       // one per wave
+
+void launch_stats_fold(const StatsPartial *parts, uint32_t nparts, StatsPartial *scratch, size_t n, const unsigned long long *respawned,
+                       th_counters *out, hipStream_t s)
+{
+    // (scratch holds ceil(nparts / 256) partials; a state of up to 2^31 texels leaves <= 2^23 + 8 partials: two levels, then the fold)
+    while (nparts > 4096u) {
+        const uint32_t blocks = (nparts + 255u) / 256u;
+        hipLaunchKernelGGL(stats_fold_parts_kernel, dim3(blocks), dim3(256), 0, s, parts, nparts, scratch);
+        parts = scratch; scratch += blocks; nparts = blocks;
+    }
+    hipLaunchKernelGGL(stats_fold_kernel, dim3(1), dim3(256), 0, s, parts, (int)nparts, n, respawned, out);
 }
 
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials,

@@ -65,6 +65,7 @@ struct LogicParams {
     // fused multi-step launches (logic_fused_kernel): nsteps consecutive steps per particle in one pass
     float4 *out_prev;        // receives state nsteps-1 (p.out receives state nsteps); may alias p.in
     uint32_t nsteps;
+    struct StatsPartial *stats_part;   // (optional) per workgroup: the statistics of state nsteps, taken while it is in registers
     float times[kMaxFusedSteps];   // `time` of each fused step
 };
 
@@ -195,6 +196,10 @@ void launch_fill(float4 *dst, float4 value, size_t n, hipStream_t stream);
 void launch_hash_tables(float4 *block, hipStream_t stream);      // the hash tables in front of the gradient table (th_kernels.hip)
 int hash_table_vectors();
 void launch_finite_check(const float4 *src, size_t n, unsigned int *flag, hipStream_t stream);
+// the fold of `nparts` per-workgroup partials a fused launch left (LogicParams::stats_part; fused_stats_parts() of them)
+void launch_stats_fold(const StatsPartial *parts, uint32_t nparts, StatsPartial *scratch, size_t n, const unsigned long long *respawned,
+                       th_counters *out, hipStream_t stream);
+uint32_t fused_stats_parts(uint32_t count, bool sorted);
 void launch_stats(const float4 *state, size_t n, float speed_limit, StatsPartial *partials, const unsigned long long *respawned,
                   th_counters *out, hipStream_t stream);
 void launch_counter_add(unsigned long long *counter, unsigned long long n, hipStream_t s);

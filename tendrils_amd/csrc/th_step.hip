@@ -352,6 +352,21 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 p.perm = order >= 0 ? c->orders[(size_t)order].perm : nullptr;
                 p.nsteps = (uint32_t)m;
                 for (int32_t k = 0; k < m; ++k) p.times[k] = times[(size_t)(done + k)];
+                // the last launch of the call takes the statistics of the state it leaves in buffers[0] (f32 ring: a packed
+                // ring's statistics are those of the stored texels, which th_stats decodes)
+                const bool takes_stats = !c->packed && done + m == n;
+                if (takes_stats) {
+                    const uint32_t parts = th::fused_stats_parts(p.count, p.perm != nullptr), need = parts + (parts + 255u) / 256u + 16u;
+                    if (c->fused_parts_cap < need) {
+                        TH_HIP(hipStreamSynchronize(c->stream));
+                        (void)hipFree(c->fused_parts); c->fused_parts = nullptr; c->fused_parts_cap = 0;
+                        TH_HIP(hipMalloc((void **)&c->fused_parts, (size_t)need * sizeof(th::StatsPartial)));
+                        c->fused_parts_cap = need;
+                    }
+                    p.stats_part = c->fused_parts;
+                    TH_HIP(hipMemsetAsync(c->fused_parts, 0, (size_t)parts * sizeof(th::StatsPartial), c->stream));     // (waves beyond the last slot store nothing)
+                    c->fused_stats.nparts = parts; c->fused_stats.limit = p.u.speedLimit;
+                }
                 hipEvent_t k0 = nullptr, k1 = nullptr;
                 if (c->kernel_timing) {
                     if (th_status s = timing_events(c, &k0, &k1)) return s;
@@ -365,6 +380,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 if (m & 1) { c->ring[0] = other; c->ring[1] = cur; }
                 c->steps_since_sort += m; c->total_steps += m;
                 done += m;
+                if (takes_stats) { c->fused_stats.valid = true; c->fused_stats.buf = c->ring[0]; }
             }
             return TH_OK;
         }

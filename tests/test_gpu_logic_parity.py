@@ -284,6 +284,39 @@ def test_step_n_graph_equals_single_steps(n, steps):
     assert bits_equal(outs[0][1], outs[1][1]).all()
 
 
+@pytest.mark.parametrize("n,steps", [(256, 7), (200, 40), (1024, 6)])
+def test_statistics_taken_by_the_fused_launch_equal_the_statistics_pass(n, steps):
+    """th_step_n's last fused launch takes the statistics of the state it leaves in buffers[0] while that state is in
+    registers; th_stats then only folds the per-workgroup partials.  They must be the statistics pass's: counts and the
+    maximum exactly, the sum of the speeds up to the order of its additions - with the launch's own speedLimit (the cached
+    partials), with another limit (the pass over the state), after one more host call (the cache is dropped: the pass
+    again), and again after the next fused launch."""
+    import ctypes as C
+    import tendrils_amd as ta
+    from tendrils_amd import _capi
+    st, fl = seeded_case(n, 77 + n)
+    t = make_tendrils(n, (96, 54), (96, 54), {"forceWeight": 0.2, "noiseWeight": 0.02}, ta.TH_MODE_EXACT)    # forces that drive many particles into the speed limit: `capped`
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.timer.time = 4000.0
+    limit = t.state["speedLimit"]
+    for _ in range(2):
+        t.step_n(steps)
+        fused = t.particles.stats(limit)                   # (the fused launch's partials, when the launch was a fused one)
+        other = t.particles.stats(limit * 0.5)             # another limit: the pass over the state
+        _capi.call("th_set_mode", t.particles._ctx, ta.TH_MODE_EXACT)      # any call that may write state drops the partials
+        again = t.particles.stats(limit)
+        got = t.particles.read(0)
+        speed = np.sqrt(got[..., 2].astype(np.float32) ** 2 + got[..., 3].astype(np.float32) ** 2)
+        live = (got[..., 0] != np.float32(-1e6)) | (got[..., 1] != np.float32(-1e6))
+        assert fused["live"] == again["live"] == int(live.sum()) and fused["nan"] == again["nan"] == other["nan"]
+        assert 0 < fused["capped"] == again["capped"] < fused["live"] and other["capped"] > fused["capped"]
+        assert fused["max_speed"] == again["max_speed"] == float(speed[live].max())
+        assert abs(fused["sum_speed"] - again["sum_speed"]) <= 1e-12 * again["sum_speed"]
+        assert fused["particles"] == n * n
+    t.dispose()
+
+
 def test_c3_size_matches_reference_row_bands():
     """4096^2 on the GPU against the row bands captured from the reference's own 4096^2 run."""
     import os
