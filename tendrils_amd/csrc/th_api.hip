@@ -90,11 +90,13 @@ th_status resolve_target(th_context *c, int32_t target, bool rotate_ok, float4 *
         c->ring.pop_back();
         c->ring.insert(c->ring.begin(), last);
         *out = c->ring[0];
+        state_written(c, *out);
     } else if (target == TH_TARGET_TARGETS) {
         *out = c->targets;
         c->targets_checked = false;
     } else if (target >= 0 && target < (int32_t)c->ring.size()) {
         *out = c->ring[target];
+        state_written(c, *out);
     } else {
         return fail(TH_ERR_INVALID, "bad render target %d (ring has %zu buffers)", target, c->ring.size());
     }
@@ -335,6 +337,7 @@ th_status th_upload_state(th_context *c, int32_t buffer, const float *rgba, int3
         TH_HIP(hipMemcpy2DAsync(dst, (size_t)c->cfg.width * sizeof(float4), rgba, (size_t)w * sizeof(float4),
                                 (size_t)w * sizeof(float4), h, hipMemcpyHostToDevice, c->stream));
         if (th_status s = commit_target(c, c->ring[b], view)) return s;
+        state_written(c, c->ring[b]);
     }
     TH_HIP(hipStreamSynchronize(c->stream));   // the caller may reuse `rgba` immediately (setPixels semantics)
     return TH_OK;
@@ -543,6 +546,7 @@ th_status th_state_device_ptr(th_context *c, int32_t buffer, void **dptr)
     if (moved) TH_HIP(hipStreamSynchronize(c->stream));
     TH_REQUIRE(buffer >= 0 && buffer < (int32_t)c->ring.size(), "bad buffer index %d", buffer);
     *dptr = c->ring[buffer];
+    state_written(c, c->ring[buffer]);        // (whoever holds the address may write through it)
     // (use() above dropped the geometry a view pass would reuse from the last flow pass: whoever holds this address may write
     // the state behind the library's back - after such a write, call any state entry point, or th_sync, before th_view_draw)
     return TH_OK;

@@ -140,7 +140,9 @@ struct th_context {
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
     th_draw_info last_draw{};            // th_draw_query
     // auto policy: the binned pipeline while the target is not crowded (th_api.hip: draw_uses_bins)
-    long long draws = 0, stream_until = 0;
+    long long draws = 0, stream_until = 0;        // (`draws` counts frames: the passes drawn at one total_steps share a count ...
+    long long draw_frame_step = -1;               //  ... and a pipeline)
+    int frame_bins = -1;
     int crowded_streak = 0, stream_spell = 0;
     long long last_binned_draw = -(1ll << 40);   // total_steps at the last draw over slot order
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
@@ -212,6 +214,10 @@ th_status render_target(th_context *c, float4 *buf, int k, float4 **out);
 th_status commit_target(th_context *c, float4 *buf, float4 *rendered);
 constexpr size_t kPinnedBytes = 1024;
 th_status read_back(th_context *c, void *host, const void *dev, size_t bytes);
+// the gathered whole-texture copy (th_state_gather / _ptr) is a copy of one ring buffer's CONTENT: writing that buffer ends
+// its validity, moving the content to another allocation (slot-order moves through `spare`) takes the association along
+inline void state_written(th_context *c, const float4 *buf) { if (c->gathered_of == (const void *)buf) c->gathered_of = nullptr; }
+inline void state_moved(th_context *c, const float4 *from, const float4 *to) { if (c->gathered_of == (const void *)from) c->gathered_of = to; }
 
 // ---- th_order.hip ----------------------------------------------------------------------------------------------------
 void destroy_graph(GraphEntry &g);

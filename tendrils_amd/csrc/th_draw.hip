@@ -56,8 +56,10 @@ th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::Depos
 {
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
-    if (want_bins) ++c->draws;
-    bool use_bins = want_bins && draw_uses_bins(c);
+    // The auto policy counts FRAMES, and the passes of one frame - th_flow_deposit then th_view_draw, or two widths - take one
+    // pipeline: a view pass that left the slot order its flow pass had drawn over would throw the order away in mid-frame.
+    if (want_bins && c->draw_frame_step != c->total_steps) { ++c->draws; c->draw_frame_step = c->total_steps; c->frame_bins = -1; }
+    bool use_bins = want_bins && (c->frame_bins >= 0 && c->draw_pipeline == TH_DRAW_AUTO ? c->frame_bins == 1 : draw_uses_bins(c));
     if (use_bins) {
         // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
         // another particle (line_rows) keep to the stream-ordered pipeline in texel order
@@ -66,6 +68,7 @@ th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::Depos
         else if (any_sorted(c)) { if (th_status s = align_slot_orders(c)) return s; }
     }
     if (bins) *bins = use_bins;
+    if (want_bins) c->frame_bins = use_bins ? 1 : 0;
     if (use_bins) c->last_binned_draw = c->total_steps;
     else {
         if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
@@ -288,6 +291,12 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
 }
 
 // the chunk store of the binned pipeline: nbins + pool chunks of keys (all empty) and varyings
+constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
+
+// The varyings are sized by the pass that needs them (one float4 per place; two once a th_draw has run) and the pool starts
+// at a quarter of the bins' first pages: the growth path is there (deposit_run_bins repeats a pass whose pool ran dry), and
+// at 1920 x 1080 the store is 0.9 GB for a flow-only host, 1.4 GB with both passes - not 2.7 GB up front.  A store that
+// cannot be allocated (a small device, many contexts) leaves the draw to the stream-ordered pipeline.
 static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool pairs)
 {
     if (c->bins_keys && c->bins_store_bins == nbins && c->bins_pool >= pool && (c->bins_pairs || !pairs)) return TH_OK;
@@ -295,20 +304,22 @@ static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool p
     (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors);
     c->bins_keys = nullptr; c->bins_colors = nullptr;
     pool = pool > c->bins_pool ? pool : c->bins_pool;
-    pairs = true;           // (room for both varyings of a th_draw from the start: growing the store later costs a frame)
+    pairs = pairs || c->bins_pairs;
     c->bins_pool = 0; c->bins_store_bins = 0;
     const size_t places = ((size_t)nbins * th::kBinReplicas + pool) * th::kBinPage;
     TH_REQUIRE(places < ((size_t)1 << 32), "the binned draw's chunk store would hold 2^32 places or more");
-    TH_HIP(hipMalloc((void **)&c->bins_keys, places * sizeof(unsigned long long)));
-    TH_HIP(hipMalloc((void **)&c->bins_colors, places * (pairs ? 2 : 1) * sizeof(float4)));
+    if (hipMalloc((void **)&c->bins_keys, places * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&c->bins_colors, places * (pairs ? 2 : 1) * sizeof(float4)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(c->bins_keys); c->bins_keys = nullptr; c->bins_colors = nullptr;
+        return kRetryInStreamOrder;
+    }
     TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, places * sizeof(unsigned long long), c->stream));
     c->bins_pool = pool; c->bins_store_bins = nbins; c->bins_pairs = pairs;
     return TH_OK;
 }
 
 constexpr double kEarlyBlendShare = 0.5;            // (of a draw's fragments in crowded bins: see deposit_run_bins)
-constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
-
 // the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + emit into the bins, plan, per-bin order + blend
 static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
 {
@@ -330,7 +341,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     for (int attempt = 0;; ++attempt) {
         // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
         const uint32_t pool0 = c->opt.bins_pool;
-        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 16u > 16384u ? p.nbins * 16u : 16384u));
+        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 4u > 4096u ? p.nbins * 4u : 4096u));
         if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
         p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
@@ -426,6 +437,7 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
         if (!bins) return deposit_run(c, p, fragments);
         const th_status s = deposit_run_bins(c, p, fragments);
         if (s != kRetryInStreamOrder) return s;
+        c->frame_bins = 0;                  // (the other passes of this frame as well)
     }
 }
 
@@ -458,6 +470,7 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
         if (!bins) return deposit_run(c, p, fragments);
         const th_status s = deposit_run_bins(c, p, fragments);
         if (s != kRetryInStreamOrder) return s;
+        c->frame_bins = 0;                  // (the other passes of this frame as well)
     }
 }
 
@@ -475,6 +488,7 @@ th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fra
         if (!bins) return deposit_run(c, p, fragments);
         const th_status s = deposit_run_bins(c, p, fragments);
         if (s != kRetryInStreamOrder) return s;
+        c->frame_bins = 0;                  // (the other passes of this frame as well)
     }
 }
 

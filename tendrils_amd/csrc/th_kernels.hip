@@ -624,7 +624,6 @@ constexpr bool kFusedPermTable = true;      // hash stages through the LDS table
 // cost 3 % of a launch of 65 536 short workgroups).  `first`: the wave's first round overwrites, later rounds add.
 TH_D void stats_take(StatsPartial *slot, const float4 &v, float limit, bool first)
 {
-
     const float cap = limit * (1.0f - 9.5367431640625e-07f);
     const bool is_live = v.x != kInert || v.y != kInert;
     const bool is_nan = (v.x != v.x) || (v.y != v.y) || (v.z != v.z) || (v.w != v.w);
@@ -704,7 +703,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 // Packed ring (TH_STATE_F16): the same fusion on 8-B texels.  The storage quantisation is part of every step
 // (a step reads what the previous one stored), so each intermediate state goes through pack -> unpack in
 // registers: bit-identical to nsteps logic_packed_kernel launches.
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED>
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED, bool STATS>
 __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicParams p)
 {
     __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
@@ -730,6 +729,7 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
     }
     v2u nxt = {0x80008000u, 0u};
     uint32_t npid = idx;
+    [[maybe_unused]] bool first = true;
     if (idx < end) {
         nxt = __builtin_nontemporal_load(&in[idx]);
         if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx]);
@@ -748,6 +748,8 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
         v2u a = {wprev.x, wprev.y}, b = {w.x, w.y};
         __builtin_nontemporal_store(a, &out_prev[idx]);
         __builtin_nontemporal_store(b, &out[idx]);
+        // (the statistics of a packed ring are those of what its texels decode to - what th_stats reads through its f32 view)
+        if constexpr (STATS) { stats_take(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], unpack_state(w), p.u.speedLimit, first); first = false; }
     }
 }
 
@@ -770,7 +772,11 @@ static void launch_fused_p2(const LogicParams &p, bool pow2, bool packed, hipStr
     if (packed) {
         const bool sorted = p.perm != nullptr;
         const int pgrid = fused_grid(p.count, sorted);
-#define TH_GO(P2, BK) hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, P2, BK>), dim3(pgrid), dim3(256), 0, s, p)
+#define TH_GO(P2, BK)                                                                                                                 \
+    do {                                                                                                                              \
+        if (p.stats_part) hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, P2, BK, true>), dim3(pgrid), dim3(256), 0, s, p);   \
+        else hipLaunchKernelGGL((logic_fused_packed_kernel<FAST, NOISE, TARGET, P2, BK, false>), dim3(pgrid), dim3(256), 0, s, p);               \
+    } while (0)
         if (pow2) { if (sorted) TH_GO(true, true); else TH_GO(true, false); }
         else { if (sorted) TH_GO(false, true); else TH_GO(false, false); }
 #undef TH_GO

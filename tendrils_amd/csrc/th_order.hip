@@ -149,6 +149,7 @@ th_status ensure_identity(th_context *c, bool *launched)
         if (o < 0) continue;
         th::launch_unpermute_state(c->spare, b, c->orders[(size_t)o].perm, (uint32_t)c->texels(), c->packed, c->stream);
         set_order(c, b, -1);
+        state_moved(c, b, c->spare);
         float4 *t = b; b = c->spare; c->spare = t;
         if (launched) *launched = true;
     }
@@ -199,10 +200,12 @@ th_status align_slot_orders(th_context *c)
     if (o1 >= 0) {
         th::launch_unpermute_state(c->spare, b, c->orders[(size_t)o1].perm, (uint32_t)c->texels(), c->packed, c->stream);
         set_order(c, b, -1);
+        state_moved(c, b, c->spare);
         float4 *t = b; b = c->spare; c->spare = t;
     }
     if (o0 >= 0) {
         th::launch_permute_state(c->spare, b, c->orders[(size_t)o0].perm, (uint32_t)c->texels(), c->packed, c->stream);
+        state_moved(c, b, c->spare);
         float4 *t = b; b = c->spare; c->spare = t;
         set_order(c, b, o0);
     }

@@ -416,6 +416,7 @@ th_status th_state_gather_ptr(th_context *c, int32_t buffer, void **dptr)
     if (th_status s = use(c, true)) return s;
     TH_REQUIRE(dptr, "null output");
     if (th_status s = gather_storage(c, buffer)) return s;
+    if (th_status s = ensure_identity(c)) return s;          // (the association below is with the buffer as the host will see it)
     c->gathered_of = c->ring[(size_t)buffer];
     *dptr = c->gathered;
     return TH_OK;

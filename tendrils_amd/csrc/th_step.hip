@@ -178,6 +178,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
             TH_HIP(hipGetLastError());
             clear_graphs(c);               // captured sequences name the ring buffers: one of them changes places with the spare
             float4 *old = in;
+            state_moved(c, old, c->spare);
             for (float4 *&r : c->ring) if (r == old) r = c->spare;
             c->spare = old;
             set_order(c, old, -1);
@@ -253,6 +254,7 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         clear_graphs(c);
         float4 *old = c->ring[1];
         set_order(c, old, -1);
+        state_moved(c, old, c->spare);
         c->ring[1] = c->spare; c->spare = old;
         set_order(c, c->ring[1], out_order);
     }
@@ -324,6 +326,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 TH_HIP(hipGetLastError());
                 set_order(c, other, fresh);
                 set_order(c, cur, -1);                 // (its content is dead: the sorted copy is the newest state now)
+                state_written(c, other); state_moved(c, cur, other);
                 c->ring[0] = other; c->ring[1] = cur;
             }
         } else if (th_status s = ensure_identity(c)) return s;
@@ -344,6 +347,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 p.flow3 = pack3 ? c->flow3 : nullptr;
                 float4 *cur = c->ring[0], *other = c->ring[1];
                 const int order = order_of(c, cur);
+                state_written(c, cur); state_written(c, other);
                 p.in = cur;
                 // a lane only ever touches its own texel, so one of the two outputs may overwrite the input;
                 // after m rotations of [cur, other]: m even -> [cur, other], m odd -> [other, cur]
@@ -352,9 +356,9 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                 p.perm = order >= 0 ? c->orders[(size_t)order].perm : nullptr;
                 p.nsteps = (uint32_t)m;
                 for (int32_t k = 0; k < m; ++k) p.times[k] = times[(size_t)(done + k)];
-                // the last launch of the call takes the statistics of the state it leaves in buffers[0] (f32 ring: a packed
-                // ring's statistics are those of the stored texels, which th_stats decodes)
-                const bool takes_stats = !c->packed && done + m == n;
+                // the last launch of the call takes the statistics of the state it leaves in buffers[0] (a packed ring's: of
+                // what the stored texels decode to)
+                const bool takes_stats = done + m == n;
                 if (takes_stats) {
                     const uint32_t parts = th::fused_stats_parts(p.count, p.perm != nullptr), need = parts + (parts + 255u) / 256u + 16u;
                     if (c->fused_parts_cap < need) {

@@ -64,6 +64,32 @@ def test_packed_steps_equal_decode_oracle_encode(oracle, n, overrides):
     t.dispose()
 
 
+def test_packed_statistics_taken_by_the_fused_launch():
+    """As tests/test_gpu_logic_parity.py:test_statistics_taken_by_the_fused_launch..., on a packed ring: the statistics are
+    those of what the stored texels decode to."""
+    from tendrils_amd import _capi
+    import tendrils_amd as ta
+    n = 256
+    st, fl = seeded_case(n, 99)
+    t = packed_tendrils(n, (96, 54), {"forceWeight": 0.2, "noiseWeight": 0.02})
+    t.particles.upload_texels(st)
+    t.flow.set_pixels(fl)
+    t.timer.time = 4000.0
+    limit = t.state["speedLimit"]
+    for steps in (6, 7):
+        t.step_n(steps)
+        fused = t.particles.stats(limit)
+        _capi.call("th_set_mode", t.particles._ctx, ta.TH_MODE_EXACT)      # drops the launch's partials: the pass over the state
+        again = t.particles.stats(limit)
+        got = t.particles.read(0)
+        speed = np.sqrt(got[..., 2] ** 2 + got[..., 3] ** 2)
+        live = (got[..., 0] != np.float32(-1e6)) | (got[..., 1] != np.float32(-1e6))
+        assert {k: v for k, v in fused.items() if k != "sum_speed"} == {k: v for k, v in again.items() if k != "sum_speed"}
+        assert abs(fused["sum_speed"] - again["sum_speed"]) <= 1e-12 * again["sum_speed"]
+        assert fused["live"] == int(live.sum()) and fused["max_speed"] == float(speed[live].max()) and 0 < fused["capped"] < fused["live"]
+    t.dispose()
+
+
 def test_packed_graph_replay_and_spawners(oracle):
     from tendrils_amd.spawn import spawnBall
     n = 128
