@@ -405,6 +405,7 @@ typedef struct th_draw_info {
     int32_t pipeline;            /* TH_DRAW_STREAM / TH_DRAW_BINS */
     int32_t reserved;
     uint64_t fragments, crowded_fragments;
+    uint64_t frame_passes;       /* frames so far whose step ran inside the draw's pass over the slots (TH_OPT_FRAME_FUSE) */
 } th_draw_info;
 th_status th_draw_query(th_context *ctx, th_draw_info *out);
 

@@ -66,10 +66,11 @@ th_status fail(th_status code, const char *fmt, ...)
 
 // keeps_lines: the entry point leaves the particle state and the per-line / per-fragment buffers of the last draw pass
 // alone, so that a view pass can still reuse the flow pass's geometry (deposit_run)
-th_status use(th_context *c, bool keeps_lines)
+th_status use(th_context *c, bool keeps_lines, bool keep_pending)
 {
     if (!c) return fail(TH_ERR_INVALID, "null context");
     TH_HIP(hipSetDevice(c->cfg.device));
+    if (c->pending.active && !keep_pending) if (th_status s = flush_pending_step(c)) return s;
     if (!keeps_lines) { c->drawn.valid = false; c->fused_stats.valid = false; }
     return TH_OK;
 }

@@ -930,6 +930,8 @@ napi_value DrawQuery(napi_env env, napi_callback_info info)
     NAPI_OK(napi_set_named_property(env, o, "fragments", v));
     NAPI_OK(napi_create_double(env, (double)q.crowded_fragments, &v));
     NAPI_OK(napi_set_named_property(env, o, "crowdedFragments", v));
+    NAPI_OK(napi_create_double(env, (double)q.frame_passes, &v));
+    NAPI_OK(napi_set_named_property(env, o, "framePasses", v));
     return o;
 }
 
