@@ -405,14 +405,13 @@ typedef struct th_draw_info {
     int32_t pipeline;            /* TH_DRAW_STREAM / TH_DRAW_BINS */
     int32_t reserved;
     uint64_t fragments, crowded_fragments;
-    uint64_t frame_passes;       /* frames so far whose step ran inside the draw's pass over the slots (TH_OPT_FRAME_FUSE) */
 } th_draw_info;
 th_status th_draw_query(th_context *ctx, th_draw_info *out);
 
 /* Per-context switches between equivalent paths (build-defined; no switch changes a result - the parity suites rerun under
  * each, tests/conftest.py).  A context starts from the environment variables of the same names, read by th_create
- * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL,
- * TH_FRAME_FUSE; TH_DRAW=stream|bins sets what TH_DRAW_AUTO means).
+ * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL;
+ * TH_DRAW=stream|bins sets what TH_DRAW_AUTO means).
  *   TH_OPT_BUCKET          tile-sorted slot order never (0) / always (1) / when it pays (-1, default)
  *   TH_OPT_RESORT_STEPS    re-sort period of single-step launches (default 64)
  *   TH_OPT_REBUCKET_STEPS  ... of fused th_step_n launches (default 256)
@@ -421,14 +420,11 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
  *   TH_OPT_FORCE_GENERIC   every step through the reference-order kernel (default 0)
  *   TH_OPT_DRAW_REUSE      the stream-ordered view pass reuses the flow pass's rasterisation and sort (default 1)
  *   TH_OPT_BINS_POOL       first size, in pages, of the binned pipeline's page pool (default 0: by the target's size)
- *   TH_OPT_FRAME_FUSE      th_step immediately followed by th_draw / th_flow_deposit runs as one pass over the slots where
- *                          both would run on tile-sorted slots (default 1)
  *   TH_OPT_INJECT_FAILURE  (tests) the next th_draw_sharded of THIS context fails on its own at stage 1 (its edge rows; packed rings), 2
  *                          (rasterising its lines) or 3 (making room for what it owns); the switch resets itself.  What is
  *                          tested: every other rank of the job returns an error too instead of waiting in a collective */
 enum { TH_OPT_BUCKET = 0, TH_OPT_RESORT_STEPS = 1, TH_OPT_REBUCKET_STEPS = 2, TH_OPT_FUSE = 3, TH_OPT_GRAPH = 4,
-       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_FRAME_FUSE = 8,
-       TH_OPT_INJECT_FAILURE = 9 };
+       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_INJECT_FAILURE = 8 };
 th_status th_option_set(th_context *ctx, int32_t option, int64_t value);
 th_status th_option_get(th_context *ctx, int32_t option, int64_t *value);
 

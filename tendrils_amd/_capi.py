@@ -90,8 +90,7 @@ class SlotOrderInfo(C.Structure):
 
 
 class DrawInfo(C.Structure):
-    _fields_ = [("pipeline", C.c_int32), ("reserved", C.c_int32), ("fragments", C.c_uint64), ("crowded_fragments", C.c_uint64),
-                ("frame_passes", C.c_uint64)]
+    _fields_ = [("pipeline", C.c_int32), ("reserved", C.c_int32), ("fragments", C.c_uint64), ("crowded_fragments", C.c_uint64)]
 
 
 class CommInfo(C.Structure):

@@ -44,7 +44,6 @@ void options_from_environment(th_options &o)
     o.draw = !d ? -1 : (!strcmp(d, "bins") ? 1 : (!strcmp(d, "stream") ? 0 : -1));
     o.draw_reuse = number("TH_DRAW_REUSE", 1) != 0;
     o.bins_pool = (uint32_t)number("TH_BINS_POOL", 0);
-    o.frame_fuse = number("TH_FRAME_FUSE", 1) != 0;
 }
 
 }  // namespace
@@ -66,11 +65,10 @@ th_status fail(th_status code, const char *fmt, ...)
 
 // keeps_lines: the entry point leaves the particle state and the per-line / per-fragment buffers of the last draw pass
 // alone, so that a view pass can still reuse the flow pass's geometry (deposit_run)
-th_status use(th_context *c, bool keeps_lines, bool keep_pending)
+th_status use(th_context *c, bool keeps_lines)
 {
     if (!c) return fail(TH_ERR_INVALID, "null context");
     TH_HIP(hipSetDevice(c->cfg.device));
-    if (c->pending.active && !keep_pending) if (th_status s = flush_pending_step(c)) return s;
     if (!keeps_lines) { c->drawn.valid = false; c->fused_stats.valid = false; }
     return TH_OK;
 }
@@ -617,7 +615,6 @@ th_status th_option_set(th_context *c, int32_t option, int64_t value)
     case TH_OPT_FORCE_GENERIC: o.force_generic = value != 0; break;
     case TH_OPT_DRAW_REUSE: o.draw_reuse = value != 0; break;
     case TH_OPT_BINS_POOL: TH_REQUIRE(value >= 0 && value < (1ll << 32), "TH_OPT_BINS_POOL out of range"); o.bins_pool = (uint32_t)value; break;
-    case TH_OPT_FRAME_FUSE: o.frame_fuse = value != 0; break;
     case TH_OPT_INJECT_FAILURE: TH_REQUIRE(value >= 0 && value <= 3, "TH_OPT_INJECT_FAILURE takes 0..3"); o.inject_failure = (int)value; break;
     default: return fail(TH_ERR_INVALID, "unknown option %d", option);
     }
@@ -638,7 +635,6 @@ th_status th_option_get(th_context *c, int32_t option, int64_t *value)
     case TH_OPT_FORCE_GENERIC: *value = o.force_generic; break;
     case TH_OPT_DRAW_REUSE: *value = o.draw_reuse; break;
     case TH_OPT_BINS_POOL: *value = o.bins_pool; break;
-    case TH_OPT_FRAME_FUSE: *value = o.frame_fuse; break;
     case TH_OPT_INJECT_FAILURE: *value = o.inject_failure; break;
     default: return fail(TH_ERR_INVALID, "unknown option %d", option);
     }

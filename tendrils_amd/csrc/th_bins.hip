@@ -31,7 +31,6 @@
 // The stream index of a line is a pure function of its particle id, so the result is the stream-ordered pipeline's, and
 // the restatement's, bit for bit, whatever the slot order and whatever the atomics did.
 #include "th_kernels.hpp"
-#include "th_logic.hpp"
 #include "th_raster.hpp"
 
 namespace th {
@@ -186,32 +185,13 @@ struct LineStage {
     uint32_t pad;                            // (24 words: 16-byte aligned fields)
 };
 
-// What the pass keeps in LDS while it emits ...
 template <uint32_t BS, bool DEAL>
-struct EmitLds {
-    static constexpr uint32_t kTab = BS * 4u;   // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly), half full at most
-    Reservations<kTab> t;
-    LineStage stage[DEAL ? BS : 1u];
-    uint8_t owner[DEAL ? BS / 64u : 1u][DEAL ? 64u * kMaxRowsDealt : 1u];     // per wave: the line (lane) of every dealt row
-};
-// ... and the step of a FRAME pass: bit 0 set - the pass first moves every particle of its block one step on (th_logic.hpp:
-// integrate, the single-step launch's arithmetic bit for bit) and emits the line from the state it read to the state it
-// wrote, both still in registers; bits 1, 2, 3: FAST, NOISE, TARGET.  The integrator's LDS tables and the emit's share
-// their LDS: the tables are dead when the step is done.
-constexpr int kStepOn = 1, kStepFast = 2, kStepNoise = 4, kStepTarget = 8;
-
-template <uint32_t BS, bool DEAL, int STEP>
-__global__ __launch_bounds__(BS, 4) void bins_fused_kernel(const DepositParams p, const LogicParams lp)
+__global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 {
-    constexpr uint32_t kTab = EmitLds<BS, DEAL>::kTab;
-    constexpr bool kStep = (STEP & kStepOn) != 0, kNoise = (STEP & kStepNoise) != 0;
-    constexpr size_t kTableBytes = kStep && kNoise ? (size_t)(kHashVec + kLutSize) * sizeof(float4) : (kStep ? sizeof(float4) : 0);
-    constexpr size_t kLdsBytes = sizeof(EmitLds<BS, DEAL>) > kTableBytes ? sizeof(EmitLds<BS, DEAL>) : kTableBytes;
-    __shared__ __align__(16) unsigned char lds[kLdsBytes];
-    EmitLds<BS, DEAL> &E = *reinterpret_cast<EmitLds<BS, DEAL> *>(lds);
-    auto &t = E.t;
-    auto &stage = E.stage;
-    auto &owner = E.owner;
+    constexpr uint32_t kTab = BS * 4u;          // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly), half full at most
+    __shared__ Reservations<kTab> t;
+    __shared__ LineStage stage[DEAL ? BS : 1u];
+    __shared__ uint8_t owner[DEAL ? BS / 64u : 1u][DEAL ? 64u * kMaxRowsDealt : 1u];     // per wave: the line (lane) of every dealt row
     const uint32_t slots = p.W * p.rows, blocks = (slots + BS - 1u) / BS;
     // (the workgroups walk the blocks of 256 slots with the stride of the grid: a grid of a few workgroups per CU stays
     // resident for the whole pass instead of 65 536 short-lived ones waiting to be dispatched)
@@ -219,19 +199,6 @@ __global__ __launch_bounds__(BS, 4) void bins_fused_kernel(const DepositParams p
     const uint32_t s = block * BS + threadIdx.x;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);
-    [[maybe_unused]] float4 stepped[2];                 // (frame pass) the state written, the state read
-    if constexpr (kStep) {
-        float4 *smem = reinterpret_cast<float4 *>(lds);
-        const float4 *lut = smem + (kNoise ? kHashVec : 0);
-        const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
-        if (s < slots) stepped[1] = load_stream(&lp.in[s]);
-        __syncthreads();                                    // (a block before this one is done with the emit's LDS)
-        if constexpr (kNoise) { fill_hash_tables(smem, lp.lut); __syncthreads(); }
-        if (s < slots) {
-            stepped[0] = integrate<(STEP & kStepFast) != 0, kNoise, (STEP & kStepTarget) != 0, true, true, kNoise>(lp, lut, stepped[1], lp.perm[s], lp.u.time, &tabs);
-            store_stream(&lp.out[s], stepped[0]);
-        }
-    }
     // In the tile-sorted order the particles whose lines can draw lie apart from the others inside every tile
     // (th_kernels.hip: tile_key): most blocks meet only one kind - whole waves of lines that exist, or nothing to do.
     __syncthreads();                                    // (the block before is done with the table)
@@ -243,8 +210,7 @@ __global__ __launch_bounds__(BS, 4) void bins_fused_kernel(const DepositParams p
     if (t.any == 0u) continue;
 
     float4 own[2];                                      // (both ends of the line, before anything else)
-    if constexpr (kStep) { own[0] = stepped[0]; own[1] = stepped[1]; }
-    else if (can) { own[0] = p.cur[s]; own[1] = p.prev[s]; }
+    if (can) { own[0] = p.cur[s]; own[1] = p.prev[s]; }
     DepositLine L;
     L.draws = false;
     LineRecord r{};
@@ -1275,10 +1241,7 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
 
 }  // namespace
 
-// step: the frame pass - the particles are moved one step on by the pass itself (LogicParams as th_step would launch them:
-// in = buffers[1], out = buffers[0] of the draw, perm = their common slot order, the decoded plane of this step's time); the
-// flags pick the integrator variant.  nullptr: the plain pass over the two states in memory.
-void launch_bins_fused(const DepositParams &p, hipStream_t s, const LogicParams *step, bool fast, bool noise, bool target)
+void launch_bins_fused(const DepositParams &p, hipStream_t s)
 {
     const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
     (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
@@ -1287,19 +1250,13 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s, const LogicParams 
     // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
     // per SIMD instead of 4)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
-    const dim3 grid(blocks ? blocks : 1u), wg(256);
-    if (!step) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 0>), grid, wg, 0, s, p, LogicParams{});
-    else {
-#define TH_FRAME(F, N, T) hipLaunchKernelGGL((bins_fused_kernel<256u, true, kStepOn | (F ? kStepFast : 0) | (N ? kStepNoise : 0) | (T ? kStepTarget : 0)>), grid, wg, 0, s, p, *step)
-        if (fast) { if (noise) { if (target) TH_FRAME(true, true, true); else TH_FRAME(true, true, false); } else { if (target) TH_FRAME(true, false, true); else TH_FRAME(true, false, false); } }
-        else { if (noise) { if (target) TH_FRAME(false, true, true); else TH_FRAME(false, true, false); } else { if (target) TH_FRAME(false, false, true); else TH_FRAME(false, false, false); } }
-#undef TH_FRAME
-    }
+    hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 8u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }
 
+// p.nlarge: the large bins, as the plan counted them (totals[kTotLarge])
 void launch_bins_regroup(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;

@@ -52,7 +52,6 @@ struct th_options {
     int draw = -1;                       // TH_DRAW=stream (0) / bins (1): the default of th_draw_pipeline's AUTO
     bool draw_reuse = true;              // TH_DRAW_REUSE: the stream-ordered view pass reuses the flow pass's geometry
     uint32_t bins_pool = 0;              // TH_BINS_POOL: first size of the binned pipeline's page pool (0: by the target's size)
-    bool frame_fuse = true;              // TH_FRAME_FUSE: step() + draw() of one frame in one pass where both run on sorted slots
     int inject_failure = 0;              // (tests) the next th_draw_sharded fails on THIS rank at stage 1 / 2 / 3: the ranks must all leave
 };
 
@@ -169,16 +168,6 @@ struct th_context {
     std::vector<hipEvent_t> kt_events;   // pairs (start, stop); kt_used of them recorded
     size_t kt_used = 0;
     std::vector<GraphEntry> graphs;      // th_step_n cache
-    // A single step that has been PLANNED but not launched (th_step on sorted slots while frames are being drawn with the
-    // binned pipeline): ring, slot orders and step counters are already those after the step; the launch is the next draw's
-    // frame pass (th_bins.hip: one pass steps and emits) - or, if anything else comes first, the plain launch (use()).
-    struct {
-        bool active = false;
-        th::LogicParams p{};
-        bool noise = false, targets = false, pow2 = false;
-        int mode = 0;
-    } pending;
-    unsigned long long frame_passes = 0; // frames stepped and drawn in one pass so far (th_slot_order)
 
     // Tile-sorted slot orders (th_kernels.hip "Tile-sorted slot order"); lazily allocated.  Every ring buffer is in
     // texel order or in one of `orders` (a step that re-sorts writes its output in a new order while its input keeps
@@ -214,11 +203,7 @@ namespace thi {
 // ---- th_api.hip ------------------------------------------------------------------------------------------------------
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 inline uint32_t ilog2(uint32_t v) { uint32_t r = 0; while (v >>= 1) ++r; return r; }
-// every entry point starts here.  keep_pending: the caller may consume a planned, not yet launched step (the draw entry
-// points); everybody else has it launched first
-th_status use(th_context *c, bool keeps_lines = false, bool keep_pending = false);
-th_status flush_pending_step(th_context *c);          // (th_step.hip)
-th_status timing_events(th_context *c, hipEvent_t *k0, hipEvent_t *k1);     // th_kernel_timing: the next event pair
+th_status use(th_context *c, bool keeps_lines = false);
 th_status alloc_state(th_context *c, float4 **out);
 th_status resolve_target(th_context *c, int32_t target, bool rotate_ok, float4 **out);
 th_status rect_ok(th_context *c, int32_t x0, int32_t y0, int32_t w, int32_t h);

@@ -38,31 +38,17 @@ float drawn_line_width(const th_context *c, int pass)
     return w < c->line_range[0] ? c->line_range[0] : (w > c->line_range[1] ? c->line_range[1] : w);
 }
 
-static bool draw_uses_bins(th_context *c, long long draws)
+static bool draw_uses_bins(th_context *c)
 {
     const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : c->opt.draw;
     if (policy == 0) return false;
     if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
     if (policy == 1) return true;
-    if (draws < c->stream_until) return false;
+    if (c->draws < c->stream_until) return false;
     // (lines wider than 2 cover more texels than a line's record holds: nearly all of them would leave the fused pass
     // for the long list, one atomic per fragment - the stream-ordered pipeline counts and scans instead)
     if (drawn_line_width(c, TH_PASS_FLOW) > 2.0f || drawn_line_width(c, TH_PASS_VIEW) > 2.0f) return false;
     return sorting_possible(c);
-}
-
-// Does this draw pass go through the binned pipeline?  The auto policy counts FRAMES, and the passes of one frame -
-// th_flow_deposit then th_view_draw, or two line widths - take one pipeline: a view pass that left the slot order its flow
-// pass had drawn over would throw the order away in mid-frame.  commit = false: only asking (the draw entry points, before
-// they decide what to do with a planned step).
-static bool decide_bins(th_context *c, bool commit)
-{
-    const bool fresh = c->draw_frame_step != c->total_steps;
-    if (commit && fresh) { ++c->draws; c->draw_frame_step = c->total_steps; c->frame_bins = -1; }
-    if (!fresh && c->frame_bins >= 0 && c->draw_pipeline == TH_DRAW_AUTO) return c->frame_bins == 1;
-    // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
-    // another particle (line_rows, worked out when the context was made) keep to the stream-ordered pipeline in texel order
-    return draw_uses_bins(c, c->draws + (fresh && !commit ? 1 : 0)) && c->lines_local == 1;
 }
 
 // per-line buffers + parameters.  want_bins: the caller can run the binned pipeline (*bins tells whether it will)
@@ -70,8 +56,17 @@ th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::Depos
 {
     TH_REQUIRE(u, "null uniforms");
     TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
-    bool use_bins = want_bins && decide_bins(c, true);
-    if (use_bins && any_sorted(c)) if (th_status s = align_slot_orders(c)) return s;
+    // The auto policy counts FRAMES, and the passes of one frame - th_flow_deposit then th_view_draw, or two widths - take one
+    // pipeline: a view pass that left the slot order its flow pass had drawn over would throw the order away in mid-frame.
+    if (want_bins && c->draw_frame_step != c->total_steps) { ++c->draws; c->draw_frame_step = c->total_steps; c->frame_bins = -1; }
+    bool use_bins = want_bins && (c->frame_bins >= 0 && c->draw_pipeline == TH_DRAW_AUTO ? c->frame_bins == 1 : draw_uses_bins(c));
+    if (use_bins) {
+        // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
+        // another particle (line_rows) keep to the stream-ordered pipeline in texel order
+        if (th_status s = line_rows(c)) return s;
+        if (c->lines_local != 1) use_bins = false;
+        else if (any_sorted(c)) { if (th_status s = align_slot_orders(c)) return s; }
+    }
     if (bins) *bins = use_bins;
     if (want_bins) c->frame_bins = use_bins ? 1 : 0;
     if (use_bins) c->last_binned_draw = c->total_steps;
@@ -350,22 +345,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
         p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
-        if (c->pending.active) {
-            // the frame pass: this frame's step was planned and not launched (th_step) - the pass over the slots moves the
-            // particles on and emits their lines from registers.  (A repeated attempt finds the step done.)
-            const th::LogicParams &lp = c->pending.p;
-            c->pending.active = false;
-            th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, lp.u.time, nullptr, lp.u.flowDecay, c->stream);
-            hipEvent_t k0 = nullptr, k1 = nullptr;
-            if (c->kernel_timing) {
-                if (th_status s = timing_events(c, &k0, &k1)) return s;
-                TH_HIP(hipEventRecord(k0, c->stream));
-            }
-            th::launch_bins_fused(p, c->stream, &lp, c->pending.mode == TH_MODE_FAST, c->pending.noise, c->pending.targets);
-            if (k1) TH_HIP(hipEventRecord(k1, c->stream));
-            ++c->frame_passes;
-        } else
-            th::launch_bins_fused(p, c->stream);
+        th::launch_bins_fused(p, c->stream);
         // the totals come back over the side stream while the ordinary bins are already being blended (the kernel looks at the
         // pass's flags itself): the host's round trip - it sizes the crowded bins' launches - costs the GPU nothing
         TH_HIP(hipEventRecord(c->forked, c->stream));
@@ -445,20 +425,9 @@ th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *li
     return export_run(c, p, lines, capacity, count);
 }
 
-// a planned step stays planned only for a pass that will take it along: the binned pipeline over both ring buffers as the
-// step left them
-static th_status settle_pending_step(th_context *c)
-{
-    if (!c->pending.active) return TH_OK;
-    const bool takes = c->ring.size() == 2 && c->pending.p.out == c->ring[0] && c->pending.p.in == c->ring[1] &&
-                       c->cfg.height == c->cfg.global_height && decide_bins(c, false);
-    return takes ? TH_OK : flush_pending_step(c);
-}
-
 th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
 {
-    if (th_status s = use(c, false, true)) return s;
-    if (th_status s = settle_pending_step(c)) return s;
+    if (th_status s = use(c)) return s;
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
     for (int pass = 0;; ++pass) {            // (a binned pass that gives up before blending is repeated in stream order)
@@ -469,7 +438,6 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
         const th_status s = deposit_run_bins(c, p, fragments);
         if (s != kRetryInStreamOrder) return s;
         c->frame_bins = 0;                  // (the other passes of this frame as well)
-        if (th_status f = flush_pending_step(c)) return f;      // (a planned step the pass did not get to)
     }
 }
 
@@ -480,8 +448,7 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
 // by th_view_draw.
 th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
 {
-    if (th_status s = use(c, false, true)) return s;
-    if (th_status s = settle_pending_step(c)) return s;
+    if (th_status s = use(c)) return s;
     TH_REQUIRE(du && ru, "null uniforms");
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "draw on a row-band shard (%d of %d rows): the passes go through th_deposit_emit / th_deposit_merge and th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
@@ -504,7 +471,6 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
         const th_status s = deposit_run_bins(c, p, fragments);
         if (s != kRetryInStreamOrder) return s;
         c->frame_bins = 0;                  // (the other passes of this frame as well)
-        if (th_status f = flush_pending_step(c)) return f;      // (a planned step the pass did not get to)
     }
 }
 
@@ -523,7 +489,6 @@ th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fra
         const th_status s = deposit_run_bins(c, p, fragments);
         if (s != kRetryInStreamOrder) return s;
         c->frame_bins = 0;                  // (the other passes of this frame as well)
-        if (th_status f = flush_pending_step(c)) return f;      // (a planned step the pass did not get to)
     }
 }
 
@@ -584,7 +549,6 @@ th_status th_draw_query(th_context *c, th_draw_info *out)
 {
     TH_REQUIRE(c && out, "null argument");
     *out = c->last_draw;
-    out->frame_passes = c->frame_passes;
     return TH_OK;
 }
 

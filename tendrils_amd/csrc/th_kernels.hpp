@@ -226,7 +226,7 @@ constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits
 // totals[]: device words of one pass
 enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWords = 8 };
 enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
-void launch_bins_fused(const DepositParams &p, hipStream_t stream, const LogicParams *step = nullptr, bool fast = false, bool noise = false, bool target = false);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
+void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
 void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
 void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs of more fragments than a wave orders (the longest first)
 void launch_bins_blend_crowd(const DepositParams &p, hipStream_t stream);             // their other runs, a wave each: order by stream index, blend

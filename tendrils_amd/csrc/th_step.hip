@@ -124,8 +124,7 @@ static uint32_t plan_flags(const StepPlan &plan)
            (plan.generic ? 16u : 0u);
 }
 
-namespace thi {
-th_status timing_events(th_context *c, hipEvent_t *k0, hipEvent_t *k1)
+static th_status timing_events(th_context *c, hipEvent_t *k0, hipEvent_t *k1)
 {
     if (c->kt_used + 2 > c->kt_events.size()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -136,15 +135,12 @@ th_status timing_events(th_context *c, hipEvent_t *k0, hipEvent_t *k1)
     c->kt_used += 2;
     return TH_OK;
 }
-}  // namespace thi
 
 // Rotate / resolve the render target and launch (flow decode +) the integrator.  Launches only:
 // safe inside a stream capture.  `time_dev` (optional) overrides plan.p.u.time on the device.
 // `sorted`: the pass may read and write tile-sorted slots (else every ring buffer is in texel order already).
-// `defer`: a pass that turns out to be the plain gather launch over sorted slots (no re-sort around it) is planned - ring,
-// orders, counters - but not launched: c->pending holds it for the next draw's frame pass (or flush_pending_step).
 static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t target, float time, const float *time_dev,
-                              bool timing, bool sorted = false, bool defer = false)
+                              bool timing, bool sorted = false)
 {
     th::LogicParams p = plan.p;
     float4 *out = nullptr;
@@ -236,15 +232,6 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
         }
     }
 
-    if (defer && gather && !time_dev && plan.decoded && plan.pow2) {
-        c->pending.active = true;
-        c->pending.p = p; c->pending.noise = plan.noise; c->pending.targets = plan.use_targets; c->pending.pow2 = plan.pow2;
-        c->pending.mode = c->cfg.mode;
-        set_order(c, out, out_order);
-        ++c->steps_since_sort; ++c->total_steps;
-        c->counted.buf = nullptr;
-        return TH_OK;
-    }
     if (plan.decoded)
         th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, time, time_dev, p.u.flowDecay, c->stream);
 
@@ -279,28 +266,6 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     return TH_OK;
 }
 
-namespace thi {
-
-// the launch a planned step was waiting for, when no draw came to take it into its frame pass
-th_status flush_pending_step(th_context *c)
-{
-    if (!c->pending.active) return TH_OK;
-    c->pending.active = false;
-    const th::LogicParams &p = c->pending.p;
-    th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, p.u.time, nullptr, p.u.flowDecay, c->stream);
-    hipEvent_t k0 = nullptr, k1 = nullptr;
-    if (c->kernel_timing) {
-        if (th_status s = timing_events(c, &k0, &k1)) return s;
-        TH_HIP(hipEventRecord(k0, c->stream));
-    }
-    th::launch_logic(p, c->pending.mode, c->pending.noise, c->pending.targets, c->pending.pow2, true, false, false, c->stream);
-    if (k1) TH_HIP(hipEventRecord(k1, c->stream));
-    TH_HIP(hipGetLastError());
-    return TH_OK;
-}
-
-}  // namespace thi
-
 extern "C" {
 
 th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
@@ -313,12 +278,7 @@ th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
     if (th_status s = plan_step(c, *u, target, plan)) return s;
     const bool sorted = plan.may_sort && !plan.generic;
     if (!sorted) if (th_status s = ensure_identity(c)) return s;
-    // A frame loop - step(); draw() - over sorted slots with the binned draw: the step waits for the draw, whose first pass
-    // over the slots moves the particles on and emits their lines in one go (th_bins.hip).  Only while draws ARE going on
-    // (the last frame was drawn over the slot order): a host that only steps never waits.
-    const bool defer = c->opt.frame_fuse && sorted && target == TH_TARGET_RING && !c->packed && c->ring.size() == 2 &&
-                       c->last_binned_draw == c->total_steps;
-    return enqueue_step(c, plan, target, u->time, nullptr, true, sorted, defer);
+    return enqueue_step(c, plan, target, u->time, nullptr, true, sorted);
 }
 
 // n fixed-step Tendrils.step() calls.  The launch sequence (2 kernels per step) is captured once into

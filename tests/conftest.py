@@ -47,8 +47,6 @@ VARIANTS = {
     # ... and over tile-sorted slots re-sorted every few steps
     "bins-on-sorted": ({"TH_DRAW": "bins", "TH_BUCKET": "1", "TH_RESORT_STEPS": "3", "TH_REBUCKET_STEPS": "2"},
                        ["test_gpu_deposit", "test_gpu_view", "test_gpu_fuzz", "test_gpu_scene"]),
-    # step() and draw() of a frame as two launches even where they could run as one pass
-    "no-frame-fuse": ({"TH_FRAME_FUSE": "0"}, ["test_gpu_deposit", "test_gpu_scene", "test_gpu_fuzz"]),
 }
 
 
