@@ -732,8 +732,15 @@ def main():
                 "uniform_set": "flow only (noiseWeight = 0)" if args.flow_only else "default (simplex noise on)",
                 "achieved_is": "algorithmic bytes (SURVEY.md 8d: %d B per particle-step) / mean launch duration - an equivalent "
                                "single-step bandwidth (equivalent_frac = achieved / peak); the fused launch streams 48/n B per "
-                               "particle-step (hbm_physical); frac = the fraction of the bound named in `bound`" % bytes_per_step,
+                               "particle-step (hbm_physical); frac = achieved / peak (the resource the launch runs out of: `limited_by`)" % bytes_per_step,
                 "pmc_note": pmc_note}
+    if fused and head["equivalent_frac"] <= 1.0:
+        # the contract's figure for the dominant kernel: algorithmic bytes / launch duration against the HBM peak.
+        # What the launch actually runs out of is named beside it: a register-resident launch streams 48/n B per particle-step
+        # and is limited by VALU issue (`limited_by`, `limited_by_frac`; never reported as more than 1)
+        head["limited_by"], head["limited_by_frac"], head["limited_by_frac_is"] = head["bound"], head["frac"], head["frac_is"]
+        head["bound"], head["frac"] = "hbm", head["equivalent_frac"]
+        head["frac_is"] = "achieved / peak: algorithmic bytes (SURVEY.md 8d) per launch / mean launch duration / 8 TB/s"
     roofline.update(head)
     single = bind(rl(single_s, 1, pmc.get("single")), False)
     single["kernel"] = "logic_packed_kernel" if packed else "logic_kernel over tile-sorted slots (gathered taps; every 64th launch re-sorts through logic_sorted_kernel)"
@@ -843,6 +850,10 @@ def frame_loop(t, ctx, state, frames=20):
     for _ in range(5):
         t.timer.tick(); t.step()
         both_ms.append(timed(t.draw))
+    frame_ms = []                         # ... and the frame as one piece: step() + draw() inside one event pair
+    for _ in range(10):
+        t.timer.tick()
+        frame_ms.append(timed(lambda: (t.step(), t.draw())))
     # ... and the same loop once the wake has crowded the target (the reference's loop runs for minutes: after ~60 frames
     # at this size most fragments fall into texels with hundreds and thousands of them, and a draw waits for the
     # longest run of one texel): `settle` more frames untimed, then 50 timed
@@ -887,6 +898,7 @@ def frame_loop(t, ctx, state, frames=20):
                               "draw_both_ms": float(np.max(both_ms))},
             "fragments_per_draw": f, "frames_per_s": 1e3 / (s_ms + d),
             "frame_ms_reference_loop": s_ms + b_ms,
+            "frame_ms": float(np.median(frame_ms)),
             "wall_ms_per_frame": wall_ms,
             "crowded": crowded,
             "pipeline": "binned (th_bins.hip): particles stay in the integrator's tile-sorted slot order; one fused rasterise + emit pass into "

@@ -250,7 +250,7 @@ th_status th_destroy(th_context *c)
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)c->transport->destroy(c->comm); c->comm = nullptr; }
-    (void)hipFree(c->d_status);
+    (void)hipFree(c->d_status); (void)hipFree(c->own_mem);
     for (float4 *b : c->ring) (void)hipFree(b);
     (void)hipFree(c->flow); (void)hipFree(c->flow_dec); (void)hipFree(c->flow3); (void)hipFree(c->targets); (void)hipFree(c->lut_block);
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);

@@ -1239,6 +1239,167 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
     quad_walk<MODE>(p, texel, len, c, [sorted](uint32_t j) { return sorted[j]; });
 }
 
+// ---- row-band shards: the bins travel to the ranks that own them -----------------------------------------------------------
+// A sharded job draws with the binned pipeline like a single context does - every rank rasterises its band's lines into
+// ITS page store (bins_fused_kernel, untouched) - and then the bins change hands: a rank owns whole bin rows of the target
+// (OwnerParams::bin_lo: contiguous ranges, hence contiguous texel ranges for the all-gather that follows), and what a rank
+// emitted into the bins of owner r is compacted into one contiguous part per owner (keys + varyings, bin by bin, with the
+// per-bin counts beside it), exchanged, and laid out in the owner's page store exactly as if the owner had emitted it: cursors,
+// pages from the pool, page table - so that the plan and every blend kernel run unchanged.  The order inside a bin is of no
+// consequence (the blend restores GL's order from the keys), so nothing is sorted anywhere on the way.
+//   owner_counts_kernel    places per bin, their exclusive scan (= where each bin goes in the outgoing arrays), the owners' bounds
+//   owner_extract_kernel   a workgroup per bin: its lists walked, fragments copied out; the lists' pages forgotten
+//   owner_prefix_kernel    (owner) per source: where each of my bins starts inside that source's part
+//   owner_layout_kernel    (owner) per bin: places in all, list lengths, pool pages, page table, cursors
+//   owner_insert_kernel    (owner) a workgroup per bin: every source's fragments of the bin copied to their places
+
+// all threads of a 1024-thread workgroup: `mine` -> its exclusive prefix over the workgroup; `total` (same on every thread)
+TH_D unsigned long long block_scan_1024(unsigned long long *lds, unsigned long long mine, unsigned long long &total)
+{
+    const uint32_t t = threadIdx.x;
+    __syncthreads();
+    lds[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const unsigned long long a = t >= off ? lds[t - off] : 0ull;
+        __syncthreads();
+        lds[t] += a;
+        __syncthreads();
+    }
+    total = lds[1023];
+    return lds[t] - mine;
+}
+
+__global__ __launch_bounds__(1024) void owner_counts_kernel(const DepositParams p, const OwnerParams o)
+{
+    __shared__ unsigned long long lds[1024];
+    const uint32_t per = (p.nbins + 1023u) / 1024u, lo = threadIdx.x * per < p.nbins ? threadIdx.x * per : p.nbins, hi = lo + per < p.nbins ? lo + per : p.nbins;
+    unsigned long long n = 0, total = 0;
+    for (uint32_t b = lo; b < hi; ++b) n += bin_places(p, b);
+    unsigned long long run = block_scan_1024(lds, n, total);
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t c = bin_places(p, b);
+        o.counts[b] = c;
+        o.offsets[b] = run;
+        run += c;
+    }
+    if (threadIdx.x == 0u) o.offsets[p.nbins] = total;
+    __syncthreads();
+    __threadfence_block();
+    if (threadIdx.x <= o.world) o.owner_bounds[threadIdx.x] = threadIdx.x == o.world ? total : 0ull;
+    __syncthreads();
+    // (the bounds are read from the offsets just written: by the threads that wrote them or after the barrier above)
+    for (uint32_t b = lo; b < hi; ++b)
+        for (uint32_t r = 0; r < o.world; ++r) if (o.bin_lo[r] == b) o.owner_bounds[r] = o.offsets[b];
+    if (threadIdx.x == 0u) for (uint32_t r = 0; r < o.world; ++r) if (o.bin_lo[r] >= p.nbins) o.owner_bounds[r] = total;
+}
+
+// the places of bin b walked list after list: place f of the walk (lists[] = first place of every list, lists[kBinReplicas] = all)
+TH_D uint32_t walk_place(const DepositParams &p, uint32_t b, const uint32_t *lists, uint32_t f)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t q = 1; q < kBinReplicas; ++q) r += f >= lists[q] ? 1u : 0u;
+    return place_of(p, b * kBinReplicas + r, f - lists[r]);
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void owner_extract_kernel(const DepositParams p, const OwnerParams o)
+{
+    __shared__ uint32_t lists[kBinReplicas + 1u];
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (t == 0u) {
+        uint32_t run = 0;
+        for (uint32_t r = 0; r < kBinReplicas; ++r) { lists[r] = run; run += *list_cursor(p, b, r); }
+        lists[kBinReplicas] = run;
+    }
+    __syncthreads();
+    const uint32_t n = lists[kBinReplicas];
+    const unsigned long long base = o.offsets[b];
+    for (uint32_t f = t; f < n; f += 256u) {
+        const uint32_t at = walk_place(p, b, lists, f);
+        o.out_keys[base + f] = p.frag_keys[at];
+        if constexpr (PAIRS) { o.out_colors[2u * (base + f)] = p.colors[2u * (size_t)at]; o.out_colors[2u * (base + f) + 1u] = p.colors[2u * (size_t)at + 1u]; }
+        else o.out_colors[base + f] = p.colors[at];
+    }
+    __syncthreads();
+    for (uint32_t r = 0; r < kBinReplicas; ++r) if (lists[r + 1u] - lists[r] > kBinPage) pages_forget(p, b * kBinReplicas + r, lists[r + 1u] - lists[r], t, 256u);
+}
+
+// table[s][b'] (what source s holds for my bin b') -> src_prefix[s][b'] (its exclusive scan over b'); one workgroup per source
+__global__ __launch_bounds__(1024) void owner_prefix_kernel(const OwnerParams o)
+{
+    __shared__ unsigned long long lds[1024];
+    const uint32_t s = blockIdx.x, per = (o.nb + 1023u) / 1024u, lo = threadIdx.x * per < o.nb ? threadIdx.x * per : o.nb, hi = lo + per < o.nb ? lo + per : o.nb;
+    const uint32_t *row = o.table + (size_t)s * o.nb;
+    unsigned long long n = 0, total = 0;
+    for (uint32_t b = lo; b < hi; ++b) n += row[b];
+    unsigned long long run = block_scan_1024(lds, n, total);
+    for (uint32_t b = lo; b < hi; ++b) { o.src_prefix[(size_t)s * o.nb + b] = run; run += row[b]; }
+}
+
+// how a bin of `total` places is spread over its lists: places per list (a multiple of the page size above one page per list)
+TH_D uint32_t owner_list_len(uint32_t total)
+{
+    if (total <= kBinCap) return kBinPage;
+    const uint32_t per = (total + kBinReplicas - 1u) / kBinReplicas;
+    return (per + kBinPage - 1u) / kBinPage * kBinPage;
+}
+
+__global__ __launch_bounds__(1024) void owner_layout_kernel(const DepositParams p, const OwnerParams o)
+{
+    __shared__ unsigned long long lds[1024];
+    const uint32_t b0 = o.bin_lo[o.rank];
+    const uint32_t per = (o.nb + 1023u) / 1024u, lo = threadIdx.x * per < o.nb ? threadIdx.x * per : o.nb, hi = lo + per < o.nb ? lo + per : o.nb;
+    unsigned long long pages = 0, all = 0;
+    bool full = false;
+    for (uint32_t b = lo; b < hi; ++b) {
+        unsigned long long total = 0;
+        for (uint32_t s = 0; s < o.world; ++s) total += o.table[(size_t)s * o.nb + b];
+        if (total > (unsigned long long)kBinMaxPages * kBinPage * kBinReplicas) { full = true; total = 0; }
+        o.bin_total[b] = (uint32_t)total;
+        pages += (unsigned long long)(owner_list_len((uint32_t)total) / kBinPage - 1u) * kBinReplicas;
+    }
+    unsigned long long first = block_scan_1024(lds, pages, all);
+    if (full) bins_flag(p, kBinsBinFull);
+    if (threadIdx.x == 0u) {
+        p.totals[kTotPool] = (uint32_t)(all > 0xffffffffull ? 0xffffffffull : all);
+        if (all > p.pool_pages) bins_flag(p, kBinsPoolExhausted);
+    }
+    if (all > p.pool_pages) return;                     // (the host grows the store and lays the bins out again)
+    for (uint32_t b = lo; b < hi; ++b) {
+        const uint32_t total = o.bin_total[b], len = owner_list_len(total), extra = len / kBinPage - 1u, bin = b0 + b;
+        for (uint32_t r = 0; r < kBinReplicas; ++r) {
+            const unsigned long long begin = (unsigned long long)r * len;
+            *list_cursor(p, bin, r) = total > begin ? (uint32_t)(total - begin < len ? total - begin : len) : 0u;
+            for (uint32_t n = 1; n <= extra; ++n)
+                p.page_table[(size_t)(bin * kBinReplicas + r) * kBinMaxPages + n] = p.nbins * kBinReplicas + (uint32_t)first + r * extra + (n - 1u);
+        }
+        first += (unsigned long long)extra * kBinReplicas;
+    }
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void owner_insert_kernel(const DepositParams p, const OwnerParams o)
+{
+    const uint32_t b = blockIdx.x, bin = o.bin_lo[o.rank] + b, t = threadIdx.x;
+    const uint32_t total = o.bin_total[b], len = owner_list_len(total);
+    if (total == 0u || p.totals[kTotFlags] != 0u) return;
+    uint32_t seen = 0;                                  // places of the bin taken by the sources before s
+    for (uint32_t s = 0; s < o.world; ++s) {
+        const uint32_t n = o.table[(size_t)s * o.nb + b];
+        const unsigned long long from = o.recv_base[s] + o.src_prefix[(size_t)s * o.nb + b];
+        for (uint32_t f = t; f < n; f += 256u) {
+            const uint32_t j = seen + f, r = j / len, v = j - r * len;
+            const uint32_t at = place_of(p, bin * kBinReplicas + r, v);
+            p.frag_keys[at] = o.in_keys[from + f];
+            if constexpr (PAIRS) { p.colors[2u * (size_t)at] = o.in_colors[2u * (from + f)]; p.colors[2u * (size_t)at + 1u] = o.in_colors[2u * (from + f) + 1u]; }
+            else p.colors[at] = o.in_colors[from + f];
+        }
+        seen += n;
+    }
+}
+
 }  // namespace
 
 void launch_bins_fused(const DepositParams &p, hipStream_t s)
@@ -1252,6 +1413,34 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
     hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 8u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
+}
+
+
+// ---- the bins on their way to their owners (row-band shards) --------------------------------------------------------------
+// sender: places per bin, their offsets in the outgoing arrays, the owners' bounds (o.owner_bounds: world + 1 values)
+void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t s)
+{
+    hipLaunchKernelGGL(owner_counts_kernel, dim3(1), dim3(1024), 0, s, p, o);
+}
+// sender: every bin's fragments into o.out_keys / o.out_colors at o.offsets; the store is left ready for the next emit
+void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hipStream_t s)
+{
+    if (p.mode == 2) hipLaunchKernelGGL(owner_extract_kernel<true>, dim3(p.nbins), dim3(256), 0, s, p, o);
+    else hipLaunchKernelGGL(owner_extract_kernel<false>, dim3(p.nbins), dim3(256), 0, s, p, o);
+}
+// owner: the received parts (o.table, o.recv_base, o.in_keys / o.in_colors) laid out in this context's store as if it had
+// emitted them; then the plan of the ordinary binned pass (large bins, totals).  p.totals must have been zeroed.
+void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipStream_t s)
+{
+    (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(owner_prefix_kernel, dim3(o.world), dim3(1024), 0, s, o);
+    hipLaunchKernelGGL(owner_layout_kernel, dim3(1), dim3(1024), 0, s, p, o);
+    if (o.nb) {
+        if (p.mode == 2) hipLaunchKernelGGL(owner_insert_kernel<true>, dim3(o.nb), dim3(256), 0, s, p, o);
+        else hipLaunchKernelGGL(owner_insert_kernel<false>, dim3(o.nb), dim3(256), 0, s, p, o);
+    }
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }

@@ -101,6 +101,8 @@ struct th_context {
     void *comm = nullptr;                // communicator of the job's ranks (th_comm_init), one rank per context ...
     const th::Transport *transport = nullptr;   // ... and how its ranks exchange bytes (RCCL; in-process for tests)
     uint32_t *d_status = nullptr;        // the word the ranks agree on (agree_status)
+    void *own_mem = nullptr;             // th_draw_sharded through the bins: counts, offsets, tables (th_bins.hip: OwnerParams)
+    uint32_t own_bins = 0;
     bool sharded_draw_ready = false;     // th_draw_sharded has allocated its fixed buffers (and the ranks agreed that all did)
     int32_t comm_rank = 0, comm_world = 1;
     // flow deposit scratch (grow-only): per-flow-texel counters and the fragment lists
@@ -249,5 +251,13 @@ th_status deposit_temp(th_context *c, size_t need);
 th_status view_storage(th_context *c);
 void view_fields(th_context *c, const th_render_uniforms *u, th::DepositParams &p);
 th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositParams &p, bool want_bins = false, bool *bins = nullptr);
+// the binned pipeline in parts (deposit_run_bins = emit + finish; row-band shards put the owners' exchange in between)
+constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
+th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least);
+th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early);
+th_status bins_pass_totals(th_context *c);
+th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early, bool policy);
+bool binned_shards(const th_context *c);              // a sharded draw() of this job goes through the bins (the same answer on every rank)
+th_status deposit_prepare_bins(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p);
 
 }  // namespace thi

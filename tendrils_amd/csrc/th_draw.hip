@@ -52,6 +52,33 @@ static bool draw_uses_bins(th_context *c)
 }
 
 // per-line buffers + parameters.  want_bins: the caller can run the binned pipeline (*bins tells whether it will)
+static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, bool use_bins);
+
+// Does a sharded job draw through the bins?  Only what every rank sees alike may enter: the job's shapes, the lines' widths,
+// the switches (set alike on all ranks) - not this band's size, not how crowded its last draw was.
+bool binned_shards(const th_context *c)
+{
+    const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : c->opt.draw;
+    if (policy == 0 || c->lines_local != 1 || c->packed) return false;
+    if (c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
+    if (drawn_line_width(c, TH_PASS_FLOW) > 2.0f || drawn_line_width(c, TH_PASS_VIEW) > 2.0f) return false;
+    if (policy == 1 || c->opt.bucket == 1) return true;
+    if (c->opt.bucket == 0) return false;
+    // (sorting_possible's rule on the job's average band: the integrator steps over sorted slots there)
+    const size_t flow_texels = (size_t)c->fw * c->fh, per_rank = (size_t)c->cfg.width * c->cfg.global_height / (size_t)std::max(c->comm_world, 1);
+    return per_rank >= ((size_t)1 << 20) && per_rank >= 2 * flow_texels && flow_texels * sizeof(float2) > ((size_t)3 << 20);
+}
+
+// the binned pass over a band's slots in whatever order they are held (row-band shards: th_shard.hip)
+th_status deposit_prepare_bins(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p)
+{
+    TH_REQUIRE(u, "null uniforms");
+    TH_REQUIRE(c->ring.size() >= 2, "draw needs at least 2 state buffers (have %zu)", c->ring.size());
+    if (any_sorted(c)) if (th_status s = align_slot_orders(c)) return s;
+    c->last_binned_draw = c->total_steps;
+    return prepare_pass(c, u, p, true);
+}
+
 th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, bool want_bins, bool *bins)
 {
     TH_REQUIRE(u, "null uniforms");
@@ -74,6 +101,12 @@ th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::Depos
         if (th_status s = ensure_identity(c)) return s;      // the vertex stream addresses particles in texel order
         c->hold_texel_order_until = c->total_steps + c->opt.rebucket_steps;   // a frame loop of step + draw stays in texel order
     }
+    return prepare_pass(c, u, p, use_bins);
+}
+
+// per-line buffers + parameters of a pass whose pipeline is decided
+static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p, bool use_bins)
+{
     const size_t lines = c->texels();
     TH_REQUIRE((size_t)c->fw * c->fh > 0 && (uint64_t)c->cfg.width * c->cfg.global_height < (1ull << 32), "bad shapes");
     if (c->dep_lines != lines) {
@@ -291,8 +324,6 @@ static th_status deposit_run(th_context *c, th::DepositParams &p, uint64_t *frag
 }
 
 // the chunk store of the binned pipeline: nbins + pool chunks of keys (all empty) and varyings
-constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
-
 // The varyings are sized by the pass that needs them (one float4 per place; two once a th_draw has run) and the pool starts
 // at a quarter of the bins' first pages: the growth path is there (deposit_run_bins repeats a pass whose pool ran dry), and
 // at 1920 x 1080 the store is 0.9 GB for a flow-only host, 1.4 GB with both passes - not 2.7 GB up front.  A store that
@@ -320,41 +351,61 @@ static th_status bins_store(th_context *c, uint32_t nbins, uint32_t pool, bool p
 }
 
 constexpr double kEarlyBlendShare = 0.5;            // (of a draw's fragments in crowded bins: see deposit_run_bins)
-// the binned pipeline (th_bins.hip) over the (prepared) pass `p`: rasterise + emit into the bins, plan, per-bin order + blend
-static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
+// ---- the binned pipeline (th_bins.hip) over the (prepared) pass `p`, in three parts ------------------------------------------
+namespace thi {
+
+th_status bins_streams(th_context *c)
+{
+    if (c->side) return TH_OK;
+    TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
+    TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
+    TH_HIP(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
+    TH_HIP(hipEventCreateWithFlags(&c->joined2, hipEventDisableTiming));
+    TH_HIP(hipEventCreateWithFlags(&c->regrouped, hipEventDisableTiming));
+    TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
+    return TH_OK;
+}
+
+// the pass's totals to the host over the side stream (behind `forked`, recorded by the caller on the main stream)
+static th_status bins_totals(th_context *c)
+{
+    TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
+    TH_HIP(hipMemcpyAsync(c->bins_totals_host, c->dep_total, th::kTotWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
+    TH_HIP(hipStreamSynchronize(c->side));
+    return TH_OK;
+}
+
+th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least)
+{
+    // (TH_OPT_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
+    const uint32_t pool0 = c->opt.bins_pool;
+    uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 4u > 4096u ? p.nbins * 4u : 4096u));
+    if (pool < at_least) pool = at_least;
+    if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
+    p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
+    return TH_OK;
+}
+
+// Part 1: rasterise + emit into the bins, the plan; repeated with a larger pool when the pool ran dry (nothing has been
+// blended).  blend_early: the ordinary bins' blend goes out right behind the pass and covers the totals' read-back.
+// Leaves the totals in c->bins_totals_host.  kRetryInStreamOrder: a bin outgrew its lists (or the store cannot be had).
+th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
 {
     c->drawn.valid = false;
-    if (!c->side) {
-        TH_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        TH_HIP(hipEventCreateWithFlags(&c->forked, hipEventDisableTiming));
-        TH_HIP(hipEventCreateWithFlags(&c->joined, hipEventDisableTiming));
-        TH_HIP(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
-        TH_HIP(hipEventCreateWithFlags(&c->joined2, hipEventDisableTiming));
-        TH_HIP(hipEventCreateWithFlags(&c->regrouped, hipEventDisableTiming));
-        TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
-    }
+    if (th_status s = bins_streams(c)) return s;
     uint32_t *host = c->bins_totals_host;
-    // Which comes first behind the emitting pass: the ordinary bins' blend - it needs nothing from the host and covers the
-    // read-back - or, on a crowded target, the crowded bins' kernels: their long runs (walked by one thread each, on the
-    // side stream) are then the longest chain of the draw and must start as early as they can.  Decided by the last draw.
-    const bool early = !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
     for (int attempt = 0;; ++attempt) {
-        // (TH_BINS_POOL: the first pool's size in pages - tests make it small to run the growth path)
-        const uint32_t pool0 = c->opt.bins_pool;
-        const uint32_t pool = c->bins_pool ? c->bins_pool : (pool0 ? pool0 : (p.nbins * 4u > 4096u ? p.nbins * 4u : 4096u));
-        if (th_status s = bins_store(c, p.nbins, pool, p.mode == 2)) return s;
-        p.frag_keys = c->bins_keys; p.colors = c->bins_colors; p.pool_pages = c->bins_pool;
+        if (th_status s = bins_store_for(c, p, 0)) return s;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
         th::launch_bins_fused(p, c->stream);
         // the totals come back over the side stream while the ordinary bins are already being blended (the kernel looks at the
         // pass's flags itself): the host's round trip - it sizes the crowded bins' launches - costs the GPU nothing
         TH_HIP(hipEventRecord(c->forked, c->stream));
-        if (early) th::launch_bins_blend(p, c->stream);
-        TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
-        TH_HIP(hipMemcpyAsync(host, c->dep_total, th::kTotWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
-        TH_HIP(hipStreamSynchronize(c->side));
+        if (blend_early) th::launch_bins_blend(p, c->stream);
+        if (th_status s = bins_totals(c)) return s;
         const uint32_t flags = host[th::kTotFlags];
-        if (flags == 0) break;
+        if (flags == 0) return TH_OK;
         // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
         // outgrew its chunk table or a line its reservation, left to the stream-ordered pipeline
         TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
@@ -363,10 +414,17 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         const uint32_t want = 2u * host[th::kTotPool] + 64;      // (generously: growing the store costs a frame's worth of time)
         if (th_status s = bins_store(c, p.nbins, want, p.mode == 2)) return s;
     }
+}
+
+// Part 2: with the totals in c->bins_totals_host - the crowded bins regrouped and blended on the side streams, the ordinary
+// bins' blend unless it went out early.  `policy`: the draw counts for the auto policy (a single context's draws do).
+th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early, bool policy)
+{
+    uint32_t *host = c->bins_totals_host;
     const uint32_t total = host[th::kTotFragments], nlarge = host[th::kTotLarge];
     if (fragments) *fragments = total;
     c->last_draw.pipeline = TH_DRAW_BINS; c->last_draw.fragments = total; c->last_draw.crowded_fragments = host[th::kTotCrowdKeys];
-    {   // (auto policy: see draw_uses_bins)
+    if (policy) {   // (auto policy: see draw_uses_bins)
         const bool crowded = total > 0 && (double)host[th::kTotCrowdKeys] > kCrowdedShare * (double)total;
         c->crowded_streak = crowded ? c->crowded_streak + 1 : 0;
         if (!crowded) c->stream_spell = 0;
@@ -408,10 +466,31 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
         th::launch_bins_blend_crowd(p, c->side2);
         TH_HIP(hipEventRecord(c->joined2, c->side2));
     }
-    if (!early) th::launch_bins_blend(p, c->stream);
+    if (!blended_early) th::launch_bins_blend(p, c->stream);
     if (nlarge) { TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0)); }
     TH_HIP(hipGetLastError());
     return TH_OK;
+}
+
+// (row-band shards, th_shard.hip) the received bins are in the store, laid out by launch_bins_owner_insert: the totals of its
+// plan to the host
+th_status bins_pass_totals(th_context *c)
+{
+    TH_HIP(hipEventRecord(c->forked, c->stream));
+    return bins_totals(c);
+}
+
+}  // namespace thi
+
+static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t *fragments)
+{
+    if (th_status s = bins_streams(c)) return s;
+    // Which comes first behind the emitting pass: the ordinary bins' blend - it needs nothing from the host and covers the
+    // read-back - or, on a crowded target, the crowded bins' kernels: their long runs (walked by one thread each, on the
+    // side stream) are then the longest chain of the draw and must start as early as they can.  Decided by the last draw.
+    const bool early = !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
+    if (th_status s = bins_pass_emit(c, p, early)) return s;
+    return bins_pass_finish(c, p, fragments, early, true);
 }
 
 extern "C" {

@@ -166,6 +166,26 @@ struct DepositParams {
     uint32_t *crowd_long, *crowd_giant;            // texels of large bins whose runs one wave does not order (large bin << 8 | texel): up to kGiantRun fragments / more
 };
 
+// row-band shards drawing with the binned pipeline (th_bins.hip "the bins travel to the ranks that own them")
+struct OwnerParams {
+    uint32_t world, rank;
+    uint32_t bin_lo[33];                 // owner r owns the bins [bin_lo[r], bin_lo[r + 1]): whole bin rows of the target
+    // sender
+    uint32_t *counts;                    // [nbins] places per bin
+    unsigned long long *offsets;         // [nbins + 1] their exclusive scan: where each bin lies in the outgoing arrays
+    unsigned long long *owner_bounds;    // [world + 1] offsets at the owners' first bins (and the total)
+    unsigned long long *out_keys;
+    float4 *out_colors;
+    // owner
+    uint32_t nb;                         // my bins
+    const uint32_t *table;               // [world][nb] what every source holds for each of my bins
+    unsigned long long *src_prefix;      // [world][nb] where each of my bins starts inside that source's part
+    uint32_t *bin_total;                 // [nb]
+    const unsigned long long *recv_base; // [world] first fragment of every source's part in the received arrays
+    const unsigned long long *in_keys;
+    const float4 *in_colors;
+};
+
 struct TrianglePoly {           // a clipped, snapped, oriented triangle (th_deposit.hip)
     int32_t n;
     int32_t x[8], y[8];
@@ -227,6 +247,9 @@ constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits
 enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWords = 8 };
 enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
+void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
+void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
+void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
 void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs of more fragments than a wave orders (the longest first)
 void launch_bins_blend_crowd(const DepositParams &p, hipStream_t stream);             // their other runs, a wave each: order by stream index, blend

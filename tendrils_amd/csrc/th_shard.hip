@@ -159,6 +159,7 @@ th_status th_draw_merge(th_context *c, const void *keys_dev, const void *colors_
 // waiting inside a collective: before every exchange whose size or success depends on something rank-local, the ranks
 // agree on a status word, and all of them leave together.
 constexpr unsigned long long kPeerFailed = 1ull << 62;       // (a count travels below bit 31)
+constexpr unsigned long long kPeerRetries = 1ull << 61;      // ... a rank whose binned pass gave up: everybody takes the stream-ordered pass
 
 // (tests: TH_OPT_INJECT_FAILURE) this rank fails at `stage` once
 static th_status injected(th_context *c, int stage)
@@ -178,13 +179,15 @@ static th_status agree_status(th_context *c, th_status mine, const char *stage)
 {
     if (c->comm_world <= 1) return mine;
     const std::string why = mine != TH_OK ? last_error() : std::string();
-    const uint32_t word = mine != TH_OK ? (((uint32_t)(c->comm_world - c->comm_rank)) | 0x10000u) : 0u;      // the lowest failing rank wins the maximum
+    // the lowest failing rank wins the maximum; a failure (2) outranks a binned pass that only wants the stream-ordered pass (1)
+    const uint32_t word = mine != TH_OK ? (((uint32_t)(c->comm_world - c->comm_rank)) | (mine == kRetryInStreamOrder ? 0x10000u : 0x20000u)) : 0u;
     hipError_t e = hipMemcpyAsync(c->d_status, &word, sizeof word, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // (`word` is a stack variable)
     if (c->transport->allreduce_max_u32(c->comm, c->d_status, c->stream)) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
     uint32_t worst = 0;
     if (th_status s = read_back(c, &worst, c->d_status, sizeof worst)) return s;
     TH_HIP(e);
+    if ((worst >> 16) == 1u) return kRetryInStreamOrder;              // (every rank returns this together)
     if (mine != TH_OK) { last_error() = why; return mine; }
     if (worst) return peer_failure(c, c->comm_world - (int)(worst & 0xffffu), stage);
     return TH_OK;
@@ -293,6 +296,148 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     return TH_OK;
 }
 
+// The same pass through the BINS (th_bins.hip "the bins travel to the ranks that own them"): every rank rasterises its band's
+// lines into its own page store over whatever slot order its ring is held in (the integrator's tile-sorted one: no return to
+// texel order, no 64-bit keys, no sort anywhere); an owner owns whole bin rows; the bins change hands bin by bin with their
+// counts beside them and are laid out in the owner's store as if it had emitted them; plan and blend kernels as in a single
+// context.  kRetryInStreamOrder (on every rank together): a store could not be had or a bin outgrew its lists - the caller
+// runs the stream-ordered pass.
+static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
+{
+    const int world = c->comm_world, rank = c->comm_rank;
+    const bool view = ru != nullptr, both = ru != nullptr && du != nullptr;
+    th_deposit_uniforms d{};
+    if (du) d = *du; else { d.viewSize[0] = ru->viewSize[0]; d.viewSize[1] = ru->viewSize[1]; d.time = ru->time; d.speedLimit = ru->speedLimit; }
+    // ---- stage 1: my band's lines into my store, then compacted owner by owner
+    th::DepositParams p;
+    th::OwnerParams o{};
+    uint32_t *host = nullptr;
+    std::vector<unsigned long long> hb((size_t)world + 1, 0ull);
+    auto stage1 = [&]() -> th_status {
+        if (th_status s = injected(c, 2)) return s;
+        if (th_status s = deposit_prepare_bins(c, &d, p)) return s;
+        p.mode = both ? 2 : (view ? 1 : 0);
+        if (view) { view_fields(c, ru, p); p.view = c->view; if (!both) p.line_half = 0.5f * drawn_line_width(c, TH_PASS_VIEW); }
+        if (th_status s = bins_pass_emit(c, p, false)) return s;
+        host = c->bins_totals_host;
+        const uint32_t bins_y = p.nbins / p.bins_x;
+        o.world = (uint32_t)world; o.rank = (uint32_t)rank;
+        for (int r = 0; r <= world; ++r) o.bin_lo[r] = (uint32_t)((unsigned long long)bins_y * (unsigned)r / (unsigned)world) * p.bins_x;
+        o.nb = o.bin_lo[rank + 1] - o.bin_lo[rank];
+        if (c->own_bins < p.nbins) {
+            TH_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->own_mem); c->own_mem = nullptr; c->own_bins = 0;
+            const size_t words = (size_t)p.nbins * (1 + 2 + 1 + 32 * 1 + 32 * 2) + 2 * (2 + 33 + 32) + 64;
+            TH_HIP(hipMalloc(&c->own_mem, words * sizeof(uint32_t)));
+            c->own_bins = p.nbins;
+        }
+        unsigned long long *q = static_cast<unsigned long long *>(c->own_mem);           // (the 8-byte arrays first)
+        o.offsets = q; q += (size_t)p.nbins + 1;
+        o.owner_bounds = q; q += 33;
+        unsigned long long *recv_base = q; q += 32;
+        o.recv_base = recv_base;
+        o.src_prefix = q; q += (size_t)32 * p.nbins;
+        uint32_t *w = reinterpret_cast<uint32_t *>(q);
+        o.counts = w; w += p.nbins;
+        o.bin_total = w; w += p.nbins;
+        o.table = w;
+        const uint32_t total = host[th::kTotFragments];
+        if (total) {
+            if (th_status s = deposit_reserve(c, total, true, both)) return s;
+            o.out_keys = c->dep_u64[0]; o.out_colors = c->dep_colors;
+        }
+        th::launch_bins_owner_counts(p, o, c->stream);
+        if (total) th::launch_bins_owner_extract(p, o, c->stream);
+        TH_HIP(hipGetLastError());
+        return read_back(c, hb.data(), o.owner_bounds, ((size_t)world + 1) * sizeof(unsigned long long));
+    };
+    th_status mine = stage1();
+    const std::string why = mine != TH_OK ? last_error() : std::string();
+    if (mine != TH_OK) std::fill(hb.begin(), hb.end(), 0ull);
+    if (fragments) *fragments = mine == TH_OK ? hb[(size_t)world] : 0;
+    unsigned long long *sendc = c->x_counts + 33, *recvc = c->x_counts + 65;
+    std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
+    std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        scount[(size_t)r] = (size_t)(hb[(size_t)r + 1] - hb[(size_t)r]); soff[(size_t)r] = (size_t)hb[(size_t)r]; idx[(size_t)r] = (size_t)r;
+        hs[(size_t)r] = scount[(size_t)r] | (mine == TH_OK ? 0ull : (mine == kRetryInStreamOrder ? kPeerRetries : kPeerFailed));
+    }
+    TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    if (c->transport->alltoallv(c->comm, sendc, one.data(), idx.data(), recvc, one.data(), idx.data(), sizeof(unsigned long long), world, c->stream))
+        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    if (th_status s = read_back(c, hr.data(), recvc, (size_t)world * sizeof(unsigned long long))) return s;
+    if (mine != TH_OK && mine != kRetryInStreamOrder) { last_error() = why; return mine; }
+    for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerFailed) return peer_failure(c, r, "rasterising its band's lines");
+    for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerRetries) return kRetryInStreamOrder;
+    size_t total = 0;
+    for (int r = 0; r < world; ++r) { rcount[(size_t)r] = (size_t)(hr[(size_t)r] & 0xffffffffull); roff[(size_t)r] = total; total += rcount[(size_t)r]; }
+    // ---- stage 2: every source's counts for my bins; room for what arrives; my store laid out for it (the last things that can
+    // fail on one rank alone: agreed on before the fragments travel)
+    {
+        std::vector<size_t> tc((size_t)world), to((size_t)world), rc((size_t)world, o.nb), ro((size_t)world);
+        for (int r = 0; r < world; ++r) { tc[(size_t)r] = o.bin_lo[r + 1] - o.bin_lo[r]; to[(size_t)r] = o.bin_lo[r]; ro[(size_t)r] = (size_t)r * o.nb; }
+        if (c->transport->alltoallv(c->comm, o.counts, tc.data(), to.data(), const_cast<uint32_t *>(o.table), rc.data(), ro.data(), sizeof(uint32_t), world, c->stream))
+            return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    }
+    auto stage2 = [&]() -> th_status {
+        if (th_status s = injected(c, 3)) return s;
+        if (total >= ((size_t)1 << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one owner");
+        if (c->x_capacity < total || (both && !c->x_pairs)) {
+            (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
+            c->x_keys = nullptr; c->x_colors = nullptr;
+            const size_t cap = std::max(total, c->x_capacity) + total / 4 + 1024;
+            c->x_capacity = 0;
+            c->x_pairs = c->x_pairs || both;
+            TH_HIP(hipMalloc((void **)&c->x_keys, cap * sizeof(unsigned long long)));
+            TH_HIP(hipMalloc((void **)&c->x_colors, (c->x_pairs ? 2 : 1) * cap * sizeof(float4)));
+            c->x_capacity = cap;
+        }
+        std::vector<unsigned long long> base((size_t)world);
+        for (int r = 0; r < world; ++r) base[(size_t)r] = roff[(size_t)r];
+        TH_HIP(hipMemcpyAsync(const_cast<unsigned long long *>(o.recv_base), base.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));                   // (`base` is a local)
+        return TH_OK;
+    };
+    mine = stage2();
+    if (th_status s = agree_status(c, mine, "making room for the bins it owns")) return s;
+    // ---- stage 3: the bins travel; laid out and blended where they are owned; the owned rows back to everybody
+    if (c->transport->alltoallv(c->comm, o.out_keys, scount.data(), soff.data(), c->x_keys, rcount.data(), roff.data(), sizeof(unsigned long long), world, c->stream) ||
+        c->transport->alltoallv(c->comm, o.out_colors, scount.data(), soff.data(), c->x_colors, rcount.data(), roff.data(), both ? 2 * sizeof(float4) : sizeof(float4), world, c->stream))
+        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    o.in_keys = c->x_keys; o.in_colors = c->x_colors;
+    th_status laid = TH_OK;
+    for (int attempt = 0;; ++attempt) {
+        TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
+        th::launch_bins_owner_insert(p, o, c->stream);
+        TH_HIP(hipGetLastError());
+        if (th_status s = bins_pass_totals(c)) return s;
+        const uint32_t flags = host[th::kTotFlags];
+        if (flags == 0) break;
+        // (nothing of mine has been blended; a bin beyond its lists' reach cannot be drawn through the bins at all)
+        if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) { laid = fail(TH_ERR_UNSUPPORTED, "a bin of the target received more fragments than its lists hold (%u places)", th::kBinMaxPages * th::kBinPage * th::kBinReplicas); break; }
+        TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t), c->stream));
+        if ((laid = bins_store_for(c, p, host[th::kTotPool] + 64u)) != TH_OK) break;
+    }
+    if (laid == TH_OK) laid = bins_pass_finish(c, p, nullptr, false, false);
+    // (an owner that could not lay its bins out has blended nothing; the others have: the draw is lost, and everybody says so)
+    if (th_status s = agree_status(c, laid == kRetryInStreamOrder ? fail(TH_ERR_HIP, "the owner's store could not be had") : laid, "laying out the bins it owns")) return s;
+    const uint32_t bins_y = p.nbins / p.bins_x;
+    for (int plane_of = 0; plane_of < 2; ++plane_of) {          // 0: the flow texture, 1: the view buffer
+        if (plane_of == 0 ? (view && !both) : !view) continue;
+        const size_t elem = plane_of ? sizeof(uchar4) : sizeof(float4);
+        std::vector<size_t> gb((size_t)world), go((size_t)world);
+        for (int r = 0; r < world; ++r) {
+            const size_t row_lo = std::min<size_t>((size_t)c->fh, ((size_t)bins_y * (size_t)r / (size_t)world) << th::kBinShift);
+            const size_t row_hi = std::min<size_t>((size_t)c->fh, ((size_t)bins_y * ((size_t)r + 1) / (size_t)world) << th::kBinShift);
+            gb[(size_t)r] = (row_hi - row_lo) * (size_t)c->fw * elem; go[(size_t)r] = row_lo * (size_t)c->fw * elem;
+        }
+        char *plane = plane_of ? reinterpret_cast<char *>(c->view) : reinterpret_cast<char *>(c->flow);
+        if (c->transport->allgather_bytes(c->comm, plane + go[(size_t)rank], plane, gb.data(), go.data(), rank, world, c->stream))
+            return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+    }
+    return TH_OK;
+}
+
 th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
 {
     if (th_status s = use(c)) return s;
@@ -316,8 +461,10 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
     // the neighbouring bands' edge rows of both state buffers (the fp32 row lookup of the vertex stream can land one row
     // beside a line's own row for some texture heights): my first row to the rank below, my last row to the rank above.
     // A packed ring sends the rows of its f32 views - what the stored texels decode to, what the lines are made of.
+    // (a job that draws through the bins needs none of it: there every vertex of every line is the line's own particle)
+    const bool bins = binned_shards(c);
     c->halo_lo = c->halo_hi = nullptr;
-    if (world > 1) {
+    if (world > 1 && !bins) {
         th_status mine = c->packed ? injected(c, 1) : TH_OK;
         if (mine == TH_OK) mine = ensure_identity(c);
         const float4 *state[2] = {nullptr, nullptr};
@@ -342,12 +489,19 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
         c->halo_hi = rank + 1 < world ? c->x_halo + (size_t)2 * W : nullptr;
     }
     c->dep_owners = (uint32_t)world;
+    auto pass = [&](const th_deposit_uniforms *d, const th_render_uniforms *r, uint64_t *n) -> th_status {
+        if (bins) {
+            const th_status s = sharded_pass_bins(c, d, r, n);
+            if (s != kRetryInStreamOrder) return s;          // (on every rank together: the stream-ordered pass instead)
+        }
+        return sharded_pass(c, d, r, n);
+    };
     if (ru && drawn_line_width(c, TH_PASS_FLOW) == drawn_line_width(c, TH_PASS_VIEW)) {
-        // both passes draw the same lines: one rasterisation, one sort, one exchange of fragments carrying both varyings
-        if (th_status s = sharded_pass(c, du, ru, fragments)) return s;
+        // both passes draw the same lines: one rasterisation, one exchange of fragments carrying both varyings
+        if (th_status s = pass(du, ru, fragments)) return s;
     } else {
-        if (th_status s = sharded_pass(c, du, nullptr, fragments)) return s;
-        if (ru) if (th_status s = sharded_pass(c, nullptr, ru, nullptr)) return s;
+        if (th_status s = pass(du, nullptr, fragments)) return s;
+        if (ru) if (th_status s = pass(nullptr, ru, nullptr)) return s;
     }
     TH_HIP(hipStreamSynchronize(c->stream));
     return TH_OK;

@@ -68,10 +68,13 @@ def in_threads(world, body):
     return out, err
 
 
-def world_of(n, view, world, cur, prev, base, fmt="f32"):
+def world_of(n, view, world, cur, prev, base, fmt="f32", pipeline=None):
     from tendrils_amd import sharding
     ident = sharding.loopback_id()
     shards = [make(n, view, cur, prev, base, sharding.shard_rows(n, world, r), fmt) for r in range(world)]
+    if pipeline:
+        for t in shards:
+            t.particles.draw_pipeline(pipeline)
     _, err = in_threads(world, lambda r: sharding.comm_join(shards[r].particles._ctx, ident, r, world))
     assert err == [None] * world, err
     assert all(sharding.comm_query(t.particles._ctx)["world"] == world for t in shards)
@@ -103,6 +106,52 @@ def test_draw_sharded_over_loopback_equals_unsharded(n, view, world, fmt):
                 assert bits_equal(t.flow.read(), want_flow).all()
                 assert (t.read_view() == want_view).all()
     for t in shards:
+        t.dispose()
+
+
+def last_pipeline(t):
+    from tendrils_amd import _capi
+    info = _capi.DrawInfo()
+    _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
+    return info.pipeline
+
+
+@pytest.mark.parametrize("n,view,world,spread,sorted_slots", [(64, (96, 54), 2, 0.9, False), (128, (50, 27), 3, 0.9, True),
+                                                              (256, (96, 54), 4, 0.15, True), (256, (40, 200), 3, 0.9, False)])
+def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, sorted_slots):
+    """The sharded draw() through the binned pipeline (th_bins.hip: the bins travel to the ranks that own them): every rank
+    rasterises into its own page store, whole bin rows change hands with their counts, the owner lays them out as if it had
+    emitted them and blends with the unchanged kernels.  spread 0.15 at 256^2: bins of tens of thousands of fragments (pool
+    pages in the owner's layout, the crowded bins' kernels); 40 x 200 texels over 3 owners: 13 bin rows, 4 / 4 / 5 each;
+    sorted_slots: after a step over tile-sorted slots (the bands keep their order: no return to texel order)."""
+    from tendrils_amd import sharding
+    cur, prev, base = inputs(n, view, 31 * n + world, spread)
+    one = make(n, view, cur, prev, base)
+    shards = world_of(n, view, world, cur, prev, base, pipeline="bins")
+    everybody = [one] + shards
+    if sorted_slots:
+        for t in everybody:
+            t.particles.option("bucket", 1)
+            t.state["noiseWeight"] = 0.0005
+    for frame in range(3):
+        for t in everybody:
+            t.timer.tick()
+            if sorted_slots:
+                t.step()
+        one.draw()
+        frags, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+        assert err == [None] * world, err
+        assert sum(frags) == one.fragments > 1000
+        want_flow, want_view = one.flow.read(), one.read_view()
+        for t in shards:
+            assert last_pipeline(t) == 1                       # TH_DRAW_BINS
+            assert bits_equal(t.flow.read(), want_flow).all()
+            assert (t.read_view() == want_view).all()
+    if sorted_slots:                                           # the bands stepped over sorted slots all along
+        info = __import__("tendrils_amd")._capi.SlotOrderInfo()
+        __import__("tendrils_amd")._capi.call("th_slot_order", shards[0].particles._ctx, C.byref(info))
+        assert info.sorted_buffers == 2
+    for t in everybody:
         t.dispose()
 
 
