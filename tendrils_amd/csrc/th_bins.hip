@@ -1247,10 +1247,12 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
 // per-bin counts beside it), exchanged, and laid out in the owner's page store exactly as if the owner had emitted it: cursors,
 // pages from the pool, page table - so that the plan and every blend kernel run unchanged.  The order inside a bin is of no
 // consequence (the blend restores GL's order from the keys), so nothing is sorted anywhere on the way.
-//   owner_counts_kernel    places per bin, their exclusive scan (= where each bin goes in the outgoing arrays), the owners' bounds
+//   owner_places_kernel, owner_counts_kernel   places per bin; their exclusive scan (= where each bin goes in the outgoing
+//                          arrays) and the owners' bounds
 //   owner_extract_kernel   a workgroup per bin: its lists walked, fragments copied out; the lists' pages forgotten
 //   owner_prefix_kernel    (owner) per source: where each of my bins starts inside that source's part
-//   owner_layout_kernel    (owner) per bin: places in all, list lengths, pool pages, page table, cursors
+//   owner_totals_kernel, owner_pages_kernel, owner_layout_kernel   (owner) per bin: places in all; pool pages (a scan);
+//                          cursors and page table, a thread per list
 //   owner_insert_kernel    (owner) a workgroup per bin: every source's fragments of the bin copied to their places
 
 // all threads of a 1024-thread workgroup: `mine` -> its exclusive prefix over the workgroup; `total` (same on every thread)
@@ -1270,28 +1272,28 @@ TH_D unsigned long long block_scan_1024(unsigned long long *lds, unsigned long l
     return lds[t] - mine;
 }
 
+__global__ __launch_bounds__(256) void owner_places_kernel(const DepositParams p, const OwnerParams o)
+{
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b < p.nbins) o.counts[b] = bin_places(p, b);
+}
+
 __global__ __launch_bounds__(1024) void owner_counts_kernel(const DepositParams p, const OwnerParams o)
 {
     __shared__ unsigned long long lds[1024];
     const uint32_t per = (p.nbins + 1023u) / 1024u, lo = threadIdx.x * per < p.nbins ? threadIdx.x * per : p.nbins, hi = lo + per < p.nbins ? lo + per : p.nbins;
     unsigned long long n = 0, total = 0;
-    for (uint32_t b = lo; b < hi; ++b) n += bin_places(p, b);
+    for (uint32_t b = lo; b < hi; ++b) n += o.counts[b];
     unsigned long long run = block_scan_1024(lds, n, total);
     for (uint32_t b = lo; b < hi; ++b) {
-        const uint32_t c = bin_places(p, b);
-        o.counts[b] = c;
+        for (uint32_t r = 0; r < o.world; ++r) if (o.bin_lo[r] == b) o.owner_bounds[r] = run;
         o.offsets[b] = run;
-        run += c;
+        run += o.counts[b];
     }
-    if (threadIdx.x == 0u) o.offsets[p.nbins] = total;
-    __syncthreads();
-    __threadfence_block();
-    if (threadIdx.x <= o.world) o.owner_bounds[threadIdx.x] = threadIdx.x == o.world ? total : 0ull;
-    __syncthreads();
-    // (the bounds are read from the offsets just written: by the threads that wrote them or after the barrier above)
-    for (uint32_t b = lo; b < hi; ++b)
-        for (uint32_t r = 0; r < o.world; ++r) if (o.bin_lo[r] == b) o.owner_bounds[r] = o.offsets[b];
-    if (threadIdx.x == 0u) for (uint32_t r = 0; r < o.world; ++r) if (o.bin_lo[r] >= p.nbins) o.owner_bounds[r] = total;
+    if (threadIdx.x == 0u) {
+        o.offsets[p.nbins] = total;
+        for (uint32_t r = 0; r <= o.world; ++r) if (o.bin_lo[r] >= p.nbins) o.owner_bounds[r] = total;
+    }
 }
 
 // the places of bin b walked list after list: place f of the walk (lists[] = first place of every list, lists[kBinReplicas] = all)
@@ -1346,37 +1348,45 @@ TH_D uint32_t owner_list_len(uint32_t total)
     return (per + kBinPage - 1u) / kBinPage * kBinPage;
 }
 
-__global__ __launch_bounds__(1024) void owner_layout_kernel(const DepositParams p, const OwnerParams o)
+// per bin of mine: places in all (0 and a flag when they are more than a bin's lists can hold)
+__global__ __launch_bounds__(256) void owner_totals_kernel(const DepositParams p, const OwnerParams o)
+{
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= o.nb) return;
+    unsigned long long total = 0;
+    for (uint32_t s = 0; s < o.world; ++s) total += o.table[(size_t)s * o.nb + b];
+    if (total > (unsigned long long)kBinMaxPages * kBinPage * kBinReplicas) { bins_flag(p, kBinsBinFull); total = 0; }
+    o.bin_total[b] = (uint32_t)total;
+}
+
+// the pool pages every bin of mine needs, and the first of them (o.bin_page: their exclusive scan); the pool's use in totals
+__global__ __launch_bounds__(1024) void owner_pages_kernel(const DepositParams p, const OwnerParams o)
 {
     __shared__ unsigned long long lds[1024];
-    const uint32_t b0 = o.bin_lo[o.rank];
     const uint32_t per = (o.nb + 1023u) / 1024u, lo = threadIdx.x * per < o.nb ? threadIdx.x * per : o.nb, hi = lo + per < o.nb ? lo + per : o.nb;
     unsigned long long pages = 0, all = 0;
-    bool full = false;
-    for (uint32_t b = lo; b < hi; ++b) {
-        unsigned long long total = 0;
-        for (uint32_t s = 0; s < o.world; ++s) total += o.table[(size_t)s * o.nb + b];
-        if (total > (unsigned long long)kBinMaxPages * kBinPage * kBinReplicas) { full = true; total = 0; }
-        o.bin_total[b] = (uint32_t)total;
-        pages += (unsigned long long)(owner_list_len((uint32_t)total) / kBinPage - 1u) * kBinReplicas;
-    }
+    for (uint32_t b = lo; b < hi; ++b) pages += (unsigned long long)(owner_list_len(o.bin_total[b]) / kBinPage - 1u) * kBinReplicas;
     unsigned long long first = block_scan_1024(lds, pages, all);
-    if (full) bins_flag(p, kBinsBinFull);
+    for (uint32_t b = lo; b < hi; ++b) {
+        o.bin_page[b] = (uint32_t)(first > 0xffffffffull ? 0xffffffffull : first);
+        first += (unsigned long long)(owner_list_len(o.bin_total[b]) / kBinPage - 1u) * kBinReplicas;
+    }
     if (threadIdx.x == 0u) {
         p.totals[kTotPool] = (uint32_t)(all > 0xffffffffull ? 0xffffffffull : all);
-        if (all > p.pool_pages) bins_flag(p, kBinsPoolExhausted);
+        if (all > p.pool_pages) bins_flag(p, kBinsPoolExhausted);      // (the host grows the store and lays the bins out again)
     }
-    if (all > p.pool_pages) return;                     // (the host grows the store and lays the bins out again)
-    for (uint32_t b = lo; b < hi; ++b) {
-        const uint32_t total = o.bin_total[b], len = owner_list_len(total), extra = len / kBinPage - 1u, bin = b0 + b;
-        for (uint32_t r = 0; r < kBinReplicas; ++r) {
-            const unsigned long long begin = (unsigned long long)r * len;
-            *list_cursor(p, bin, r) = total > begin ? (uint32_t)(total - begin < len ? total - begin : len) : 0u;
-            for (uint32_t n = 1; n <= extra; ++n)
-                p.page_table[(size_t)(bin * kBinReplicas + r) * kBinMaxPages + n] = p.nbins * kBinReplicas + (uint32_t)first + r * extra + (n - 1u);
-        }
-        first += (unsigned long long)extra * kBinReplicas;
-    }
+}
+
+// a bin's cursors and page table, one thread per list
+__global__ __launch_bounds__(256) void owner_layout_kernel(const DepositParams p, const OwnerParams o)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, b = i / kBinReplicas, r = i - b * kBinReplicas;
+    if (b >= o.nb || p.totals[kTotFlags] != 0u) return;
+    const uint32_t total = o.bin_total[b], len = owner_list_len(total), extra = len / kBinPage - 1u, bin = o.bin_lo[o.rank] + b;
+    const unsigned long long begin = (unsigned long long)r * len;
+    *list_cursor(p, bin, r) = total > begin ? (uint32_t)(total - begin < len ? total - begin : len) : 0u;
+    for (uint32_t n = 1; n <= extra; ++n)
+        p.page_table[(size_t)(bin * kBinReplicas + r) * kBinMaxPages + n] = p.nbins * kBinReplicas + o.bin_page[b] + r * extra + (n - 1u);
 }
 
 template <bool PAIRS>
@@ -1422,6 +1432,7 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
 // sender: places per bin, their offsets in the outgoing arrays, the owners' bounds (o.owner_bounds: world + 1 values)
 void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t s)
 {
+    hipLaunchKernelGGL(owner_places_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p, o);
     hipLaunchKernelGGL(owner_counts_kernel, dim3(1), dim3(1024), 0, s, p, o);
 }
 // sender: every bin's fragments into o.out_keys / o.out_colors at o.offsets; the store is left ready for the next emit
@@ -1436,8 +1447,10 @@ void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipS
 {
     (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
     hipLaunchKernelGGL(owner_prefix_kernel, dim3(o.world), dim3(1024), 0, s, o);
-    hipLaunchKernelGGL(owner_layout_kernel, dim3(1), dim3(1024), 0, s, p, o);
     if (o.nb) {
+        hipLaunchKernelGGL(owner_totals_kernel, dim3((o.nb + 255u) / 256u), dim3(256), 0, s, p, o);
+        hipLaunchKernelGGL(owner_pages_kernel, dim3(1), dim3(1024), 0, s, p, o);
+        hipLaunchKernelGGL(owner_layout_kernel, dim3((o.nb * kBinReplicas + 255u) / 256u), dim3(256), 0, s, p, o);
         if (p.mode == 2) hipLaunchKernelGGL(owner_insert_kernel<true>, dim3(o.nb), dim3(256), 0, s, p, o);
         else hipLaunchKernelGGL(owner_insert_kernel<false>, dim3(o.nb), dim3(256), 0, s, p, o);
     }

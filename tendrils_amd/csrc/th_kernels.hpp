@@ -181,6 +181,7 @@ struct OwnerParams {
     const uint32_t *table;               // [world][nb] what every source holds for each of my bins
     unsigned long long *src_prefix;      // [world][nb] where each of my bins starts inside that source's part
     uint32_t *bin_total;                 // [nb]
+    uint32_t *bin_page;                  // [nb] first pool page of the bin's lists
     const unsigned long long *recv_base; // [world] first fragment of every source's part in the received arrays
     const unsigned long long *in_keys;
     const float4 *in_colors;

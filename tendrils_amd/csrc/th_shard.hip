@@ -327,7 +327,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         if (c->own_bins < p.nbins) {
             TH_HIP(hipStreamSynchronize(c->stream));
             (void)hipFree(c->own_mem); c->own_mem = nullptr; c->own_bins = 0;
-            const size_t words = (size_t)p.nbins * (1 + 2 + 1 + 32 * 1 + 32 * 2) + 2 * (2 + 33 + 32) + 64;
+            const size_t words = (size_t)p.nbins * (1 + 2 + 1 + 1 + 32 * 1 + 32 * 2) + 2 * (2 + 33 + 32) + 64;
             TH_HIP(hipMalloc(&c->own_mem, words * sizeof(uint32_t)));
             c->own_bins = p.nbins;
         }
@@ -340,6 +340,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         uint32_t *w = reinterpret_cast<uint32_t *>(q);
         o.counts = w; w += p.nbins;
         o.bin_total = w; w += p.nbins;
+        o.bin_page = w; w += p.nbins;
         o.table = w;
         const uint32_t total = host[th::kTotFragments];
         if (total) {
@@ -382,7 +383,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     auto stage2 = [&]() -> th_status {
         if (th_status s = injected(c, 3)) return s;
         if (total >= ((size_t)1 << 31)) return fail(TH_ERR_UNSUPPORTED, "too many fragments for one owner");
-        if (c->x_capacity < total || (both && !c->x_pairs)) {
+        if (world > 1 && (c->x_capacity < total || (both && !c->x_pairs))) {
             (void)hipFree(c->x_keys); (void)hipFree(c->x_colors);
             c->x_keys = nullptr; c->x_colors = nullptr;
             const size_t cap = std::max(total, c->x_capacity) + total / 4 + 1024;
@@ -401,10 +402,13 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     mine = stage2();
     if (th_status s = agree_status(c, mine, "making room for the bins it owns")) return s;
     // ---- stage 3: the bins travel; laid out and blended where they are owned; the owned rows back to everybody
-    if (c->transport->alltoallv(c->comm, o.out_keys, scount.data(), soff.data(), c->x_keys, rcount.data(), roff.data(), sizeof(unsigned long long), world, c->stream) ||
-        c->transport->alltoallv(c->comm, o.out_colors, scount.data(), soff.data(), c->x_colors, rcount.data(), roff.data(), both ? 2 * sizeof(float4) : sizeof(float4), world, c->stream))
-        return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
-    o.in_keys = c->x_keys; o.in_colors = c->x_colors;
+    if (world == 1) { o.in_keys = o.out_keys; o.in_colors = o.out_colors; }        // (nobody to send to: the compacted parts are the received ones)
+    else {
+        if (c->transport->alltoallv(c->comm, o.out_keys, scount.data(), soff.data(), c->x_keys, rcount.data(), roff.data(), sizeof(unsigned long long), world, c->stream) ||
+            c->transport->alltoallv(c->comm, o.out_colors, scount.data(), soff.data(), c->x_colors, rcount.data(), roff.data(), both ? 2 * sizeof(float4) : sizeof(float4), world, c->stream))
+            return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+        o.in_keys = c->x_keys; o.in_colors = c->x_colors;
+    }
     th_status laid = TH_OK;
     for (int attempt = 0;; ++attempt) {
         TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
