@@ -498,8 +498,6 @@ th_status th_stats_async(th_context *c, float speed_limit, void **device_counter
 {
     if (th_status s = use(c, true)) return s;
     TH_REQUIRE(!c->ring.empty(), "no state buffers");
-    float4 *view = nullptr;
-    if (th_status s = unpacked_view(c, c->ring[0], 0, &view)) return s;
     if (c->fused_stats.valid && c->fused_stats.buf == c->ring[0] && memcmp(&c->fused_stats.limit, &speed_limit, sizeof speed_limit) == 0) {
         // the launch that wrote this state took its statistics on the way (th_step_n): only the fold is left
         const uint32_t n = c->fused_stats.nparts;
@@ -508,6 +506,8 @@ th_status th_stats_async(th_context *c, float speed_limit, void **device_counter
         if (device_counters) *device_counters = c->d_counters;
         return TH_OK;
     }
+    float4 *view = nullptr;                      // (a packed ring: the f32 copy of what its texels decode to)
+    if (th_status s = unpacked_view(c, c->ring[0], 0, &view)) return s;
     th::launch_stats(view, c->texels(), speed_limit, c->partials, c->d_respawned, c->d_counters, c->stream);
     TH_HIP(hipGetLastError());
     if (device_counters) *device_counters = c->d_counters;

@@ -11,14 +11,13 @@
 //      every covered texel's fragment - (texel, stream index) key + varying(s) - goes straight into the bin it falls
 //      into.  No counting pass: a bin is kBinReplicas LISTS of PAGES of kBinPage places (page 0 of list r of bin b is
 //      page b * kBinReplicas + r - a bin's first pages lie side by side - further pages come from a pool as a list
-//      grows); a line reserves an upper bound of its fragments per bin - from the bounding box of its snapped hexagon,
-//      before it is rasterised - the reservations of a workgroup's lines are added up in an LDS table, ONE global atomic
+//      grows); a line is rasterised in registers first (a record of <= kRecordTexels texels) and reserves EXACTLY its
+//      fragments per bin - the reservations of a workgroup's lines are added up in an LDS table, ONE global atomic
 //      per (workgroup, bin) moves the cursor of the list the workgroup uses (a crowded bin is met by thousands of
 //      workgroups, and device-wide atomics on one cache line are served one after the other at the memory side - a
 //      thousand of them set the time of a whole pass - hence the lists, their cursors kept bin_stride words apart), and the
-//      workgroup whose reservation crosses into a new page takes that page from the pool and publishes it.  Places
-//      reserved and not used stay empty (key ~0: every reader of a key leaves ~0 behind, so the store starts every
-//      pass empty).
+//      workgroup whose reservation crosses into a new page takes that page from the pool and publishes it.  Every place
+//      handed out is written (a pass that ran out of pages is flagged and repeated before anything reads it).
 //      bins_listed_kernel: the few lines that cross the view's edge (clipped) and the lines of more fragments than a record
 //      holds, one place at a time.
 //   2. bins_plan_kernel / crowd_plan_kernel: the bins of more than kBinCap places ("large").
