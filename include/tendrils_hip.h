@@ -427,7 +427,8 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
  *   TH_OPT_DRAW_REUSE      the stream-ordered view pass reuses the flow pass's rasterisation and sort (default 1)
  *   TH_OPT_BINS_POOL       first size, in pages, of the binned pipeline's page pool (default 0: by the target's size)
  *   TH_OPT_INJECT_FAILURE  (tests) the next th_draw_sharded of THIS context fails on its own at stage 1 (its edge rows; packed rings), 2
- *                          (rasterising its lines) or 3 (making room for what it owns); the switch resets itself.  What is
+ *                          (rasterising its lines) or 3 (making room for what it owns); 4: its binned pass gives up (every rank takes the stream-ordered pass, the draw succeeds);
+ *                          the switch resets itself.  What is
  *                          tested: every other rank of the job returns an error too instead of waiting in a collective */
 enum { TH_OPT_BUCKET = 0, TH_OPT_RESORT_STEPS = 1, TH_OPT_REBUCKET_STEPS = 2, TH_OPT_FUSE = 3, TH_OPT_GRAPH = 4,
        TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_INJECT_FAILURE = 8 };

@@ -615,7 +615,7 @@ th_status th_option_set(th_context *c, int32_t option, int64_t value)
     case TH_OPT_FORCE_GENERIC: o.force_generic = value != 0; break;
     case TH_OPT_DRAW_REUSE: o.draw_reuse = value != 0; break;
     case TH_OPT_BINS_POOL: TH_REQUIRE(value >= 0 && value < (1ll << 32), "TH_OPT_BINS_POOL out of range"); o.bins_pool = (uint32_t)value; break;
-    case TH_OPT_INJECT_FAILURE: TH_REQUIRE(value >= 0 && value <= 3, "TH_OPT_INJECT_FAILURE takes 0..3"); o.inject_failure = (int)value; break;
+    case TH_OPT_INJECT_FAILURE: TH_REQUIRE(value >= 0 && value <= 4, "TH_OPT_INJECT_FAILURE takes 0..4"); o.inject_failure = (int)value; break;
     default: return fail(TH_ERR_INVALID, "unknown option %d", option);
     }
     clear_graphs(c);                 // (captured sequences were planned under the old switches)

@@ -241,6 +241,7 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     const std::string why = mine != TH_OK ? last_error() : std::string();
     if (mine != TH_OK) std::fill(hb.begin(), hb.end(), 0ull);
     if (fragments) *fragments = mine == TH_OK ? count : 0;
+    c->last_draw.pipeline = TH_DRAW_STREAM; c->last_draw.fragments = mine == TH_OK ? count : 0; c->last_draw.crowded_fragments = 0;
     std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
     std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
     for (int r = 0; r < world; ++r) {
@@ -315,6 +316,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     std::vector<unsigned long long> hb((size_t)world + 1, 0ull);
     auto stage1 = [&]() -> th_status {
         if (th_status s = injected(c, 2)) return s;
+        if (c->opt.inject_failure == 4) { c->opt.inject_failure = 0; return kRetryInStreamOrder; }      // (tests: this rank's binned pass gives up)
         if (th_status s = deposit_prepare_bins(c, &d, p)) return s;
         p.mode = both ? 2 : (view ? 1 : 0);
         if (view) { view_fields(c, ru, p); p.view = c->view; if (!both) p.line_half = 0.5f * drawn_line_width(c, TH_PASS_VIEW); }

@@ -155,6 +155,34 @@ def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, 
         t.dispose()
 
 
+def test_one_rank_giving_up_on_the_bins_sends_everybody_to_the_stream_ordered_pass():
+    """A rank whose binned pass cannot go on (no store, a bin beyond its lists' reach: here TH_OPT_INJECT_FAILURE = 4) says so
+    with its counts; every rank then runs the stream-ordered pass for that draw - same result, nobody waits."""
+    from tendrils_amd import sharding
+    n, view, world = 128, (96, 54), 3
+    cur, prev, base = inputs(n, view, 17)
+    one = make(n, view, cur, prev, base)
+    one.draw()
+    want_flow, want_view = one.flow.read(), one.read_view()
+    one.dispose()
+    shards = world_of(n, view, world, cur, prev, base, pipeline="bins")
+    shards[2].particles.option("inject_failure", 4)
+    frags, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+    assert err == [None] * world, err
+    for t in shards:
+        assert last_pipeline(t) == 0                           # TH_DRAW_STREAM: the fallback drew
+        assert bits_equal(t.flow.read(), want_flow).all() and (t.read_view() == want_view).all()
+    for t in shards:                                           # ... and the next draw goes through the bins again
+        t.flow.set_pixels(base)
+        t.clearView()
+    _, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+    assert err == [None] * world, err
+    for t in shards:
+        assert last_pipeline(t) == 1
+        assert bits_equal(t.flow.read(), want_flow).all() and (t.read_view() == want_view).all()
+        t.dispose()
+
+
 def test_gather_and_counters_over_loopback_with_unequal_bands():
     """th_state_gather (bands of 34 / 33 / 33 rows: parts of different sizes) and the counter all-reduce"""
     from tendrils_amd import _capi, sharding

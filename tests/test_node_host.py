@@ -30,6 +30,36 @@ def test_addon_loads_and_exports_the_abi():
     assert info == {"n": 90, "abi": 12, "ring": -1}
 
 
+@pytest.mark.gpu
+def test_options_and_communicator_ids_through_the_shim():
+    """Particles.option(name[, value]) reads / sets a per-context switch; commLoopbackId() makes the id of an in-process world
+    (th_comm_init tells it from an RCCL id by itself: a context joins it as rank 0 of 1)."""
+    r = node("""
+    const T = require('./tendrils_amd/js');
+    const native = require('./tendrils_amd/js/native');
+    const t = new T.Tendrils({drawingBufferWidth: 32, drawingBufferHeight: 32}, {});
+    t.resize(); t.setup(32);
+    const h = t.particles.handle, out = {};
+    out.bucket0 = native.option(h, native.OPT_BUCKET);
+    out.bucket1 = native.option(h, native.OPT_BUCKET, 1);
+    out.resort = native.option(h, native.OPT_RESORT_STEPS, 7);
+    let threw = false; try { native.option(h, native.OPT_BUCKET, 5); } catch (e) { threw = /TH_OPT_BUCKET/.test(String(e)); }
+    out.threw = threw;
+    const id = native.commLoopbackId();
+    out.idBytes = id.length;
+    native.commInit(h, id, 0, 1);
+    out.comm = native.commQuery(h);
+    out.stats = native.statsGlobal(h, 0.01).particles;
+    native.commDestroy(h);
+    t.dispose();
+    console.log(JSON.stringify(out));
+    """)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["bucket0"] == -1 and out["bucket1"] == 1 and out["resort"] == 7 and out["threw"] and out["idBytes"] == 128
+    assert out["comm"]["active"] == 2 and out["comm"]["world"] == 1 and out["stats"] == 32 * 32
+
+
 def test_timer_matches_reference_semantics():
     """Fixed-step, wall-clock, pause, end and loop behaviour of src/timer.js, JS mirror vs Python mirror."""
     from tendrils_amd.timer import Timer
