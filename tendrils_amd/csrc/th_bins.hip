@@ -1242,16 +1242,17 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
 // A sharded job draws with the binned pipeline like a single context does - every rank rasterises its band's lines into
 // ITS page store (bins_fused_kernel, untouched) - and then the bins change hands: a rank owns whole bin rows of the target
 // (OwnerParams::bin_lo: contiguous ranges, hence contiguous texel ranges for the all-gather that follows), and what a rank
-// emitted into the bins of owner r is compacted into one contiguous part per owner (keys + varyings, bin by bin, with the
-// per-bin counts beside it), exchanged, and laid out in the owner's page store exactly as if the owner had emitted it: cursors,
-// pages from the pool, page table - so that the plan and every blend kernel run unchanged.  The order inside a bin is of no
-// consequence (the blend restores GL's order from the keys), so nothing is sorted anywhere on the way.
+// emitted into the bins of ANOTHER owner r is compacted into one contiguous part per owner (keys + varyings, bin by bin, with
+// the per-bin counts beside it) and exchanged; what it emitted into its OWN bins stays where it is, and what the other ranks
+// send for those bins is appended to their lists exactly as if this rank had emitted it too: cursors moved on, pages from the
+// pool, page table - so that the plan and every blend kernel run unchanged.  The order inside a bin is of no consequence (the
+// blend restores GL's order from the keys), so nothing is sorted anywhere on the way; a world of one moves nothing at all.
 //   owner_places_kernel, owner_counts_kernel   places per bin; their exclusive scan (= where each bin goes in the outgoing
 //                          arrays) and the owners' bounds
 //   owner_extract_kernel   a workgroup per bin: its lists walked, fragments copied out; the lists' pages forgotten
 //   owner_prefix_kernel    (owner) per source: where each of my bins starts inside that source's part
-//   owner_totals_kernel, owner_pages_kernel, owner_layout_kernel   (owner) per bin: places in all; pool pages (a scan);
-//                          cursors and page table, a thread per list
+//   owner_totals_kernel, owner_pages_kernel, owner_layout_kernel   (owner) per bin: places arriving; the pool pages they open
+//                          (a scan); page table and cursors
 //   owner_insert_kernel    (owner) a workgroup per bin: every source's fragments of the bin copied to their places
 
 // all threads of a 1024-thread workgroup: `mine` -> its exclusive prefix over the workgroup; `total` (same on every thread)
@@ -1271,10 +1272,13 @@ TH_D unsigned long long block_scan_1024(unsigned long long *lds, unsigned long l
     return lds[t] - mine;
 }
 
+TH_D bool owner_mine(const OwnerParams &o, uint32_t b) { return b >= o.bin_lo[o.rank] && b < o.bin_lo[o.rank + 1u]; }
+
+// what leaves: the places of every bin of another owner (my own bins stay in my store)
 __global__ __launch_bounds__(256) void owner_places_kernel(const DepositParams p, const OwnerParams o)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b < p.nbins) o.counts[b] = bin_places(p, b);
+    if (b < p.nbins) o.counts[b] = owner_mine(o, b) ? 0u : bin_places(p, b);
 }
 
 __global__ __launch_bounds__(1024) void owner_counts_kernel(const DepositParams p, const OwnerParams o)
@@ -1309,6 +1313,7 @@ __global__ __launch_bounds__(256) void owner_extract_kernel(const DepositParams 
 {
     __shared__ uint32_t lists[kBinReplicas + 1u];
     const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (owner_mine(o, b)) return;                       // (stays: the others' fragments of this bin will join it)
     if (t == 0u) {
         uint32_t run = 0;
         for (uint32_t r = 0; r < kBinReplicas; ++r) { lists[r] = run; run += *list_cursor(p, b, r); }
@@ -1325,6 +1330,7 @@ __global__ __launch_bounds__(256) void owner_extract_kernel(const DepositParams 
     }
     __syncthreads();
     for (uint32_t r = 0; r < kBinReplicas; ++r) if (lists[r + 1u] - lists[r] > kBinPage) pages_forget(p, b * kBinReplicas + r, lists[r + 1u] - lists[r], t, 256u);
+    if (t < kBinReplicas) *list_cursor(p, b, t) = 0u;    // (the bin is somebody else's: nothing of it is blended here)
 }
 
 // table[s][b'] (what source s holds for my bin b') -> src_prefix[s][b'] (its exclusive scan over b'); one workgroup per source
@@ -1339,67 +1345,99 @@ __global__ __launch_bounds__(1024) void owner_prefix_kernel(const OwnerParams o)
     for (uint32_t b = lo; b < hi; ++b) { o.src_prefix[(size_t)s * o.nb + b] = run; run += row[b]; }
 }
 
-// how a bin of `total` places is spread over its lists: places per list (a multiple of the page size above one page per list)
-TH_D uint32_t owner_list_len(uint32_t total)
+// How the `incoming` places of a bin are spread over its lists: the same share for every list, appended behind what the list
+// holds.  take(r): list r's share; a list holding e places that takes n more opens the pages (e + 255) / 256 (from page 1 on:
+// page 0 is the list's own) ... (e + n - 1) / 256.
+TH_D uint32_t owner_share(uint32_t incoming) { return (incoming + kBinReplicas - 1u) / kBinReplicas; }
+TH_D uint32_t owner_take(uint32_t incoming, uint32_t r)
 {
-    if (total <= kBinCap) return kBinPage;
-    const uint32_t per = (total + kBinReplicas - 1u) / kBinReplicas;
-    return (per + kBinPage - 1u) / kBinPage * kBinPage;
+    const uint32_t len = owner_share(incoming);
+    const unsigned long long begin = (unsigned long long)r * len;
+    return incoming > begin ? (uint32_t)(incoming - begin < len ? incoming - begin : len) : 0u;
+}
+TH_D void owner_new_pages(uint32_t e, uint32_t n, uint32_t &first, uint32_t &count)
+{
+    first = (e + kBinPage - 1u) >> kPageShift;
+    if (first == 0u) first = 1u;
+    const uint32_t last = n ? (e + n - 1u) >> kPageShift : 0u;
+    count = n && last >= first ? last - first + 1u : 0u;
 }
 
-// per bin of mine: places in all (0 and a flag when they are more than a bin's lists can hold)
+// per bin of mine: places arriving from the other ranks (0 and a flag when a list would outgrow its page table)
 __global__ __launch_bounds__(256) void owner_totals_kernel(const DepositParams p, const OwnerParams o)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= o.nb) return;
     unsigned long long total = 0;
     for (uint32_t s = 0; s < o.world; ++s) total += o.table[(size_t)s * o.nb + b];
-    if (total > (unsigned long long)kBinMaxPages * kBinPage * kBinReplicas) { bins_flag(p, kBinsBinFull); total = 0; }
+    const uint32_t bin = o.bin_lo[o.rank] + b;
+    bool full = total > (unsigned long long)kBinMaxPages * kBinPage * kBinReplicas;
+    if (!full)
+        for (uint32_t r = 0; r < kBinReplicas; ++r)
+            full = full || (unsigned long long)*list_cursor(p, bin, r) + owner_take((uint32_t)total, r) > (unsigned long long)kBinMaxPages * kBinPage;
+    if (full) { bins_flag(p, kBinsBinFull); total = 0; }
     o.bin_total[b] = (uint32_t)total;
 }
 
-// the pool pages every bin of mine needs, and the first of them (o.bin_page: their exclusive scan); the pool's use in totals
+// the pool pages every bin of mine opens for what arrives, and the first of them (o.bin_page: their exclusive scan behind the
+// pages the emitting pass took: o.pool_used); the pool's use in totals
 __global__ __launch_bounds__(1024) void owner_pages_kernel(const DepositParams p, const OwnerParams o)
 {
     __shared__ unsigned long long lds[1024];
     const uint32_t per = (o.nb + 1023u) / 1024u, lo = threadIdx.x * per < o.nb ? threadIdx.x * per : o.nb, hi = lo + per < o.nb ? lo + per : o.nb;
+    auto pages_of = [&](uint32_t b) {
+        uint32_t n = 0;
+        const uint32_t total = o.bin_total[b], bin = o.bin_lo[o.rank] + b;
+        for (uint32_t r = 0; r < kBinReplicas && total; ++r) { uint32_t first, count; owner_new_pages(*list_cursor(p, bin, r), owner_take(total, r), first, count); n += count; }
+        return n;
+    };
     unsigned long long pages = 0, all = 0;
-    for (uint32_t b = lo; b < hi; ++b) pages += (unsigned long long)(owner_list_len(o.bin_total[b]) / kBinPage - 1u) * kBinReplicas;
+    for (uint32_t b = lo; b < hi; ++b) pages += pages_of(b);
     unsigned long long first = block_scan_1024(lds, pages, all);
     for (uint32_t b = lo; b < hi; ++b) {
         o.bin_page[b] = (uint32_t)(first > 0xffffffffull ? 0xffffffffull : first);
-        first += (unsigned long long)(owner_list_len(o.bin_total[b]) / kBinPage - 1u) * kBinReplicas;
+        first += pages_of(b);
     }
     if (threadIdx.x == 0u) {
-        p.totals[kTotPool] = (uint32_t)(all > 0xffffffffull ? 0xffffffffull : all);
-        if (all > p.pool_pages) bins_flag(p, kBinsPoolExhausted);      // (the host grows the store and lays the bins out again)
+        const unsigned long long used = (unsigned long long)o.pool_used + all;
+        p.totals[kTotPool] = (uint32_t)(used > 0xffffffffull ? 0xffffffffull : used);
+        if (used > p.pool_pages) bins_flag(p, kBinsPoolExhausted);      // (the host grows the store - keeping what is in it - and lays the bins out again)
     }
 }
 
-// a bin's cursors and page table, one thread per list
+// a bin's page table and cursors moved on, one thread per bin
 __global__ __launch_bounds__(256) void owner_layout_kernel(const DepositParams p, const OwnerParams o)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x, b = i / kBinReplicas, r = i - b * kBinReplicas;
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= o.nb || p.totals[kTotFlags] != 0u) return;
-    const uint32_t total = o.bin_total[b], len = owner_list_len(total), extra = len / kBinPage - 1u, bin = o.bin_lo[o.rank] + b;
-    const unsigned long long begin = (unsigned long long)r * len;
-    *list_cursor(p, bin, r) = total > begin ? (uint32_t)(total - begin < len ? total - begin : len) : 0u;
-    for (uint32_t n = 1; n <= extra; ++n)
-        p.page_table[(size_t)(bin * kBinReplicas + r) * kBinMaxPages + n] = p.nbins * kBinReplicas + o.bin_page[b] + r * extra + (n - 1u);
+    const uint32_t total = o.bin_total[b], bin = o.bin_lo[o.rank] + b;
+    if (total == 0u) return;
+    uint32_t page = p.nbins * kBinReplicas + o.pool_used + o.bin_page[b];
+    for (uint32_t r = 0; r < kBinReplicas; ++r) {
+        uint32_t *cursor = list_cursor(p, bin, r);
+        const uint32_t e = *cursor, n = owner_take(total, r);
+        uint32_t first, count;
+        owner_new_pages(e, n, first, count);
+        for (uint32_t k = 0; k < count; ++k) p.page_table[(size_t)(bin * kBinReplicas + r) * kBinMaxPages + first + k] = page++;
+        *cursor = e + n;
+    }
 }
 
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void owner_insert_kernel(const DepositParams p, const OwnerParams o)
 {
+    __shared__ uint32_t was[kBinReplicas];              // where every list of the bin ended before the layout moved its cursor on
     const uint32_t b = blockIdx.x, bin = o.bin_lo[o.rank] + b, t = threadIdx.x;
-    const uint32_t total = o.bin_total[b], len = owner_list_len(total);
+    const uint32_t total = o.bin_total[b], len = owner_share(total);
     if (total == 0u || p.totals[kTotFlags] != 0u) return;
-    uint32_t seen = 0;                                  // places of the bin taken by the sources before s
+    if (t < kBinReplicas) was[t] = *list_cursor(p, bin, t) - owner_take(total, t);
+    __syncthreads();
+    uint32_t seen = 0;                                  // places of the bin's incoming sequence taken by the sources before s
     for (uint32_t s = 0; s < o.world; ++s) {
         const uint32_t n = o.table[(size_t)s * o.nb + b];
         const unsigned long long from = o.recv_base[s] + o.src_prefix[(size_t)s * o.nb + b];
         for (uint32_t f = t; f < n; f += 256u) {
-            const uint32_t j = seen + f, r = j / len, v = j - r * len;
+            const uint32_t j = seen + f, r = j / len, v = was[r] + (j - r * len);
             const uint32_t at = place_of(p, bin * kBinReplicas + r, v);
             p.frag_keys[at] = o.in_keys[from + f];
             if constexpr (PAIRS) { p.colors[2u * (size_t)at] = o.in_colors[2u * (from + f)]; p.colors[2u * (size_t)at + 1u] = o.in_colors[2u * (from + f) + 1u]; }
@@ -1440,16 +1478,16 @@ void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hip
     if (p.mode == 2) hipLaunchKernelGGL(owner_extract_kernel<true>, dim3(p.nbins), dim3(256), 0, s, p, o);
     else hipLaunchKernelGGL(owner_extract_kernel<false>, dim3(p.nbins), dim3(256), 0, s, p, o);
 }
-// owner: the received parts (o.table, o.recv_base, o.in_keys / o.in_colors) laid out in this context's store as if it had
-// emitted them; then the plan of the ordinary binned pass (large bins, totals).  p.totals must have been zeroed.
+// owner: the received parts (o.table, o.recv_base, o.in_keys / o.in_colors) appended to this context's own bins as if it had
+// emitted them too (o.pool_used: the pool pages its emitting pass took); then the plan of the ordinary binned pass (large
+// bins, totals).  p.totals must have been zeroed.
 void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipStream_t s)
 {
-    (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
     hipLaunchKernelGGL(owner_prefix_kernel, dim3(o.world), dim3(1024), 0, s, o);
     if (o.nb) {
         hipLaunchKernelGGL(owner_totals_kernel, dim3((o.nb + 255u) / 256u), dim3(256), 0, s, p, o);
         hipLaunchKernelGGL(owner_pages_kernel, dim3(1), dim3(1024), 0, s, p, o);
-        hipLaunchKernelGGL(owner_layout_kernel, dim3((o.nb * kBinReplicas + 255u) / 256u), dim3(256), 0, s, p, o);
+        hipLaunchKernelGGL(owner_layout_kernel, dim3((o.nb + 255u) / 256u), dim3(256), 0, s, p, o);
         if (p.mode == 2) hipLaunchKernelGGL(owner_insert_kernel<true>, dim3(o.nb), dim3(256), 0, s, p, o);
         else hipLaunchKernelGGL(owner_insert_kernel<false>, dim3(o.nb), dim3(256), 0, s, p, o);
     }

@@ -254,6 +254,7 @@ th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositPar
 // the binned pipeline in parts (deposit_run_bins = emit + finish; row-band shards put the owners' exchange in between)
 constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
 th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least);
+th_status bins_store_grow_keep(th_context *c, th::DepositParams &p, uint32_t pool);
 th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early);
 th_status bins_pass_totals(th_context *c);
 th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early, bool policy);

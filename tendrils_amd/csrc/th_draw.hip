@@ -387,6 +387,27 @@ th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least)
     return TH_OK;
 }
 
+// a larger pool behind the same bins WITH what the store holds (row-band shards: the owner's own bins wait in it for the
+// other ranks' fragments); page ids stay what they are
+th_status bins_store_grow_keep(th_context *c, th::DepositParams &p, uint32_t pool)
+{
+    if (pool <= c->bins_pool) return TH_OK;
+    const size_t had = ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage;
+    const size_t places = ((size_t)c->bins_store_bins * th::kBinReplicas + pool) * th::kBinPage, per = c->bins_pairs ? 2 : 1;
+    TH_REQUIRE(places < ((size_t)1 << 32), "the binned draw's chunk store would hold 2^32 places or more");
+    unsigned long long *keys = nullptr;
+    float4 *colors = nullptr;
+    TH_HIP(hipMalloc((void **)&keys, places * sizeof(unsigned long long)));
+    if (hipMalloc((void **)&colors, places * per * sizeof(float4)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(keys); return fail(TH_ERR_HIP, "the binned store could not grow to %zu places", places); }
+    TH_HIP(hipMemcpyAsync(keys, c->bins_keys, had * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    TH_HIP(hipMemcpyAsync(colors, c->bins_colors, had * per * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors);
+    c->bins_keys = keys; c->bins_colors = colors; c->bins_pool = pool;
+    p.frag_keys = keys; p.colors = colors; p.pool_pages = pool;
+    return TH_OK;
+}
+
 // Part 1: rasterise + emit into the bins, the plan; repeated with a larger pool when the pool ran dry (nothing has been
 // blended).  blend_early: the ordinary bins' blend goes out right behind the pass and covers the totals' read-back.
 // Leaves the totals in c->bins_totals_host.  kRetryInStreamOrder: a bin outgrew its lists (or the store cannot be had).

@@ -178,6 +178,7 @@ struct OwnerParams {
     float4 *out_colors;
     // owner
     uint32_t nb;                         // my bins
+    uint32_t pool_used;                  // pool pages my own emitting pass took
     const uint32_t *table;               // [world][nb] what every source holds for each of my bins
     unsigned long long *src_prefix;      // [world][nb] where each of my bins starts inside that source's part
     uint32_t *bin_total;                 // [nb]

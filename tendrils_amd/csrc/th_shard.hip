@@ -312,7 +312,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     // ---- stage 1: my band's lines into my store, then compacted owner by owner
     th::DepositParams p;
     th::OwnerParams o{};
-    uint32_t *host = nullptr;
+    uint32_t *host = nullptr, emitted = 0;
     std::vector<unsigned long long> hb((size_t)world + 1, 0ull);
     auto stage1 = [&]() -> th_status {
         if (th_status s = injected(c, 2)) return s;
@@ -322,6 +322,8 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         if (view) { view_fields(c, ru, p); p.view = c->view; if (!both) p.line_half = 0.5f * drawn_line_width(c, TH_PASS_VIEW); }
         if (th_status s = bins_pass_emit(c, p, false)) return s;
         host = c->bins_totals_host;
+        o.pool_used = host[th::kTotPool];                     // (my own bins stay in the store: what arrives goes behind them)
+        emitted = host[th::kTotFragments];
         const uint32_t bins_y = p.nbins / p.bins_x;
         o.world = (uint32_t)world; o.rank = (uint32_t)rank;
         for (int r = 0; r <= world; ++r) o.bin_lo[r] = (uint32_t)((unsigned long long)bins_y * (unsigned)r / (unsigned)world) * p.bins_x;
@@ -344,7 +346,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         o.bin_total = w; w += p.nbins;
         o.bin_page = w; w += p.nbins;
         o.table = w;
-        const uint32_t total = host[th::kTotFragments];
+        const uint32_t total = emitted;                        // (an upper bound of what leaves)
         if (total) {
             if (th_status s = deposit_reserve(c, total, true, both)) return s;
             o.out_keys = c->dep_u64[0]; o.out_colors = c->dep_colors;
@@ -357,7 +359,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     th_status mine = stage1();
     const std::string why = mine != TH_OK ? last_error() : std::string();
     if (mine != TH_OK) std::fill(hb.begin(), hb.end(), 0ull);
-    if (fragments) *fragments = mine == TH_OK ? hb[(size_t)world] : 0;
+    if (fragments) *fragments = mine == TH_OK ? emitted : 0;          // (what leaves + what stays)
     unsigned long long *sendc = c->x_counts + 33, *recvc = c->x_counts + 65;
     std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
     std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
@@ -419,10 +421,9 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         if (th_status s = bins_pass_totals(c)) return s;
         const uint32_t flags = host[th::kTotFlags];
         if (flags == 0) break;
-        // (nothing of mine has been blended; a bin beyond its lists' reach cannot be drawn through the bins at all)
+        // (nothing has been blended; a bin beyond its lists' reach cannot be drawn through the bins at all)
         if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) { laid = fail(TH_ERR_UNSUPPORTED, "a bin of the target received more fragments than its lists hold (%u places)", th::kBinMaxPages * th::kBinPage * th::kBinReplicas); break; }
-        TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t), c->stream));
-        if ((laid = bins_store_for(c, p, host[th::kTotPool] + 64u)) != TH_OK) break;
+        if ((laid = bins_store_grow_keep(c, p, host[th::kTotPool] + host[th::kTotPool] / 2u + 64u)) != TH_OK) break;
     }
     if (laid == TH_OK) laid = bins_pass_finish(c, p, nullptr, false, false);
     // (an owner that could not lay its bins out has blended nothing; the others have: the draw is lost, and everybody says so)
