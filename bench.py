@@ -323,10 +323,27 @@ class Job:
             t.flow.set_pixels(synth_flow(self.time0))
         t.timer.time = self.time0
         # the job's communicator inside the library: the counter all-reduce of the timed region is th_stats_allreduce
-        self.comm = None
+        self.comm, self.comm_fallback = None, None
         if dist is not None:
-            comm_init(ctx, dist)
-            self.comm = comm_query(ctx)
+            # (should the library's own communicator not come up - librccl not loadable beside torch's, say - on any rank,
+            # every rank falls back to reducing the counter block through torch.distributed, and the line says so: a
+            # scaling run is not lost to it)
+            import torch
+            why = "--no-library-comm" if args.no_library_comm else ""
+            try:
+                if not why:
+                    comm_init(ctx, dist)
+                    self.comm = comm_query(ctx)
+            except ta.TendrilsHipError as e:
+                why = str(e)
+            ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if self.comm is not None:
+                    _capi.call("th_comm_destroy", ctx)
+                self.comm = None
+                self.comm_fallback = why or "another rank could not join the library's communicator"
+                self._counters_view = None
         self.reductions = 0
         if args.flow_only:
             t.state["noiseWeight"] = 0
@@ -342,10 +359,30 @@ class Job:
     def stats_tick(self):
         """statistics of buffers[0] and - world > 1 - their reduction over the ranks, both enqueued on the context's
         stream (the library's RCCL all-reduce: no host sync, no second stream)"""
-        self.capi.call("th_stats_async", self.ctx, C.c_float(self.t.state["speedLimit"]), None)
+        dev = C.c_void_p()
+        self.capi.call("th_stats_async", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(dev))
         if self.comm is not None:
             self.capi.call("th_stats_allreduce", self.ctx)
             self.reductions += 1
+        elif self.comm_fallback:
+            self.fallback_reduce(dev.value)
+            self.reductions += 1
+
+    def fallback_reduce(self, dev_ptr):
+        """(fallback) the th_counters block - five u64 and a f64 summed, a f64 maximised - reduced in place through
+        torch.distributed on the context's stream"""
+        import torch
+        from tendrils_amd.sharding import device_view
+        if self._counters_view is None:
+            sp = C.c_void_p()
+            self.capi.call("th_stream", self.ctx, C.byref(sp))
+            self._ext = torch.cuda.ExternalStream(sp.value)
+            self._counters_view = (device_view(dev_ptr, (5,), "<i8"), device_view(dev_ptr + 40, (1,), "<f8"), device_view(dev_ptr + 48, (1,), "<f8"))
+        counts, total, peak = self._counters_view
+        with torch.cuda.stream(self._ext):
+            self.dist.all_reduce(counts)
+            self.dist.all_reduce(total)
+            self.dist.all_reduce(peak, op=self.dist.ReduceOp.MAX)
 
     def run(self, k_steps, every=None, refresh=True):
         # the step loop runs as fused launches (Tendrils.step_n -> th_step_n), `every` steps each; after EVERY launch
@@ -413,6 +450,17 @@ class Job:
 
     def global_stats(self):
         """th_stats_global: the job's counters (local pass + the library's all-reduce + download)"""
+        if self.comm_fallback:
+            import torch
+            dev = C.c_void_p()
+            self.capi.call("th_stats_async", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(dev))
+            self.fallback_reduce(dev.value)
+            self.t.particles.sync()
+            torch.cuda.synchronize()
+            counts, total, peak = self._counters_view
+            names = [k for k, _ in self.capi.Counters._fields_]
+            vals = [int(v) for v in counts.cpu().tolist()] + [float(total.cpu()[0]), float(peak.cpu()[0])]
+            return dict(zip(names, vals))
         c = self.capi.Counters()
         self.capi.call("th_stats_global", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(c))
         return {k: getattr(c, k) for k, _ in self.capi.Counters._fields_}
@@ -425,6 +473,8 @@ class Job:
                      "context holds no communicator and the local block is the global one"}
         if self.comm is not None:
             b.update(version=self.comm["rccl_version"], in_library=True, rank=self.comm["rank"])
+        elif self.comm_fallback:
+            b.update(in_library=False, fallback="torch.distributed all-reduce of the counter block: " + self.comm_fallback)
         return b
 
     def dispose(self):
@@ -592,6 +642,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check: gloo ranks stepping the CPU restatement")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # PMC child: launches of this length only
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
+    ap.add_argument("--no-library-comm", action="store_true", help="reduce the counters through torch.distributed instead of the library's own communicator (what the bench falls back to when th_comm_init fails on any rank)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
     ap.add_argument("--state", default=None, choices=["f32", "f16"], help="state ring storage (f16 = packed 8 B/particle); default: the config's")
     ap.add_argument("--in-view", action="store_true", help="experiment: keep every particle inside the view (|y*viewSize.y| < 1)")
