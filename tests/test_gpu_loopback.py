@@ -32,10 +32,13 @@ def inputs(n, view, seed, spread=0.9):
     return cur, prev, base
 
 
-def make(n, view, cur, prev, base, band=None, fmt="f32"):
+def make(n, view, cur, prev, base, band=None, fmt="f32", widths=None):
     import tendrils_amd as ta
     from tendrils_amd.tendrils import View
     opts = ta.defaults()
+    if widths:                                      # a GL that honours gl.lineWidth up to 2: (flowWidth, lineWidth)
+        opts["lineWidthRange"] = (1, 2)
+        opts["state"]["flowWidth"], opts["state"]["lineWidth"] = widths
     row0, rows = band if band else (0, n)
     opts.update(row0=row0, rows=rows, globalHeight=n, stateFormat=ta._capi.TH_STATE_F16 if fmt == "f16" else ta._capi.TH_STATE_F32)
     t = ta.Tendrils(View(*view), opts)
@@ -158,6 +161,35 @@ def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, 
         __import__("tendrils_amd")._capi.call("th_slot_order", shards[0].particles._ctx, C.byref(info))
         assert info.sorted_buffers == 2
     for t in everybody:
+        t.dispose()
+
+
+@pytest.mark.parametrize("how", ["flow pass only", "two widths"])
+def test_sharded_bins_pass_by_pass(how):
+    """Tendrils.draw() of band contexts (the library's exchange, through the bins) when the passes do not share one
+    rasterisation: the flow pass alone (renderView off: mode 0), and lines 2 wide in the flow pass but 1 wide in the view -
+    two sharded passes, the second with the view's colours only (mode 1)."""
+    from tendrils_amd import sharding
+    n, view, world = 128, (96, 54), 3
+    widths = (2, 1) if how == "two widths" else None
+    cur, prev, base = inputs(n, view, 23)
+    one = make(n, view, cur, prev, base, widths=widths)
+    ident = sharding.loopback_id()
+    shards = [make(n, view, cur, prev, base, sharding.shard_rows(n, world, r), widths=widths) for r in range(world)]
+    _, err = in_threads(world, lambda r: sharding.comm_join(shards[r].particles._ctx, ident, r, world))
+    assert err == [None] * world, err
+    for t in [one] + shards:
+        t.particles.draw_pipeline("bins")
+        t.renderView = how != "flow pass only"
+    one.draw()
+    _, err = in_threads(world, lambda r: shards[r].draw())
+    assert err == [None] * world, err
+    want_flow, want_view = one.flow.read(), one.read_view()
+    assert one.fragments > 1000 and want_view.any() == (how != "flow pass only")
+    for t in shards:
+        assert last_pipeline(t) == 1
+        assert bits_equal(t.flow.read(), want_flow).all() and (t.read_view() == want_view).all()
+    for t in [one] + shards:
         t.dispose()
 
 
