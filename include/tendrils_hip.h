@@ -198,7 +198,7 @@ th_status th_step_n(th_context *ctx, const th_logic_uniforms *u, double time0, d
  * fract(sin(dot(..)) * 43758.5453) (glsl-random), and GLSL leaves sin() to the implementation - the captured GL's values
  * are not reproducible by arithmetic.  This library fixes ONE sequence (sin evaluated in fp64, rounded once); the HIP path
  * equals its restatement bit for bit and the reference's captures in DISTRIBUTION only (radius, speed, acceptance
- * statistics: tests/test_spawn_oracle.py).  th_spawn_init, th_spawn_direct and the geometry raster have no such
+ * statistics: the spawn tests).  th_spawn_init, th_spawn_direct and the geometry raster have no such
  * freedom and are bit-exact against the captures. */
 th_status th_spawn_init(th_context *ctx, int32_t target);
 th_status th_spawn_ball(th_context *ctx, const th_spawn_ball_uniforms *u, int32_t target);
