@@ -185,6 +185,13 @@ class Particles {
   updateRender() {}
 
   sync() { native.sync(this.handle); }
+  // a switch between equivalent paths of the library (th_option_set / _get; no switch changes a result):
+  // option('bucket') reads, option('bucket', 1) sets and returns the value
+  option(name, value) {
+    const key = native['OPT_' + name.replace(/[A-Z]/g, (ch) => '_' + ch).toUpperCase()];
+    if (key === undefined) throw new Error('unknown option ' + name);
+    return (value === undefined) ? native.option(this.handle, key) : native.option(this.handle, key, +value);
+  }
   stats(speedLimit) { return native.stats(this.handle, speedLimit); }
 
   // -- one Node process per GPU (row-band shards; build-defined: the reference is one WebGL context) --------------
@@ -192,6 +199,8 @@ class Particles {
   // ranks (a file, a socket, an environment variable), every rank joins with commInit(id, rank, world); from then on
   // statsGlobal() is the job's counter block - the library's RCCL all-reduce on the context's stream.
   static commUniqueId() { return native.commUniqueId(); }
+  // ... or the id of an in-process world (contexts of this process as ranks; a test transport: see include/tendrils_hip.h)
+  static commLoopbackId() { return native.commLoopbackId(); }
   commInit(id, rank, world) { native.commInit(this.handle, id, rank | 0, world | 0); return this; }
   commDestroy() { native.commDestroy(this.handle); return this; }
   commQuery() { return native.commQuery(this.handle); }

@@ -40,12 +40,12 @@ def test_options_and_communicator_ids_through_the_shim():
     const t = new T.Tendrils({drawingBufferWidth: 32, drawingBufferHeight: 32}, {});
     t.resize(); t.setup(32);
     const h = t.particles.handle, out = {};
-    out.bucket0 = native.option(h, native.OPT_BUCKET);
-    out.bucket1 = native.option(h, native.OPT_BUCKET, 1);
-    out.resort = native.option(h, native.OPT_RESORT_STEPS, 7);
+    out.bucket0 = t.particles.option('bucket');
+    out.bucket1 = t.particles.option('bucket', 1);
+    out.resort = t.particles.option('resortSteps', 7);
     let threw = false; try { native.option(h, native.OPT_BUCKET, 5); } catch (e) { threw = /TH_OPT_BUCKET/.test(String(e)); }
     out.threw = threw;
-    const id = native.commLoopbackId();
+    const id = T.Particles.commLoopbackId();
     out.idBytes = id.length;
     native.commInit(h, id, 0, 1);
     out.comm = native.commQuery(h);
