@@ -624,6 +624,79 @@ def gen_animate(r_unused, only):
     print("wrote animate_script.json (%d player calls)" % len(res["out"]))
 
 
+def random_animate_script(seed, n_ops=48):
+    """A seeded random script for the reference's Player: keyframes of every kind added before and DURING playback, removals,
+    plays forwards and backwards, seeks, playFroms.  Values are dyadic rationals (exact in binary), times multiples of 1/4."""
+    rng = np.random.default_rng(seed)
+    keys = ["alpha", "beta", "gamma", "delta"]
+
+    def value():
+        return float(rng.integers(-64, 65)) / 16.0
+
+    def frame(track):
+        if track == "vec":
+            to = [value() for _ in range(4)]
+        else:
+            to = {k: value() for k in keys if rng.random() < 0.6} or {"alpha": value()}
+            if rng.random() < 0.15:
+                to["flag"] = bool(rng.random() < 0.5)
+        f = {"to": to, "time": float(rng.integers(0, 16000)) / 4.0}
+        if rng.random() < 0.7:
+            f["ease"] = [0.0] + [float(rng.integers(-8, 25)) / 16.0 for _ in range(int(rng.integers(0, 5)))] + [1.0]
+        if rng.random() < 0.2:
+            f["call"] = ["c%d" % int(rng.integers(0, 100))]
+        return f
+    ops, now = [], 0.0
+    for k in range(n_ops):
+        track = "vec" if rng.random() < 0.3 else "obj"
+        r = rng.random()
+        if k < 6 or r < 0.35:
+            kind = ["to", "smoothTo", "flipTo", "easeTo", "over", "smoothOver", "flipOver", "easeOver"][int(rng.integers(0, 8))]
+            args = []
+            if kind.endswith("Over") or kind == "over":
+                args.append(float(rng.integers(0, 2400)) / 4.0)
+            if kind in ("easeTo", "easeOver"):
+                args.append(float(rng.integers(-8, 9)) / 8.0)
+            ops.append(["track", track, kind] + args + [frame(track)])
+        elif r < 0.42:
+            ops.append(["track", track, "spliceAt", float(rng.integers(0, 16000)) / 4.0] + ([1] if rng.random() < 0.5 else []))
+        elif r < 0.47:
+            ops.append(["track", track, "spliceSpan", float(rng.integers(0, 4000)) / 4.0, float(rng.integers(0, 16000)) / 4.0])
+        elif r < 0.50:
+            ops.append(["track", track, "spliceIndex", int(rng.integers(-3, 8))])
+        elif r < 0.55:
+            ops.append(["query", track, ["gapAt", "indexOf"][int(rng.integers(0, 2))]] + ([float(rng.integers(0, 16000)) / 4.0] if rng.random() < 2 else []))
+            if ops[-1][2] == "indexOf":
+                ops[-1][3] = {"time": ops[-1][3]}
+        else:
+            step = float(rng.integers(1, 3000)) / 4.0
+            now = max(0.0, now - step) if rng.random() < 0.2 else now + step
+            if r < 0.85:
+                ops.append(["play", now])
+            elif r < 0.93:
+                ops.append(["seek", now])
+            else:
+                ops.append(["playFrom", now, float(rng.integers(0, 8000)) / 4.0])
+    return ops
+
+
+def gen_animate_fuzz(r_unused, only):
+    """Twelve seeded random scripts on the reference's own Player (see random_animate_script): what tests/golden/animate_script.json
+    pins by hand, in bulk."""
+    if only and only not in ("animate_fuzz", "animate"):
+        return
+    r = RefRunner("demo-modules")
+    cases = []
+    for seed in range(12):
+        ops = random_animate_script(1000 + seed)
+        outputs = {"obj": {"alpha": 0.5, "beta": -1, "flag": True, "label": "x"}, "vec": [0, 0.25, 0.5, 1]}
+        res = r.animate({"obj": [], "vec": []}, ops, outputs)
+        cases.append({"seed": 1000 + seed, "ops": ops, "outputs": outputs, "expected": res["out"], "queries": res["queries"], "frames": res["frames"]})
+    with open(os.path.join(GOLDEN, "animate_fuzz.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote animate_fuzz.json (%d scripts, %d player calls)" % (len(cases), sum(len(c["expected"]) for c in cases)))
+
+
 def scene_colour(proxy, name, preset):
     """The demo's colour proxy (src/demo.main.js:1335-1354): a preset assigns `<name>Color` (0..255) and / or `<name>Alpha`
     to a proxy that keeps everything else, and the state colour is then [r / 255, g / 255, b / 255, alpha]."""
@@ -737,6 +810,7 @@ def main():
     gen_geometry(r, args.only)
     gen_view(r, args.only)
     gen_animate(r, args.only)
+    gen_animate_fuzz(r, args.only)
     gen_presets(r, args.only)
     gen_scene(r, args.only)
     gen_spawn_map(r, args.only)

@@ -99,28 +99,33 @@ def test_python_player_replays_the_reference_script():
 
 
 JS_REPLAY = """
+// replays one script (an object with ops / outputs and, optionally, tracks) or a list of them through js/animate.js
 const {Player} = require('./tendrils_amd/js/animate');
-const fx = JSON.parse(require('fs').readFileSync(process.argv[1]));
-const log = [];
-const fix = (frame) => { if (frame && frame.call) frame.call = frame.call.map((label) => () => log.push(label)); return frame; };
 const spell = (key, v) => (v === Infinity ? 'inf' : (v === -Infinity ? '-inf' : (typeof v === 'number' && v !== v ? 'nan' : v)));
-const tracks = {}; for (const k in fx.tracks) tracks[k] = fx.tracks[k].map(fix);
-const player = new Player(tracks, JSON.parse(JSON.stringify(fx.outputs)));
-const out = [], queries = [];
-for (const op of fx.ops) {
-  if (op[0] === 'track' || op[0] === 'query') {
-    const tl = player.tracks[op[1]];
-    const val = tl[op[2]](...op.slice(3).map((a) => (a && typeof a === 'object' && !Array.isArray(a)) ? fix(a) : a));
-    if (op[0] === 'query') queries.push(JSON.parse(JSON.stringify(val === undefined ? null : val, spell)));
-    continue;
+function replay(fx) {
+  const log = [];
+  const fix = (frame) => { if (frame && frame.call) frame.call = frame.call.map((label) => () => log.push(label)); return frame; };
+  const tracks = {};
+  for (const k of Object.keys(fx.tracks || fx.outputs).sort()) tracks[k] = ((fx.tracks || {})[k] || []).map(fix);
+  const player = new Player(tracks, JSON.parse(JSON.stringify(fx.outputs)));
+  const out = [], queries = [];
+  for (const op of fx.ops) {
+    if (op[0] === 'track' || op[0] === 'query') {
+      const tl = player.tracks[op[1]];
+      const val = tl[op[2]](...op.slice(3).map((a) => (a && typeof a === 'object' && !Array.isArray(a)) ? fix(a) : a));
+      if (op[0] === 'query') queries.push(JSON.parse(JSON.stringify(val === undefined ? null : val, spell)));
+      continue;
+    }
+    if (op[0] === 'play') player.play(op[1]); else if (op[0] === 'seek') player.seek(op[1]); else player.playFrom(op[1], op[2]);
+    const heads = {}; for (const k in player.tracks) heads[k] = [player.tracks[k].time, player.tracks[k].gap, player.tracks[k].frames.length];
+    out.push({outputs: JSON.parse(JSON.stringify(player.outputs)), heads, calls: log.slice()});
   }
-  if (op[0] === 'play') player.play(op[1]); else if (op[0] === 'seek') player.seek(op[1]); else player.playFrom(op[1], op[2]);
-  const heads = {}; for (const k in player.tracks) heads[k] = [player.tracks[k].time, player.tracks[k].gap, player.tracks[k].frames.length];
-  out.push({outputs: JSON.parse(JSON.stringify(player.outputs)), heads, calls: log.slice()});
+  const frames = {};
+  for (const k in player.tracks) frames[k] = player.tracks[k].frames.map((f) => ({time: spell('', f.time), ease: f.ease || null, to: (f.to === undefined ? null : f.to)}));
+  return {out, queries, frames, player: {start: spell('', player.start()), end: spell('', player.end()), duration: spell('', player.duration())}};
 }
-const frames = {};
-for (const k in player.tracks) frames[k] = player.tracks[k].frames.map((f) => ({time: spell('', f.time), ease: f.ease || null, to: (f.to === undefined ? null : f.to)}));
-console.log(JSON.stringify({out, queries, frames, player: {start: spell('', player.start()), end: spell('', player.end()), duration: spell('', player.duration())}}));
+const given = JSON.parse(require('fs').readFileSync(process.argv[1]));
+console.log(JSON.stringify(Array.isArray(given) ? given.map(replay) : replay(given)));
 """
 
 
@@ -134,6 +139,69 @@ def test_js_player_replays_the_reference_script():
     for k, (g, w) in enumerate(zip(got["out"], FIX["expected"])):
         same(g, w, "call %d" % k)
     assert got["queries"] == FIX["queries"] and got["frames"] == FIX["frames"] and got["player"] == FIX["player"]
+
+
+FUZZ = json.load(open(os.path.join(GOLDEN, "animate_fuzz.json")))
+
+
+def replay_python(case):
+    from tendrils_amd.animate import Player
+    log = []
+
+    def fix(frame):
+        if isinstance(frame, dict) and frame.get("call"):
+            frame["call"] = [(lambda out, span, label=label: log.append(label)) for label in frame["call"]]
+        return frame
+    player = Player({k: [] for k in sorted(case["outputs"])}, copy.deepcopy(case["outputs"]))
+    got, queries = [], []
+    for op in copy.deepcopy(case["ops"]):
+        if op[0] in ("track", "query"):
+            val = getattr(player.tracks[op[1]], SNAKE[op[2]])(*[fix(a) if isinstance(a, dict) else a for a in op[3:]])
+            if op[0] == "query":
+                queries.append(spelled(val))
+            continue
+        if op[0] == "play":
+            player.play(op[1])
+        elif op[0] == "seek":
+            player.seek(op[1])
+        else:
+            player.play_from(op[1], op[2])
+        got.append({"outputs": copy.deepcopy(player.outputs),
+                    "heads": {k: [t.time, t.gap, len(t.frames)] for k, t in player.tracks.items()}, "calls": list(log)})
+    frames = {k: [{"time": spelled(f["time"]), "ease": f.get("ease") or None, "to": f.get("to")} for f in t.frames] for k, t in player.tracks.items()}
+    return got, queries, frames
+
+
+@pytest.mark.parametrize("case", FUZZ, ids=lambda c: "seed%d" % c["seed"])
+def test_python_player_replays_random_reference_scripts(case):
+    """Twelve seeded random scripts run on the reference's own Player (oracle/gen_fixtures.py:random_animate_script): keyframes of
+    every kind added before and during playback, removals, plays forwards and backwards, seeks, playFroms - every output, every
+    playhead, every call, every query result and the final timelines, double for double."""
+    got, queries, frames = replay_python(case)
+    assert len(got) == len(case["expected"]) > 5
+    for k, (g, w) in enumerate(zip(got, case["expected"])):
+        same(g, w, "call %d" % k)
+    for k, (g, w) in enumerate(zip(queries, case["queries"])):
+        same(g, w, "query %d" % k)
+    for name, want in case["frames"].items():
+        mine = frames[name]
+        assert len(mine) == len(want)
+        for f, w in zip(mine, want):
+            assert f["time"] == w["time"] and f["ease"] == w["ease"] and f["to"] == w["to"], (name, f, w)
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+def test_js_player_replays_random_reference_scripts():
+    r = subprocess.run([shutil.which("node"), "-e", JS_REPLAY, os.path.join(GOLDEN, "animate_fuzz.json")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    assert len(got) == len(FUZZ)
+    for case, g in zip(FUZZ, got):
+        assert len(g["out"]) == len(case["expected"])
+        for k, (a, w) in enumerate(zip(g["out"], case["expected"])):
+            same(a, w, "seed %d call %d" % (case["seed"], k))
+        assert g["queries"] == case["queries"] and g["frames"] == case["frames"], case["seed"]
 
 
 def test_tween_forms_and_curves():
