@@ -708,51 +708,58 @@ def scene_colour(proxy, name, preset):
     return (name + "Color" in cp) or (name + "Alpha" in cp)
 
 
-def gen_scene(r_unused, only):
-    """preset "Flow" set at once, then keyframes easing into "Turbulence" (reached at frame 12 over 10 frames)
-    and into "Wings" (frame 24, ease joined to the one before) on the reference's own Player, 24 frames of the demo's loop
-    body on the reference's own Tendrils.  Stores the script, the state object after every frame, the particle texture of
-    every frame and flow + view of five frames."""
-    name = "scene_flow_turbulence_wings_64"
-    if only and only not in name and only != "scene":
-        return
-    table = json.load(open(os.path.join(GOLDEN, "presets.json")))
-    n, view, frames, time0, step = 64, (96, 54), 24, 1000.0, 1000 / 60
-    rng = np.random.default_rng(41)
-    st = np.zeros((n, n, 4), np.float32)
-    st[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, 0.55]
-    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
-    defaults = {"baseColor": [1, 1, 1, 0.5], "flowColor": [1, 1, 1, 0.04], "fadeColor": [0.1333, 0.1333, 0.1333, 0]}
-    proxy = {}
-    for c in ("base", "flow", "fade"):
-        proxy[c + "Color"] = [v * 255 for v in defaults[c + "Color"][:3]]
-        proxy[c + "Alpha"] = defaults[c + "Color"][3]
+SCENES = {
+    # name: (first preset, [(preset, frame it is reached at, frames of easing before it (0: from the key before), ease)], seed)
+    "scene_flow_turbulence_wings_64": ("Flow", [("Turbulence", 12, 10, [0, 0.95, 1]), ("Wings", 24, 0, [0, 0.2, 1])], 41),
+    # autoClearView (the view is wiped every frame), a translucent fade, the colour map on: "Fluid", "Ghostly", "Rorschach"
+    "scene_fluid_ghostly_rorschach_64": ("Fluid", [("Ghostly", 9, 6, [0, 0.1, 0.9, 1]), ("Rorschach", 24, 12, [0, 0.95, 1])], 43),
+}
 
-    def colours(preset, only_named):
-        out = {}
+
+def gen_scene(r_unused, only):
+    """a preset set at once, then keyframes easing into others on the reference's own Player, 24 frames of the
+    demo's loop body on the reference's own Tendrils.  Stores the script, the state object after every frame, the particle
+    texture of every frame and flow + view of five frames."""
+    table = json.load(open(os.path.join(GOLDEN, "presets.json")))
+    r = None
+    for name, (first_name, keys, seed) in SCENES.items():
+        if only and only not in name and only != "scene":
+            continue
+        n, view, frames, time0, step = 64, (96, 54), 24, 1000.0, 1000 / 60
+        rng = np.random.default_rng(seed)
+        st = np.zeros((n, n, 4), np.float32)
+        st[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, 0.55]
+        st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+        defaults = {"baseColor": [1, 1, 1, 0.5], "flowColor": [1, 1, 1, 0.04], "fadeColor": [0.1333, 0.1333, 0.1333, 0]}
+        proxy = {}
         for c in ("base", "flow", "fade"):
-            if scene_colour(proxy, c, preset) or not only_named:
-                out[c + "Color"] = [v / 255 for v in proxy[c + "Color"]] + [proxy[c + "Alpha"]]
-        return out
-    first = table["Flow"]
-    colors0 = colours(first, False)
-    script = [dict(preset="Turbulence", time=time0 + 12 * step, duration=10 * step, ease=[0, 0.95, 1]),
-              dict(preset="Wings", time=time0 + 24 * step, duration=0, ease=[0, 0.2, 1])]
-    ops = []
-    for k in script:
-        p = table[k["preset"]]
-        tracks = dict(tendrils=dict(p.get("state", {})), **colours(p, True))
-        for tr, to in tracks.items():
-            frame = {"to": to, "time": k["time"], "ease": list(k["ease"])}
-            ops.append(["track", tr, "smoothOver", k["duration"], frame] if k["duration"] else ["track", tr, "smoothTo", frame])
-    r = RefRunner("demo-modules")
-    grab = [0, 7, 11, 15, 23]
-    res = r.scene(st, ops, state0=first.get("state", {}), colors0=colors0, time0=time0, frames=frames, view=view, grab=grab)
-    assert res["samples"] == 0
-    meta = dict(kind="scene", N=n, frames=frames, viewRes=list(view), viewSize=res["viewSize"], time0=time0, times=res["times"],
-                dts=res["dts"], first="Flow", script=script, ops=ops, colors0=colors0, grab=grab, states=res["states"])
-    save(name, state=st, out=res["particles"], flows=np.stack([res["flows"][g] for g in grab]),
-         views=np.stack([res["views"][g] for g in grab]), uniforms=json.dumps(meta))
+            proxy[c + "Color"] = [v * 255 for v in defaults[c + "Color"][:3]]
+            proxy[c + "Alpha"] = defaults[c + "Color"][3]
+
+        def colours(preset, only_named):
+            out = {}
+            for c in ("base", "flow", "fade"):
+                if scene_colour(proxy, c, preset) or not only_named:
+                    out[c + "Color"] = [v / 255 for v in proxy[c + "Color"]] + [proxy[c + "Alpha"]]
+            return out
+        first = table[first_name]
+        colors0 = colours(first, False)
+        script = [dict(preset=p, time=time0 + at * step, duration=over * step, ease=ease) for p, at, over, ease in keys]
+        ops = []
+        for k in script:
+            p = table[k["preset"]]
+            tracks = dict(tendrils=dict(p.get("state", {})), **colours(p, True))
+            for tr, to in tracks.items():
+                frame = {"to": to, "time": k["time"], "ease": list(k["ease"])}
+                ops.append(["track", tr, "smoothOver", k["duration"], frame] if k["duration"] else ["track", tr, "smoothTo", frame])
+        r = r or RefRunner("demo-modules")
+        grab = [0, 7, 11, 15, 23]
+        res = r.scene(st, ops, state0=first.get("state", {}), colors0=colors0, time0=time0, frames=frames, view=view, grab=grab)
+        assert res["samples"] == 0
+        meta = dict(kind="scene", N=n, frames=frames, viewRes=list(view), viewSize=res["viewSize"], time0=time0, times=res["times"],
+                    dts=res["dts"], first=first_name, script=script, ops=ops, colors0=colors0, grab=grab, states=res["states"])
+        save(name, state=st, out=res["particles"], flows=np.stack([res["flows"][g] for g in grab]),
+             views=np.stack([res["views"][g] for g in grab]), uniforms=json.dumps(meta))
 
 
 def gen_presets(r_unused, only):

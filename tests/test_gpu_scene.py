@@ -1,6 +1,7 @@
 """Scene replay on the GPU against frames captured from the REFERENCE: its own Player driving its own
-Tendrils - preset "Flow", then keyframes easing into "Turbulence" and "Wings" over 24 frames of tick / play / step / draw
-(oracle/gen_fixtures.py:gen_scene -> tests/golden/scene_flow_turbulence_wings_64.npz).  The same script runs through
+Tendrils - preset "Flow", then keyframes easing into "Turbulence" and "Wings"; preset "Fluid" (the view wiped every frame)
+into "Ghostly" and "Rorschach" - over 24 frames of tick / play / step / draw (oracle/gen_fixtures.py:gen_scene ->
+tests/golden/scene_*.npz).  The same script runs through
 tendrils_amd/scenes.py and through the Node host's js/scenes.js: the state object must follow the reference's double for
 double, the particle texture, the flow field and the view image within tests/test_scene_script.py:scene_close."""
 import json
@@ -12,13 +13,19 @@ import numpy as np
 import pytest
 
 from helpers import GOLDEN, ROOT
-from test_scene_script import FX, META, TABLE, check_states, scene_close
+from test_scene_script import SCENES, TABLE, check_states, scene_close
 
 pytestmark = pytest.mark.gpu
 
 
-def test_python_scene_against_the_reference_frames():
+@pytest.fixture(params=SCENES, ids=lambda c: c.name)
+def captured(request):
+    return request.param
+
+
+def test_python_scene_against_the_reference_frames(captured):
     import copy
+    FX, META = captured.FX, captured.META
     import tendrils_amd as ta
     from tendrils_amd.scenes import Scene
     from tendrils_amd.tendrils import View
@@ -42,12 +49,13 @@ def test_python_scene_against_the_reference_frames():
             views.append(tn.read_view())
     scene.run(META["frames"], each=each)
     t.dispose()
-    check_states(hosts)
-    scene_close(states, flows, views)
+    check_states(hosts, META)
+    scene_close(states, flows, views, captured)
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
-def test_node_scene_against_the_reference_frames(tmp_path):
+def test_node_scene_against_the_reference_frames(tmp_path, captured):
+    FX, META = captured.FX, captured.META
     FX["state"].astype(np.float32).tofile(tmp_path / "state.bin")
     spec = dict(kind="scene", N=META["N"], viewRes=META["viewRes"], inputs={"state": "state.bin"}, time0=META["time0"],
                 frames=META["frames"], grab=META["grab"], first=META["first"], script=META["script"], table=TABLE)
@@ -57,12 +65,12 @@ def test_node_scene_against_the_reference_frames(tmp_path):
     assert r.returncode == 0, r.stderr
     res = json.loads((tmp_path / "result.json").read_text())
     assert res["times"] == META["times"]
-    check_states(res["states"])
+    check_states(res["states"], META)
     n, (fw, fh) = META["N"], META["viewRes"]
     states = [np.fromfile(tmp_path / ("state_%d.bin" % k), np.float32).reshape(n, n, 4) for k in range(META["frames"])]
     flows = [np.fromfile(tmp_path / ("flow_%d.bin" % k), np.float32).reshape(fh, fw, 4) for k in META["grab"]]
     views = [np.fromfile(tmp_path / ("view_%d.bin" % k), np.uint8).reshape(fh, fw, 4) for k in META["grab"]]
-    scene_close(states, flows, views)
+    scene_close(states, flows, views, captured)
 
 
 def test_replay_tool_runs(tmp_path):
