@@ -552,7 +552,9 @@ def c4_leg(args, rank, local_rank, world, dist):
            "particles_per_gpu": job.particles_rank, "repetitions": repetition_block(walls, args.steps),
            "rccl": job.rccl_block(stats, reductions),
            "workload": (job.cfg["label"] % "RGBA32F") + ", same flow and uniforms as the headline, fused launches of <= %d steps, "
-                       "statistics + counter all-reduce after every launch" % job.launch_len}
+                       "statistics + counter all-reduce after every launch" % job.launch_len,
+           "note": "K = %d steps run as %s: a short trailing launch streams 48 / n bytes per particle-step like any other and costs "
+                   "its own statistics" % (args.steps, " + ".join(str(min(job.launch_len, args.steps - d)) for d in range(0, args.steps, job.launch_len)) + " step launches")}
     job.dispose()
     return out
 
