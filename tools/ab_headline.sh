@@ -1,6 +1,8 @@
 #!/bin/bash
 # Same-box A/B of the headline (driver command) between the round-2 tree (tools/bin/ab/r2, built from 1583d4f~1 by
 # `git archive` + make; git-ignored, travels with gpurun) and the working tree: alternating runs, `value` of each.
+# Set up (build container): mkdir -p tools/bin/ab/r2 && git archive 1583d4f~1 -- tendrils_amd oracle bench.py include __graft_entry__.py tests/helpers.py | tar -x -C tools/bin/ab/r2
+#                           && make -C tools/bin/ab/r2/tendrils_amd/csrc all && make -C tools/bin/ab/r2/oracle all
 # usage (on the GPU box): bash tools/ab_headline.sh [rounds] > gpurun_out/ab_headline.txt
 rounds=${1:-3}
 root=$(pwd)
