@@ -64,8 +64,6 @@ import argparse
 import ctypes as C
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -74,559 +72,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N = 4096                        # C3: particles per rank = N*N
-FLOW_W, FLOW_H = 1920, 1080
-BYTES_PER_PARTICLE_STEP = 32    # 16 B state read + 16 B written; 8 + 8 with packed state
-HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK = 256 * 4 * 2.4e9 / 2     # wave64 VALU instructions per second: 2 cycles each on a SIMD-32
-MAX_FUSED = 32                  # th::kMaxFusedSteps
-PREROLL_MS = 60.0
-
-CONFIGS = {
-    # name: (width, global height as a function of world, rows per rank, state, steps per group, scaling)
-    "c3": dict(width=N, rows=lambda w: N, gheight=lambda w: N * w, state="f32", group=32, scaling="weak",
-               label="C3: 4096x4096 %s state (16.8M particles) per GPU"),
-    "c4": dict(width=8192, rows=lambda w: 8192 // w, gheight=lambda w: 8192, state="f32", group=16, scaling="strong",
-               label="C4: 8192x8192 %s state (67.1M particles) row-sharded over the GPUs"),
-    "c5": dict(width=16384, rows=lambda w: 16384 // w, gheight=lambda w: 16384, state="f16", group=16, scaling="strong",
-               label="C5: 16384x16384 %s state (268M particles) row-sharded over the GPUs"),
-}
-
-
-def synth_rows(width, rows, seed):
-    rng = np.random.default_rng(seed)
-    st = np.empty((rows, width, 4), np.float32)
-    st[..., :2] = rng.uniform(-1, 1, (rows, width, 2))
-    st[..., 2:] = rng.uniform(-.01, .01, (rows, width, 2))
-    return st
-
-
-def synth_state(rank):
-    return synth_rows(N, N, 12345 + rank)
-
-
-def synth_frames():
-    """frame0 = seeded band-limited pattern, frame1 = frame0 translated by (1.5, 0.7) px."""
-    yy, xx = np.mgrid[0:FLOW_H, 0:FLOW_W].astype(np.float64)
-
-    def pattern(dx, dy):
-        img = np.zeros((FLOW_H, FLOW_W, 3))
-        r = np.random.default_rng(778)
-        for _ in range(24):
-            fx, fy = r.uniform(-0.08, 0.08, 2)
-            ph = r.uniform(0, 2 * np.pi, 3)
-            amp = r.uniform(0.2, 1.0)
-            for c in range(3):
-                img[..., c] += amp * np.sin((xx - dx) * fx + (yy - dy) * fy + ph[c])
-        img = (img - img.min()) / (img.max() - img.min())
-        out = np.empty((FLOW_H, FLOW_W, 4), np.uint8)
-        out[..., :3] = np.clip(np.rint(img * 255), 0, 255).astype(np.uint8)
-        out[..., 3] = 255
-        return out
-    return pattern(0.0, 0.0), pattern(1.5, 0.7)
-
-
-def synth_flow(time_ms):
-    """Divergence-free seeded field in reference flow format (Fx, Fy, t_deposit, alpha)."""
-    yy, xx = np.mgrid[0:FLOW_H, 0:FLOW_W].astype(np.float32)
-    r = np.random.default_rng(4242)
-    psi_x = np.zeros((FLOW_H, FLOW_W), np.float32)
-    psi_y = np.zeros((FLOW_H, FLOW_W), np.float32)
-    for _ in range(12):
-        fx, fy = r.uniform(-0.05, 0.05, 2).astype(np.float32)
-        ph = np.float32(r.uniform(0, 2 * np.pi))
-        a = np.float32(r.uniform(0.3, 1.0))
-        c = a * np.cos(xx * fx + yy * fy + ph)
-        psi_x += c * fy        # d(psi)/dy
-        psi_y += -c * fx       # -d(psi)/dx
-    s = np.float32(0.01) / max(np.abs(psi_x).max(), np.abs(psi_y).max())
-    fl = np.empty((FLOW_H, FLOW_W, 4), np.float32)
-    fl[..., 0] = psi_x * s
-    fl[..., 1] = psi_y * s
-    fl[..., 2] = time_ms
-    fl[..., 3] = 1.0
-    return fl
-
-
-# ---- rocprofv3 PMC child passes ----------------------------------------------------------------------------
-PMC_PASSES = (("FETCH_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"), ("WRITE_SIZE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"))
-
-
-def kernel_class(name):
-    """Which of the measured launches a kernel-trace row belongs to (template arguments: <FAST, NOISE, ...>)."""
-    for base in ("logic_fused_packed_kernel", "logic_fused_kernel", "logic_packed_kernel", "logic_sorted_kernel", "logic_kernel"):
-        if "th::" + base + "<" in name:
-            args = name.split(base + "<", 1)[1].split(",")
-            noise = len(args) > 1 and args[1].strip().startswith("true")
-            fused = "fused" in base
-            return ("fused" if fused else "single") + ("" if noise else "_flow_only")
-    return None
-
-
-def measure_pmc(extra_args, launch_len):
-    """PMC counters of the integrator launches from rocprofv3, as MI355X_MICROARCH.md (HBM) prescribes: FETCH_SIZE
-    and WRITE_SIZE in separate --pmc passes of the same workload (short child runs of this script with launches of
-    `launch_len` steps like the timed region), FETCH_SIZE doubled when turned into bytes (gfx950 tallies the 128-B
-    requests of a wide coalesced stream at 64 B), both in KiB.  Runs before this process touches the GPU.
-    Returns {class: {counter: mean per launch}} and a note."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
-        return {}, "rocprofv3 not found"
-    out_all = {}
-    notes = []
-    for group in PMC_PASSES:
-        out = tempfile.mkdtemp(prefix="th_pmc_", dir="/tmp")
-        cmd = [prof, "--pmc"] + list(group) + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
-               sys.executable, os.path.abspath(__file__), "--pmc-child", str(launch_len), "--no-cpu", "--no-traffic"] + extra_args
-        try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=300, check=True)
-            dur = {}
-            for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
-            per_dispatch = {}
-            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    cls = kernel_class(row.get("Kernel_Name", ""))
-                    if cls:
-                        per_dispatch.setdefault((cls, row["Dispatch_Id"]), {})[row["Counter_Name"]] = float(row["Counter_Value"])
-            for (cls, did), cs in per_dispatch.items():
-                d = out_all.setdefault(cls, {})
-                for k, v in cs.items():
-                    d.setdefault(k, []).append(v)
-                if cs.get("GRBM_GUI_ACTIVE", 0) > 0:
-                    cyc = cs["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
-                    if dur.get(did, 0) > 0:
-                        d.setdefault("clock_ghz", []).append(cyc / dur[did])          # cycles per ns
-                        d.setdefault("profiled_launch_ms", []).append(dur[did] * 1e-6)
-                    if "SQ_INSTS_VALU" in cs:      # issue slots used: 2 cycles per wave64 instruction on each of 1024 SIMDs
-                        d.setdefault("valu_issue_utilization", []).append(cs["SQ_INSTS_VALU"] * 2.0 / (cyc * 1024.0))
-        except (subprocess.SubprocessError, OSError) as e:
-            notes.append("pass %s failed: %s" % ("+".join(group), type(e).__name__))
-        finally:
-            shutil.rmtree(out, ignore_errors=True)
-    res = {cls: {k: sum(v) / len(v) for k, v in cs.items()} for cls, cs in out_all.items()}
-    note = "rocprofv3 PMC, child runs with %d-step launches; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB" % launch_len
-    if notes:
-        note += "; " + "; ".join(notes)
-    return res, note
-
-
-def pmc_bytes(c):
-    if not c or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
-        return None
-    return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-
-
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
-def self_launch(gpus, argv):
-    """`bench.py --gpus N` with no launcher around it: start the N ranks as a child job - from a process that has not
-    touched the GPU (nothing here imports torch) - relay rank 0's JSON line, return the child's status."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what this pool's driver supports (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", "4")
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    line = None
-    for out in child.stdout:
-        text = out.strip()
-        if text.startswith("{") and '"metric"' in text:
-            line = text
-        elif text:
-            sys.stderr.write(out)
-    rc = child.wait()
-    if line is not None:
-        print(line, flush=True)
-    return rc if rc else (0 if line is not None else 1)
-
-
-def median(xs):
-    ys = sorted(xs)
-    return ys[len(ys) // 2] if len(ys) % 2 else 0.5 * (ys[len(ys) // 2 - 1] + ys[len(ys) // 2])
-
-
-def repetition_block(walls, steps):
-    ms = [w / steps * 1e3 for w in walls]
-    mid = median(ms)
-    return {"n": len(ms), "ms_per_step": ms, "median": mid, "min": min(ms), "max": max(ms),
-            "spread": (max(ms) - min(ms)) / mid if mid > 0 else None,
-            "note": "each repetition: barrier + synchronize, K steps, barrier + synchronize; max over ranks; value = median"}
-
-
-class Job:
-    """One rank's share of a configuration: the Tendrils object with its synthetic state and flow, the step loop of the
-    timed region (fused launches + statistics + the counter all-reduce + optical-flow refresh) and its timing."""
-
-    def __init__(self, args, config, rank, local_rank, world, dist, launch_len=None):
-        import tendrils_amd as ta
-        from tendrils_amd import _capi
-        from tendrils_amd.sharding import comm_init, comm_query, shard_rows
-        from tendrils_amd.tendrils import View
-        self.ta, self.capi, self.dist, self.world, self.rank = ta, _capi, dist, world, rank
-        cfg = CONFIGS[config]
-        self.cfg, self.config = cfg, config
-        self.state_fmt = args.state or cfg["state"]
-        self.group = cfg["group"]                    # steps per fused launch and per statistics reduction
-        self.width, self.rows, self.gheight = cfg["width"], cfg["rows"](world), cfg["gheight"](world)
-        self.particles_rank = self.width * self.rows
-        self.launch_len = launch_len or min(self.group, args.steps)
-        opts = ta.defaults()
-        opts.update(device=local_rank, mode=ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT,
-                    row0=shard_rows(self.gheight, world, rank)[0], rows=self.rows, globalHeight=self.gheight,
-                    stateFormat=ta.TH_STATE_F16 if self.state_fmt == "f16" else ta.TH_STATE_F32)
-        t = self.t = ta.Tendrils(View(FLOW_W, FLOW_H), opts)
-        t.resize()                       # viewRes 1920x1080 -> viewSize [1, 1.7778]; flow.shape = viewRes
-        t.setup(self.width)
-        ctx = self.ctx = t.particles._ctx
-        band = 1024                      # generated and uploaded in row bands (bounded host memory at C5)
-        full = synth_state(rank) if config == "c3" else None
-        for r0 in range(0, self.rows, band):
-            r1 = min(self.rows, r0 + band)
-            st = full[r0:r1] if full is not None else synth_rows(self.width, r1 - r0, 12345 + rank * 1000003 + r0)
-            if args.in_view:
-                st = st.copy()
-                st[..., 1] *= np.float32(0.56)
-            _capi.call("th_upload_state", ctx, -1, np.ascontiguousarray(st).ctypes.data_as(_capi._fp), 0, r0, self.width, r1 - r0)
-        full = st = None
-
-        # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
-        self.time0 = 1000.0
-        self.flow_source = "optical-flow(synthetic 1080p frame pair)"
-        self.of = None
-        try:
-            from tendrils_amd.optical_flow import OpticalFlow
-            f0, f1 = synth_frames()
-            of = OpticalFlow(t, uniforms=dict(speed=0.08, offset=0.1, scaleUV=[-1, -1]))   # src/demo.main.js:526-530
-            of.resize([FLOW_W, FLOW_H])
-            of.set_pixels(f0)
-            of.step()
-            of.set_pixels(f1)
-            of.update(dict(speedLimit=t.state["speedLimit"], time=self.time0, viewSize=t.viewSize))
-            of.render()
-            self.of = of
-        except (ImportError, ta.TendrilsHipError):
-            self.flow_source = "synthetic divergence-free field (optical-flow pass unavailable)"
-            t.flow.set_pixels(synth_flow(self.time0))
-        t.timer.time = self.time0
-        # the job's communicator inside the library: the counter all-reduce of the timed region is th_stats_allreduce
-        self.comm, self.comm_fallback = None, None
-        if dist is not None:
-            # (should the library's own communicator not come up - librccl not loadable beside torch's, say - on any rank,
-            # every rank falls back to reducing the counter block through torch.distributed, and the line says so: a
-            # scaling run is not lost to it)
-            import torch
-            why = "--no-library-comm" if args.no_library_comm else ""
-            try:
-                if not why:
-                    comm_init(ctx, dist)
-                    self.comm = comm_query(ctx)
-            except ta.TendrilsHipError as e:
-                why = str(e)
-            ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if self.comm is not None:
-                    _capi.call("th_comm_destroy", ctx)
-                self.comm = None
-                self.comm_fallback = why or "another rank could not join the library's communicator"
-                self._counters_view = None
-        self.reductions = 0
-        if args.flow_only:
-            t.state["noiseWeight"] = 0
-
-    def sync_all(self):
-        import torch
-        self.t.particles.sync()
-        torch.cuda.synchronize()
-        if self.dist is not None:
-            self.dist.barrier()
-            torch.cuda.synchronize()
-
-    def stats_tick(self):
-        """statistics of buffers[0] and - world > 1 - their reduction over the ranks, both enqueued on the context's
-        stream (the library's RCCL all-reduce: no host sync, no second stream)"""
-        dev = C.c_void_p()
-        self.capi.call("th_stats_async", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(dev))
-        if self.comm is not None:
-            self.capi.call("th_stats_allreduce", self.ctx)
-            self.reductions += 1
-        elif self.comm_fallback:
-            self.fallback_reduce(dev.value)
-            self.reductions += 1
-
-    def fallback_reduce(self, dev_ptr):
-        """(fallback) the th_counters block - five u64 and a f64 summed, a f64 maximised - reduced in place through
-        torch.distributed on the context's stream"""
-        import torch
-        from tendrils_amd.sharding import device_view
-        if self._counters_view is None:
-            sp = C.c_void_p()
-            self.capi.call("th_stream", self.ctx, C.byref(sp))
-            self._ext = torch.cuda.ExternalStream(sp.value)
-            self._counters_view = (device_view(dev_ptr, (5,), "<i8"), device_view(dev_ptr + 40, (1,), "<f8"), device_view(dev_ptr + 48, (1,), "<f8"))
-        counts, total, peak = self._counters_view
-        with torch.cuda.stream(self._ext):
-            self.dist.all_reduce(counts)
-            self.dist.all_reduce(total)
-            self.dist.all_reduce(peak, op=self.dist.ReduceOp.MAX)
-
-    def run(self, k_steps, every=None, refresh=True):
-        # the step loop runs as fused launches (Tendrils.step_n -> th_step_n), `every` steps each; after EVERY launch
-        # (a trailing partial one included): statistics + their reduction over the ranks; after every full group the
-        # optical-flow refresh
-        t, of = self.t, self.of
-        every = min(every or self.group, max(k_steps, 1))
-        done = 0
-        while done < k_steps:
-            n = min(every, k_steps - done)
-            t.step_n(n)
-            done += n
-            self.stats_tick()
-            if of is not None and refresh and done % self.group == 0:      # keep the field alive: re-stamp it from the frame pair (blended)
-                of.update(dict(speedLimit=t.state["speedLimit"], time=t.timer.time, viewSize=t.viewSize))
-                of.render()
-
-    def run_kernel_only(self, k_steps, length):
-        done = 0
-        while done < k_steps:
-            n = min(length, k_steps - done)
-            self.t.step_n(n)
-            done += n
-
-    def timed_kernels(self, fn):
-        """mean launch duration (HIP event pair around every integrator launch on the context's stream)"""
-        ms, n = C.c_float(), C.c_int32()
-        self.capi.call("th_kernel_timing", self.ctx, 1)
-        fn()
-        self.capi.call("th_kernel_timing_read", self.ctx, C.byref(ms), C.byref(n))
-        self.capi.call("th_kernel_timing", self.ctx, 0)
-        return ms.value, n.value
-
-    def preroll(self):
-        """clock pre-roll: the launches of the timed region, untimed, until >= PREROLL_MS have run on the device"""
-        self.sync_all()
-        p0 = time.perf_counter()
-        self.run_kernel_only(self.launch_len, self.launch_len)
-        self.sync_all()
-        est = max(time.perf_counter() - p0, 1e-4)
-        pre_launches = int(min(max(PREROLL_MS * 1e-3 / est, 1), 4096))
-        p0 = time.perf_counter()
-        self.run_kernel_only(pre_launches * self.launch_len, self.launch_len)
-        self.sync_all()
-        return (time.perf_counter() - p0) * 1e3
-
-    def timed_region(self, steps, reps, **kw):
-        """`reps` x [barrier + synchronize, `steps` steps, barrier + synchronize] -> wall seconds of each (this rank)"""
-        walls = []
-        for _ in range(reps):
-            self.sync_all()
-            t0 = time.perf_counter()
-            self.run(steps, **kw)
-            self.sync_all()
-            walls.append(time.perf_counter() - t0)
-        return walls
-
-    def max_over_ranks(self, values):
-        if self.dist is None:
-            return [float(v) for v in values]
-        import torch
-        v = torch.tensor(list(values), dtype=torch.float64, device="cuda")
-        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
-        return [float(x) for x in v]
-
-    def global_stats(self):
-        """th_stats_global: the job's counters (local pass + the library's all-reduce + download)"""
-        if self.comm_fallback:
-            import torch
-            dev = C.c_void_p()
-            self.capi.call("th_stats_async", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(dev))
-            self.fallback_reduce(dev.value)
-            self.t.particles.sync()
-            torch.cuda.synchronize()
-            counts, total, peak = self._counters_view
-            names = [k for k, _ in self.capi.Counters._fields_]
-            vals = [int(v) for v in counts.cpu().tolist()] + [float(total.cpu()[0]), float(peak.cpu()[0])]
-            return dict(zip(names, vals))
-        c = self.capi.Counters()
-        self.capi.call("th_stats_global", self.ctx, C.c_float(self.t.state["speedLimit"]), C.byref(c))
-        return {k: getattr(c, k) for k, _ in self.capi.Counters._fields_}
-
-    def rccl_block(self, stats, reductions_per_rep):
-        seen = stats["particles"] / float(self.particles_rank)
-        b = {"world": self.world, "nranks_seen": seen, "reductions_per_timed_repetition": reductions_per_rep,
-             "note": "nranks_seen = the all-reduced `particles` counter / this rank's particles: the ranks whose blocks the "
-                     "library's RCCL all-reduce (th_stats_allreduce, on the context's stream) added up; at world 1 the "
-                     "context holds no communicator and the local block is the global one"}
-        if self.comm is not None:
-            b.update(version=self.comm["rccl_version"], in_library=True, rank=self.comm["rank"])
-        elif self.comm_fallback:
-            b.update(in_library=False, fallback="torch.distributed all-reduce of the counter block: " + self.comm_fallback)
-        return b
-
-    def dispose(self):
-        self.t.dispose()
-
-
-def roofline_entry(job, launch_s, steps_in_launch, counters, bytes_per_step):
-    """roofline entries of one kind of launch"""
-    alg = bytes_per_step * job.particles_rank * steps_in_launch
-    eq = alg / launch_s / 1e9 / HBM_PEAK_GBS
-    e = {"avg_launch_ms": launch_s * 1e3, "steps_per_launch": steps_in_launch,
-         "ms_per_step": launch_s * 1e3 / steps_in_launch,
-         "achieved": alg / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "equivalent_frac": eq,
-         "algorithmic_bytes_per_launch": alg}
-    tb = pmc_bytes(counters)
-    e["traffic"] = tb
-    if tb is not None:
-        e["hbm_physical"] = {"achieved": tb / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": tb / launch_s / 1e9 / HBM_PEAK_GBS, "bytes_over_algorithmic": tb / alg}
-    if counters and "SQ_INSTS_VALU" in counters:
-        v = counters["SQ_INSTS_VALU"]
-        e["valu"] = {"wave_insts_per_launch": v, "per_wave_step": v / (job.particles_rank / 64.0 * steps_in_launch),
-                     "achieved": v / launch_s, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": v / launch_s / VALU_PEAK}
-        if "clock_ghz" in counters:      # under the profiler (launches run a few % slower there)
-            e["valu"]["clock_ghz"] = counters["clock_ghz"]
-            e["valu"]["profiled_launch_ms"] = counters.get("profiled_launch_ms")
-            e["valu"]["issue_utilization_at_held_clock"] = counters.get("valu_issue_utilization")
-            e["valu"]["note"] = "peak = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 instruction; clock_ghz = GRBM_GUI_ACTIVE / 8 / launch " \
-                                "duration and issue_utilization = 2 x SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), both per " \
-                                "dispatch in the PMC child run: the clock the chip held under this load and the share of its issue " \
-                                "slots the launch used at that clock"
-    if counters and "SQ_LDS_IDX_ACTIVE" in counters and counters["SQ_LDS_IDX_ACTIVE"] > 0:
-        e["lds"] = {"bank_conflict_share": counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]}
-    return e
-
-
-def bind(e, fused):
-    """`bound` and `frac` of an entry: the fraction of the bound it names, never the equivalent bandwidth of a
-    register-resident launch.  One step per launch streams its algorithmic bytes: HBM, frac = algorithmic / peak.
-    A fused launch is bound by whichever of VALU issue and physical HBM traffic it uses more of (PMC child runs);
-    without counters the bound is not known and frac stays null."""
-    if not fused:
-        e["bound"], e["frac"] = "hbm", e["equivalent_frac"]
-        e["frac_is"] = "algorithmic bytes / launch duration / HBM peak (a single-step launch streams them)"
-        return e
-    v = (e.get("valu") or {}).get("frac")
-    h = (e.get("hbm_physical") or {}).get("frac")
-    if v is None and h is None:
-        e["bound"], e["frac"] = "valu", None
-        e["frac_is"] = "unknown: the PMC child runs gave no counters (equivalent_frac is the SURVEY.md 8d figure)"
-    elif h is None or (v is not None and v >= h):
-        e["bound"], e["frac"] = "valu", v
-        e["frac_is"] = "valu.frac: wave64 VALU instructions per second / the chip's issue peak at 2.4 GHz"
-    else:
-        e["bound"], e["frac"] = "hbm", h
-        e["frac_is"] = "hbm_physical.frac: PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) / launch duration / HBM peak"
-    return e
-
-
-def c4_leg(args, rank, local_rank, world, dist):
-    """BASELINE.json config 4 beside the metric's own configuration: 8192 x 8192 particles row-sharded over the ranks
-    (strong scaling: 64 M particles in all, whatever N), counters reduced after every 16-step launch."""
-    job = Job(args, "c4", rank, local_rank, world, dist)
-    job.run(args.warmup)
-    job.preroll()
-    job.reductions = 0
-    walls = job.timed_region(args.steps, max(args.reps // 2, 3))
-    reductions = job.reductions // max(args.reps // 2, 3)
-    walls = job.max_over_ranks(walls)
-    stats = job.global_stats()
-    particles = job.particles_rank * world
-    mid = median(walls)
-    out = {"value": particles * args.steps / mid, "unit": "particle-steps/s", "ms_per_step": mid / args.steps * 1e3,
-           "scaling": "strong", "n_gpus": world, "steps": args.steps, "particles": particles,
-           "particles_per_gpu": job.particles_rank, "repetitions": repetition_block(walls, args.steps),
-           "rccl": job.rccl_block(stats, reductions),
-           "workload": (job.cfg["label"] % "RGBA32F") + ", same flow and uniforms as the headline, fused launches of <= %d steps, "
-                       "statistics + counter all-reduce after every launch" % job.launch_len,
-           "note": "K = %d steps run as %s: a short trailing launch streams 48 / n bytes per particle-step like any other and costs "
-                   "its own statistics" % (args.steps, " + ".join(str(min(job.launch_len, args.steps - d)) for d in range(0, args.steps, job.launch_len)) + " step launches")}
-    job.dispose()
-    return out
-
-
-def dry_run(args, rank, world):
-    """The launcher path, the rank plumbing, the timed-region protocol and the collective on CPU: gloo ranks stepping a
-    small row band each with the CPU restatement (test infrastructure - this measures nothing and says so)."""
-    import torch
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29512")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    from tendrils_amd.sharding import reduce_counters, shard_rows
-    n = 48
-    gheight = n * world
-    row0, rows = shard_rows(gheight, world, rank)
-    band = synth_rows(n, rows, 12345 + rank)
-    fl = np.zeros((27, 48, 4), np.float32)
-    fl[..., :2] = np.random.default_rng(5).uniform(-.01, .01, (27, 48, 2))
-    fl[..., 2] = 990.0
-    group = min(4, max(args.steps, 1))
-    tm = {"time": 1000.0}
-
-    def counters(b):
-        live = (b[..., 0] != -1e6) | (b[..., 1] != -1e6)
-        sp = np.hypot(b[..., 2].astype(np.float64), b[..., 3].astype(np.float64))[live]
-        return dict(particles=b.shape[0] * n, live=int(live.sum()), nan=int(np.isnan(b).any(-1).sum()),
-                    capped=int((sp >= 0.01 * (1 - 2 ** -20)).sum()), respawned=0, sum_speed=float(np.nansum(sp)),
-                    max_speed=float(np.nanmax(sp)) if sp.size else 0.0)
-
-    state = {"band": band, "red": None, "reductions": 0}
-
-    def run(k):
-        done = 0
-        while done < k:
-            m = min(group, k - done)
-            for _ in range(m):
-                tm["time"] += 1000.0 / 60.0
-                u = O.logic_uniforms(n, gheight, tm["time"], 1000.0 / 60.0, view_size=(1, 48 / 27))
-                state["band"] = O.logic_step(u, state["band"], fl, y0=row0)
-            done += m
-            state["red"] = reduce_counters(dist, counters(state["band"]))
-            state["reductions"] += 1
-
-    run(args.warmup)
-    walls = []
-    for _ in range(args.reps):
-        dist.barrier()
-        t0 = time.perf_counter()
-        state["reductions"] = 0
-        run(args.steps)
-        dist.barrier()
-        walls.append(time.perf_counter() - t0)
-    v = torch.tensor(walls, dtype=torch.float64)
-    dist.all_reduce(v, op=dist.ReduceOp.MAX)
-    walls = [float(x) for x in v]
-    mid = median(walls)
-    line = {"metric": "particle-steps/sec (dry run: CPU restatement over gloo, plumbing only)", "dry_run": True,
-            "value": n * gheight * args.steps / mid, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": mid / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "dry run: %d x %d particles per rank, CPU restatement, gloo" % (n, rows)},
-            "repetitions": repetition_block(walls, args.steps),
-            "rccl": {"world": world, "nranks_seen": state["red"]["particles"] / float(rows * n), "backend": "gloo",
-                     "reductions_per_timed_repetition": state["reductions"]},
-            "counters": state["red"]}
-    dist.barrier()
-    dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(line), flush=True)
+from benchlib import workload as W  # noqa: E402
+from benchlib.job import Job, median, repetition_block  # noqa: E402
+from benchlib.launcher import dry_run, self_launch  # noqa: E402
+from benchlib.legs import c4_leg, cpu_baseline, frame_loop  # noqa: E402
+from benchlib.pmc import measure_pmc, pmc_bytes  # noqa: E402,F401
+from benchlib.roofline import bind, roofline_entry  # noqa: E402
+from benchlib.workload import (BYTES_PER_PARTICLE_STEP, CONFIGS, HBM_PEAK_GBS, MAX_FUSED, synth_rows, synth_state)  # noqa: E402,F401
 
 
 def main():
@@ -652,9 +104,8 @@ def main():
     args = ap.parse_args()
     args.reps = max(args.reps, 1)
 
-    global FLOW_W, FLOW_H
     if args.flow_size:
-        FLOW_W, FLOW_H = (int(v) for v in args.flow_size.lower().split("x"))
+        W.FLOW_W, W.FLOW_H = (int(v) for v in args.flow_size.lower().split("x"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: become one (before anything touches the GPU) and relay rank 0's line
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -818,7 +269,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",     # arithmetic is fp32 in both storage formats
         "preroll_ms": preroll_ms,
         "repetitions": repetition_block(walls, args.steps),
-        "config": {"workload": (cfg["label"] % storage) + ", flow %dx%d from " % (FLOW_W, FLOW_H)
+        "config": {"workload": (cfg["label"] % storage) + ", flow %dx%d from " % (W.FLOW_W, W.FLOW_H)
                                + job.flow_source + ", reference default uniforms"
                                + (" with noiseWeight=0 (flow-only)" if args.flow_only else " (simplex noise on)")
                                + ", 60 Hz fixed timer; step loop as fused launches of <= %d steps, statistics "
@@ -842,7 +293,7 @@ def main():
             line["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
-            line["cpu_baseline"] = cpu_baseline(t, width, min(rows, N))
+            line["cpu_baseline"] = cpu_baseline(t, width, min(rows, W.N))
         except Exception as e:            # noqa: BLE001
             line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %s: %s" % (type(e).__name__, e)}
@@ -870,153 +321,6 @@ def main():
         print(json.dumps(line), flush=True)
 
 
-def frame_loop(t, ctx, state, frames=20):
-    """SURVEY.md 8f-1/8f-2 beside the headline: the reference's frame loop - timer.tick(), step(), draw() - on the same
-    particles: one single-step launch, the flow pass of draw() (the particle lines blended into the flow field in GL
-    primitive order) and the view pass (the same lines into the RGBA8 view buffer), each timed with a HIP event pair
-    on the context's stream."""
-    from tendrils_amd import _capi
-    ms = C.c_float()
-
-    def timed(fn):
-        _capi.call("th_timer_start", ctx)
-        fn()
-        _capi.call("th_timer_stop", ctx, C.byref(ms))
-        return ms.value
-
-    t.particles.upload_texels(state)
-    t.timer.time = 1000.0
-    keep = t.renderView
-    for _ in range(5):
-        t.timer.tick(); t.step(); t.draw()
-    step_ms, flow_ms, view_ms, frags = [], [], [], []
-    for _ in range(frames):
-        t.timer.tick()
-        step_ms.append(timed(t.step))
-        t.renderView = False
-        flow_ms.append(timed(t.draw))
-        frags.append(t.fragments)
-        t.renderView = True
-        u, n = t.render_uniforms(), C.c_uint64(0)
-        view_ms.append(timed(lambda: _capi.call("th_view_draw", ctx, C.byref(u), C.byref(n))))
-    both_ms = []                          # Tendrils.draw() as it runs with renderView: both passes in one call (th_draw)
-    for _ in range(5):
-        t.timer.tick(); t.step()
-        both_ms.append(timed(t.draw))
-    frame_ms = []                         # ... and the frame as one piece: step() + draw() inside one event pair
-    for _ in range(10):
-        t.timer.tick()
-        frame_ms.append(timed(lambda: (t.step(), t.draw())))
-    # ... and the same loop once the wake has crowded the target (the reference's loop runs for minutes: after ~60 frames
-    # at this size most fragments fall into texels with hundreds and thousands of them, and a draw waits for the
-    # longest run of one texel): `settle` more frames untimed, then 50 timed
-    def wall(n):
-        """n frames of the loop as a host runs it - no event, no sync but the draw's own read-back - against the wall clock"""
-        _capi.call("th_sync", ctx)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            t.timer.tick(); t.step(); t.draw()
-        _capi.call("th_sync", ctx)
-        return (time.perf_counter() - t0) / n * 1e3
-    wall_ms = wall(20)
-    settle = 230
-    for _ in range(settle):
-        t.timer.tick(); t.step(); t.draw()
-    c_step, c_both, c_frags = [], [], []
-    for _ in range(50):
-        t.timer.tick()
-        c_step.append(timed(t.step))
-        c_both.append(timed(t.draw))
-        c_frags.append(t.fragments)
-    crowded = {"after_frames": 5 + frames + 5 + 20 + settle, "frames": 50, "step_ms": float(np.median(c_step)), "draw_both_ms": float(np.median(c_both)),
-               "wall_ms_per_frame": wall(50),
-               "slowest_frame": {"step_ms": float(np.max(c_step)), "draw_both_ms": float(np.max(c_both))},
-               "fragments_per_draw": float(np.mean(c_frags)),
-               "frame_ms_reference_loop": float(np.median(c_step)) + float(np.median(c_both))}
-    t.renderView = keep
-    lines, f = state.shape[0] * state.shape[1], float(np.mean(frags))
-    texels = FLOW_W * FLOW_H
-    # the binned pipeline (th_bins.hip; what `auto` runs over tile-sorted slots).  Per slot: the particle id (4 B); per line that
-    # can draw (half of the rows: state-at-frame.glsl reads `current` twice in the others): two state texels (32 B); per
-    # fragment: key + varying written (24 B) and read once where its bin is put in order (24 B); the target read and written (32 B
-    # per texel).  Round 2's pipeline (three radix passes + a gather between emit and blend) moved 88 B per line + 124 B per
-    # fragment: its model is kept beside for the comparison across rounds.
-    alg = lines * 4.0 + lines * 0.5 * 32.0 + f * 48.0 + texels * 32.0
-    alg_r2 = lines * 88.0 + f * 124.0
-    # medians over the frames (a frame in which a store grows - a hipMalloc inside the pass - would otherwise own the mean);
-    # the slowest frame is reported beside
-    d, s_ms, b_ms = float(np.median(flow_ms)), float(np.median(step_ms)), float(np.median(both_ms))
-    return {"frames": frames, "step_ms": s_ms, "draw_flow_ms": d, "draw_view_ms": float(np.median(view_ms)), "draw_both_ms": b_ms,
-            "slowest_frame": {"step_ms": float(np.max(step_ms)), "draw_flow_ms": float(np.max(flow_ms)), "draw_view_ms": float(np.max(view_ms)),
-                              "draw_both_ms": float(np.max(both_ms))},
-            "fragments_per_draw": f, "frames_per_s": 1e3 / (s_ms + d),
-            "frame_ms_reference_loop": s_ms + b_ms,
-            "frame_ms": float(np.median(frame_ms)),
-            "wall_ms_per_frame": wall_ms,
-            "crowded": crowded,
-            "pipeline": "binned (th_bins.hip): particles stay in the integrator's tile-sorted slot order; one fused rasterise + emit pass into "
-                        "16x16-texel bins of the target, per-bin ordering by (texel, stream index) and blending in LDS",
-            "roofline": {"bound": "hbm", "kernel": "flow pass of draw(): bins_fused_kernel + per-bin blend kernels", "achieved": alg / d / 1e6,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / d / 1e6 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_draw": alg,
-                         "achieved_is": "4 B per slot + 32 B per drawable line + 48 B per fragment + 32 B per target texel / median duration of the pass "
-                                        "(the pass is bound by the rasteriser's integer arithmetic and by latency, not by bytes: DESIGN.md 3.4)",
-                         "r2_model": {"algorithmic_bytes_per_draw": alg_r2, "achieved": alg_r2 / d / 1e6, "frac": alg_r2 / d / 1e6 / HBM_PEAK_GBS,
-                                      "note": "round 2's byte model (88 B per line + 124 B per fragment: what the stream-ordered pipeline moves) over "
-                                              "this round's duration - comparable with round 2's frame_loop.roofline.frac"}},
-            "note": "timer.tick(); step(); draw(): one single-step launch over tile-sorted slots + the flow pass; the view pass timed separately "
-                    "(th_view_draw after th_flow_deposit: a full pass of its own in the binned pipeline), and both passes in one call "
-                    "(th_draw, what Tendrils.draw() runs with renderView: one rasterisation, two varyings per fragment) over 5 more frames; "
-                    "wall_ms_per_frame: the loop as a host runs it (no events, no sync but the draw's own read-back) against the wall clock, 20 frames"}
-
-
-def cpu_baseline(t, width, rows_avail):
-    """The oracle (CPU restatement, bit-equal to the reference shader) timed on this host's cores
-    on a bounded sample of the same workload: whole steps of a row band until ~12 s have been spent."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    st = synth_rows(width, rows_avail, 12345)
-    fl = t.flow.read()
-    gh = t.particles._global_height or t.particles.shape[1]
-    u = O.logic_uniforms(width, gh, 1000.0 + 1000 / 60, 1000 / 60, view_size=t.viewSize,
-                         **{k: v for k, v in t.state.items() if isinstance(v, (int, float))})
-    # threads: the host may expose more CPUs than this process can run on (cgroup quota, SMT) - probe a few
-    # OpenMP team sizes on a quarter sample and time the baseline with the best one
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    gomp = C.CDLL("libgomp.so.1")
-    O.logic_step(u, st[:64], fl)                 # warm (library load)
-    scratch = np.zeros_like(st)                  # output buffer, touched once here
-    best, cores = 0.0, ncpu
-    q = rows_avail // 4
-    for cand in sorted({ncpu, max(ncpu // 2, 1), max(ncpu // 4, 1), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}):
-        gomp.omp_set_num_threads(int(cand))
-        probe = st[:q]
-        O.logic_step(u, probe[:cand * 2], fl)    # spin the team up
-        p0 = time.perf_counter()
-        O.logic_step(u, probe, fl, out=scratch[:q])
-        rate = probe.shape[0] * width / (time.perf_counter() - p0)
-        if rate > best:
-            best, cores = rate, int(cand)
-    gomp.omp_set_num_threads(cores)
-    rows = rows_avail if best >= 20e6 else q     # keep the leg within ~10-30 s on small hosts
-    sample = st[:rows]
-    done, t0 = 0, time.perf_counter()
-    while True:
-        O.logic_step(u, sample, fl, out=scratch[:rows])
-        done += 1
-        el = time.perf_counter() - t0
-        if el > 12.0 or done >= 8:
-            break
-    return {"value": rows * width * done / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d step(s) of rows [0,%d) x %d of the same state/flow (oracle/tendrils_oracle.c, "
-                      "OpenMP over rows with the best of the probed team sizes, strict fp32; %d CPUs visible)" % (done, rows, width, ncpu),
-            # the reference itself (JS + GLSL) cannot run on the GPU box: /root/reference does not travel and the box has
-            # no GL.  Its own CPU figure, measured in the build container (BASELINE.md 2), carried here for the record:
-            "reference_on_cpu": {"value": 5.86e6, "unit": "particle-steps/s", "cores": 8, "kind": "reference",
-                                 "sample": "1 step() of 4096^2 particles, the reference's own bundle (docs/js/index.js) on "
-                                           "SwiftShader software WebGL in kaleido's headless Chromium, 8-core Xeon 2.1 GHz, "
-                                           "measured in the build container, not on this host (BASELINE.md section 2)"}}
-
-
 if __name__ == "__main__":
     main()
+

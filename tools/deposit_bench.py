@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (synthetic C3 inputs)
+from benchlib import workload as bench  # noqa: E402  (the synthetic C3 inputs)
 import tendrils_amd as ta  # noqa: E402
 from tendrils_amd import _capi  # noqa: E402
 from tendrils_amd.tendrils import View  # noqa: E402

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+from benchlib import workload as bench  # noqa: E402  (the synthetic C3 inputs)
 import tendrils_amd as ta  # noqa: E402
 from tendrils_amd.sharding import flow_view, shard_rows  # noqa: E402
 from tendrils_amd.tendrils import View  # noqa: E402
