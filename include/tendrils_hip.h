@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 12
+#define TH_ABI_VERSION 13
 
 typedef int32_t th_status;
 enum {
@@ -416,7 +416,7 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
 
 /* Per-context switches between equivalent paths (build-defined; no switch changes a result - the parity suites rerun under
  * each, tests/conftest.py).  A context starts from the environment variables of the same names, read by th_create
- * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL;
+ * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL, TH_BINS_PAGES;
  * TH_DRAW=stream|bins sets what TH_DRAW_AUTO means).
  *   TH_OPT_BUCKET          tile-sorted slot order never (0) / always (1) / when it pays (-1, default)
  *   TH_OPT_RESORT_STEPS    re-sort period of single-step launches (default 64)
@@ -426,12 +426,16 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
  *   TH_OPT_FORCE_GENERIC   every step through the reference-order kernel (default 0)
  *   TH_OPT_DRAW_REUSE      the stream-ordered view pass reuses the flow pass's rasterisation and sort (default 1)
  *   TH_OPT_BINS_POOL       first size, in pages, of the binned pipeline's page pool (default 0: by the target's size)
+ *   TH_OPT_BINS_PAGES      pages one list of a bin of the binned pipeline can grow to at first (default 0: 128 - half a million
+ *                          fragments per 16 x 16-texel bin; a bin that outgrows its lists gets a table four times as wide and the
+ *                          pass is repeated, up to 4096); negative: that many and never more (the draw then goes to the
+ *                          stream-ordered pipeline - tests)
  *   TH_OPT_INJECT_FAILURE  (tests) the next th_draw_sharded of THIS context fails on its own at stage 1 (its edge rows; packed rings), 2
  *                          (rasterising its lines) or 3 (making room for what it owns); 4: its binned pass gives up (every rank takes the stream-ordered pass, the draw succeeds);
  *                          the switch resets itself.  What is
  *                          tested: every other rank of the job returns an error too instead of waiting in a collective */
 enum { TH_OPT_BUCKET = 0, TH_OPT_RESORT_STEPS = 1, TH_OPT_REBUCKET_STEPS = 2, TH_OPT_FUSE = 3, TH_OPT_GRAPH = 4,
-       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_INJECT_FAILURE = 8 };
+       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_INJECT_FAILURE = 8, TH_OPT_BINS_PAGES = 9 };
 th_status th_option_set(th_context *ctx, int32_t option, int64_t value);
 th_status th_option_get(th_context *ctx, int32_t option, int64_t *value);
 

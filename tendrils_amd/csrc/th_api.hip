@@ -44,6 +44,7 @@ void options_from_environment(th_options &o)
     o.draw = !d ? -1 : (!strcmp(d, "bins") ? 1 : (!strcmp(d, "stream") ? 0 : -1));
     o.draw_reuse = number("TH_DRAW_REUSE", 1) != 0;
     o.bins_pool = (uint32_t)number("TH_BINS_POOL", 0);
+    o.bins_pages = (int)number("TH_BINS_PAGES", 0); if (o.bins_pages > (int)th::kBinPagesLimit || o.bins_pages < -(int)th::kBinPagesLimit) o.bins_pages = 0;
 }
 
 }  // namespace
@@ -257,7 +258,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
     (void)hipFree(c->bin_mem); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
-    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); (void)hipFree(c->gathered);
+    (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); (void)hipFree(c->crowd_parted); (void)hipFree(c->crowd_windows); (void)hipFree(c->gathered);
     if (c->forked) (void)hipEventDestroy(c->forked);
     if (c->joined) (void)hipEventDestroy(c->joined);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -616,6 +617,14 @@ th_status th_option_set(th_context *c, int32_t option, int64_t value)
     case TH_OPT_DRAW_REUSE: o.draw_reuse = value != 0; break;
     case TH_OPT_BINS_POOL: TH_REQUIRE(value >= 0 && value < (1ll << 32), "TH_OPT_BINS_POOL out of range"); o.bins_pool = (uint32_t)value; break;
     case TH_OPT_INJECT_FAILURE: TH_REQUIRE(value >= 0 && value <= 4, "TH_OPT_INJECT_FAILURE takes 0..4"); o.inject_failure = (int)value; break;
+    case TH_OPT_BINS_PAGES:
+        TH_REQUIRE(value >= -(int64_t)th::kBinPagesLimit && value <= (int64_t)th::kBinPagesLimit && value != 1 && value != -1, "TH_OPT_BINS_PAGES takes 0, or 2..%u (negative: never widened)", th::kBinPagesLimit);
+        o.bins_pages = (int)value;
+        if (c->chunk_table) {           // (takes effect at once: the table is laid out again by the next binned pass)
+            TH_HIP(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->chunk_table); c->chunk_table = nullptr; (void)hipFree(c->bin_mem); c->bin_mem = nullptr; c->bin_capacity = 0; c->bin_max_pages = 0;
+        }
+        break;
     default: return fail(TH_ERR_INVALID, "unknown option %d", option);
     }
     clear_graphs(c);                 // (captured sequences were planned under the old switches)
@@ -636,6 +645,7 @@ th_status th_option_get(th_context *c, int32_t option, int64_t *value)
     case TH_OPT_DRAW_REUSE: *value = o.draw_reuse; break;
     case TH_OPT_BINS_POOL: *value = o.bins_pool; break;
     case TH_OPT_INJECT_FAILURE: *value = o.inject_failure; break;
+    case TH_OPT_BINS_PAGES: *value = o.bins_pages; break;
     default: return fail(TH_ERR_INVALID, "unknown option %d", option);
     }
     return TH_OK;

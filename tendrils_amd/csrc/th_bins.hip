@@ -59,8 +59,8 @@ template <bool WAIT>
 TH_D uint32_t page_of(const DepositParams &p, uint32_t list, uint32_t pn)
 {
     if (pn == 0u) return list;
-    if (pn >= kBinMaxPages) return kNoPlace;
-    uint32_t *slot = &p.page_table[(size_t)list * kBinMaxPages + pn];
+    if (pn >= p.max_pages) return kNoPlace;
+    uint32_t *slot = &p.page_table[(size_t)list * p.max_pages + pn];
     if constexpr (!WAIT) return *slot;
     uint32_t id = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (id == 0u) {
@@ -82,18 +82,18 @@ TH_D void pages_open(const DepositParams &p, uint32_t list, uint32_t base, uint3
     if (pn == 0u) pn = 1u;
     const uint32_t last = (base + n - 1u) >> kPageShift;
     for (; pn <= last; ++pn) {
-        if (pn >= kBinMaxPages) { bins_flag(p, kBinsBinFull); break; }
+        if (pn >= p.max_pages) { bins_flag(p, kBinsBinFull); break; }
         const uint32_t k = atomicAdd(&p.totals[kTotPool], 1u);
         uint32_t id = p.nbins * kBinReplicas + k;
         if (k >= p.pool_pages) { id = kNoPlace; bins_flag(p, kBinsPoolExhausted); }
-        __hip_atomic_store(&p.page_table[(size_t)list * kBinMaxPages + pn], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.page_table[(size_t)list * p.max_pages + pn], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // a reader is done with list `list` of `n` places: its table entries are left empty for the next pass
 TH_D void pages_forget(const DepositParams &p, uint32_t list, uint32_t n, uint32_t tid, uint32_t threads)
 {
     const uint32_t pages = (n + kBinPage - 1u) >> kPageShift;
-    for (uint32_t pn = 1u + tid; pn < pages && pn < kBinMaxPages; pn += threads) p.page_table[(size_t)list * kBinMaxPages + pn] = 0u;
+    for (uint32_t pn = 1u + tid; pn < pages && pn < p.max_pages; pn += threads) p.page_table[(size_t)list * p.max_pages + pn] = 0u;
 }
 TH_D uint32_t *list_cursor(const DepositParams &p, uint32_t bin, uint32_t r) { return p.bin_cursor + (size_t)r * p.bin_stride + bin; }
 
@@ -571,6 +571,29 @@ TH_D void quad_walk(const DepositParams &p, uint32_t texel, uint32_t len, uint32
     if constexpr (MODE != 0) reinterpret_cast<unsigned char *>(p.view + texel)[c] = (unsigned char)v;
 }
 
+// The chain of one staged batch: n sources - {x, y, z, w, 1 - alpha} side by side from `from` on - applied to this lane's
+// channel `ch` of the destination, one after the other (read eight ahead of the dependent blends).  The loop holds ONE target's
+// arithmetic: with the flow texel's lanes and the view texel's lanes choosing theirs fragment by fragment, a wave spent more
+// on its execution mask than on the blends (profiles/r4_g_giants.txt).
+template <bool VIEW>
+TH_D void apply_batch(float &comp, const BlendSource *from, uint32_t ch, uint32_t n)
+{
+    const float *mine = reinterpret_cast<const float *>(from) + ch, *das = reinterpret_cast<const float *>(from) + 4u;
+    auto apply = [&](float src, float da) {
+        if constexpr (VIEW) ViewTarget::apply_channel(comp, src, da);
+        else FlowTarget::apply_channel(comp, src, da);
+    };
+    uint32_t q = 0;
+    for (; q + 8u <= n; q += 8u) {
+        float sv[8], da[8];
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) { sv[e] = mine[(q + e) * 5u]; da[e] = das[(q + e) * 5u]; }
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; ++e) apply(sv[e], da[e]);
+    }
+    for (; q < n; ++q) apply(mine[q * 5u], das[q * 5u]);
+}
+
 // a long run by the whole workgroup: every thread turns one fragment's varying into its side of the blend (256 loads in
 // flight); then the destination's CHANNELS are applied side by side, a lane each - lanes 0-3 of the workgroup the flow
 // texel's four floats, lanes 4-7 the view texel's four bytes (as integer-valued floats) - instead of one thread doing all
@@ -601,25 +624,9 @@ TH_D void bin_blend_long(BinShared<MODE> &s, const DepositParams &p, uint32_t be
         if (channel) {
             if (j0 == 0u) comp = s.chan[t];
             // this lane's component of every source, and the source's 1 - alpha: {x, y, z, w, da} lie side by side
-            const float *mine = reinterpret_cast<const float *>((MODE == 2 && !flow_lane) ? s.stage_b : s.stage_a) + (t & 3u);
-            const float *das = reinterpret_cast<const float *>((MODE == 2 && !flow_lane) ? s.stage_b : s.stage_a) + 4u;
             const uint32_t n = len - j0 < 256u ? len - j0 : 256u;
-            auto apply = [&](float src, float da) {
-                if (MODE != 1 && flow_lane) comp = src + comp * da;                                   // FlowTarget::apply, one channel
-                else {                                                                                // ViewTarget::apply_unpacked, one channel
-                    const float o = src + (comp * (1.0f / 255.0f)) * da;
-                    comp = __builtin_floorf(__builtin_fminf(__builtin_fmaxf(o, 0.0f), 1.0f) * 255.0f + 0.5f);
-                }
-            };
-            uint32_t q = 0;
-            for (; q + 8u <= n; q += 8u) {      // (sources read eight ahead of the dependent blends)
-                float sv[8], da[8];
-#pragma unroll
-                for (uint32_t e = 0; e < 8u; ++e) { sv[e] = mine[(q + e) * 5u]; da[e] = das[(q + e) * 5u]; }
-#pragma unroll
-                for (uint32_t e = 0; e < 8u; ++e) apply(sv[e], da[e]);
-            }
-            for (; q < n; ++q) apply(mine[q * 5u], das[q * 5u]);
+            if (MODE != 1 && flow_lane) apply_batch<false>(comp, s.stage_a, t & 3u, n);
+            else apply_batch<true>(comp, MODE == 2 ? s.stage_b : s.stage_a, t & 3u, n);
             if (j0 + 256u >= len) s.chan[t] = comp;
         }
         __syncthreads();
@@ -1046,6 +1053,7 @@ __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p,
     __shared__ BinShared<MODE> s;
     const uint32_t t = threadIdx.x, nlong = *count;
     for (uint32_t e = blockIdx.x; e < nlong; e += gridDim.x) {
+        if (p.crowd_giant_win[2u * e] != 0xffffffffu) continue;    // (parted, ordered window by window and walked: giant_*_kernel)
         const uint32_t entry = list[e], i = entry >> 8, lt = entry & 255u;
         const uint32_t b = p.large_bins[i];
         const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
@@ -1070,6 +1078,60 @@ __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p,
     }
 }
 
+TH_D void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+// One texel's run of `len` fragments walked by ONE wave: place_at(j) = where the varying(s) of the j-th fragment in blend order
+// lie (asked for j < len, by lane j & 63 of a batch).  64 sources staged at a time in the wave's own LDS words (the next
+// batches' varyings in flight meanwhile, the places of the batch after those too) and the destination's channels applied by
+// lanes 0-7: lanes 0-3 the flow texel's floats, 4-7 the view texel's bytes - the same operations on every channel in the same
+// order as one thread doing all eight.  PART (a store of MODE 2 - two varyings per fragment): -1 both targets by this wave,
+// 0 / 1 the flow / the view target alone - two waves then walk the run side by side, each its own chain.
+template <int MODE, int PART = -1, typename PlaceAt>
+TH_D void wave_walk(const DepositParams &p, uint32_t texel, uint32_t len, BlendSource (*stage_a)[64], BlendSource (*stage_b)[(MODE == 2 && PART < 0) ? 64 : 1], PlaceAt place_at)
+{
+    static_assert(PART < 0 || MODE == 2, "parts are halves of a store with two varyings per fragment");
+    constexpr bool kFlow = PART == 0 || (PART < 0 && MODE != 1), kView = PART == 1 || (PART < 0 && MODE != 0), kBoth = kFlow && kView;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool flow_lane = kFlow && lane < 4u, view_lane = kView && lane >= 4u && lane < 8u;
+    float comp = 0.0f;
+    if (flow_lane) comp = reinterpret_cast<const float *>(p.flow + texel)[lane & 3u];
+    if (view_lane) comp = (float)reinterpret_cast<const unsigned char *>(p.view + texel)[lane & 3u];
+    // kAhead batches of varyings in flight (and the places of the batch after those): a batch is applied in about a
+    // microsecond, a scattered read out of a store of a gigabyte can take longer than that
+    constexpr uint32_t kAhead = 3;
+    auto place_of_batch = [&](uint32_t j0) { const uint32_t j = j0 + lane; return place_at(j < len ? j : len - 1u); };
+    auto fetch = [&](uint32_t place, float4 &c0, float4 &c1) {
+        if constexpr (PART < 0) fetch_colors<MODE>(p, (size_t)place, c0, c1);
+        else { c0 = p.colors[2u * (size_t)place + (uint32_t)PART]; c1 = c0; }
+    };
+    float4 c0[kAhead], c1[kAhead];
+#pragma unroll
+    for (uint32_t k = 0; k < kAhead; ++k) if (k * 64u < len) fetch(place_of_batch(k * 64u), c0[k], c1[k]);
+    uint32_t at_ahead = place_of_batch(kAhead * 64u < len ? kAhead * 64u : 0u);
+    uint32_t buf = 0;
+    for (uint32_t j00 = 0; j00 < len; j00 += kAhead * 64u) {
+#pragma unroll
+        for (uint32_t k = 0; k < kAhead; ++k) {
+            const uint32_t j0 = j00 + k * 64u;
+            if (j0 >= len) break;
+            if constexpr (kFlow) stage_a[buf][lane] = FlowTarget::source(c0[k]);
+            else stage_a[buf][lane] = ViewTarget::source(c0[k]);
+            if constexpr (kBoth) stage_b[buf][lane] = ViewTarget::source(c1[k]);
+            if (j0 + kAhead * 64u < len) {                                // this slot's next batch
+                fetch(at_ahead, c0[k], c1[k]);
+                if (j0 + (kAhead + 1u) * 64u < len) at_ahead = place_of_batch(j0 + (kAhead + 1u) * 64u);
+            }
+            wave_sync();
+            const uint32_t n = len - j0 < 64u ? len - j0 : 64u;
+            if (flow_lane) apply_batch<false>(comp, stage_a[buf], lane & 3u, n);
+            if (view_lane) apply_batch<true>(comp, kBoth ? stage_b[kBoth ? buf : 0u] : stage_a[buf], lane & 3u, n);
+            buf ^= 1u;
+        }
+    }
+    if (flow_lane) reinterpret_cast<float *>(p.flow + texel)[lane & 3u] = comp;
+    if (view_lane) reinterpret_cast<unsigned char *>(p.view + texel)[lane & 3u] = (unsigned char)comp;
+}
+
 // The long list (kWaveRun < fragments <= kGiantRun) by ONE WAVE per run, four runs per workgroup side by side: the run's keys
 // ordered by a bitonic network in the wave's own LDS words - no workgroup barrier between its steps: a workgroup per run spent
 // most of its time in the 55 barriers of a thousand-key sort -, then 64 sources staged at a time (the next 64 varyings in
@@ -1081,7 +1143,6 @@ __global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositPar
     __shared__ BlendSource stage_a[4][2][64], stage_b[4][MODE == 2 ? 2 : 1][MODE == 2 ? 64 : 1];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nlong = *count;
     unsigned long long *skey = skeys[wave];
-    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     for (uint32_t e = blockIdx.x * 4u + wave; e < nlong; e += gridDim.x * 4u) {
         const uint32_t entry = list[e], i = entry >> 8, lt = entry & 255u;
         const uint32_t b = p.large_bins[i];
@@ -1105,51 +1166,178 @@ __global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositPar
                 }
                 wave_sync();
             }
-        // the destination, a channel per lane: lanes 0-3 the flow texel's floats, 4-7 the view texel's bytes
-        const bool flow_lane = lane < 4u;
-        const bool channel = lane < 8u && (MODE == 2 || (MODE == 0) == flow_lane);
-        float comp = 0.0f;
-        if (channel) {
-            if (MODE != 1 && flow_lane) comp = reinterpret_cast<const float *>(p.flow + texel)[lane & 3u];
-            else comp = (float)reinterpret_cast<const unsigned char *>(p.view + texel)[lane & 3u];
-        }
-        auto fetch = [&](uint32_t j0, float4 &c0, float4 &c1) {
-            const uint32_t j = j0 + lane;
-            fetch_colors<MODE>(p, (size_t)(uint32_t)(skey[j < len ? j : len - 1u] & 0xffffffffull), c0, c1);
+        wave_walk<MODE>(p, texel, len, stage_a[wave], stage_b[wave], [&](uint32_t j) { return (uint32_t)(skey[j] & 0xffffffffull); });
+        wave_sync();                                              // (the words are free for the wave's next run)
+    }
+}
+
+// ---- the giants (runs of more than kGiantRun fragments) --------------------------------------------------------------------
+// Once the wake of a long-running loop has drawn the particles together, single texels receive thousands and tens of
+// thousands of fragments per draw, and a thousand such texels at once.  Their runs are put in order in three steps, none of
+// which reads a key more than a fixed number of times:
+//   giant_part_kernel   a workgroup per run: its keys parted ONCE by the leading bits of their stream indices (1024 buckets:
+//                       histogram, scan, scatter into p.crowd_parted) and the buckets grouped into WINDOWS of up to
+//                       kGiantWindow keys - stream indices are distinct inside a texel and spread evenly, a bucket of a run
+//                       of 20 000 holds ~20.  (A run with a bucket larger than a window - particles with neighbouring ids
+//                       in one texel: a spawn - is left to crowd_blend_kernel, which narrows its windows as it goes.)
+//   giant_sort_kernel   a workgroup per WINDOW, all windows of all runs side by side: ordered in LDS, the places of the
+//                       varyings written in blend order (p.crowd_sorted)
+//   giant_walk_kernel   a wave per run: wave_walk over those places - what is left on the draw's critical path is the chain
+//                       of the longest run, one fragment after the other, and nothing else.
+// (crowd_blend_kernel did all of this inside one workgroup per run, window after window - and read the whole run twice per
+// window: a run of 17 000 fragments took 1.5 ms, profiles/r4_g_giants.txt.)
+constexpr uint32_t kGiantWindow = 2048;
+constexpr uint32_t kGiantFallback = 0xffffffffu;
+TH_D uint32_t giant_id_shift(const DepositParams &p)
+{
+    uint32_t id_bits = 1;                           // bits of a stream index: ceil(log2(W * H))
+    while (id_bits < 32u && (1ull << id_bits) < (unsigned long long)p.W * p.H) ++id_bits;
+    return id_bits > 10u ? id_bits - 10u : 0u;
+}
+struct GiantRun { uint32_t i, texel, r0, len; };
+TH_D GiantRun giant_run(const DepositParams &p, uint32_t entry)
+{
+    GiantRun g;
+    g.i = entry >> 8;
+    const uint32_t lt = entry & 255u, b = p.large_bins[g.i];
+    g.r0 = p.crowd_start[(size_t)g.i * (kBinTexels + 1u) + lt];
+    g.len = p.crowd_start[(size_t)g.i * (kBinTexels + 1u) + lt + 1u] - g.r0;
+    const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
+    const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
+    g.texel = y * (uint32_t)p.fw + x;               // (a texel with fragments lies inside the target)
+    return g;
+}
+
+__global__ __launch_bounds__(256) void giant_part_kernel(const DepositParams p)
+{
+    __shared__ uint32_t hist[1024], start[1025], wave_total[4], win[2];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, ngiant = p.totals[kTotGiant], shift = giant_id_shift(p);
+    constexpr uint32_t kPer = 8;
+    for (uint32_t e = blockIdx.x; e < ngiant; e += gridDim.x) {
+        const GiantRun g = giant_run(p, p.crowd_giant[e]);
+        const unsigned long long *run = p.crowd_keys + p.large_key0[g.i] + g.r0;
+        unsigned long long *out = p.crowd_parted + p.large_key0[g.i] + g.r0;
+        for (uint32_t k = t; k < 1024u; k += 256u) hist[k] = 0u;
+        __syncthreads();
+        auto bucket = [&](unsigned long long k) { const uint32_t b = (uint32_t)(k >> 32) >> shift; return b < 1023u ? b : 1023u; };
+        auto for_run = [&](auto body) {              // (a thread's loads of one round go out together)
+            for (uint32_t f0 = 0; f0 < g.len; f0 += kPer * 256u) {
+                unsigned long long k[kPer];
+#pragma unroll
+                for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = f0 + q * 256u + t; k[q] = run[f < g.len ? f : g.len - 1u]; }
+#pragma unroll
+                for (uint32_t q = 0; q < kPer; ++q) if (f0 + q * 256u + t < g.len) body(k[q]);
+            }
         };
-        float4 c0, c1;
-        fetch(0u, c0, c1);
-        uint32_t buf = 0;
-        for (uint32_t j0 = 0; j0 < len; j0 += 64u, buf ^= 1u) {
-            if constexpr (MODE == 1) stage_a[wave][buf][lane] = ViewTarget::source(c0);
-            else stage_a[wave][buf][lane] = FlowTarget::source(c0);
-            if constexpr (MODE == 2) stage_b[wave][buf][lane] = ViewTarget::source(c1);
-            if (j0 + 64u < len) fetch(j0 + 64u, c0, c1);              // in flight while this batch is applied
-            wave_sync();
-            if (channel) {
-                const BlendSource *from = (MODE == 2 && !flow_lane) ? stage_b[wave][MODE == 2 ? buf : 0u] : stage_a[wave][buf];
-                const float *mine = reinterpret_cast<const float *>(from) + (lane & 3u), *das = reinterpret_cast<const float *>(from) + 4u;
-                const uint32_t n = len - j0 < 64u ? len - j0 : 64u;
-                auto apply = [&](float src, float da) {
-                    if (MODE != 1 && flow_lane) FlowTarget::apply_channel(comp, src, da);
-                    else ViewTarget::apply_channel(comp, src, da);
-                };
-                uint32_t q = 0;
-                for (; q + 8u <= n; q += 8u) {
-                    float sv[8], da[8];
+        for_run([&](unsigned long long k) { atomicAdd(&hist[bucket(k)], 1u); });
+        __syncthreads();
+        // exclusive scan of the buckets (every thread its four), the largest bucket
+        const uint32_t h0 = hist[4u * t], h1 = hist[4u * t + 1u], h2 = hist[4u * t + 2u], h3 = hist[4u * t + 3u], mine = h0 + h1 + h2 + h3;
+        uint32_t incl = mine, most = h0 > h1 ? h0 : h1;
+        most = most > h2 ? most : h2; most = most > h3 ? most : h3;
 #pragma unroll
-                    for (uint32_t k = 0; k < 8u; ++k) { sv[k] = mine[(q + k) * 5u]; da[k] = das[(q + k) * 5u]; }
-#pragma unroll
-                    for (uint32_t k = 0; k < 8u; ++k) apply(sv[k], da[k]);
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += up;
+            const uint32_t other = __shfl_xor(most, o);
+            most = other > most ? other : most;
+        }
+        if (lane == 63u) wave_total[wave] = incl;
+        if (t == 0u) win[0] = 0u;
+        __syncthreads();
+        if (lane == 0u && most > kGiantWindow) win[0] = 1u;
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += wave_total[w];
+        const uint32_t s0 = before + incl - mine;
+        start[4u * t] = s0; start[4u * t + 1u] = s0 + h0; start[4u * t + 2u] = s0 + h0 + h1; start[4u * t + 3u] = s0 + h0 + h1 + h2;
+        if (t == 255u) start[1024] = s0 + mine;
+        hist[4u * t] = s0; hist[4u * t + 1u] = s0 + h0; hist[4u * t + 2u] = s0 + h0 + h1; hist[4u * t + 3u] = s0 + h0 + h1 + h2;      // (fill cursors)
+        __syncthreads();
+        if (win[0]) {                                // a bucket no window holds: crowd_blend_kernel takes the run
+            if (t == 0u) { p.crowd_giant_win[2u * e] = kGiantFallback; p.crowd_giant_win[2u * e + 1u] = 0u; }
+            __syncthreads();
+            continue;
+        }
+        for_run([&](unsigned long long k) { out[atomicAdd(&hist[bucket(k)], 1u)] = k; });
+        // the windows: as many leading buckets as kGiantWindow keys allow, again and again (one wave; every window's end is
+        // found by bisection over the buckets' starts)
+        if (wave == 0u) {
+            // (all lanes alike; counted first - the list wants a run's windows side by side - then written.  A run whose
+            // windows the list has no room for - its size bounds them: more than kGiantWindow keys in any two neighbours - goes
+            // the other way too)
+            uint32_t n = 0, first = 0;
+            bool fits = true;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) {
+                    if (lane == 0u) first = atomicAdd(&p.totals[kTotWindows], n);
+                    first = (uint32_t)__shfl((int)first, 0);
+                    fits = (unsigned long long)first + n <= p.crowd_windows_cap;
+                    if (lane == 0u) { p.crowd_giant_win[2u * e] = fits ? first : kGiantFallback; p.crowd_giant_win[2u * e + 1u] = n; }
                 }
-                for (; q < n; ++q) apply(mine[q * 5u], das[q * 5u]);
+                uint32_t b0 = 0;
+                n = 0;
+                while (b0 < 1024u && start[b0] < g.len) {
+                    uint32_t lo = b0 + 1u, hi = 1024u;             // the largest b1 in (b0, 1024] with start[b1] - start[b0] <= kGiantWindow
+                    while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (start[mid] - start[b0] <= kGiantWindow) lo = mid; else hi = mid - 1u; }
+                    if (pass == 1 && lane == 0u && (unsigned long long)first + n < p.crowd_windows_cap) {
+                        uint32_t *w = p.crowd_windows + 3u * (size_t)(first + n);
+                        w[0] = e; w[1] = start[b0]; w[2] = fits ? start[lo] - start[b0] : 0u;
+                    }
+                    ++n;
+                    b0 = lo;
+                }
             }
         }
-        if (channel) {
-            if (MODE != 1 && flow_lane) reinterpret_cast<float *>(p.flow + texel)[lane & 3u] = comp;
-            else reinterpret_cast<unsigned char *>(p.view + texel)[lane & 3u] = (unsigned char)comp;
-        }
-        wave_sync();                                              // (the words are free for the wave's next run)
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void giant_sort_kernel(const DepositParams p)
+{
+    __shared__ unsigned long long skey[kGiantWindow];
+    const uint32_t t = threadIdx.x, total = p.totals[kTotWindows], nwin = total < p.crowd_windows_cap ? total : p.crowd_windows_cap;
+    for (uint32_t w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const uint32_t *rec = p.crowd_windows + 3u * (size_t)w;
+        const uint32_t e = rec[0], first = rec[1], m = rec[2];
+        if (m == 0u) continue;                      // (a run the list had no room for)
+        const GiantRun g = giant_run(p, p.crowd_giant[e]);
+        const size_t base = (size_t)p.large_key0[g.i] + g.r0 + first;
+        uint32_t P = 64u;
+        while (P < m) P <<= 1;
+        for (uint32_t f = t; f < P; f += 256u) skey[f] = f < m ? p.crowd_parted[base + f] : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t q = t; q < (P >> 1); q += 256u) {
+                    const uint32_t lo = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), hi = lo | j;
+                    const unsigned long long a = skey[lo], c = skey[hi];
+                    const bool up = (lo & k) == 0u;
+                    if ((a > c) == up) { skey[lo] = c; skey[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (uint32_t f = t; f < m; f += 256u) p.crowd_sorted[base + f] = (uint32_t)(skey[f] & 0xffffffffull);
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void giant_walk_kernel(const DepositParams p)
+{
+    __shared__ BlendSource stage_a[4][2][64], none[1][1];
+    constexpr uint32_t kParts = MODE == 2 ? 2u : 1u;          // (both targets: a wave each - two chains side by side instead of one after the other)
+    const uint32_t wave = threadIdx.x >> 6, ntask = p.totals[kTotGiant] * kParts;
+    for (uint32_t task = blockIdx.x * 4u + wave; task < ntask; task += gridDim.x * 4u) {
+        const uint32_t e = task / kParts;
+        if (p.crowd_giant_win[2u * e] == kGiantFallback) continue;
+        const GiantRun g = giant_run(p, p.crowd_giant[e]);
+        const uint32_t *sorted = p.crowd_sorted + p.large_key0[g.i] + g.r0;
+        auto place_at = [&](uint32_t j) { return sorted[j]; };
+        if constexpr (MODE == 2) {
+            if (task & 1u) wave_walk<2, 1>(p, g.texel, g.len, stage_a[wave], none, place_at);
+            else wave_walk<2, 0>(p, g.texel, g.len, stage_a[wave], none, place_at);
+        } else wave_walk<MODE>(p, g.texel, g.len, stage_a[wave], none, place_at);
+        wave_sync();
     }
 }
 
@@ -1371,10 +1559,10 @@ __global__ __launch_bounds__(256) void owner_totals_kernel(const DepositParams p
     unsigned long long total = 0;
     for (uint32_t s = 0; s < o.world; ++s) total += o.table[(size_t)s * o.nb + b];
     const uint32_t bin = o.bin_lo[o.rank] + b;
-    bool full = total > (unsigned long long)kBinMaxPages * kBinPage * kBinReplicas;
+    bool full = total > (unsigned long long)p.max_pages * kBinPage * kBinReplicas;
     if (!full)
         for (uint32_t r = 0; r < kBinReplicas; ++r)
-            full = full || (unsigned long long)*list_cursor(p, bin, r) + owner_take((uint32_t)total, r) > (unsigned long long)kBinMaxPages * kBinPage;
+            full = full || (unsigned long long)*list_cursor(p, bin, r) + owner_take((uint32_t)total, r) > (unsigned long long)p.max_pages * kBinPage;
     if (full) { bins_flag(p, kBinsBinFull); total = 0; }
     o.bin_total[b] = (uint32_t)total;
 }
@@ -1418,7 +1606,7 @@ __global__ __launch_bounds__(256) void owner_layout_kernel(const DepositParams p
         const uint32_t e = *cursor, n = owner_take(total, r);
         uint32_t first, count;
         owner_new_pages(e, n, first, count);
-        for (uint32_t k = 0; k < count; ++k) p.page_table[(size_t)(bin * kBinReplicas + r) * kBinMaxPages + first + k] = page++;
+        for (uint32_t k = 0; k < count; ++k) p.page_table[(size_t)(bin * kBinReplicas + r) * p.max_pages + first + k] = page++;
         *cursor = e + n;
     }
 }
@@ -1508,11 +1696,21 @@ void launch_bins_regroup(const DepositParams &p, hipStream_t s)
 // the runs a wave does not order (more than kWaveRun fragments), a workgroup each, the giants first: a run of ten thousand
 // fragments is walked by one thread for a few hundred microseconds - the caller puts this on a stream of its own beside
 // launch_bins_blend (disjoint texels), so that the walk overlaps with everything else instead of following it.
+void launch_bins_blend_giants(const DepositParams &p, hipStream_t s)
+{
+    if (!p.nlarge) return;
+    hipLaunchKernelGGL(giant_part_kernel, dim3(2048), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(giant_sort_kernel, dim3(4096), dim3(256), 0, s, p);
+#define TH_GO(M) do { hipLaunchKernelGGL(giant_walk_kernel<M>, dim3(512), dim3(256), 0, s, p); \
+                      hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(256), dim3(256), 0, s, p, (const uint32_t *)p.crowd_giant, (const uint32_t *)(p.totals + kTotGiant)); } while (0)
+    if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
+#undef TH_GO
+}
+// ... and the runs in between, a wave each (disjoint texels again: on whatever stream has room - th_draw.hip)
 void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;
-#define TH_GO(M) do { hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(256), dim3(256), 0, s, p, (const uint32_t *)p.crowd_giant, (const uint32_t *)(p.totals + kTotGiant)); \
-                      hipLaunchKernelGGL(crowd_blend_waves_kernel<M>, dim3(1024), dim3(256), 0, s, p, (const uint32_t *)p.crowd_long, (const uint32_t *)(p.totals + kTotLong)); } while (0)
+#define TH_GO(M) hipLaunchKernelGGL(crowd_blend_waves_kernel<M>, dim3(1024), dim3(256), 0, s, p, (const uint32_t *)p.crowd_long, (const uint32_t *)(p.totals + kTotLong))
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO
 }
@@ -1538,6 +1736,6 @@ void launch_bins_blend(const DepositParams &p, hipStream_t s)
     else if (p.mode == 1) hipLaunchKernelGGL(bins_blend_kernel<1>, dim3(p.nbins), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(bins_blend_kernel<2>, dim3(p.nbins), dim3(256), 0, s, p);
 }
-size_t crowd_words_per_bin() { return 5u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list, the giants' list
+size_t crowd_words_per_bin() { return 7u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list, the giants' list, the giants' windows (2)
 
 }  // namespace th

@@ -52,6 +52,7 @@ struct th_options {
     int draw = -1;                       // TH_DRAW=stream (0) / bins (1): the default of th_draw_pipeline's AUTO
     bool draw_reuse = true;              // TH_DRAW_REUSE: the stream-ordered view pass reuses the flow pass's geometry
     uint32_t bins_pool = 0;              // TH_BINS_POOL: first size of the binned pipeline's page pool (0: by the target's size)
+    int bins_pages = 0;                  // TH_BINS_PAGES: pages a bin's list can grow to at first (0: kBinFirstPages); negative: that many and never more
     int inject_failure = 0;              // (tests) the next th_draw_sharded fails on THIS rank at stage 1 / 2 / 3: the ranks must all leave
 };
 
@@ -119,7 +120,8 @@ struct th_context {
     // binned pipeline (th_bins.hip): the bins' cursors | the large bins | first block of each (+ 1) | first regrouped key of each (+ 1)
     uint32_t *bin_mem = nullptr;
     uint32_t bin_capacity = 0;
-    uint32_t *chunk_table = nullptr;     // per list x kBinMaxPages: the pages a list has grown by
+    uint32_t *chunk_table = nullptr;     // per list x bin_max_pages: the pages a list has grown by
+    uint32_t bin_max_pages = 0;          // (widened when a bin outgrows its lists: bins_table_widen)
     unsigned long long *bins_keys = nullptr;   // the page store: (bins x kBinReplicas + bins_pool) pages of kBinPage places - keys (~0 = empty) ...
     float4 *bins_colors = nullptr;       // ... and varyings (two per place once a th_draw has run)
     uint32_t bins_pool = 0, bins_store_bins = 0;
@@ -128,6 +130,8 @@ struct th_context {
     uint32_t crowd_capacity = 0;
     unsigned long long *crowd_keys = nullptr;  // the large bins' fragments regrouped by texel
     uint32_t *crowd_sorted = nullptr;          // ... their places, run by run in blend order
+    unsigned long long *crowd_parted = nullptr;  // ... the giants' keys parted by stream index, and their windows (th_bins.hip: giant_*_kernel)
+    uint32_t *crowd_windows = nullptr;
     size_t crowd_keys_cap = 0;
     hipStream_t side = nullptr;                // the long runs of a crowded target are blended beside everything else
     hipEvent_t forked = nullptr, joined = nullptr;
@@ -255,6 +259,7 @@ th_status view_params(th_context *c, const th_render_uniforms *u, th::DepositPar
 constexpr th_status kRetryInStreamOrder = -1;        // (internal) the binned pass gave up before it touched a target
 th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least);
 th_status bins_store_grow_keep(th_context *c, th::DepositParams &p, uint32_t pool);
+th_status bins_table_widen(th_context *c, th::DepositParams &p, bool keep);       // kRetryInStreamOrder: as wide as it goes (or no memory)
 th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early);
 th_status bins_pass_totals(th_context *c);
 th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early, bool policy);

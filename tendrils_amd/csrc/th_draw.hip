@@ -119,7 +119,7 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         TH_HIP(hipMalloc((void **)&c->dep_record, 2 * lines * sizeof(uint4)));
         TH_HIP(hipMalloc((void **)&c->dep_lists, th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &c->dep_list_cap) * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->dep_blocks, (size_t)th::deposit_scan_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height) * sizeof(uint32_t)));
-        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 8 * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag, [2] largest bin, [3] large bins, [4] their blocks
+        if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, th::kTotWords * sizeof(uint32_t)));      // [0] total, [1] out-of-band flag, [2] largest bin, [3] large bins, [4] their blocks
         c->dep_lines = lines;
     }
     p = th::DepositParams{};
@@ -146,7 +146,7 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
     }
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
-    TH_HIP(hipMemsetAsync(c->dep_total, 0, 8 * sizeof(uint32_t), c->stream));
+    TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
     if (th_status s = line_rows(c)) return s;
     p.row_draws = c->d_row_draws;
     if (use_bins) {
@@ -160,7 +160,10 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
             (void)hipFree(c->chunk_table); c->chunk_table = nullptr;
             const size_t stride = ((size_t)p.nbins + 255) / 256 * 256 + 64;      // (the lists' cursors of one bin on different memory channels)
             TH_HIP(hipMalloc((void **)&c->bin_mem, (th::kBinReplicas * stride + 2 * (size_t)p.nbins + 2) * sizeof(uint32_t)));
-            const size_t table = (size_t)p.nbins * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t);
+            // (TH_OPT_BINS_PAGES: how far a list can grow at first - tests make it small to run the widening path)
+            const int first = c->opt.bins_pages;
+            c->bin_max_pages = first > 0 ? (uint32_t)first : (first < 0 ? (uint32_t)-first : th::kBinFirstPages);
+            const size_t table = (size_t)p.nbins * th::kBinReplicas * c->bin_max_pages * sizeof(uint32_t);
             TH_HIP(hipMalloc((void **)&c->chunk_table, table));
             TH_HIP(hipMemsetAsync(c->chunk_table, 0, table, c->stream));        // (every reader of a list leaves its entries empty)
             c->bin_capacity = p.nbins;
@@ -168,7 +171,7 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         p.bin_stride = (uint32_t)(((size_t)c->bin_capacity + 255) / 256 * 256 + 64);
         p.bin_cursor = c->bin_mem; p.large_bins = c->bin_mem + (size_t)th::kBinReplicas * p.bin_stride;
         p.large_key0 = p.large_bins + c->bin_capacity;
-        p.page_table = c->chunk_table;
+        p.page_table = c->chunk_table; p.max_pages = c->bin_max_pages;
         p.totals = c->dep_total;
     }
     return TH_OK;
@@ -387,6 +390,24 @@ th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least)
     return TH_OK;
 }
 
+// every list's page table four times as wide (`keep`: with its entries - row-band shards: the owner's own bins are laid out
+// already; otherwise the table is empty, as every pass leaves it)
+th_status bins_table_widen(th_context *c, th::DepositParams &p, bool keep)
+{
+    const uint32_t had = c->bin_max_pages, wide = had * 4u < th::kBinPagesLimit ? had * 4u : th::kBinPagesLimit;
+    if (c->opt.bins_pages < 0 || wide <= had) return kRetryInStreamOrder;
+    const size_t lists = (size_t)c->bin_capacity * th::kBinReplicas;
+    uint32_t *table = nullptr;
+    if (hipMalloc((void **)&table, lists * wide * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return kRetryInStreamOrder; }
+    TH_HIP(hipMemsetAsync(table, 0, lists * wide * sizeof(uint32_t), c->stream));
+    if (keep) TH_HIP(hipMemcpy2DAsync(table, (size_t)wide * sizeof(uint32_t), c->chunk_table, (size_t)had * sizeof(uint32_t), (size_t)had * sizeof(uint32_t), lists, hipMemcpyDeviceToDevice, c->stream));
+    TH_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->chunk_table);
+    c->chunk_table = table; c->bin_max_pages = wide;
+    p.page_table = table; p.max_pages = wide;
+    return TH_OK;
+}
+
 // a larger pool behind the same bins WITH what the store holds (row-band shards: the owner's own bins wait in it for the
 // other ranks' fragments); page ids stay what they are
 th_status bins_store_grow_keep(th_context *c, th::DepositParams &p, uint32_t pool)
@@ -430,10 +451,15 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
         // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
         // outgrew its chunk table or a line its reservation, left to the stream-ordered pipeline
         TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
-        TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * th::kBinMaxPages * sizeof(uint32_t), c->stream));
-        if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) return kRetryInStreamOrder;
-        const uint32_t want = 2u * host[th::kTotPool] + 64;      // (generously: growing the store costs a frame's worth of time)
-        if (th_status s = bins_store(c, p.nbins, want, p.mode == 2)) return s;
+        TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * c->bin_max_pages * sizeof(uint32_t), c->stream));
+        if ((flags & ~(th::kBinsPoolExhausted | th::kBinsBinFull)) || attempt >= 6) return kRetryInStreamOrder;
+        // (a bin that outgrew its lists - the wake of a long-running loop draws half a million fragments into 16 x 16 texels -
+        // gets a wider page table: a list's pages x 4, up to kBinPagesLimit)
+        if (flags & th::kBinsBinFull) { if (th_status s = bins_table_widen(c, p, false)) return s; }
+        if (flags & th::kBinsPoolExhausted) {
+            const uint32_t want = 2u * host[th::kTotPool] + 64;      // (generously: growing the store costs a frame's worth of time)
+            if (th_status s = bins_store(c, p.nbins, want, p.mode == 2)) return s;
+        }
     }
 }
 
@@ -463,16 +489,21 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         c->crowd_capacity = cap;
     }
     if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
-        (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); c->crowd_keys = nullptr; c->crowd_sorted = nullptr; c->crowd_keys_cap = 0;
+        (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); (void)hipFree(c->crowd_parted); (void)hipFree(c->crowd_windows);
+        c->crowd_keys = nullptr; c->crowd_sorted = nullptr; c->crowd_parted = nullptr; c->crowd_windows = nullptr; c->crowd_keys_cap = 0;
         const size_t cap = 2 * (size_t)host[th::kTotCrowdKeys] + ((size_t)1 << 20);
         TH_HIP(hipMalloc((void **)&c->crowd_keys, cap * sizeof(unsigned long long)));
         TH_HIP(hipMalloc((void **)&c->crowd_sorted, cap * sizeof(uint32_t)));
+        TH_HIP(hipMalloc((void **)&c->crowd_parted, cap * sizeof(unsigned long long)));
+        TH_HIP(hipMalloc((void **)&c->crowd_windows, (cap / 512 + 2) * 3 * sizeof(uint32_t)));      // (th_bins.hip: giant_part_kernel)
         c->crowd_keys_cap = cap;
     }
     p.nlarge = nlarge;
     p.crowd_count = c->crowd_mem; p.crowd_cursor = c->crowd_mem + (size_t)c->crowd_capacity * 256; p.crowd_start = p.crowd_cursor + (size_t)c->crowd_capacity * 256;
     p.crowd_long = p.crowd_start + (size_t)c->crowd_capacity * 257; p.crowd_giant = p.crowd_long + (size_t)c->crowd_capacity * 256;
-    p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted;
+    p.crowd_giant_win = p.crowd_giant + (size_t)c->crowd_capacity * 256;
+    p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted; p.crowd_parted = c->crowd_parted;
+    p.crowd_windows = c->crowd_windows; p.crowd_windows_cap = (uint32_t)(c->crowd_keys_cap / 512 + 2);
     if (nlarge) {
         // The crowded bins on two streams of their own, beside the ordinary bins' blend (disjoint texels, kernels that wait on
         // chains and loads rather than fill the chip): their fragments regrouped by texel, then the long runs on one stream -
@@ -482,13 +513,21 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         th::launch_bins_regroup(p, c->side2);
         TH_HIP(hipEventRecord(c->regrouped, c->side2));
         TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
-        th::launch_bins_blend_long(p, c->side);
+        th::launch_bins_blend_giants(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
         th::launch_bins_blend_crowd(p, c->side2);
         TH_HIP(hipEventRecord(c->joined2, c->side2));
     }
     if (!blended_early) th::launch_bins_blend(p, c->stream);
-    if (nlarge) { TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0)); }
+    if (nlarge) {
+        // ... and the runs in between (a wave each) behind the ordinary bins' blend on the main stream: behind the giants on
+        // their stream they started when the longest chain had ended, with most of the chip idle; a stream of their own
+        // shares a hardware queue with one of the others (four per process by default) and holds that one's kernels back
+        // (tools/gpu_r4_steady_trace.sh)
+        TH_HIP(hipStreamWaitEvent(c->stream, c->regrouped, 0));
+        th::launch_bins_blend_long(p, c->stream);
+        TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0));
+    }
     TH_HIP(hipGetLastError());
     return TH_OK;
 }

@@ -153,7 +153,8 @@ struct DepositParams {
     const uint32_t *perm;
     uint32_t bins_x, nbins;
     uint32_t *bin_cursor, bin_stride;              // per list (r * bin_stride + bin): places handed out so far (virtual indices inside the list)
-    uint32_t *page_table;                          // per list x kBinMaxPages: page id of the list's n-th page, n >= 1 (0: not handed out yet)
+    uint32_t *page_table;                          // per list x max_pages: page id of the list's n-th page, n >= 1 (0: not handed out yet)
+    uint32_t max_pages;                            // pages one list can grow to in this pass (the host widens the table when a bin outgrew it)
     uint32_t pool_pages;                           // pages in the pool: ids nbins * kBinReplicas .. + pool_pages - 1
     uint32_t *totals;                              // device words (th_bins.hip: kTot*)
     unsigned long long *frag_keys;                 // per place, chunk-major: (y << 12 | x) << 32 | stream index of the line; ~0 = empty
@@ -164,6 +165,9 @@ struct DepositParams {
     unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 32 | place of its varying
     uint32_t *crowd_sorted;                        // ... and the places alone, every texel's run in blend order (crowd_blend_lanes_kernel)
     uint32_t *crowd_long, *crowd_giant;            // texels of large bins whose runs one wave does not order (large bin << 8 | texel): up to kGiantRun fragments / more
+    unsigned long long *crowd_parted;              // the giants' keys parted by the leading bits of their stream indices (same positions as crowd_keys)
+    uint32_t *crowd_giant_win;                     // per entry of crowd_giant: first window, windows (first = ~0: left to crowd_blend_kernel)
+    uint32_t *crowd_windows, crowd_windows_cap;    // per window: entry of crowd_giant, first key inside the run, keys
 };
 
 // row-band shards drawing with the binned pipeline (th_bins.hip "the bins travel to the ranks that own them")
@@ -243,17 +247,19 @@ constexpr int kBinShift = 4;                       // 16 x 16 texel bins
 constexpr uint32_t kBinCap = 4096;                 // places of a bin that one workgroup orders in LDS
 constexpr uint32_t kBinReplicas = 16;              // lists per bin (th_bins.hip)
 constexpr uint32_t kBinPage = 256;                 // places per page
-constexpr uint32_t kBinMaxPages = 128;             // pages one list can grow to (half a million places per bin)
+constexpr uint32_t kBinFirstPages = 128;           // pages one list can grow to at first (half a million places per bin) ...
+constexpr uint32_t kBinPagesLimit = 4096;          // ... and after the table has been widened as far as it goes (16 M places per bin)
 constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits per texel coordinate
 // totals[]: device words of one pass
-enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWords = 8 };
+enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWindows = 8, kTotWords = 12 };
 enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
 void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
-void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs of more fragments than a wave orders (the longest first)
+void launch_bins_blend_giants(const DepositParams &p, hipStream_t stream);            // their runs of more than kGiantRun fragments, a workgroup each (the longest chains of a draw)
+void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs a wave orders and blends on its own (kWaveRun + 1 .. kGiantRun fragments)
 void launch_bins_blend_crowd(const DepositParams &p, hipStream_t stream);             // their other runs, a wave each: order by stream index, blend
 void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // the bins one workgroup orders: by (texel, stream index), blend (needs no host value)
 size_t crowd_words_per_bin();

@@ -214,7 +214,7 @@ static th_status merge_reserve(th_context *c, uint32_t total, int target)
         c->mrg_capacity = cap;
     }
     if (th_status s = deposit_temp(c, th::radix_sort_temp_bytes(total, 32, 32 + deposit_texel_bits(c)))) return s;
-    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, 8 * sizeof(uint32_t)));
+    if (!c->dep_total) TH_HIP(hipMalloc((void **)&c->dep_total, th::kTotWords * sizeof(uint32_t)));
     return TH_OK;
 }
 
@@ -422,8 +422,13 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         const uint32_t flags = host[th::kTotFlags];
         if (flags == 0) break;
         // (nothing has been blended; a bin beyond its lists' reach cannot be drawn through the bins at all)
-        if ((flags & ~th::kBinsPoolExhausted) || attempt >= 2) { laid = fail(TH_ERR_UNSUPPORTED, "a bin of the target received more fragments than its lists hold (%u places)", th::kBinMaxPages * th::kBinPage * th::kBinReplicas); break; }
-        if ((laid = bins_store_grow_keep(c, p, host[th::kTotPool] + host[th::kTotPool] / 2u + 64u)) != TH_OK) break;
+        if ((flags & ~(th::kBinsPoolExhausted | th::kBinsBinFull)) || attempt >= 6) { laid = fail(TH_ERR_UNSUPPORTED, "the bins this rank owns could not be laid out (flags %u)", flags); break; }
+        if (flags & th::kBinsBinFull) {         // (a wider page table, with the entries of what this rank emitted itself)
+            if ((laid = bins_table_widen(c, p, true)) == kRetryInStreamOrder)
+                laid = fail(TH_ERR_UNSUPPORTED, "a bin of the target received more fragments than its lists hold (%u places)", c->bin_max_pages * th::kBinPage * th::kBinReplicas);
+            if (laid != TH_OK) break;
+        }
+        if ((flags & th::kBinsPoolExhausted) && (laid = bins_store_grow_keep(c, p, host[th::kTotPool] + host[th::kTotPool] / 2u + 64u)) != TH_OK) break;
     }
     if (laid == TH_OK) laid = bins_pass_finish(c, p, nullptr, false, false);
     // (an owner that could not lay its bins out has blended nothing; the others have: the draw is lost, and everybody says so)

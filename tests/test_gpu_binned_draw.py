@@ -127,15 +127,19 @@ def test_crowded_targets_are_order_exact(oracle, n, spread, view):
             assert (view_px == first_view).all() and view_px.any()
 
 
-def test_pool_growth_and_overfull_bins_fall_back_exactly(oracle, monkeypatch):
+def test_pool_growth_and_overfull_bins_exactly(oracle, monkeypatch):
     """The binned pass hands pages out from a pool sized from experience: a pool that runs dry is grown and the pass repeated
-    before anything is blended (TH_BINS_POOL=8 forces it), and a bin that outgrows its lists (more than half a million
-    fragments in 16 x 16 texels) leaves the draw to the stream-ordered pipeline - both with the exact result."""
+    before anything is blended (TH_BINS_POOL=8 forces it); a bin that outgrows its lists (more than half a million
+    fragments in 16 x 16 texels - where the wake of a long-running loop ends up) gets a page table four times as wide and the
+    pass is repeated; and a table that may not be widened (option bins_pages < 0) leaves the draw to the stream-ordered
+    pipeline - all with the exact result."""
+    import ctypes as C
     import tendrils_amd as ta
+    from tendrils_amd import _capi
     from tendrils_amd.tendrils import View
     monkeypatch.setenv("TH_BINS_POOL", "8")              # (a context's switches start from the environment it is created in)
 
-    def run(n, spread, view, seed):
+    def run(n, spread, view, seed, pages=0, pipeline=1):        # (pipeline: TH_DRAW_BINS = 1, TH_DRAW_STREAM = 0)
         rng = np.random.default_rng(seed)
         prev = np.zeros((n, n, 4), np.float32)
         prev[..., :2] = rng.uniform(-spread, spread, (n, n, 2))
@@ -148,6 +152,8 @@ def test_pool_growth_and_overfull_bins_fall_back_exactly(oracle, monkeypatch):
         t.resize()
         t.setup(n)
         assert t.particles.option("bins_pool") == 8
+        if pages:
+            t.particles.option("bins_pages", pages)
         t.particles.draw_pipeline("bins")
         t.particles.upload_texels(cur, 0)
         t.particles.upload_texels(prev, 1)
@@ -157,12 +163,17 @@ def test_pool_growth_and_overfull_bins_fall_back_exactly(oracle, monkeypatch):
         t.draw()
         assert t.fragments == frags, (t.fragments, frags)
         assert bits_equal(t.flow.read(), want).all()
+        info = _capi.DrawInfo()
+        _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
+        assert info.pipeline == pipeline, (info.pipeline, pipeline)
         t.draw()                                  # (and again: the store is clean after a repeated / abandoned pass)
         t.dispose()
         return frags
     a = run(256, 0.2, (96, 54), 5)               # a few bins, hundreds of fragments per list, a pool of 8 pages: grown, pass repeated
-    b = run(1536, 0.004, (64, 36), 6)            # 1.2 M drawable lines inside one bin: the bin outgrows its lists
+    b = run(1536, 0.004, (64, 36), 6)            # 1.2 M drawable lines inside one bin: the bin outgrows its lists, the table is widened
     assert a > 20_000 and b > 600_000, (a, b)
+    assert run(256, 0.2, (96, 54), 5, pages=2) == a                 # lists of 2 pages at first: widened
+    assert run(256, 0.02, (96, 54), 7, pages=-2, pipeline=0) > 20_000      # ... and never: the stream-ordered pipeline draws
 
 
 def test_auto_policy_leaves_a_crowded_target_to_the_stream_ordered_pipeline():

@@ -119,25 +119,30 @@ def last_pipeline(t):
     return info.pipeline
 
 
-@pytest.mark.parametrize("n,view,world,spread,sorted_slots,pool", [(64, (96, 54), 2, 0.9, False, 0), (128, (50, 27), 3, 0.9, True, 0),
-                                                                   (256, (96, 54), 4, 0.15, True, 0), (256, (40, 200), 3, 0.9, False, 0),
-                                                                   (256, (96, 54), 2, 0.15, False, 8), (256, (96, 54), 3, 0.3, True, 40), (256, (96, 54), 4, 0.12, True, 8)])
-def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, sorted_slots, pool):
+@pytest.mark.parametrize("n,view,world,spread,sorted_slots,pool,pages", [(64, (96, 54), 2, 0.9, False, 0, 0), (128, (50, 27), 3, 0.9, True, 0, 0),
+                                                                         (256, (96, 54), 4, 0.15, True, 0, 0), (256, (40, 200), 3, 0.9, False, 0, 0),
+                                                                         (256, (96, 54), 2, 0.15, False, 8, 0), (256, (96, 54), 3, 0.3, True, 40, 0), (256, (96, 54), 4, 0.12, True, 8, 0),
+                                                                         (256, (96, 54), 3, 0.15, True, 8, 2), (256, (96, 54), 2, 0.3, False, 0, 4)])
+def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, sorted_slots, pool, pages):
     """The sharded draw() through the binned pipeline (th_bins.hip: the bins travel to the ranks that own them): every rank
     rasterises into its own page store, whole bin rows change hands with their counts, the owner lays them out as if it had
     emitted them and blends with the unchanged kernels.  spread 0.15 at 256^2: bins of tens of thousands of fragments (pool
     pages in the owner's layout, the crowded bins' kernels); 40 x 200 texels over 3 owners: 13 bin rows, 4 / 4 / 5 each;
     sorted_slots: after a step over tile-sorted slots (the bands keep their order: no return to texel order); pool: a page
     pool of that many pages to start with - it runs dry in the emitting pass (repeated with a larger one) and again when the
-    other ranks' fragments arrive (grown with the owner's own bins kept in it)."""
+    other ranks' fragments arrive (grown with the owner's own bins kept in it); pages: lists that can grow to that many pages
+    at first - a bin outgrows them in the emitting pass (wider table, pass repeated) and again at its owner (widened with the
+    entries of the owner's own fragments kept)."""
     from tendrils_amd import sharding
     cur, prev, base = inputs(n, view, 31 * n + world, spread)
     one = make(n, view, cur, prev, base)
     shards = world_of(n, view, world, cur, prev, base, pipeline="bins")
     everybody = [one] + shards
-    if pool:
-        for t in shards:
+    for t in shards:
+        if pool:
             t.particles.option("bins_pool", pool)
+        if pages:
+            t.particles.option("bins_pages", pages)
     if sorted_slots:
         for t in everybody:
             t.particles.option("bucket", 1)

@@ -69,10 +69,23 @@ if os.environ.get("TH_BENCH_TRACE") and both_ms:        # how the frame changes 
     for k in range(0, len(both_ms), 50):
         print("frames %4d-%4d  step %.3f  draw(both) %.3f  fragments %.2f M  binned %3d%%  crowded share %.2f" % (k, min(k + 50, len(both_ms)) - 1, np.mean(step_ms[k:k + 50]),
               np.mean(both_ms[k:k + 50]), np.mean(frags[k:k + 50]) / 1e6, 100 * np.mean(pipes[k:k + 50]), np.mean(crowded[k:k + 50])))
+wall_ms = None
+if "--wall" in sys.argv:                 # ... and 200 more frames as a host runs them (no event pair, no sync but the draw's own read-back)
+    import time
+    _capi.call("th_sync", ctx)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        t.timer.tick(); t.step(); t.draw()
+    _capi.call("th_sync", ctx)
+    wall_ms = (time.perf_counter() - t0) / 200 * 1e3
+if os.environ.get("TH_BENCH_FRAMES") and both_ms:       # e.g. 640:710 - those frames one by one
+    lo, hi = (int(x) for x in os.environ["TH_BENCH_FRAMES"].split(":"))
+    for k in range(lo, min(hi, len(both_ms))):
+        print("frame %4d  step %.3f  draw(both) %.3f  fragments %.2f M  crowded share %.2f" % (k, step_ms[k], both_ms[k], frags[k] / 1e6, crowded[k]))
 stats = t.particles.stats(t.state["speedLimit"])
 print(json.dumps({"pipeline": os.environ.get("TH_PIPE", "auto"), "particles": N * N, "flow": [1920, 1080], "frames": frames, "in_view": in_view,
                   "step_ms": float(np.mean(step_ms)), "draw_ms": float(np.mean(draw_ms)) if draw_ms else None, "view_ms": float(np.mean(view_ms)) if view_ms else None,
                   "draw_both_ms": float(np.mean(both_ms)) if both_ms else None,
                   "fragments_per_frame": float(np.mean(frags)), "frames_per_s": 1e3 / float(np.mean(step_ms) + (np.mean(both_ms) if both_ms else np.mean(draw_ms))),
-                  "live": stats["live"], "nan": stats["nan"]}))
+                  "wall_ms_per_frame": wall_ms, "live": stats["live"], "nan": stats["nan"]}))
 t.dispose()
