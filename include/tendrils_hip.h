@@ -401,12 +401,12 @@ th_status th_slot_order(th_context *ctx, th_slot_order_info *out);
  * particles in texel order, stable radix sort by texel (th_deposit.hip).  TH_DRAW_BINS: particles walked in whatever slot
  * order the ring is held in, fragments bucketed by 16 x 16-texel bin of the target and put in order inside each bin
  * (th_bins.hip) - what lets a step() + draw() frame loop (src/demo.main.js:1082) stay on tile-sorted slots.
- * TH_DRAW_AUTO (default): bins wherever the integrator steps over sorted slots, while the target is not crowded (th_draw_query). */
+ * TH_DRAW_AUTO (default): bins wherever the integrator steps over sorted slots. */
 enum { TH_DRAW_AUTO = -1, TH_DRAW_STREAM = 0, TH_DRAW_BINS = 1 };
 th_status th_draw_pipeline(th_context *ctx, int32_t which);
 /* What the last draw pass did: the pipeline it took, its fragments, and (binned pipeline) how many of them fell into bins of
- * more than 4096 fragments - the share TH_DRAW_AUTO watches: it moves to the stream-ordered pipeline for a spell when the
- * target is crowded (most fragments in texels of hundreds and thousands) and comes back to try again. */
+ * more than 4096 fragments - how crowded the target is (most fragments in texels of hundreds and thousands once the wake of a
+ * long-running loop has drawn the particles together). */
 typedef struct th_draw_info {
     int32_t pipeline;            /* TH_DRAW_STREAM / TH_DRAW_BINS */
     int32_t reserved;

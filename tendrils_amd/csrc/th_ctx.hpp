@@ -144,11 +144,9 @@ struct th_context {
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
     th_draw_info last_draw{};            // th_draw_query
-    // auto policy: the binned pipeline while the target is not crowded (th_api.hip: draw_uses_bins)
-    long long draws = 0, stream_until = 0;        // (`draws` counts frames: the passes drawn at one total_steps share a count ...
-    long long draw_frame_step = -1;               //  ... and a pipeline)
+    long long draws = 0;                          // (`draws` counts frames: the passes drawn at one total_steps share a count ...
+    long long draw_frame_step = -1;               //  ... and a pipeline: th_draw.hip, draw_uses_bins)
     int frame_bins = -1;
-    int crowded_streak = 0, stream_spell = 0;
     long long last_binned_draw = -(1ll << 40);   // total_steps at the last draw over slot order
     uint32_t *dep_u32[4] = {nullptr, nullptr, nullptr, nullptr};     // per fragment: keys, slots, and both sorted
     unsigned long long *dep_u64[2] = {nullptr, nullptr};             // sharded form: (texel, stream index) keys, sorted
@@ -262,7 +260,7 @@ th_status bins_store_grow_keep(th_context *c, th::DepositParams &p, uint32_t poo
 th_status bins_table_widen(th_context *c, th::DepositParams &p, bool keep);       // kRetryInStreamOrder: as wide as it goes (or no memory)
 th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early);
 th_status bins_pass_totals(th_context *c);
-th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early, bool policy);
+th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early);
 bool binned_shards(const th_context *c);              // a sharded draw() of this job goes through the bins (the same answer on every rank)
 th_status deposit_prepare_bins(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p);
 

@@ -21,16 +21,12 @@ int deposit_texel_bits(const th_context *c)
 // whenever the integrator would step over tile-sorted slots (sorting_possible): a step() + draw() frame loop then never
 // leaves the sorted order.
 // Which pipeline a draw pass takes.  auto: wherever the integrator steps over tile-sorted slots the frame loop - step(); draw() -
-// stays on them: the binned pipeline takes particles in any order.  It is ahead while the target is not crowded (first ~60
-// frames at C3: 1.7 against 2.3 ms per draw with both passes) and level with the stream-ordered pipeline once the wake has made
-// the particles converge (70-76 % of all fragments in bins of more than 4096, in texels with hundreds and thousands of them:
-// 2.0-2.7 ms either way; profiles/r3_b_fused_pass_experiments.txt) - restoring GL's order per texel then means sorting most
-// fragments by stream index, an order the stream-ordered pipeline gets for free from walking particles in texel order.  Beyond
-// that, auto hands over: when more than kCrowdedShare of a binned pass's fragments fell into large bins three passes in a row,
-// the next kStreamSpell passes (doubling, up to 4096, while it stays so) go to the stream-ordered pipeline, then the binned one
-// is tried again.
-constexpr double kCrowdedShare = 0.8;
-constexpr int kStreamSpell = 256;
+// stays on them: the binned pipeline takes particles in any order, and it is ahead of the stream-ordered one from the first
+// frame (1.3 against 2.2 ms per draw with both passes at C3) to the crowded target the wake leaves after a thousand frames
+// (70-77 % of all fragments in bins of more than 4096, in texels with thousands of them: 1.3-1.7 against 1.7-2.3 ms;
+// profiles/r4_g_giants.txt).  (Round 3 handed a crowded target over to the stream-ordered pipeline for a spell: it was level
+// then.)  A binned pass that cannot go on - no memory for its store - is repeated in stream order, and the ring then keeps
+// texel order for opt.rebucket_steps steps (deposit_prepare): that many frames pass before the bins are tried again.
 
 float drawn_line_width(const th_context *c, int pass)
 {
@@ -44,7 +40,6 @@ static bool draw_uses_bins(th_context *c)
     if (policy == 0) return false;
     if (c->cfg.height != c->cfg.global_height || c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
     if (policy == 1) return true;
-    if (c->draws < c->stream_until) return false;
     // (lines wider than 2 cover more texels than a line's record holds: nearly all of them would leave the fused pass
     // for the long list, one atomic per fragment - the stream-ordered pipeline counts and scans instead)
     if (drawn_line_width(c, TH_PASS_FLOW) > 2.0f || drawn_line_width(c, TH_PASS_VIEW) > 2.0f) return false;
@@ -464,23 +459,13 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
 }
 
 // Part 2: with the totals in c->bins_totals_host - the crowded bins regrouped and blended on the side streams, the ordinary
-// bins' blend unless it went out early.  `policy`: the draw counts for the auto policy (a single context's draws do).
-th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early, bool policy)
+// bins' blend unless it went out early.
+th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early)
 {
     uint32_t *host = c->bins_totals_host;
     const uint32_t total = host[th::kTotFragments], nlarge = host[th::kTotLarge];
     if (fragments) *fragments = total;
     c->last_draw.pipeline = TH_DRAW_BINS; c->last_draw.fragments = total; c->last_draw.crowded_fragments = host[th::kTotCrowdKeys];
-    if (policy) {   // (auto policy: see draw_uses_bins)
-        const bool crowded = total > 0 && (double)host[th::kTotCrowdKeys] > kCrowdedShare * (double)total;
-        c->crowded_streak = crowded ? c->crowded_streak + 1 : 0;
-        if (!crowded) c->stream_spell = 0;
-        if (c->crowded_streak >= 3 || (crowded && c->stream_spell > 0)) {
-            c->stream_spell = c->stream_spell ? std::min(2 * c->stream_spell, 4096) : kStreamSpell;
-            c->stream_until = c->draws + c->stream_spell;
-            c->crowded_streak = 0;
-        }
-    }
     if (host[th::kTotCrowdKeys] == 0xffffffffu) return fail(TH_ERR_UNSUPPORTED, "too many fragments in crowded bins for one draw (2^32 or more places)");
     if (c->crowd_capacity < nlarge) {
         (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
@@ -550,7 +535,7 @@ static th_status deposit_run_bins(th_context *c, th::DepositParams &p, uint64_t 
     // side stream) are then the longest chain of the draw and must start as early as they can.  Decided by the last draw.
     const bool early = !(c->last_draw.pipeline == TH_DRAW_BINS && (double)c->last_draw.crowded_fragments > kEarlyBlendShare * (double)c->last_draw.fragments);
     if (th_status s = bins_pass_emit(c, p, early)) return s;
-    return bins_pass_finish(c, p, fragments, early, true);
+    return bins_pass_finish(c, p, fragments, early);
 }
 
 extern "C" {

@@ -430,7 +430,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         }
         if ((flags & th::kBinsPoolExhausted) && (laid = bins_store_grow_keep(c, p, host[th::kTotPool] + host[th::kTotPool] / 2u + 64u)) != TH_OK) break;
     }
-    if (laid == TH_OK) laid = bins_pass_finish(c, p, nullptr, false, false);
+    if (laid == TH_OK) laid = bins_pass_finish(c, p, nullptr, false);
     // (an owner that could not lay its bins out has blended nothing; the others have: the draw is lost, and everybody says so)
     if (th_status s = agree_status(c, laid == kRetryInStreamOrder ? fail(TH_ERR_HIP, "the owner's store could not be had") : laid, "laying out the bins it owns")) return s;
     const uint32_t bins_y = p.nbins / p.bins_x;
