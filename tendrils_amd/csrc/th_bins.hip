@@ -1013,8 +1013,18 @@ __global__ __launch_bounds__(256) void crowd_scan_kernel(const DepositParams p)
     p.crowd_start[(size_t)i * (kBinTexels + 1u) + t] = start;
     p.crowd_cursor[(size_t)i * kBinTexels + t] = start;
     if (t == 255u) p.crowd_start[(size_t)i * (kBinTexels + 1u) + 256u] = before + incl;
-    if (mine > kGiantRun) p.crowd_giant[atomicAdd(&p.totals[kTotGiant], 1u)] = (i << 8) | t;       // (in whatever order)
-    else if (mine > kWaveRun) p.crowd_long[atomicAdd(&p.totals[kTotLong], 1u)] = (i << 8) | t;
+    // the lists of the runs a wave does not order, in whatever order: one atomic per wave and list (a crowded target has
+    // thousands of such texels - one atomic each on the same two words was most of this kernel's time)
+    auto listed = [&](bool is, uint32_t *list, uint32_t *counter) {
+        const unsigned long long who = __ballot(is);
+        if (who == 0ull) return;
+        uint32_t first = 0;
+        if (lane == (uint32_t)__builtin_ctzll(who)) first = atomicAdd(counter, (uint32_t)__builtin_popcountll(who));
+        first = (uint32_t)__shfl((int)first, __builtin_ctzll(who));
+        if (is) list[first + (uint32_t)__builtin_popcountll(who & ((1ull << lane) - 1ull))] = (i << 8) | t;
+    };
+    listed(mine > kGiantRun, p.crowd_giant, &p.totals[kTotGiant]);
+    listed(mine > kWaveRun && mine <= kGiantRun, p.crowd_long, &p.totals[kTotLong]);
 }
 
 __global__ __launch_bounds__(256) void crowd_scatter_kernel(const DepositParams p)
@@ -1132,45 +1142,6 @@ TH_D void wave_walk(const DepositParams &p, uint32_t texel, uint32_t len, BlendS
     if (view_lane) reinterpret_cast<unsigned char *>(p.view + texel)[lane & 3u] = (unsigned char)comp;
 }
 
-// The long list (kWaveRun < fragments <= kGiantRun) by ONE WAVE per run, four runs per workgroup side by side: the run's keys
-// ordered by a bitonic network in the wave's own LDS words - no workgroup barrier between its steps: a workgroup per run spent
-// most of its time in the 55 barriers of a thousand-key sort -, then 64 sources staged at a time (the next 64 varyings in
-// flight meanwhile) and the destination's channels applied by lanes 0-7 as in bin_blend_long.
-template <int MODE>
-__global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositParams p, const uint32_t *list, const uint32_t *count)
-{
-    __shared__ unsigned long long skeys[4][kGiantRun];
-    __shared__ BlendSource stage_a[4][2][64], stage_b[4][MODE == 2 ? 2 : 1][MODE == 2 ? 64 : 1];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nlong = *count;
-    unsigned long long *skey = skeys[wave];
-    for (uint32_t e = blockIdx.x * 4u + wave; e < nlong; e += gridDim.x * 4u) {
-        const uint32_t entry = list[e], i = entry >> 8, lt = entry & 255u;
-        const uint32_t b = p.large_bins[i];
-        const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
-        const uint32_t by = b / p.bins_x, bx = b - by * p.bins_x;
-        const uint32_t x = (bx << kBinShift) + (lt & (kBinSide - 1u)), y = (by << kBinShift) + (lt >> kBinShift);
-        const uint32_t texel = y * (uint32_t)p.fw + x;            // (a texel with fragments lies inside the target)
-        const unsigned long long *run = p.crowd_keys + p.large_key0[i] + r0;
-        // the keys (stream index << 32 | place of the varying), padded to a power of two, ordered
-        uint32_t P = 64u;
-        while (P < len) P <<= 1;
-        for (uint32_t f = lane; f < P; f += 64u) skey[f] = f < len ? run[f] : ~0ull;
-        wave_sync();
-        for (uint32_t k = 2; k <= P; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t q = lane; q < (P >> 1); q += 64u) {
-                    const uint32_t lo = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), hi = lo | j;
-                    const unsigned long long a = skey[lo], c = skey[hi];
-                    const bool up = (lo & k) == 0u;
-                    if ((a > c) == up) { skey[lo] = c; skey[hi] = a; }
-                }
-                wave_sync();
-            }
-        wave_walk<MODE>(p, texel, len, stage_a[wave], stage_b[wave], [&](uint32_t j) { return (uint32_t)(skey[j] & 0xffffffffull); });
-        wave_sync();                                              // (the words are free for the wave's next run)
-    }
-}
-
 // ---- the giants (runs of more than kGiantRun fragments) --------------------------------------------------------------------
 // Once the wake of a long-running loop has drawn the particles together, single texels receive thousands and tens of
 // thousands of fragments per draw, and a thousand such texels at once.  Their runs are put in order in three steps, none of
@@ -1182,7 +1153,7 @@ __global__ __launch_bounds__(256) void crowd_blend_waves_kernel(const DepositPar
 //                       in one texel: a spawn - is left to crowd_blend_kernel, which narrows its windows as it goes.)
 //   giant_sort_kernel   a workgroup per WINDOW, all windows of all runs side by side: ordered in LDS, the places of the
 //                       varyings written in blend order (p.crowd_sorted)
-//   giant_walk_kernel   a wave per run: wave_walk over those places - what is left on the draw's critical path is the chain
+//   run_walk_kernel     a wave per run and target: wave_walk over those places - what is left on the draw's critical path is the chain
 //                       of the longest run, one fragment after the other, and nothing else.
 // (crowd_blend_kernel did all of this inside one workgroup per run, window after window - and read the whole run twice per
 // window: a run of 17 000 fragments took 1.5 ms, profiles/r4_g_giants.txt.)
@@ -1321,16 +1292,51 @@ __global__ __launch_bounds__(256) void giant_sort_kernel(const DepositParams p)
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void giant_walk_kernel(const DepositParams p)
+// The long list (kWaveRun < fragments <= kGiantRun): ONE WAVE per run orders it, four runs per workgroup side by side - a
+// bitonic network in the wave's own LDS words, no workgroup barrier between its steps (a workgroup per run spent most of its
+// time in the 55 barriers of a thousand-key sort) - and leaves the places of the varyings in blend order (p.crowd_sorted)
+// for run_walk_kernel, as the giants' windows do.
+__global__ __launch_bounds__(256) void long_sort_kernel(const DepositParams p)
+{
+    __shared__ unsigned long long skeys[4][kGiantRun];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nlong = p.totals[kTotLong];
+    unsigned long long *skey = skeys[wave];
+    for (uint32_t e = blockIdx.x * 4u + wave; e < nlong; e += gridDim.x * 4u) {
+        const GiantRun g = giant_run(p, p.crowd_long[e]);
+        const size_t base = (size_t)p.large_key0[g.i] + g.r0;
+        // the keys (stream index << 32 | place of the varying), padded to a power of two, ordered
+        uint32_t P = 64u;
+        while (P < g.len) P <<= 1;
+        for (uint32_t f = lane; f < P; f += 64u) skey[f] = f < g.len ? p.crowd_keys[base + f] : ~0ull;
+        wave_sync();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t q = lane; q < (P >> 1); q += 64u) {
+                    const uint32_t lo = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), hi = lo | j;
+                    const unsigned long long a = skey[lo], c = skey[hi];
+                    const bool up = (lo & k) == 0u;
+                    if ((a > c) == up) { skey[lo] = c; skey[hi] = a; }
+                }
+                wave_sync();
+            }
+        for (uint32_t f = lane; f < g.len; f += 64u) p.crowd_sorted[base + f] = (uint32_t)(skey[f] & 0xffffffffull);
+        wave_sync();                                              // (the words are free for the wave's next run)
+    }
+}
+
+// The runs of a list (GIANTS: p.crowd_giant, else p.crowd_long) walked over their places in blend order, a wave per run and
+// target: with both targets in one store two waves walk a run side by side, each its own chain.
+template <int MODE, bool GIANTS>
+__global__ __launch_bounds__(256) void run_walk_kernel(const DepositParams p)
 {
     __shared__ BlendSource stage_a[4][2][64], none[1][1];
-    constexpr uint32_t kParts = MODE == 2 ? 2u : 1u;          // (both targets: a wave each - two chains side by side instead of one after the other)
-    const uint32_t wave = threadIdx.x >> 6, ntask = p.totals[kTotGiant] * kParts;
+    constexpr uint32_t kParts = MODE == 2 ? 2u : 1u;
+    const uint32_t wave = threadIdx.x >> 6, ntask = p.totals[GIANTS ? kTotGiant : kTotLong] * kParts;
+    const uint32_t *list = GIANTS ? p.crowd_giant : p.crowd_long;
     for (uint32_t task = blockIdx.x * 4u + wave; task < ntask; task += gridDim.x * 4u) {
         const uint32_t e = task / kParts;
-        if (p.crowd_giant_win[2u * e] == kGiantFallback) continue;
-        const GiantRun g = giant_run(p, p.crowd_giant[e]);
+        if (GIANTS && p.crowd_giant_win[2u * e] == kGiantFallback) continue;
+        const GiantRun g = giant_run(p, list[e]);
         const uint32_t *sorted = p.crowd_sorted + p.large_key0[g.i] + g.r0;
         auto place_at = [&](uint32_t j) { return sorted[j]; };
         if constexpr (MODE == 2) {
@@ -1701,16 +1707,22 @@ void launch_bins_blend_giants(const DepositParams &p, hipStream_t s)
     if (!p.nlarge) return;
     hipLaunchKernelGGL(giant_part_kernel, dim3(2048), dim3(256), 0, s, p);
     hipLaunchKernelGGL(giant_sort_kernel, dim3(4096), dim3(256), 0, s, p);
-#define TH_GO(M) do { hipLaunchKernelGGL(giant_walk_kernel<M>, dim3(512), dim3(256), 0, s, p); \
+#define TH_GO(M) do { hipLaunchKernelGGL((run_walk_kernel<M, true>), dim3(512), dim3(256), 0, s, p); \
                       hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(256), dim3(256), 0, s, p, (const uint32_t *)p.crowd_giant, (const uint32_t *)(p.totals + kTotGiant)); } while (0)
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO
 }
-// ... and the runs in between, a wave each (disjoint texels again: on whatever stream has room - th_draw.hip)
-void launch_bins_blend_long(const DepositParams &p, hipStream_t s)
+// ... and the runs in between (kWaveRun + 1 .. kGiantRun fragments), ordered by a wave each, then walked by a wave per run and
+// target - two launches the caller can put on different streams (disjoint texels again; th_draw.hip)
+void launch_bins_sort_long(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;
-#define TH_GO(M) hipLaunchKernelGGL(crowd_blend_waves_kernel<M>, dim3(1024), dim3(256), 0, s, p, (const uint32_t *)p.crowd_long, (const uint32_t *)(p.totals + kTotLong))
+    hipLaunchKernelGGL(long_sort_kernel, dim3(1024), dim3(256), 0, s, p);
+}
+void launch_bins_walk_long(const DepositParams &p, hipStream_t s)
+{
+    if (!p.nlarge) return;
+#define TH_GO(M) hipLaunchKernelGGL((run_walk_kernel<M, false>), dim3(2048), dim3(256), 0, s, p)
     if (p.mode == 0) TH_GO(0); else if (p.mode == 1) TH_GO(1); else TH_GO(2);
 #undef TH_GO
 }

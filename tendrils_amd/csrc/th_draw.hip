@@ -505,12 +505,14 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
     }
     if (!blended_early) th::launch_bins_blend(p, c->stream);
     if (nlarge) {
-        // ... and the runs in between (a wave each) behind the ordinary bins' blend on the main stream: behind the giants on
-        // their stream they started when the longest chain had ended, with most of the chip idle; a stream of their own
-        // shares a hardware queue with one of the others (four per process by default) and holds that one's kernels back
-        // (tools/gpu_r4_steady_trace.sh)
+        // ... and the runs in between, put in order and walked behind the ordinary bins' blend on the main stream.  (Behind
+        // the giants they waited for the longest chain of the draw; a stream of their own shares a hardware queue with one of
+        // the others - four per process by default - and holds that one's kernels back; ordered behind the short runs on
+        // their stream and walked here: 1.40 against 1.44 ms per frame late in the loop, 1.88 against 1.79 early -
+        // profiles/r4_g_giants.txt)
         TH_HIP(hipStreamWaitEvent(c->stream, c->regrouped, 0));
-        th::launch_bins_blend_long(p, c->stream);
+        th::launch_bins_sort_long(p, c->stream);
+        th::launch_bins_walk_long(p, c->stream);
         TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0));
     }
     TH_HIP(hipGetLastError());

@@ -259,7 +259,8 @@ void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hip
 void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
 void launch_bins_blend_giants(const DepositParams &p, hipStream_t stream);            // their runs of more than kGiantRun fragments, a workgroup each (the longest chains of a draw)
-void launch_bins_blend_long(const DepositParams &p, hipStream_t stream);              // their runs a wave orders and blends on its own (kWaveRun + 1 .. kGiantRun fragments)
+void launch_bins_sort_long(const DepositParams &p, hipStream_t stream);               // their runs a wave orders on its own (kWaveRun + 1 .. kGiantRun fragments) ...
+void launch_bins_walk_long(const DepositParams &p, hipStream_t stream);               // ... walked
 void launch_bins_blend_crowd(const DepositParams &p, hipStream_t stream);             // their other runs, a wave each: order by stream index, blend
 void launch_bins_blend(const DepositParams &p, hipStream_t stream);                   // the bins one workgroup orders: by (texel, stream index), blend (needs no host value)
 size_t crowd_words_per_bin();
