@@ -499,20 +499,19 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         TH_HIP(hipEventRecord(c->regrouped, c->side2));
         TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
         th::launch_bins_blend_giants(p, c->side);
+        // ... and the runs in between behind them.  (A stream of their own shares a hardware queue with one of the others -
+        // four per process by default - and holds that one's kernels back; behind the ordinary bins' blend on the main stream,
+        // or ordered behind the short runs and walked on the main stream: the same within 1-3 % one way or the other, by the
+        // phase of the loop - the blend phase of a crowded draw is bound by the chip's throughput, not by one stream's chain:
+        // profiles/r4_g_giants.txt)
+        th::launch_bins_sort_long(p, c->side);
+        th::launch_bins_walk_long(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
         th::launch_bins_blend_crowd(p, c->side2);
         TH_HIP(hipEventRecord(c->joined2, c->side2));
     }
     if (!blended_early) th::launch_bins_blend(p, c->stream);
     if (nlarge) {
-        // ... and the runs in between, put in order and walked behind the ordinary bins' blend on the main stream.  (Behind
-        // the giants they waited for the longest chain of the draw; a stream of their own shares a hardware queue with one of
-        // the others - four per process by default - and holds that one's kernels back; ordered behind the short runs on
-        // their stream and walked here: 1.40 against 1.44 ms per frame late in the loop, 1.88 against 1.79 early -
-        // profiles/r4_g_giants.txt)
-        TH_HIP(hipStreamWaitEvent(c->stream, c->regrouped, 0));
-        th::launch_bins_sort_long(p, c->stream);
-        th::launch_bins_walk_long(p, c->stream);
         TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0));
     }
     TH_HIP(hipGetLastError());
