@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench as B
+from benchlib import workload as B
 import tendrils_amd as ta
 from tendrils_amd import _capi
 from tendrils_amd.tendrils import View
