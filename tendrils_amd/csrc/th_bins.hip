@@ -25,8 +25,10 @@
 //      texel's run ordered by the stream index of its line (short runs: rank by counting; long ones: bitonic sort) and
 //      blended in that order by the texel's thread - dst = src*a + dst*(1-a), fragment after fragment, GL's order and
 //      arithmetic.
-//      crowd_*_kernel: the large bins get one more level of the same scheme (regrouped by texel, then a wave or a
-//      workgroup per texel).
+//      crowd_*_kernel: the large bins get one more level of the same scheme - regrouped by texel, then by the length of a
+//      texel's run: up to 256 fragments ordered by a wave and walked by four lanes, up to 1024 ordered by a wave
+//      (long_sort_kernel), beyond that parted by stream index and ordered window by window (giant_*_kernel), both walked by
+//      a wave per run and target (run_walk_kernel).
 // The stream index of a line is a pure function of its particle id, so the result is the stream-ordered pipeline's, and
 // the restatement's, bit for bit, whatever the slot order and whatever the atomics did.
 #include "th_kernels.hpp"
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
 //   crowd_blend_kernel       one workgroup per texel of the long list (windows of stream indices when a run does not fit LDS):
 //                            sources staged by all threads, the destination's channels applied side by side, a lane each
 constexpr uint32_t kWaveRun = 256;           // runs up to this length are ordered and blended by ONE wave
-constexpr uint32_t kGiantRun = 1024;         // longer runs are listed apart and started first: the longest run's walk is the critical path of the blend
+constexpr uint32_t kGiantRun = 1024;         // longer runs are listed apart (the giants): parted by stream index and ordered window by window
 
 __global__ __launch_bounds__(1024) void crowd_plan_kernel(const DepositParams p)
 {
@@ -1056,7 +1058,8 @@ __global__ __launch_bounds__(256) void crowd_scatter_kernel(const DepositParams 
     pages_forget(p, list, n, t, 256u);
 }
 
-// the texels of the long list (runs of more than kWaveRun fragments), a workgroup each
+// the giants that giant_part_kernel (below) left alone - more of one bucket of stream indices than a window holds - a
+// workgroup each: ordered in LDS at once (up to kCrowdCap fragments) or in windows of stream indices narrowed as it goes
 template <int MODE>
 __global__ __launch_bounds__(256) void crowd_blend_kernel(const DepositParams p, const uint32_t *list, const uint32_t *count)
 {
@@ -1699,9 +1702,10 @@ void launch_bins_regroup(const DepositParams &p, hipStream_t s)
     hipLaunchKernelGGL(crowd_scatter_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
 }
 
-// the runs a wave does not order (more than kWaveRun fragments), a workgroup each, the giants first: a run of ten thousand
-// fragments is walked by one thread for a few hundred microseconds - the caller puts this on a stream of its own beside
-// launch_bins_blend (disjoint texels), so that the walk overlaps with everything else instead of following it.
+// the giants (runs of more than kGiantRun fragments): parted, ordered window by window, walked - a run of ten thousand
+// fragments is applied one after the other for a few hundred microseconds: the caller puts this on a stream of its own beside
+// launch_bins_blend (disjoint texels), so that the walk overlaps with everything else instead of following it.  Last, the
+// runs giant_part_kernel left alone (more of one bucket than a window holds), a workgroup each.
 void launch_bins_blend_giants(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;

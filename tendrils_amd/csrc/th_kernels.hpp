@@ -163,7 +163,7 @@ struct DepositParams {
     uint32_t nlarge;
     uint32_t *crowd_count, *crowd_start, *crowd_cursor;   // per large bin: fragments per texel (256), first of every texel (257), fill cursors (256)
     unsigned long long *crowd_keys;                // per fragment of a large bin, grouped by texel: stream index << 32 | place of its varying
-    uint32_t *crowd_sorted;                        // ... and the places alone, every texel's run in blend order (crowd_blend_lanes_kernel)
+    uint32_t *crowd_sorted;                        // ... and the places alone, every texel's run in blend order (crowd_sort_kernel, long_sort_kernel, giant_sort_kernel)
     uint32_t *crowd_long, *crowd_giant;            // texels of large bins whose runs one wave does not order (large bin << 8 | texel): up to kGiantRun fragments / more
     unsigned long long *crowd_parted;              // the giants' keys parted by the leading bits of their stream indices (same positions as crowd_keys)
     uint32_t *crowd_giant_win;                     // per entry of crowd_giant: first window, windows (first = ~0: left to crowd_blend_kernel)
