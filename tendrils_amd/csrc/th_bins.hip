@@ -127,7 +127,6 @@ template <uint32_t N>                       // (a power of two)
 struct Reservations {
     uint32_t tag[N];                         // bin + 1 (0: free)
     uint32_t sum[N];                         // places reserved by the workgroup's lines; after the flush: the first of them
-    uint32_t any;
 };
 // n places of `bin` for the calling line -> entry << 20 | offset inside the workgroup's share
 template <uint32_t N>
@@ -173,6 +172,48 @@ TH_D uint32_t place_single(const DepositParams &p, uint32_t bin, uint32_t rep)
     return place_of<true>(p, bin * kBinReplicas + rep, v);
 }
 
+// all threads of a 1024-thread workgroup: `mine` -> its exclusive prefix over the workgroup; `total` (same on every thread)
+TH_D unsigned long long block_scan_1024(unsigned long long *lds, unsigned long long mine, unsigned long long &total)
+{
+    const uint32_t t = threadIdx.x;
+    __syncthreads();
+    lds[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const unsigned long long a = t >= off ? lds[t - off] : 0ull;
+        __syncthreads();
+        lds[t] += a;
+        __syncthreads();
+    }
+    total = lds[1023];
+    return lds[t] - mine;
+}
+
+// The blocks of 256 slots in which some slot's line can draw at all (a property of the slot order and the shape alone: found
+// once per order), in rising order.
+__global__ __launch_bounds__(256) void bins_block_flags_kernel(const DepositParams p, uint8_t *flags)
+{
+    __shared__ uint32_t any;
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    uint32_t col, row;
+    const bool can = s < p.W * p.rows && slot_particle(p, s, col, row);
+    if (threadIdx.x == 0u) any = 0u;
+    __syncthreads();
+    if (can && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(can)))) any = 1u;
+    __syncthreads();
+    if (threadIdx.x == 0u) flags[blockIdx.x] = (uint8_t)any;
+}
+__global__ __launch_bounds__(1024) void bins_block_list_kernel(const uint8_t *flags, uint32_t blocks, uint32_t *list, uint32_t *count)
+{
+    __shared__ unsigned long long lds[1024];
+    const uint32_t per = (blocks + 1023u) / 1024u, lo = threadIdx.x * per < blocks ? threadIdx.x * per : blocks, hi = lo + per < blocks ? lo + per : blocks;
+    unsigned long long n = 0, total = 0;
+    for (uint32_t b = lo; b < hi; ++b) n += flags[b];
+    uint32_t at = (uint32_t)block_scan_1024(lds, n, total);
+    for (uint32_t b = lo; b < hi; ++b) if (flags[b]) list[at++] = b;
+    if (threadIdx.x == 0u) *count = (uint32_t)total;
+}
+
 // pass 1.  Per slot: the line set up, classified, and - the common case: a small hexagon inside the view, all in registers -
 // rasterised into a record of <= kRecordTexels texels; its places reserved per bin, exactly; its fragments written.
 // a line's hexagon and its record while the wave's rows are dealt to its lanes (LDS, one per line of the workgroup)
@@ -193,22 +234,19 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     __shared__ Reservations<kTab> t;
     __shared__ LineStage stage[DEAL ? BS : 1u];
     __shared__ uint8_t owner[DEAL ? BS / 64u : 1u][DEAL ? 64u * kMaxRowsDealt : 1u];     // per wave: the line (lane) of every dealt row
-    const uint32_t slots = p.W * p.rows, blocks = (slots + BS - 1u) / BS;
-    // (the workgroups walk the blocks of 256 slots with the stride of the grid: a grid of a few workgroups per CU stays
-    // resident for the whole pass instead of 65 536 short-lived ones waiting to be dispatched)
-    for (uint32_t block = blockIdx.x; block < blocks; block += gridDim.x) {
+    const uint32_t slots = p.W * p.rows;
+    // In the tile-sorted order the particles whose lines can draw lie apart from the others inside every tile
+    // (th_kernels.hip: tile_key): most blocks of 256 slots meet only one kind - whole waves of lines that exist, or nothing to
+    // do.  The blocks with something to do are listed once per slot order (bins_block_list_kernel): half of all blocks never
+    // start.
+    for (uint32_t k = blockIdx.x; k < p.draw_nblocks; k += gridDim.x) {
+    const uint32_t block = p.draw_blocks[k];
     const uint32_t s = block * BS + threadIdx.x;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);
-    // In the tile-sorted order the particles whose lines can draw lie apart from the others inside every tile
-    // (th_kernels.hip: tile_key): most blocks meet only one kind - whole waves of lines that exist, or nothing to do.
     __syncthreads();                                    // (the block before is done with the table)
-    if (threadIdx.x == 0u) t.any = 0u;
     for (uint32_t e = threadIdx.x; e < kTab; e += BS) { t.tag[e] = 0u; t.sum[e] = 0u; }
     __syncthreads();
-    if (can && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(can)))) t.any = 1u;
-    __syncthreads();
-    if (t.any == 0u) continue;
 
     float4 own[2];                                      // (both ends of the line, before anything else)
     if (can) { own[0] = p.cur[s]; own[1] = p.prev[s]; }
@@ -1452,23 +1490,6 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
 //                          (a scan); page table and cursors
 //   owner_insert_kernel    (owner) a workgroup per bin: every source's fragments of the bin copied to their places
 
-// all threads of a 1024-thread workgroup: `mine` -> its exclusive prefix over the workgroup; `total` (same on every thread)
-TH_D unsigned long long block_scan_1024(unsigned long long *lds, unsigned long long mine, unsigned long long &total)
-{
-    const uint32_t t = threadIdx.x;
-    __syncthreads();
-    lds[t] = mine;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const unsigned long long a = t >= off ? lds[t - off] : 0ull;
-        __syncthreads();
-        lds[t] += a;
-        __syncthreads();
-    }
-    total = lds[1023];
-    return lds[t] - mine;
-}
-
 TH_D bool owner_mine(const OwnerParams &o, uint32_t b) { return b >= o.bin_lo[o.rank] && b < o.bin_lo[o.rank + 1u]; }
 
 // what leaves: the places of every bin of another owner (my own bins stay in my store)
@@ -1646,9 +1667,16 @@ __global__ __launch_bounds__(256) void owner_insert_kernel(const DepositParams p
 
 }  // namespace
 
-void launch_bins_fused(const DepositParams &p, hipStream_t s)
+void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, hipStream_t s)
 {
     const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
+    hipLaunchKernelGGL(bins_block_flags_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p, flags);
+    hipLaunchKernelGGL(bins_block_list_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)flags, blocks, list, count);
+}
+
+void launch_bins_fused(const DepositParams &p, hipStream_t s)
+{
+    const uint32_t blocks = p.draw_nblocks;
     (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
     (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
     // (one short workgroup per 256 slots.  Measured and not kept, profiles/r3_b_fused_pass_experiments.txt: a resident grid of

@@ -121,6 +121,11 @@ struct th_context {
     uint32_t *bin_mem = nullptr;
     uint32_t bin_capacity = 0;
     uint32_t *chunk_table = nullptr;     // per list x bin_max_pages: the pages a list has grown by
+    // the blocks of 256 slots with a line that can draw, for the slot order ring[0] is held in (th_bins.hip: bins_block_list_kernel)
+    uint32_t *draw_blocks = nullptr, draw_nblocks = 0;
+    uint8_t *draw_block_flags = nullptr;
+    int draw_blocks_order = -2;
+    unsigned long long draw_blocks_stamp = 0;
     uint32_t bin_max_pages = 0;          // (widened when a bin outgrows its lists: bins_table_widen)
     unsigned long long *bins_keys = nullptr;   // the page store: (bins x kBinReplicas + bins_pool) pages of kBinPage places - keys (~0 = empty) ...
     float4 *bins_colors = nullptr;       // ... and varyings (two per place once a th_draw has run)
@@ -184,6 +189,7 @@ struct th_context {
         th::TileGeom geom{};                 // key function the order was sorted with
         int32_t fw = 0, fh = 0;
         int refs = 0;                        // ring buffers stored in this order
+        unsigned long long stamp = 0;        // c->sorts when the order was laid out (what is cached per order - the draw's block list - knows it by this)
     };
     std::vector<SlotOrder> orders;
     std::vector<std::pair<float4 *, int>> buf_order;   // ring buffers held in a sorted order (absent = texel order)

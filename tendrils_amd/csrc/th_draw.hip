@@ -168,6 +168,20 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         p.large_key0 = p.large_bins + c->bin_capacity;
         p.page_table = c->chunk_table; p.max_pages = c->bin_max_pages;
         p.totals = c->dep_total;
+        // the blocks of slots with something to draw: listed once per slot order (one read-back per re-sort)
+        const unsigned long long stamp = o >= 0 ? c->orders[(size_t)o].stamp : 0ull;
+        if (!c->draw_blocks || c->draw_blocks_order != o || c->draw_blocks_stamp != stamp) {
+            const size_t blocks = (c->texels() + 255) / 256;
+            if (!c->draw_blocks) {
+                TH_HIP(hipMalloc((void **)&c->draw_blocks, (blocks + 1) * sizeof(uint32_t)));
+                TH_HIP(hipMalloc((void **)&c->draw_block_flags, blocks));
+            }
+            th::launch_bins_block_list(p, c->draw_block_flags, c->draw_blocks + 1, c->draw_blocks, c->stream);
+            TH_HIP(hipGetLastError());
+            if (th_status s = read_back(c, &c->draw_nblocks, c->draw_blocks, sizeof(uint32_t))) return s;
+            c->draw_blocks_order = o; c->draw_blocks_stamp = stamp;
+        }
+        p.draw_blocks = c->draw_blocks + 1; p.draw_nblocks = c->draw_nblocks;
     }
     return TH_OK;
 }

@@ -151,6 +151,8 @@ struct DepositParams {
     // fall into.  A bin is kBinReplicas lists of pages of kBinPage places: page 0 of list r of bin b is page
     // b * kBinReplicas + r, further pages come from a pool.
     const uint32_t *perm;
+    const uint32_t *draw_blocks;                   // the blocks of 256 slots that hold a line that can draw at all, in rising order (launch_bins_block_list)
+    uint32_t draw_nblocks;
     uint32_t bins_x, nbins;
     uint32_t *bin_cursor, bin_stride;              // per list (r * bin_stride + bin): places handed out so far (virtual indices inside the list)
     uint32_t *page_table;                          // per list x max_pages: page id of the list's n-th page, n >= 1 (0: not handed out yet)
@@ -253,6 +255,7 @@ constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits
 // totals[]: device words of one pass
 enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWindows = 8, kTotWords = 12 };
 enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
+void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, hipStream_t stream);   // list: a word per block of 256 slots
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
 void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hipStream_t stream);

@@ -183,6 +183,7 @@ th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, 
     TH_HIP(hipGetLastError());
     c->steps_since_sort = 0;
     ++c->sorts;
+    o.stamp = c->sorts;
     c->counted.buf = nullptr;
     if (params) *params = b;
     return TH_OK;

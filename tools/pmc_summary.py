@@ -1,7 +1,7 @@
 """Per-kernel averages of the counters of tools/gpu_pmc_draw.sh: python tools/pmc_summary.py gpurun_out/r3/pmc_TAG [name filter...]"""
 import csv, glob, sys, collections
 out = sys.argv[1]
-want = sys.argv[2:] or ["bins_", "crowd_", "deposit_", "radix_"]
+want = sys.argv[2:] or ["bins_", "crowd_", "giant_", "long_sort", "run_walk", "deposit_", "radix_"]
 dur, acc = {}, collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + '/*/*/*kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
