@@ -1461,7 +1461,12 @@ __global__ __launch_bounds__(64) void crowd_walk_kernel(const DepositParams p)
 {
     // four lanes per texel, a channel each (of the flow texel and / or of the view texel): 16 runs side by side per wave, every
     // run's chain a quarter as long as with a lane per texel doing all channels (the pass is bound by its longest chains)
-    const uint32_t lane = threadIdx.x, c = lane & 3u, i = blockIdx.x >> 4, lt = ((blockIdx.x & 15u) << 4) + (lane >> 2);
+    // The 16 waves of a bin on ONE XCD (workgroups go to the eight XCDs in turn: blockIdx.x % 8): the varyings of a bin's
+    // fragments lie in the order they arrived, four to a 128-byte line, and its texels' runs pick them out in blend order -
+    // with the bin's waves spread over all XCDs every L2 fetched most of the bin's lines for itself (3.4 x the bytes the
+    // fragments hold, and the kernel runs at the memory's rate: profiles/r4_g_giants.txt)
+    const uint32_t lane = threadIdx.x, c = lane & 3u, xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const uint32_t i = ((k >> 4) << 3) + xcd, lt = ((k & 15u) << 4) + (lane >> 2);
     if (i >= p.nlarge) return;
     const uint32_t r0 = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt], len = p.crowd_start[(size_t)i * (kBinTexels + 1u) + lt + 1u] - r0;
     if (len == 0u || len > kWaveRun) return;                  // (longer runs: crowd_blend_kernel, sources by the workgroup)
@@ -1767,9 +1772,10 @@ void launch_bins_blend_crowd(const DepositParams &p, hipStream_t s)
     // against 2.28 ms per crowded draw.)
     hipLaunchKernelGGL(crowd_sort_kernel, dim3(p.nlarge * (kBinTexels / 16u)), dim3(256), 0, s, p);
     // ... and walked by a lane of its own
-    if (p.mode == 0) hipLaunchKernelGGL(crowd_walk_kernel<0>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
-    else if (p.mode == 1) hipLaunchKernelGGL(crowd_walk_kernel<1>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(crowd_walk_kernel<2>, dim3(p.nlarge * 16u), dim3(64), 0, s, p);
+    const uint32_t walkers = ((p.nlarge + 7u) & ~7u) * 16u;       // (eight bins side by side, one per XCD)
+    if (p.mode == 0) hipLaunchKernelGGL(crowd_walk_kernel<0>, dim3(walkers), dim3(64), 0, s, p);
+    else if (p.mode == 1) hipLaunchKernelGGL(crowd_walk_kernel<1>, dim3(walkers), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(crowd_walk_kernel<2>, dim3(walkers), dim3(64), 0, s, p);
 }
 
 // the bins of up to kBinCap places, a workgroup each.  Needs nothing from the host: launched right behind launch_bins_fused,
