@@ -483,14 +483,17 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
     if (host[th::kTotCrowdKeys] == 0xffffffffu) return fail(TH_ERR_UNSUPPORTED, "too many fragments in crowded bins for one draw (2^32 or more places)");
     if (c->crowd_capacity < nlarge) {
         (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
-        const uint32_t cap = 2u * nlarge + 256;
+        const uint32_t cap = std::min(p.nbins, std::max(2u * nlarge + 256u, p.nbins / 4u));      // (a quarter of the bins at once: no growth step by step)
         TH_HIP(hipMalloc((void **)&c->crowd_mem, (size_t)cap * th::crowd_words_per_bin() * sizeof(uint32_t)));
         c->crowd_capacity = cap;
     }
     if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
         (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); (void)hipFree(c->crowd_parted); (void)hipFree(c->crowd_windows);
         c->crowd_keys = nullptr; c->crowd_sorted = nullptr; c->crowd_parted = nullptr; c->crowd_windows = nullptr; c->crowd_keys_cap = 0;
-        const size_t cap = 2 * (size_t)host[th::kTotCrowdKeys] + ((size_t)1 << 20);
+        // (room for every fragment of a pass like this one and a quarter more: the share of the crowded bins grows from a third
+        // to three quarters over the first hundred frames of a loop - sized by what it is now, the four buffers were freed and
+        // allocated again every few frames on the way, milliseconds each time)
+        const size_t cap = std::max(2 * (size_t)host[th::kTotCrowdKeys], (size_t)total + total / 4) + ((size_t)1 << 20);
         TH_HIP(hipMalloc((void **)&c->crowd_keys, cap * sizeof(unsigned long long)));
         TH_HIP(hipMalloc((void **)&c->crowd_sorted, cap * sizeof(uint32_t)));
         TH_HIP(hipMalloc((void **)&c->crowd_parted, cap * sizeof(unsigned long long)));
