@@ -52,6 +52,47 @@ def test_frame_loop_at_c3_size_bins_equal_stream():
     assert bits_equal(a[3], b[3]).all() and bits_equal(a[4], b[4]).all()
 
 
+def test_seven_hundred_frames_at_c3_bins_equal_stream():
+    """The loop bench.py and tools/deposit_bench.py time, run until the wake has drawn the particles together: after ~650 frames
+    a thousand texels of the 1920 x 1080 target receive runs of 1000-17 000 fragments per draw (the giants: parted by stream
+    index, ordered window by window, walked by a wave per target) and single bins more than half a million (their page tables
+    are widened on the way) - profiles/r4_g_giants.txt.  The default policy (tile-sorted slots, binned pipeline all the way)
+    against the stream-ordered pipeline in texel order: the fragments of every frame, and flow field, view buffer and
+    particles after the last, bit for bit - a single texel blended in another order anywhere on the way steers the particles
+    apart."""
+    import ctypes as C
+    from benchlib import workload
+    from tendrils_amd import _capi
+    n, frames = 4096, 700
+    workload.N = n
+    st = workload.synth_state(0)
+    outs = []
+    for pipeline in ("stream", "auto"):
+        t = make(n, (1920, 1080), pipeline)
+        t.particles.upload_texels(st)
+        t.timer.time = 1000.0
+        t.renderView = True
+        frags, used, crowd = [], set(), 0
+        info = _capi.DrawInfo()
+        for _ in range(frames):
+            t.timer.tick()
+            t.step()
+            t.draw()
+            frags.append(t.fragments)
+            _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
+            used.add(int(info.pipeline))
+            crowd = max(crowd, int(info.crowded_fragments))
+        outs.append((frags, t.flow.read(), t.read_view(), t.particles.read(0), used, crowd))
+        t.dispose()
+    a, b = outs
+    assert a[4] == {0} and b[4] == {1}                   # stream-ordered all the way / binned all the way
+    assert b[5] > 8_000_000                              # (most fragments in crowded bins)
+    assert a[0] == b[0] and min(a[0]) > 4_000_000
+    assert bits_equal(a[1], b[1]).all()
+    assert (a[2] == b[2]).all() and a[2].any()
+    assert bits_equal(a[3], b[3]).all()
+
+
 def test_loop_on_a_crowded_target_bins_equal_stream():
     """A million particles over a 160 x 90 target: every texel holds a run of dozens of fragments from the first frame on,
     hundreds and thousands (the long list, the giants, their windows) once the wake has pulled the particles together.  30
