@@ -142,7 +142,9 @@ struct th_context {
     hipEvent_t forked = nullptr, joined = nullptr;
     hipStream_t side2 = nullptr;               // ... and the crowded bins' short runs beside both
     hipEvent_t joined2 = nullptr, regrouped = nullptr;
-    uint32_t *bins_totals_host = nullptr;      // (pinned) the binned pass's totals, read back over the side stream
+    uint32_t *bins_totals_host = nullptr;      // (pinned, coherent; kTotWords + 1 words) the binned pass's totals, written by the plan's last kernel, and the sequence number behind them
+    uint32_t *bins_totals_dev = nullptr;       // ... as the device addresses it
+    uint32_t totals_seq = 0;
     bool mrg_pairs = false, x_pairs = false;   // the merge / exchange colour buffers hold two varyings per fragment (th_draw_emit / _merge)
     void *pinned = nullptr;                    // (pinned, kPinnedBytes) small read-backs: a pageable hipMemcpyAsync costs ~0.15 ms per call
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
@@ -265,7 +267,8 @@ th_status bins_store_for(th_context *c, th::DepositParams &p, uint32_t at_least)
 th_status bins_store_grow_keep(th_context *c, th::DepositParams &p, uint32_t pool);
 th_status bins_table_widen(th_context *c, th::DepositParams &p, bool keep);       // kRetryInStreamOrder: as wide as it goes (or no memory)
 th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early);
-th_status bins_pass_totals(th_context *c);
+void bins_pass_expect(th_context *c, th::DepositParams &p);          // before the plan's kernels are launched with p ...
+th_status bins_pass_totals(th_context *c, const th::DepositParams &p);  // ... their totals in c->bins_totals_host
 th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragments, bool blended_early);
 bool binned_shards(const th_context *c);              // a sharded draw() of this job goes through the bins (the same answer on every rank)
 th_status deposit_prepare_bins(th_context *c, const th_deposit_uniforms *u, th::DepositParams &p);

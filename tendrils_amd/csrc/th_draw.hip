@@ -1,6 +1,7 @@
 // th_draw.hip - Tendrils.draw() (src/index.js:278-337): the flow pass, the view pass, both in one call, the trail export;
 // which pipeline draws (binned over sorted slots, th_bins.hip / stream-ordered in texel order, th_deposit.hip + th_sort.hip).
 #include "th_ctx.hpp"
+#include <chrono>
 
 using namespace thi;
 
@@ -167,7 +168,7 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         p.bin_cursor = c->bin_mem; p.large_bins = c->bin_mem + (size_t)th::kBinReplicas * p.bin_stride;
         p.large_key0 = p.large_bins + c->bin_capacity;
         p.page_table = c->chunk_table; p.max_pages = c->bin_max_pages;
-        p.totals = c->dep_total;
+        p.totals = c->dep_total; p.totals_host = nullptr; p.totals_seq = 0;       // (bins_expect, before the plan's kernels go out)
         // the blocks of slots with something to draw: listed once per slot order (one read-back per re-sort)
         const unsigned long long stamp = o >= 0 ? c->orders[(size_t)o].stamp : 0ull;
         if (!c->draw_blocks || c->draw_blocks_order != o || c->draw_blocks_stamp != stamp) {
@@ -375,16 +376,38 @@ th_status bins_streams(th_context *c)
     TH_HIP(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     TH_HIP(hipEventCreateWithFlags(&c->joined2, hipEventDisableTiming));
     TH_HIP(hipEventCreateWithFlags(&c->regrouped, hipEventDisableTiming));
-    TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, th::kTotWords * sizeof(uint32_t), hipHostMallocDefault));
+    TH_HIP(hipHostMalloc((void **)&c->bins_totals_host, (th::kTotWords + 1) * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(c->bins_totals_host, 0, (th::kTotWords + 1) * sizeof(uint32_t));
+    TH_HIP(hipHostGetDevicePointer((void **)&c->bins_totals_dev, c->bins_totals_host, 0));
     return TH_OK;
 }
 
 // the pass's totals to the host over the side stream (behind `forked`, recorded by the caller on the main stream)
-static th_status bins_totals(th_context *c)
+// crowd_plan_kernel, the last kernel of a pass's plan, has been launched with p.totals_host / p.totals_seq (bins_expect): wait
+// for the sequence number to arrive behind the totals.  (Polled: the device writes host memory; a copy on the side stream had
+// to be scheduled behind an event, run and be signalled before the host woke up - 43 us in which nothing ran.)
+static void bins_expect(th_context *c, th::DepositParams &p)
 {
-    TH_HIP(hipStreamWaitEvent(c->side, c->forked, 0));
-    TH_HIP(hipMemcpyAsync(c->bins_totals_host, c->dep_total, th::kTotWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->side));
-    TH_HIP(hipStreamSynchronize(c->side));
+    p.totals_host = c->bins_totals_dev; p.totals_seq = ++c->totals_seq;
+    if (p.totals_seq == 0u) p.totals_seq = ++c->totals_seq;          // (0: what the word holds before the first pass)
+}
+static th_status bins_totals(th_context *c, const th::DepositParams &p)
+{
+    volatile uint32_t *seq = c->bins_totals_host + th::kTotWords;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != p.totals_seq; ++spins) {
+        if ((spins & 1023u) == 1023u) {
+            // a kernel that faulted never writes the word: ask the runtime now and then, give up after a long while
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail(TH_ERR_HIP, "the binned pass failed: %s", hipGetErrorString(e));
+            if (e == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != p.totals_seq) {
+                // (the stream is done and the word is not there: read the totals the slow way)
+                TH_HIP(hipMemcpy(c->bins_totals_host, c->dep_total, th::kTotWords * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                return TH_OK;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) return fail(TH_ERR_HIP, "the binned pass's totals did not arrive");
+        }
+    }
     return TH_OK;
 }
 
@@ -449,12 +472,13 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
     for (int attempt = 0;; ++attempt) {
         if (th_status s = bins_store_for(c, p, 0)) return s;
         if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
+        bins_expect(c, p);
         th::launch_bins_fused(p, c->stream);
         // the totals come back over the side stream while the ordinary bins are already being blended (the kernel looks at the
         // pass's flags itself): the host's round trip - it sizes the crowded bins' launches - costs the GPU nothing
         TH_HIP(hipEventRecord(c->forked, c->stream));
         if (blend_early) th::launch_bins_blend(p, c->stream);
-        if (th_status s = bins_totals(c)) return s;
+        if (th_status s = bins_totals(c, p)) return s;
         const uint32_t flags = host[th::kTotFlags];
         if (flags == 0) return TH_OK;
         // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
@@ -514,6 +538,9 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan: the ordinary bins' blend need not be waited for)
         th::launch_bins_regroup(p, c->side2);
         TH_HIP(hipEventRecord(c->regrouped, c->side2));
+        // (the ordinary bins' blend goes out as soon as the head of the longest chain has: behind all of the crowded bins'
+        // launches - fifteen of them - the main stream stood idle for 100 us)
+        if (!blended_early) { th::launch_bins_blend(p, c->stream); blended_early = true; }
         TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
         th::launch_bins_blend_giants(p, c->side);
         // ... and the runs in between behind them.  (A stream of their own shares a hardware queue with one of the others -
@@ -537,10 +564,11 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
 
 // (row-band shards, th_shard.hip) the received bins are in the store, laid out by launch_bins_owner_insert: the totals of its
 // plan to the host
-th_status bins_pass_totals(th_context *c)
+void bins_pass_expect(th_context *c, th::DepositParams &p) { bins_expect(c, p); }
+th_status bins_pass_totals(th_context *c, const th::DepositParams &p)
 {
     TH_HIP(hipEventRecord(c->forked, c->stream));
-    return bins_totals(c);
+    return bins_totals(c, p);
 }
 
 }  // namespace thi

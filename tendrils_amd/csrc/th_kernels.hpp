@@ -159,6 +159,7 @@ struct DepositParams {
     uint32_t max_pages;                            // pages one list can grow to in this pass (the host widens the table when a bin outgrew it)
     uint32_t pool_pages;                           // pages in the pool: ids nbins * kBinReplicas .. + pool_pages - 1
     uint32_t *totals;                              // device words (th_bins.hip: kTot*)
+    uint32_t *totals_host, totals_seq;             // (host memory the device writes) the totals once the plan is done, then totals_seq behind them: the host's poll ends
     unsigned long long *frag_keys;                 // per place, chunk-major: (y << 12 | x) << 32 | stream index of the line; ~0 = empty
     // ... bins of more places than one workgroup orders in LDS (crowd_*_kernel)
     uint32_t *large_bins, *large_key0;             // the large bins (in any order); first regrouped key of each (+ 1)

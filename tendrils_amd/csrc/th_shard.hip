@@ -416,9 +416,10 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     th_status laid = TH_OK;
     for (int attempt = 0;; ++attempt) {
         TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
+        bins_pass_expect(c, p);
         th::launch_bins_owner_insert(p, o, c->stream);
         TH_HIP(hipGetLastError());
-        if (th_status s = bins_pass_totals(c)) return s;
+        if (th_status s = bins_pass_totals(c, p)) return s;
         const uint32_t flags = host[th::kTotFlags];
         if (flags == 0) break;
         // (nothing has been blended; a bin beyond its lists' reach cannot be drawn through the bins at all)
