@@ -214,6 +214,15 @@ __global__ __launch_bounds__(1024) void bins_block_list_kernel(const uint8_t *fl
     if (threadIdx.x == 0u) *count = (uint32_t)total;
 }
 
+__global__ __launch_bounds__(256) void bins_zero_kernel(uint32_t *a, uint32_t na, uint32_t *b, uint32_t nb, uint32_t *c, uint32_t nc)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < na + nb + nc; i += gridDim.x * 256u) {
+        if (i < na) a[i] = 0u;
+        else if (i < na + nb) b[i - na] = 0u;
+        else c[i - na - nb] = 0u;
+    }
+}
+
 // pass 1.  Per slot: the line set up, classified, and - the common case: a small hexagon inside the view, all in registers -
 // rasterised into a record of <= kRecordTexels texels; its places reserved per bin, exactly; its fragments written.
 // a line's hexagon and its record while the wave's rows are dealt to its lanes (LDS, one per line of the workgroup)
@@ -1692,8 +1701,9 @@ void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *li
 void launch_bins_fused(const DepositParams &p, hipStream_t s)
 {
     const uint32_t blocks = p.draw_nblocks;
-    (void)hipMemsetAsync(p.list_n, 0, (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t), s);
-    (void)hipMemsetAsync(p.bin_cursor, 0, (size_t)kBinReplicas * p.bin_stride * sizeof(uint32_t), s);
+    // the pass's totals, the two lists' counters and the bins' cursors start from zero: one launch (three memsets are three
+    // launches with their gaps, between a step and a draw that wait for each other)
+    hipLaunchKernelGGL(bins_zero_kernel, dim3(128), dim3(256), 0, s, p.totals, kTotWords, p.list_n, 2u * kDepLists * kDepListStride, p.bin_cursor, kBinReplicas * p.bin_stride);
     // (one short workgroup per 256 slots.  Measured and not kept, profiles/r3_b_fused_pass_experiments.txt: a resident grid of
     // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
     // per SIMD instead of 4)

@@ -142,7 +142,7 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
     }
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
-    TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
+    if (!use_bins) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));      // (bins: launch_bins_fused)
     if (th_status s = line_rows(c)) return s;
     p.row_draws = c->d_row_draws;
     if (use_bins) {
@@ -471,7 +471,6 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
     uint32_t *host = c->bins_totals_host;
     for (int attempt = 0;; ++attempt) {
         if (th_status s = bins_store_for(c, p, 0)) return s;
-        if (attempt) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));
         bins_expect(c, p);
         th::launch_bins_fused(p, c->stream);
         // the totals come back over the side stream while the ordinary bins are already being blended (the kernel looks at the
