@@ -1463,14 +1463,24 @@ __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
     longest = max(longest, (uint32_t)__shfl_xor((int)longest, 32));
     if (longest == 0u) return;
     const size_t key0 = p.large_key0[i];
+    // (as many keys a lane as the longest run asks for: most runs of a crowded bin are a few dozen fragments long, and every key
+    // a lane holds is compared on every trip - four where one would do was three quarters of this kernel's arithmetic)
     if (longest <= 64u) {
-        lanes_rank_sort<16u, 4u>(p.crowd_keys + key0 + r0, p.crowd_sorted + key0 + r0, len, ids[wave] + sub * 64u, sl, longest);
+        const unsigned long long *run = p.crowd_keys + key0 + r0;
+        uint32_t *sorted = p.crowd_sorted + key0 + r0, *words = ids[wave] + sub * 64u;
+        if (longest <= 16u) lanes_rank_sort<16u, 1u>(run, sorted, len, words, sl, longest);
+        else if (longest <= 32u) lanes_rank_sort<16u, 2u>(run, sorted, len, words, sl, longest);
+        else lanes_rank_sort<16u, 4u>(run, sorted, len, words, sl, longest);
         return;
     }
     for (uint32_t q = 0; q < 4u; ++q) {
         const uint32_t qr0 = (uint32_t)__shfl((int)r0, (int)(q << 4)), qlen = (uint32_t)__shfl((int)len, (int)(q << 4));
         if (qlen == 0u) continue;
-        lanes_rank_sort<64u, 4u>(p.crowd_keys + key0 + qr0, p.crowd_sorted + key0 + qr0, qlen, ids[wave], lane, qlen);
+        const unsigned long long *run = p.crowd_keys + key0 + qr0;
+        uint32_t *sorted = p.crowd_sorted + key0 + qr0;
+        if (qlen <= 64u) lanes_rank_sort<64u, 1u>(run, sorted, qlen, ids[wave], lane, qlen);
+        else if (qlen <= 128u) lanes_rank_sort<64u, 2u>(run, sorted, qlen, ids[wave], lane, qlen);
+        else lanes_rank_sort<64u, 4u>(run, sorted, qlen, ids[wave], lane, qlen);
         __builtin_amdgcn_wave_barrier();                              // (everybody is done with the words before the next run's)
     }
 }
