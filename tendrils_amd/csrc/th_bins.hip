@@ -1206,11 +1206,12 @@ TH_D void wave_walk(const DepositParams &p, uint32_t texel, uint32_t len, BlendS
 // Once the wake of a long-running loop has drawn the particles together, single texels receive thousands and tens of
 // thousands of fragments per draw, and a thousand such texels at once.  Their runs are put in order in three steps, none of
 // which reads a key more than a fixed number of times:
-//   giant_part_kernel   a workgroup per run: its keys parted ONCE by the leading bits of their stream indices (1024 buckets:
-//                       histogram, scan, scatter into p.crowd_parted) and the buckets grouped into WINDOWS of up to
-//                       kGiantWindow keys - stream indices are distinct inside a texel and spread evenly, a bucket of a run
-//                       of 20 000 holds ~20.  (A run with a bucket larger than a window - particles with neighbouring ids
-//                       in one texel: a spawn - is left to crowd_blend_kernel, which narrows its windows as it goes.)
+//   giant_part_kernel   a workgroup per run: its keys parted ONCE by the leading bits of their stream indices (1024 buckets
+//                       over the range of indices the run holds: histogram, scan, scatter into p.crowd_parted) and the
+//                       buckets grouped into WINDOWS of up to kGiantWindow keys - stream indices are distinct inside a
+//                       texel; spread evenly, a bucket of a run of 20 000 holds ~20.  (A run with a bucket larger than a
+//                       window all the same - dense clusters of indices far apart - is left to crowd_blend_kernel, which
+//                       narrows its windows as it goes.)
 //   giant_sort_kernel   a workgroup per WINDOW, all windows of all runs side by side: ordered in LDS, the places of the
 //                       varyings written in blend order (p.crowd_sorted)
 //   run_walk_kernel     a wave per run and target: wave_walk over those places - what is left on the draw's critical path is the chain
@@ -1219,12 +1220,6 @@ TH_D void wave_walk(const DepositParams &p, uint32_t texel, uint32_t len, BlendS
 // window: a run of 17 000 fragments took 1.5 ms, profiles/r4_g_giants.txt.)
 constexpr uint32_t kGiantWindow = 2048;
 constexpr uint32_t kGiantFallback = 0xffffffffu;
-TH_D uint32_t giant_id_shift(const DepositParams &p)
-{
-    uint32_t id_bits = 1;                           // bits of a stream index: ceil(log2(W * H))
-    while (id_bits < 32u && (1ull << id_bits) < (unsigned long long)p.W * p.H) ++id_bits;
-    return id_bits > 10u ? id_bits - 10u : 0u;
-}
 struct GiantRun { uint32_t i, texel, r0, len; };
 TH_D GiantRun giant_run(const DepositParams &p, uint32_t entry)
 {
@@ -1241,16 +1236,16 @@ TH_D GiantRun giant_run(const DepositParams &p, uint32_t entry)
 
 __global__ __launch_bounds__(256) void giant_part_kernel(const DepositParams p)
 {
-    __shared__ uint32_t hist[1024], start[1025], wave_total[4], win[2];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, ngiant = p.totals[kTotGiant], shift = giant_id_shift(p);
+    __shared__ uint32_t hist[1024], start[1025], wave_total[4], win[2], span[2];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, ngiant = p.totals[kTotGiant];
     constexpr uint32_t kPer = 8;
     for (uint32_t e = blockIdx.x; e < ngiant; e += gridDim.x) {
         const GiantRun g = giant_run(p, p.crowd_giant[e]);
         const unsigned long long *run = p.crowd_keys + p.large_key0[g.i] + g.r0;
         unsigned long long *out = p.crowd_parted + p.large_key0[g.i] + g.r0;
         for (uint32_t k = t; k < 1024u; k += 256u) hist[k] = 0u;
+        if (t == 0u) { span[0] = 0xffffffffu; span[1] = 0u; }
         __syncthreads();
-        auto bucket = [&](unsigned long long k) { const uint32_t b = (uint32_t)(k >> 32) >> shift; return b < 1023u ? b : 1023u; };
         auto for_run = [&](auto body) {              // (a thread's loads of one round go out together)
             for (uint32_t f0 = 0; f0 < g.len; f0 += kPer * 256u) {
                 unsigned long long k[kPer];
@@ -1260,6 +1255,25 @@ __global__ __launch_bounds__(256) void giant_part_kernel(const DepositParams p)
                 for (uint32_t q = 0; q < kPer; ++q) if (f0 + q * 256u + t < g.len) body(k[q]);
             }
         };
+        // the buckets cover the stream indices the run HOLDS, not all there are: the particles of a spawn - neighbours in the
+        // state texture - stay together for a long time, and a thousand buckets over sixteen million indices put all of them
+        // into one (such runs are a tenth of a crowded frame's giants: they went the slow way, 30-40 us at the end of the
+        // giants' stream)
+        {
+            uint32_t lo = 0xffffffffu, hi = 0u;
+            for_run([&](unsigned long long k) { const uint32_t id = (uint32_t)(k >> 32); lo = id < lo ? id : lo; hi = id > hi ? id : hi; });
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, o), h2 = (uint32_t)__shfl_xor((int)hi, o);
+                lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+            }
+            if (lane == 0u) { atomicMin(&span[0], lo); atomicMax(&span[1], hi); }
+        }
+        __syncthreads();
+        const uint32_t id0 = span[0], width = span[1] - span[0];
+        uint32_t shift = 0;
+        while (shift < 32u && (width >> shift) >= 1024u) ++shift;
+        auto bucket = [&](unsigned long long k) { return ((uint32_t)(k >> 32) - id0) >> shift; };       // (< 1024)
         for_run([&](unsigned long long k) { atomicAdd(&hist[bucket(k)], 1u); });
         __syncthreads();
         // exclusive scan of the buckets (every thread its four), the largest bucket

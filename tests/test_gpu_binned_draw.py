@@ -218,11 +218,13 @@ def test_pool_growth_and_overfull_bins_exactly(oracle, monkeypatch):
 
 
 def test_giant_runs_whose_stream_indices_lie_side_by_side(oracle):
-    """A texel that receives thousands of fragments has its run parted by the leading bits of the stream indices, ordered window
-    by window and walked by a wave per target (th_bins.hip: giant_*_kernel) - the 1.2 M-line case above runs that way.  Here the
-    other way: the lines of NEIGHBOURING particles (columns 0-2 of a 4096 x 4096 state: stream indices 0..12287 - one bucket of
-    the 1024 that 2^24 indices are parted into - half of them rows that draw) all end in one texel - more of one bucket than a window holds, so the run is left to the workgroup that
-    narrows its windows as it goes (crowd_blend_kernel) - beside a run of the first kind in another texel."""
+    """A texel that receives thousands of fragments has its run parted by the leading bits of the stream indices it holds,
+    ordered window by window and walked by a wave per target (th_bins.hip: giant_*_kernel).  Three such texels of a
+    4096 x 4096 state's lines: 9000 particles from all over the state (indices spread over all sixteen million); the
+    NEIGHBOURS of columns 2000-2002 (12 288 indices in a row, half of them rows that draw: the buckets cover just that range);
+    and columns 0-2 together with columns 4000-4002 - two dense clusters sixteen million apart: a thousand buckets over that
+    range put each cluster into one, more than a window holds, and the run goes to the workgroup that narrows its windows as
+    it goes (crowd_blend_kernel)."""
     import ctypes as C
     import tendrils_amd as ta
     from tendrils_amd import _capi
@@ -231,18 +233,24 @@ def test_giant_runs_whose_stream_indices_lie_side_by_side(oracle):
     rng = np.random.default_rng(11)
     prev = np.zeros((n, n, 4), np.float32)
     prev[..., :2] = 5.0                                           # everybody else: outside the view
-    prev[:, :3, 0] = 0.296875 + rng.uniform(-5e-4, 5e-4, (n, 3))   # (the middle of a texel; lines a tenth of a texel long)
-    prev[:, :3, 1] = 0.17 + rng.uniform(-5e-4, 5e-4, (n, 3))
-    far = rng.choice(n * (n - 3), 9000, replace=False)            # ... and 9000 particles from all over the state in another texel
-    rows, cols = far % n, 3 + far // n
-    prev[rows, cols, 0] = -0.421875 + rng.uniform(-5e-4, 5e-4, far.size)
-    prev[rows, cols, 1] = -0.23 + rng.uniform(-5e-4, 5e-4, far.size)
+
+    def gather(rows, cols, x, y):                                 # (the middle of a texel; lines a tenth of a texel long)
+        prev[rows, cols, 0] = x + rng.uniform(-5e-4, 5e-4, np.broadcast(rows, cols).shape)
+        prev[rows, cols, 1] = y + rng.uniform(-5e-4, 5e-4, np.broadcast(rows, cols).shape)
+    every = np.arange(n)[:, None]
+    gather(every, np.array([0, 1, 2, 4000, 4001, 4002])[None, :], 0.296875, 0.17)
+    gather(every, np.array([2000, 2001, 2002])[None, :], 0.609375, -0.390625)
+    taken = np.zeros((n, n), bool)
+    taken[:, [0, 1, 2, 2000, 2001, 2002, 4000, 4001, 4002]] = True
+    free = np.flatnonzero(~taken.ravel())
+    far = rng.choice(free, 9000, replace=False)
+    gather(far // n, far % n, -0.421875, -0.23)
     prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
     cur = prev.copy()
     cur[..., :2] += rng.uniform(-1e-3, 1e-3, (n, n, 2)).astype(np.float32)
     base = np.zeros((view[1], view[0], 4), np.float32)
     want, frags = oracle.flow_deposit(cur, prev, base, 2500.0, view_size=(1.0, view[0] / view[1]))
-    assert frags > 10000 and np.count_nonzero(np.abs(want).sum(-1)) == 2         # two texels, more than four thousand fragments each
+    assert frags > 15000 and np.count_nonzero(np.abs(want).sum(-1)) == 3         # three texels, thousands of fragments each
     t = ta.Tendrils(View(*view))
     t.resize()
     t.setup(n)
@@ -257,7 +265,7 @@ def test_giant_runs_whose_stream_indices_lie_side_by_side(oracle):
     assert bits_equal(t.flow.read(), want).all()
     info = _capi.DrawInfo()
     _capi.call("th_draw_query", t.particles._ctx, C.byref(info))
-    assert info.pipeline == 1 and info.crowded_fragments == frags, (info.pipeline, info.crowded_fragments)     # (both bins are crowded ones)
+    assert info.pipeline == 1 and info.crowded_fragments == frags, (info.pipeline, info.crowded_fragments)     # (all three bins are crowded ones)
     t.dispose()
 
 
