@@ -122,7 +122,8 @@ def last_pipeline(t):
 @pytest.mark.parametrize("n,view,world,spread,sorted_slots,pool,pages", [(64, (96, 54), 2, 0.9, False, 0, 0), (128, (50, 27), 3, 0.9, True, 0, 0),
                                                                          (256, (96, 54), 4, 0.15, True, 0, 0), (256, (40, 200), 3, 0.9, False, 0, 0),
                                                                          (256, (96, 54), 2, 0.15, False, 8, 0), (256, (96, 54), 3, 0.3, True, 40, 0), (256, (96, 54), 4, 0.12, True, 8, 0),
-                                                                         (256, (96, 54), 3, 0.15, True, 8, 2), (256, (96, 54), 2, 0.3, False, 0, 4)])
+                                                                         (256, (96, 54), 3, 0.15, True, 8, 2), (256, (96, 54), 2, 0.3, False, 0, 4),
+                                                                         (1024, (160, 90), 2, 0.3, True, 0, 0)])
 def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, sorted_slots, pool, pages):
     """The sharded draw() through the binned pipeline (th_bins.hip: the bins travel to the ranks that own them): every rank
     rasterises into its own page store, whole bin rows change hands with their counts, the owner lays them out as if it had
@@ -132,7 +133,9 @@ def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, 
     pool of that many pages to start with - it runs dry in the emitting pass (repeated with a larger one) and again when the
     other ranks' fragments arrive (grown with the owner's own bins kept in it); pages: lists that can grow to that many pages
     at first - a bin outgrows them in the emitting pass (wider table, pass repeated) and again at its owner (widened with the
-    entries of the owner's own fragments kept)."""
+    entries of the owner's own fragments kept); a million particles over 160 x 90 texels at spread 0.3: texels of thousands of
+    fragments - the giants' kernels (parted, ordered window by window, walked by a wave per target) over bins that were put
+    together from two ranks' fragments."""
     from tendrils_amd import sharding
     cur, prev, base = inputs(n, view, 31 * n + world, spread)
     one = make(n, view, cur, prev, base)
