@@ -385,8 +385,9 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 // run-time indexed edges): one place at a time from the lists' cursors.  (Counting a line's fragments per bin first and
 // reserving them together - two rasterisations, one round trip - was slower: 115 against 92 us; the pass is bound by the
 // general rasteriser, not by its atomics.)
-TH_D void bins_slow_lines(const DepositParams &p, uint32_t block, uint32_t blocks)
+TH_D void bins_slow_lines(const DepositParams &p, uint32_t block, uint32_t blocks, float *polygons)
 {
+    LdsWords<256> words{polygons + threadIdx.x};          // (the clipped polygon: indexed at run time - in LDS, not in scratch memory)
     dep_list_work(p, kListSlow, [&](bool have, uint32_t s, uint32_t seg) {
         const uint32_t rep = seg & (kBinReplicas - 1u);
         if (have) {
@@ -397,7 +398,7 @@ TH_D void bins_slow_lines(const DepositParams &p, uint32_t block, uint32_t block
             const uint32_t id = col * p.H + p.row0 + row;
             dep_raster_line(p, L, [&](int x, int y) {
                 bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
-            });
+            }, words);
         }
     }, block, blocks);
 }
@@ -419,8 +420,39 @@ TH_D void bins_long_lines(const DepositParams &p, uint32_t block, uint32_t block
             dep_hexagon(p, L, cx, cy);                       // (inside and small: the fused pass said so)
             dep_snap_hexagon(p, cx, cy, PX, PY);
             dep_hexagon_is_small(PX, PY, ymin, ymax);
+            // Rasterised twice - the register rasteriser is cheap, a round trip to a list's cursor is not, and a fragment at a
+            // time a line of twenty fragments made twenty of them one after the other (this kernel stands between the fused
+            // pass and the plan, alone on the chip): first its fragments counted per bin (up to four bins - a line of ten
+            // texels meets no more; further ones take their places one by one), their places reserved together, then written.
+            uint32_t bin[4] = {kNoPlace, kNoPlace, kNoPlace, kNoPlace}, cnt[4] = {0u, 0u, 0u, 0u};
             dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) {
-                bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
+                const uint32_t b = bin_of(p, (uint32_t)x, (uint32_t)y);
+                bool placed = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!placed && (bin[j] == b || bin[j] == kNoPlace)) { bin[j] = b; ++cnt[j]; placed = true; }
+                }
+            });
+            uint32_t base[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) base[j] = cnt[j] ? atomicAdd(list_cursor(p, bin[j], rep), cnt[j]) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (cnt[j] == 0u) continue;
+                if (base[j] + cnt[j] < base[j]) { bins_flag(p, kBinsBinFull); cnt[j] = 0u; bin[j] = kNoPlace - 1u; }        // (nothing of it is written: the pass is repeated)
+                else if (((base[j] + cnt[j] - 1u) >> kPageShift) != (base[j] >> kPageShift) || (base[j] & (kBinPage - 1u)) == 0u)
+                    pages_open(p, bin[j] * kBinReplicas + rep, base[j], cnt[j]);
+            }
+            dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) {
+                const uint32_t b = bin_of(p, (uint32_t)x, (uint32_t)y);
+                uint32_t at = kNoPlace;
+                bool placed = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!placed && bin[j] == b) { at = place_of<true>(p, b * kBinReplicas + rep, base[j]++); placed = true; }
+                }
+                if (!placed) at = place_single(p, b, rep);
+                bins_put(p, L, id, at, x, y);
             });
         }
     }, block, blocks);
@@ -429,9 +461,10 @@ TH_D void bins_long_lines(const DepositParams &p, uint32_t block, uint32_t block
 // both lists in one launch, half of the grid each: two small grids that wait on their loads and atomics, side by side
 __global__ __launch_bounds__(256) void bins_listed_kernel(const DepositParams p)
 {
+    __shared__ float polygons[48 * 256];                  // (48 KB: three workgroups per CU - the grid is that large)
     const uint32_t half = gridDim.x >> 1;
     if (blockIdx.x < half) bins_long_lines(p, blockIdx.x, half);
-    else bins_slow_lines(p, blockIdx.x - half, half);
+    else bins_slow_lines(p, blockIdx.x - half, half, polygons);
 }
 
 // the places handed out in bin b (all its lists; saturated)
@@ -1733,7 +1766,7 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // per SIMD instead of 4)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
     hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 8u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 6u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }

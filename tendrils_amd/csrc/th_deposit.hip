@@ -68,13 +68,15 @@ __global__ __launch_bounds__(256) void deposit_raster_kernel(const DepositParams
 
 __global__ __launch_bounds__(256) void deposit_raster_slow_kernel(const DepositParams p)
 {
+    __shared__ float polygons[48 * 256];                  // (the clipped polygon, indexed at run time: LDS, not scratch memory)
+    LdsWords<256> words{polygons + threadIdx.x};
     dep_list_work(p, kListSlow, [&](bool have, uint32_t t, uint32_t seg) {
         LineRecord r{};
         if (have) {
             const uint32_t row = t / p.W, col = t - row * p.W;
             DepositLine L;
             dep_setup(p, col, p.row0 + row, L, (size_t)row * p.W + col);
-            dep_raster_line(p, L, [&](int x, int y) { rec_add(r, x, y); });
+            dep_raster_line(p, L, [&](int x, int y) { rec_add(r, x, y); }, words);
             p.count[t] = r.n;
             if (r.n) rec_store(p, t, r);
         }
@@ -134,6 +136,8 @@ __global__ __launch_bounds__(kPatchCols * 64) void deposit_emit_kernel(const Dep
 // ... and the lines of more fragments than a record holds, rasterised again
 __global__ __launch_bounds__(256) void deposit_emit_long_kernel(const DepositParams p)
 {
+    __shared__ float polygons[48 * 256];
+    LdsWords<256> words{polygons + threadIdx.x};
     dep_list_work(p, kListLong, [&](bool have, uint32_t t, uint32_t) {
         if (!have) return;
         const uint32_t row = t / p.W, col = t - row * p.W;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void deposit_emit_long_kernel(const DepositPar
         uint32_t at = p.offset[t];
         DepositLine L;
         dep_setup(p, col, p.row0 + row, L, (size_t)row * p.W + col);
-        dep_raster_line(p, L, [&](int x, int y) { dep_put(p, L, id, at, x, y); ++at; });
+        dep_raster_line(p, L, [&](int x, int y) { dep_put(p, L, id, at, x, y); ++at; }, words);
     });
 }
 

@@ -133,9 +133,23 @@ struct DepositLine {
     bool short32;              // snapped endpoints less than 2^14 sixteenths apart: the varying's integers fit 32 bits
     DepositVertex a, b;
     int sx[2], sy[2];          // snapped endpoints (1/16 texel, texel centres at multiples of 16)
-    int n;                     // polygon vertices after clipping
-    int PX[12], PY[12];
+    int n;                     // polygon vertices after clipping (the vertices: PolygonWords)
 };
+
+// The words a clipped polygon lives in while it is indexed at run time (the clipper's two vertex lists of up to 12 points, then
+// the snapped vertices in the second one's place): a column of a table in LDS - in a thread's own arrays they were scratch
+// memory, hundreds of nanoseconds per indexed access instead of tens (the lines that cross the view's edge are few, but a
+// kernel of them stands alone between two passes of a draw: th_bins.hip bins_listed_kernel 76 -> 54 us).
+template <int STRIDE>
+struct LdsWords {
+    float *column;             // word k of this thread's 48: column[k * STRIDE]
+    TH_D float &f(int k) const { return column[k * STRIDE]; }
+    TH_D int &i(int k) const { return reinterpret_cast<int *>(column)[k * STRIDE]; }
+};
+template <typename Words>
+struct PolygonX { Words &w; TH_D int operator[](int k) const { return w.i(24 + k); } };
+template <typename Words>
+struct PolygonY { Words &w; TH_D int operator[](int k) const { return w.i(36 + k); } };
 
 // everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
 TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const float4 *own = nullptr, bool colors = true)
@@ -211,11 +225,13 @@ TH_D void dep_snap_hexagon(const DepositParams &p, const float (&cx)[6], const f
 }
 
 // the hexagon clipped against the view volume (lines that cross the view's edge: the rare case, runtime-indexed arrays)
-TH_D void dep_clip_hexagon(const DepositParams &p, DepositLine &L, const float (&hx6)[6], const float (&hy6)[6])
+template <typename Words>
+TH_D void dep_clip_hexagon(const DepositParams &p, DepositLine &L, const float (&hx6)[6], const float (&hy6)[6], Words &w)
 {
     const float wx16 = 8.0f * (float)p.fw, wy16 = 8.0f * (float)p.fh;
     const float x0 = wx16 - 8.0f, y0 = wy16 - 8.0f;
-    float cx[12], cy[12], tx[12], ty[12];
+    struct At { Words &w; int first; TH_D float &operator[](int k) const { return w.f(first + k); } };
+    const At cx{w, 0}, cy{w, 12}, tx{w, 24}, ty{w, 36};
     for (int k = 0; k < 6; ++k) { cx[k] = hx6[k]; cy[k] = hy6[k]; }
     int n = 6;
     // Sutherland-Hodgman against left, right, top, bottom; intersection (dj*Vi - di*Vj) * (1/(dj - di)), inside vertex first
@@ -246,14 +262,14 @@ TH_D void dep_clip_hexagon(const DepositParams &p, DepositLine &L, const float (
     }
     if (n < 3) { L.draws = false; L.n = 0; return; }
     L.n = n;
-    for (int k = 0; k < n; ++k) { L.PX[k] = dep_snap(cx[k], wx16, x0); L.PY[k] = dep_snap(cy[k], wy16, y0); }
+    for (int k = 0; k < n; ++k) { w.i(24 + k) = dep_snap(cx[k], wx16, x0); w.i(36 + k) = dep_snap(cy[k], wy16, y0); }      // (PolygonX / PolygonY)
 }
 
 // scan conversion: calls emit(x, y) for every covered texel.  Edges going up in y set `left`, edges going down set
 // `right` (a later edge overwrites an earlier one on the same row, as in the captured rasteriser); texels
 // left <= x < right.  Rows are walked in windows so that arbitrarily long lines need no large arrays.
-template <int N, typename Emit>
-TH_D void dep_raster_poly(const DepositParams &p, const int *PX, const int *PY, int count, Emit emit)
+template <int N, typename VX, typename VY, typename Emit>
+TH_D void dep_raster_poly(const DepositParams &p, const VX &PX, const VY &PY, int count, Emit emit)
 {
     // N > 0: a polygon of exactly N vertices held in registers (loops unrolled, static indices); N == 0: `count` vertices
     const int nv = N > 0 ? N : count;
@@ -276,8 +292,8 @@ TH_D void dep_raster_poly(const DepositParams &p, const int *PX, const int *PY, 
             if constexpr (N == 6) {
                 // the six vertices stay in registers: the loop is not unrolled (six copies of its body cost 190 VGPRs),
                 // a vertex is picked with a chain of selects instead of an index
-                auto pick = [](const int *v, int i) { int r = v[0]; r = i == 1 ? v[1] : r; r = i == 2 ? v[2] : r; r = i == 3 ? v[3] : r;
-                                                      r = i == 4 ? v[4] : r; r = i == 5 ? v[5] : r; return r; };
+                auto pick = [](const auto &v, int i) { int r = v[0]; r = i == 1 ? v[1] : r; r = i == 2 ? v[2] : r; r = i == 3 ? v[3] : r;
+                                                       r = i == 4 ? v[4] : r; r = i == 5 ? v[5] : r; return r; };
                 Xa = pick(PX, k); Ya = pick(PY, k); Xb = pick(PX, kn); Yb = pick(PY, kn);
             } else { Xa = PX[k]; Ya = PY[k]; Xb = PX[kn]; Yb = PY[kn]; }
             if (Ya == Yb) continue;
@@ -442,9 +458,9 @@ TH_D void dep_hexagon_row_span(const DepositParams &p, const int (&PX)[6], const
     right = hr ? ceil_at(rx, ry, rdx, rdy) : 0;
 }
 
-// a line, whichever way it has to go: straight from its hexagon, or clipped first
-template <typename Emit>
-TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
+// a line, whichever way it has to go: straight from its hexagon, or clipped first (`words`: where the clipped polygon lives)
+template <typename Emit, typename Words>
+TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit, Words &words)
 {
     float cx[6], cy[6];
     const int where = dep_hexagon(p, L, cx, cy);
@@ -453,10 +469,11 @@ TH_D void dep_raster_line(const DepositParams &p, DepositLine &L, Emit emit)
         dep_snap_hexagon(p, cx, cy, PX, PY);
         dep_raster_poly<6>(p, PX, PY, 6, emit);
     } else if (where == kHexClip) {
-        dep_clip_hexagon(p, L, cx, cy);
-        if (L.draws) dep_raster_poly<0>(p, L.PX, L.PY, L.n, emit);
+        dep_clip_hexagon(p, L, cx, cy, words);
+        if (L.draws) dep_raster_poly<0>(p, PolygonX<Words>{words}, PolygonY<Words>{words}, L.n, emit);
     }
 }
+
 
 // the varying of line L at texel (x, y): linear along the snapped endpoints, extrapolated, unclamped.  dep_param: the
 // interpolation parameter (false: both endpoints snap to the same point, the first vertex's value is taken)
