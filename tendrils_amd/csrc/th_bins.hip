@@ -383,8 +383,8 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 
 // ... and the lines of the slow list (hexagons that cross the view's edge or need 64-bit edges: clipped, scan-converted with
 // run-time indexed edges): one place at a time from the lists' cursors.  (Counting a line's fragments per bin first and
-// reserving them together - two rasterisations, one round trip - was slower: 115 against 92 us; the pass is bound by the
-// general rasteriser, not by its atomics.)
+// reserving them together - two rasterisations, one round trip - was slower with the polygon in scratch memory, 115 against
+// 92 us, and is no faster with it in LDS, 58 against 54: the pass is bound by the general rasteriser, not by its atomics.)
 TH_D void bins_slow_lines(const DepositParams &p, uint32_t block, uint32_t blocks, float *polygons)
 {
     LdsWords<256> words{polygons + threadIdx.x};          // (the clipped polygon: indexed at run time - in LDS, not in scratch memory)
