@@ -257,8 +257,8 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     for (uint32_t e = threadIdx.x; e < kTab; e += BS) { t.tag[e] = 0u; t.sum[e] = 0u; }
     __syncthreads();
 
-    float4 own[2];                                      // (both ends of the line, before anything else)
-    if (can) { own[0] = p.cur[s]; own[1] = p.prev[s]; }
+    OwnTexels own;                                      // (both ends of the line, before anything else)
+    if (can) { own.have = true; own.cur = p.cur[s]; own.prev = p.prev[s]; }
     DepositLine L;
     L.draws = false;
     LineRecord r{};
@@ -322,6 +322,10 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
             r.n = q.n;
 #pragma unroll
             for (uint32_t k = 0; k < kRecordTexels; ++k) r.r[k] = q.rec[k];
+        } else {                                            // (the last phase reads every line's record from there)
+            LineStage &q = stage[threadIdx.x];
+#pragma unroll
+            for (uint32_t k = 0; k < kRecordTexels; ++k) q.rec[k] = r.r[k];
         }
     }
     const bool lengthy = r.n > kRecordTexels;                // more fragments than a record holds: the long list
@@ -364,19 +368,25 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
         const uint32_t ga1 = q.c1 ? page_of<true>(p, l1, pa1) : 0u, gb1 = (q.c1 && pb1 != pa1) ? page_of<true>(p, l1, pb1) : ga1;
         const uint32_t id = col * p.H + p.row0 + row;
         // (bins run on contexts whose every vertex reads the line's own particle: th_api.hip, lines_local)
-        dep_vertex_colors(p, L.a.from_cur ? own[0] : own[1], L.a);
-        dep_vertex_colors(p, L.b.from_cur ? own[0] : own[1], L.b);
+        // (the line's texels read again - from the caches - rather than kept through the reservations: the kernel is short of
+        // registers, and kept as an array they had gone to scratch memory)
+        const float4 again_cur = p.cur[s], again_prev = p.prev[s];
+        auto texel = [&](bool c) { return make_float4(c ? again_cur.x : again_prev.x, c ? again_cur.y : again_prev.y, c ? again_cur.z : again_prev.z, c ? again_cur.w : again_prev.w); };
+        dep_vertex_colors(p, texel(L.a.from_cur), L.a);
+        dep_vertex_colors(p, texel(L.b.from_cur), L.b);
+        // (one fragment at a time, the record read back from the line's own words of the stage: eight fragments' varyings side
+        // by side were the kernel's register peak)
         uint32_t i0 = 0, i1 = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kRecordTexels; ++k)
-            if (k < n) {
-                const uint32_t x = r.r[k] & 0xffffu, y = r.r[k] >> 16;
-                uint32_t at;
-                if (q.bin[k] == q.b0) { const uint32_t v = v0 + i0++, g = (v >> kPageShift) == pa0 ? ga0 : gb0; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
-                else if (q.bin[k] == q.b1) { const uint32_t v = v1 + i1++, g = (v >> kPageShift) == pa1 ? ga1 : gb1; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
-                else at = place_single(p, q.bin[k], rep);
-                bins_put(p, L, id, at, (int)x, (int)y);
-            }
+        const uint32_t *rec = stage[DEAL ? threadIdx.x : 0u].rec;
+#pragma unroll 1
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t xy = DEAL ? rec[k] : r.r[0], x = xy & 0xffffu, y = xy >> 16, b = bin_of(p, x, y);
+            uint32_t at;
+            if (b == q.b0) { const uint32_t v = v0 + i0++, g = (v >> kPageShift) == pa0 ? ga0 : gb0; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
+            else if (b == q.b1) { const uint32_t v = v1 + i1++, g = (v >> kPageShift) == pa1 ? ga1 : gb1; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
+            else at = place_single(p, b, rep);
+            bins_put(p, L, id, at, (int)x, (int)y);
+        }
     }
     }
 }

@@ -85,7 +85,11 @@ TH_D void dep_vertex_colors(const DepositParams &p, float4 t, DepositVertex &v)
     } else dep_render_color(p, t, v.uvx, v.uvy, v.c);
 }
 
-TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at, const float4 *own = nullptr, bool colors = true)
+// the line's own texel of both buffers, when the caller holds them already (by VALUE, and chosen between with a select of values:
+// handed over as a pointer to a two-element array they lived in scratch memory - 64 bytes written and read back per line of a
+// pass over sixteen million, a quarter of what the binned pass's first kernel wrote)
+struct OwnTexels { bool have = false; float4 cur{}, prev{}; };
+TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at, const OwnTexels own = OwnTexels{}, bool colors = true)
 {
     const int W = (int)p.W, H = (int)p.H;
     const float uvx = (float)((double)i * p.inv_x), uvy = (float)((double)j * p.inv_y);   // Float32Array of JS doubles
@@ -108,8 +112,10 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uin
         else *p.oob = 1u;
     }
     float4 t;
-    if (own && self) t = offset > 0.25f ? own[0] : own[1];
-    else t = *from;
+    if (own.have && self) {
+        const bool c = offset > 0.25f;
+        t = make_float4(c ? own.cur.x : own.prev.x, c ? own.cur.y : own.prev.y, c ? own.cur.z : own.prev.z, c ? own.cur.w : own.prev.w);
+    } else t = *from;
     DepositVertex v;
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
@@ -152,7 +158,7 @@ template <typename Words>
 struct PolygonY { Words &w; TH_D int operator[](int k) const { return w.i(36 + k); } };
 
 // everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
-TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const float4 *own = nullptr, bool colors = true)
+TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const OwnTexels own = OwnTexels{}, bool colors = true)
 {
     L.draws = false;
     L.short32 = false;
