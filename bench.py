@@ -75,7 +75,7 @@ sys.path.insert(0, ROOT)
 from benchlib import workload as W  # noqa: E402
 from benchlib.job import Job, median, repetition_block  # noqa: E402
 from benchlib.launcher import dry_run, self_launch  # noqa: E402
-from benchlib.legs import c4_leg, cpu_baseline, frame_loop  # noqa: E402
+from benchlib.legs import c4_leg, c5_leg, cpu_baseline, frame_loop, frame_loop_sharded  # noqa: E402
 from benchlib.pmc import measure_pmc, pmc_bytes  # noqa: E402,F401
 from benchlib.roofline import bind, roofline_entry  # noqa: E402
 from benchlib.workload import (BYTES_PER_PARTICLE_STEP, CONFIGS, HBM_PEAK_GBS, MAX_FUSED, synth_rows, synth_state)  # noqa: E402,F401
@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
     ap.add_argument("--no-frame-loop", action="store_true", help="skip the step() + draw() frame-loop leg")
     ap.add_argument("--no-c4", action="store_true", help="skip the config-4 leg (8192 x 8192 row-sharded, strong scaling) of a c3 run")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 leg (16384 x 16384 packed state row-sharded, strong scaling) of a c3 run")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check: gloo ranks stepping the CPU restatement")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # PMC child: launches of this length only
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
@@ -291,6 +292,12 @@ def main():
             line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
         except Exception as e:            # noqa: BLE001
             line["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if world > 1 and args.config == "c3" and not args.no_frame_loop:
+        # (collective: every rank runs it; a rank-local failure inside th_draw_sharded ends the draw on every rank - th_shard.hip)
+        try:
+            line["frame_loop_sharded"] = frame_loop_sharded(job)
+        except Exception as e:            # noqa: BLE001
+            line["frame_loop_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             line["cpu_baseline"] = cpu_baseline(t, width, min(rows, W.N))
@@ -308,6 +315,13 @@ def main():
             line["c4"] = c4_leg(args, rank, local_rank, world, dist)
         except Exception as e:            # noqa: BLE001
             line["c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if under_profiler and args.config == "c3" and not args.no_c5:
+        line["c5"] = {"skipped": "under a profiler: run without it (or --config c5) for the config-5 leg"}
+    elif args.config == "c3" and not args.no_c5 and not args.flow_size:
+        try:
+            line["c5"] = c5_leg(args, rank, local_rank, world, dist)
+        except Exception as e:            # noqa: BLE001
+            line["c5"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

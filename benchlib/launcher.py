@@ -109,9 +109,106 @@ def dry_run(args, rank, world):
             "rccl": {"world": world, "nranks_seen": state["red"]["particles"] / float(rows * n), "backend": "gloo",
                      "reductions_per_timed_repetition": state["reductions"]},
             "counters": state["red"]}
+    line["c5"] = dry_c5(args, rank, world, dist, O)
+    line["frame_loop_sharded"] = dry_frame_loop_sharded(rank, world, dist, O, state["band"], fl, row0, gheight)
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
+
+
+def dry_c5(args, rank, world, dist, O):
+    """(dry run) the config-5 leg's plumbing: ONE texture row-sharded over the ranks (strong scaling), the state kept in the
+    packed 8-byte form between steps - SNORM16 position over [-2, 2), fp16 velocity, as th_logic.hpp packs it (inert and NaN
+    codes aside: none occur here) -, counters reduced after every 4-step group."""
+    import torch
+    from tendrils_amd.sharding import reduce_counters, shard_rows
+    n, gheight = 32, 64
+    row0, rows = shard_rows(gheight, world, rank)
+    band = synth_rows(n, gheight, 4242)[row0:row0 + rows]            # (every rank generates the texture, keeps its band)
+    fl = np.zeros((27, 48, 4), np.float32)
+    fl[..., :2] = np.random.default_rng(6).uniform(-.01, .01, (27, 48, 2))
+    fl[..., 2] = 990.0
+
+    def pack(b):
+        return np.rint(np.clip(b[..., :2] * np.float32(16384.0), -32767, 32767)).astype(np.int16), b[..., 2:].astype(np.float16)
+
+    def unpack(q):
+        out = np.empty(q[0].shape[:2] + (4,), np.float32)
+        out[..., :2] = q[0].astype(np.float32) * np.float32(6.103515625e-05)
+        out[..., 2:] = q[1].astype(np.float32)
+        return out
+    ring, tm, red, reductions = pack(band), 1000.0, None, 0
+    dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        tm += 1000.0 / 60.0
+        u = O.logic_uniforms(n, gheight, tm, 1000.0 / 60.0, view_size=(1, 48 / 27))
+        ring = pack(O.logic_step(u, unpack(ring), fl, y0=row0))
+        if (k + 1) % 4 == 0 or k + 1 == args.steps:
+            b = unpack(ring)
+            sp = np.hypot(b[..., 2].astype(np.float64), b[..., 3].astype(np.float64))
+            red = reduce_counters(dist, dict(particles=rows * n, live=rows * n, nan=0, capped=0, respawned=0,
+                                             sum_speed=float(sp.sum()), max_speed=float(sp.max())))
+            reductions += 1
+    dist.barrier()
+    v = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    return {"dry_run": True, "value": n * gheight * args.steps / float(v[0]), "unit": "particle-steps/s", "scaling": "strong",
+            "n_gpus": world, "steps": args.steps, "particles": n * gheight, "particles_per_gpu": n * rows,
+            "rccl": {"world": world, "nranks_seen": red["particles"] / float(rows * n), "backend": "gloo", "reductions": reductions},
+            "roofline": {"bound": "hbm", "frac": None, "note": "dry run: nothing measured (16 B per particle-step on the GPU run)"}}
+
+
+def dry_frame_loop_sharded(rank, world, dist, O, band, fl, row0, gheight, frames=2):
+    """(dry run) the exchange of a row-band job's draw() over gloo: every rank steps its band, keys a fragment per particle in
+    view by the flow texel it lies in (owner << 56 | texel << 32 | global particle id - th::kOwnerShift), the counts and
+    then the keys travel to the texels' owners (all-to-all), the owner tallies them per texel, and the owned ranges are
+    gathered back to every rank - the collectives of th_draw_sharded's stream-ordered pass, with a count in place of the blend."""
+    import torch
+    from tendrils_amd.sharding import OWNER_SHIFT, TEXEL_MASK, owner_chunk, split_by_owner
+    n = band.shape[1]
+    fh, fw = fl.shape[:2]
+    texels = fw * fh
+    chunk = owner_chunk(texels, world)
+    tm, sent, recv, frags, walls = 2000.0, [], [], [], []
+    for _ in range(frames):
+        dist.barrier()
+        t0 = time.perf_counter()
+        tm += 1000.0 / 60.0
+        u = O.logic_uniforms(n, gheight, tm, 1000.0 / 60.0, view_size=(1, fw / fh))
+        band = O.logic_step(u, band, fl, y0=row0)
+        x, y = band[..., 0].astype(np.float64), band[..., 1].astype(np.float64) * (fw / fh)
+        inside = (np.abs(x) < 1) & (np.abs(y) < 1)
+        tx = np.clip(((x + 1) * 0.5 * fw).astype(np.int64), 0, fw - 1)[inside]
+        ty = np.clip(((y + 1) * 0.5 * fh).astype(np.int64), 0, fh - 1)[inside]
+        texel = ty * fw + tx
+        ids = (np.arange(band.shape[0] * n, dtype=np.int64).reshape(band.shape[:2]) + row0 * n)[inside]
+        owner = np.minimum(texel // chunk, world - 1)
+        order = np.lexsort((ids, owner))
+        keys = torch.from_numpy(((owner << OWNER_SHIFT) | (texel << 32) | ids)[order])
+        send = split_by_owner(keys, texels, world)
+        send_t, recv_t = torch.tensor(send, dtype=torch.int64), torch.empty(world, dtype=torch.int64)
+        dist.all_to_all_single(recv_t, send_t)
+        got = [int(c) for c in recv_t.tolist()]
+        mine = torch.empty(sum(got), dtype=torch.int64)
+        dist.all_to_all_single(mine, keys, got, send)
+        tally = np.zeros(chunk, np.int64)
+        np.add.at(tally, ((mine.numpy() >> 32) & TEXEL_MASK) - rank * chunk, 1)
+        parts = [torch.empty(chunk, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(tally))
+        whole = torch.cat(parts).numpy()
+        total = torch.tensor([int(inside.sum())], dtype=torch.int64)
+        dist.all_reduce(total)
+        assert int(whole.sum()) == int(total[0]), "fragments were lost or duplicated in the exchange"
+        dist.barrier()
+        walls.append(time.perf_counter() - t0)
+        sent.append(8 * (sum(send) - send[rank]) + 8 * chunk)
+        recv.append(8 * (sum(got) - got[rank]) + 8 * chunk * (world - 1))
+        frags.append(int(total[0]))
+    v = torch.tensor([float(np.median(walls)) * 1e3, float(np.median(sent)), float(np.median(recv))], dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    return {"dry_run": True, "frames": frames, "n_gpus": world, "wall_ms_per_frame": float(v[0]), "sent_bytes_per_draw": float(v[1]),
+            "received_bytes_per_draw": float(v[2]), "fragments_per_draw_all_ranks": float(np.mean(frags)), "pipeline": "stream (tallied, not blended)"}
 
 

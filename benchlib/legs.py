@@ -37,6 +37,96 @@ def c4_leg(args, rank, local_rank, world, dist):
 
 
 
+def c5_leg(args, rank, local_rank, world, dist):
+    """BASELINE.json config 5 beside the metric's own configuration: 16384 x 16384 particles in the packed 8-byte ring
+    (SNORM16 position + fp16 velocity: 16 B per particle-step) row-sharded over the ranks (strong scaling: 268 M particles in
+    all, whatever N), 16-step fused launches - th_step_n: a captured sequence where it does not fuse -, the trail / history
+    double-buffer being the two-buffer ring itself, counters reduced after every launch.  Carries its own roofline entry."""
+    from .roofline import bind, roofline_entry
+    job = Job(args, "c5", rank, local_rank, world, dist)
+    job.run(args.warmup)
+    job.preroll()
+    job.reductions = 0
+    reps = max(args.reps // 2, 3)
+    walls = job.timed_region(args.steps, reps)
+    reductions = job.reductions // reps
+    job.run_kernel_only(2 * job.launch_len, job.launch_len)
+    k_ms, k_n = job.timed_kernels(lambda: job.run_kernel_only(args.steps, job.launch_len))
+    walls = job.max_over_ranks(walls)
+    (kern_s,) = job.max_over_ranks([k_ms / 1e3])
+    stats = job.global_stats()
+    particles = job.particles_rank * world
+    mid = median(walls)
+    steps_per_launch = args.steps / max(int(k_n), 1)
+    e = roofline_entry(job, kern_s, steps_per_launch, None, W.BYTES_PER_PARTICLE_STEP // 2)
+    e = bind(e, False)          # (no counters in this leg: the algorithmic figure against the HBM peak, named as such)
+    e.update(kernel="logic_fused_packed_kernel" if steps_per_launch > 1 else "logic_packed_kernel", launches=int(k_n),
+             frac_is="algorithmic bytes (16 B per particle-step: 8 B packed texel read + 8 B written) per launch / mean launch "
+                     "duration / 8 TB/s - an equivalent bandwidth: a fused launch streams 24/n B per particle-step and is "
+                     "limited by VALU issue (DESIGN.md 5)")
+    out = {"value": particles * args.steps / mid, "unit": "particle-steps/s", "ms_per_step": mid / args.steps * 1e3,
+           "scaling": "strong", "n_gpus": world, "steps": args.steps, "particles": particles, "dtype": "f32 arithmetic on packed 8-B texels",
+           "particles_per_gpu": job.particles_rank, "repetitions": repetition_block(walls, args.steps),
+           "rccl": job.rccl_block(stats, reductions), "roofline": e,
+           "workload": (job.cfg["label"] % "packed 8-B (SNORM16 pos + fp16 vel)") + ", same flow and uniforms as the headline, fused "
+                       "launches of <= %d steps, statistics + counter all-reduce after every launch" % job.launch_len}
+    job.dispose()
+    return out
+
+
+def frame_loop_sharded(job, frames=12):
+    """The frame loop of a row-band job - timer.tick(); step(); draw() on every rank together - with the path's one real data
+    exchange inside: Tendrils.draw() of a band context is th_draw_sharded (the bins - or, on the fallback, the fragments - to
+    the ranks that own them over the library's communicator, then the all-gather of the owned rows of both targets).
+    Per frame, max over ranks: the band's step, the draw with its exchange, the payload bytes this rank sent / received, and
+    the loop against the wall clock between two barriers."""
+    import torch
+    from tendrils_amd import _capi
+    t, ctx, dist = job.t, job.ctx, job.dist
+    if job.comm is None:
+        return {"skipped": "the library's communicator is not up (%s): Tendrils.draw() of a band needs it" % (job.comm_fallback or "world 1")}
+    ms = C.c_float()
+
+    def timed(fn):
+        _capi.call("th_timer_start", ctx)
+        fn()
+        _capi.call("th_timer_stop", ctx, C.byref(ms))
+        return ms.value
+
+    st = synth_rows(job.width, job.rows, 777 + job.rank)
+    t.particles.upload_texels(st)
+    st = None
+    t.timer.time = 1000.0
+    info = _capi.DrawInfo()
+    for _ in range(3):
+        t.timer.tick(); t.step(); t.draw()
+    step_ms, draw_ms, sent, recv, frags, pipes = [], [], [], [], [], []
+    for _ in range(frames):
+        t.timer.tick()
+        step_ms.append(timed(t.step))
+        job.sync_all()
+        t0 = time.perf_counter()
+        t.draw()                                   # (th_draw_sharded ends with a stream synchronize: the wall clock is the draw)
+        draw_ms.append((time.perf_counter() - t0) * 1e3)
+        _capi.call("th_draw_query", ctx, C.byref(info))
+        sent.append(info.sent_bytes); recv.append(info.received_bytes); frags.append(t.fragments); pipes.append(info.pipeline)
+    job.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        t.timer.tick(); t.step(); t.draw()
+    job.sync_all()
+    wall = (time.perf_counter() - t0) / frames * 1e3
+    med = [float(np.median(step_ms)), float(np.median(draw_ms)), wall, float(np.median(sent)), float(np.median(recv))]
+    med = job.max_over_ranks(med)
+    total = torch.tensor([float(np.mean(frags))], dtype=torch.float64, device="cuda")
+    dist.all_reduce(total)
+    return {"frames": frames, "n_gpus": job.world, "step_ms": med[0], "draw_both_ms": med[1], "wall_ms_per_frame": med[2],
+            "sent_bytes_per_draw": med[3], "received_bytes_per_draw": med[4], "fragments_per_draw_all_ranks": float(total.item()),
+            "pipeline": "bins" if all(p == 1 for p in pipes) else ("stream" if not any(p == 1 for p in pipes) else "mixed"),
+            "note": "max over ranks of each rank's median; draw_both_ms against the wall clock around Tendrils.draw() (both passes, "
+                    "one exchange); bytes: th_draw_query (payload handed to / taken from the other ranks per draw)"}
+
+
 def frame_loop(t, ctx, state, frames=20):
     """SURVEY.md 8f-1/8f-2 beside the headline: the reference's frame loop - timer.tick(), step(), draw() - on the same
     particles: one single-step launch, the flow pass of draw() (the particle lines blended into the flow field in GL

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 13
+#define TH_ABI_VERSION 14
 
 typedef int32_t th_status;
 enum {
@@ -359,6 +359,21 @@ th_status th_draw(th_context *ctx, const th_deposit_uniforms *u, const th_render
 th_status th_view_fill(th_context *ctx, const float rgba[4]);
 th_status th_view_clear(th_context *ctx);                              /* gl.clear(COLOR_BUFFER_BIT), clear colour 0 */
 th_status th_view_download(th_context *ctx, uint8_t *rgba8);           /* flow-shape RGBA8, row-major */
+/* Tendrils.buffers (src/index.js:66-68 `numBuffers`, 172-184 setupBuffers, 359-391 drawBuffer / copyBuffer / stepBuffers): a
+ * ring of off-screen RGBA8 view images of the drawing buffer's shape beside the screen image.  Every view entry point above
+ * and below (th_view_draw, the view pass of th_draw / th_draw_sharded, th_view_fill / _clear / _download / _device_ptr) works
+ * on the BOUND image: the screen unless th_view_bind chose a buffer - Tendrils.draw() binds buffers[0] when there is one
+ * (src/index.js:318-325), drawBuffer() the screen.  A buffer keeps being bound when the ring rotates under it (GL binds the
+ * object, not the position); a bound buffer that th_view_buffers removes leaves the screen bound.  A resize empties them all.
+ *   th_view_buffers       setupBuffers(count): buffers added (transparent black) or removed at the ring's end
+ *   th_view_bind          gl.bindFramebuffer: index -1 = the screen, k = buffers[k] as the ring stands now
+ *   th_view_copy          copyBuffer(index): buffers[index] through copy.frag - texel for texel - blended SRC_ALPHA /
+ *                         ONE_MINUS_SRC_ALPHA into the bound image; an index beyond the ring does nothing, as there
+ *   th_view_step_buffers  stepBuffers(): buffers.unshift(buffers.pop()) when there are two or more */
+th_status th_view_buffers(th_context *ctx, int32_t count);
+th_status th_view_bind(th_context *ctx, int32_t index);
+th_status th_view_copy(th_context *ctx, int32_t index);
+th_status th_view_step_buffers(th_context *ctx);
 /* tendrils.colorMap (src/index.js:94-96: a 1x1 float FBO unless given): RGBA32F, NEAREST, CLAMP_TO_EDGE */
 th_status th_colormap_upload(th_context *ctx, const float *rgba, int32_t w, int32_t h);
 /* th_export_lines with the view pass's vertex colours in place of the flow varyings */
@@ -411,6 +426,9 @@ typedef struct th_draw_info {
     int32_t pipeline;            /* TH_DRAW_STREAM / TH_DRAW_BINS */
     int32_t reserved;
     uint64_t fragments, crowded_fragments;
+    uint64_t sent_bytes, received_bytes;   /* th_draw_sharded: the payload this rank gave to / took from the other ranks in the whole
+                                            * call - edge rows, counts, fragments (or bins) for other owners, the owned ranges of the
+                                            * target(s), each counted once; 0 after a local draw and in a world of one */
 } th_draw_info;
 th_status th_draw_query(th_context *ctx, th_draw_info *out);
 

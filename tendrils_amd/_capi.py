@@ -90,7 +90,8 @@ class SlotOrderInfo(C.Structure):
 
 
 class DrawInfo(C.Structure):
-    _fields_ = [("pipeline", C.c_int32), ("reserved", C.c_int32), ("fragments", C.c_uint64), ("crowded_fragments", C.c_uint64)]
+    _fields_ = [("pipeline", C.c_int32), ("reserved", C.c_int32), ("fragments", C.c_uint64), ("crowded_fragments", C.c_uint64),
+                ("sent_bytes", C.c_uint64), ("received_bytes", C.c_uint64)]
 
 
 class CommInfo(C.Structure):
@@ -179,6 +180,10 @@ PROTOTYPES = {
     "th_view_fill": (C.c_int32, [_ctx, _fp]),
     "th_view_clear": (C.c_int32, [_ctx]),
     "th_view_download": (C.c_int32, [_ctx, C.POINTER(C.c_uint8)]),
+    "th_view_buffers": (C.c_int32, [_ctx, C.c_int32]),
+    "th_view_bind": (C.c_int32, [_ctx, C.c_int32]),
+    "th_view_copy": (C.c_int32, [_ctx, C.c_int32]),
+    "th_view_step_buffers": (C.c_int32, [_ctx]),
     "th_colormap_upload": (C.c_int32, [_ctx, _fp, C.c_int32, C.c_int32]),
     "th_export_view_lines": (C.c_int32, [_ctx, C.POINTER(RenderUniforms), _fp, C.c_uint64, C.POINTER(C.c_uint64)]),
 }

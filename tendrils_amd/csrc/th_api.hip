@@ -272,7 +272,8 @@ th_status th_destroy(th_context *c)
     for (unsigned long long *q : c->dep_u64) (void)hipFree(q);
     (void)hipFree(c->dep_colors_sorted); (void)hipFree(c->mrg_keys); (void)hipFree(c->mrg_vals[0]); (void)hipFree(c->mrg_vals[1]);
     (void)hipFree(c->dep_colors); (void)hipFree(c->dep_temp);
-    (void)hipFree(c->image); (void)hipFree(c->view); (void)hipFree(c->colormap);
+    (void)hipFree(c->image); (void)hipFree(c->view_screen); (void)hipFree(c->colormap);
+    for (uchar4 *b : c->view_ring) (void)hipFree(b);
     (void)hipFree(c->d_flag); (void)hipFree(c->partials); (void)hipFree(c->fused_parts); (void)hipFree(c->d_counters); (void)hipFree(c->d_respawned);
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);

@@ -127,6 +127,8 @@ struct th_context {
     int draw_blocks_order = -2;
     unsigned long long draw_blocks_stamp = 0;
     uint32_t bin_max_pages = 0;          // (widened when a bin outgrows its lists: bins_table_widen)
+    bool bins_dirty = false;             // an emitting pass filled the store and no blend has emptied it since (a sharded draw that ended
+                                         // between the two): the next emitting pass wipes it first
     unsigned long long *bins_keys = nullptr;   // the page store: (bins x kBinReplicas + bins_pool) pages of kBinPage places - keys (~0 = empty) ...
     float4 *bins_colors = nullptr;       // ... and varyings (two per place once a th_draw has run)
     uint32_t bins_pool = 0, bins_store_bins = 0;
@@ -167,8 +169,12 @@ struct th_context {
     float4 *dep_colors = nullptr;
     void *dep_temp = nullptr;
     size_t dep_lines = 0, dep_capacity = 0, dep_temp_bytes = 0;
-    uchar4 *view = nullptr;              // the view pass's RGBA8 drawing buffer (flow shape), lazily allocated
+    uchar4 *view = nullptr;              // the BOUND view image (RGBA8, flow shape): what the view pass, fills, clears and read-backs touch
     int32_t view_w = 0, view_h = 0;
+    uchar4 *view_screen = nullptr;       // the drawing buffer (bound unless th_view_bind chose a buffer), lazily allocated
+    std::vector<uchar4 *> view_ring;     // Tendrils.buffers (src/index.js:172-184): off-screen view images, in ring order
+    int32_t view_buffers = 0;            // how many the host asked for (th_view_buffers)
+    int32_t view_bound = -1;             // ring position of the bound image when it was bound; -1: the screen (the pointer `view` is what counts)
     float4 *colormap = nullptr;          // tendrils.colorMap (nullptr = the 1x1 zero texture)
     int32_t cmap_w = 0, cmap_h = 0;
     float4 *image = nullptr;             // PixelSpawner's own buffer (TH_SOURCE_IMAGE)

@@ -317,6 +317,19 @@ __global__ __launch_bounds__(256) void view_fill_kernel(uchar4 *view, size_t n, 
     }
 }
 
+// Tendrils.copyBuffer (src/index.js:370-383, src/screen/copy.frag): a full-screen quad textured with a view buffer of the
+// target's own shape - gl_FragCoord.xy / viewRes samples every texel at its centre - blended like everything else.
+// (dst == src: every texel over itself.)
+__global__ __launch_bounds__(256) void view_copy_kernel(uchar4 *view, const uchar4 *src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uchar4 s = src[i];
+        uchar4 d = view[i];
+        dep_blend_rgba8(d, make_float4((float)s.x / 255.0f, (float)s.y / 255.0f, (float)s.z / 255.0f, (float)s.w / 255.0f));
+        view[i] = d;
+    }
+}
+
 __global__ __launch_bounds__(256) void deposit_gather_colors_kernel(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n)
 {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[index[i]];
@@ -683,6 +696,11 @@ void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t s)
                                         TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, 1u, total, (uint32_t *)nullptr);
     else hipLaunchKernelGGL((deposit_blend_kernel<ViewTarget, TexelKeys>), grid, dim3(256), 0, s, p.view,
                             TexelKeys{p.keys_sorted}, (const float4 *)p.colors_sorted, 1u, total, (uint32_t *)nullptr);
+}
+
+void launch_view_copy(uchar4 *view, const uchar4 *src, size_t texels, hipStream_t s)
+{
+    if (texels) hipLaunchKernelGGL(view_copy_kernel, dim3(deposit_grid((uint32_t)(texels < 0xffffffffull ? texels : 0xffffffffull))), dim3(256), 0, s, view, src, texels);
 }
 
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t s)

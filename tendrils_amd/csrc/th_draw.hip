@@ -246,15 +246,34 @@ th_status deposit_temp(th_context *c, size_t need)
 }
 
 // ---- view pass ---------------------------------------------------------------------------------------------
+// The screen image and Tendrils.buffers at the target's shape (Tendrils.resize gives every buffer viewRes, src/index.js:404:
+// a resized FBO starts empty); c->view = the bound one.
 th_status view_storage(th_context *c)
 {
-    if (c->view && c->view_w == c->fw && c->view_h == c->fh) return TH_OK;
+    const bool shaped = c->view_w == c->fw && c->view_h == c->fh;
+    if (c->view && shaped && (int32_t)c->view_ring.size() == c->view_buffers) return TH_OK;
+    const size_t bytes = (size_t)c->fw * c->fh * sizeof(uchar4);
+    auto fresh = [&](uchar4 **img) -> th_status {
+        TH_HIP(hipMalloc((void **)img, bytes));
+        TH_HIP(hipMemsetAsync(*img, 0, bytes, c->stream));       // a fresh drawing buffer is transparent black
+        return TH_OK;
+    };
+    const uchar4 *was = c->view;
+    int32_t bound = was && was != c->view_screen ? -2 : -1;      // (-2: a buffer that may be gone in a moment)
+    for (size_t k = 0; k < c->view_ring.size(); ++k) if (c->view_ring[k] == was) bound = (int32_t)k;
     TH_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->view);
-    c->view = nullptr; c->view_w = c->view_h = 0;
-    TH_HIP(hipMalloc((void **)&c->view, (size_t)c->fw * c->fh * sizeof(uchar4)));
-    TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->fw * c->fh * sizeof(uchar4), c->stream));     // a fresh drawing buffer is transparent black
+    c->view = nullptr;
+    if (!shaped) {
+        (void)hipFree(c->view_screen); c->view_screen = nullptr;
+        for (uchar4 *&b : c->view_ring) { (void)hipFree(b); b = nullptr; }
+        c->view_w = c->view_h = 0;
+    }
+    while ((int32_t)c->view_ring.size() > c->view_buffers) { (void)hipFree(c->view_ring.back()); c->view_ring.pop_back(); }
+    while ((int32_t)c->view_ring.size() < c->view_buffers) c->view_ring.push_back(nullptr);
+    if (!c->view_screen) if (th_status s = fresh(&c->view_screen)) return s;
+    for (uchar4 *&b : c->view_ring) if (!b) if (th_status s = fresh(&b)) return s;
     c->view_w = c->fw; c->view_h = c->fh;
+    c->view = bound >= 0 && bound < (int32_t)c->view_ring.size() ? c->view_ring[(size_t)bound] : c->view_screen;   // (a bound buffer that was removed: the screen)
     return TH_OK;
 }
 
@@ -469,6 +488,14 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
     c->drawn.valid = false;
     if (th_status s = bins_streams(c)) return s;
     uint32_t *host = c->bins_totals_host;
+    // A pass that emitted and was never blended (th_shard.hip: a peer gave up or failed after this rank's own emit had
+    // succeeded) left keys in its places and page ids in its lists' tables: a page id found there before this pass publishes
+    // its own would send fragments to pages another list owns now, and stale keys would blend as fragments nobody drew.
+    if (c->bins_dirty) {
+        if (c->bins_keys) TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
+        if (c->chunk_table) TH_HIP(hipMemsetAsync(c->chunk_table, 0, (size_t)c->bin_capacity * th::kBinReplicas * c->bin_max_pages * sizeof(uint32_t), c->stream));
+        c->bins_dirty = false;
+    }
     for (int attempt = 0;; ++attempt) {
         if (th_status s = bins_store_for(c, p, 0)) return s;
         bins_expect(c, p);
@@ -479,7 +506,7 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
         if (blend_early) th::launch_bins_blend(p, c->stream);
         if (th_status s = bins_totals(c, p)) return s;
         const uint32_t flags = host[th::kTotFlags];
-        if (flags == 0) return TH_OK;
+        if (flags == 0) { c->bins_dirty = true; return TH_OK; }        // (until bins_pass_finish has sent the blends after it)
         // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
         // outgrew its chunk table or a line its reservation, left to the stream-ordered pipeline
         TH_HIP(hipMemsetAsync(c->bins_keys, 0xff, ((size_t)c->bins_store_bins * th::kBinReplicas + c->bins_pool) * th::kBinPage * sizeof(unsigned long long), c->stream));
@@ -558,6 +585,7 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0));
     }
     TH_HIP(hipGetLastError());
+    c->bins_dirty = false;          // (every reader of a list leaves its places and its table entries empty)
     return TH_OK;
 }
 
@@ -597,6 +625,7 @@ th_status th_export_lines(th_context *c, const th_deposit_uniforms *u, float *li
 th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t *fragments)
 {
     if (th_status s = use(c)) return s;
+    c->last_draw.sent_bytes = c->last_draw.received_bytes = 0;      // (a local draw moves nothing between ranks)
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "flow deposit on a row-band shard (%d of %d rows): use th_deposit_emit / th_deposit_merge with the exchange of tendrils_amd/sharding.py", c->cfg.height, c->cfg.global_height);
     for (int pass = 0;; ++pass) {            // (a binned pass that gives up before blending is repeated in stream order)
@@ -618,6 +647,7 @@ th_status th_flow_deposit(th_context *c, const th_deposit_uniforms *u, uint64_t 
 th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_uniforms *ru, uint64_t *fragments)
 {
     if (th_status s = use(c)) return s;
+    c->last_draw.sent_bytes = c->last_draw.received_bytes = 0;      // (a local draw moves nothing between ranks)
     TH_REQUIRE(du && ru, "null uniforms");
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "draw on a row-band shard (%d of %d rows): the passes go through th_deposit_emit / th_deposit_merge and th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
@@ -646,6 +676,7 @@ th_status th_draw(th_context *c, const th_deposit_uniforms *du, const th_render_
 th_status th_view_draw(th_context *c, const th_render_uniforms *u, uint64_t *fragments)
 {
     if (th_status s = use(c, true)) return s;
+    c->last_draw.sent_bytes = c->last_draw.received_bytes = 0;      // (a local draw moves nothing between ranks)
     if (c->cfg.height != c->cfg.global_height)
         return fail(TH_ERR_UNSUPPORTED, "view pass on a row-band shard (%d of %d rows): use th_view_emit / th_view_merge with the owners' exchange in between", c->cfg.height, c->cfg.global_height);
     if (th_status s = view_storage(c)) return s;
@@ -676,6 +707,47 @@ th_status th_view_clear(th_context *c)
     if (th_status s = use(c, true)) return s;
     if (th_status s = view_storage(c)) return s;
     TH_HIP(hipMemsetAsync(c->view, 0, (size_t)c->view_w * c->view_h * sizeof(uchar4), c->stream));
+    return TH_OK;
+}
+
+// Tendrils.buffers (src/index.js:172-184, 359-391)
+th_status th_view_buffers(th_context *c, int32_t count)
+{
+    if (th_status s = use(c, true)) return s;
+    TH_REQUIRE(count >= 0 && count <= 64, "bad number of view buffers %d", count);
+    c->view_buffers = count;
+    return view_storage(c);
+}
+
+th_status th_view_bind(th_context *c, int32_t index)
+{
+    if (th_status s = use(c, true)) return s;
+    if (th_status s = view_storage(c)) return s;
+    TH_REQUIRE(index >= -1 && index < (int32_t)c->view_ring.size(), "no view buffer %d (there are %zu)", index, c->view_ring.size());
+    c->view = index < 0 ? c->view_screen : c->view_ring[(size_t)index];
+    c->view_bound = index;
+    return TH_OK;
+}
+
+th_status th_view_copy(th_context *c, int32_t index)
+{
+    if (th_status s = use(c, true)) return s;
+    if (th_status s = view_storage(c)) return s;
+    if (index < 0 || index >= (int32_t)c->view_ring.size()) return TH_OK;       // src/index.js:371: `if(index < this.buffers.length)`
+    th::launch_view_copy(c->view, c->view_ring[(size_t)index], (size_t)c->view_w * c->view_h, c->stream);
+    TH_HIP(hipGetLastError());
+    return TH_OK;
+}
+
+th_status th_view_step_buffers(th_context *c)
+{
+    if (th_status s = use(c, true)) return s;
+    if (th_status s = view_storage(c)) return s;
+    if (c->view_ring.size() > 1) {               // src/utils/index.js:1-7: array.unshift(array.pop())
+        uchar4 *last = c->view_ring.back();
+        c->view_ring.pop_back();
+        c->view_ring.insert(c->view_ring.begin(), last);
+    }
     return TH_OK;
 }
 

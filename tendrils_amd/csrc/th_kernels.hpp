@@ -245,6 +245,7 @@ void launch_triangles(const float *positions, int ntri, float view_x, float view
                       float4 *img, int w, int h, hipStream_t stream);
 void launch_deposit_blend(const DepositParams &p, uint32_t total, hipStream_t stream);
 void launch_view_fill(uchar4 *view, size_t texels, float4 color, hipStream_t stream);
+void launch_view_copy(uchar4 *view, const uchar4 *src, size_t texels, hipStream_t stream);
 // binned pipeline (th_bins.hip)
 constexpr int kBinShift = 4;                       // 16 x 16 texel bins
 constexpr uint32_t kBinCap = 4096;                 // places of a bin that one workgroup orders in LDS

@@ -325,6 +325,27 @@ napi_value ViewClear(napi_env env, napi_callback_info info)
     return undefined(env);
 }
 
+// Tendrils.buffers: viewBuffers(ctx, count), viewBind(ctx, index | -1), viewCopy(ctx, index), viewStepBuffers(ctx)
+template <th_status (*FN)(th_context *, int32_t)>
+napi_value ViewIndexed(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    int32_t k = a.i32(1);
+    if (!a.ok) BAD_ARGS("th_view_buffers / th_view_bind / th_view_copy");
+    TH_CALL("th_view_buffers / th_view_bind / th_view_copy", FN(c, k));
+    return undefined(env);
+}
+
+napi_value ViewStepBuffers(napi_env env, napi_callback_info info)
+{
+    Args a(env, info);
+    th_context *c = a.ctx(0);
+    if (!a.ok) BAD_ARGS("th_view_step_buffers");
+    TH_CALL("th_view_step_buffers", th_view_step_buffers(c));
+    return undefined(env);
+}
+
 // viewDownload(ctx) -> Uint8Array (flow shape, RGBA8, row-major)
 napi_value ViewDownload(napi_env env, napi_callback_info info)
 {
@@ -930,6 +951,10 @@ napi_value DrawQuery(napi_env env, napi_callback_info info)
     NAPI_OK(napi_set_named_property(env, o, "fragments", v));
     NAPI_OK(napi_create_double(env, (double)q.crowded_fragments, &v));
     NAPI_OK(napi_set_named_property(env, o, "crowdedFragments", v));
+    NAPI_OK(napi_create_double(env, (double)q.sent_bytes, &v));
+    NAPI_OK(napi_set_named_property(env, o, "sentBytes", v));
+    NAPI_OK(napi_create_double(env, (double)q.received_bytes, &v));
+    NAPI_OK(napi_set_named_property(env, o, "receivedBytes", v));
     return o;
 }
 
@@ -1013,6 +1038,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"opticalFlow", OpticalFlow},
         {"flowDeposit", FlowDeposit}, {"exportLines", ExportLines},
         {"viewDraw", ViewDraw}, {"draw", Draw}, {"viewFill", ViewFill}, {"viewClear", ViewClear}, {"viewDownload", ViewDownload},
+        {"viewBuffers", ViewIndexed<th_view_buffers>}, {"viewBind", ViewIndexed<th_view_bind>}, {"viewCopy", ViewIndexed<th_view_copy>}, {"viewStepBuffers", ViewStepBuffers},
         {"colormapUpload", ColormapUpload}, {"exportViewLines", ExportViewLines},
         {"depositSetOwners", DepositSetOwners}, {"depositSetHalo", DepositSetHalo}, {"depositEmit", DepositEmit},
         {"depositMerge", DepositMerge}, {"flowDevicePtr", FlowDevicePtr}, {"stateDevicePtr", StateDevicePtr},

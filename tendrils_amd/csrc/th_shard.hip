@@ -256,6 +256,10 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerFailed) return peer_failure(c, r, "rasterising its band's lines");
     size_t total = 0;
     for (int r = 0; r < world; ++r) { rcount[(size_t)r] = (size_t)hr[(size_t)r]; roff[(size_t)r] = total; total += rcount[(size_t)r]; }
+    for (int r = 0; r < world; ++r) if (r != rank) {
+        c->last_draw.sent_bytes += 8 + scount[(size_t)r] * (sizeof(unsigned long long) + color_bytes);
+        c->last_draw.received_bytes += 8 + rcount[(size_t)r] * (sizeof(unsigned long long) + color_bytes);
+    }
     // stage 2 - room for what arrives and for its merge: the last thing that can fail on one rank alone
     mine = total < ((size_t)1 << 31) ? TH_OK : fail(TH_ERR_UNSUPPORTED, "too many fragments for one owner");
     auto room = [&]() -> th_status {
@@ -293,6 +297,8 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
         char *plane = plane_of ? reinterpret_cast<char *>(c->view) : reinterpret_cast<char *>(c->flow);
         if (c->transport->allgather_bytes(c->comm, plane + go[(size_t)rank], plane, gb.data(), go.data(), rank, world, c->stream))
             return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+        for (int r = 0; r < world; ++r) if (r != rank) c->last_draw.received_bytes += gb[(size_t)r];
+        if (world > 1) c->last_draw.sent_bytes += gb[(size_t)rank];
     }
     return TH_OK;
 }
@@ -376,6 +382,13 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerRetries) return kRetryInStreamOrder;
     size_t total = 0;
     for (int r = 0; r < world; ++r) { rcount[(size_t)r] = (size_t)(hr[(size_t)r] & 0xffffffffull); roff[(size_t)r] = total; total += rcount[(size_t)r]; }
+    {   // (counts word, the per-bin counts of the owner's bins, keys + varyings of what changes hands)
+        const size_t frag_bytes = sizeof(unsigned long long) + (both ? 2 : 1) * sizeof(float4);
+        for (int r = 0; r < world; ++r) if (r != rank) {
+            c->last_draw.sent_bytes += 8 + (size_t)(o.bin_lo[r + 1] - o.bin_lo[r]) * sizeof(uint32_t) + scount[(size_t)r] * frag_bytes;
+            c->last_draw.received_bytes += 8 + (size_t)o.nb * sizeof(uint32_t) + rcount[(size_t)r] * frag_bytes;
+        }
+    }
     // ---- stage 2: every source's counts for my bins; room for what arrives; my store laid out for it (the last things that can
     // fail on one rank alone: agreed on before the fragments travel)
     {
@@ -447,6 +460,8 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         char *plane = plane_of ? reinterpret_cast<char *>(c->view) : reinterpret_cast<char *>(c->flow);
         if (c->transport->allgather_bytes(c->comm, plane + go[(size_t)rank], plane, gb.data(), go.data(), rank, world, c->stream))
             return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+        for (int r = 0; r < world; ++r) if (r != rank) c->last_draw.received_bytes += gb[(size_t)r];
+        if (world > 1) c->last_draw.sent_bytes += gb[(size_t)rank];
     }
     return TH_OK;
 }
@@ -461,6 +476,7 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
                        memcmp(&du->speedLimit, &ru->speedLimit, sizeof du->speedLimit) == 0,
                        "the two passes of one draw share viewSize, time and speedLimit");      // (the same on every rank: a host error, not a rank-local one)
     const int world = c->comm_world, rank = c->comm_rank, W = c->cfg.width;
+    c->last_draw.sent_bytes = c->last_draw.received_bytes = 0;
     if (!c->sharded_draw_ready) {
         // the fixed buffers of the exchange, once - and the ranks make sure that every one of them has them
         auto fixed = [&]() -> th_status {
@@ -497,6 +513,10 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
             if (rank + 1 < world) { sc[(size_t)rank + 1] = 1; so[(size_t)rank + 1] = (size_t)c->cfg.height - 1; rc[(size_t)rank + 1] = 1; ro[(size_t)rank + 1] = 2 + (size_t)b; }
             if (c->transport->alltoallv(c->comm, state[b], sc.data(), so.data(), c->x_halo, rc.data(), ro.data(), (size_t)W * sizeof(float4), world, c->stream))
                 return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+        }
+        {
+            const uint64_t rows_moved = 2ull * ((rank > 0 ? 1u : 0u) + (rank + 1 < world ? 1u : 0u)) * (uint64_t)W * sizeof(float4);
+            c->last_draw.sent_bytes += rows_moved; c->last_draw.received_bytes += rows_moved;
         }
         c->halo_lo = rank > 0 ? c->x_halo : nullptr;
         c->halo_hi = rank + 1 < world ? c->x_halo + (size_t)2 * W : nullptr;

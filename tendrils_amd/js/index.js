@@ -6,7 +6,7 @@
 const native = require('./native');
 const { Particles, Program } = require('./particles');
 const { Timer } = require('./timer');
-const { coverAspect, inert } = require('./utils');
+const { coverAspect, inert, step } = require('./utils');
 
 const defaults = () => ({                         // src/index.js:28-75
   state: {
@@ -68,6 +68,15 @@ const initSpawner = (data) => {                   // src/spawn/init/cpu.js:3-8
   return data;
 };
 
+// One of Tendrils.buffers (src/index.js:172-177: `FBO(gl, [1, 1])`, given viewRes by resize()): an off-screen RGBA8 view
+// image on the device, addressed by its place in the owner's ring
+class ViewBuffer {
+  constructor(owner) { this.owner = owner; this.shape = [1, 1]; }
+  bind() { this.owner.bindView(this); return this; }
+  read() { return this.owner.readView(this); }     // Uint8Array, viewRes[0] x viewRes[1] RGBA8
+  dispose() { this.owner = null; }
+}
+
 class Tendrils {
   constructor(gl, options) {
     const params = { ...defaults(), ...options };
@@ -94,6 +103,8 @@ class Tendrils {
     // what gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE) reports here: [1, 1] like the GL the reference was captured on
     // (flowWidth: 5 then draws width-1 lines, as it does there); up to [1, 64] for the picture of a GL that honours widths
     this.lineWidthRange = (params.lineWidthRange || [1, 1]);
+    this.bound = null;                             // the bound view image: null = the screen, else one of this.buffers
+    this.setupBuffers(params.numBuffers);          // src/index.js:109
   }
 
   setup(...rest) { this.setupParticles(...rest); this.reset(); return this; }
@@ -103,6 +114,44 @@ class Tendrils {
     if (this.particles) { this.particles.dispose(); this.particles = null; }
     return this;
   }
+
+  // ---- Tendrils.buffers: off-screen view images (src/index.js:172-184, 359-391)
+  setupBuffers(numBuffers = 0) {                   // src/index.js:172-184
+    while (this.buffers.length < numBuffers) this.buffers.push(new ViewBuffer(this));
+    while (this.buffers.length > numBuffers) {
+      const gone = this.buffers.pop();
+      if (this.bound === gone) this.bound = null;  // (the library leaves the screen bound as well)
+      gone.dispose();
+    }
+    if (this.particles) native.viewBuffers(this.particles.handle, this.buffers.length);
+    return this;
+  }
+
+  bindView(buffer = null) {                        // gl.bindFramebuffer: null = the screen, else one of this.buffers
+    this.bound = buffer;
+    if (this.particles) native.viewBind(this.particles.handle, buffer ? this.buffers.indexOf(buffer) : -1);
+  }
+
+  drawBuffer(index) {                              // src/index.js:359-367: a buffer's contents to the screen
+    this.bindView(null);
+    if (this.state.autoClearView) native.viewClear(this.particles.handle);   // gl.clear of the bound framebuffer - the screen - alone
+    return this.copyBuffer(index).stepBuffers();
+  }
+
+  copyBuffer(index = 0) {                          // src/index.js:370-383: into the current render target
+    if (index < this.buffers.length && index >= 0) native.viewCopy(this.particles.handle, index | 0);
+    return this;
+  }
+
+  stepBuffers() {                                  // src/index.js:385-391
+    if (this.buffers.length > 1) {
+      step(this.buffers);
+      if (this.particles) native.viewStepBuffers(this.particles.handle);
+    }
+    return this;
+  }
+
+  viewport() { return this; }                      // src/index.js:410-419: gl.viewport(0, 0, ...viewRes) - every pass here covers its whole target
 
   setupParticles(rootNum = this.state.rootNum, numBuffers = 2) {   // src/index.js:186-210
     this.state.rootNum = rootNum;
@@ -125,6 +174,8 @@ class Tendrils {
     this.flow.shape = this.flow.shape;            // (re)create on the new context
     if (this.colorMap) native.colormapUpload(this.particles.handle, this.colorMap.data, this.colorMap.shape[0], this.colorMap.shape[1]);
     native.lineWidthRange(this.particles.handle, this.lineWidthRange[0], this.lineWidthRange[1]);
+    this.bound = null;                             // (a new context: its screen is bound, its ring is empty)
+    if (this.buffers.length) native.viewBuffers(this.particles.handle, this.buffers.length);
     return this;
   }
 
@@ -137,7 +188,12 @@ class Tendrils {
   }
 
   clear() { this.clearView(); this.clearFlow(); return this; }
-  clearView() { native.viewClear(this.particles.handle); return this; }   // src/index.js:215-229 (no extra buffers here)
+  clearView() {                                    // src/index.js:220-229: every buffer, then the screen - which it leaves bound
+    this.buffers.forEach((buffer) => { this.bindView(buffer); native.viewClear(this.particles.handle); });
+    this.bindView(null);
+    native.viewClear(this.particles.handle);
+    return this;
+  }
 
   drawFade() {                                     // src/index.js:342-348
     if (this.state.fadeColor[3] > 0) this.drawFill(this.state.fadeColor);
@@ -158,7 +214,14 @@ class Tendrils {
   }
 
   // the view buffer: Uint8Array, viewRes[0] x viewRes[1] RGBA8 in readPixels order
-  readView() { return native.viewDownload(this.particles.handle); }
+  // (the screen image, or one of this.buffers; what is bound stays bound)
+  readView(buffer = null) {
+    const was = this.bound;
+    if (was !== buffer) this.bindView(buffer);
+    const pixels = native.viewDownload(this.particles.handle);
+    if (was !== buffer) this.bindView(was);
+    return pixels;
+  }
 
   setColorMap(texels, shape) {                     // tendrils.colorMap (src/index.js:94-96): RGBA32F texels, [w, h]
     this.colorMap = { shape: [shape[0], shape[1]], data: texels };
@@ -220,6 +283,7 @@ class Tendrils {
       // a row band of a larger texture (one process per GPU): the passes' exchange is the library's, over the communicator
       // the ranks joined with particles.commInit() - every rank calls draw() together
       if (this.renderView) {
+        this.bindView(this.buffers.length ? this.buffers[0] : null);
         if (this.state.autoClearView) this.clearView();
         if (this.state.autoFade) this.drawFade();
       }
@@ -232,7 +296,9 @@ class Tendrils {
       return this;
     }
     // (the clear and the fade only touch the view buffer; both passes draw the same lines: rasterised and sorted once
-    // when they draw them with the same width)
+    // when they draw them with the same width).  The view goes to buffers[0] when there are buffers, else to the screen
+    // (src/index.js:318-325) - unless autoClearView comes in between: clearView() leaves the SCREEN bound (src/index.js:226).
+    this.bindView(this.buffers.length ? this.buffers[0] : null);
     if (this.state.autoClearView) this.clearView();
     if (this.state.autoFade) this.drawFade();
     this.fragments = this.viewFragments = native.draw(this.particles.handle, deposit, this.renderUniforms());
@@ -243,6 +309,7 @@ class Tendrils {
     this.viewRes[0] = this.gl.drawingBufferWidth;
     this.viewRes[1] = this.gl.drawingBufferHeight;
     coverAspect(this.viewSize, this.viewRes);
+    this.buffers.forEach((buffer) => { buffer.shape = [...this.viewRes]; });   // src/index.js:404 (the images follow the flow texture's shape)
     this.flow.shape = this.viewRes;
     return this;
   }

@@ -139,6 +139,26 @@ def init_spawner(data, x=0, y=0):
     return data
 
 
+class ViewBuffer:
+    """One of Tendrils.buffers (src/index.js:172-177: `FBO(gl, [1, 1])`, given viewRes by resize()): an off-screen RGBA8 view
+    image on the device, addressed by its place in the owner's ring."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.shape = [1, 1]
+
+    def bind(self):
+        self._o._bind_view(self)
+        return self
+
+    def read(self):
+        """[viewRes.y, viewRes.x, 4] uint8"""
+        return self._o.read_view(self)
+
+    def dispose(self):
+        self._o = None
+
+
 class Tendrils:
     def __init__(self, gl=None, options=None):
         params = {**defaults(), **(options or {})}
@@ -163,6 +183,8 @@ class Tendrils:
         # what gl.getParameter(gl.ALIASED_LINE_WIDTH_RANGE) reports here: [1, 1] like the GL the reference was captured on
         # (flowWidth: 5 then draws width-1 lines, as it does there); up to [1, 64] for the picture of a GL that honours widths
         self.lineWidthRange = tuple(params.get("lineWidthRange", (1, 1)))
+        self._bound = None                       # the bound view image: None = the screen, else one of self.buffers
+        self.setupBuffers(int(params.get("numBuffers", 0) or 0))      # src/index.js:109
 
     # -- setup ---------------------------------------------------------------------
     def setup(self, *rest):                                   # src/index.js:149-154
@@ -179,6 +201,46 @@ class Tendrils:
             self.particles.dispose()
             self.particles = None
         return self
+
+    # -- Tendrils.buffers: off-screen view images (src/index.js:172-184, 359-391) ----------------------------------------
+    def setupBuffers(self, numBuffers=0):                      # src/index.js:172-184
+        while len(self.buffers) < numBuffers:
+            self.buffers.append(ViewBuffer(self))
+        while len(self.buffers) > numBuffers:
+            gone = self.buffers.pop()
+            if self._bound is gone:
+                self._bound = None                             # (the library leaves the screen bound as well)
+            gone.dispose()
+        if self.particles is not None:
+            call("th_view_buffers", self.particles._ctx, len(self.buffers))
+        return self
+
+    def _bind_view(self, buffer=None):
+        """gl.bindFramebuffer: None = the screen, else one of self.buffers"""
+        self._bound = buffer
+        if self.particles is not None:
+            call("th_view_bind", self.particles._ctx, -1 if buffer is None else self.buffers.index(buffer))
+
+    def drawBuffer(self, index=None):                          # src/index.js:359-367: a buffer's contents to the screen
+        self._bind_view(None)
+        if self.state["autoClearView"]:
+            call("th_view_clear", self.particles._ctx)         # gl.clear of the bound framebuffer - the screen - alone
+        return self.copyBuffer(0 if index is None else index).stepBuffers()      # (`undefined` takes copyBuffer's default)
+
+    def copyBuffer(self, index=0):                             # src/index.js:370-383: into the current render target
+        if 0 <= index < len(self.buffers):
+            call("th_view_copy", self.particles._ctx, int(index))
+        return self
+
+    def stepBuffers(self):                                     # src/index.js:385-391
+        if len(self.buffers) > 1:
+            self.buffers.insert(0, self.buffers.pop())         # src/utils/index.js:1-7
+            if self.particles is not None:
+                call("th_view_step_buffers", self.particles._ctx)
+        return self
+
+    def viewport(self):                                        # src/index.js:410-419: gl.viewport(0, 0, ...viewRes) - every pass
+        return self                                            # here covers its whole target already
 
     def setupParticles(self, rootNum=None, numBuffers=2):     # src/index.js:186-210
         rootNum = self.state["rootNum"] if rootNum is None else rootNum
@@ -199,6 +261,9 @@ class Tendrils:
             self.colorMap._o = self
             self.colorMap.bind()
         call("th_line_width_range", self.particles._ctx, float(self.lineWidthRange[0]), float(self.lineWidthRange[1]))
+        self._bound = None                       # (a new context: its screen is bound, its ring is empty)
+        if self.buffers:
+            call("th_view_buffers", self.particles._ctx, len(self.buffers))
         return self
 
     def line_widths(self):
@@ -216,7 +281,11 @@ class Tendrils:
         self.clearFlow()
         return self
 
-    def clearView(self):                                       # src/index.js:215-229 (no extra buffers here)
+    def clearView(self):                                       # src/index.js:220-229: every buffer, then the screen -
+        for b in self.buffers:                                 # which it leaves bound
+            self._bind_view(b)
+            call("th_view_clear", self.particles._ctx)
+        self._bind_view(None)
         call("th_view_clear", self.particles._ctx)
         return self
 
@@ -242,10 +311,16 @@ class Tendrils:
             u.baseColor[k], u.flowColor[k] = float(s["baseColor"][k]), float(s["flowColor"][k])
         return u
 
-    def read_view(self):
-        """The view buffer: [viewRes.y, viewRes.x, 4] uint8 (readPixels order)."""
+    def read_view(self, buffer=None):
+        """The screen image - or one of self.buffers -: [viewRes.y, viewRes.x, 4] uint8 (readPixels order).  What is bound
+        stays bound."""
         out = np.empty((self.viewRes[1], self.viewRes[0], 4), np.uint8)
+        was = self._bound
+        if was is not buffer:
+            self._bind_view(buffer)
         call("th_view_download", self.particles._ctx, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if was is not buffer:
+            self._bind_view(was)
         return out
 
     def clearFlow(self):                                       # src/index.js:231-236
@@ -296,6 +371,7 @@ class Tendrils:
         if self.dist is not None:          # row-band shard of a torch.distributed job: emit / exchange / merge, pass by pass
             from .sharding import draw_sharded
             if self.renderView:            # (every rank holds the whole view buffer: the clear / fade are the same everywhere)
+                self._bind_view(self.buffers[0] if self.buffers else None)
                 if self.state["autoClearView"]:
                     self.clearView()
                 if self.state["autoFade"]:
@@ -309,6 +385,7 @@ class Tendrils:
             # joined with sharding.comm_init() (th_draw_sharded; what the Node host runs) - every rank calls draw() together
             from .sharding import draw_sharded_native
             if self.renderView:
+                self._bind_view(self.buffers[0] if self.buffers else None)
                 if self.state["autoClearView"]:
                     self.clearView()
                 if self.state["autoFade"]:
@@ -320,6 +397,9 @@ class Tendrils:
             self.fragments = self.particles.deposit_flow(self.viewSize, self.timer.time, self.state["speedLimit"])
             return self
         # (the clear and the fade only touch the view buffer: it does not matter that the flow pass comes after them here)
+        # The view goes to buffers[0] when there are buffers, else to the screen (src/index.js:318-325) - unless autoClearView
+        # comes in between: clearView() leaves the SCREEN bound (src/index.js:226), there as here.
+        self._bind_view(self.buffers[0] if self.buffers else None)
         if self.state["autoClearView"]:
             self.clearView()
         if self.state["autoFade"]:
@@ -348,6 +428,8 @@ class Tendrils:
         self.viewRes[0] = self.gl.drawingBufferWidth
         self.viewRes[1] = self.gl.drawingBufferHeight
         self.viewSize[:] = cover_aspect(self.viewRes)
+        for b in self.buffers:                                 # src/index.js:404 (the images follow the flow texture's shape)
+            b.shape = list(self.viewRes)
         self.flow.shape = self.viewRes
         return self
 

@@ -23,6 +23,14 @@ def test_self_launch_two_ranks_dry_run(oracle):
     assert line["repetitions"]["n"] == 3 and line["repetitions"]["min"] <= line["ms_per_step"] <= line["repetitions"]["max"]
     assert line["counters"]["particles"] == 2 * 48 * 48
     assert line["value"] > 0 and line["unit"] == "particle-steps/s"
+    # the legs a scaling sweep of the driver's command carries beside the headline: config 5 (strong scaling, packed ring) and
+    # the frame loop of a row-band job with the draw's exchange inside
+    c5 = line["c5"]
+    assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["particles"] == 2 * c5["particles_per_gpu"] == 32 * 64
+    assert c5["rccl"]["nranks_seen"] == 2.0 and c5["rccl"]["reductions"] == 2 and c5["value"] > 0 and "roofline" in c5
+    fls = line["frame_loop_sharded"]
+    assert fls["n_gpus"] == 2 and fls["frames"] == 2 and fls["wall_ms_per_frame"] > 0
+    assert fls["sent_bytes_per_draw"] > 0 and fls["received_bytes_per_draw"] > 0 and fls["fragments_per_draw_all_ranks"] > 100
 
 
 def test_child_failure_is_the_parents_status():

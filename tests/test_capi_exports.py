@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for s in syms:
         assert hasattr(lib, s), "library does not export %s" % s
     assert sorted(_capi.PROTOTYPES) == syms, "ctypes binding and header disagree"
-    assert lib.th_abi_version() == 13
+    assert lib.th_abi_version() == 14
 
 
 def test_one_rocm_runtime_in_the_process(lib):

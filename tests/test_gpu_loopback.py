@@ -201,16 +201,27 @@ def test_sharded_bins_pass_by_pass(how):
         t.dispose()
 
 
-def test_one_rank_giving_up_on_the_bins_sends_everybody_to_the_stream_ordered_pass():
+@pytest.mark.parametrize("n,spread", [(128, 0.9), (256, 0.15)])
+def test_one_rank_giving_up_on_the_bins_sends_everybody_to_the_stream_ordered_pass(n, spread):
     """A rank whose binned pass cannot go on (no store, a bin beyond its lists' reach: here TH_OPT_INJECT_FAILURE = 4) says so
-    with its counts; every rank then runs the stream-ordered pass for that draw - same result, nobody waits."""
+    with its counts; every rank then runs the stream-ordered pass for that draw - same result, nobody waits.  The other
+    ranks had emitted into their stores by then and nothing blended them: the next binned draw - of ANOTHER state - must not
+    meet what they left (spread 0.15 at 256^2: lists of many pages, whose stale page ids a later pass would follow)."""
     from tendrils_amd import sharding
-    n, view, world = 128, (96, 54), 3
-    cur, prev, base = inputs(n, view, 17)
+    view, world = (96, 54), 3
+    cur, prev, base = inputs(n, view, 17, spread)
+    cur2, prev2, _ = inputs(n, view, 18, spread * 1.5)
     one = make(n, view, cur, prev, base)
     one.draw()
     want_flow, want_view = one.flow.read(), one.read_view()
+    one.flow.set_pixels(base)
+    one.clearView()
+    one.particles.upload_texels(cur2, 0)
+    one.particles.upload_texels(prev2, 1)
+    one.draw()
+    want_flow2, want_view2 = one.flow.read(), one.read_view()
     one.dispose()
+    assert not bits_equal(want_flow, want_flow2).all()
     shards = world_of(n, view, world, cur, prev, base, pipeline="bins")
     shards[2].particles.option("inject_failure", 4)
     frags, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
@@ -218,14 +229,17 @@ def test_one_rank_giving_up_on_the_bins_sends_everybody_to_the_stream_ordered_pa
     for t in shards:
         assert last_pipeline(t) == 0                           # TH_DRAW_STREAM: the fallback drew
         assert bits_equal(t.flow.read(), want_flow).all() and (t.read_view() == want_view).all()
-    for t in shards:                                           # ... and the next draw goes through the bins again
+    for r, t in enumerate(shards):                             # ... and the next draw goes through the bins again
+        row0, rows = sharding.shard_rows(n, world, r)
         t.flow.set_pixels(base)
         t.clearView()
+        t.particles.upload_texels(cur2[row0:row0 + rows], 0)
+        t.particles.upload_texels(prev2[row0:row0 + rows], 1)
     _, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
     assert err == [None] * world, err
     for t in shards:
         assert last_pipeline(t) == 1
-        assert bits_equal(t.flow.read(), want_flow).all() and (t.read_view() == want_view).all()
+        assert bits_equal(t.flow.read(), want_flow2).all() and (t.read_view() == want_view2).all()
         t.dispose()
 
 
