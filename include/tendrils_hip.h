@@ -8,10 +8,13 @@
  * 432-457) over WebGL FBO ping-pong.  Each entry point below replaces one of
  * those GL-backed operations; the ctypes binding (tendrils_amd/_capi.py) binds exactly these
  * symbols and the N-API shim (tendrils_amd/csrc/th_napi.cc) all of them except th_stream, th_stats_async,
- * th_spawn_image_download and th_slot_order (the multi-GPU exchange primitives - th_deposit_emit / _merge / _set_halo /
- * _set_owners, th_flow_device_ptr, th_state_device_ptr - hand device addresses to JS as BigInt; the transport between the
- * ranks is the host application's: the host that ships with this build for sharded runs is the Python one, over
- * torch.distributed - INTEGRATION.md).
+ * th_spawn_image_download and th_slot_order.  Both hosts run row-band-sharded jobs, one process per GPU: the ranks join the
+ * library's own communicator (th_comm_unique_id -> th_comm_init; JS: Particles.commUniqueId / commInit) and from then on
+ * the path's collectives - the counter all-reduce, the draw()'s exchange, the state gather - are issued by the library over
+ * RCCL (th_stats_allreduce, th_draw_sharded, th_state_gather); the host only carries the 128-byte id between its processes.
+ * The exchange primitives underneath (th_deposit_emit / _merge / _set_halo / _set_owners, th_flow_device_ptr,
+ * th_state_device_ptr; device addresses reach JS as BigInt) stay exported for hosts with a transport of their own - the
+ * Python host's torch.distributed path, tendrils_amd/sharding.py:draw_sharded - INTEGRATION.md.
  *
  * Conventions
  *  - plain C, no exceptions across the boundary; every call returns th_status
@@ -308,13 +311,17 @@ typedef struct th_comm_info {
     int32_t rccl_version;    /* ncclGetVersion (0: librccl not loadable) */
 } th_comm_info;
 th_status th_comm_unique_id(void *id_out /* TH_COMM_ID_BYTES */);
-/* An id of an IN-PROCESS world instead: the ranks are contexts of one process (on one device or several), each driven by a
+#ifdef TH_TESTING
+/* TEST BUILDS ONLY (make TESTING=1, the default of tendrils_amd/csrc/Makefile and what __graft_entry__.build() makes: the
+ * suites need it; `make release` leaves it - th_loopback.hip, this entry point, TH_OPT_INJECT_FAILURE - out of the library).
+ * An id of an IN-PROCESS world instead: the ranks are contexts of one process (on one device or several), each driven by a
  * host thread of its own, and the exchanges are device-to-device copies around a host-side rendezvous (th_loopback.hip).
  * Everything above the byte transport - which fragments go to which owner, bands, owned ranges, the agreement on failures
  * - is the code an RCCL job runs; this is how it is exercised with more ranks than a box has GPUs.  th_comm_init tells the
  * two kinds of id apart by itself.  A collective that the other ranks do not join within TH_LOOPBACK_TIMEOUT_MS
  * (default 120 000) fails instead of hanging. */
 th_status th_comm_loopback_id(void *id_out /* TH_COMM_ID_BYTES */);
+#endif
 th_status th_comm_init(th_context *ctx, const void *id /* TH_COMM_ID_BYTES */, int32_t rank, int32_t world);
 th_status th_comm_destroy(th_context *ctx);
 th_status th_comm_query(th_context *ctx, th_comm_info *out);
@@ -448,12 +455,17 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
  *                          fragments per 16 x 16-texel bin; a bin that outgrows its lists gets a table four times as wide and the
  *                          pass is repeated, up to 4096); negative: that many and never more (the draw then goes to the
  *                          stream-ordered pipeline - tests)
- *   TH_OPT_INJECT_FAILURE  (tests) the next th_draw_sharded of THIS context fails on its own at stage 1 (its edge rows; packed rings), 2
+ *   TH_OPT_INJECT_FAILURE  (TH_TESTING builds only - a release build answers "unknown option"; the one switch that DOES change what a
+ *                          call returns) the next th_draw_sharded of THIS context fails on its own at stage 1 (its edge rows; packed rings), 2
  *                          (rasterising its lines) or 3 (making room for what it owns); 4: its binned pass gives up (every rank takes the stream-ordered pass, the draw succeeds);
  *                          the switch resets itself.  What is
  *                          tested: every other rank of the job returns an error too instead of waiting in a collective */
 enum { TH_OPT_BUCKET = 0, TH_OPT_RESORT_STEPS = 1, TH_OPT_REBUCKET_STEPS = 2, TH_OPT_FUSE = 3, TH_OPT_GRAPH = 4,
-       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7, TH_OPT_INJECT_FAILURE = 8, TH_OPT_BINS_PAGES = 9 };
+       TH_OPT_FORCE_GENERIC = 5, TH_OPT_DRAW_REUSE = 6, TH_OPT_BINS_POOL = 7,
+#ifdef TH_TESTING
+       TH_OPT_INJECT_FAILURE = 8,
+#endif
+       TH_OPT_BINS_PAGES = 9 };
 th_status th_option_set(th_context *ctx, int32_t option, int64_t value);
 th_status th_option_get(th_context *ctx, int32_t option, int64_t *value);
 

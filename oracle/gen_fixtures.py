@@ -519,6 +519,53 @@ def gen_view(r, only):
          uniforms=dict(baseColor=[0.9, 0.4, 0.1, 0.7], flowColor=[0.2, 0.7, 1.0, 0.35], speedAlpha=2.5, flowDecay=0.012))
 
 
+BUFFER_SCRIPTS = {
+    # the demo's loop (src/demo.main.js:89, 1082-1101): one buffer; per frame tick, step().draw(), then - to the screen -
+    # drawFade() [the blur pass that reads buffers[0] there is out of scope], stepBuffers()
+    "buffers_demo_loop_48": dict(num=1, ops=[["tickStep"], ["draw"], ["bind", -1], ["viewport"], ["drawFade"], ["stepBuffers"],
+                                             ["tickStep"], ["draw"], ["bind", -1], ["drawFade"], ["stepBuffers"],
+                                             ["read", 0], ["read", -1]]),
+    # two buffers: the view lands in buffers[0], the ring rotates under it, copyBuffer blends a buffer into whatever is
+    # bound, drawBuffer clears (autoClearView) or not, copies to the screen and rotates
+    "buffers_copy_and_rotate_48": dict(num=2, ops=[["draw"], ["read", 0], ["read", 1], ["read", -1],
+                                                   ["bind", 1], ["copyBuffer", 0], ["read", 1],
+                                                   ["bind", -1], ["drawFill", [0.2, 0.5, 0.1, 0.7]], ["drawBuffer", 0], ["read", -1],
+                                                   ["read", 0], ["read", 1],
+                                                   ["stepBuffers"], ["tickStep"], ["draw"], ["read", 0], ["read", 1],
+                                                   ["copyBuffer", 5], ["read", 0],
+                                                   ["set", "autoClearView", True], ["drawBuffer", None], ["read", -1],
+                                                   ["tickStep"], ["draw"], ["read", 0], ["read", 1], ["read", -1],
+                                                   ["setupBuffers", 1], ["read", 0], ["setupBuffers", 3], ["read", 2]]),
+}
+
+
+def gen_buffers(r, only):
+    """Tendrils.buffers (src/index.js:66-68, 172-184, 318-325, 359-391) on the reference: scripts of its own draw /
+    copyBuffer / drawBuffer / stepBuffers / setupBuffers / clearView calls, and every image the script reads on the way
+    (RGBA8; a context without multisampling).  Stored sparsely per read."""
+    for name, sc in BUFFER_SCRIPTS.items():
+        if only and only not in name:
+            continue
+        rng = np.random.default_rng(4711 + len(name))
+        n, view = 48, (48, 32)
+        prev = rand_state(rng, n, pos_range=0.9, vel_range=0.012)
+        prev[..., 1] *= view[1] / view[0]
+        cur = prev.copy()
+        cur[..., :2] += rng.uniform(-.1, .1, (n, n, 2)).astype(np.float32)
+        cur[..., 2:] = rng.uniform(-.012, .012, (n, n, 2)).astype(np.float32)
+        uniforms = dict(baseColor=[1, 0.7, 0.3, 0.6], flowColor=[0.2, 1, 0.9, 0.3], fadeColor=[0.1, 0.2, 0.3, 0.25], speedAlpha=1.5)
+        res = r.buffers(cur, prev, sc["ops"], num_buffers=sc["num"], uniforms=uniforms, time=2500.0, view=view)
+        assert res["samples"] == 0 and len(res["images"]) == sum(1 for op in sc["ops"] if op[0] == "read")
+        arrs = {}
+        for k, img in enumerate(res["images"]):
+            idx = np.flatnonzero(img.any(-1)).astype(np.int32)
+            arrs["idx%d" % k], arrs["val%d" % k] = idx, img.reshape(-1, 4)[idx]
+        m = dict(kind="buffers", N=n, viewRes=list(view), viewSize=res["viewSize"], time0=2500.0, numBuffers=sc["num"], ops=sc["ops"],
+                 lengths=res["lengths"], reads=len(res["images"]), state=uniforms, samples=res["samples"])
+        save(name, current=cur, previous=prev, uniforms=json.dumps(m), **arrs)
+        print("wrote %s (%d reads; non-empty: %s)" % (name, len(res["images"]), [int(i.any()) for i in res["images"]]))
+
+
 def gen_spawn_map(r, only):
     """Particles.spawn(map, pixels, offset) (src/particles.js:94-117): the [w, h, 4] staging array is filled x-outer /
     y-inner and handed to setPixels - which texel ends up with map(x, y) is what these captures pin."""
@@ -713,6 +760,8 @@ SCENES = {
     "scene_flow_turbulence_wings_64": ("Flow", [("Turbulence", 12, 10, [0, 0.95, 1]), ("Wings", 24, 0, [0, 0.2, 1])], 41),
     # autoClearView (the view is wiped every frame), a translucent fade, the colour map on: "Fluid", "Ghostly", "Rorschach"
     "scene_fluid_ghostly_rorschach_64": ("Fluid", [("Ghostly", 9, 6, [0, 0.1, 0.9, 1]), ("Rorschach", 24, 12, [0, 0.95, 1])], 43),
+    # `target` > 0 with a targets texture (a ring of positions): "Funhouse" (target 0.005, varyTarget 5) eased in, then "Rave"
+    "scene_flow_funhouse_rave_targets_64": ("Flow", [("Funhouse", 10, 8, [0, 0.9, 1]), ("Rave", 24, 10, [0, 0.3, 1])], 47),
 }
 
 
@@ -754,18 +803,85 @@ def gen_scene(r_unused, only):
                 ops.append(["track", tr, "smoothOver", k["duration"], frame] if k["duration"] else ["track", tr, "smoothTo", frame])
         r = r or RefRunner("demo-modules")
         grab = [0, 7, 11, 15, 23]
-        res = r.scene(st, ops, state0=first.get("state", {}), colors0=colors0, time0=time0, frames=frames, view=view, grab=grab)
+        extra = {}
+        if "targets" in name:            # every particle is pulled towards a point of a ring (velocity part unused by logic.frag)
+            ang = rng.uniform(0, 2 * np.pi, (n, n))
+            tg = np.zeros((n, n, 4), np.float32)
+            tg[..., 0], tg[..., 1] = 0.6 * np.cos(ang), 0.3 * np.sin(ang)
+            extra["targets"] = tg
+        res = r.scene(st, ops, state0=first.get("state", {}), colors0=colors0, time0=time0, frames=frames, view=view, grab=grab, **extra)
         assert res["samples"] == 0
         meta = dict(kind="scene", N=n, frames=frames, viewRes=list(view), viewSize=res["viewSize"], time0=time0, times=res["times"],
                     dts=res["dts"], first=first_name, script=script, ops=ops, colors0=colors0, grab=grab, states=res["states"])
         save(name, state=st, out=res["particles"], flows=np.stack([res["flows"][g] for g in grab]),
-             views=np.stack([res["views"][g] for g in grab]), uniforms=json.dumps(meta))
+             views=np.stack([res["views"][g] for g in grab]), uniforms=json.dumps(meta), **extra)
+
+
+def _js_object_entries(text):
+    """`key: value` pairs of a JS object literal's inside (comments removed), split at top-level commas"""
+    import re
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    for part in parts:
+        if ":" in part:
+            k, v = part.split(":", 1)
+            if re.fullmatch(r"[A-Za-z_][A-Za-z0-9_]*", k.strip()):
+                yield k.strip(), " ".join(v.split())
+
+
+def _js_value(expr, names):
+    """A literal (number, boolean, array of numbers) or a little arithmetic over known names (`state.flowDecay`,
+    `audioDefaults.trackFlowAt`, Math.max / Math.min): -> (value, computed?) or None when it is neither"""
+    import ast
+    import re
+    if re.fullmatch(r"-?[0-9.]+(?:e-?[0-9]+)?|true|false|\[[-0-9., e]*\]", expr):
+        return json.loads(expr), False
+    py = expr.replace("Math.max", "max").replace("Math.min", "min")
+    try:
+        tree = ast.parse(py, mode="eval")
+    except SyntaxError:
+        return None
+
+    def ev(n):
+        if isinstance(n, ast.Expression):
+            return ev(n.body)
+        if isinstance(n, ast.Constant) and isinstance(n.value, (int, float)):
+            return n.value
+        if isinstance(n, ast.BinOp) and isinstance(n.op, (ast.Mult, ast.Div, ast.Add, ast.Sub)):
+            a, b = ev(n.left), ev(n.right)
+            return {ast.Mult: a * b, ast.Add: a + b, ast.Sub: a - b}.get(type(n.op)) if not isinstance(n.op, ast.Div) else a / b
+        if isinstance(n, ast.UnaryOp) and isinstance(n.op, ast.USub):
+            return -ev(n.operand)
+        if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id in ("max", "min"):
+            return (max if n.func.id == "max" else min)(*[ev(a) for a in n.args])
+        if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name):
+            return names[n.value.id][n.attr]
+        raise KeyError(ast.dump(n))
+    try:
+        return ev(tree), True
+    except (KeyError, TypeError):
+        return None
 
 
 def gen_presets(r_unused, only):
-    """The demo's presets (src/demo.main.js:1483-3238) as DATA: for every preset the literal numbers / booleans / colour
-    arrays its function assigns to `state`, to the reset spawner's uniforms and to the colour proxy (entries computed
-    from other values at run time are left out and listed under "skipped").  Only the values travel - no code."""
+    """The demo's presets (src/demo.main.js:1483-3238) as DATA: for every preset the numbers / booleans / colour arrays its
+    function assigns to `state`, the reset spawner's uniforms, the colour proxy - and, for completeness, to the blur, blend,
+    optical-flow and audio-trigger tables the out-of-scope passes read.  A preset runs on top of the defaults
+    (wrapPresetter, src/demo.main.js:3244-3264); an entry written as arithmetic over values known here (`Math.max(state.
+    flowDecay, 0.1)`, `audioDefaults.trackSpawnAt*0.8`) is evaluated and listed under "computed"; whatever is neither lands
+    under "skipped".  Only values travel - no code."""
     if only and only != "presets":
         return
     import re
@@ -774,29 +890,61 @@ def gen_presets(r_unused, only):
     body = src[start:]
     heads = [(m.start(), m.group(1)) for m in re.finditer(r"\n    '([^']+)'\(\) \{", body)]
     end = body.index("\n  };", heads[-1][0])
+
+    def object_after(text, at):
+        """the inside of the object literal whose `{` is the first one at or after `at`"""
+        a = text.index("{", at)
+        depth, k = 0, a
+        while True:
+            depth += text[k] == "{"
+            depth -= text[k] == "}"
+            if depth == 0:
+                return text[a + 1:k]
+            k += 1
+    audio_defaults = {}
+    for k, v in _js_object_entries(object_after(src, src.index("const audioDefaults = {"))):
+        got = _js_value(v, {})
+        if got is not None and k not in audio_defaults:
+            audio_defaults[k] = got[0]
+    # (the microphone's thresholds sit in a conditional spread: the branch taken when `settings.mic_track` is not set)
+    for k, v in _js_object_entries(object_after(src, src.index("settings.mic_track !== 'true')?"))):
+        got = _js_value(v, {})
+        if got is not None and k not in audio_defaults:
+            audio_defaults[k] = got[0]
+    default_state = {k: _js_value(v, {})[0] for k, v in _js_object_entries(object_after(open("/root/reference/src/index.js").read(),
+                     open("/root/reference/src/index.js").read().index("state: {"))) if _js_value(v, {}) is not None}
+    targets = (("state", "state"), ("resetSpawner.uniforms", "spawn"), ("colorProxy", "colorProxy"), ("blurState", "blur"),
+               ("blendProxy", "blend"), ("opticalFlowState", "opticalFlow"), ("audioState", "audio"))
     out = {}
-    lit = re.compile(r"^\s*([A-Za-z_][A-Za-z0-9_]*):\s*(-?[0-9.]+(?:e-?[0-9]+)?|true|false|\[[-0-9., ]*\])\s*,?\s*$")
-    for k, (pos, name) in enumerate(heads):
-        block = body[pos:(heads[k + 1][0] if k + 1 < len(heads) else end)]
-        entry, skipped = {}, []
-        for target, key in (("state", "state"), ("resetSpawner.uniforms", "spawn"), ("colorProxy", "colorProxy")):
-            for m in re.finditer(r"Object\.assign\(" + re.escape(target) + r", \{(.*?)\n\s*\}\);", block, re.S):
-                for line in m.group(1).split("\n"):
-                    line = line.split("//")[0]
-                    if not line.strip():
-                        continue
-                    g = lit.match(line)
-                    if g:
-                        entry.setdefault(key, {})[g.group(1)] = json.loads(g.group(2))
-                    elif ":" in line and not line.strip().startswith(("}", "{")):
-                        skipped.append(key + "." + line.strip().split(":")[0])
+    for n, (pos, name) in enumerate(heads):
+        block = body[pos:(heads[n + 1][0] if n + 1 < len(heads) else end)]
+        entry, skipped, computed = {}, [], []
+        assigns = []
+        for target, key in targets:
+            for m in re.finditer(r"Object\.assign\(" + re.escape(target) + r",\s*\{", block):
+                assigns.append((m.start(), key, object_after(block, m.end() - 1)))
+        names = {"state": dict(default_state), "audioDefaults": audio_defaults}
+        for _, key, inside in sorted(assigns):                      # in source order: later entries see earlier state
+            for k, v in _js_object_entries(inside):
+                got = _js_value(v, names)
+                if got is None:
+                    skipped.append(key + "." + k)
+                    continue
+                entry.setdefault(key, {})[k] = got[0]
+                if got[1]:
+                    computed.append(key + "." + k)
+                if key == "state":
+                    names["state"][k] = got[0]
+        if computed:
+            entry["computed"] = computed
         if skipped:
             entry["skipped"] = skipped
         out[name] = entry
     os.makedirs(GOLDEN, exist_ok=True)
     with open(os.path.join(GOLDEN, "presets.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote presets.json (%d presets)" % len(out))
+    print("wrote presets.json (%d presets; %d computed entries, %d skipped)" % (len(out), sum(len(e.get("computed", [])) for e in out.values()),
+                                                                             sum(len(e.get("skipped", [])) for e in out.values())))
 
 
 def main():
@@ -816,6 +964,7 @@ def main():
     gen_spawn_image(r, args.only)
     gen_geometry(r, args.only)
     gen_view(r, args.only)
+    gen_buffers(r, args.only)
     gen_animate(r, args.only)
     gen_animate_fuzz(r, args.only)
     gen_presets(r, args.only)

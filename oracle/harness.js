@@ -19,6 +19,8 @@
  *                                           array, every ring buffer read back
  *   {kind:'timer', ...}                  -> a scripted sequence of operations on the reference's
  *                                           own Timer class (tendrils.timer.constructor)
+ *   {kind:'buffers', ...}                -> a script on the reference's Tendrils.buffers surface (setupBuffers, draw,
+ *                                           copyBuffer, drawBuffer, stepBuffers ...), the images it reads on the way
  *   {kind:'shader', ...}                 -> one full-screen pass of a compiled
  *                                           reference shader string (spawners,
  *                                           optical flow) handed in by python
@@ -297,6 +299,50 @@
     return {out: out};
   }
 
+  // ---- Tendrils.buffers: the reference's own setupBuffers / draw / copyBuffer / drawBuffer / stepBuffers, scripted -------
+  // job.ops: ['draw'] | ['stepBuffers'] | ['drawFade'] | ['drawFill', rgba] | ['clearView'] | ['copyBuffer', i] |
+  //          ['drawBuffer', i | null] | ['bind', i | -1] | ['setupBuffers', n] | ['set', key, value] | ['tickStep'] |
+  //          ['read', i | -1]  (-1 = the screen; a read binds what it reads and leaves it bound - the script says so)
+  function runBuffers(job) {
+    var T = window.Tendrils, N = job.N;
+    var gl = getGL(job.viewW, job.viewH, T, {preserveDrawingBuffer: true, antialias: false, alpha: true, premultipliedAlpha: false});
+    var t = new T.Tendrils(gl, {numBuffers: job.numBuffers});
+    t.resize();
+    t.setup(N);
+    var k;
+    for (k in (job.state || {})) t.state[k] = job.state[k];
+    uploadF32(gl, t.particles.buffers[0].color[0].handle, N, N, f32FromB64(job.inputs.current));
+    uploadF32(gl, t.particles.buffers[1].color[0].handle, N, N, f32FromB64(job.inputs.previous));
+    t.timer.time = job.time;
+    gl.enable(gl.BLEND);
+    gl.blendFunc(gl.SRC_ALPHA, gl.ONE_MINUS_SRC_ALPHA);
+    var reads = [], lengths = [];
+    job.ops.forEach(function (op) {
+      var what = op[0];
+      if (what === 'draw') t.draw();
+      else if (what === 'tickStep') { t.timer.tick(); t.step(); }
+      else if (what === 'stepBuffers') t.stepBuffers();
+      else if (what === 'drawFade') t.drawFade();
+      else if (what === 'drawFill') t.drawFill(op[1]);
+      else if (what === 'clearView') t.clearView();
+      else if (what === 'copyBuffer') t.copyBuffer(op[1]);
+      else if (what === 'drawBuffer') { if (op[1] === null) t.drawBuffer(); else t.drawBuffer(op[1]); }
+      else if (what === 'setupBuffers') { t.setupBuffers(op[1]); t.resize(); }
+      else if (what === 'set') t.state[op[1]] = op[2];
+      else if (what === 'viewport') t.viewport();
+      else if (what === 'bind') { if (op[1] < 0) gl.bindFramebuffer(gl.FRAMEBUFFER, null); else t.buffers[op[1]].bind(); }
+      else if (what === 'read') {
+        if (op[1] < 0) gl.bindFramebuffer(gl.FRAMEBUFFER, null); else t.buffers[op[1]].bind();
+        var px = new Uint8Array(4 * job.viewW * job.viewH);
+        gl.readPixels(0, 0, job.viewW, job.viewH, gl.RGBA, gl.UNSIGNED_BYTE, px);
+        reads.push(bytesToB64(px));
+      } else throw new Error('unknown op ' + what);
+      lengths.push(t.buffers.length);
+    });
+    return {reads: reads, lengths: lengths, samples: gl.getParameter(gl.SAMPLES), viewSize: [t.viewSize[0], t.viewSize[1]],
+            state: t.state, time: t.timer.time, err: gl.getError()};
+  }
+
   window.Plotly = {
     version: '2.0.0',
     toImage: function (fig) {
@@ -317,6 +363,7 @@
         else if (job.kind === 'spawn_map') res = runSpawnMap(job);
         else if (job.kind === 'timer') res = runTimer(job);
         else if (job.kind === 'shader') res = runShader(job);
+        else if (job.kind === 'buffers') res = runBuffers(job);
         else res = {error: 'unknown job kind'};
       } catch (e) {
         res = {error: String(e), stack: e && e.stack};

@@ -75,7 +75,8 @@
 
   // ---- a keyframed scene: the reference's Player driving the reference's Tendrils ------------------------------------
   // job: {kind:'scene', N, viewW, viewH, state0:{...scalars}, colors0:{baseColor:[..],...}, particles: b64 f32 [N*N*4],
-  //       time0, frames, ops:[['track', name, method, ...args]...], grab:[frame indices whose flow + view are returned]}
+  //       time0, frames, ops:[['track', name, method, ...args]...], grab:[frame indices whose flow + view are returned],
+  //       targets: (optional) b64 f32 [N*N*4] for tendrils.targets}
   // Every frame is the demo's loop body (src/demo.main.js:1027-1031, :1082): timer.tick(); player.play(time); step(); draw().
   function b64ToBytes(s) {
     var bin = atob(s), n = bin.length, out = new Uint8Array(n);
@@ -111,6 +112,10 @@
     for (var b = 0; b < t.particles.buffers.length; ++b) {
       gl.bindTexture(gl.TEXTURE_2D, t.particles.buffers[b].color[0].handle);
       gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGBA, N, N, 0, gl.RGBA, gl.FLOAT, st);
+    }
+    if (job.targets) {                 // tendrils.targets (src/index.js:105,207): what `target` > 0 pulls the particles towards
+      gl.bindTexture(gl.TEXTURE_2D, t.targets.color[0].handle);
+      gl.texImage2D(gl.TEXTURE_2D, 0, gl.RGBA, N, N, 0, gl.RGBA, gl.FLOAT, new Float32Array(b64ToBytes(job.targets).buffer));
     }
     // the demo's track table (src/demo.main.js:836-857), restricted to what the particle path reads
     var outputs = {tendrils: t.state, baseColor: t.state.baseColor, flowColor: t.state.flowColor, fadeColor: t.state.fadeColor};

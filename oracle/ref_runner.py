@@ -122,11 +122,24 @@ class RefRunner:
             res["view_out"] = np.frombuffer(base64.b64decode(res["view"]), dtype=np.uint8).reshape(int(view[1]), int(view[0]), 4).copy()
         return _f32(res["out"], (h, w, 4)), res
 
+    def buffers(self, current, previous, ops, num_buffers=1, uniforms=None, time=0.0, view=(64, 64)):
+        """A script on the reference's own Tendrils.buffers surface (src/index.js:172-184, 318-325, 359-391), on a context
+        without multisampling: returns the RGBA8 images the script's 'read' ops took, in order, and the ring's length after
+        every op."""
+        job = {"kind": "buffers", "N": current.shape[0], "viewW": int(view[0]), "viewH": int(view[1]), "numBuffers": int(num_buffers),
+               "state": uniforms or {}, "time": float(time), "ops": ops,
+               "inputs": {"current": _b64(current, np.float32), "previous": _b64(previous, np.float32)}}
+        res = self._run(job)
+        if res.get("err"):
+            raise RuntimeError("GL error %s" % res["err"])
+        res["images"] = [np.frombuffer(base64.b64decode(b), dtype=np.uint8).reshape(int(view[1]), int(view[0]), 4).copy() for b in res["reads"]]
+        return res
+
     # -- the reference's Player / Timeline classes, scripted (bundle="demo-modules") ---------------
     def animate(self, tracks, ops, outputs=None):
         return self._run({"kind": "animate", "tracks": tracks, "ops": ops, "outputs": outputs or {}})
 
-    def scene(self, particles, ops, state0=None, colors0=None, time0=0.0, frames=24, view=(96, 54), grab=()):
+    def scene(self, particles, ops, state0=None, colors0=None, time0=0.0, frames=24, view=(96, 54), grab=(), targets=None):
         """bundle="demo-modules": the reference's Player (tracks tendrils / baseColor / flowColor / fadeColor writing into
         tendrils.state, as src/demo.main.js:836-857) keyframed by `ops`, then `frames` x [timer.tick(); player.play(time);
         step(); draw()] of the reference's Tendrils.  Returns per frame: time, dt, the whole state object, the particle
@@ -134,7 +147,8 @@ class RefRunner:
         n = particles.shape[0]
         res = self._run({"kind": "scene", "N": n, "viewW": int(view[0]), "viewH": int(view[1]), "state0": state0 or {},
                          "colors0": colors0 or {}, "particles": _b64(particles, np.float32), "time0": float(time0),
-                         "frames": int(frames), "ops": ops, "grab": [int(g) for g in grab]})
+                         "frames": int(frames), "ops": ops, "grab": [int(g) for g in grab],
+                         **({"targets": _b64(targets, np.float32)} if targets is not None else {})})
         if res.get("err"):
             raise RuntimeError("GL error %s" % res["err"])
         fw, fh = res["flowShape"]

@@ -189,6 +189,7 @@ PROTOTYPES = {
 }
 
 _NO_STATUS = {"th_abi_version", "th_last_error"}
+TEST_BUILD_ONLY = {"th_comm_loopback_id"}      # declared under TH_TESTING in include/tendrils_hip.h
 _lib = None
 
 
@@ -243,6 +244,8 @@ def load():
                           "shared between them - import torch before anything loads the ROCm runtime, or set "
                           "TH_SKIP_TORCH=1 and keep torch out of the process" % ", ".join(sorted(paths)))
         for name, (res, args) in PROTOTYPES.items():
+            if name in TEST_BUILD_ONLY and not hasattr(lib, name):
+                continue                 # a release build of the library (make release): the test machinery is not in it
             fn = getattr(lib, name)      # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
         _lib = lib

@@ -19,6 +19,11 @@ How it is built (the same design as tendrils_amd/js/animate.js):
   package (its two-point special case included), the mix as a*(1-w) + b*w (`lerp` package).
 
 Outputs and key values are dicts or lists (colours); a key's "call" is a list of callables f(out, span).
+
+One deliberate difference: frames of EQUAL time in a list handed to the constructor / setup() keep the order they were
+given in.  The reference sorts that list with a comparator that answers -1 for a tie (`order`, src/animate/timeline.js),
+which hands their order to the engine's sort algorithm (a V8 with TimSort turns A, B into B, A; an insertion sort need not)
+- nothing the reference's source defines, so nothing is pinned there.  Ties met by add() follow the reference's rule.
 """
 import math
 from bisect import bisect_left, bisect_right

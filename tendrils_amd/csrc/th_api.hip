@@ -617,7 +617,9 @@ th_status th_option_set(th_context *c, int32_t option, int64_t value)
     case TH_OPT_FORCE_GENERIC: o.force_generic = value != 0; break;
     case TH_OPT_DRAW_REUSE: o.draw_reuse = value != 0; break;
     case TH_OPT_BINS_POOL: TH_REQUIRE(value >= 0 && value < (1ll << 32), "TH_OPT_BINS_POOL out of range"); o.bins_pool = (uint32_t)value; break;
+#ifdef TH_TESTING
     case TH_OPT_INJECT_FAILURE: TH_REQUIRE(value >= 0 && value <= 4, "TH_OPT_INJECT_FAILURE takes 0..4"); o.inject_failure = (int)value; break;
+#endif
     case TH_OPT_BINS_PAGES:
         TH_REQUIRE(value >= -(int64_t)th::kBinPagesLimit && value <= (int64_t)th::kBinPagesLimit && value != 1 && value != -1, "TH_OPT_BINS_PAGES takes 0, or 2..%u (negative: never widened)", th::kBinPagesLimit);
         o.bins_pages = (int)value;
@@ -645,7 +647,9 @@ th_status th_option_get(th_context *c, int32_t option, int64_t *value)
     case TH_OPT_FORCE_GENERIC: *value = o.force_generic; break;
     case TH_OPT_DRAW_REUSE: *value = o.draw_reuse; break;
     case TH_OPT_BINS_POOL: *value = o.bins_pool; break;
+#ifdef TH_TESTING
     case TH_OPT_INJECT_FAILURE: *value = o.inject_failure; break;
+#endif
     case TH_OPT_BINS_PAGES: *value = o.bins_pages; break;
     default: return fail(TH_ERR_INVALID, "unknown option %d", option);
     }

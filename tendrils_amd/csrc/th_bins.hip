@@ -45,6 +45,7 @@ constexpr uint32_t kRankMaxRun = 256;        // runs up to this length are order
 constexpr uint32_t kOwnRun = 256;            // runs up to this length are blended by their texel's thread alone (64 texels of a wave side by side: a chain per lane, nothing redundant)
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr uint32_t kNoPlace = 0xffffffffu;
+constexpr uint32_t kPageSpins = 1u << 19;        // tries of page_of<WAIT> (each a sleep of ~128 cycles and a load: ~50 ms in all) before it gives up
 
 TH_D uint32_t bin_of(const DepositParams &p, uint32_t x, uint32_t y) { return (y >> kBinShift) * p.bins_x + (x >> kBinShift); }
 TH_D void bins_flag(const DepositParams &p, uint32_t what) { atomicOr(&p.totals[kTotFlags], what); }
@@ -53,7 +54,10 @@ TH_D void bins_flag(const DepositParams &p, uint32_t what) { atomicOr(&p.totals[
 // Place `v` (a virtual index handed out by the list's cursor) of list `list` = bin * kBinReplicas + r -> position in the
 // key / varying arrays.  The page a place lies in was taken from the pool by whoever's reservation contained the page's
 // FIRST place - a thread that had moved the cursor before this one and publishes the page right after, without waiting for
-// anybody: the wait below always ends.
+// anybody: the wait below always ends.  Should that ever not hold (a reservation lost, a table entry overwritten), the wait
+// gives up after kPageSpins tries - tens of milliseconds, a thousand times the longest wait a pass has been seen to make -:
+// the place is nowhere, the pass is flagged (kBinsWaitBroken) and the host repeats the draw in stream order like any pass
+// it cannot trust, instead of a launch that never ends.
 // (WAIT: inside the pass that hands the pages out - a relaxed device-scope load per try: only the entry's own value is
 // needed, nothing else is published with it, and an acquire would empty the caches at every fragment; readers of later
 // launches load plainly)
@@ -65,7 +69,8 @@ TH_D uint32_t page_of(const DepositParams &p, uint32_t list, uint32_t pn)
     uint32_t *slot = &p.page_table[(size_t)list * p.max_pages + pn];
     if constexpr (!WAIT) return *slot;
     uint32_t id = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (id == 0u) {
+    for (uint32_t spins = 0; id == 0u; ++spins) {
+        if (spins >= kPageSpins) { bins_flag(p, kBinsWaitBroken); return kNoPlace; }
         __builtin_amdgcn_s_sleep(2);
         id = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -189,7 +189,9 @@ int comm_unique_id(void *out, size_t bytes)
 // (the device of the calling context is current)
 int comm_init(void **comm, const Transport **transport, const void *id_bytes, size_t bytes, int rank, int world)
 {
-    if (loopback_id(id_bytes)) return loopback_init(comm, transport, id_bytes, bytes, rank, world);
+#ifdef TH_TESTING
+    if (loopback_id(id_bytes)) return loopback_init(comm, transport, id_bytes, bytes, rank, world);      // (th_loopback.hip: test builds)
+#endif
     Rccl &R = rccl();
     if (!R.lib) return comm_fail("librccl could not be loaded (" + R.error + ")");
     if (bytes != sizeof(ncclUniqueId)) return comm_fail("a communicator id is " + std::to_string(sizeof(ncclUniqueId)) + " bytes");

@@ -256,7 +256,7 @@ constexpr uint32_t kBinPagesLimit = 4096;          // ... and after the table ha
 constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits per texel coordinate
 // totals[]: device words of one pass
 enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWindows = 8, kTotWords = 12 };
-enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u };
+enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u, kBinsWaitBroken = 8u };      // (8: a page nobody published - page_of)
 void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, hipStream_t stream);   // list: a word per block of 256 slots
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
 void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t stream);

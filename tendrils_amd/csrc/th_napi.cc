@@ -584,6 +584,7 @@ napi_value CommUniqueId(napi_env env, napi_callback_info)
     return arr;
 }
 
+#ifdef TH_TESTING
 // commLoopbackId() -> Uint8Array(128): the id of an in-process world (th_comm_loopback_id)
 napi_value CommLoopbackId(napi_env env, napi_callback_info)
 {
@@ -594,6 +595,7 @@ napi_value CommLoopbackId(napi_env env, napi_callback_info)
     NAPI_OK(napi_create_typedarray(env, napi_uint8_array, TH_COMM_ID_BYTES, buf, 0, &arr));
     return arr;
 }
+#endif
 
 // commInit(ctx, id: Uint8Array(128), rank, world)  (collective: returns when every rank has joined)
 napi_value CommInit(napi_env env, napi_callback_info info)
@@ -1045,7 +1047,11 @@ napi_value Init(napi_env env, napi_value exports)
         {"stats", Stats}, {"sync", Sync}, {"timerStart", TimerStart}, {"timerStop", TimerStop},
         {"kernelTiming", KernelTiming}, {"kernelTimingRead", KernelTimingRead}, {"drawPipeline", DrawPipeline}, {"drawQuery", DrawQuery}, {"option", Option},
         {"lineWidth", LineWidth}, {"lineWidthRange", LineWidthRange}, {"lineWidthQuery", LineWidthQuery},
-        {"commUniqueId", CommUniqueId}, {"commLoopbackId", CommLoopbackId}, {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
+        {"commUniqueId", CommUniqueId},
+#ifdef TH_TESTING
+        {"commLoopbackId", CommLoopbackId},
+#endif
+        {"commInit", CommInit}, {"commDestroy", CommDestroy}, {"commQuery", CommQuery},
         {"statsAllreduce", StatsAllreduce}, {"statsGlobal", StatsGlobal},
         {"viewEmit", ViewEmit}, {"viewMerge", ViewMerge}, {"drawEmit", DrawEmit}, {"drawMerge", DrawMerge}, {"viewDevicePtr", ViewDevicePtr},
         {"stateGather", StateGather}, {"stateGatherPtr", StateGatherPtr}, {"drawSharded", DrawSharded},
@@ -1062,7 +1068,10 @@ napi_value Init(napi_env env, napi_value exports)
         {"SOURCE_IMAGE", TH_SOURCE_IMAGE}, {"DRAW_AUTO", TH_DRAW_AUTO}, {"DRAW_STREAM", TH_DRAW_STREAM}, {"DRAW_BINS", TH_DRAW_BINS},
         {"OPT_BUCKET", TH_OPT_BUCKET}, {"OPT_RESORT_STEPS", TH_OPT_RESORT_STEPS}, {"OPT_REBUCKET_STEPS", TH_OPT_REBUCKET_STEPS},
         {"OPT_FUSE", TH_OPT_FUSE}, {"OPT_GRAPH", TH_OPT_GRAPH}, {"OPT_FORCE_GENERIC", TH_OPT_FORCE_GENERIC},
-        {"OPT_DRAW_REUSE", TH_OPT_DRAW_REUSE}, {"OPT_BINS_POOL", TH_OPT_BINS_POOL}, {"OPT_INJECT_FAILURE", TH_OPT_INJECT_FAILURE}, {"OPT_BINS_PAGES", TH_OPT_BINS_PAGES},
+        {"OPT_DRAW_REUSE", TH_OPT_DRAW_REUSE}, {"OPT_BINS_POOL", TH_OPT_BINS_POOL}, {"OPT_BINS_PAGES", TH_OPT_BINS_PAGES},
+#ifdef TH_TESTING
+        {"OPT_INJECT_FAILURE", TH_OPT_INJECT_FAILURE},
+#endif
     };
     for (auto &e : consts) {
         if (napi_create_int32(env, e.val, &v) != napi_ok) return nullptr;

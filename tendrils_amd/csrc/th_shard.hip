@@ -161,13 +161,24 @@ th_status th_draw_merge(th_context *c, const void *keys_dev, const void *colors_
 constexpr unsigned long long kPeerFailed = 1ull << 62;       // (a count travels below bit 31)
 constexpr unsigned long long kPeerRetries = 1ull << 61;      // ... a rank whose binned pass gave up: everybody takes the stream-ordered pass
 
-// (tests: TH_OPT_INJECT_FAILURE) this rank fails at `stage` once
+// (TH_TESTING builds: TH_OPT_INJECT_FAILURE) this rank fails at `stage` once; a release build has no such switch
+#ifdef TH_TESTING
 static th_status injected(th_context *c, int stage)
 {
     if (c->opt.inject_failure != stage) return TH_OK;
     c->opt.inject_failure = 0;
     return fail(TH_ERR_UNSUPPORTED, "injected failure at stage %d of the sharded draw (TH_OPT_INJECT_FAILURE)", stage);
 }
+static bool injected_give_up(th_context *c)       // value 4: this rank's binned pass gives up (everybody takes the stream-ordered pass)
+{
+    if (c->opt.inject_failure != 4) return false;
+    c->opt.inject_failure = 0;
+    return true;
+}
+#else
+static th_status injected(th_context *, int) { return TH_OK; }
+static bool injected_give_up(th_context *) { return false; }
+#endif
 
 static th_status peer_failure(th_context *c, int who, const char *stage)
 {
@@ -322,7 +333,7 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
     std::vector<unsigned long long> hb((size_t)world + 1, 0ull);
     auto stage1 = [&]() -> th_status {
         if (th_status s = injected(c, 2)) return s;
-        if (c->opt.inject_failure == 4) { c->opt.inject_failure = 0; return kRetryInStreamOrder; }      // (tests: this rank's binned pass gives up)
+        if (injected_give_up(c)) return kRetryInStreamOrder;
         if (th_status s = deposit_prepare_bins(c, &d, p)) return s;
         p.mode = both ? 2 : (view ? 1 : 0);
         if (view) { view_fields(c, ru, p); p.view = c->view; if (!both) p.line_half = 0.5f * drawn_line_width(c, TH_PASS_VIEW); }
@@ -548,12 +559,14 @@ th_status th_comm_unique_id(void *id_out)
     return TH_OK;
 }
 
+#ifdef TH_TESTING
 th_status th_comm_loopback_id(void *id_out)
 {
     TH_REQUIRE(id_out, "null output");
     if (th::loopback_unique_id(id_out, TH_COMM_ID_BYTES)) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
     return TH_OK;
 }
+#endif
 
 th_status th_comm_init(th_context *c, const void *id, int32_t rank, int32_t world)
 {

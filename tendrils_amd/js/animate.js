@@ -137,6 +137,8 @@ class Timeline {
 
   // -- keys
 
+  // (frames of equal time keep their given order: the reference's comparator answers -1 for a tie and so leaves them to the
+  // engine's sort algorithm - src/animate/timeline.js `order`; ties met by add() follow the reference's rule)
   setup(frames = [], infinite = this.infinite) {
     this.infinite = infinite;
     const sorted = frames.map((frame, i) => [frame, i]).sort((p, q) => (p[0].time - q[0].time) || (p[1] - q[1]));

@@ -206,3 +206,29 @@ def deposit_hashed_inputs(n, seed, pos_range, step, inert_mod):
     cur[..., :2] = np.where(live[..., None], prev[..., :2] + b[..., :2] * np.float32(step), prev[..., :2])
     cur[..., 2:] = np.where(live[..., None], b[..., 2:], prev[..., 2:])
     return cur.astype(np.float32), prev.astype(np.float32)
+
+
+def buffers_fixture(path):
+    """A Tendrils.buffers script captured on the reference (oracle/gen_fixtures.py:gen_buffers): meta (ops, state, ...), the
+    two state textures, and the images its 'read' ops took, in order."""
+    d = np.load(path)
+    m = json.loads(str(d["uniforms"]))
+    fw, fh = m["viewRes"]
+    images = []
+    for k in range(m["reads"]):
+        img = np.zeros((fh * fw, 4), np.uint8)
+        img[d["idx%d" % k]] = d["val%d" % k]
+        images.append(img.reshape(fh, fw, 4))
+    return m, d["current"], d["previous"], images
+
+
+def blend_rgba8_over(src, dst):
+    """A full-screen quad textured with the RGBA8 image `src` (texel for texel: copy.frag) - or of one colour, `src` a
+    4-vector of floats - through SRC_ALPHA / ONE_MINUS_SRC_ALPHA into the RGBA8 image `dst`, in the view pass's own
+    arithmetic (th_raster.hpp: dep_blend_rgba8 - fp32, a*b + c as two rounded operations, round half up)."""
+    src = np.asarray(src)
+    c = (src.astype(np.float32) / np.float32(255.0)) if src.dtype == np.uint8 else np.clip(src.astype(np.float32), 0, 1)
+    sa = c[..., 3:4]
+    da = np.float32(1.0) - sa
+    o = c * sa + (dst.astype(np.float32) * np.float32(1.0 / 255.0)) * da
+    return (np.clip(o, 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)

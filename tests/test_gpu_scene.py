@@ -1,6 +1,7 @@
 """Scene replay on the GPU against frames captured from the REFERENCE: its own Player driving its own
 Tendrils - preset "Flow", then keyframes easing into "Turbulence" and "Wings"; preset "Fluid" (the view wiped every frame)
-into "Ghostly" and "Rorschach" - over 24 frames of tick / play / step / draw (oracle/gen_fixtures.py:gen_scene ->
+into "Ghostly" and "Rorschach"; "Flow" into "Funhouse" and "Rave" (`target` and `varyTarget` eased up from 0 over a targets
+texture: the integrator's TARGET kernels under a moving uniform) - over 24 frames of tick / play / step / draw (oracle/gen_fixtures.py:gen_scene ->
 tests/golden/scene_*.npz).  The same script runs through
 tendrils_amd/scenes.py and through the Node host's js/scenes.js: the state object must follow the reference's double for
 double, the particle texture, the flow field and the view image within tests/test_scene_script.py:scene_close."""
@@ -37,6 +38,8 @@ def test_python_scene_against_the_reference_frames(captured):
     for k in META["script"]:
         scene.keyframe(TABLE[k["preset"]], k["time"], k["duration"], k["ease"])
     t.particles.upload_texels(FX["state"])
+    if "targets" in FX.files:                      # (the scene with `target` > 0: tendrils.targets, src/index.js:105,207)
+        t.targets.set_pixels(FX["targets"])
     t.timer.time = META["time0"]
     hosts, states, flows, views = [], [], [], []
 
@@ -57,7 +60,11 @@ def test_python_scene_against_the_reference_frames(captured):
 def test_node_scene_against_the_reference_frames(tmp_path, captured):
     FX, META = captured.FX, captured.META
     FX["state"].astype(np.float32).tofile(tmp_path / "state.bin")
-    spec = dict(kind="scene", N=META["N"], viewRes=META["viewRes"], inputs={"state": "state.bin"}, time0=META["time0"],
+    inputs = {"state": "state.bin"}
+    if "targets" in FX.files:
+        FX["targets"].astype(np.float32).tofile(tmp_path / "targets.bin")
+        inputs["targets"] = "targets.bin"
+    spec = dict(kind="scene", N=META["N"], viewRes=META["viewRes"], inputs=inputs, time0=META["time0"],
                 frames=META["frames"], grab=META["grab"], first=META["first"], script=META["script"], table=TABLE)
     (tmp_path / "case.json").write_text(json.dumps(spec))
     r = subprocess.run([shutil.which("node"), os.path.join(ROOT, "tests", "js", "run_case.js"), str(tmp_path / "case.json")],

@@ -223,3 +223,121 @@ def test_node_host_runs_the_demo_loop_with_buffers():
     assert (img("drawn") == blend_over(img("back"), img("screen"))).all()
     assert res["count"] == 2 and res["left"] == 0
     t.dispose()
+
+
+# ---- the reference's own scripts (tests/golden/buffers_*.npz; tests/test_view_buffers_oracle.py) on the hosts -----------------
+def replay(t, ops):
+    """one captured op on the Python host -> the image a 'read' takes"""
+    def run(op):
+        what = op[0]
+        if what == "tickStep":
+            t.timer.tick(); t.step()
+        elif what == "draw":
+            t.draw()
+        elif what in ("stepBuffers", "drawFade", "clearView", "viewport"):
+            getattr(t, what)()
+        elif what == "drawFill":
+            t.drawFill(op[1])
+        elif what == "copyBuffer":
+            t.copyBuffer(op[1])
+        elif what == "drawBuffer":
+            t.drawBuffer() if op[1] is None else t.drawBuffer(op[1])
+        elif what == "setupBuffers":
+            t.setupBuffers(op[1]).resize()
+        elif what == "set":
+            t.state[op[1]] = op[2]
+        elif what == "bind":
+            t._bind_view(None if op[1] < 0 else t.buffers[op[1]])
+        elif what == "read":
+            t._bind_view(None if op[1] < 0 else t.buffers[op[1]])       # (the capture's read binds what it reads)
+            return t.read_view(t._bound)
+        else:
+            raise ValueError(what)
+        return None
+    return [img for img in (run(op) for op in ops) if img is not None]
+
+
+@pytest.mark.parametrize("path", __import__("helpers").golden("buffers"), ids=lambda p: p.split("/")[-1][:-4])
+def test_reference_scripts_on_the_python_host(oracle, path):
+    """every image the reference's script read: the host's own, against the capture (coverage exact, values +-1, +-2 after
+    copies) and against the restated semantics over the restatement's passes - bit for bit"""
+    import tendrils_amd as ta
+    from helpers import buffers_fixture
+    from tendrils_amd.tendrils import View
+    from test_view_buffers_oracle import RingModel, close_to_reference
+    m, cur, prev, images = buffers_fixture(path)
+    opts = ta.defaults()
+    opts["numBuffers"] = m["numBuffers"]
+    opts["state"].update(m["state"])
+    t = ta.Tendrils(View(*m["viewRes"]), opts)
+    t.resize()
+    t.setup(m["N"])
+    t.viewSize[:] = m["viewSize"]
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.timer.time = m["time0"]
+    got = replay(t, m["ops"])
+    lengths = len(t.buffers)
+    t.dispose()
+    model = RingModel(oracle, m, cur, prev)
+    want = [img for img in (model.run(op) for op in m["ops"]) if img is not None]
+    assert len(got) == len(images) == len(want) and lengths == m["lengths"][-1]
+    copied = False
+    reads = iter(range(len(images)))
+    for op in m["ops"]:
+        copied = copied or op[0] in ("copyBuffer", "drawBuffer")
+        if op[0] == "read":
+            k = next(reads)
+            close_to_reference(got[k], images[k], k, copied)
+            assert (got[k] == want[k]).all(), "read %d differs from the restated semantics" % k
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+@pytest.mark.parametrize("path", __import__("helpers").golden("buffers"), ids=lambda p: p.split("/")[-1][:-4])
+def test_reference_scripts_on_the_node_host(path):
+    from helpers import buffers_fixture
+    from test_view_buffers_oracle import close_to_reference
+    m, cur, prev, images = buffers_fixture(path)
+    script = """
+    const T = require('./tendrils_amd/js');
+    const cfg = JSON.parse(require('fs').readFileSync(0, 'utf8'));
+    const f32 = (b) => new Float32Array(new Uint8Array(Buffer.from(b, 'base64')).buffer);
+    const opts = T.defaults();
+    Object.assign(opts.state, cfg.state);
+    const t = new T.Tendrils({drawingBufferWidth: cfg.view[0], drawingBufferHeight: cfg.view[1]}, {...opts, numBuffers: cfg.numBuffers});
+    t.resize(); t.setup(cfg.n);
+    t.viewSize[0] = cfg.viewSize[0]; t.viewSize[1] = cfg.viewSize[1];
+    t.particles.uploadTexels(f32(cfg.cur), 0); t.particles.uploadTexels(f32(cfg.prev), 1);
+    t.timer.time = cfg.time0;
+    const reads = [], lengths = [];
+    for (const op of cfg.ops) {
+      const what = op[0];
+      if (what === 'tickStep') { t.timer.tick(); t.step(); }
+      else if (what === 'draw' || what === 'stepBuffers' || what === 'drawFade' || what === 'clearView' || what === 'viewport') t[what]();
+      else if (what === 'drawFill') t.drawFill(op[1]);
+      else if (what === 'copyBuffer') t.copyBuffer(op[1]);
+      else if (what === 'drawBuffer') { if (op[1] === null) t.drawBuffer(); else t.drawBuffer(op[1]); }
+      else if (what === 'setupBuffers') t.setupBuffers(op[1]).resize();
+      else if (what === 'set') t.state[op[1]] = op[2];
+      else if (what === 'bind') t.bindView(op[1] < 0 ? null : t.buffers[op[1]]);
+      else if (what === 'read') { t.bindView(op[1] < 0 ? null : t.buffers[op[1]]); reads.push(Buffer.from(t.readView(t.bound).buffer).toString('base64')); }
+      else throw new Error(what);
+      lengths.push(t.buffers.length);
+    }
+    t.dispose();
+    console.log(JSON.stringify({reads, lengths}));
+    """
+    cfg = dict(n=m["N"], view=m["viewRes"], viewSize=m["viewSize"], time0=m["time0"], numBuffers=m["numBuffers"], ops=m["ops"], state=m["state"],
+               cur=base64.b64encode(np.ascontiguousarray(cur, np.float32).tobytes()).decode(),
+               prev=base64.b64encode(np.ascontiguousarray(prev, np.float32).tobytes()).decode())
+    r = subprocess.run([shutil.which("node"), "-e", script], input=json.dumps(cfg), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout)
+    assert res["lengths"] == m["lengths"] and len(res["reads"]) == len(images)
+    fw, fh = m["viewRes"]
+    copied, k = False, 0
+    for op in m["ops"]:
+        copied = copied or op[0] in ("copyBuffer", "drawBuffer")
+        if op[0] == "read":
+            close_to_reference(np.frombuffer(base64.b64decode(res["reads"][k]), np.uint8).reshape(fh, fw, 4), images[k], k, copied)
+            k += 1

@@ -117,7 +117,7 @@ def scene_close(states, flows, views, captured):
     META["grab"].  Frame 0 has no wake yet and no eased value: bit-exact.  Afterwards the deposit's value tolerance (the GL's
     varying interpolation is implementation-defined) feeds back through the flow tap: positions in [-1, 1]
     drift by <= 5e-8 per frame (measured: 9.1e-7 after 24).  Coverage of both targets stays identical in every grabbed
-    frame; flow values within 1e-7 (x, y), 2e-5 * time (z: the blended deposit time, ~1400 ms; measured 1.05e-5) and 1e-5 (alpha); the view within 1 of
+    frame; flow values within 3e-7 (x, y: velocities of <= 0.01; measured 4e-8, and 2.4e-7 on one texel of the scene with targets), 2e-5 * time (z: the blended deposit time, ~1400 ms; measured 1.05e-5) and 1e-5 (alpha); the view within 1 of
     255 per channel (the captured GL blends RGBA8 in fixed point: with a fade fill every frame most texels may sit one step
     off, none two)."""
     FX, META = captured.FX, captured.META
@@ -129,12 +129,14 @@ def scene_close(states, flows, views, captured):
         ref, t = FX["flows"][g], META["times"][META["grab"][g]]
         assert ((flow != 0).any(-1) == (ref != 0).any(-1)).all(), "flow coverage, frame %d" % META["grab"][g]
         d = np.abs(flow.astype(np.float64) - ref)
-        assert d[..., 0].max() <= 1e-7 and d[..., 1].max() <= 1e-7 and d[..., 2].max() <= 2e-5 * t and d[..., 3].max() <= 1e-5
+        assert d[..., 0].max() <= 3e-7 and d[..., 1].max() <= 3e-7 and d[..., 2].max() <= 2e-5 * t and d[..., 3].max() <= 1e-5
         rv = FX["views"][g]
         assert (view.any(-1) == rv.any(-1)).all(), "view coverage, frame %d" % META["grab"][g]
         assert np.abs(view.astype(np.int32) - rv.astype(np.int32)).max() <= 1
     if captured.name == "scene_flow_turbulence_wings_64":
-        assert (FX["views"][0].any(-1).sum(), FX["views"][-1].any(-1).sum()) == (1258, 96 * 54)     # lines only, then the fade's fill
+        # ("Flow" fades with alpha max(flowDecay, 0.05) from its first frame on - src/demo.main.js, colorProxy.fadeAlpha: every
+        # texel of the view carries the fade's fill)
+        assert (FX["views"][0].any(-1).sum(), FX["views"][-1].any(-1).sum()) == (96 * 54, 96 * 54)
 
 
 def test_oracle_replays_the_scene(oracle, captured):
@@ -148,7 +150,7 @@ def test_oracle_replays_the_scene(oracle, captured):
         s, t = META["states"][k], META["times"][k]
         scalars = {a: b for a, b in s.items() if isinstance(b, (int, float)) and not isinstance(b, bool)}
         u = oracle.logic_uniforms(n, n, t, META["dts"][k], view_size=META["viewSize"], **scalars)
-        prev, cur = cur, oracle.logic_step(u, cur, flow)
+        prev, cur = cur, oracle.logic_step(u, cur, flow, targets=FX["targets"] if "targets" in FX.files else None)
         flow, _ = oracle.flow_deposit(cur, prev, flow, t, view_size=META["viewSize"], speedLimit=s["speedLimit"])
         if s["autoClearView"]:
             view = np.zeros_like(view)
