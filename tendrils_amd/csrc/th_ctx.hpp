@@ -202,7 +202,7 @@ struct th_context {
     std::vector<SlotOrder> orders;
     std::vector<std::pair<float4 *, int>> buf_order;   // ring buffers held in a sorted order (absent = texel order)
     float4 *spare = nullptr;             // spare state buffer (ensure_identity moves through it)
-    uint32_t *tile_mem = nullptr;        // hist | cursor (kSortReplicas x kMaxTileBins words each) | misses
+    uint32_t *tile_mem = nullptr;        // hist | cursor (kSortReplicas x kMaxTileBins words each) | misses (8 words) | totals | starts (kMaxTileBins each)
     th::ChunkRecord *block_records = nullptr;   // per 4096-slot block: tile_hist's table for tile_scatter
     uint32_t max_chunks = 0;
     int steps_since_sort = 0;

@@ -89,7 +89,25 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
     const uint32_t stride = gridDim.x * 256u, end = p.count;
     uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     const uint32_t *perm = p.perm;
-    if constexpr (!PIPE) {
+    if constexpr (PIPE >= 3) {
+        // Blocked sweep: a workgroup owns a contiguous span of the slots (one after the other 256 at a time) instead of every
+        // gridDim-th block.  Over tile-sorted slots its taps then stay in one tile for a dozen iterations and are served by
+        // the CU's own L1 (PIPE 4: the spans dealt to the 8 XCDs in eighths as well - blockIdx % 8 = XCD -, so one XCD's L2
+        // sees one band of the field).
+        const uint32_t span = ((end + stride - 1u) / stride) * 256u;
+        const uint32_t b = PIPE == 4 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+        const uint32_t lo = b * span, hi = lo + span < end ? lo + span : end;
+        idx = lo + threadIdx.x;
+        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t pnxt = idx;
+        if (idx < hi) { nxt = load_stream(&p.in[idx]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx]); }
+        for (; idx < hi; idx += 256u) {
+            float4 st = nxt;
+            const uint32_t pid = perm ? pnxt : idx;
+            if (idx + 256u < hi) { nxt = load_stream(&p.in[idx + 256u]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx + 256u]); }
+            store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, st, pid, time, &tabs));
+        }
+    } else if constexpr (!PIPE) {
         float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         uint32_t pnxt = idx;
         if (idx < end) { nxt = load_stream(&p.in[idx]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx]); }
@@ -304,7 +322,7 @@ static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipSt
     static const int per_cu = getenv("TH_STEP_GRID") ? atoi(getenv("TH_STEP_GRID")) : 20;
     const int grid = grid_for(p.count, per_cu);
     static const int variant = getenv("TH_STEP_VARIANT") ? atoi(getenv("TH_STEP_VARIANT")) : 1;      // (experiment switch)
-    if (variant >= 3 && p.perm && decoded) {
+    if ((variant == 3 || variant == 4) && p.perm && decoded) {
         static const int ring_per_cu = getenv("TH_RING_GRID") ? atoi(getenv("TH_RING_GRID")) : 6;
         const size_t threads = variant == 4 ? 1024 : 512, blocks = (p.count + threads - 1) / threads, cap = (size_t)256 * ring_per_cu;
         const int rgrid = (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
@@ -314,7 +332,9 @@ static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipSt
                else hipLaunchKernelGGL((logic_ring_kernel<FAST, NOISE, TARGET, false, 8>), dim3(rgrid), dim3(512), 0, s, p); }
         return;
     }
-#define TH_GO(P2, DEC) do { if (p.perm) { if (variant == 2) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 2>), dim3(grid), dim3(256), 0, s, p); \
+#define TH_GO(P2, DEC) do { if (p.perm) { if (variant == 6) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 4>), dim3(grid & ~7), dim3(256), 0, s, p); \
+                                          else if (variant == 5) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 3>), dim3(grid), dim3(256), 0, s, p); \
+                                          else if (variant == 2) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 2>), dim3(grid), dim3(256), 0, s, p); \
                                           else if (variant == 1) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 1>), dim3(grid), dim3(256), 0, s, p); \
                                           else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 0>), dim3(grid), dim3(256), 0, s, p); } \
                             else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, false, 0>), dim3(grid), dim3(256), 0, s, p); } while (0)
@@ -711,9 +731,32 @@ __global__ __launch_bounds__(256) void tile_hist_kernel(const TileSortParams b)
     bins_flush(bins, b.hist, replica_of(blockIdx.x), b.block_records ? &b.block_records[blockIdx.x] : nullptr);
 }
 
-// One workgroup: exclusive scan of the histogram (bins = tiles + the no-tap class, summed over the copies) into the
-// first slot of every bin, the rank cursors of every copy (copy r of a bin starts where copies < r end) and the
-// chunk table.  Clears the histogram.
+// Exclusive scan of the histogram (bins = tiles + the no-tap class, summed over the copies) into the first slot of every
+// bin, the rank cursors of every copy (copy r of a bin starts where copies < r end) and the chunk table; clears the
+// histogram.  Three launches: one workgroup doing all of it walked 64 copies x 4 bins per thread, one dependent global access
+// after the other, twice - 70-220 us in which nothing else ran, inside the one frame in 64 that re-sorts.
+//   tile_scan_sum_kernel    a thread per bin: the copies' counts (64 independent, coalesced loads) summed; every copy's cursor
+//                           relative to the bin's first slot; the histogram cleared; the bin's total to b.totals
+//   tile_scan_kernel        one workgroup: the totals scanned (4 bins per thread), every bin's first slot to b.starts, the chunk table
+//   tile_scan_place_kernel  a thread per bin: the bin's first slot added to its copies' cursors
+__global__ __launch_bounds__(256) void tile_scan_sum_kernel(const TileSortParams b)
+{
+    const uint32_t bins = 2u * b.g.ntiles + 2u, k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= bins) return;
+    uint32_t h[kSortReplicas];
+#pragma unroll
+    for (uint32_t r = 0; r < kSortReplicas; ++r) h[r] = b.hist[(size_t)r * kMaxTileBins + k];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < kSortReplicas; ++r) {
+        const size_t w = (size_t)r * kMaxTileBins + k;
+        b.hist[w] = 0u;
+        b.cursor[w] = sum;
+        sum += h[r];
+    }
+    b.totals[k] = sum;
+}
+
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileSortParams b)
 {
     __shared__ uint32_t part_n[1024], part_c[1024];
@@ -721,8 +764,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileSortParams b)
     const uint32_t lo = threadIdx.x * per < bins ? threadIdx.x * per : bins, hi = lo + per < bins ? lo + per : bins;
     uint32_t n = 0, c = 0;
     for (uint32_t k = lo; k < hi; ++k) {
-        uint32_t h = 0;
-        for (uint32_t r = 0; r < kSortReplicas; ++r) h += b.hist[(size_t)r * kMaxTileBins + k];
+        const uint32_t h = b.totals[k];
         n += h; c += (h + kTileChunk - 1u) / kTileChunk;
     }
     part_n[threadIdx.x] = n; part_c[threadIdx.x] = c;
@@ -736,19 +778,22 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const TileSortParams b)
     }
     uint32_t slot = part_n[threadIdx.x] - n, chunk = part_c[threadIdx.x] - c;
     for (uint32_t k = lo; k < hi; ++k) {
-        uint32_t h = 0;
-        for (uint32_t r = 0; r < kSortReplicas; ++r) {
-            const size_t w = (size_t)r * kMaxTileBins + k;
-            const uint32_t hr = b.hist[w];
-            b.hist[w] = 0;
-            b.cursor[w] = slot + h;
-            h += hr;
-        }
+        const uint32_t h = b.totals[k];
+        b.starts[k] = slot;
         for (uint32_t done = 0; done < h; done += kTileChunk, ++chunk)
             b.chunks[chunk] = TileChunk{slot + done, h - done < kTileChunk ? h - done : kTileChunk, k, 0u};
         slot += h;
     }
     if (threadIdx.x == 1023u) *b.nchunks = part_c[1023];
+}
+
+__global__ __launch_bounds__(256) void tile_scan_place_kernel(const TileSortParams b)
+{
+    const uint32_t bins = 2u * b.g.ntiles + 2u, k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= bins) return;
+    const uint32_t start = b.starts[k];
+#pragma unroll
+    for (uint32_t r = 0; r < kSortReplicas; ++r) b.cursor[(size_t)r * kMaxTileBins + k] += start;
 }
 
 // new slot of every valid lane: one returning atomic per run of equal (copy, key) words
@@ -843,7 +888,10 @@ void launch_tile_hist(const TileSortParams &b, hipStream_t s)
 
 void launch_tile_scan(const TileSortParams &b, hipStream_t s)
 {
+    const uint32_t bins = 2u * b.g.ntiles + 2u, grid = (bins + 255u) / 256u;
+    hipLaunchKernelGGL(tile_scan_sum_kernel, dim3(grid), dim3(256), 0, s, b);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(tile_scan_place_kernel, dim3(grid), dim3(256), 0, s, b);
 }
 
 void launch_tile_scatter(const TileSortParams &b, hipStream_t s)

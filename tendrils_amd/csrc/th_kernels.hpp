@@ -76,6 +76,7 @@ struct TileSortParams {
     TileGeom g;
     uint32_t *hist;              // [kSortReplicas][kMaxTileBins], zero on entry of tile_hist, cleared by tile_scan
     uint32_t *cursor;            // [kSortReplicas][kMaxTileBins] next free slot of every bin, per copy
+    uint32_t *totals, *starts;   // [kMaxTileBins] each: a bin's count over all copies / its first slot (between the scan's launches)
     TileChunk *chunks;           // chunk table of the NEW order
     uint32_t *nchunks;
     float4 *state_out;           // tile_scatter only

@@ -114,8 +114,8 @@ th_status sort_storage(th_context *c)
     if (c->tile_mem) return TH_OK;
     const size_t n = c->texels();
     TH_HIP(hipMalloc((void **)&c->spare, n * sizeof(float4)));
-    TH_HIP(hipMalloc((void **)&c->tile_mem, (kTileWords + 8) * sizeof(uint32_t)));
-    TH_HIP(hipMemsetAsync(c->tile_mem, 0, (kTileWords + 8) * sizeof(uint32_t), c->stream));
+    TH_HIP(hipMalloc((void **)&c->tile_mem, (kTileWords + 8 + 2 * th::kMaxTileBins) * sizeof(uint32_t)));
+    TH_HIP(hipMemsetAsync(c->tile_mem, 0, (kTileWords + 8 + 2 * th::kMaxTileBins) * sizeof(uint32_t), c->stream));
     TH_HIP(hipMalloc((void **)&c->block_records, ((n + th::kTileChunk - 1) / th::kTileChunk) * sizeof(th::ChunkRecord)));
     TH_HIP(hipHostMalloc((void **)&c->miss_host, 2 * sizeof(uint32_t)));
     c->miss_host[0] = c->miss_host[1] = 0;
@@ -170,6 +170,7 @@ th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, 
     b.state = state; b.perm_in = perm_in; b.count = (uint32_t)c->texels();
     b.g = g;
     b.hist = c->tile_mem; b.cursor = c->tile_mem + kTileWords / 2;
+    b.totals = c->tile_mem + kTileWords + 8; b.starts = b.totals + th::kMaxTileBins;
     b.chunks = o.chunks; b.nchunks = o.nchunks;
     b.perm_out = o.perm;
     b.block_records = have_hist ? nullptr : c->block_records;      // (only a tile_hist pass over the same blocks fills them)

@@ -178,7 +178,7 @@ def test_node_host_runs_the_demo_loop_with_buffers():
     cur, prev = inputs(n, view, 3)
     script = """
     const T = require('./tendrils_amd/js');
-    const cfg = JSON.parse(process.argv[1]);
+    const cfg = JSON.parse(require('fs').readFileSync(0, 'utf8'));
     const f32 = (b) => new Float32Array(new Uint8Array(Buffer.from(b, 'base64')).buffer);
     const gl = {drawingBufferWidth: cfg.view[0], drawingBufferHeight: cfg.view[1]};
     const opts = T.defaults();
@@ -207,7 +207,7 @@ def test_node_host_runs_the_demo_loop_with_buffers():
     cfg = dict(n=n, view=view, state=state,
                cur=base64.b64encode(np.ascontiguousarray(cur, np.float32).tobytes()).decode(),
                prev=base64.b64encode(np.ascontiguousarray(prev, np.float32).tobytes()).decode())
-    r = subprocess.run([shutil.which("node"), "-e", script, json.dumps(cfg)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([shutil.which("node"), "-e", script], input=json.dumps(cfg), cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout)
     img = lambda k: np.frombuffer(base64.b64decode(res[k]), np.uint8).reshape(view[1], view[0], 4)      # noqa: E731
