@@ -28,10 +28,15 @@ bound by VALU issue, not by HBM.  The line therefore carries
   * roofline.achieved/peak/equivalent_frac : the SURVEY.md 8d figure - ALGORITHMIC bytes (32 B x
     particles x steps of one launch) / mean launch duration, against 8 TB/s.  An equivalent
     single-step bandwidth, not a physical one (for a register-resident fused launch it can exceed
-    the peak); roofline.frac is the fraction of the bound the entry NAMES (`bound`): VALU issue for
-    the fused noise-on launch, the larger of physical HBM and VALU for the fused flow-only one,
-    HBM (algorithmic bytes, which a single-step launch really streams) for one step per launch -
-    never above 1;
+    the peak).  Two rules for `bound` / `frac`, and every entry says which it follows in `frac_is`:
+      - the HEADLINE entry (the line's own `roofline.bound / .frac`) is the contract's: bound "hbm",
+        frac = achieved / peak - for a fused launch an equivalent bandwidth; what the launch physically
+        runs out of stands beside it as `limited_by` / `limited_by_frac` (VALU issue).  Used only while
+        the equivalent figure is <= 1;
+      - every SUB-entry (flow_only, single_step_kernel, c5 ...) and a headline whose equivalent figure
+        would exceed 1 follow benchlib/roofline.bind(): the fraction of the resource the entry names -
+        VALU issue or physical HBM traffic for a fused launch, HBM (algorithmic bytes, which a
+        single-step launch really streams) for one step per launch - never above 1;
   * roofline.hbm_physical       : rocprofv3 PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE KiB,
     as MI355X_MICROARCH.md prescribes) / the same duration;
   * roofline.valu               : SQ_INSTS_VALU per launch / duration against the chip's VALU issue

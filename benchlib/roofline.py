@@ -15,7 +15,12 @@ def roofline_entry(job, launch_s, steps_in_launch, counters, bytes_per_step):
     e["traffic"] = tb
     if tb is not None:
         e["hbm_physical"] = {"achieved": tb / launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": tb / launch_s / 1e9 / HBM_PEAK_GBS, "bytes_over_algorithmic": tb / alg}
+                             "frac": tb / launch_s / 1e9 / HBM_PEAK_GBS, "bytes_over_algorithmic": tb / alg,
+                             "counted_at": "the L2s' memory-side interface (TCC_EA0 read / write requests: every read of the integrator is "
+                                           "128 B and DRAM-destined - profiles/r5_a_single_step_memory_path_pmc.txt); requests the 256 MB "
+                                           "Infinity Cache serves are in it - the decoded flow plane lives there, so of a single step's "
+                                           "traffic HBM itself moves the streams (state in + out, 4 B of slot order per particle) and the "
+                                           "plane once: ~1.15 x the algorithmic bytes"}
     if counters and "SQ_INSTS_VALU" in counters:
         v = counters["SQ_INSTS_VALU"]
         e["valu"] = {"wave_insts_per_launch": v, "per_wave_step": v / (job.particles_rank / 64.0 * steps_in_launch),
@@ -35,7 +40,9 @@ def roofline_entry(job, launch_s, steps_in_launch, counters, bytes_per_step):
 
 def bind(e, fused):
     """`bound` and `frac` of an entry: the fraction of the bound it names, never the equivalent bandwidth of a
-    register-resident launch.  One step per launch streams its algorithmic bytes: HBM, frac = algorithmic / peak.
+    register-resident launch.  (bench.py relabels ONE entry after this - the line's headline, to the bench contract's
+    `frac = achieved / peak` against the HBM roofline, keeping what this function found as `limited_by` / `limited_by_frac`;
+    its docstring says so, and `frac_is` of every entry names the rule it follows.)  One step per launch streams its algorithmic bytes: HBM, frac = algorithmic / peak.
     A fused launch is bound by whichever of VALU issue and physical HBM traffic it uses more of (PMC child runs);
     without counters the bound is not known and frac stays null."""
     if not fused:

@@ -60,19 +60,11 @@ int hash_table_vectors() { return kHashVec; }
 
 
 
-// Plain grid-stride.  Slots are in texel order (slot == particle id) or - p.perm - in a tile-sorted order (the particle of
-// slot s is perm[s]): a wave's taps then fall into one neighbourhood of the decoded field, and the gather costs what a
-// staged window would.  The hash stages of the noise run through the LDS tables of the fused kernel.
-//
-// Software pipeline, two slots deep (PIPE; round 5).  Loads return in issue order on gfx9 (one vmcnt), so waiting for a
-// slot's tap also waits for every load issued before it: with the tap of slot i issued INSIDE iteration i (behind the
-// state load of slot i + 1), both had only the noise arithmetic of one iteration to arrive, and the waves stood at that
-// wait 45 % of their cycles (profiles/r4_a_*: SQ_WAIT_INST_ANY).  Here iteration i starts with everything it needs already
-// asked for a whole iteration ago - state i, its tap, state i + 1 - issues the tap of slot i + 1 (whose address state i + 1
-// gives) and the state of slot i + 2, and then integrates slot i: every load has a full iteration to arrive and there is
-// one wait per iteration, at its top.  Loads are unconditional (clamped slots): a load under a branch makes hipcc wait for
-// it at the join.
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB, int PIPE>
+// Plain grid-stride, the next state texel of each lane prefetched one iteration ahead.  Slots are in texel order (slot ==
+// particle id) or - p.perm - in a tile-sorted order (the particle of slot s is perm[s]): a wave's taps then fall into
+// one neighbourhood of the decoded field, and the gather costs what a staged window would.  The hash
+// stages of the noise run through the LDS tables of the fused kernel.
+template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB>
 __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
 {
     const float time = p.time_dev ? *p.time_dev : p.u.time;     // captured-graph replays keep `time` in device memory
@@ -88,185 +80,15 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
     }
     const uint32_t stride = gridDim.x * 256u, end = p.count;
     uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const uint32_t *perm = p.perm;
-    if constexpr (PIPE >= 3) {
-        // Blocked sweep: a workgroup owns a contiguous span of the slots (one after the other 256 at a time) instead of every
-        // gridDim-th block.  Over tile-sorted slots its taps then stay in one tile for a dozen iterations and are served by
-        // the CU's own L1 (PIPE 4: the spans dealt to the 8 XCDs in eighths as well - blockIdx % 8 = XCD -, so one XCD's L2
-        // sees one band of the field).
-        const uint32_t span = ((end + stride - 1u) / stride) * 256u;
-        const uint32_t b = PIPE == 4 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-        const uint32_t lo = b * span, hi = lo + span < end ? lo + span : end;
-        idx = lo + threadIdx.x;
-        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t pnxt = idx;
-        if (idx < hi) { nxt = load_stream(&p.in[idx]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx]); }
-        for (; idx < hi; idx += 256u) {
-            float4 st = nxt;
-            const uint32_t pid = perm ? pnxt : idx;
-            if (idx + 256u < hi) { nxt = load_stream(&p.in[idx + 256u]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx + 256u]); }
-            store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, st, pid, time, &tabs));
-        }
-    } else if constexpr (!PIPE) {
-        float4 nxt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t pnxt = idx;
-        if (idx < end) { nxt = load_stream(&p.in[idx]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx]); }
-        for (; idx < end; idx += stride) {
-            float4 st = nxt;
-            const uint32_t pid = perm ? pnxt : idx;
-            if (idx + stride < end) { nxt = load_stream(&p.in[idx + stride]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx + stride]); }
-            store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, st, pid, time, &tabs));
-        }
-    } else {
-        if (idx >= end) return;
-        const uint32_t last = end - 1u;
-        auto slot = [&](uint32_t s) { return s < last ? s : last; };        // (beyond the end: the last slot again, never used)
-        auto tap_of = [&](const float4 &st) {
-            return flow_tap_load<DECODED>(p, in_logic_domain(p, st.x, st.y) ? flow_tap_texel(p, st.x, st.y) : 0);
-        };
-        auto settle = [](FlowTap<DECODED> &t) {         // a use of the tap: hipcc waits for it (and every older load) here
-            if constexpr (DECODED) asm volatile("" : "+v"(t.d.x), "+v"(t.d.y)); else asm volatile("" : "+v"(t.t.x), "+v"(t.t.y), "+v"(t.t.z), "+v"(t.t.w));
-        };
-        if constexpr (PIPE == 1) {
-            float4 cur = load_stream(&p.in[idx]), nxt = load_stream(&p.in[slot(idx + stride)]);
-            uint32_t pcur = idx, pnxt = idx + stride;
-            if (perm) { pcur = __builtin_nontemporal_load(&perm[idx]); pnxt = __builtin_nontemporal_load(&perm[slot(idx + stride)]); }
-            FlowTap<DECODED> tcur = tap_of(cur);
-            settle(tcur);       // (nothing pending on entry: the loop's waits are then those of its own steady state)
-            for (;;) {
-                const FlowTap<DECODED> tnxt = tap_of(nxt);
-                const uint32_t s2 = slot(idx + 2u * stride);
-                const float4 nn = load_stream(&p.in[s2]);
-                uint32_t pnn = idx + 2u * stride;
-                if (perm) pnn = __builtin_nontemporal_load(&perm[s2]);
-                store_stream(&p.out[idx], integrate_tapped<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, cur, pcur, time, &tabs, tcur));
-                idx += stride;
-                if (idx >= end) break;
-                cur = nxt; pcur = pnxt; tcur = tnxt; nxt = nn; pnxt = pnn;
-            }
-        } else {
-            // State three slots ahead - two iterations to arrive - and the tap one.  Three register sets take turns (the loop
-            // is unrolled by three): handing an in-flight value from one variable to the next is a register copy, and a copy
-            // waits for the load.  A set's state is asked for at the END of the iteration that integrated its last occupant.
-            struct Set { float4 st; uint32_t pid; FlowTap<DECODED> tap; };
-            auto fetch = [&](Set &q, uint32_t s) {
-                const uint32_t at = slot(s);
-                q.st = load_stream(&p.in[at]);
-                q.pid = perm ? __builtin_nontemporal_load(&perm[at]) : s;
-            };
-            Set A, B, C;
-            fetch(A, idx); fetch(B, idx + stride); fetch(C, idx + 2u * stride);
-            A.tap = tap_of(A.st);
-            B.tap = C.tap = FlowTap<DECODED>{};
-            settle(A.tap);
-            auto pass = [&](Set &c, Set &n) {
-                n.tap = tap_of(n.st);
-                store_stream(&p.out[idx], integrate_tapped<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, c.st, c.pid, time, &tabs, c.tap));
-                fetch(c, idx + 3u * stride);
-                idx += stride;
-                return idx < end;
-            };
-            for (;;) {
-                if (!pass(A, B)) break;
-                if (!pass(B, C)) break;
-                if (!pass(C, A)) break;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// logic_ring_kernel - the single step over tile-sorted slots with its memory pipeline in LDS (round 5).
-// What a lane reads from memory for slot i - its state texel, its particle id, its flow tap - arrives by LDS-DMA
-// (global_load_lds_*: no VGPR destination) in a ring that belongs to the lane's own wave, and is read from there when its
-// turn comes: state THREE iterations ahead (two whole iterations to arrive from HBM), particle id and tap one iteration
-// ahead (the tap's address needs the state).  Registers hold one particle.  In logic_kernel everything in flight lives in
-// VGPRs, hipcc's in-order wait for the tap drains the prefetched state with it, and handing an in-flight value on to the
-// next iteration is a register copy that waits for the load: one iteration of lead at most, at 76-86 VGPRs.
-//   iteration i (phase = i mod 3), after the wait that left only {state i + 2, store i - 1} outstanding:
-//     ds_read  state i (slot phase), id i, tap i, position of state i + 1 (slot phase + 1)
-//     DMA      tap i + 1 (x, y planes), id i + 1, state i + 3 (into slot phase: just read)
-//     integrate particle i, store
-//     s_waitcnt vmcnt(2)          everything but {state i + 3, store i}
-// The DMAs and the waits are asm (hipcc counts none of them and drains every LDS-DMA at the next ordinary load's use,
-// cdna_hip_programming.md 5): all of the launch's loads are asm, its LDS reads and its store are the compiler's.  A wave
-// reads only what it asked for itself: its counted vmcnt is all the ordering it needs (MI355X_MICROARCH.md, co-residence 7).
-// Lanes beyond the end ask for the last slot again and store nothing.
-// ---------------------------------------------------------------------------
-TH_D void ring_dma16(const void *src, uint32_t lds)      // 16 B per lane -> lds + 16 * lane (`lds` wave-uniform), streaming
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
-}
-template <bool NT>
-TH_D void ring_dma4(const void *src, uint32_t lds)       // 4 B per lane -> lds + 4 * lane
-{
-    unsigned keep;
-    if constexpr (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(lds) : "memory");
-}
-TH_D uint32_t lds_address(const void *q) { return (uint32_t)(uintptr_t)q; }     // (the LDS aperture's low word is the offset)
-
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 16 ? 8 : 6) void logic_ring_kernel(const LogicParams p)      // (the second number: waves per SIMD)
-{
-    constexpr uint32_t kThreads = 64u * WAVES;
-    const float time = p.time_dev ? *p.time_dev : p.u.time;
-    __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
-    __shared__ float4 ring_state[WAVES][3][64];
-    __shared__ uint32_t ring_id[WAVES][64];
-    __shared__ float ring_tap[WAVES][2][64];
-    const float4 *lut = smem + (NOISE ? kHashVec : 0);
-    const HashTables tabs{reinterpret_cast<const uint32_t *>(smem), reinterpret_cast<const uint32_t *>(smem) + kPermA};
-    if constexpr (NOISE) {
-        const float4 *block = p.lut - kHashVec;
-        for (uint32_t k = threadIdx.x; k < (uint32_t)(kHashVec + kLutSize); k += kThreads) smem[k] = block[k];
-        __syncthreads();
-    }
-    const uint32_t stride = gridDim.x * kThreads, end = p.count;
-    uint32_t idx = blockIdx.x * kThreads + threadIdx.x;
-    if (idx >= end) return;
-    const uint32_t last = end - 1u;
-    auto slot = [&](uint32_t s) { return s < last ? s : last; };
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t st_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring_state[wave][0][0]));
-    const uint32_t id_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring_id[wave][0]));
-    const uint32_t tap_lds = __builtin_amdgcn_readfirstlane(lds_address(&ring_tap[wave][0][0]));
-    const float4 *my_state = &ring_state[wave][0][lane];        // + 64 per ring slot
-    auto ask_tap_and_id = [&](float px, float py, uint32_t s) {
-        const float *d = reinterpret_cast<const float *>(p.flow_dec + (in_logic_domain(p, px, py) ? flow_tap_texel(p, px, py) : 0));
-        ring_dma4<false>(d, tap_lds);
-        ring_dma4<false>(d + 1, tap_lds + 256u);
-        ring_dma4<true>(&p.perm[slot(s)], id_lds);
-    };
-
-    ring_dma16(&p.in[idx], st_lds);
-    ring_dma16(&p.in[slot(idx + stride)], st_lds + 1024u);
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    { const float4 first = my_state[0]; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ask_tap_and_id(first.x, first.y, idx); }
-    ring_dma16(&p.in[slot(idx + 2u * stride)], st_lds + 2048u);
-    asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    uint32_t phase = 0;                          // i mod 3 (wave-uniform)
-    for (;;) {
-        const uint32_t nphase = phase == 2u ? 0u : phase + 1u;
-        const float4 cur = my_state[phase * 64u];
-        const uint32_t pid = ring_id[wave][lane];
-        FlowTap<true> tap;
-        tap.d.x = ring_tap[wave][0][lane]; tap.d.y = ring_tap[wave][1][lane];
-        const float2 npos = *reinterpret_cast<const float2 *>(&my_state[nphase * 64u]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slots are read: they may be asked for again
-        ask_tap_and_id(npos.x, npos.y, idx + stride);
-        ring_dma16(&p.in[slot(idx + 3u * stride)], st_lds + phase * 1024u);
-        store_stream(&p.out[idx], integrate_tapped<FAST, NOISE, TARGET, POW2, true, NOISE>(p, lut, cur, pid, time, &tabs, tap));
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        idx += stride;
-        if (idx >= end) break;
-        phase = nphase;
+    uint32_t pnxt = idx;
+    if (idx < end) { nxt = load_stream(&p.in[idx]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx]); }
+    for (; idx < end; idx += stride) {
+        float4 st = nxt;
+        const uint32_t pid = perm ? pnxt : idx;
+        if (idx + stride < end) { nxt = load_stream(&p.in[idx + stride]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx + stride]); }
+        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, st, pid, time, &tabs));
     }
 }
 
@@ -319,25 +141,9 @@ template <bool FAST, bool NOISE, bool TARGET>
 static void launch_logic_p2(const LogicParams &p, bool pow2, bool decoded, hipStream_t s)
 {
     // 7 workgroups per CU are resident: 2048 workgroups (8 per CU) ran as 1792 + a second round of 256; 20 per CU ends evenly
-    static const int per_cu = getenv("TH_STEP_GRID") ? atoi(getenv("TH_STEP_GRID")) : 20;
-    const int grid = grid_for(p.count, per_cu);
-    static const int variant = getenv("TH_STEP_VARIANT") ? atoi(getenv("TH_STEP_VARIANT")) : 1;      // (experiment switch)
-    if ((variant == 3 || variant == 4) && p.perm && decoded) {
-        static const int ring_per_cu = getenv("TH_RING_GRID") ? atoi(getenv("TH_RING_GRID")) : 6;
-        const size_t threads = variant == 4 ? 1024 : 512, blocks = (p.count + threads - 1) / threads, cap = (size_t)256 * ring_per_cu;
-        const int rgrid = (int)(blocks < cap ? (blocks ? blocks : 1) : cap);
-        if (variant == 4) { if (pow2) hipLaunchKernelGGL((logic_ring_kernel<FAST, NOISE, TARGET, true, 16>), dim3(rgrid), dim3(1024), 0, s, p);
-                            else hipLaunchKernelGGL((logic_ring_kernel<FAST, NOISE, TARGET, false, 16>), dim3(rgrid), dim3(1024), 0, s, p); }
-        else { if (pow2) hipLaunchKernelGGL((logic_ring_kernel<FAST, NOISE, TARGET, true, 8>), dim3(rgrid), dim3(512), 0, s, p);
-               else hipLaunchKernelGGL((logic_ring_kernel<FAST, NOISE, TARGET, false, 8>), dim3(rgrid), dim3(512), 0, s, p); }
-        return;
-    }
-#define TH_GO(P2, DEC) do { if (p.perm) { if (variant == 6) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 4>), dim3(grid & ~7), dim3(256), 0, s, p); \
-                                          else if (variant == 5) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 3>), dim3(grid), dim3(256), 0, s, p); \
-                                          else if (variant == 2) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 2>), dim3(grid), dim3(256), 0, s, p); \
-                                          else if (variant == 1) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 1>), dim3(grid), dim3(256), 0, s, p); \
-                                          else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true, 0>), dim3(grid), dim3(256), 0, s, p); } \
-                            else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, false, 0>), dim3(grid), dim3(256), 0, s, p); } while (0)
+    const int grid = grid_for(p.count, 20);
+#define TH_GO(P2, DEC) do { if (p.perm) hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, true>), dim3(grid), dim3(256), 0, s, p); \
+                            else hipLaunchKernelGGL((logic_kernel<FAST, NOISE, TARGET, P2, DEC, false>), dim3(grid), dim3(256), 0, s, p); } while (0)
     if (pow2) { if (decoded) TH_GO(true, true); else TH_GO(true, false); }
     else { if (decoded) TH_GO(false, true); else TH_GO(false, false); }
 #undef TH_GO

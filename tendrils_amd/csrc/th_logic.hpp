@@ -308,58 +308,9 @@ TH_D float snoise_finish(const NoiseCorners &n, float4 g0, float4 g1, float4 g2,
 // ---------------------------------------------------------------------------
 // One particle: state texel `st` of particle `pid` (= texel index in this context's rows).
 constexpr int kTileShift = 5;            // 32 x 32-texel tiles of the flow field: the key of the tile-sorted slot order
-
-// The flow tap of one particle (flowAtScreenPos: posToUV, then one NEAREST / CLAMP texel), split from the arithmetic so that a
-// kernel can have the tap of its NEXT particle in flight while it integrates this one (logic_kernel).
-//   flow_tap_texel  the texel a position taps; 0 for positions outside the specialised path's domain (those lanes never use
-//                   the tap: integrate_tapped() hands them to logic_texel_ref, which reads for itself)
-//   FlowTap         what the tap returns: the decoded float2 (DECODED) or the raw texel
-TH_D bool in_logic_domain(const LogicParams &p, float posx, float posy)
-{
-    // two compares (not max): a NaN in either component must fail the test.  pos_bound < |inert| (host), so inert
-    // particles (src/logic.frag:52) fail it too and are passed through by logic_texel_ref.
-    return __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
-}
-TH_D int flow_tap_texel(const LogicParams &p, float posx, float posy)
-{
-    const th_logic_uniforms &u = p.u;
-    float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
-    // posToUV = (1*(v+1))/2, then *size: halving is exact, so ((v+1)*0.5)*size == (v+1)*(0.5*size) - one rounding
-    // either way (half_fw = 0.5*fw from the host; a denormal (v+1)/2 lands in texel 0 on both routes)
-    int tx = (int)__builtin_amdgcn_fmed3f((sx + 1.0f) * p.half_fw, 0.0f, p.fwm1);      // trunc == floor on [0, n-1]
-    int ty = (int)__builtin_amdgcn_fmed3f((sy + 1.0f) * p.half_fh, 0.0f, p.fhm1);
-    return ty * p.fw + tx;
-}
-template <bool DECODED> struct FlowTap;
-template <> struct FlowTap<true> { float2 d; };
-template <> struct FlowTap<false> { float4 t; };
-template <bool DECODED>
-TH_D FlowTap<DECODED> flow_tap_load(const LogicParams &p, int texel)
-{
-    FlowTap<DECODED> r;
-    if constexpr (DECODED) r.d = p.flow_dec[texel];
-    else if (p.flow3) { const float *f3 = p.flow3 + 3u * (uint32_t)texel; r.t = make_float4(f3[0], f3[1], f3[2], 0.0f); }     // (uniform branch)
-    else r.t = p.flow[texel];
-    return r;
-}
-
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false>
-TH_D float4 integrate_tapped(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
-                             const HashTables *tabs, const FlowTap<DECODED> &tap);
-
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB = false>
 TH_D float4 integrate(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
                       const HashTables *tabs = nullptr)
-{
-    // flow tap (issued first: its latency hides under the noise arithmetic)
-    FlowTap<DECODED> tap{};
-    if (in_logic_domain(p, st.x, st.y)) tap = flow_tap_load<DECODED>(p, flow_tap_texel(p, st.x, st.y));
-    return integrate_tapped<FAST, NOISE, TARGET, POW2, DECODED, PTAB>(p, lut, st, pid, time, tabs, tap);
-}
-
-template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool DECODED, bool PTAB>
-TH_D float4 integrate_tapped(const LogicParams &p, const float4 *lut, float4 st, uint32_t pid, float time,
-                             const HashTables *tabs, const FlowTap<DECODED> &tap)
 {
     const th_logic_uniforms &u = p.u;
     float posx = st.x, posy = st.y, velx = st.z, vely = st.w;
@@ -369,7 +320,9 @@ TH_D float4 integrate_tapped(const LogicParams &p, const float4 *lut, float4 st,
     else { y = pid / p.width; x = pid - y * p.width; }
     y += p.row0;
 
-    const bool in_domain = in_logic_domain(p, posx, posy);
+    // two compares (not max): a NaN in either component must fail the test.  pos_bound < |inert| (host), so inert
+    // particles (src/logic.frag:52) fail it too and are passed through by logic_texel_ref.
+    bool in_domain = __builtin_fabsf(posx) < p.pos_bound && __builtin_fabsf(posy) < p.pos_bound;
     if (__builtin_expect(!in_domain, 0)) {
         if (!(posx != kInert || posy != kInert)) return st;              // inert: pass through (src/logic.frag:52)
         // A NaN or infinite position component makes every output component NaN in the reference: the first noise
@@ -399,10 +352,18 @@ TH_D float4 integrate_tapped(const LogicParams &p, const float4 *lut, float4 st,
         i = (fcx + (fcy * p.wf)) / (p.wf * p.hf);
     }
 
+    // flow tap (issued first: its latency hides under the noise arithmetic)
+    float sx = posx * u.viewSize[0], sy = posy * u.viewSize[1];
+    // posToUV = (1*(v+1))/2, then *size: halving is exact, so ((v+1)*0.5)*size == (v+1)*(0.5*size) - one rounding
+    // either way (half_fw = 0.5*fw from the host; a denormal (v+1)/2 lands in texel 0 on both routes)
+    int tx = (int)__builtin_amdgcn_fmed3f((sx + 1.0f) * p.half_fw, 0.0f, p.fwm1);      // trunc == floor on [0, n-1]
+    int ty = (int)__builtin_amdgcn_fmed3f((sy + 1.0f) * p.half_fh, 0.0f, p.fhm1);
+    const int texel = ty * p.fw + tx;
     float ffx, ffy;      // getFlow(): data.xy * max(0, 1 - (time - data.z)*decay), src/flow/get.glsl:4
     float4 ft;
-    if constexpr (DECODED) { ffx = tap.d.x; ffy = tap.d.y; }
-    else ft = tap.t;
+    if constexpr (DECODED) { float2 d = p.flow_dec[texel]; ffx = d.x; ffy = d.y; }
+    else if (p.flow3) { const float *f3 = p.flow3 + 3u * (uint32_t)texel; ft = make_float4(f3[0], f3[1], f3[2], 0.0f); }     // (uniform branch)
+    else ft = p.flow[texel];
 
     float wxs = 0.0f, wys = 0.0f;   // (wander * dt) * vary(noiseWeight)
     if constexpr (NOISE) {

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 5: single-step integrator variants (TH_STEP_VARIANT: 0 = one texel prefetched in registers, 1 / 2 = register pipelines,
+# (the variants live in the tree of commit 0dc8af8 - `git show 0dc8af8:tendrils_amd/csrc/th_kernels.hip`; none was faster and the
+# product kept round 4's kernel: profiles/r5_b_single_step_variants.txt)
 # 3 / 4 = LDS ring, 512 / 1024-thread workgroups) on one box: parity first, then the step probe.
 set -u
 GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

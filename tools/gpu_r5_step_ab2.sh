@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: the blocked sweeps (TH_STEP_VARIANT 5 / 6) against the interleaved one (0) over grids, with the memory-side request counters
+# (variants 5 / 6 / 7 live in the trees of commits 0dc8af8 and its successor; not kept: profiles/r5_b_single_step_variants.txt)
 set -u
 GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$GRAFT_REPO_ROOT"
@@ -9,7 +10,7 @@ for v in 5 6; do
   TH_STEP_VARIANT=$v timeout 600 python -m pytest tests/test_gpu_logic_parity.py tests/test_gpu_bucketed.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -3
 done 2>&1 | tee $O/parity.txt
 for round in 1 2; do
-  for cfg in "0 20" "5 7" "5 14" "5 20" "5 28" "5 56" "6 8" "6 16" "6 24" "6 56"; do
+  for cfg in "0 20" "5 7" "5 14" "5 20" "5 56" "6 8" "6 16" "6 56"; do
     set -- $cfg
     export TH_STEP_VARIANT=$1 TH_STEP_GRID=$2
     echo "=== variant $1 grid $2: default"; timeout 120 python tools/step_probe.py 2>&1 | grep "single step" | tail -1
@@ -35,20 +36,16 @@ out=sys.argv[1]
 for v in sorted(glob.glob(out+'/pmc_v*')):
     acc=collections.defaultdict(lambda: collections.defaultdict(list))
     dur={}
-    for f in glob.glob(v+'/*/*/*kernel_trace.csv'):
-        for r in csv.DictReader(open(f)):
-            dur[(f.split('/')[-3], r['Dispatch_Id'])]=float(r['End_Timestamp'])-float(r['Start_Timestamp'])
     for f in glob.glob(v+'/*/*/*counter_collection.csv'):
         run=f.split('/')[-3]
         for r in csv.DictReader(open(f)):
             k=r['Kernel_Name'].split('(')[0].replace('void ','')
-            if 'logic_kernel' not in k: continue
+            if 'logic_kernel' not in k and 'logic_ring' not in k: continue
             acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
-            acc[k]['_ns_'+run].append(dur.get((run,r['Dispatch_Id']),0))
+            acc[k]['_ns_'+run].append(float(r['End_Timestamp'])-float(r['Start_Timestamp']))
     print('##',v)
     for k,cs in acc.items():
         print('#',k)
         for c,vv in sorted(cs.items()):
             print('   %-40s %16.1f (n=%d)'%(c,sum(vv)/len(vv),len(vv)))
 PY
-timeout 300 python -m pytest tests/test_gpu_view_buffers.py tests/test_gpu_loopback.py tests/test_gpu_scene.py -x -q -m gpu 2>&1 | tail -8
