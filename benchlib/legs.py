@@ -106,7 +106,8 @@ def frame_loop_sharded(job, frames=12):
         step_ms.append(timed(t.step))
         job.sync_all()
         t0 = time.perf_counter()
-        t.draw()                                   # (th_draw_sharded ends with a stream synchronize: the wall clock is the draw)
+        t.draw()
+        t.particles.sync()                         # (the call enqueues and returns like any other: the wall clock needs the stream's end)
         draw_ms.append((time.perf_counter() - t0) * 1e3)
         _capi.call("th_draw_query", ctx, C.byref(info))
         sent.append(info.sent_bytes); recv.append(info.received_bytes); frags.append(t.fragments); pipes.append(info.pipeline)

@@ -670,6 +670,37 @@ void launch_owner_bounds(const unsigned long long *keys, uint32_t n, uint32_t wo
     hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys, n, world, bounds);
 }
 
+// The small words of a sharded draw's exchange, made where they are needed instead of travelling through the host (every trip
+// was a copy, a stream synchronize and a copy back - th_shard.hip):
+//   exchange_send_counts  what this rank holds for every owner = the differences of its owners' bounds (status bits: none - a
+//                         rank with something to report uploads its words itself)
+//   exchange_recv_base    where every source's part starts in the received arrays = the running sum of the received counts
+//   exchange_word         one word from the kernel arguments (the status the ranks agree on)
+__global__ void exchange_send_counts_kernel(const unsigned long long *bounds, uint32_t world, unsigned long long *send)
+{
+    if (threadIdx.x < world) send[threadIdx.x] = bounds[threadIdx.x + 1u] - bounds[threadIdx.x];
+}
+__global__ void exchange_recv_base_kernel(const unsigned long long *recv, uint32_t world, unsigned long long *base)
+{
+    if (threadIdx.x == 0u) {
+        unsigned long long run = 0;
+        for (uint32_t r = 0; r < world; ++r) { base[r] = run; run += recv[r] & 0xffffffffull; }
+    }
+}
+__global__ void exchange_word_kernel(uint32_t *dst, uint32_t word) { if (threadIdx.x == 0u) *dst = word; }
+void launch_exchange_send_counts(const unsigned long long *bounds, uint32_t world, unsigned long long *send, hipStream_t s)
+{
+    hipLaunchKernelGGL(exchange_send_counts_kernel, dim3(1), dim3(64), 0, s, bounds, world, send);
+}
+void launch_exchange_recv_base(const unsigned long long *recv, uint32_t world, unsigned long long *base, hipStream_t s)
+{
+    hipLaunchKernelGGL(exchange_recv_base_kernel, dim3(1), dim3(64), 0, s, recv, world, base);
+}
+void launch_exchange_word(uint32_t *dst, uint32_t word, hipStream_t s)
+{
+    hipLaunchKernelGGL(exchange_word_kernel, dim3(1), dim3(64), 0, s, dst, word);
+}
+
 // ... and the view pass of a row-band shard: the same merge into the RGBA8 view buffer
 void launch_view_blend64(uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                          const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t s)

@@ -311,6 +311,9 @@ void launch_deposit_gather_colors(float4 *dst, const float4 *src, const uint32_t
 void launch_deposit_blend64(float4 *flow, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                             const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);
 void launch_owner_bounds(const unsigned long long *keys, uint32_t n, uint32_t world, unsigned long long *bounds, hipStream_t stream);   // world <= 32
+void launch_exchange_send_counts(const unsigned long long *bounds, uint32_t world, unsigned long long *send, hipStream_t stream);
+void launch_exchange_recv_base(const unsigned long long *recv, uint32_t world, unsigned long long *base, hipStream_t stream);
+void launch_exchange_word(uint32_t *dst, uint32_t word, hipStream_t stream);
 void launch_view_blend64(uchar4 *view, const unsigned long long *keys_sorted, const uint32_t *slots_sorted,
                          const float4 *colors, float4 *colors_sorted, uint32_t total, uint32_t *too_many, hipStream_t stream);
 void launch_deposit_gather_pairs(float4 *dst, const float4 *src, const uint32_t *index, uint32_t n, hipStream_t stream);

@@ -192,8 +192,8 @@ static th_status agree_status(th_context *c, th_status mine, const char *stage)
     const std::string why = mine != TH_OK ? last_error() : std::string();
     // the lowest failing rank wins the maximum; a failure (2) outranks a binned pass that only wants the stream-ordered pass (1)
     const uint32_t word = mine != TH_OK ? (((uint32_t)(c->comm_world - c->comm_rank)) | (mine == kRetryInStreamOrder ? 0x10000u : 0x20000u)) : 0u;
-    hipError_t e = hipMemcpyAsync(c->d_status, &word, sizeof word, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);       // (`word` is a stack variable)
+    th::launch_exchange_word(c->d_status, word, c->stream);         // (from the kernel arguments: no host buffer to outlive, no sync)
+    const hipError_t e = hipGetLastError();
     if (c->transport->allreduce_max_u32(c->comm, c->d_status, c->stream)) return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
     uint32_t worst = 0;
     if (th_status s = read_back(c, &worst, c->d_status, sizeof worst)) return s;
@@ -244,25 +244,31 @@ static th_status sharded_pass(th_context *c, const th_deposit_uniforms *du, cons
     if (mine == TH_OK)
         mine = both ? th_draw_emit(c, du, ru, &count, &keys, &colors)
                     : (view ? th_view_emit(c, ru, &count, &keys, &colors) : th_deposit_emit(c, du, &count, &keys, &colors));
+    // (the owners' bounds stay on the device: what this rank holds for every owner is their differences, computed there, and
+    // comes back to the host together with what the others hold for it - one trip where there were two.  A rank with
+    // something to report, or nothing to send, uploads its words itself.)
     unsigned long long *bounds = c->x_counts, *sendc = c->x_counts + 33, *recvc = c->x_counts + 65;
-    if (mine == TH_OK && count) {
-        th::launch_owner_bounds(static_cast<const unsigned long long *>(keys), (uint32_t)count, (uint32_t)world, bounds, c->stream);
-        mine = read_back(c, hb.data(), bounds, ((size_t)world + 1) * sizeof(unsigned long long));
-    }
     const std::string why = mine != TH_OK ? last_error() : std::string();
-    if (mine != TH_OK) std::fill(hb.begin(), hb.end(), 0ull);
     if (fragments) *fragments = mine == TH_OK ? count : 0;
     c->last_draw.pipeline = TH_DRAW_STREAM; c->last_draw.fragments = mine == TH_OK ? count : 0; c->last_draw.crowded_fragments = 0;
     std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
-    std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
-    for (int r = 0; r < world; ++r) {
-        scount[(size_t)r] = (size_t)(hb[(size_t)r + 1] - hb[(size_t)r]); soff[(size_t)r] = (size_t)hb[(size_t)r]; idx[(size_t)r] = (size_t)r;
-        hs[(size_t)r] = scount[(size_t)r] | (mine != TH_OK ? kPeerFailed : 0ull);
-    }
-    TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    std::vector<unsigned long long> hs((size_t)world, mine != TH_OK ? kPeerFailed : 0ull), hr((size_t)world);
+    for (int r = 0; r < world; ++r) idx[(size_t)r] = (size_t)r;
+    const bool on_device = mine == TH_OK && count;
+    if (on_device) {
+        th::launch_owner_bounds(static_cast<const unsigned long long *>(keys), (uint32_t)count, (uint32_t)world, bounds, c->stream);
+        th::launch_exchange_send_counts(bounds, (uint32_t)world, sendc, c->stream);
+        TH_HIP(hipGetLastError());
+    } else TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     if (c->transport->alltoallv(c->comm, sendc, one.data(), idx.data(), recvc, one.data(), idx.data(), sizeof(unsigned long long), world, c->stream))
         return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
-    if (th_status s = read_back(c, hr.data(), recvc, (size_t)world * sizeof(unsigned long long))) return s;
+    {
+        std::vector<unsigned long long> words(97);
+        if (th_status s = read_back(c, words.data(), c->x_counts, words.size() * sizeof(unsigned long long))) return s;
+        if (on_device) std::copy(words.begin(), words.begin() + world + 1, hb.begin());
+        std::copy(words.begin() + 65, words.begin() + 65 + world, hr.begin());
+    }
+    for (int r = 0; r < world; ++r) { scount[(size_t)r] = (size_t)(hb[(size_t)r + 1] - hb[(size_t)r]); soff[(size_t)r] = (size_t)hb[(size_t)r]; }
     if (mine != TH_OK) { last_error() = why; return mine; }
     for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerFailed) return peer_failure(c, r, "rasterising its band's lines");
     size_t total = 0;
@@ -354,7 +360,8 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         }
         unsigned long long *q = static_cast<unsigned long long *>(c->own_mem);           // (the 8-byte arrays first)
         o.offsets = q; q += (size_t)p.nbins + 1;
-        o.owner_bounds = q; q += 33;
+        q += 33;                                               // (the owners' bounds lived here: they lie beside the counts now)
+        o.owner_bounds = c->x_counts;
         unsigned long long *recv_base = q; q += 32;
         o.recv_base = recv_base;
         o.src_prefix = q; q += (size_t)32 * p.nbins;
@@ -370,24 +377,29 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
         }
         th::launch_bins_owner_counts(p, o, c->stream);
         if (total) th::launch_bins_owner_extract(p, o, c->stream);
+        th::launch_exchange_send_counts(o.owner_bounds, (uint32_t)world, c->x_counts + 33, c->stream);
         TH_HIP(hipGetLastError());
-        return read_back(c, hb.data(), o.owner_bounds, ((size_t)world + 1) * sizeof(unsigned long long));
+        return TH_OK;                   // (the owners' bounds come back with the counts the others send: one trip, below)
     };
     th_status mine = stage1();
     const std::string why = mine != TH_OK ? last_error() : std::string();
-    if (mine != TH_OK) std::fill(hb.begin(), hb.end(), 0ull);
     if (fragments) *fragments = mine == TH_OK ? emitted : 0;          // (what leaves + what stays)
     unsigned long long *sendc = c->x_counts + 33, *recvc = c->x_counts + 65;
     std::vector<size_t> scount((size_t)world), soff((size_t)world), rcount((size_t)world), roff((size_t)world), one((size_t)world, 1), idx((size_t)world);
-    std::vector<unsigned long long> hs((size_t)world), hr((size_t)world);
-    for (int r = 0; r < world; ++r) {
-        scount[(size_t)r] = (size_t)(hb[(size_t)r + 1] - hb[(size_t)r]); soff[(size_t)r] = (size_t)hb[(size_t)r]; idx[(size_t)r] = (size_t)r;
-        hs[(size_t)r] = scount[(size_t)r] | (mine == TH_OK ? 0ull : (mine == kRetryInStreamOrder ? kPeerRetries : kPeerFailed));
-    }
-    TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    std::vector<unsigned long long> hs((size_t)world, mine == kRetryInStreamOrder ? kPeerRetries : kPeerFailed), hr((size_t)world);
+    for (int r = 0; r < world; ++r) idx[(size_t)r] = (size_t)r;
+    // (a rank whose stage 1 went through left its counts on the device - launch_exchange_send_counts; one that has something to
+    // report uploads its words)
+    if (mine != TH_OK) TH_HIP(hipMemcpyAsync(sendc, hs.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     if (c->transport->alltoallv(c->comm, sendc, one.data(), idx.data(), recvc, one.data(), idx.data(), sizeof(unsigned long long), world, c->stream))
         return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
-    if (th_status s = read_back(c, hr.data(), recvc, (size_t)world * sizeof(unsigned long long))) return s;
+    {
+        std::vector<unsigned long long> words(97);
+        if (th_status s = read_back(c, words.data(), c->x_counts, words.size() * sizeof(unsigned long long))) return s;
+        if (mine == TH_OK) std::copy(words.begin(), words.begin() + world + 1, hb.begin());
+        std::copy(words.begin() + 65, words.begin() + 65 + world, hr.begin());
+    }
+    for (int r = 0; r < world; ++r) { scount[(size_t)r] = (size_t)(hb[(size_t)r + 1] - hb[(size_t)r]); soff[(size_t)r] = (size_t)hb[(size_t)r]; }
     if (mine != TH_OK && mine != kRetryInStreamOrder) { last_error() = why; return mine; }
     for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerFailed) return peer_failure(c, r, "rasterising its band's lines");
     for (int r = 0; r < world; ++r) if (hr[(size_t)r] & kPeerRetries) return kRetryInStreamOrder;
@@ -421,10 +433,9 @@ static th_status sharded_pass_bins(th_context *c, const th_deposit_uniforms *du,
             TH_HIP(hipMalloc((void **)&c->x_colors, (c->x_pairs ? 2 : 1) * cap * sizeof(float4)));
             c->x_capacity = cap;
         }
-        std::vector<unsigned long long> base((size_t)world);
-        for (int r = 0; r < world; ++r) base[(size_t)r] = roff[(size_t)r];
-        TH_HIP(hipMemcpyAsync(const_cast<unsigned long long *>(o.recv_base), base.data(), (size_t)world * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-        TH_HIP(hipStreamSynchronize(c->stream));                   // (`base` is a local)
+        // (where every source's part starts in what arrives: the running sum of the received counts, made on the device)
+        th::launch_exchange_recv_base(recvc, (uint32_t)world, const_cast<unsigned long long *>(o.recv_base), c->stream);
+        TH_HIP(hipGetLastError());
         return TH_OK;
     };
     mine = stage2();
@@ -547,7 +558,8 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
         if (th_status s = pass(du, nullptr, fragments)) return s;
         if (ru) if (th_status s = pass(nullptr, ru, nullptr)) return s;
     }
-    TH_HIP(hipStreamSynchronize(c->stream));
+    // (no synchronize: like every other entry point the call enqueues and returns - the all-gathers of the owned ranges are
+    // on the context's stream, and so is whatever the host asks for next)
     return TH_OK;
 }
 
