@@ -297,7 +297,7 @@ def main():
             line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
         except Exception as e:            # noqa: BLE001
             line["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if world > 1 and args.config == "c3" and not args.no_frame_loop:
+    if (world > 1 or args.force_dist) and args.config == "c3" and not args.no_frame_loop:
         # (collective: every rank runs it; a rank-local failure inside th_draw_sharded ends the draw on every rank - th_shard.hip)
         try:
             line["frame_loop_sharded"] = frame_loop_sharded(job)

@@ -104,11 +104,7 @@ def frame_loop_sharded(job, frames=12):
     for _ in range(frames):
         t.timer.tick()
         step_ms.append(timed(t.step))
-        job.sync_all()
-        t0 = time.perf_counter()
-        t.draw()
-        t.particles.sync()                         # (the call enqueues and returns like any other: the wall clock needs the stream's end)
-        draw_ms.append((time.perf_counter() - t0) * 1e3)
+        draw_ms.append(timed(t.draw))              # (an event pair on the context's stream: the exchange's collectives are on it too)
         _capi.call("th_draw_query", ctx, C.byref(info))
         sent.append(info.sent_bytes); recv.append(info.received_bytes); frags.append(t.fragments); pipes.append(info.pipeline)
     job.sync_all()
@@ -124,8 +120,10 @@ def frame_loop_sharded(job, frames=12):
     return {"frames": frames, "n_gpus": job.world, "step_ms": med[0], "draw_both_ms": med[1], "wall_ms_per_frame": med[2],
             "sent_bytes_per_draw": med[3], "received_bytes_per_draw": med[4], "fragments_per_draw_all_ranks": float(total.item()),
             "pipeline": "bins" if all(p == 1 for p in pipes) else ("stream" if not any(p == 1 for p in pipes) else "mixed"),
-            "note": "max over ranks of each rank's median; draw_both_ms against the wall clock around Tendrils.draw() (both passes, "
-                    "one exchange); bytes: th_draw_query (payload handed to / taken from the other ranks per draw)"}
+            "note": "max over ranks of each rank's median; step_ms / draw_both_ms: an event pair on the context's stream around the call "
+                    "(Tendrils.draw() of a band = th_draw_sharded: both passes, one exchange, its collectives on that stream); "
+                    "wall_ms_per_frame: the loop between two barriers; bytes: th_draw_query (payload handed to / taken from the other "
+                    "ranks per draw)"}
 
 
 def frame_loop(t, ctx, state, frames=20):
