@@ -43,6 +43,7 @@ void options_from_environment(th_options &o)
     const char *d = getenv("TH_DRAW");
     o.draw = !d ? -1 : (!strcmp(d, "bins") ? 1 : (!strcmp(d, "stream") ? 0 : -1));
     o.draw_reuse = number("TH_DRAW_REUSE", 1) != 0;
+    o.async_sort = number("TH_ASYNC_SORT", 1) != 0;
     o.bins_pool = (uint32_t)number("TH_BINS_POOL", 0);
     o.bins_pages = (int)number("TH_BINS_PAGES", 0); if (o.bins_pages > (int)th::kBinPagesLimit || o.bins_pages < -(int)th::kBinPagesLimit) o.bins_pages = 0;
 }
@@ -250,6 +251,8 @@ th_status th_destroy(th_context *c)
     if (!c) return TH_OK;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);          // (a re-sort beside the last draw may still be running there)
+    if (c->side2) (void)hipStreamSynchronize(c->side2);
     if (c->comm) { (void)c->transport->destroy(c->comm); c->comm = nullptr; }
     (void)hipFree(c->d_status); (void)hipFree(c->own_mem);
     for (float4 *b : c->ring) (void)hipFree(b);
@@ -278,7 +281,9 @@ th_status th_destroy(th_context *c)
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
     for (th_context::SlotOrder &o : c->orders) { (void)hipFree(o.perm); (void)hipFree(o.chunks); (void)hipFree(o.records); (void)hipFree(o.nchunks); }
-    (void)hipFree(c->spare); (void)hipFree(c->tile_mem); (void)hipFree(c->block_records);
+    (void)hipFree(c->spare); (void)hipFree(c->tile_mem); (void)hipFree(c->block_records); (void)hipFree(c->asort.dst);
+    if (c->asort.ready) (void)hipEventDestroy(c->asort.ready);
+    if (c->asort.done) (void)hipEventDestroy(c->asort.done);
     if (c->miss_host) (void)hipHostFree(c->miss_host);
     for (hipEvent_t e : c->kt_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -616,6 +621,7 @@ th_status th_option_set(th_context *c, int32_t option, int64_t value)
     case TH_OPT_GRAPH: o.graph = value != 0; break;
     case TH_OPT_FORCE_GENERIC: o.force_generic = value != 0; break;
     case TH_OPT_DRAW_REUSE: o.draw_reuse = value != 0; break;
+    case TH_OPT_ASYNC_SORT: o.async_sort = value != 0; if (!o.async_sort) { if (th_status s = asort_drop(c)) return s; } break;
     case TH_OPT_BINS_POOL: TH_REQUIRE(value >= 0 && value < (1ll << 32), "TH_OPT_BINS_POOL out of range"); o.bins_pool = (uint32_t)value; break;
 #ifdef TH_TESTING
     case TH_OPT_INJECT_FAILURE: TH_REQUIRE(value >= 0 && value <= 4, "TH_OPT_INJECT_FAILURE takes 0..4"); o.inject_failure = (int)value; break;
@@ -646,6 +652,7 @@ th_status th_option_get(th_context *c, int32_t option, int64_t *value)
     case TH_OPT_GRAPH: *value = o.graph; break;
     case TH_OPT_FORCE_GENERIC: *value = o.force_generic; break;
     case TH_OPT_DRAW_REUSE: *value = o.draw_reuse; break;
+    case TH_OPT_ASYNC_SORT: *value = o.async_sort; break;
     case TH_OPT_BINS_POOL: *value = o.bins_pool; break;
 #ifdef TH_TESTING
     case TH_OPT_INJECT_FAILURE: *value = o.inject_failure; break;

@@ -54,6 +54,7 @@ struct th_options {
     uint32_t bins_pool = 0;              // TH_BINS_POOL: first size of the binned pipeline's page pool (0: by the target's size)
     int bins_pages = 0;                  // TH_BINS_PAGES: pages a bin's list can grow to at first (0: kBinFirstPages); negative: that many and never more
     int inject_failure = 0;              // (tests) the next th_draw_sharded fails on THIS rank at stage 1 / 2 / 3: the ranks must all leave
+    bool async_sort = true;              // TH_ASYNC_SORT: a frame loop's re-sort runs beside its draw() instead of inside two of its steps (th_step.hip)
 };
 
 // One captured th_step_n sequence (see th_step_n).
@@ -209,6 +210,17 @@ struct th_context {
     unsigned long long sorts = 0;
     long long total_steps = 0, hold_texel_order_until = 0;   // texel-order consumers (draw) keep the layout off for a period
     uint32_t *miss_host = nullptr;       // pinned: window misses since the last sort, as of some recent launch
+    // A re-sort under way beside a draw() (th_step.hip "the re-sort of a frame loop"): the step's output `src` (held in order
+    // `src_order`) is being copied into `dst` in the new order `order` on the side stream; the next step takes the copy for
+    // its input when nothing has touched `src` since (state_written / state_moved), anything else drops it.
+    struct {
+        bool pending = false, valid = false;
+        const float4 *src = nullptr;
+        int src_order = -1, order = -1;
+        float4 *dst = nullptr;               // (allocated once)
+        hipEvent_t ready = nullptr, done = nullptr;
+        long long at_step = -1;              // total_steps when it was started
+    } asort;
     // a COUNT pass has histogrammed the tiles of the state it wrote: valid for a SCATTER pass that reads exactly that
     struct { const float4 *buf = nullptr; int order = -1; th::TileGeom geom{}; long long at_step = -1; } counted;
 
@@ -233,8 +245,16 @@ constexpr size_t kPinnedBytes = 1024;
 th_status read_back(th_context *c, void *host, const void *dev, size_t bytes);
 // the gathered whole-texture copy (th_state_gather / _ptr) is a copy of one ring buffer's CONTENT: writing that buffer ends
 // its validity, moving the content to another allocation (slot-order moves through `spare`) takes the association along
-inline void state_written(th_context *c, const float4 *buf) { if (c->gathered_of == (const void *)buf) c->gathered_of = nullptr; }
-inline void state_moved(th_context *c, const float4 *from, const float4 *to) { if (c->gathered_of == (const void *)from) c->gathered_of = to; }
+inline void state_written(th_context *c, const float4 *buf)
+{
+    if (c->gathered_of == (const void *)buf) c->gathered_of = nullptr;
+    if (c->asort.src == buf) c->asort.valid = false;          // (a re-sort of that content under way: its copy is stale)
+}
+inline void state_moved(th_context *c, const float4 *from, const float4 *to)
+{
+    if (c->gathered_of == (const void *)from) c->gathered_of = to;
+    if (c->asort.src == from) c->asort.valid = false;
+}
 
 // ---- th_order.hip ----------------------------------------------------------------------------------------------------
 void destroy_graph(GraphEntry &g);
@@ -251,6 +271,8 @@ void set_order(th_context *c, float4 *buf, int order);
 bool any_sorted(const th_context *c);
 th_status sort_storage(th_context *c);
 th_status free_order(th_context *c, int *out);
+th_status asort_drop(th_context *c);
+th_status asort_start(th_context *c, const th::TileGeom &g, float4 *src, int src_order);
 th_status ensure_identity(th_context *c, bool *launched = nullptr);
 th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, const uint32_t *perm_in, int *order,
                      th::TileSortParams *params, bool have_hist = false);

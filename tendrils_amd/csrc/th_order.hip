@@ -137,6 +137,62 @@ th_status free_order(th_context *c, int *out)
     return TH_OK;
 }
 
+// ---- the re-sort of a frame loop, beside its draw() -----------------------------------------------------------------------
+// A frame is step(); draw().  Re-sorting inside the steps cost two of every `resort_steps` frames 0.15 and 0.35 ms extra (a
+// COUNT pass, then the scan and a SCATTER pass) - in a loop a host runs at a fixed rate, the frames that matter.  While draws
+// are going on, the re-sort is a plain move instead, started right behind a step on the draw's side stream: histogram of the
+// step's OUTPUT, scan, a copy of it in the new order.  The draw that follows reads the same buffer (nobody writes it) and its
+// first 0.6 ms are the emit pass, which waits on atomics and leaves the memory system idle; the next step takes the copy for
+// its input - same content, new slots - and the buffer it replaces becomes the next copy's destination.
+// Anything that touches the source or the sort's scratch in between drops the copy (asort_drop); the steps then go on in the
+// old order and the re-sort is tried again behind the next one.
+th_status asort_drop(th_context *c)
+{
+    if (!c->asort.pending) return TH_OK;
+    // (the side stream's kernels use the sort's scratch and the order's arrays: whoever comes next on the main stream waits)
+    TH_HIP(hipStreamWaitEvent(c->stream, c->asort.done, 0));
+    c->asort.pending = c->asort.valid = false;
+    c->asort.src = nullptr;
+    return TH_OK;
+}
+
+th_status asort_start(th_context *c, const th::TileGeom &g, float4 *src, int src_order)
+{
+    if (th_status s = sort_storage(c)) return s;
+    if (!c->asort.dst) {
+        TH_HIP(hipMalloc((void **)&c->asort.dst, c->texels() * sizeof(float4)));
+        TH_HIP(hipEventCreateWithFlags(&c->asort.ready, hipEventDisableTiming));
+        TH_HIP(hipEventCreateWithFlags(&c->asort.done, hipEventDisableTiming));
+    }
+    int order = -1;
+    if (th_status s = free_order(c, &order)) return s;
+    th_context::SlotOrder &o = c->orders[(size_t)order];
+    o.geom = g; o.fw = c->fw; o.fh = c->fh;
+    th::TileSortParams b{};
+    b.state = src; b.perm_in = src_order >= 0 ? c->orders[(size_t)src_order].perm : nullptr; b.count = (uint32_t)c->texels();
+    b.g = g;
+    b.hist = c->tile_mem; b.cursor = c->tile_mem + kTileWords / 2;
+    b.totals = c->tile_mem + kTileWords + 8; b.starts = b.totals + th::kMaxTileBins;
+    b.chunks = o.chunks; b.nchunks = o.nchunks;
+    b.perm_out = o.perm;
+    b.block_records = c->block_records;
+    b.state_out = c->asort.dst;
+    TH_HIP(hipEventRecord(c->asort.ready, c->stream));
+    TH_HIP(hipStreamWaitEvent(c->side, c->asort.ready, 0));
+    TH_HIP(hipMemsetAsync(b.hist, 0, kTileWords / 2 * sizeof(uint32_t), c->side));
+    th::launch_tile_hist(b, c->side);
+    th::launch_tile_scan(b, c->side);
+    th::launch_tile_scatter(b, c->side);
+    TH_HIP(hipGetLastError());
+    TH_HIP(hipEventRecord(c->asort.done, c->side));
+    ++c->sorts;
+    o.stamp = c->sorts;
+    c->counted.buf = nullptr;
+    c->asort.pending = c->asort.valid = true;
+    c->asort.src = src; c->asort.src_order = src_order; c->asort.order = order; c->asort.at_step = c->total_steps;
+    return TH_OK;
+}
+
 // every ring buffer back to texel order (reports whether anything was launched)
 th_status ensure_identity(th_context *c, bool *launched)
 {
@@ -163,6 +219,7 @@ th_status begin_sort(th_context *c, const th::TileGeom &g, const float4 *state, 
                      th::TileSortParams *params, bool have_hist)
 {
     if (th_status s = sort_storage(c)) return s;
+    if (th_status s = asort_drop(c)) return s;          // (one sort at a time: the scratch and the free orders are shared)
     if (th_status s = free_order(c, order)) return s;
     th_context::SlotOrder &o = c->orders[(size_t)*order];
     o.geom = g; o.fw = c->fw; o.fh = c->fh;

@@ -163,6 +163,8 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     // the slots of a new sort keyed on the input positions (counted just before the launch).
     int in_order = sorted ? order_of(c, in) : -1, out_order = -1;
     bool use_sorted = false, scatter = false, count = false, gather = false;
+    if (c->asort.pending && (!sorted || packed_kernel)) if (th_status s = asort_drop(c)) return s;
+    bool async = false;
     if (sorted && packed_kernel) {
         // packed ring: the plain grid-stride kernel over the sorted slots; a re-sort is a plain move of the input
         // (tile_hist, scan, tile_scatter into the spare buffer, which then takes the input's place in the ring)
@@ -199,11 +201,35 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
             p.in = in; p.out = rt;
             in_order = -1;
         }
-        scatter = in_order < 0 || c->steps_since_sort >= c->opt.resort_steps;
+        // The re-sort of a frame loop (th_order.hip: asort_start): while draws over the slot order are going on, no step counts
+        // or scatters - the order laid out beside the last draw is taken up here, its copy of this step's input in the input's
+        // place - and the next one is started behind the step that is `resort_steps` launches on.
+        async = c->opt.async_sort && in_order >= 0 && plan.decoded && c->side && in == c->ring[1] && target == TH_TARGET_RING &&
+                c->total_steps - c->last_binned_draw <= 2ll * c->opt.resort_steps;
+        if (c->asort.pending) {
+            const bool take = async && c->asort.valid && c->asort.src == in && c->asort.src_order == in_order && c->asort.at_step == c->total_steps &&
+                              same_geom(c->orders[(size_t)c->asort.order].geom, g);
+            if (!take) { if (th_status s = asort_drop(c)) return s; }
+            else {
+                TH_HIP(hipStreamWaitEvent(c->stream, c->asort.done, 0));
+                clear_graphs(c);               // captured sequences name the ring buffers: one of them changes places with the copy
+                float4 *old = in, *copy = c->asort.dst;
+                const int fresh = c->asort.order;
+                c->asort.pending = c->asort.valid = false;
+                c->asort.src = nullptr;
+                set_order(c, old, -1);
+                state_moved(c, old, copy);
+                c->ring[1] = copy; c->asort.dst = old;
+                set_order(c, copy, fresh);
+                in = copy; p.in = in; in_order = fresh;
+                c->steps_since_sort = 0;
+            }
+        }
+        scatter = !async && (in_order < 0 || c->steps_since_sort >= c->opt.resort_steps);
         use_sorted = true;
         // between two sorts the pass is the plain grid-stride kernel over the sorted slots (taps gathered from the
         // decoded plane: a wave's taps fall into one neighbourhood); the chunk kernel counts and scatters around a re-sort
-        gather = !scatter && plan.decoded && c->steps_since_sort + 1 < c->opt.resort_steps;
+        gather = !scatter && plan.decoded && (async || c->steps_since_sort + 1 < c->opt.resort_steps);
         p.geom = g;
         if (in_order >= 0) {
             const th_context::SlotOrder &o = c->orders[(size_t)in_order];
@@ -263,6 +289,8 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     ++c->steps_since_sort; ++c->total_steps;
     if (count) { c->counted.buf = out; c->counted.order = out_order; c->counted.geom = p.geom; c->counted.at_step = c->total_steps; }
     else c->counted.buf = nullptr;
+    if (async && !c->asort.pending && out_order >= 0 && c->steps_since_sort >= c->opt.resort_steps)
+        if (th_status s = asort_start(c, p.geom, out, out_order)) return s;
     return TH_OK;
 }
 
@@ -277,7 +305,7 @@ th_status th_step(th_context *c, const th_logic_uniforms *u, int32_t target)
     StepPlan plan;
     if (th_status s = plan_step(c, *u, target, plan)) return s;
     const bool sorted = plan.may_sort && !plan.generic;
-    if (!sorted) if (th_status s = ensure_identity(c)) return s;
+    if (!sorted) { if (th_status s = asort_drop(c)) return s; if (th_status s = ensure_identity(c)) return s; }
     return enqueue_step(c, plan, target, u->time, nullptr, true, sorted);
 }
 
@@ -290,6 +318,7 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
     TH_REQUIRE(u && n >= 0, "bad arguments");
     TH_REQUIRE(c->ring.size() >= 2, "step needs at least 2 state buffers (have %zu)", c->ring.size());
     if (n == 0) return TH_OK;
+    if (th_status s = asort_drop(c)) return s;          // (a frame loop's re-sort under way: these launches lay their own orders out)
     th_logic_uniforms v = *u;
     v.dt = (float)dt_ms;
     std::vector<float> times((size_t)n);

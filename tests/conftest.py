@@ -47,6 +47,9 @@ VARIANTS = {
     # ... and over tile-sorted slots re-sorted every few steps
     "bins-on-sorted": ({"TH_DRAW": "bins", "TH_BUCKET": "1", "TH_RESORT_STEPS": "3", "TH_REBUCKET_STEPS": "2"},
                        ["test_gpu_deposit", "test_gpu_view", "test_gpu_fuzz", "test_gpu_scene"]),
+    # ... with the frame loop's re-sort inside its steps (a COUNT pass, a SCATTER pass) instead of beside its draws
+    "bins-on-sorted-in-steps": ({"TH_DRAW": "bins", "TH_BUCKET": "1", "TH_RESORT_STEPS": "3", "TH_REBUCKET_STEPS": "2", "TH_ASYNC_SORT": "0"},
+                                ["test_gpu_deposit", "test_gpu_scene"]),
 }
 
 

@@ -1,0 +1,139 @@
+"""The re-sort of a frame loop beside its draw() (th_order.hip: asort_start; TH_OPT_ASYNC_SORT): while draws over the slot
+order are going on, a step's output is laid out in a new tile order on the draw's side stream and the next step takes the copy
+for its input.  Invisible in every result: the loop with it, the loop with the re-sort inside its steps and the restatement
+agree bit for bit - whatever comes between a step and the step that would take the copy up."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def loop_inputs(n, view, seed):
+    rng = np.random.default_rng(seed)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-0.95, 0.95, (n, n, 2)) * [1.0, view[1] / view[0]]
+    st[..., 2:] = rng.uniform(-.008, .008, (n, n, 2))
+    st[rng.random((n, n)) < 0.03] = [-1e6, -1e6, 0, 0]
+    return st
+
+
+def make(n, view, st, async_sort, resort=3):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    t = ta.Tendrils(View(*view))
+    t.resize()
+    t.setup(n)
+    t.particles.option("bucket", 1)
+    t.particles.option("resort_steps", resort)
+    t.particles.option("async_sort", 1 if async_sort else 0)
+    t.particles.draw_pipeline("bins")
+    t.particles.upload_texels(st)
+    t.timer.time = 3000.0
+    return t
+
+
+def sorts(t):
+    from tendrils_amd import _capi
+    info = _capi.SlotOrderInfo()
+    _capi.call("th_slot_order", t.particles._ctx, C.byref(info))
+    return info.sorts, info.sorted_buffers
+
+
+def test_frame_loop_is_the_same_with_the_re_sort_beside_the_draw(oracle):
+    n, view, frames = 128, (96, 54), 14
+    st = loop_inputs(n, view, 5)
+    a, b = make(n, view, st, True), make(n, view, st, False)
+    for t in (a, b):
+        assert t.particles.option("async_sort") == (1 if t is a else 0)
+    cur, prev, flow, time, dt = st.copy(), st.copy(), np.zeros((view[1], view[0], 4), np.float32), 3000.0, 1000.0 / 60.0
+    for k in range(frames):
+        time += dt
+        u = oracle.logic_uniforms(n, n, time, dt, view_size=(1.0, view[0] / view[1]), **oracle.DEFAULT_STATE)
+        prev, cur = cur, oracle.logic_step(u, cur, flow)
+        flow, count = oracle.flow_deposit(cur, prev, flow, time, view_size=(1.0, view[0] / view[1]), speedLimit=oracle.DEFAULT_STATE["speedLimit"])
+        for t in (a, b):
+            t.timer.tick()
+            t.step().draw()
+            assert t.fragments == count
+        if k == 12:                                             # (a read-back by texel restores texel order: ask first)
+            (sa, ba), (sb, bb) = sorts(a), sorts(b)
+            assert sa >= 4 and sb >= 4 and ba == bb == 2        # both loops keep re-sorting, both ring buffers held in a sorted order
+        if k in (2, 7, 13):
+            for t in (a, b):
+                assert bits_equal(t.particles.read(0), cur).all() and bits_equal(t.particles.read(1), prev).all()
+                assert bits_equal(t.flow.read(), flow).all()
+    assert (a.read_view() == b.read_view()).all() and a.read_view().any()
+    a.dispose(); b.dispose()
+
+
+@pytest.mark.parametrize("between", ["upload", "spawn", "step_n", "read", "two draws", "no draw", "option off"])
+def test_whatever_comes_between_a_step_and_the_next(oracle, between):
+    """a copy under way is taken up only if nothing has touched its source: uploads, spawners and fused steps drop it, reads and
+    draws do not - the states agree with a loop that never sorts beside a draw either way"""
+    from tendrils_amd.spawn.ball import spawnBall
+    n, view = 128, (96, 54)
+    st = loop_inputs(n, view, 9)
+    other = loop_inputs(n, view, 10)
+    a, b = make(n, view, st, True, resort=2), make(n, view, st, False, resort=2)
+    for k in range(9):
+        for t in (a, b):
+            t.timer.tick()
+            t.step()
+            if between != "no draw" or k < 3:
+                t.draw()
+            if k in (3, 4, 6):
+                if between == "upload":
+                    t.particles.upload_texels(other if k != 4 else st, 0)
+                elif between == "spawn":
+                    spawnBall(None, dict(uniforms=dict(radius=0.4, speed=0.004))).spawn(t)
+                elif between == "step_n":
+                    t.step_n(3)
+                elif between == "read":
+                    t.particles.read(0)
+                elif between == "two draws":
+                    t.draw()
+                elif between == "option off" and t is a:
+                    t.particles.option("async_sort", 0 if k != 6 else 1)
+        if k in (4, 8):
+            assert bits_equal(a.particles.read(0), b.particles.read(0)).all() and bits_equal(a.particles.read(1), b.particles.read(1)).all()
+            assert bits_equal(a.flow.read(), b.flow.read()).all()
+    a.dispose(); b.dispose()
+
+
+def test_c3_frame_loop_sorts_beside_its_draws_and_no_step_pays_for_it():
+    """4096^2 particles over 1920 x 1080 (the default policy sorts by itself, every 64 steps): 70 frames - one re-sort beside a
+    draw in them; the steps' launches all take about the same time (no COUNT pass, no SCATTER pass among them)."""
+    import tendrils_amd as ta
+    from tendrils_amd import _capi
+    from tendrils_amd.tendrils import View
+    n = 4096
+    rng = np.random.default_rng(3)
+    st = np.empty((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2)).astype(np.float32)
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2)).astype(np.float32)
+    t = ta.Tendrils(View(1920, 1080))
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(st)
+    t.timer.time = 1000.0
+    ctx, ms, times = t.particles._ctx, C.c_float(), []
+    s0 = None
+    for k in range(72):
+        t.timer.tick()
+        _capi.call("th_timer_start", ctx)
+        t.step()
+        _capi.call("th_timer_stop", ctx, C.byref(ms))
+        times.append(ms.value)
+        t.draw()
+        if k == 4:
+            s0 = sorts(t)[0]
+    assert sorts(t)[0] == s0 + 1                           # one re-sort in frames 5..71 (after the first, synchronous one)
+    late = np.array(times[5:])
+    assert late.max() < 1.6 * np.median(late), (late.max(), float(np.median(late)))
+    stats = t.particles.stats(t.state["speedLimit"])
+    assert stats["live"] == n * n and stats["nan"] == 0
+    t.dispose()
