@@ -441,7 +441,7 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
 
 /* Per-context switches between equivalent paths (build-defined; no switch changes a result - the parity suites rerun under
  * each, tests/conftest.py).  A context starts from the environment variables of the same names, read by th_create
- * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL, TH_BINS_PAGES, TH_ASYNC_SORT;
+ * (TH_BUCKET, TH_RESORT_STEPS, TH_REBUCKET_STEPS, TH_FUSE, TH_GRAPH, TH_FORCE_GENERIC, TH_DRAW_REUSE, TH_BINS_POOL, TH_BINS_PAGES, TH_ASYNC_SORT, TH_SKIP_UNSEEN;
  * TH_DRAW=stream|bins sets what TH_DRAW_AUTO means).
  *   TH_OPT_BUCKET          tile-sorted slot order never (0) / always (1) / when it pays (-1, default)
  *   TH_OPT_RESORT_STEPS    re-sort period of single-step launches (default 64)
@@ -450,6 +450,8 @@ th_status th_draw_query(th_context *ctx, th_draw_info *out);
  *   TH_OPT_GRAPH           captured hipGraphs in th_step_n where it does not fuse (default 1)
  *   TH_OPT_FORCE_GENERIC   every step through the reference-order kernel (default 0)
  *   TH_OPT_DRAW_REUSE      the stream-ordered view pass reuses the flow pass's rasterisation and sort (default 1)
+ *   TH_OPT_SKIP_UNSEEN     (TH_SKIP_UNSEEN) a single step that a draw() follows notes per 64 slots whether any of their lines may touch
+ *                          the view, and the binned draw() skips the blocks of slots of which none may (default 1)
  *   TH_OPT_ASYNC_SORT      (TH_ASYNC_SORT) while draws are going on, the single steps' re-sort runs beside the draw that follows
  *                          a step - a plain move on the draw's side stream, taken up by the next step - instead of inside two
  *                          steps of every TH_OPT_RESORT_STEPS (default 1)
@@ -468,7 +470,7 @@ enum { TH_OPT_BUCKET = 0, TH_OPT_RESORT_STEPS = 1, TH_OPT_REBUCKET_STEPS = 2, TH
 #ifdef TH_TESTING
        TH_OPT_INJECT_FAILURE = 8,
 #endif
-       TH_OPT_BINS_PAGES = 9, TH_OPT_ASYNC_SORT = 10 };
+       TH_OPT_BINS_PAGES = 9, TH_OPT_ASYNC_SORT = 10, TH_OPT_SKIP_UNSEEN = 11 };
 th_status th_option_set(th_context *ctx, int32_t option, int64_t value);
 th_status th_option_get(th_context *ctx, int32_t option, int64_t *value);
 

@@ -44,6 +44,7 @@ void options_from_environment(th_options &o)
     o.draw = !d ? -1 : (!strcmp(d, "bins") ? 1 : (!strcmp(d, "stream") ? 0 : -1));
     o.draw_reuse = number("TH_DRAW_REUSE", 1) != 0;
     o.async_sort = number("TH_ASYNC_SORT", 1) != 0;
+    o.skip_unseen = number("TH_SKIP_UNSEEN", 1) != 0;
     o.bins_pool = (uint32_t)number("TH_BINS_POOL", 0);
     o.bins_pages = (int)number("TH_BINS_PAGES", 0); if (o.bins_pages > (int)th::kBinPagesLimit || o.bins_pages < -(int)th::kBinPagesLimit) o.bins_pages = 0;
 }
@@ -281,7 +282,7 @@ th_status th_destroy(th_context *c)
     clear_graphs(c);
     for (float4 *t : c->tmp) (void)hipFree(t);
     for (th_context::SlotOrder &o : c->orders) { (void)hipFree(o.perm); (void)hipFree(o.chunks); (void)hipFree(o.records); (void)hipFree(o.nchunks); }
-    (void)hipFree(c->spare); (void)hipFree(c->tile_mem); (void)hipFree(c->block_records); (void)hipFree(c->asort.dst);
+    (void)hipFree(c->spare); (void)hipFree(c->tile_mem); (void)hipFree(c->block_records); (void)hipFree(c->asort.dst); (void)hipFree(c->seen.bytes);
     if (c->asort.ready) (void)hipEventDestroy(c->asort.ready);
     if (c->asort.done) (void)hipEventDestroy(c->asort.done);
     if (c->miss_host) (void)hipHostFree(c->miss_host);
@@ -621,6 +622,7 @@ th_status th_option_set(th_context *c, int32_t option, int64_t value)
     case TH_OPT_GRAPH: o.graph = value != 0; break;
     case TH_OPT_FORCE_GENERIC: o.force_generic = value != 0; break;
     case TH_OPT_DRAW_REUSE: o.draw_reuse = value != 0; break;
+    case TH_OPT_SKIP_UNSEEN: o.skip_unseen = value != 0; break;
     case TH_OPT_ASYNC_SORT: o.async_sort = value != 0; if (!o.async_sort) { if (th_status s = asort_drop(c)) return s; } break;
     case TH_OPT_BINS_POOL: TH_REQUIRE(value >= 0 && value < (1ll << 32), "TH_OPT_BINS_POOL out of range"); o.bins_pool = (uint32_t)value; break;
 #ifdef TH_TESTING
@@ -653,6 +655,7 @@ th_status th_option_get(th_context *c, int32_t option, int64_t *value)
     case TH_OPT_FORCE_GENERIC: *value = o.force_generic; break;
     case TH_OPT_DRAW_REUSE: *value = o.draw_reuse; break;
     case TH_OPT_ASYNC_SORT: *value = o.async_sort; break;
+    case TH_OPT_SKIP_UNSEEN: *value = o.skip_unseen; break;
     case TH_OPT_BINS_POOL: *value = o.bins_pool; break;
 #ifdef TH_TESTING
     case TH_OPT_INJECT_FAILURE: *value = o.inject_failure; break;

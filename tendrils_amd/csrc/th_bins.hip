@@ -256,6 +256,9 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     // start.
     for (uint32_t k = blockIdx.x; k < p.draw_nblocks; k += gridDim.x) {
     const uint32_t block = p.draw_blocks[k];
+    // (a frame loop: the step that wrote these slots saw every line of the block end up beyond one edge of the view - nothing
+    // of it would be rasterised, listed or counted: LogicParams::seen)
+    if (p.block_seen && p.block_seen[block] == 0u) continue;
     const uint32_t s = block * BS + threadIdx.x;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);

@@ -54,6 +54,7 @@ struct th_options {
     uint32_t bins_pool = 0;              // TH_BINS_POOL: first size of the binned pipeline's page pool (0: by the target's size)
     int bins_pages = 0;                  // TH_BINS_PAGES: pages a bin's list can grow to at first (0: kBinFirstPages); negative: that many and never more
     int inject_failure = 0;              // (tests) the next th_draw_sharded fails on THIS rank at stage 1 / 2 / 3: the ranks must all leave
+    bool skip_unseen = true;             // TH_SKIP_UNSEEN: draw() skips the blocks of slots whose lines the step saw end up outside the view (th_step.hip)
     bool async_sort = true;              // TH_ASYNC_SORT: a frame loop's re-sort runs beside its draw() instead of inside two of its steps (th_step.hip)
 };
 
@@ -221,6 +222,16 @@ struct th_context {
         hipEvent_t ready = nullptr, done = nullptr;
         long long at_step = -1;              // total_steps when it was started
     } asort;
+    // what a single step saw of its lines (LogicParams::seen): valid for a draw() that reads exactly these two buffers in this
+    // order through this view
+    struct {
+        uint8_t *bytes = nullptr;            // texels / 64 of them (a multiple of 4)
+        const float4 *cur = nullptr, *prev = nullptr;
+        int order = -1;
+        unsigned long long stamp = 0;
+        float view_x = 0, view_y = 0;
+        int32_t fw = 0, fh = 0;
+    } seen;
     // a COUNT pass has histogrammed the tiles of the state it wrote: valid for a SCATTER pass that reads exactly that
     struct { const float4 *buf = nullptr; int order = -1; th::TileGeom geom{}; long long at_step = -1; } counted;
 
@@ -249,11 +260,13 @@ inline void state_written(th_context *c, const float4 *buf)
 {
     if (c->gathered_of == (const void *)buf) c->gathered_of = nullptr;
     if (c->asort.src == buf) c->asort.valid = false;          // (a re-sort of that content under way: its copy is stale)
+    if (c->seen.cur == buf || c->seen.prev == buf) c->seen.cur = c->seen.prev = nullptr;
 }
 inline void state_moved(th_context *c, const float4 *from, const float4 *to)
 {
     if (c->gathered_of == (const void *)from) c->gathered_of = to;
     if (c->asort.src == from) c->asort.valid = false;
+    if (c->seen.cur == from || c->seen.prev == from) c->seen.cur = c->seen.prev = nullptr;
 }
 
 // ---- th_order.hip ----------------------------------------------------------------------------------------------------

@@ -171,6 +171,11 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         p.totals = c->dep_total; p.totals_host = nullptr; p.totals_seq = 0;       // (bins_expect, before the plan's kernels go out)
         // the blocks of slots with something to draw: listed once per slot order (one read-back per re-sort)
         const unsigned long long stamp = o >= 0 ? c->orders[(size_t)o].stamp : 0ull;
+        // what the step that wrote these two buffers saw of their lines (th_step.hip): only for exactly this pair, order and view
+        if (c->opt.skip_unseen && c->seen.bytes && c->seen.cur == c->ring[0] && c->seen.prev == c->ring[1] && p.cur == c->ring[0] && p.prev == c->ring[1] &&
+            c->seen.order == o && c->seen.stamp == stamp && c->seen.view_x == p.view_x && c->seen.view_y == p.view_y && c->seen.fw == c->fw && c->seen.fh == c->fh &&
+            drawn_line_width(c, TH_PASS_FLOW) <= 2.0f && drawn_line_width(c, TH_PASS_VIEW) <= 2.0f)
+            p.block_seen = reinterpret_cast<const uint32_t *>(c->seen.bytes);
         if (!c->draw_blocks || c->draw_blocks_order != o || c->draw_blocks_stamp != stamp) {
             const size_t blocks = (c->texels() + 255) / 256;
             if (!c->draw_blocks) {

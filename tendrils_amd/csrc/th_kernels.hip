@@ -88,7 +88,15 @@ __global__ __launch_bounds__(256) void logic_kernel(const LogicParams p)
         float4 st = nxt;
         const uint32_t pid = perm ? pnxt : idx;
         if (idx + stride < end) { nxt = load_stream(&p.in[idx + stride]); if (perm) pnxt = __builtin_nontemporal_load(&perm[idx + stride]); }
-        store_stream(&p.out[idx], integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, st, pid, time, &tabs));
+        const float4 r = integrate<FAST, NOISE, TARGET, POW2, DECODED, NOISE && PTAB>(p, lut, st, pid, time, &tabs);
+        store_stream(&p.out[idx], r);
+        if (p.seen) {           // (uniform; a frame loop: LogicParams::seen)
+            // hidden for sure: both ends beyond one edge (a NaN compares false: seen)
+            const bool hidden = (st.x < p.seen_xlo && r.x < p.seen_xlo) || (st.x > p.seen_xhi && r.x > p.seen_xhi) ||
+                                (st.y < p.seen_ylo && r.y < p.seen_ylo) || (st.y > p.seen_yhi && r.y > p.seen_yhi);
+            const unsigned long long any = __ballot(!hidden);
+            if (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(true))) p.seen[idx >> 6] = any ? 1u : 0u;
+        }
     }
 }
 

@@ -62,6 +62,11 @@ struct LogicParams {
     ChunkRecord *records;    // COUNT: written per chunk; SCATTER with use_records: read per chunk
     uint32_t use_records;
     const float *time_dev;   // graph replays: `time` is read from here instead of u.time (nullptr = u.time)
+    // (single steps of a frame loop) a byte per 64 slots: some line of them - from the slot's input position to its output
+    // position - may touch the view; draw() skips the blocks of 256 slots whose four bytes are zero (th_bins.hip).  A line is
+    // hidden for sure when both its ends lie beyond the same edge of the view by more than the margin the bounds carry.
+    uint8_t *seen;
+    float seen_xlo, seen_xhi, seen_ylo, seen_yhi;
     // fused multi-step launches (logic_fused_kernel): nsteps consecutive steps per particle in one pass
     float4 *out_prev;        // receives state nsteps-1 (p.out receives state nsteps); may alias p.in
     uint32_t nsteps;
@@ -153,6 +158,7 @@ struct DepositParams {
     // b * kBinReplicas + r, further pages come from a pool.
     const uint32_t *perm;
     const uint32_t *draw_blocks;                   // the blocks of 256 slots that hold a line that can draw at all, in rising order (launch_bins_block_list)
+    const uint32_t *block_seen;                    // per block of 256 slots: the four bytes the step left (LogicParams::seen); nullptr: every listed block is walked
     uint32_t draw_nblocks;
     uint32_t bins_x, nbins;
     uint32_t *bin_cursor, bin_stride;              // per list (r * bin_stride + bin): places handed out so far (virtual indices inside the list)

@@ -1068,7 +1068,7 @@ napi_value Init(napi_env env, napi_value exports)
         {"SOURCE_IMAGE", TH_SOURCE_IMAGE}, {"DRAW_AUTO", TH_DRAW_AUTO}, {"DRAW_STREAM", TH_DRAW_STREAM}, {"DRAW_BINS", TH_DRAW_BINS},
         {"OPT_BUCKET", TH_OPT_BUCKET}, {"OPT_RESORT_STEPS", TH_OPT_RESORT_STEPS}, {"OPT_REBUCKET_STEPS", TH_OPT_REBUCKET_STEPS},
         {"OPT_FUSE", TH_OPT_FUSE}, {"OPT_GRAPH", TH_OPT_GRAPH}, {"OPT_FORCE_GENERIC", TH_OPT_FORCE_GENERIC},
-        {"OPT_DRAW_REUSE", TH_OPT_DRAW_REUSE}, {"OPT_BINS_POOL", TH_OPT_BINS_POOL}, {"OPT_BINS_PAGES", TH_OPT_BINS_PAGES}, {"OPT_ASYNC_SORT", TH_OPT_ASYNC_SORT},
+        {"OPT_DRAW_REUSE", TH_OPT_DRAW_REUSE}, {"OPT_BINS_POOL", TH_OPT_BINS_POOL}, {"OPT_BINS_PAGES", TH_OPT_BINS_PAGES}, {"OPT_ASYNC_SORT", TH_OPT_ASYNC_SORT}, {"OPT_SKIP_UNSEEN", TH_OPT_SKIP_UNSEEN},
 #ifdef TH_TESTING
         {"OPT_INJECT_FAILURE", TH_OPT_INJECT_FAILURE},
 #endif

@@ -261,6 +261,26 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     if (plan.decoded)
         th::launch_flow_decode(c->flow, c->flow_dec, (size_t)c->fw * c->fh, time, time_dev, p.u.flowDecay, c->stream);
 
+    // A frame loop: the plain kernel notes per 64 slots whether any of their lines - input position to output position - may
+    // touch the view (LogicParams::seen); the draw that follows skips the blocks of 256 slots of which none may (44 % of the
+    // bench's particles live outside the view, and the tile order keeps them together).  Hidden for sure = both ends beyond one
+    // edge by more than 2 texels: more than a line of width <= 2 reaches (its diamonds: one texel) and its snapping moves.
+    bool seeing = false;
+    const float vx = p.u.viewSize[0], vy = p.u.viewSize[1];
+    if (c->opt.skip_unseen && target == TH_TARGET_RING && !c->packed && !plan.generic && (gather || !use_sorted) && rt == out &&
+        c->total_steps - c->last_binned_draw <= 2ll * c->opt.resort_steps && vx > 0.0f && vy > 0.0f && std::isfinite(vx) && std::isfinite(vy)) {
+        if (!c->seen.bytes) {
+            const size_t bytes = ((c->texels() + 63) / 64 + 7) & ~(size_t)3;
+            TH_HIP(hipMalloc((void **)&c->seen.bytes, bytes));
+            TH_HIP(hipMemsetAsync(c->seen.bytes, 0, bytes, c->stream));
+        }
+        const float mx = 4.0f / (float)c->fw, my = 4.0f / (float)c->fh;
+        p.seen = c->seen.bytes;
+        p.seen_xlo = (-1.0f - mx) / vx; p.seen_xhi = (1.0f + mx) / vx;
+        p.seen_ylo = (-1.0f - my) / vy; p.seen_yhi = (1.0f + my) / vy;
+        seeing = true;
+    }
+
     hipEvent_t k0 = nullptr, k1 = nullptr;
     if (timing && c->kernel_timing) {
         if (th_status s = timing_events(c, &k0, &k1)) return s;
@@ -286,6 +306,11 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     }
     if (c->packed && !packed_kernel)
         if (th_status s = commit_target(c, out, rt)) return s;
+    if (seeing) {
+        c->seen.cur = out; c->seen.prev = in; c->seen.order = out_order;
+        c->seen.stamp = out_order >= 0 ? c->orders[(size_t)out_order].stamp : 0ull;
+        c->seen.view_x = vx; c->seen.view_y = vy; c->seen.fw = c->fw; c->seen.fh = c->fh;
+    }
     ++c->steps_since_sort; ++c->total_steps;
     if (count) { c->counted.buf = out; c->counted.order = out_order; c->counted.geom = p.geom; c->counted.at_step = c->total_steps; }
     else c->counted.buf = nullptr;

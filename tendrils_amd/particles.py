@@ -192,7 +192,7 @@ class Particles:
         call("th_draw_pipeline", self._ctx, {"auto": -1, "stream": 0, "bins": 1}[which])
 
     OPTIONS = dict(bucket=0, resort_steps=1, rebucket_steps=2, fuse=3, graph=4, force_generic=5, draw_reuse=6, bins_pool=7,
-                   inject_failure=8, bins_pages=9, async_sort=10)
+                   inject_failure=8, bins_pages=9, async_sort=10, skip_unseen=11)
 
     def option(self, name, value=None):
         """A switch between equivalent paths of the library (th_option_set / _get; no switch changes a result): returns the

@@ -137,3 +137,62 @@ def test_c3_frame_loop_sorts_beside_its_draws_and_no_step_pays_for_it():
     stats = t.particles.stats(t.state["speedLimit"])
     assert stats["live"] == n * n and stats["nan"] == 0
     t.dispose()
+
+
+# ---- the blocks of slots a draw() need not walk (LogicParams::seen; TH_OPT_SKIP_UNSEEN) ------------------------------------------
+def spread_inputs(n, seed):
+    """positions over twice the view's height (the bench's synthetic state): 44 % of the particles outside the view"""
+    rng = np.random.default_rng(seed)
+    st = np.zeros((n, n, 4), np.float32)
+    st[..., :2] = rng.uniform(-1, 1, (n, n, 2))
+    st[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+    st[rng.random((n, n)) < 0.02] = [-1e6, -1e6, 0, 0]
+    return st
+
+
+@pytest.mark.parametrize("what", ["sorted slots", "texel order", "view changes", "wide lines"])
+def test_draw_skips_what_the_step_saw_leave_the_view_and_nothing_else(oracle, what):
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    n, view, frames = 256, (96, 54), 7
+    st = spread_inputs(n, 21)
+
+    def build(skip):
+        opts = ta.defaults()
+        if what == "wide lines":
+            opts["lineWidthRange"] = (1, 4)
+            opts["state"]["flowWidth"] = opts["state"]["lineWidth"] = 3      # beyond what the step's margin covers: nothing is skipped
+        t = ta.Tendrils(View(*view), opts)
+        t.resize()
+        t.setup(n)
+        t.particles.option("bucket", 0 if what == "texel order" else 1)
+        t.particles.option("resort_steps", 3)
+        t.particles.option("skip_unseen", 1 if skip else 0)
+        t.particles.draw_pipeline("bins")
+        t.particles.upload_texels(st)
+        t.timer.time = 3000.0
+        return t
+    a, b = build(True), build(False)
+    width = 3.0 if what == "wide lines" else 1.0
+    cur, prev, flow, time, dt = st.copy(), st.copy(), np.zeros((view[1], view[0], 4), np.float32), 3000.0, 1000.0 / 60.0
+    size = [1.0, view[0] / view[1]]
+    for k in range(frames):
+        time += dt
+        u = oracle.logic_uniforms(n, n, time, dt, view_size=tuple(size), **oracle.DEFAULT_STATE)
+        prev, cur = cur, oracle.logic_step(u, cur, flow)
+        for t in (a, b):
+            t.timer.tick()
+            t.step()
+        if what == "view changes" and k in (2, 3):          # between the step and its draw: what the step saw no longer holds
+            size = [0.5, 0.5 * view[0] / view[1]] if k == 2 else [1.0, view[0] / view[1]]
+            for t in (a, b):
+                t.viewSize[:] = size
+        flow, count = oracle.flow_deposit(cur, prev, flow, time, view_size=tuple(size), speedLimit=oracle.DEFAULT_STATE["speedLimit"], line_width=width)
+        for t in (a, b):
+            t.draw()
+            assert t.fragments == count > 1000
+    for t in (a, b):
+        assert bits_equal(t.flow.read(), flow).all()
+        assert bits_equal(t.particles.read(0), cur).all()
+    assert (a.read_view() == b.read_view()).all()
+    a.dispose(); b.dispose()
