@@ -83,7 +83,6 @@ TH_D uint32_t place_of(const DepositParams &p, uint32_t list, uint32_t v)
     return id == kNoPlace ? kNoPlace : (id << kPageShift) | (v & (kBinPage - 1u));
 }
 // the pages that start inside the reservation [base, base + n) of `list` (n >= 1): taken from the pool and published
-template <bool SUB = false>
 TH_D void pages_open(const DepositParams &p, uint32_t list, uint32_t base, uint32_t n)
 {
     uint32_t pn = (base + kBinPage - 1u) >> kPageShift;
@@ -91,18 +90,9 @@ TH_D void pages_open(const DepositParams &p, uint32_t list, uint32_t base, uint3
     const uint32_t last = (base + n - 1u) >> kPageShift;
     for (; pn <= last; ++pn) {
         if (pn >= p.max_pages) { bins_flag(p, kBinsBinFull); break; }
-        uint32_t k, id;
-        if (SUB) {
-            const uint32_t sub = (list * 2654435761u) >> 26, per = p.pool_pages >> 6;
-            k = atomicAdd(&p.list_n[sub * kDepListStride + 32u], 1u);
-            id = p.nbins * kBinReplicas + sub * per + k;
-            if (k >= per) { id = kNoPlace; bins_flag(p, kBinsPoolExhausted); }
-            atomicAdd(&p.totals[kTotPool], 1u);
-        } else {
-        k = atomicAdd(&p.totals[kTotPool], 1u);
-        id = p.nbins * kBinReplicas + k;
+        const uint32_t k = atomicAdd(&p.totals[kTotPool], 1u);
+        uint32_t id = p.nbins * kBinReplicas + k;
         if (k >= p.pool_pages) { id = kNoPlace; bins_flag(p, kBinsPoolExhausted); }
-        }
         __hip_atomic_store(&p.page_table[(size_t)list * p.max_pages + pn], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -251,10 +241,9 @@ struct LineStage {
     uint32_t pad;                            // (24 words: 16-byte aligned fields)
 };
 
-template <uint32_t BS, bool DEAL, int EXP = 0>
+template <uint32_t BS, bool DEAL>
 __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
 {
-    __shared__ uint32_t wg_total, wg_others, wg_base;
     static_assert(DEAL, "the last phase reads every line's record from the stage (every lane walking its own line's rows was measured and dropped: 0.65 against 0.58 ms)");
     constexpr uint32_t kTab = BS * 4u;          // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly), half full at most
     __shared__ Reservations<kTab> t;
@@ -275,12 +264,10 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     const bool can = s < slots && slot_particle(p, s, col, row);
     __syncthreads();                                    // (the block before is done with the table)
     for (uint32_t e = threadIdx.x; e < kTab; e += BS) { t.tag[e] = 0u; t.sum[e] = 0u; }
-    if (EXP && threadIdx.x == 0u) { wg_total = 0u; wg_others = 0u; }
     __syncthreads();
 
     OwnTexels own;                                      // (both ends of the line, before anything else)
     if (can) { own.have = true; own.cur = p.cur[s]; own.prev = p.prev[s]; }
-    if (EXP == 7) { if (can && p.pool_pages == 0x7fffffffu) p.totals[10] = (uint32_t)(own.cur.x + own.prev.y); continue; }
     DepositLine L;
     L.draws = false;
     LineRecord r{};
@@ -308,7 +295,6 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
             } else if (where == kHexClip) slow = true;
         }
     }
-    if (EXP == 6) { if (p.pool_pages == 0x7fffffffu) p.totals[10] = (uint32_t)L.sx[0] + (uint32_t)L.sy[1] + dealt + (slow ? 1u : 0u) + r.n + (uint32_t)stage[threadIdx.x ^ 1u].PX[3]; continue; }
     if constexpr (DEAL) {
         // The rows of the wave's lines, dealt evenly to its lanes: a lane rasterises ONE row of some line per round (two
         // divisions), whatever the lengths of the lines - walking its own line's rows, a wave runs as many rounds as its
@@ -351,7 +337,6 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
             for (uint32_t k = 0; k < kRecordTexels; ++k) q.rec[k] = r.r[k];
         }
     }
-    if (EXP == 5) { if (p.pool_pages == 0x7fffffffu) p.totals[10] = r.n + r.r[0] + r.r[7] + (slow ? 1u : 0u); continue; }
     const bool lengthy = r.n > kRecordTexels;                // more fragments than a record holds: the long list
     if (lengthy) r.n = 0u;
     const uint32_t n = r.n;
@@ -359,55 +344,9 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     uint32_t took0 = 0, took1 = 0;
     if (n) took0 = resv_take(t, q.b0, q.c0);
     if (q.c1) took1 = resv_take(t, q.b1, q.c1);
-    uint32_t other_at = 0;
-    if (EXP && q.others) other_at = atomicAdd(&wg_others, q.others);
-    if (EXP < 8 || EXP >= 15) {
     dep_list_append(p, kListSlow, block, slow, s);
     dep_list_append(p, kListLong, block, lengthy, s);
-    }
     __syncthreads();
-    if constexpr (EXP != 0 && EXP != 9 && EXP < 13) {
-        // WHAT-IF (experiment; results are not the product's): the workgroup's fragments in ONE contiguous range of the store,
-        // bin after bin - one returning atomic per workgroup, no cursors, no pages
-        constexpr uint32_t kPer = kTab / BS;
-#pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) {
-            const uint32_t e = q * BS + threadIdx.x;
-            if (t.tag[e]) t.sum[e] = atomicAdd(&wg_total, t.sum[e]);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0u) wg_base = EXP >= 10 ? k * 1024u : atomicAdd(&p.totals[9], wg_total + wg_others);
-        const uint32_t id = col * p.H + p.row0 + row;
-        if (EXP == 2 && n) {
-            const float4 again_cur = p.cur[s], again_prev = p.prev[s];
-            auto texel = [&](bool c) { return make_float4(c ? again_cur.x : again_prev.x, c ? again_cur.y : again_prev.y, c ? again_cur.z : again_prev.z, c ? again_cur.w : again_prev.w); };
-            dep_vertex_colors(p, texel(L.a.from_cur), L.a);
-            dep_vertex_colors(p, texel(L.b.from_cur), L.b);
-        }
-        __syncthreads();
-        if (EXP == 4 || EXP == 8 || EXP == 10) { if (n && p.pool_pages == 0x7fffffffu) p.totals[10] = wg_base + t.sum[took0 >> 20] + (q.c1 ? t.sum[took1 >> 20] : 0u) + other_at; continue; }
-        if (n) {
-            const uint32_t v0 = wg_base + t.sum[took0 >> 20] + (took0 & 0xfffffu), v1 = q.c1 ? wg_base + t.sum[took1 >> 20] + (took1 & 0xfffffu) : 0u;
-            uint32_t vo = wg_base + wg_total + other_at;
-            if (EXP != 2) {
-                const float4 again_cur = p.cur[s], again_prev = p.prev[s];
-                auto texel = [&](bool c) { return make_float4(c ? again_cur.x : again_prev.x, c ? again_cur.y : again_prev.y, c ? again_cur.z : again_prev.z, c ? again_cur.w : again_prev.w); };
-                dep_vertex_colors(p, texel(L.a.from_cur), L.a);
-                dep_vertex_colors(p, texel(L.b.from_cur), L.b);
-            }
-            uint32_t i0 = 0, i1 = 0;
-            const uint32_t *rec = stage[threadIdx.x].rec;
-#pragma unroll 1
-            for (uint32_t k = 0; k < n; ++k) {
-                const uint32_t xy = rec[k], x = xy & 0xffffu, y = xy >> 16, b = bin_of(p, x, y);
-                uint32_t at = b == q.b0 ? v0 + i0++ : b == q.b1 ? v1 + i1++ : vo++;
-                if ((EXP == 3 || EXP == 11) && p.pool_pages != 0x7fffffffu) at = kNoPlace;      // (no stores at all)
-                if (EXP == 12) at %= (p.nbins * kBinReplicas + p.pool_pages) * kBinPage;
-                bins_put(p, L, id, at, (int)x, (int)y);
-            }
-        }
-        continue;
-    }
     // the block's share of every bin it met: one atomic each on the cursor of the block's list of that bin; the
     // pages that start inside it are taken from the pool
     const uint32_t rep = block & (kBinReplicas - 1u);
@@ -417,38 +356,21 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
         uint32_t tag[kPer], m[kPer], base[kPer];
 #pragma unroll
         for (uint32_t q = 0; q < kPer; ++q) { tag[q] = t.tag[q * BS + threadIdx.x]; m[q] = t.sum[q * BS + threadIdx.x]; }
-        float4 early_cur{}, early_prev{}, early_ma{}, early_mb{};
-        if (EXP == 15 && n) {
-            early_cur = p.cur[s]; early_prev = p.prev[s];
-            if (p.mode != 0) { early_ma = dep_colormap_texel(p, L.a.uvx, L.a.uvy); early_mb = dep_colormap_texel(p, L.b.uvx, L.b.uvy); }
-        }
-        if (EXP == 15) { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; ++q) base[q] = tag[q] ? (EXP == 13 ? (block * 37u + q * 11u) & 63u : atomicAdd(list_cursor(p, tag[q] - 1u, rep), m[q])) : 0u;
-        if (EXP == 15) {
-            asm volatile("" ::: "memory");
-            if (n) {
-                auto texel = [&](bool c) { return make_float4(c ? early_cur.x : early_prev.x, c ? early_cur.y : early_prev.y, c ? early_cur.z : early_prev.z, c ? early_cur.w : early_prev.w); };
-                dep_vertex_colors(p, texel(L.a.from_cur), early_ma, L.a);
-                dep_vertex_colors(p, texel(L.b.from_cur), early_mb, L.b);
-            }
-            asm volatile("" ::: "memory");
-        }
+        for (uint32_t q = 0; q < kPer; ++q) base[q] = tag[q] ? atomicAdd(list_cursor(p, tag[q] - 1u, rep), m[q]) : 0u;
 #pragma unroll
         for (uint32_t q = 0; q < kPer; ++q) {
             if (tag[q] == 0u) continue;
-            if (EXP == 13 || EXP == 14) { t.sum[q * BS + threadIdx.x] = base[q] & 63u; continue; }
             t.sum[q * BS + threadIdx.x] = base[q];
             if (base[q] + m[q] < base[q]) bins_flag(p, kBinsBinFull);
             else if (((base[q] + m[q] - 1u) >> kPageShift) != (base[q] >> kPageShift) || (base[q] & (kBinPage - 1u)) == 0u)
-                pages_open<EXP == 16>(p, (tag[q] - 1u) * kBinReplicas + rep, base[q], m[q]);
+                pages_open(p, (tag[q] - 1u) * kBinReplicas + rep, base[q], m[q]);
         }
     }
     __syncthreads();
     if (n) {
         // a line's <= 8 places of a bin lie in one page or two: both looked up once, all lookups in flight together
-        uint32_t v0 = t.sum[took0 >> 20] + (took0 & 0xfffffu), v1 = q.c1 ? t.sum[took1 >> 20] + (took1 & 0xfffffu) : 0u;
-        if (EXP == 13 || EXP == 14) { v0 &= 127u; v1 &= 127u; }
+        const uint32_t v0 = t.sum[took0 >> 20] + (took0 & 0xfffffu), v1 = q.c1 ? t.sum[took1 >> 20] + (took1 & 0xfffffu) : 0u;
         const uint32_t l0 = q.b0 * kBinReplicas + rep, l1 = (q.c1 ? q.b1 : q.b0) * kBinReplicas + rep;
         const uint32_t pa0 = v0 >> kPageShift, pb0 = (v0 + q.c0 - 1u) >> kPageShift, pa1 = v1 >> kPageShift, pb1 = (v1 + (q.c1 ? q.c1 - 1u : 0u)) >> kPageShift;
         const uint32_t ga0 = page_of<true>(p, l0, pa0), gb0 = pb0 != pa0 ? page_of<true>(p, l0, pb0) : ga0;
@@ -457,12 +379,10 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
         // (bins run on contexts whose every vertex reads the line's own particle: th_api.hip, lines_local)
         // (the line's texels read again - from the caches - rather than kept through the reservations: the kernel is short of
         // registers, and kept as an array they had gone to scratch memory)
-        if (EXP != 15) {
         const float4 again_cur = p.cur[s], again_prev = p.prev[s];
         auto texel = [&](bool c) { return make_float4(c ? again_cur.x : again_prev.x, c ? again_cur.y : again_prev.y, c ? again_cur.z : again_prev.z, c ? again_cur.w : again_prev.w); };
         dep_vertex_colors(p, texel(L.a.from_cur), L.a);
         dep_vertex_colors(p, texel(L.b.from_cur), L.b);
-        }
         // (one fragment at a time, the record read back from the line's own words of the stage: eight fragments' varyings side
         // by side were the kernel's register peak)
         uint32_t i0 = 0, i1 = 0;
@@ -473,7 +393,7 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
             uint32_t at;
             if (b == q.b0) { const uint32_t v = v0 + i0++, g = (v >> kPageShift) == pa0 ? ga0 : gb0; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
             else if (b == q.b1) { const uint32_t v = v1 + i1++, g = (v >> kPageShift) == pa1 ? ga1 : gb1; at = g == kNoPlace ? kNoPlace : (g << kPageShift) | (v & (kBinPage - 1u)); }
-            else at = (EXP == 13 || EXP == 14) ? (b * kBinReplicas + rep) << kPageShift : place_single(p, b, rep);
+            else at = place_single(p, b, rep);
             bins_put(p, L, id, at, (int)x, (int)y);
         }
     }
@@ -1864,24 +1784,6 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
     // per SIMD instead of 4)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
-    static const int exp_variant = getenv("TH_EMIT_EXP") ? atoi(getenv("TH_EMIT_EXP")) : 0;
-    if (exp_variant == 1) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 1>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 2) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 2>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 3) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 3>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 4) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 4>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 5) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 5>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 6) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 6>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 7) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 7>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 8) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 8>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 10) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 10>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 11) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 11>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 12) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 12>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 13) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 13>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 14) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 14>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 15) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 15>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 16) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 16>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else if (exp_variant == 9) hipLaunchKernelGGL((bins_fused_kernel<256u, true, 9>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    else
     hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 6u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);

@@ -30,18 +30,16 @@ TH_D int dep_nearest(float u, int n)       // NEAREST + CLAMP_TO_EDGE on a float
 // pre-multiplied and clamped, alpha scaled by the speed and a vignette.  Operation order as in the shader (and in the
 // checker's restatement); sin(time*flowDecay) - a uniform-only expression, implementation-defined in GLSL - comes from
 // the host (sin_term).  glsl-map: outMin + (outMax-outMin)*(v-inMin)/(inMax-inMin); mix(a, b, t) = a*(1-t) + b*t.
-// the colour map's texel for a vertex (zero without a map): uv*geomRes/dataRes, geomRes = [W, 2H]
-TH_D float4 dep_colormap_texel(const DepositParams &p, float uvx, float uvy)
-{
-    if (!p.colormap) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float mu = uvx * (float)p.W / (float)p.W, mv = uvy * (float)(2u * p.H) / (float)p.H;
-    return p.colormap[(size_t)dep_nearest(mv, p.ch) * p.cw + dep_nearest(mu, p.cw)];
-}
-TH_D void dep_render_color(const DepositParams &p, float4 state, float4 m, float (&c)[4])
+TH_D void dep_render_color(const DepositParams &p, float4 state, float uvx, float uvy, float (&c)[4])
 {
     const float velx = state.z / p.speed_limit, vely = state.w / p.speed_limit;
     const float speed_rate = __builtin_fminf((velx * velx + vely * vely) / p.speed_alpha, 1.0f);
-    float mapped[4] = {m.x, m.y, m.z, m.w};
+    float mapped[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.colormap) {       // uv*geomRes/dataRes, geomRes = [W, 2H]
+        const float mu = uvx * (float)p.W / (float)p.W, mv = uvy * (float)(2u * p.H) / (float)p.H;
+        const float4 m = p.colormap[(size_t)dep_nearest(mv, p.ch) * p.cw + dep_nearest(mu, p.cw)];
+        mapped[0] = m.x; mapped[1] = m.y; mapped[2] = m.z; mapped[3] = m.w;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) mapped[k] = mapped[k] * p.colormap_alpha;
     const float al[3] = {velx * 1.0f + vely * 0.0f, velx * -0.5000000000000004f + vely * -0.8660254037844385f,
@@ -78,18 +76,13 @@ TH_D void dep_render_color(const DepositParams &p, float4 state, float4 m, float
 // `own`: (optional) the own particle's texels of cur and prev, already loaded.
 // the varyings of a vertex from its state texel `t` (dep_fetch computes them unless told to leave them for later: a pass that
 // rasterises first needs them only for the lines that cover a texel at all)
-// (`m`: the vertex's texel of the colour map, dep_colormap_texel - a pass that has other loads in flight fetches it ahead)
-TH_D void dep_vertex_colors(const DepositParams &p, float4 t, float4 m, DepositVertex &v)
+TH_D void dep_vertex_colors(const DepositParams &p, float4 t, DepositVertex &v)
 {
     if (p.mode != 1) {
         v.c[0] = t.z; v.c[1] = t.w; v.c[2] = p.time;
         v.c[3] = __builtin_fminf(__builtin_sqrtf(t.z * t.z + t.w * t.w) / p.speed_limit, 1.0f);
-        if (p.mode == 2) dep_render_color(p, t, m, v.c2);
-    } else dep_render_color(p, t, m, v.c);
-}
-TH_D void dep_vertex_colors(const DepositParams &p, float4 t, DepositVertex &v)
-{
-    dep_vertex_colors(p, t, p.mode != 0 ? dep_colormap_texel(p, v.uvx, v.uvy) : make_float4(0.0f, 0.0f, 0.0f, 0.0f), v);
+        if (p.mode == 2) dep_render_color(p, t, v.uvx, v.uvy, v.c2);
+    } else dep_render_color(p, t, v.uvx, v.uvy, v.c);
 }
 
 // the line's own texel of both buffers, when the caller holds them already (by VALUE, and chosen between with a select of values:
