@@ -102,7 +102,12 @@ TH_D void pages_forget(const DepositParams &p, uint32_t list, uint32_t n, uint32
     const uint32_t pages = (n + kBinPage - 1u) >> kPageShift;
     for (uint32_t pn = 1u + tid; pn < pages && pn < p.max_pages; pn += threads) p.page_table[(size_t)list * p.max_pages + pn] = 0u;
 }
-TH_D uint32_t *list_cursor(const DepositParams &p, uint32_t bin, uint32_t r) { return p.bin_cursor + (size_t)r * p.bin_stride + bin; }
+// (the cursors of one list index r, transposed in 32 columns: neighbouring bins' cursors 1 KB apart, not in one 128-byte line -
+// the lines that take their places one by one, bins_listed_kernel, meet neighbouring bins at the same time: 50 -> 44 us)
+TH_D uint32_t *list_cursor(const DepositParams &p, uint32_t bin, uint32_t r)
+{
+    return p.bin_cursor + (size_t)r * p.bin_stride + (bin & 31u) * ((p.nbins + 31u) >> 5) + (bin >> 5);
+}
 
 // one fragment into place `at` (kNoPlace: nowhere - the pass is flagged and repeated)
 TH_D void bins_put(const DepositParams &p, const DepositLine &L, uint32_t id, uint32_t at, int x, int y)

@@ -161,7 +161,7 @@ struct DepositParams {
     const uint32_t *block_seen;                    // per block of 256 slots: the four bytes the step left (LogicParams::seen); nullptr: every listed block is walked
     uint32_t draw_nblocks;
     uint32_t bins_x, nbins;
-    uint32_t *bin_cursor, bin_stride;              // per list (r * bin_stride + bin): places handed out so far (virtual indices inside the list)
+    uint32_t *bin_cursor, bin_stride;              // per list (r * bin_stride + the bin's transposed index, th_bins.hip: list_cursor): places handed out so far (virtual indices inside the list)
     uint32_t *page_table;                          // per list x max_pages: page id of the list's n-th page, n >= 1 (0: not handed out yet)
     uint32_t max_pages;                            // pages one list can grow to in this pass (the host widens the table when a bin outgrew it)
     uint32_t pool_pages;                           // pages in the pool: ids nbins * kBinReplicas .. + pool_pages - 1
