@@ -83,6 +83,7 @@ from benchlib.launcher import dry_run, self_launch  # noqa: E402
 from benchlib.legs import c4_leg, c5_leg, cpu_baseline, frame_loop, frame_loop_sharded  # noqa: E402
 from benchlib.pmc import measure_pmc, pmc_bytes  # noqa: E402,F401
 from benchlib.roofline import bind, roofline_entry  # noqa: E402
+from benchlib.sidelegs import SideLegs  # noqa: E402
 from benchlib.workload import (BYTES_PER_PARTICLE_STEP, CONFIGS, HBM_PEAK_GBS, MAX_FUSED, synth_rows, synth_state)  # noqa: E402,F401
 
 
@@ -291,18 +292,18 @@ def main():
         line["counters_every_step"] = {"value": particles * args.steps / wes, "ms_per_step": wes / args.steps * 1e3,
                                        "note": "same K steps, one launch and one counter reduction per step"}
 
-    # (the side legs must not cost the line: whatever goes wrong in them is reported in their place)
-    if world == 1 and args.config == "c3" and not args.no_frame_loop:
-        try:
-            line["frame_loop"] = frame_loop(t, ctx, synth_state(rank))
-        except Exception as e:            # noqa: BLE001
-            line["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if (world > 1 or args.force_dist) and args.config == "c3" and not args.no_frame_loop:
+    # (the side legs must not cost the line: whatever goes wrong in them is reported in their place, and one that never comes
+    # back - a collective some rank does not reach - ends the job with the line as it stands: benchlib/sidelegs.py)
+    legs = SideLegs(line, rank)
+    c3 = args.config == "c3"
+    want_c4 = c3 and not args.no_c4 and not args.flow_size and not under_profiler
+    want_c5 = c3 and not args.no_c5 and not args.flow_size and not under_profiler
+    after = (["c4"] if want_c4 else []) + (["c5"] if want_c5 else [])
+    if world == 1 and c3 and not args.no_frame_loop:
+        legs.run("frame_loop", lambda: frame_loop(t, ctx, synth_state(rank)), after)
+    if (world > 1 or args.force_dist) and c3 and not args.no_frame_loop:
         # (collective: every rank runs it; a rank-local failure inside th_draw_sharded ends the draw on every rank - th_shard.hip)
-        try:
-            line["frame_loop_sharded"] = frame_loop_sharded(job)
-        except Exception as e:            # noqa: BLE001
-            line["frame_loop_sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        legs.run("frame_loop_sharded", lambda: frame_loop_sharded(job), after)
     if rank == 0 and world == 1 and not args.no_cpu:
         try:
             line["cpu_baseline"] = cpu_baseline(t, width, min(rows, W.N))
@@ -310,26 +311,22 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %s: %s" % (type(e).__name__, e)}
     job.dispose()
-    if under_profiler and args.config == "c3" and not args.no_c4:
+    if under_profiler and c3 and not args.no_c4:
         # (a kernel-trace of this command should average the headline's launches, not mix them with config 4's)
         line["c4"] = {"skipped": "under a profiler: run without it (or --config c4) for the config-4 leg"}
-    elif args.config == "c3" and not args.no_c4 and not args.flow_size:
-        # (every rank takes part; a failure on one rank would hang the others in a collective: the leg runs the same
-        # code path as the headline, so what it can still fail on - memory - fails on every rank alike)
-        try:
-            line["c4"] = c4_leg(args, rank, local_rank, world, dist)
-        except Exception as e:            # noqa: BLE001
-            line["c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if under_profiler and args.config == "c3" and not args.no_c5:
+    elif want_c4:
+        # (every rank takes part; the leg runs the same code path as the headline, so what it can still fail on - memory -
+        # fails on every rank alike)
+        legs.run("c4", lambda: c4_leg(args, rank, local_rank, world, dist), ["c5"] if want_c5 else [])
+    if under_profiler and c3 and not args.no_c5:
         line["c5"] = {"skipped": "under a profiler: run without it (or --config c5) for the config-5 leg"}
-    elif args.config == "c3" and not args.no_c5 and not args.flow_size:
-        try:
-            line["c5"] = c5_leg(args, rank, local_rank, world, dist)
-        except Exception as e:            # noqa: BLE001
-            line["c5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    elif want_c5:
+        legs.run("c5", lambda: c5_leg(args, rank, local_rank, world, dist))
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        def finish():
+            dist.barrier()
+            dist.destroy_process_group()
+        legs.run("shutdown", finish, record=False)
     if rank == 0:
         # RCCL prints its version banner through C stdio (flushed at exit when stdout is a pipe): push it out first, so
         # that the JSON line is the last thing on stdout

@@ -109,10 +109,25 @@ def dry_run(args, rank, world):
             "rccl": {"world": world, "nranks_seen": state["red"]["particles"] / float(rows * n), "backend": "gloo",
                      "reductions_per_timed_repetition": state["reductions"]},
             "counters": state["red"]}
-    line["c5"] = dry_c5(args, rank, world, dist, O)
-    line["frame_loop_sharded"] = dry_frame_loop_sharded(rank, world, dist, O, state["band"], fl, row0, gheight)
-    dist.barrier()
-    dist.destroy_process_group()
+    # the side legs under their deadlines, as in the GPU run (benchlib/sidelegs.py).  TH_BENCH_TEST_HANG=<leg>:<rank> (tests): that
+    # rank never reaches the leg's first collective
+    from .sidelegs import SideLegs
+    legs = SideLegs(line, rank)
+    hang = os.environ.get("TH_BENCH_TEST_HANG", "")
+
+    def leg(name, fn):
+        def body():
+            if hang == "%s:%d" % (name, rank):
+                time.sleep(1e6)
+            return fn()
+        return body
+    legs.run("c5", leg("c5", lambda: dry_c5(args, rank, world, dist, O)), ["frame_loop_sharded"])
+    legs.run("frame_loop_sharded", leg("frame_loop_sharded", lambda: dry_frame_loop_sharded(rank, world, dist, O, state["band"], fl, row0, gheight)))
+
+    def finish():
+        dist.barrier()
+        dist.destroy_process_group()
+    legs.run("shutdown", finish, record=False)
     if rank == 0:
         print(json.dumps(line), flush=True)
 

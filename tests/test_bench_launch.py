@@ -61,3 +61,18 @@ def test_roofline_fraction_names_its_bound():
     # one step per launch streams its algorithmic bytes
     e = bench.bind(bench.roofline_entry(J, 0.134e-3, 1, None, 32), False)
     assert e["bound"] == "hbm" and e["frac"] == e["equivalent_frac"] < 1
+
+
+def test_a_leg_that_never_comes_back_does_not_cost_the_line(oracle):
+    """Rank 1 never reaches the config-5 leg's first collective: after the leg's deadline rank 0 prints the line it has - the
+    headline, the leg marked as abandoned, the leg behind it as not run - and every rank ends (benchlib/sidelegs.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TH_BENCH_TEST_HANG="c5:1", TH_BENCH_LEG_TIMEOUT="8")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1",
+                        "--reps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 2 and line["rccl"]["nranks_seen"] == 2.0
+    assert "no result within 8 s" in line["c5"]["error"] and "c5" in line["frame_loop_sharded"]["skipped"]
