@@ -1118,6 +1118,7 @@ __global__ __launch_bounds__(256) void crowd_scan_kernel(const DepositParams p)
     __shared__ uint32_t wave_total[4];
     const uint32_t i = blockIdx.x, t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t mine = p.crowd_count[(size_t)i * kBinTexels + t];
+    p.crowd_count[(size_t)i * kBinTexels + t] = 0u;         // (left empty for the next pass: no memset between a pass's plan and its regroup)
     uint32_t incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((int)lane >= o) incl += up; }
@@ -1830,7 +1831,7 @@ void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipS
 void launch_bins_regroup(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;
-    (void)hipMemsetAsync(p.crowd_count, 0, (size_t)p.nlarge * kBinTexels * sizeof(uint32_t), s);
+    // (p.crowd_count is all zero: th_draw.hip clears it when it is allocated, crowd_scan_kernel behind every count it reads)
     hipLaunchKernelGGL(crowd_hist_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_scan_kernel, dim3(p.nlarge), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_scatter_kernel, dim3(p.nlarge * kBinReplicas), dim3(256), 0, s, p);

@@ -540,6 +540,9 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         (void)hipFree(c->crowd_mem); c->crowd_mem = nullptr; c->crowd_capacity = 0;
         const uint32_t cap = std::min(p.nbins, std::max(2u * nlarge + 256u, p.nbins / 4u));      // (a quarter of the bins at once: no growth step by step)
         TH_HIP(hipMalloc((void **)&c->crowd_mem, (size_t)cap * th::crowd_words_per_bin() * sizeof(uint32_t)));
+        // (the fragment counts per texel - the first cap * 256 words - start from zero; crowd_scan_kernel leaves them so)
+        TH_HIP(hipMemsetAsync(c->crowd_mem, 0, (size_t)cap * 256 * sizeof(uint32_t), c->stream));
+        TH_HIP(hipStreamSynchronize(c->stream));         // (whichever stream the regroup runs on: a new buffer is rare)
         c->crowd_capacity = cap;
     }
     if (c->crowd_keys_cap < host[th::kTotCrowdKeys]) {
@@ -561,17 +564,34 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
     p.crowd_giant_win = p.crowd_giant + (size_t)c->crowd_capacity * 256;
     p.crowd_keys = c->crowd_keys; p.crowd_sorted = c->crowd_sorted; p.crowd_parted = c->crowd_parted;
     p.crowd_windows = c->crowd_windows; p.crowd_windows_cap = (uint32_t)(c->crowd_keys_cap / 512 + 2);
-    if (nlarge) {
-        // The crowded bins on two streams of their own, beside the ordinary bins' blend (disjoint texels, kernels that wait on
-        // chains and loads rather than fill the chip): their fragments regrouped by texel, then the long runs on one stream -
-        // the walk of the longest run, one fragment after the other, overlaps with everything else instead of following it -
+    if (nlarge && !blended_early) {
+        // A crowded target: the crowded bins' short runs - regroup, sort, walk: the longest chain of the draw - stay on the MAIN
+        // stream, right behind the plan (no event to wait for) and right in front of whatever the host sends next (a frame
+        // loop's next step: behind a chain that ends on a side stream it waited 17-26 us for the join); beside them, on the
+        // side streams, the ordinary bins' blend (disjoint texels, kernels that wait on chains and loads rather than fill the
+        // chip) and the long runs - the walk of the longest run, one fragment after the other, overlaps with everything else.
+        th::launch_bins_regroup(p, c->stream);
+        TH_HIP(hipEventRecord(c->regrouped, c->stream));
+        TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan)
+        th::launch_bins_blend(p, c->side2);
+        TH_HIP(hipEventRecord(c->joined2, c->side2));
+        TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
+        th::launch_bins_blend_giants(p, c->side);
+        th::launch_bins_sort_long(p, c->side);
+        // (the two side streams join each other first - the ordinary bins' blend is long done when the long runs' last kernel
+        // starts - and the main stream waits for ONE event: a wait costs it ~9 us even when the event has long been signalled)
+        TH_HIP(hipStreamWaitEvent(c->side, c->joined2, 0));
+        th::launch_bins_walk_long(p, c->side);
+        TH_HIP(hipEventRecord(c->joined, c->side));
+        th::launch_bins_blend_crowd(p, c->stream);
+        TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
+    } else if (nlarge) {
+        // The ordinary bins' blend went out early on the main stream (few fragments in crowded bins last time): the crowded
+        // bins on two streams of their own beside it - their fragments regrouped by texel, then the long runs on one stream
         // and the short runs on the other.
         TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan: the ordinary bins' blend need not be waited for)
         th::launch_bins_regroup(p, c->side2);
         TH_HIP(hipEventRecord(c->regrouped, c->side2));
-        // (the ordinary bins' blend goes out as soon as the head of the longest chain has: behind all of the crowded bins'
-        // launches - fifteen of them - the main stream stood idle for 100 us)
-        if (!blended_early) { th::launch_bins_blend(p, c->stream); blended_early = true; }
         TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
         th::launch_bins_blend_giants(p, c->side);
         // ... and the runs in between behind them.  (A stream of their own shares a hardware queue with one of the others -
@@ -584,11 +604,8 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         TH_HIP(hipEventRecord(c->joined, c->side));
         th::launch_bins_blend_crowd(p, c->side2);
         TH_HIP(hipEventRecord(c->joined2, c->side2));
-    }
-    if (!blended_early) th::launch_bins_blend(p, c->stream);
-    if (nlarge) {
         TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0));
-    }
+    } else if (!blended_early) th::launch_bins_blend(p, c->stream);
     TH_HIP(hipGetLastError());
     c->bins_dirty = false;          // (every reader of a list leaves its places and its table entries empty)
     return TH_OK;
