@@ -83,7 +83,7 @@ from benchlib.launcher import dry_run, self_launch  # noqa: E402
 from benchlib.legs import c4_leg, c5_leg, cpu_baseline, frame_loop, frame_loop_sharded  # noqa: E402
 from benchlib.pmc import measure_pmc, pmc_bytes  # noqa: E402,F401
 from benchlib.roofline import bind, roofline_entry  # noqa: E402
-from benchlib.sidelegs import SideLegs  # noqa: E402
+from benchlib.sidelegs import SideLegs, Stages  # noqa: E402
 from benchlib.workload import (BYTES_PER_PARTICLE_STEP, CONFIGS, HBM_PEAK_GBS, MAX_FUSED, synth_rows, synth_state)  # noqa: E402,F401
 
 
@@ -125,6 +125,8 @@ def main():
     if args.dry_run:
         return dry_run(args, rank, world)
     cfg = CONFIGS[args.config]
+    stages = Stages(rank, world, {"metric": "particle-steps/sec (16M particles per GPU)" if args.config == "c3" else "particle-steps/sec (%s)" % args.config,
+                                  "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup})
     state_fmt = args.state or cfg["state"]
     group = cfg["group"]
     launch_len = args.pmc_child or min(group, args.steps)
@@ -134,6 +136,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_traffic and not args.force_dist and not under_profiler and not args.pmc_child:
         extra = ["--mode", args.mode, "--config", args.config, "--state", state_fmt] + \
                 (["--in-view"] if args.in_view else []) + (["--flow-size", args.flow_size] if args.flow_size else [])
+        stages.at("PMC child passes (rocprofv3)")
         pmc, pmc_note = measure_pmc(extra, launch_len)
 
     import torch
@@ -142,12 +145,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        stages.at("torch.distributed init (RCCL)")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import tendrils_amd as ta
     from tendrils_amd import _capi
 
+    stages.at("context, state upload, the library's communicator")
     job = Job(args, args.config, rank, local_rank, world, dist, launch_len=launch_len)
     t, ctx = job.t, job.ctx
     width, rows = job.width, job.rows
@@ -168,8 +173,10 @@ def main():
         job.dispose()
         return
 
+    stages.at("warm-up")
     run(args.warmup)
     preroll_ms = job.preroll()
+    stages.at("timed region")
 
     job.reductions = 0
     walls = job.timed_region(args.steps, args.reps)
@@ -180,6 +187,7 @@ def main():
     if args.config == "c4":
         walls_every_step = job.timed_region(args.steps, max(args.reps // 2, 2), every=1, refresh=False)
 
+    stages.at("kernel-only passes (roofline)")
     # kernel-only pass for the roofline: the same K steps in the same launches as the timed region, a HIP event
     # pair around every launch on the context's own stream
     run_kernel_only(2 * launch_len, launch_len)
@@ -199,6 +207,7 @@ def main():
     _capi.call("th_set_mode", ctx, ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT)
     sync_all()
 
+    stages.at("statistics, flow-only launches")
     stats = job.global_stats()          # (local pass + the library's all-reduce: every rank holds the job's counters)
 
     # second uniform set of BASELINE.md 3: flow only (noiseWeight = 0), same launches, after everything else
@@ -216,6 +225,7 @@ def main():
         t.state["noiseWeight"] = keep
         sync_all()
 
+    stages.at("max over ranks")
     walls = job.max_over_ranks(walls)
     kern_s, single_s = job.max_over_ranks([k_ms / 1e3, s_ms / 1e3])
     if walls_every_step is not None:
@@ -294,6 +304,8 @@ def main():
 
     # (the side legs must not cost the line: whatever goes wrong in them is reported in their place, and one that never comes
     # back - a collective some rank does not reach - ends the job with the line as it stands: benchlib/sidelegs.py)
+    stages.at("side legs")
+    stages.done()                       # (the headline stands: from here on every leg has its own deadline)
     legs = SideLegs(line, rank)
     c3 = args.config == "c3"
     want_c4 = c3 and not args.no_c4 and not args.flow_size and not under_profiler

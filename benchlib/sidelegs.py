@@ -23,6 +23,9 @@ class SideLegs:
         record=False: a step that has no entry of its own unless it goes wrong (the job's last barrier)"""
         with self.lock:
             self.running = name
+        if self.rank == 0:
+            import sys
+            print("[bench] leg: %s" % name, file=sys.stderr, flush=True)
         # (the other ranks leave a little later than rank 0: its line first)
         timer = threading.Timer(self.seconds + (0.0 if self.rank == 0 else 10.0), self._abandon, (name, tuple(pending)))
         timer.daemon = True
@@ -51,3 +54,39 @@ class SideLegs:
                     pass
                 print(json.dumps(self.line), flush=True)
             os._exit(0)
+
+
+class Stages:
+    """Where the job is, on stderr as it goes (rank 0; one short line per stage with the seconds since the start) - a run that is
+    ended from outside leaves its last stage in the log -, and a deadline for the whole job (TH_BENCH_TIMEOUT seconds, default
+    2400): a headline that never comes - a communicator that does not come up, a collective inside the timed region that some
+    rank does not reach - ends with a line that says where it stood instead of silence."""
+
+    def __init__(self, rank, world, describe):
+        import sys
+        import time
+        self.rank, self.world, self.describe, self.t0, self.now = rank, world, describe, time.time(), "start"
+        self._time, self._err = time, sys.stderr
+        seconds = float(os.environ.get("TH_BENCH_TIMEOUT", "2400"))
+        self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 10.0), self._expired, (seconds,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def at(self, name):
+        self.now = name
+        if self.rank == 0:
+            print("[bench] %7.1f s  %s" % (self._time.time() - self.t0, name), file=self._err, flush=True)
+
+    def done(self):
+        self.timer.cancel()
+
+    def _expired(self, seconds):
+        if self.rank == 0:
+            line = dict(self.describe)
+            line.update(value=None, error="no result within %.0f s; the job stood at: %s" % (seconds, self.now))
+            try:
+                C.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            print(json.dumps(line), flush=True)
+        os._exit(3)
