@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void bins_zero_kernel(uint32_t *a, uint32_t na
 // pass 1.  Per slot: the line set up, classified, and - the common case: a small hexagon inside the view, all in registers -
 // rasterised into a record of <= kRecordTexels texels; its places reserved per bin, exactly; its fragments written.
 // a line's hexagon and its record while the wave's rows are dealt to its lanes (LDS, one per line of the workgroup)
-constexpr uint32_t kMaxRowsDealt = 16;       // lines of more rows (none of ordinary length: a line is <= 10 texels long) walk their own rows
+constexpr uint32_t kMaxRowsDealt = 12;       // lines of more rows (none of ordinary length: a line is <= 10 texels long) walk their own rows
 struct LineStage {
     int PX[6], PY[6];
     int r0;                                  // first row
@@ -246,11 +246,13 @@ struct LineStage {
     uint32_t pad;                            // (24 words: 16-byte aligned fields)
 };
 
+// (five workgroups per CU: 31 KB of LDS each - a table of 2 entries per line, rows dealt up to 12 per line - and 96 VGPRs, nine
+// words of a lane spilled to scratch memory: 583 -> 563 us against four workgroups of 37 KB and 118 VGPRs, profiles/r5_h)
 template <uint32_t BS, bool DEAL>
-__global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
+__global__ __launch_bounds__(BS, 5) void bins_fused_kernel(const DepositParams p)
 {
     static_assert(DEAL, "the last phase reads every line's record from the stage (every lane walking its own line's rows was measured and dropped: 0.65 against 0.58 ms)");
-    constexpr uint32_t kTab = BS * 4u;          // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly), half full at most
+    constexpr uint32_t kTab = BS * 2u;          // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly): never more bins than entries
     __shared__ Reservations<kTab> t;
     __shared__ LineStage stage[DEAL ? BS : 1u];
     __shared__ uint8_t owner[DEAL ? BS / 64u : 1u][DEAL ? 64u * kMaxRowsDealt : 1u];     // per wave: the line (lane) of every dealt row
@@ -259,15 +261,17 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
     // (th_kernels.hip: tile_key): most blocks of 256 slots meet only one kind - whole waves of lines that exist, or nothing to
     // do.  The blocks with something to do are listed once per slot order (bins_block_list_kernel): half of all blocks never
     // start.
-    for (uint32_t k = blockIdx.x; k < p.draw_nblocks; k += gridDim.x) {
-    const uint32_t block = p.draw_blocks[k];
+    // (ONE listed block per workgroup, no loop: what the body computes from the pass's parameters alone - a dozen integer-to-float
+    // conversions - is then computed where it is used; hoisted out of a loop over blocks it was held in registers across the
+    // whole body, and with 96 of them spilled to scratch memory)
+    if (blockIdx.x >= p.draw_nblocks) return;
+    const uint32_t block = p.draw_blocks[blockIdx.x];
     // (a frame loop: the step that wrote these slots saw every line of the block end up beyond one edge of the view - nothing
     // of it would be rasterised, listed or counted: LogicParams::seen)
-    if (p.block_seen && p.block_seen[block] == 0u) continue;
+    if (p.block_seen && p.block_seen[block] == 0u) return;
     const uint32_t s = block * BS + threadIdx.x;
     uint32_t col = 0, row = 0;
     const bool can = s < slots && slot_particle(p, s, col, row);
-    __syncthreads();                                    // (the block before is done with the table)
     for (uint32_t e = threadIdx.x; e < kTab; e += BS) { t.tag[e] = 0u; t.sum[e] = 0u; }
     __syncthreads();
 
@@ -401,7 +405,6 @@ __global__ __launch_bounds__(BS) void bins_fused_kernel(const DepositParams p)
             else at = place_single(p, b, rep);
             bins_put(p, L, id, at, (int)x, (int)y);
         }
-    }
     }
 }
 
