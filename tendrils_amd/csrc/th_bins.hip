@@ -238,18 +238,18 @@ __global__ __launch_bounds__(256) void bins_zero_kernel(uint32_t *a, uint32_t na
 // a line's hexagon and its record while the wave's rows are dealt to its lanes (LDS, one per line of the workgroup)
 constexpr uint32_t kMaxRowsDealt = 12;       // lines of more rows (none of ordinary length: a line is <= 10 texels long) walk their own rows
 struct LineStage {
-    int PX[6], PY[6];
-    int r0;                                  // first row
+    int bx, by;                              // the hexagon's least x and y (sixteenths of a texel) ...
+    uint32_t pxy[6];                         // ... and its corners from there: x | y << 16 (a small hexagon is less than 4096 x 1024 sixteenths)
     uint32_t first;                          // first of the line's (line, row) pairs among the wave's
     uint32_t n;                              // fragments so far
     uint32_t rec[kRecordTexels];
-    uint32_t pad;                            // (24 words: 16-byte aligned fields)
+    uint32_t pad;                            // (19 words: an odd stride - a wave's lines in different banks)
 };
 
-// (five workgroups per CU: 31 KB of LDS each - a table of 2 entries per line, rows dealt up to 12 per line - and 96 VGPRs, nine
-// words of a lane spilled to scratch memory: 583 -> 563 us against four workgroups of 37 KB and 118 VGPRs, profiles/r5_h)
+// (six workgroups per CU: 26 KB of LDS each - a table of 2 entries per line, rows dealt up to 12 per line, the hexagon packed - and
+// at most 80 VGPRs; four workgroups of 37 KB and 118 VGPRs: 580 us, five of 31 KB and 81: 492-512, profiles/r5_h)
 template <uint32_t BS, bool DEAL>
-__global__ __launch_bounds__(BS, 5) void bins_fused_kernel(const DepositParams p)
+__global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p)
 {
     static_assert(DEAL, "the last phase reads every line's record from the stage (every lane walking its own line's rows was measured and dropped: 0.65 against 0.58 ms)");
     constexpr uint32_t kTab = BS * 2u;          // table entries: <= 2 bins per line reserve here (a third bin goes to its cursor directly): never more bins than entries
@@ -296,9 +296,12 @@ __global__ __launch_bounds__(BS, 5) void bins_fused_kernel(const DepositParams p
                     if (DEAL && r1 - r0 <= (int)kMaxRowsDealt) {
                         dealt = r1 > r0 ? (uint32_t)(r1 - r0) : 0u;
                         LineStage &g = stage[threadIdx.x];
+                        int xmin = PX[0];
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) { g.PX[k] = PX[k]; g.PY[k] = PY[k]; }
-                        g.r0 = r0;
+                        for (int k = 1; k < 6; ++k) xmin = PX[k] < xmin ? PX[k] : xmin;
+                        g.bx = xmin; g.by = ymin;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) g.pxy[k] = (uint32_t)(PX[k] - xmin) | ((uint32_t)(PY[k] - ymin) << 16);
                     } else dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
                 } else slow = true;
             } else if (where == kHexClip) slow = true;
@@ -323,8 +326,9 @@ __global__ __launch_bounds__(BS, 5) void bins_fused_kernel(const DepositParams p
                 LineStage &q = stage[(wave << 6) + owner[wave][g]];
                 int QX[6], QY[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { QX[k] = q.PX[k]; QY[k] = q.PY[k]; }
-                const int y = q.r0 + (int)(g - q.first);
+                for (int k = 0; k < 6; ++k) { const uint32_t w = q.pxy[k]; QX[k] = q.bx + (int)(w & 0xffffu); QY[k] = q.by + (int)(w >> 16); }
+                const int top = (q.by + 15) >> 4;                      // (the line's first row, as its thread clamped it)
+                const int y = (top < 0 ? 0 : top) + (int)(g - q.first);
                 int left, right;
                 dep_hexagon_row_span(p, QX, QY, y, left, right);
                 if (right > left) {
