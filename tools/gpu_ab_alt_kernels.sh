@@ -12,13 +12,13 @@ for v in head alt; do
   echo "== $v frames $frames  $(grep -o '"draw_both_ms": [0-9.]*' /tmp/prof_w.log)"
   f=$(find /tmp/prof_w -name '*kernel_trace.csv' | head -1)
   python3 - "$f" <<'PY'
-import csv, sys, statistics
+import csv, os, sys, statistics
 d = {}
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void th::", "").replace("th::", "")
     d.setdefault(n.split("(")[0][:44], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:12]:
-    if any(k in n for k in (sys.argv[2:] or ["bins_fused", "bins_listed"])):
+    if any(k in n for k in (os.environ.get("KERNELS", "bins_fused bins_listed").split())):
         print("   %-46s calls %5d  median %8.1f us  mean %8.1f" % (n, len(v), statistics.median(v), statistics.mean(v)))
 PY
   done
