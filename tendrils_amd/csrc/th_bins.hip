@@ -1085,13 +1085,16 @@ TH_D void crowd_block(const DepositParams &p, uint32_t block, uint32_t &i, uint3
     list = b * kBinReplicas + r;
     n = *list_cursor(p, b, r);
 }
-// the fragments of a list in rounds of kBinCap places: round(keys of the thread, their places, first index, places in the round)
+// the fragments of a list in rounds of kCrowdRound places: round(keys of the thread, their places, first index, places in the round)
+// (2048: a list of a crowded bin holds 700 fragments on average - one round either way - and eight keys and places a thread
+// instead of sixteen are 24 registers: crowd_scatter_kernel 92 -> 6x VGPRs)
+constexpr uint32_t kCrowdRound = 2048;
 template <typename Round>
 TH_D void crowd_rounds(const DepositParams &p, uint32_t list, uint32_t n, Round round)
 {
-    constexpr uint32_t kPer = kBinCap / 256u;
-    for (uint32_t f0 = 0; f0 < n; f0 += kBinCap) {
-        const uint32_t m = n - f0 < kBinCap ? n - f0 : kBinCap;
+    constexpr uint32_t kPer = kCrowdRound / 256u;
+    for (uint32_t f0 = 0; f0 < n; f0 += kCrowdRound) {
+        const uint32_t m = n - f0 < kCrowdRound ? n - f0 : kCrowdRound;
         uint32_t at[kPer];
         unsigned long long k[kPer];
 #pragma unroll
@@ -1112,9 +1115,9 @@ __global__ __launch_bounds__(256) void crowd_hist_kernel(const DepositParams p)
     if (n == 0u) return;
     hist[threadIdx.x] = 0u;
     __syncthreads();
-    crowd_rounds(p, list, n, [&](const unsigned long long (&k)[kBinCap / 256u], const uint32_t (&)[kBinCap / 256u], uint32_t) {
+    crowd_rounds(p, list, n, [&](const unsigned long long (&k)[kCrowdRound / 256u], const uint32_t (&)[kCrowdRound / 256u], uint32_t) {
 #pragma unroll
-        for (uint32_t q = 0; q < kBinCap / 256u; ++q) if (k[q] != kEmptyKey) atomicAdd(&hist[key_local(k[q])], 1u);
+        for (uint32_t q = 0; q < kCrowdRound / 256u; ++q) if (k[q] != kEmptyKey) atomicAdd(&hist[key_local(k[q])], 1u);
     });
     __syncthreads();
     if (hist[threadIdx.x]) atomicAdd(&p.crowd_count[(size_t)i * kBinTexels + threadIdx.x], hist[threadIdx.x]);
@@ -1159,17 +1162,17 @@ __global__ __launch_bounds__(256) void crowd_scatter_kernel(const DepositParams 
     if (n == 0u) return;
     const uint32_t t = threadIdx.x;
     unsigned long long *out = p.crowd_keys + p.large_key0[i];
-    crowd_rounds(p, list, n, [&](const unsigned long long (&k)[kBinCap / 256u], const uint32_t (&at)[kBinCap / 256u], uint32_t m) {
+    crowd_rounds(p, list, n, [&](const unsigned long long (&k)[kCrowdRound / 256u], const uint32_t (&at)[kCrowdRound / 256u], uint32_t m) {
         hist[t] = 0u;
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < kBinCap / 256u; ++q) if (k[q] != kEmptyKey) atomicAdd(&hist[key_local(k[q])], 1u);
+        for (uint32_t q = 0; q < kCrowdRound / 256u; ++q) if (k[q] != kEmptyKey) atomicAdd(&hist[key_local(k[q])], 1u);
         __syncthreads();
         base[t] = hist[t] ? atomicAdd(&p.crowd_cursor[(size_t)i * kBinTexels + t], hist[t]) : 0u;
         hist[t] = 0u;
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < kBinCap / 256u; ++q) {
+        for (uint32_t q = 0; q < kCrowdRound / 256u; ++q) {
             if (k[q] != kEmptyKey) {
                 const uint32_t lt = key_local(k[q]);
                 out[base[lt] + atomicAdd(&hist[lt], 1u)] = ((k[q] & 0xffffffffull) << 32) | at[q];
