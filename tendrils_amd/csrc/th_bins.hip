@@ -1516,11 +1516,18 @@ TH_D void lanes_rank_sort(const unsigned long long *run, uint32_t *sorted, uint3
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // (`trips`: the longest run of the wave's groups - every lane goes round as often, a group past its own run counts nothing)
-    for (uint32_t j = 0; j < trips; ++j) {
-        const uint32_t k = ids[j < len ? j : 0u];
-        const bool in = j < len;
+    // Four stream indices a trip, one 16-byte LDS read (the groups' words start 256 B apart; the words past a run's end hold
+    // whatever they held: `in` leaves them out): a trip per index waited for its own read - crowd_sort_kernel 198 -> 1xx us
+    const uint4 *ids4 = reinterpret_cast<const uint4 *>(ids);
+    for (uint32_t j = 0; j < trips; j += 4u) {
+        const uint4 k4 = ids4[j >> 2];
+        const uint32_t k[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-        for (uint32_t q = 0; q < K; ++q) rank[q] += (in && k < id[q]) ? 1u : 0u;
+        for (uint32_t e = 0; e < 4u; ++e) {
+            const bool in = j + e < len;
+#pragma unroll
+            for (uint32_t q = 0; q < K; ++q) rank[q] += (in && k[e] < id[q]) ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (uint32_t q = 0; q < K; ++q) { const uint32_t f = q * LANES + sl; if (f < len) sorted[rank[q]] = (uint32_t)(mine[q] & 0xffffffffull); }
@@ -1532,7 +1539,7 @@ TH_D void lanes_rank_sort(const unsigned long long *run, uint32_t *sorted, uint3
 __global__ __launch_bounds__(256) void crowd_sort_kernel(const DepositParams p)
 {
     static_assert(kWaveRun == 256u, "four keys per lane");
-    __shared__ uint32_t ids[4][kWaveRun];
+    __shared__ __align__(16) uint32_t ids[4][kWaveRun];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, sub = lane >> 4, sl = lane & 15u;
     const uint32_t g = blockIdx.x * 4u + wave, i = g >> 6, lt0 = (g & 63u) << 2;          // texels lt0 .. lt0 + 3 of large bin i
     if (i >= p.nlarge) return;
