@@ -1858,10 +1858,14 @@ void launch_bins_regroup(const DepositParams &p, hipStream_t s)
 // fragments is applied one after the other for a few hundred microseconds: the caller puts this on a stream of its own beside
 // launch_bins_blend (disjoint texels), so that the walk overlaps with everything else instead of following it.  Last, the
 // runs giant_part_kernel left alone (more of one bucket than a window holds), a workgroup each.
-void launch_bins_blend_giants(const DepositParams &p, hipStream_t s)
+void launch_bins_part_giants(const DepositParams &p, hipStream_t s)
 {
     if (!p.nlarge) return;
     hipLaunchKernelGGL(giant_part_kernel, dim3(2048), dim3(256), 0, s, p);
+}
+void launch_bins_blend_giants(const DepositParams &p, hipStream_t s)
+{
+    if (!p.nlarge) return;
     hipLaunchKernelGGL(giant_sort_kernel, dim3(4096), dim3(256), 0, s, p);
 #define TH_GO(M) do { hipLaunchKernelGGL((run_walk_kernel<M, true>), dim3(512), dim3(256), 0, s, p); \
                       hipLaunchKernelGGL(crowd_blend_kernel<M>, dim3(256), dim3(256), 0, s, p, (const uint32_t *)p.crowd_giant, (const uint32_t *)(p.totals + kTotGiant)); } while (0)

@@ -571,6 +571,7 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         // side streams, the ordinary bins' blend (disjoint texels, kernels that wait on chains and loads rather than fill the
         // chip) and the long runs - the walk of the longest run, one fragment after the other, overlaps with everything else.
         th::launch_bins_regroup(p, c->stream);
+        th::launch_bins_part_giants(p, c->stream);          // (the long runs' stream is the longer one: its first kernel here)
         TH_HIP(hipEventRecord(c->regrouped, c->stream));
         TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan)
         th::launch_bins_blend(p, c->side2);
@@ -591,6 +592,7 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         // and the short runs on the other.
         TH_HIP(hipStreamWaitEvent(c->side2, c->forked, 0));       // (recorded behind the emitting pass and its plan: the ordinary bins' blend need not be waited for)
         th::launch_bins_regroup(p, c->side2);
+        th::launch_bins_part_giants(p, c->side2);
         TH_HIP(hipEventRecord(c->regrouped, c->side2));
         TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
         th::launch_bins_blend_giants(p, c->side);

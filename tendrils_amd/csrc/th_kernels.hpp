@@ -270,6 +270,7 @@ void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipS
 void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_owner_insert(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_regroup(const DepositParams &p, hipStream_t stream);                 // the large bins' fragments regrouped by texel
+void launch_bins_part_giants(const DepositParams &p, hipStream_t stream);             // the giants' keys parted by stream index (behind the regroup, ahead of launch_bins_blend_giants)
 void launch_bins_blend_giants(const DepositParams &p, hipStream_t stream);            // their runs of more than kGiantRun fragments, a workgroup each (the longest chains of a draw)
 void launch_bins_sort_long(const DepositParams &p, hipStream_t stream);               // their runs a wave orders on its own (kWaveRun + 1 .. kGiantRun fragments) ...
 void launch_bins_walk_long(const DepositParams &p, hipStream_t stream);               // ... walked
