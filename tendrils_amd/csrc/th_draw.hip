@@ -579,13 +579,13 @@ th_status bins_pass_finish(th_context *c, th::DepositParams &p, uint64_t *fragme
         TH_HIP(hipStreamWaitEvent(c->side, c->regrouped, 0));
         th::launch_bins_blend_giants(p, c->side);
         th::launch_bins_sort_long(p, c->side);
-        // (the two side streams join each other first - the ordinary bins' blend is long done when the long runs' last kernel
-        // starts - and the main stream waits for ONE event: a wait costs it ~9 us even when the event has long been signalled)
-        TH_HIP(hipStreamWaitEvent(c->side, c->joined2, 0));
         th::launch_bins_walk_long(p, c->side);
         TH_HIP(hipEventRecord(c->joined, c->side));
         th::launch_bins_blend_crowd(p, c->stream);
-        TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0));
+        // (both side streams waited for by the main stream: a wait costs it ~9 us even when the event has long been signalled, but
+        // with the crowded bins' sort at 140 us the ordinary bins' blend ends LAST as often as not - the long runs' last kernel
+        // waiting for it, so that the main stream had one event to wait for, stood idle in half of the frames)
+        TH_HIP(hipStreamWaitEvent(c->stream, c->joined, 0)); TH_HIP(hipStreamWaitEvent(c->stream, c->joined2, 0));
     } else if (nlarge) {
         // The ordinary bins' blend went out early on the main stream (few fragments in crowded bins last time): the crowded
         // bins on two streams of their own beside it - their fragments regrouped by texel, then the long runs on one stream
