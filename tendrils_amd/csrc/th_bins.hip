@@ -642,14 +642,32 @@ TH_D void quad_walk(const DepositParams &p, uint32_t texel, uint32_t len, uint32
     const float *colors = reinterpret_cast<const float *>(p.colors);
     constexpr uint32_t kAhead = 8u, kFloats = MODE == 2 ? 8u : 4u;
     struct Piece { float c0, a0, c1, a1; };                   // the lane's component and the alpha of the fragment's varying(s)
+    // Both varyings (32 B): ONE 8-byte load a lane - floats 2c and 2c + 1 - and the quad hands the components round (six moves
+    // inside the quad and two selects) instead of four 4-byte loads a lane: a quarter of the load instructions of a kernel
+    // that is all loads.
+    struct Raw { float x, y, z, w; };
     auto fetch = [&](uint32_t place) {
         const float *at = colors + (size_t)place * kFloats;
-        Piece q{};
-        q.c0 = at[c]; q.a0 = at[3];
-        if constexpr (MODE == 2) { q.c1 = at[4u + c]; q.a1 = at[7]; }
+        Raw q{};
+        if constexpr (MODE == 2) { const float2 v = *reinterpret_cast<const float2 *>(at + 2u * c); q.x = v.x; q.y = v.y; }
+        else { q.x = at[c]; q.y = at[3]; }
         return q;
     };
-    auto apply = [&](const Piece &q) {
+    auto quad = [](float v, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    auto unpack = [&](const Raw &r) {
+        Piece q{};
+        if constexpr (MODE == 2) {
+            const bool odd = (c & 1u) != 0u;
+            const float lx = quad(r.x, std::integral_constant<int, 0x50>{}), ly = quad(r.y, std::integral_constant<int, 0x50>{});      // lanes 0 0 1 1: floats 0 1 | 2 3
+            const float hx = quad(r.x, std::integral_constant<int, 0xfa>{}), hy = quad(r.y, std::integral_constant<int, 0xfa>{});      // lanes 2 2 3 3: floats 4 5 | 6 7
+            q.c0 = odd ? ly : lx; q.c1 = odd ? hy : hx;
+            q.a0 = quad(r.y, std::integral_constant<int, 0x55>{});             // lane 1's second float: 3
+            q.a1 = quad(r.y, std::integral_constant<int, 0xff>{});             // lane 3's second float: 7
+        } else { q.c0 = r.x; q.a0 = r.y; }
+        return q;
+    };
+    auto apply = [&](const Raw &raw) {
+        const Piece q = unpack(raw);
         if constexpr (MODE != 1) {                            // FlowTarget::source + apply, one channel
             const float sa = q.a0;
             FlowTarget::apply_channel(f, q.c0 * sa, 1.0f - sa);
@@ -661,7 +679,7 @@ TH_D void quad_walk(const DepositParams &p, uint32_t texel, uint32_t len, uint32
         }
     };
     uint32_t src[kAhead];
-    Piece cur[kAhead];
+    Raw cur[kAhead];
 #pragma unroll
     for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(q < len ? q : len - 1u);
 #pragma unroll
@@ -669,7 +687,7 @@ TH_D void quad_walk(const DepositParams &p, uint32_t texel, uint32_t len, uint32
 #pragma unroll
     for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(kAhead + q < len ? kAhead + q : len - 1u);
     for (uint32_t j0 = 0; j0 < len; j0 += kAhead) {
-        Piece nxt[kAhead];
+        Raw nxt[kAhead];
         uint32_t after[kAhead];
 #pragma unroll
         for (uint32_t q = 0; q < kAhead; ++q) nxt[q] = fetch(src[q]);
