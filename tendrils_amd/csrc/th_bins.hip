@@ -1821,9 +1821,10 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // the pass's totals, the two lists' counters and the bins' cursors start from zero: one launch (three memsets are three
     // launches with their gaps, between a step and a draw that wait for each other)
     hipLaunchKernelGGL(bins_zero_kernel, dim3(128), dim3(256), 0, s, p.totals, kTotWords, p.list_n, 2u * kDepLists * kDepListStride, p.bin_cursor, kBinReplicas * p.bin_stride);
-    // (one short workgroup per 256 slots.  Measured and not kept, profiles/r3_b_fused_pass_experiments.txt: a resident grid of
-    // 4 / 8 / 16 workgroups per CU walking the blocks; workgroups of 64 or 128 slots; a register budget for 5, 6 or 8 waves
-    // per SIMD instead of 4)
+    // (one short workgroup per listed block of 256 slots - exactly one: the kernel has no loop over blocks, see there.  Measured
+    // and not kept in round 3, profiles/r3_b_fused_pass_experiments.txt: a resident grid of 4 / 8 / 16 workgroups per CU walking
+    // the blocks; workgroups of 64 or 128 slots; register CAPS for 5, 6 or 8 waves per SIMD instead of 4 - spills; what got it to
+    // six in round 5 was fewer registers needed, not fewer allowed: profiles/r5_h_emit_taken_apart.txt)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
     hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 6u), dim3(256), 0, s, p);
