@@ -474,13 +474,22 @@ TH_D void bins_long_lines(const DepositParams &p, uint32_t block, uint32_t block
                 else if (((base[j] + cnt[j] - 1u) >> kPageShift) != (base[j] >> kPageShift) || (base[j] & (kBinPage - 1u)) == 0u)
                     pages_open(p, bin[j] * kBinReplicas + rep, base[j], cnt[j]);
             }
+            // (a bin's places of a line lie in one page or two: the page looked up when a place leaves the one before - on a crowded
+            // target every place lies beyond its list's first page, and a device-scope load per fragment, twenty one after the
+            // other, was the longest chain of the kernel)
+            uint32_t seen_pn[4] = {kNoPlace, kNoPlace, kNoPlace, kNoPlace}, seen_page[4] = {0u, 0u, 0u, 0u};
             dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) {
                 const uint32_t b = bin_of(p, (uint32_t)x, (uint32_t)y);
                 uint32_t at = kNoPlace;
                 bool placed = false;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (!placed && bin[j] == b) { at = place_of<true>(p, b * kBinReplicas + rep, base[j]++); placed = true; }
+                    if (!placed && bin[j] == b) {
+                        const uint32_t v = base[j]++, pn = v >> kPageShift;
+                        if (pn != seen_pn[j]) { seen_page[j] = page_of<true>(p, b * kBinReplicas + rep, pn); seen_pn[j] = pn; }
+                        at = seen_page[j] == kNoPlace ? kNoPlace : (seen_page[j] << kPageShift) | (v & (kBinPage - 1u));
+                        placed = true;
+                    }
                 }
                 if (!placed) at = place_single(p, b, rep);
                 bins_put(p, L, id, at, x, y);
