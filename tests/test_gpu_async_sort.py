@@ -133,7 +133,10 @@ def test_c3_frame_loop_sorts_beside_its_draws_and_no_step_pays_for_it():
             s0 = sorts(t)[0]
     assert sorts(t)[0] == s0 + 1                           # one re-sort in frames 5..71 (after the first, synchronous one)
     late = np.array(times[5:])
-    assert late.max() < 1.6 * np.median(late), (late.max(), float(np.median(late)))
+    # (a re-sort inside the steps makes TWO of them slow - its COUNT pass and its SCATTER pass, 2.6-4 x a plain step; one slow
+    # step is a box's hiccup, not the library's)
+    slow = late > 1.6 * np.median(late)
+    assert slow.sum() <= 1, (late[slow], float(np.median(late)))
     stats = t.particles.stats(t.state["speedLimit"])
     assert stats["live"] == n * n and stats["nan"] == 0
     t.dispose()
