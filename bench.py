@@ -25,18 +25,13 @@ the reduction saw.
 Roofline block.  The step loop runs as fused launches (th_step_n: <= 32 steps of a
 particle back to back in registers), which stream 48/n bytes per particle-step instead of 32 and are
 bound by VALU issue, not by HBM.  The line therefore carries
-  * roofline.achieved/peak/equivalent_frac : the SURVEY.md 8d figure - ALGORITHMIC bytes (32 B x
-    particles x steps of one launch) / mean launch duration, against 8 TB/s.  An equivalent
-    single-step bandwidth, not a physical one (for a register-resident fused launch it can exceed
-    the peak).  Two rules for `bound` / `frac`, and every entry says which it follows in `frac_is`:
-      - the HEADLINE entry (the line's own `roofline.bound / .frac`) is the contract's: bound "hbm",
-        frac = achieved / peak - for a fused launch an equivalent bandwidth; what the launch physically
-        runs out of stands beside it as `limited_by` / `limited_by_frac` (VALU issue).  Used only while
-        the equivalent figure is <= 1;
-      - every SUB-entry (flow_only, single_step_kernel, c5 ...) and a headline whose equivalent figure
-        would exceed 1 follow benchlib/roofline.bind(): the fraction of the resource the entry names -
-        VALU issue or physical HBM traffic for a fused launch, HBM (algorithmic bytes, which a
-        single-step launch really streams) for one step per launch - never above 1;
+  * roofline.achieved / peak / hbm_equivalent_frac (= equivalent_frac): the SURVEY.md 8d figure - ALGORITHMIC
+    bytes (32 B x particles x steps of one launch) / mean launch duration, against 8 TB/s.  An equivalent
+    single-step bandwidth, not a physical one (for a register-resident fused launch it can exceed the peak);
+  * roofline.bound / frac : ONE rule for every entry, the headline included (benchlib/roofline.bind(); `frac_is`
+    names it): the fraction of the resource the entry names and runs out of - VALU issue or physical HBM traffic
+    for a fused launch (PMC child runs; unknown without them), HBM (algorithmic bytes, which a single-step launch
+    really streams) for one step per launch - never above 1.  The headline's fused launch reads `"bound": "valu"`;
   * roofline.hbm_physical       : rocprofv3 PMC bytes per launch (2 x FETCH_SIZE + WRITE_SIZE KiB,
     as MI355X_MICROARCH.md prescribes) / the same duration;
   * roofline.valu               : SQ_INSTS_VALU per launch / duration against the chip's VALU issue
@@ -53,8 +48,10 @@ fragments per draw, and the flow pass's own HBM roofline; `crow
 280 frames on, when the wake has crowded the target (step and draw with both passes).
 
 Multi-GPU: one process per GPU.  c3: every rank holds a 4096-row band of a 4096 x (4096 N) texture
-(weak scaling; the N = 1 line is the single-GPU bench).  c4: 8192 x 8192 row-sharded (64 M particles in
-all, strong scaling), counters reduced every 16 steps (and, reported beside it, every step) - also run as
+(weak scaling; the N = 1 line is the single-GPU bench).  c3_strong: the metric's own 16 M particles as ONE
+4096 x 4096 texture row-sharded over the ranks (4096 // N rows each: strong scaling; key `c3_strong` of the
+default invocation, with what a launch group costs beside its kernel under `fixed_costs`).  c4: 8192 x 8192
+row-sharded (64 M particles in all, strong scaling), counters reduced every 16 steps (and, reported beside it, every step) - also run as
 a second leg of the default c3 invocation (key `c4`), so that a scaling sweep of the driver's command
 carries both curves.  c5: 16384 x 16384 packed fp16 state row-sharded, 16-step fused groups.  Flow
 replicated; no data-path collective; the counter block is reduced by the library's RCCL all-reduce
@@ -80,10 +77,10 @@ sys.path.insert(0, ROOT)
 from benchlib import workload as W  # noqa: E402
 from benchlib.job import Job, median, repetition_block  # noqa: E402
 from benchlib.launcher import dry_run, self_launch  # noqa: E402
-from benchlib.legs import c4_leg, c5_leg, cpu_baseline, frame_loop, frame_loop_sharded  # noqa: E402
+from benchlib.legs import c3_strong_leg, c4_leg, c5_leg, cpu_baseline, frame_loop, frame_loop_sharded  # noqa: E402
 from benchlib.pmc import measure_pmc, pmc_bytes  # noqa: E402,F401
 from benchlib.roofline import bind, roofline_entry  # noqa: E402
-from benchlib.sidelegs import SideLegs, Stages  # noqa: E402
+from benchlib.sidelegs import SideLegs, Stages, comm_deadline  # noqa: E402
 from benchlib.workload import (BYTES_PER_PARTICLE_STEP, CONFIGS, HBM_PEAK_GBS, MAX_FUSED, synth_rows, synth_state)  # noqa: E402,F401
 
 
@@ -98,12 +95,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
     ap.add_argument("--no-frame-loop", action="store_true", help="skip the step() + draw() frame-loop leg")
+    ap.add_argument("--no-c3-strong", action="store_true", help="skip the strong-scaling leg of the metric's own particles (ONE 4096 x 4096 texture row-sharded) of a c3 run")
     ap.add_argument("--no-c4", action="store_true", help="skip the config-4 leg (8192 x 8192 row-sharded, strong scaling) of a c3 run")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-5 leg (16384 x 16384 packed state row-sharded, strong scaling) of a c3 run")
     ap.add_argument("--dry-run", action="store_true", help="CPU plumbing check: gloo ranks stepping the CPU restatement")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # PMC child: launches of this length only
     ap.add_argument("--force-dist", action="store_true", help="init RCCL even at world size 1 (path check)")
     ap.add_argument("--no-library-comm", action="store_true", help="reduce the counters through torch.distributed instead of the library's own communicator (what the bench falls back to when th_comm_init fails on any rank)")
+    ap.add_argument("--pretend-world", type=int, default=0, help="experiment: every rank holds the band rank 0 of a job of this many ranks would hold (the per-GPU share of a strong-scaling point on one GPU: tools/band_sweep.py)")
     ap.add_argument("--flow-size", default=None, help="experiment: WxH of the flow/view instead of 1920x1080")
     ap.add_argument("--state", default=None, choices=["f32", "f16"], help="state ring storage (f16 = packed 8 B/particle); default: the config's")
     ap.add_argument("--in-view", action="store_true", help="experiment: keep every particle inside the view (|y*viewSize.y| < 1)")
@@ -153,7 +152,8 @@ def main():
     from tendrils_amd import _capi
 
     stages.at("context, state upload, the library's communicator")
-    job = Job(args, args.config, rank, local_rank, world, dist, launch_len=launch_len)
+    job = Job(args, args.config, rank, local_rank, world, dist, launch_len=launch_len,
+              comm_guard=comm_deadline(rank, sys.argv[1:], os.path.abspath(__file__)))
     t, ctx = job.t, job.ctx
     width, rows = job.width, job.rows
     particles_rank = job.particles_rank
@@ -252,16 +252,14 @@ def main():
     roofline = {"kernel": kernel_name, "launches": launches,
                 "uniform_set": "flow only (noiseWeight = 0)" if args.flow_only else "default (simplex noise on)",
                 "achieved_is": "algorithmic bytes (SURVEY.md 8d: %d B per particle-step) / mean launch duration - an equivalent "
-                               "single-step bandwidth (equivalent_frac = achieved / peak); the fused launch streams 48/n B per "
-                               "particle-step (hbm_physical); frac = achieved / peak (the resource the launch runs out of: `limited_by`)" % bytes_per_step,
+                               "single-step bandwidth (hbm_equivalent_frac = equivalent_frac = achieved / peak); the fused launch streams "
+                               "48/n B per particle-step (hbm_physical) and runs out of VALU issue: `bound` / `frac` name THAT resource "
+                               "(`frac_is`)" % bytes_per_step,
                 "pmc_note": pmc_note}
-    if fused and head["equivalent_frac"] <= 1.0:
-        # the contract's figure for the dominant kernel: algorithmic bytes / launch duration against the HBM peak.
-        # What the launch actually runs out of is named beside it: a register-resident launch streams 48/n B per particle-step
-        # and is limited by VALU issue (`limited_by`, `limited_by_frac`; never reported as more than 1)
-        head["limited_by"], head["limited_by_frac"], head["limited_by_frac_is"] = head["bound"], head["frac"], head["frac_is"]
-        head["bound"], head["frac"] = "hbm", head["equivalent_frac"]
-        head["frac_is"] = "achieved / peak: algorithmic bytes (SURVEY.md 8d) per launch / mean launch duration / 8 TB/s"
+    # `bound` / `frac` are what bind() found - the resource the launch runs out of (VALU issue for a fused launch), never above 1;
+    # the contract's figure for the dominant kernel (algorithmic bytes / launch duration against the HBM peak) stands
+    # beside it under its own name: achieved / peak / hbm_equivalent_frac
+    head["hbm_equivalent_frac"] = head["equivalent_frac"]
     roofline.update(head)
     single = bind(rl(single_s, 1, pmc.get("single")), False)
     single["kernel"] = "logic_packed_kernel" if packed else "logic_kernel over tile-sorted slots (gathered taps; every 64th launch re-sorts through logic_sorted_kernel)"
@@ -302,15 +300,24 @@ def main():
         line["counters_every_step"] = {"value": particles * args.steps / wes, "ms_per_step": wes / args.steps * 1e3,
                                        "note": "same K steps, one launch and one counter reduction per step"}
 
+    if cfg["scaling"] == "strong":
+        # what a launch group costs beside its kernel: the part of a strong-scaling point that does not shrink with the band
+        from benchlib.legs import fixed_costs
+        try:
+            line["fixed_costs"] = fixed_costs(job)
+        except Exception as e:            # noqa: BLE001
+            line["fixed_costs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # (the side legs must not cost the line: whatever goes wrong in them is reported in their place, and one that never comes
     # back - a collective some rank does not reach - ends the job with the line as it stands: benchlib/sidelegs.py)
     stages.at("side legs")
     stages.done()                       # (the headline stands: from here on every leg has its own deadline)
     legs = SideLegs(line, rank)
     c3 = args.config == "c3"
+    want_c3s = c3 and not args.no_c3_strong and not args.flow_size and not under_profiler
     want_c4 = c3 and not args.no_c4 and not args.flow_size and not under_profiler
     want_c5 = c3 and not args.no_c5 and not args.flow_size and not under_profiler
-    after = (["c4"] if want_c4 else []) + (["c5"] if want_c5 else [])
+    after = (["c3_strong"] if want_c3s else []) + (["c4"] if want_c4 else []) + (["c5"] if want_c5 else [])
     if world == 1 and c3 and not args.no_frame_loop:
         legs.run("frame_loop", lambda: frame_loop(t, ctx, synth_state(rank)), after)
     if (world > 1 or args.force_dist) and c3 and not args.no_frame_loop:
@@ -323,6 +330,8 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
                                     "sample": "failed: %s: %s" % (type(e).__name__, e)}
     job.dispose()
+    if want_c3s:
+        legs.run("c3_strong", lambda: c3_strong_leg(args, rank, local_rank, world, dist), after[1:])
     if under_profiler and c3 and not args.no_c4:
         # (a kernel-trace of this command should average the headline's launches, not mix them with config 4's)
         line["c4"] = {"skipped": "under a profiler: run without it (or --config c4) for the config-4 leg"}

@@ -25,7 +25,7 @@ class Job:
     """One rank's share of a configuration: the Tendrils object with its synthetic state and flow, the step loop of the
     timed region (fused launches + statistics + the counter all-reduce + optical-flow refresh) and its timing."""
 
-    def __init__(self, args, config, rank, local_rank, world, dist, launch_len=None):
+    def __init__(self, args, config, rank, local_rank, world, dist, launch_len=None, comm_guard=None):
         import tendrils_amd as ta
         from tendrils_amd import _capi
         from tendrils_amd.sharding import comm_init, comm_query, shard_rows
@@ -35,27 +35,23 @@ class Job:
         self.cfg, self.config = cfg, config
         self.state_fmt = args.state or cfg["state"]
         self.group = cfg["group"]                    # steps per fused launch and per statistics reduction
-        self.width, self.rows, self.gheight = cfg["width"], cfg["rows"](world), cfg["gheight"](world)
+        # `--pretend-world P` (experiment): the band rank 0 of a P-rank job would hold, on however many ranks there are - the per-GPU
+        # share of a strong-scaling point measured on one GPU (tools/band_sweep.py)
+        share = getattr(args, "pretend_world", 0) or world
+        self.share = share
+        self.width, self.rows, self.gheight = cfg["width"], cfg["rows"](share), cfg["gheight"](share)
         self.particles_rank = self.width * self.rows
         self.launch_len = launch_len or min(self.group, args.steps)
         opts = ta.defaults()
         opts.update(device=local_rank, mode=ta.TH_MODE_FAST if args.mode == "fast" else ta.TH_MODE_EXACT,
-                    row0=shard_rows(self.gheight, world, rank)[0], rows=self.rows, globalHeight=self.gheight,
+                    row0=shard_rows(self.gheight, share, rank if share == world else 0)[0], rows=self.rows, globalHeight=self.gheight,
                     stateFormat=ta.TH_STATE_F16 if self.state_fmt == "f16" else ta.TH_STATE_F32)
         t = self.t = ta.Tendrils(View(W.FLOW_W, W.FLOW_H), opts)
         t.resize()                       # viewRes 1920x1080 -> viewSize [1, 1.7778]; flow.shape = viewRes
         t.setup(self.width)
         ctx = self.ctx = t.particles._ctx
-        band = 1024                      # generated and uploaded in row bands (bounded host memory at C5)
-        full = synth_state(rank) if config == "c3" else None
-        for r0 in range(0, self.rows, band):
-            r1 = min(self.rows, r0 + band)
-            st = full[r0:r1] if full is not None else synth_rows(self.width, r1 - r0, 12345 + rank * 1000003 + r0)
-            if args.in_view:
-                st = st.copy()
-                st[..., 1] *= np.float32(0.56)
-            _capi.call("th_upload_state", ctx, -1, np.ascontiguousarray(st).ctypes.data_as(_capi._fp), 0, r0, self.width, r1 - r0)
-        full = st = None
+        self.args, self.rank_seed = args, rank
+        self.upload_synthetic()
 
         # flow field: optical-flow pass over the synthetic frame pair (C3), else a seeded field
         self.time0 = 1000.0
@@ -82,17 +78,23 @@ class Job:
             # (should the library's own communicator not come up - librccl not loadable beside torch's, say - on any rank,
             # every rank falls back to reducing the counter block through torch.distributed, and the line says so: a
             # scaling run is not lost to it)
+            # `comm_guard` (the headline's job: benchlib/sidelegs.py comm_deadline): a communicator that never comes up - a rank
+            # that does not arrive - ends in a fresh child process that reduces through torch.distributed, not in silence
+            import contextlib
+            import os
             import torch
-            why = "--no-library-comm" if args.no_library_comm else ""
-            try:
-                if not why:
-                    comm_init(ctx, dist)
-                    self.comm = comm_query(ctx)
-            except ta.TendrilsHipError as e:
-                why = str(e)
-            ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
+            why = (os.environ.get("TH_BENCH_COMM_FALLBACK") or "--no-library-comm") if args.no_library_comm else ""
+            with (comm_guard if comm_guard is not None and not why else contextlib.nullcontext()):
+                try:
+                    if not why:
+                        comm_init(ctx, dist)
+                        self.comm = comm_query(ctx)
+                except ta.TendrilsHipError as e:
+                    why = str(e)
+                ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                agreed = int(ok.item())
+            if agreed == 0:
                 if self.comm is not None:
                     _capi.call("th_comm_destroy", ctx)
                 self.comm = None
@@ -101,6 +103,18 @@ class Job:
         self.reductions = 0
         if args.flow_only:
             t.state["noiseWeight"] = 0
+
+    def upload_synthetic(self):
+        """the configuration's seeded state into ring buffer 0 ... (generated and uploaded in row bands: bounded host memory at C5)"""
+        band, rank, t = 1024, self.rank_seed, self.t
+        full = synth_state(rank) if self.config == "c3" else None
+        for r0 in range(0, self.rows, band):
+            r1 = min(self.rows, r0 + band)
+            st = full[r0:r1] if full is not None else synth_rows(self.width, r1 - r0, 12345 + rank * 1000003 + r0)
+            if self.args.in_view:
+                st = st.copy()
+                st[..., 1] *= np.float32(0.56)
+            self.capi.call("th_upload_state", self.ctx, -1, np.ascontiguousarray(st).ctypes.data_as(self.capi._fp), 0, r0, self.width, r1 - r0)
 
     def sync_all(self):
         import torch

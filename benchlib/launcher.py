@@ -65,6 +65,18 @@ def dry_run(args, rank, world):
     fl[..., 2] = 990.0
     group = min(4, max(args.steps, 1))
     tm = {"time": 1000.0}
+    hang = os.environ.get("TH_BENCH_TEST_HANG", "")
+    # where the GPU run brings the library's communicator up (benchlib/job.py), under the same deadline: a rank that never
+    # arrives (TH_BENCH_TEST_HANG=comm_init:<rank>) sends every rank into a fresh child with --no-library-comm
+    fallback = None
+    if args.no_library_comm:
+        fallback = os.environ.get("TH_BENCH_COMM_FALLBACK") or "--no-library-comm"
+    else:
+        from .sidelegs import comm_deadline
+        with comm_deadline(rank, sys.argv[1:], BENCH):
+            if hang == "comm_init:%d" % rank:
+                time.sleep(1e6)
+            dist.barrier()
 
     def counters(b):
         live = (b[..., 0] != -1e6) | (b[..., 1] != -1e6)
@@ -109,11 +121,12 @@ def dry_run(args, rank, world):
             "rccl": {"world": world, "nranks_seen": state["red"]["particles"] / float(rows * n), "backend": "gloo",
                      "reductions_per_timed_repetition": state["reductions"]},
             "counters": state["red"]}
+    if fallback:
+        line["rccl"]["fallback"] = fallback
     # the side legs under their deadlines, as in the GPU run (benchlib/sidelegs.py).  TH_BENCH_TEST_HANG=<leg>:<rank> (tests): that
     # rank never reaches the leg's first collective
     from .sidelegs import SideLegs
     legs = SideLegs(line, rank)
-    hang = os.environ.get("TH_BENCH_TEST_HANG", "")
 
     def leg(name, fn):
         def body():
@@ -121,7 +134,8 @@ def dry_run(args, rank, world):
                 time.sleep(1e6)
             return fn()
         return body
-    legs.run("c5", leg("c5", lambda: dry_c5(args, rank, world, dist, O)), ["frame_loop_sharded"])
+    legs.run("c3_strong", leg("c3_strong", lambda: dry_strong(args, rank, world, dist, O, packed=False)), ["c5", "frame_loop_sharded"])
+    legs.run("c5", leg("c5", lambda: dry_strong(args, rank, world, dist, O, packed=True)), ["frame_loop_sharded"])
     legs.run("frame_loop_sharded", leg("frame_loop_sharded", lambda: dry_frame_loop_sharded(rank, world, dist, O, state["band"], fl, row0, gheight)))
 
     def finish():
@@ -132,10 +146,10 @@ def dry_run(args, rank, world):
         print(json.dumps(line), flush=True)
 
 
-def dry_c5(args, rank, world, dist, O):
-    """(dry run) the config-5 leg's plumbing: ONE texture row-sharded over the ranks (strong scaling), the state kept in the
-    packed 8-byte form between steps - SNORM16 position over [-2, 2), fp16 velocity, as th_logic.hpp packs it (inert and NaN
-    codes aside: none occur here) -, counters reduced after every 4-step group."""
+def dry_strong(args, rank, world, dist, O, packed):
+    """(dry run) the strong-scaling legs' plumbing: ONE texture row-sharded over the ranks, counters reduced after every 4-step
+    group.  packed (config 5): the state kept in the packed 8-byte form between steps - SNORM16 position over [-2, 2), fp16
+    velocity, as th_logic.hpp packs it (inert and NaN codes aside: none occur here); else (c3_strong) plain f32 texels."""
     import torch
     from tendrils_amd.sharding import reduce_counters, shard_rows
     n, gheight = 32, 64
@@ -146,9 +160,13 @@ def dry_c5(args, rank, world, dist, O):
     fl[..., 2] = 990.0
 
     def pack(b):
+        if not packed:
+            return b
         return np.rint(np.clip(b[..., :2] * np.float32(16384.0), -32767, 32767)).astype(np.int16), b[..., 2:].astype(np.float16)
 
     def unpack(q):
+        if not packed:
+            return q
         out = np.empty(q[0].shape[:2] + (4,), np.float32)
         out[..., :2] = q[0].astype(np.float32) * np.float32(6.103515625e-05)
         out[..., 2:] = q[1].astype(np.float32)
@@ -170,9 +188,9 @@ def dry_c5(args, rank, world, dist, O):
     v = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
     return {"dry_run": True, "value": n * gheight * args.steps / float(v[0]), "unit": "particle-steps/s", "scaling": "strong",
-            "n_gpus": world, "steps": args.steps, "particles": n * gheight, "particles_per_gpu": n * rows,
+            "n_gpus": world, "steps": args.steps, "particles": n * gheight, "particles_per_gpu": n * rows, "rows_per_gpu": rows,
             "rccl": {"world": world, "nranks_seen": red["particles"] / float(rows * n), "backend": "gloo", "reductions": reductions},
-            "roofline": {"bound": "hbm", "frac": None, "note": "dry run: nothing measured (16 B per particle-step on the GPU run)"}}
+            "roofline": {"bound": "hbm", "frac": None, "note": "dry run: nothing measured (%d B per particle-step on the GPU run)" % (16 if packed else 32)}}
 
 
 def dry_frame_loop_sharded(rank, world, dist, O, band, fl, row0, gheight, frames=2):

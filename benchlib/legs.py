@@ -11,29 +11,139 @@ from .job import Job, median, repetition_block
 from .workload import HBM_PEAK_GBS, ROOT, synth_rows
 
 
-def c4_leg(args, rank, local_rank, world, dist):
-    """BASELINE.json config 4 beside the metric's own configuration: 8192 x 8192 particles row-sharded over the ranks
-    (strong scaling: 64 M particles in all, whatever N), counters reduced after every 16-step launch."""
-    job = Job(args, "c4", rank, local_rank, world, dist)
+def fixed_costs(job, groups=24):
+    """What one launch group of the timed region costs beside its integrator kernel - the part of a strong-scaling point that
+    does not shrink with the band: the host's time to enqueue a th_step_n, the statistics fold and the counter all-reduce
+    (an event pair on the context's stream around each), and a group's wall time against its kernel's."""
+    import numpy as np
+    capi, ctx, t, L = job.capi, job.ctx, job.t, job.launch_len
+    ms = C.c_float()
+    limit = C.c_float(t.state["speedLimit"])
+
+    def timed(fn):
+        capi.call("th_timer_start", ctx)
+        fn()
+        capi.call("th_timer_stop", ctx, C.byref(ms))
+        return ms.value
+    fold, reduce_, enqueue = [], [], []
+    for _ in range(groups):
+        job.t.particles.sync()
+        h0 = time.perf_counter()
+        t.step_n(L)
+        enqueue.append((time.perf_counter() - h0) * 1e3)
+        fold.append(timed(lambda: capi.call("th_stats_async", ctx, limit, None)))
+        if job.comm is not None:
+            reduce_.append(timed(lambda: capi.call("th_stats_allreduce", ctx)))
+    k_ms, k_n = job.timed_kernels(lambda: job.run_kernel_only(groups * L, L))
+    job.sync_all()
+    w0 = time.perf_counter()
+    job.run(groups * L, every=L, refresh=False)
+    job.t.particles.sync()
+    wall = (time.perf_counter() - w0) / groups * 1e3
+    empty = timed(lambda: None)
+    brackets = []
+    for _ in range(7):                    # what the timed region's bracket alone costs: [barrier + sync | nothing | barrier + sync]
+        job.sync_all()
+        b0 = time.perf_counter()
+        job.sync_all()
+        brackets.append((time.perf_counter() - b0) * 1e3)
+    return {"steps_per_launch": L, "bracket_ms": float(np.median(brackets)), "launch_ms": k_ms, "group_wall_ms": wall, "beside_the_kernel_ms": wall - k_ms,
+            "host_enqueue_ms": float(np.median(enqueue)), "stats_fold_ms": float(np.median(fold)),
+            "allreduce_ms": float(np.median(reduce_)) if reduce_ else None, "empty_event_pair_ms": empty,
+            "note": "per launch group of the timed region: th_step_n(%d) + th_stats_async (the fold of the statistics the launch took) + "
+                    "th_stats_allreduce; fold / all-reduce: an event pair on the stream around the call, enqueue to done (an empty pair "
+                    "beside them); group_wall_ms: %d groups back to back against the wall clock" % (L, groups)}
+
+
+def short_frame_loop(job, frames=12):
+    """tick(); step(); draw() on a strong-scaling configuration's particles (at N = 1 the whole texture: the local draw(); at
+    N > 1 the band's step and th_draw_sharded): medians of an event pair around step and draw, the loop against the wall clock,
+    which pipeline drew, per-particle cost - max over ranks."""
+    import numpy as np
+    from tendrils_amd import _capi
+    t, ctx = job.t, job.ctx
+    if job.world > 1 and job.comm is None:
+        return {"skipped": "the library's communicator is not up: Tendrils.draw() of a band needs it"}
+    ms, info = C.c_float(), _capi.DrawInfo()
+
+    def timed(fn):
+        _capi.call("th_timer_start", ctx)
+        fn()
+        _capi.call("th_timer_stop", ctx, C.byref(ms))
+        return ms.value
+    job.upload_synthetic()
+    t.timer.time = 1000.0
+    t.renderView = True
+    for _ in range(3):
+        t.timer.tick(); t.step(); t.draw()
+    step_ms, draw_ms, frags, pipes = [], [], [], []
+    for _ in range(frames):
+        t.timer.tick()
+        step_ms.append(timed(t.step))
+        draw_ms.append(timed(t.draw))
+        _capi.call("th_draw_query", ctx, C.byref(info))
+        frags.append(t.fragments); pipes.append(info.pipeline)
+    job.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        t.timer.tick(); t.step(); t.draw()
+    job.sync_all()
+    wall = (time.perf_counter() - t0) / frames * 1e3
+    med = job.max_over_ranks([float(np.median(step_ms)), float(np.median(draw_ms)), wall])
+    particles = job.particles_rank * job.world
+    return {"frames": frames, "step_ms": med[0], "draw_both_ms": med[1], "wall_ms_per_frame": med[2],
+            "fragments_per_draw_this_rank": float(np.mean(frags)),
+            "ns_per_particle_frame": med[2] * 1e6 / particles,
+            "pipeline": "bins" if all(p == 1 for p in pipes) else ("stream" if not any(p == 1 for p in pipes) else "mixed"),
+            "note": "first frames from the synthetic state; draw_both_ms: Tendrils.draw() with both passes (a band: th_draw_sharded); "
+                    "ns_per_particle_frame = wall per frame / all particles of the job (C3's frame loop on one GPU: 1.28 ms / 16.8 M = 0.076)"}
+
+
+def strong_leg(args, name, rank, local_rank, world, dist, costs=False, loop=False):
+    """A strong-scaling configuration beside the metric's own: ONE texture row-sharded over the ranks, whatever N - `c4`
+    (BASELINE.json config 4: 8192 x 8192, 64 M particles, counters reduced after every 16-step launch) and `c3_strong` (the
+    metric's 16 M particles read as one 4096 x 4096 texture over the GPUs: 4096 // N rows per rank)."""
+    job = Job(args, name, rank, local_rank, world, dist)
     job.run(args.warmup)
     job.preroll()
     job.reductions = 0
-    walls = job.timed_region(args.steps, max(args.reps // 2, 3))
-    reductions = job.reductions // max(args.reps // 2, 3)
+    reps = max(args.reps // 2, 3)
+    walls = job.timed_region(args.steps, reps)
+    reductions = job.reductions // reps
     walls = job.max_over_ranks(walls)
     stats = job.global_stats()
     particles = job.particles_rank * world
     mid = median(walls)
     out = {"value": particles * args.steps / mid, "unit": "particle-steps/s", "ms_per_step": mid / args.steps * 1e3,
            "scaling": "strong", "n_gpus": world, "steps": args.steps, "particles": particles,
-           "particles_per_gpu": job.particles_rank, "repetitions": repetition_block(walls, args.steps),
+           "particles_per_gpu": job.particles_rank, "rows_per_gpu": job.rows, "repetitions": repetition_block(walls, args.steps),
            "rccl": job.rccl_block(stats, reductions),
            "workload": (job.cfg["label"] % "RGBA32F") + ", same flow and uniforms as the headline, fused launches of <= %d steps, "
                        "statistics + counter all-reduce after every launch" % job.launch_len,
            "note": "K = %d steps run as %s: a short trailing launch streams 48 / n bytes per particle-step like any other and costs "
                    "its own statistics" % (args.steps, " + ".join(str(min(job.launch_len, args.steps - d)) for d in range(0, args.steps, job.launch_len)) + " step launches")}
+    if job.share != world:
+        out["pretend_world"] = job.share
+    if costs:
+        try:
+            out["fixed_costs"] = fixed_costs(job)
+        except Exception as e:            # noqa: BLE001
+            out["fixed_costs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if loop and not args.no_frame_loop:
+        try:
+            out["frame_loop"] = short_frame_loop(job)
+        except Exception as e:            # noqa: BLE001
+            out["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     job.dispose()
     return out
+
+
+def c4_leg(args, rank, local_rank, world, dist):
+    return strong_leg(args, "c4", rank, local_rank, world, dist, loop=True)
+
+
+def c3_strong_leg(args, rank, local_rank, world, dist):
+    return strong_leg(args, "c3_strong", rank, local_rank, world, dist, costs=True)
 
 
 

@@ -18,6 +18,9 @@ CONFIGS = {
     # name: (width, global height as a function of world, rows per rank, state, steps per group, scaling)
     "c3": dict(width=N, rows=lambda w: N, gheight=lambda w: N * w, state="f32", group=32, scaling="weak",
                label="C3: 4096x4096 %s state (16.8M particles) per GPU"),
+    # the metric's own particles ("16M particles at 1/2/4/8 MI355X") read as ONE texture over the GPUs: a 4096 // N-row band each
+    "c3_strong": dict(width=N, rows=lambda w: N // w, gheight=lambda w: N, state="f32", group=32, scaling="strong",
+                      label="C3 strong: ONE 4096x4096 %s state (16.8M particles) row-sharded over the GPUs"),
     "c4": dict(width=8192, rows=lambda w: 8192 // w, gheight=lambda w: 8192, state="f32", group=16, scaling="strong",
                label="C4: 8192x8192 %s state (67.1M particles) row-sharded over the GPUs"),
     "c5": dict(width=16384, rows=lambda w: 16384 // w, gheight=lambda w: 16384, state="f16", group=16, scaling="strong",

@@ -25,6 +25,10 @@ def test_self_launch_two_ranks_dry_run(oracle):
     assert line["value"] > 0 and line["unit"] == "particle-steps/s"
     # the legs a scaling sweep of the driver's command carries beside the headline: config 5 (strong scaling, packed ring) and
     # the frame loop of a row-band job with the draw's exchange inside
+    c3s = line["c3_strong"]            # the metric's own particles as ONE texture over the ranks
+    assert c3s["scaling"] == "strong" and c3s["n_gpus"] == 2 and c3s["particles"] == 2 * c3s["particles_per_gpu"] and c3s["rows_per_gpu"] == 32
+    assert c3s["rccl"]["nranks_seen"] == 2.0 and c3s["value"] > 0
+    assert line["legs_failed"] == []
     c5 = line["c5"]
     assert c5["scaling"] == "strong" and c5["n_gpus"] == 2 and c5["particles"] == 2 * c5["particles_per_gpu"] == 32 * 64
     assert c5["rccl"]["nranks_seen"] == 2.0 and c5["rccl"]["reductions"] == 2 and c5["value"] > 0 and "roofline" in c5
@@ -76,3 +80,45 @@ def test_a_leg_that_never_comes_back_does_not_cost_the_line(oracle):
     line = json.loads(lines[0])
     assert line["value"] > 0 and line["n_gpus"] == 2 and line["rccl"]["nranks_seen"] == 2.0
     assert "no result within 8 s" in line["c5"]["error"] and "c5" in line["frame_loop_sharded"]["skipped"]
+    assert line["legs_failed"] == ["c5"] and line["c3_strong"]["value"] > 0          # (rc 0 keeps the headline; THIS names what hung)
+
+
+def test_a_communicator_that_never_comes_up_ends_in_a_fresh_child_with_the_line(oracle):
+    """Rank 1 never reaches the communicator's start: the others stand inside a collective nobody can call them back from.
+    After TH_BENCH_COMM_TIMEOUT every rank starts the bench again as a child process with --no-library-comm (a rendezvous of
+    its own) and ends with its status; rank 0's child prints the line, which says why - well inside the job's own deadline."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TH_BENCH_TEST_HANG="comm_init:1", TH_BENCH_COMM_TIMEOUT="6", TH_BENCH_TIMEOUT="400")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1",
+                        "--reps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert time.time() - t0 < 300
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 2 and line["rccl"]["nranks_seen"] == 2.0
+    assert "had not come up on every rank within 6 s" in line["rccl"]["fallback"]
+    assert line["legs_failed"] == [] and line["c5"]["value"] > 0
+    assert "starts again as a child process" in r.stderr
+
+
+def test_every_deadline_lies_under_the_drivers():
+    """the driver gives a bench run 1800 s (BENCH_r05.json: timeout_s): the job's own end, the legs' and the communicator's
+    deadlines all come before it, and the legs are cut to what is left of the job's time"""
+    sys.path.insert(0, ROOT)
+    from benchlib import sidelegs
+    for k in ("TH_BENCH_TIMEOUT", "TH_BENCH_LEG_TIMEOUT", "TH_BENCH_COMM_TIMEOUT"):
+        assert k not in os.environ
+    assert sidelegs.job_seconds() <= 1500
+    legs = sidelegs.SideLegs({}, 0)
+    assert legs.limit <= 300
+    assert sidelegs.comm_deadline(0, [], "bench.py").seconds <= 300
+    keep = sidelegs.T_START
+    try:
+        sidelegs.T_START = keep - (sidelegs.job_seconds() - 100.0)      # 100 s of the job's time left
+        legs.run("quick", lambda: {"ok": 1})
+        assert legs.seconds <= 100.0 and legs.line["quick"] == {"ok": 1} and legs.line["legs_failed"] == []
+    finally:
+        sidelegs.T_START = keep
