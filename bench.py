@@ -294,6 +294,7 @@ def main():
         "roofline": roofline,
         "rccl": job.rccl_block(stats, reductions_per_rep),
         "counters": stats,
+        "barrier": job.barrier.kind if job.barrier is not None else "none (one rank)",
     }
     if walls_every_step is not None:
         wes = median(walls_every_step)

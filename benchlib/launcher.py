@@ -99,14 +99,16 @@ def dry_run(args, rank, world):
             state["red"] = reduce_counters(dist, counters(state["band"]))
             state["reductions"] += 1
 
+    from .job import NodeBarrier
+    barrier = NodeBarrier.of(dist, rank, world)           # (the bracket's barrier of the GPU run: the ranks meet in shared memory)
     run(args.warmup)
     walls = []
     for _ in range(args.reps):
-        dist.barrier()
+        barrier()
         t0 = time.perf_counter()
         state["reductions"] = 0
         run(args.steps)
-        dist.barrier()
+        barrier()
         walls.append(time.perf_counter() - t0)
     v = torch.tensor(walls, dtype=torch.float64)
     dist.all_reduce(v, op=dist.ReduceOp.MAX)
@@ -120,7 +122,7 @@ def dry_run(args, rank, world):
             "repetitions": repetition_block(walls, args.steps),
             "rccl": {"world": world, "nranks_seen": state["red"]["particles"] / float(rows * n), "backend": "gloo",
                      "reductions_per_timed_repetition": state["reductions"]},
-            "counters": state["red"]}
+            "counters": state["red"], "barrier": barrier.kind}
     if fallback:
         line["rccl"]["fallback"] = fallback
     # the side legs under their deadlines, as in the GPU run (benchlib/sidelegs.py).  TH_BENCH_TEST_HANG=<leg>:<rank> (tests): that

@@ -55,7 +55,7 @@ def fixed_costs(job, groups=24):
                     "beside them); group_wall_ms: %d groups back to back against the wall clock" % (L, groups)}
 
 
-def short_frame_loop(job, frames=12):
+def short_frame_loop(job, frames=12, reupload=True):
     """tick(); step(); draw() on a strong-scaling configuration's particles (at N = 1 the whole texture: the local draw(); at
     N > 1 the band's step and th_draw_sharded): medians of an event pair around step and draw, the loop against the wall clock,
     which pipeline drew, per-particle cost - max over ranks."""
@@ -71,8 +71,9 @@ def short_frame_loop(job, frames=12):
         fn()
         _capi.call("th_timer_stop", ctx, C.byref(ms))
         return ms.value
-    job.upload_synthetic()
-    t.timer.time = 1000.0
+    if reupload:                      # (config 5: the state the timed region left - generating 268 M particles again takes half a minute)
+        job.upload_synthetic()
+        t.timer.time = 1000.0
     t.renderView = True
     for _ in range(3):
         t.timer.tick(); t.step(); t.draw()
@@ -180,6 +181,11 @@ def c5_leg(args, rank, local_rank, world, dist):
            "rccl": job.rccl_block(stats, reductions), "roofline": e,
            "workload": (job.cfg["label"] % "packed 8-B (SNORM16 pos + fp16 vel)") + ", same flow and uniforms as the headline, fused "
                        "launches of <= %d steps, statistics + counter all-reduce after every launch" % job.launch_len}
+    if not args.no_frame_loop:
+        try:
+            out["frame_loop"] = short_frame_loop(job, frames=8, reupload=False)
+        except Exception as e:            # noqa: BLE001
+            out["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     job.dispose()
     return out
 

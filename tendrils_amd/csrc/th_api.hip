@@ -261,7 +261,7 @@ th_status th_destroy(th_context *c)
     (void)hipFree(c->frames[0]); (void)hipFree(c->frames[1]);
     (void)hipFree(c->dep_count); (void)hipFree(c->dep_offset); (void)hipFree(c->dep_blocks); (void)hipFree(c->dep_total);
     (void)hipFree(c->dep_record); (void)hipFree(c->dep_lists); (void)hipFree(c->mrg_keys2); (void)hipFree(c->mrg_colors);
-    (void)hipFree(c->bin_mem); (void)hipFree(c->draw_blocks); (void)hipFree(c->draw_block_flags); (void)hipFree(c->d_row_draws); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
+    (void)hipFree(c->bin_mem); (void)hipFree(c->draw_blocks); (void)hipFree(c->draw_block_flags); (void)hipFree(c->d_row_draws); (void)hipFree(c->src_row_index); (void)hipFree(c->src_col_index); (void)hipFree(c->src_slots); (void)hipFree(c->edge_rows); (void)hipFree(c->crowd_mem); (void)hipFree(c->chunk_table);
     (void)hipFree(c->bins_keys); (void)hipFree(c->bins_colors); (void)hipFree(c->crowd_keys); (void)hipFree(c->crowd_sorted); (void)hipFree(c->crowd_parted); (void)hipFree(c->crowd_windows); (void)hipFree(c->gathered);
     if (c->forked) (void)hipEventDestroy(c->forked);
     if (c->joined) (void)hipEventDestroy(c->joined);

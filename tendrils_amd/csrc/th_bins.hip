@@ -33,6 +33,7 @@
 // the restatement's, bit for bit, whatever the slot order and whatever the atomics did.
 #include "th_kernels.hpp"
 #include "th_raster.hpp"
+#include <cstdlib>
 
 namespace th {
 namespace {
@@ -49,6 +50,7 @@ constexpr uint32_t kPageSpins = 1u << 19;        // tries of page_of<WAIT> (each
 
 TH_D uint32_t bin_of(const DepositParams &p, uint32_t x, uint32_t y) { return (y >> kBinShift) * p.bins_x + (x >> kBinShift); }
 TH_D void bins_flag(const DepositParams &p, uint32_t what) { atomicOr(&p.totals[kTotFlags], what); }
+TH_D void wave_sync_lds() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 // ---- pages ---------------------------------------------------------------------------------------------------------------
 // Place `v` (a virtual index handed out by the list's cursor) of list `list` = bin * kBinReplicas + r -> position in the
@@ -201,12 +203,19 @@ TH_D unsigned long long block_scan_1024(unsigned long long *lds, unsigned long l
 
 // The blocks of 256 slots in which some slot's line can draw at all (a property of the slot order and the shape alone: found
 // once per order), in rising order.
-__global__ __launch_bounds__(256) void bins_block_flags_kernel(const DepositParams p, uint8_t *flags)
+// (the same walk over a new slot order notes where the texels lie that other lines' vertices read - LineSources, shapes whose
+// lookup drifts off the line's own texel: src_slots)
+__global__ __launch_bounds__(256) void bins_block_flags_kernel(const DepositParams p, uint8_t *flags, uint32_t *src_slots)
 {
     __shared__ uint32_t any;
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    uint32_t col, row;
+    uint32_t col = 0, row = 0;
     const bool can = s < p.W * p.rows && slot_particle(p, s, col, row);
+    if (src_slots && s < p.W * p.rows) {
+        const uint32_t ri = p.src.row_index[row], ci = p.src.col_index[col];
+        if (ri != 0xffffu) src_slots[(size_t)ri * p.W + col] = s;
+        if (ci != 0xffffu) src_slots[(size_t)p.src.nrows * p.W + (size_t)ci * p.rows + row] = s;
+    }
     if (threadIdx.x == 0u) any = 0u;
     __syncthreads();
     if (can && (__lane_id() == (uint32_t)__builtin_ctzll(__ballot(can)))) any = 1u;
@@ -248,7 +257,10 @@ struct LineStage {
 
 // (six workgroups per CU: 26 KB of LDS each - a table of 2 entries per line, rows dealt up to 12 per line, the hexagon packed - and
 // at most 80 VGPRs; four workgroups of 37 KB and 118 VGPRs: 580 us, five of 31 KB and 81: 492-512, profiles/r5_h)
-template <uint32_t BS, bool DEAL>
+// PLAIN: f32 texels and every vertex of every line its own particle (the shapes of the frame loop this kernel was tuned on: the
+// own texels go through the kernel by value); otherwise - a packed ring, or a shape whose vertex lookup drifts off the line's own
+// texel (LineSources) - the vertices are fetched by dep_fetch, again when the varyings are made.
+template <uint32_t BS, bool DEAL, bool PLAIN>
 __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p)
 {
     static_assert(DEAL, "the last phase reads every line's record from the stage (every lane walking its own line's rows was measured and dropped: 0.65 against 0.58 ms)");
@@ -276,14 +288,14 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
     __syncthreads();
 
     OwnTexels own;                                      // (both ends of the line, before anything else)
-    if (can) { own.have = true; own.cur = p.cur[s]; own.prev = p.prev[s]; }
+    if (can) { own.have = true; own.cur = PLAIN ? p.cur[s] : dep_state(p, p.cur, s); own.prev = PLAIN ? p.prev[s] : dep_state(p, p.prev, s); }
     DepositLine L;
     L.draws = false;
     LineRecord r{};
-    bool slow = false;
+    bool slow = false, spans = false;
     uint32_t dealt = 0;                                 // rows of this line handed to the wave's lanes
     if (can) {
-        dep_setup(p, col, p.row0 + row, L, s, own, false);          // (the varyings: once the line is known to cover a texel)
+        dep_setup<PLAIN>(p, col, p.row0 + row, L, s, own, false);          // (the varyings: once the line is known to cover a texel)
         if (L.draws) {
             float cx[6], cy[6];
             const int where = dep_hexagon(p, L, cx, cy);
@@ -305,6 +317,14 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
                     } else dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
                 } else slow = true;
             } else if (where == kHexClip) slow = true;
+        }
+        // a slow line that SPANS the view - tens, hundreds of rows or columns - is a wave's work, not a lane's (bins_span_lines); asked
+        // of the few slow lines alone, their corners made again: not an instruction on the other lines' path
+        if (slow) {
+            float ax[6], ay[6];
+            dep_hexagon(p, L, ax, ay);
+            spans = dep_hexagon_spans(p, ax, ay);
+            slow = !spans;
         }
     }
     if constexpr (DEAL) {
@@ -359,6 +379,7 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
     if (q.c1) took1 = resv_take(t, q.b1, q.c1);
     dep_list_append(p, kListSlow, block, slow, s);
     dep_list_append(p, kListLong, block, lengthy, s);
+    dep_list_append(p, kListSpan, block, spans, s);
     __syncthreads();
     // the block's share of every bin it met: one atomic each on the cursor of the block's list of that bin; the
     // pages that start inside it are taken from the pool
@@ -389,13 +410,17 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
         const uint32_t ga0 = page_of<true>(p, l0, pa0), gb0 = pb0 != pa0 ? page_of<true>(p, l0, pb0) : ga0;
         const uint32_t ga1 = q.c1 ? page_of<true>(p, l1, pa1) : 0u, gb1 = (q.c1 && pb1 != pa1) ? page_of<true>(p, l1, pb1) : ga1;
         const uint32_t id = col * p.H + p.row0 + row;
-        // (bins run on contexts whose every vertex reads the line's own particle: th_api.hip, lines_local)
         // (the line's texels read again - from the caches - rather than kept through the reservations: the kernel is short of
         // registers, and kept as an array they had gone to scratch memory)
-        const float4 again_cur = p.cur[s], again_prev = p.prev[s];
-        auto texel = [&](bool c) { return make_float4(c ? again_cur.x : again_prev.x, c ? again_cur.y : again_prev.y, c ? again_cur.z : again_prev.z, c ? again_cur.w : again_prev.w); };
-        dep_vertex_colors(p, texel(L.a.from_cur), L.a);
-        dep_vertex_colors(p, texel(L.b.from_cur), L.b);
+        if constexpr (PLAIN) {
+            const float4 again_cur = p.cur[s], again_prev = p.prev[s];
+            auto texel = [&](bool c) { return make_float4(c ? again_cur.x : again_prev.x, c ? again_cur.y : again_prev.y, c ? again_cur.z : again_prev.z, c ? again_cur.w : again_prev.w); };
+            dep_vertex_colors(p, texel(L.a.from_cur), L.a);
+            dep_vertex_colors(p, texel(L.b.from_cur), L.b);
+        } else {            // (whichever particles the vertices are: fetched as the set-up fetched them, with their varyings this time)
+            L.a = dep_fetch(p, col, 2u * (p.row0 + row), row, s);
+            L.b = dep_fetch(p, col, 2u * (p.row0 + row) + 1u, row, s);
+        }
         // (one fragment at a time, the record read back from the line's own words of the stage: eight fragments' varyings side
         // by side were the kernel's register peak)
         uint32_t i0 = 0, i1 = 0;
@@ -498,13 +523,126 @@ TH_D void bins_long_lines(const DepositParams &p, uint32_t block, uint32_t block
     }, block, blocks);
 }
 
-// both lists in one launch, half of the grid each: two small grids that wait on their loads and atomics, side by side
+// ... and the lines that SPAN the view (kListSpan): A WAVE PER LINE.  Where the vertex lookup of the texture's shape drifts
+// off a line's own texel (th_order.hip: line_rows - every texture of 8192 and more, heights such as 100 and 1080) the lines of
+// those rows and columns join two UNRELATED particles: tens of thousands of lines hundreds of texels long, as the reference's
+// GL would draw them.  A lane walking such a line alone - the slow list's way - takes its thousand places one by one while the
+// 63 other lanes of its wave walk theirs in lockstep, every one in its own branch: 15 ms per draw at 8192 x 8192 particles.
+// Here the wave's lanes take the polygon's ROWS (64 at a time: the span of each, the same edge arithmetic in the same vertex
+// order as dep_raster_poly), the spans' texels are dealt evenly to the lanes (a prefix sum over the rows, a search per lane),
+// and the places of the lanes that meet in one bin are reserved with ONE atomic on that bin's cursor.
+TH_D void bins_span_lines(const DepositParams &p, uint32_t block, uint32_t blocks, float *scratch)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = __lane_id();
+    float *words = scratch + wave * 128u;                // per wave: the clipped polygon (48 words), then 64 row starts
+    uint32_t *starts = reinterpret_cast<uint32_t *>(words + 48);
+    LdsWords<1> w{words};                                // (every lane of the wave computes the same polygon into the same words)
+    const uint32_t seg = block & (kDepLists - 1u), part = block / kDepLists, parts = blocks / kDepLists;
+    const uint32_t n = p.list_n[(kListSpan * kDepLists + seg) * kDepListStride];
+    const uint32_t *list = p.lists + ((size_t)kListSpan * kDepLists + seg) * p.list_cap;
+    const uint32_t rep = seg & (kBinReplicas - 1u);
+    for (uint32_t e = part * 4u + wave; e < n; e += parts * 4u) {
+        const uint32_t s = list[e];
+        uint32_t col, row;
+        slot_particle(p, s, col, row);
+        DepositLine L;
+        dep_setup(p, col, p.row0 + row, L, s);
+        const uint32_t id = col * p.H + p.row0 + row;
+        if (!L.draws) continue;                          // (wave-uniform: every lane set the same line up)
+        float cx[6], cy[6];
+        const int where = dep_hexagon(p, L, cx, cy);
+        int nv = 0;
+        if (where == kHexInside) {
+            int PX[6], PY[6];
+            dep_snap_hexagon(p, cx, cy, PX, PY);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { w.i(24 + k) = PX[k]; w.i(36 + k) = PY[k]; }
+            nv = 6;
+        } else if (where == kHexClip) {
+            dep_clip_hexagon(p, L, cx, cy, w);
+            nv = L.draws ? L.n : 0;
+        }
+        wave_sync_lds();
+        if (nv < 3) continue;
+        int ymin = w.i(36), ymax = w.i(36);
+        for (int k = 1; k < nv; ++k) { const int y = w.i(36 + k); ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax; }
+        int r0 = (ymin + 15) >> 4, r1 = (ymax + 15) >> 4;
+        r0 = r0 < 0 ? 0 : r0; r1 = r1 > p.fh ? p.fh : r1;
+        for (int base = r0; base < r1; base += 64) {
+            // this lane's row: its span, edge by edge in vertex order - a later edge over an earlier one, as dep_raster_poly has it
+            const int y = base + (int)lane;
+            int left = p.fw, right = 0;
+            if (y < r1)
+                for (int k = 0; k < nv; ++k) {
+                    const int kn = k + 1 == nv ? 0 : k + 1;
+                    const int Xa = w.i(24 + k), Ya = w.i(36 + k), Xb = w.i(24 + kn), Yb = w.i(36 + kn);
+                    if (Ya == Yb) continue;
+                    const bool swap = Yb < Ya;
+                    const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
+                    if (y < ((Y1 + 15) >> 4) || y >= ((Y2 + 15) >> 4)) continue;
+                    const long long DX = X2 - X1, DY = Y2 - Y1;
+                    long long x = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                    x = x < 0 ? 0 : (x > p.fw ? p.fw : x);
+                    if (swap) right = (int)x; else left = (int)x;
+                }
+            const uint32_t len = right > left ? (uint32_t)(right - left) : 0u;
+            uint32_t incl = len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(incl, o); if ((int)lane >= o) incl += up; }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+            starts[lane] = incl - len;
+            wave_sync_lds();
+            for (uint32_t f0 = 0; f0 < total; f0 += 64u) {
+                const uint32_t f = f0 + lane;
+                const bool have = f < total;
+                // the row fragment f lies in: the last lane whose rows start at or before it (a search over the wave's 64 starts)
+                uint32_t j = 0;
+#pragma unroll
+                for (uint32_t step = 32u; step > 0u; step >>= 1) if (starts[j + step] <= (have ? f : 0u)) j += step;
+                const int x = __shfl(left, (int)j) + (int)((have ? f : 0u) - starts[j]), yy = base + (int)j;
+                const uint32_t b = have ? bin_of(p, (uint32_t)x, (uint32_t)yy) : kNoPlace;
+                // one reservation per bin the 64 fragments meet (a line passes from bin to bin: a handful)
+                uint32_t v = 0;
+                unsigned long long left_over = __ballot(have);
+                while (left_over) {
+                    const int leader = __builtin_ctzll(left_over);
+                    const uint32_t lb = (uint32_t)__shfl((int)b, leader);
+                    const unsigned long long same = __ballot(have && b == lb) & left_over;
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
+                    uint32_t first = 0;
+                    if ((int)lane == leader) {
+                        first = atomicAdd(list_cursor(p, lb, rep), cnt);
+                        if (first + cnt < first) { bins_flag(p, kBinsBinFull); first = 0xffffffffu - cnt; }
+                        else if (((first + cnt - 1u) >> kPageShift) != (first >> kPageShift) || (first & (kBinPage - 1u)) == 0u)
+                            pages_open(p, lb * kBinReplicas + rep, first, cnt);
+                    }
+                    first = (uint32_t)__shfl((int)first, leader);
+                    if (same >> lane & 1ull) v = first + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+                    left_over &= ~same;
+                }
+                if (have) bins_put(p, L, id, place_of<true>(p, b * kBinReplicas + rep, v), x, yy);       // (a list that overflowed: no place, the pass is repeated)
+            }
+            wave_sync_lds();                             // (the starts are the next 64 rows' now)
+        }
+        wave_sync_lds();                                 // (... and the polygon's words the next line's)
+    }
+}
+
+// the three lists in one launch, a third of the grid each: small grids that wait on their loads and atomics, side by side
 __global__ __launch_bounds__(256) void bins_listed_kernel(const DepositParams p)
 {
     __shared__ float polygons[48 * 256];                  // (48 KB: three workgroups per CU - the grid is that large)
-    const uint32_t half = gridDim.x >> 1;
-    if (blockIdx.x < half) bins_long_lines(p, blockIdx.x, half);
-    else bins_slow_lines(p, blockIdx.x - half, half, polygons);
+    const uint32_t third = gridDim.x / 3u;
+    if (blockIdx.x < third) bins_long_lines(p, blockIdx.x, third);
+    else if (blockIdx.x < 2u * third) bins_slow_lines(p, blockIdx.x - third, third, polygons);
+    else if (!p.src.row_index) bins_span_lines(p, blockIdx.x - 2u * third, third, polygons);
+}
+// ... where there are tens of thousands of spanning lines for sure - the shapes whose vertex lookup drifts - a launch of their own:
+// 2 KB of LDS instead of 48, every wave slot of the chip (the third of bins_listed_kernel's grid: 1.6 ms at 8192 x 8192 particles)
+__global__ __launch_bounds__(256) void bins_span_kernel(const DepositParams p)
+{
+    __shared__ float scratch[4 * 128];
+    bins_span_lines(p, blockIdx.x, gridDim.x, scratch);
 }
 
 // the places handed out in bin b (all its lists; saturated)
@@ -557,10 +695,17 @@ struct BinTexel {
     }
 };
 
-template <int MODE>
+template <int MODE, bool NT = false>
 TH_D void fetch_colors(const DepositParams &p, size_t frag, float4 &c0, float4 &c1)
 {
-    if constexpr (MODE == 2) { c0 = p.colors[2u * frag]; c1 = p.colors[2u * frag + 1u]; }
+    if constexpr (NT) {             // (read once: streamed past the caches' replacement)
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4 *src = reinterpret_cast<const v4 *>(p.colors);
+        if constexpr (MODE == 2) {
+            const v4 a = __builtin_nontemporal_load(src + 2u * frag), b = __builtin_nontemporal_load(src + 2u * frag + 1u);
+            c0 = make_float4(a.x, a.y, a.z, a.w); c1 = make_float4(b.x, b.y, b.z, b.w);
+        } else { const v4 a = __builtin_nontemporal_load(src + frag); c0 = make_float4(a.x, a.y, a.z, a.w); c1 = c0; }
+    } else if constexpr (MODE == 2) { c0 = p.colors[2u * frag]; c1 = p.colors[2u * frag + 1u]; }
     else { c0 = p.colors[frag]; c1 = c0; }
 }
 template <int MODE>
@@ -622,17 +767,17 @@ TH_D uint32_t bin_scan_counts(BinShared<MODE> &s)
 
 // a texel's run blended by its own thread: `len` fragments whose positions src_at(0..len-1) gives in blend order; the
 // varyings are fetched eight ahead of the dependent blends
-template <int MODE, typename SrcAt>
+template <int MODE, typename SrcAt, uint32_t AHEAD = (MODE == 2 ? 4u : 8u), bool NT = false>
 TH_D void bin_blend_own(const DepositParams &p, uint32_t begin, uint32_t len, BinTexel<MODE> &d, SrcAt src_at)
 {
-    constexpr uint32_t kAhead = MODE == 2 ? 4u : 8u;
+    constexpr uint32_t kAhead = AHEAD;
     for (uint32_t j0 = 0; j0 < len; j0 += kAhead) {
         uint32_t src[kAhead];
         float4 c0[kAhead], c1[kAhead];
 #pragma unroll
         for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(j0 + q < len ? j0 + q : len - 1u);
 #pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE>(p, (size_t)begin + src[q], c0[q], c1[q]);
+        for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE, NT>(p, (size_t)begin + src[q], c0[q], c1[q]);
 #pragma unroll
         for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply_colors<MODE>(d, c0[q], c1[q]);
     }
@@ -948,22 +1093,42 @@ TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned
     }
 }
 
-template <int MODE>
+#ifdef TH_BLEND_STAMPS
+// (diagnostic builds only - tools/gpu_r6_blend_stamps.sh: where a bin's workgroup spends its life, cycles per phase summed over the launch)
+__device__ unsigned long long g_blend_stamps[16];
+#define TH_STAMP(k) do { if (threadIdx.x == 0u) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_blend_stamps[k], now_ - last_); last_ = now_; } } while (0)
+#define TH_STAMP_BEGIN() unsigned long long last_ = __builtin_readcyclecounter()
+#else
+#define TH_STAMP(k) do {} while (0)
+#define TH_STAMP_BEGIN() do {} while (0)
+#endif
+
+template <int MODE, int VAR>           // EXPERIMENT (r6): VAR 0 round 5's blend, 1 twice the varyings in flight, 2 ... streamed past the caches, 3 windows in LDS
 __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(const DepositParams p)
 {
+    constexpr bool WIN = VAR == 3;
     __shared__ BinShared<MODE> s;
     const uint32_t b = blockIdx.x, t = threadIdx.x;
+    TH_STAMP_BEGIN();
     // (the pass is launched before the host has seen the emitting pass's flags - its read-back hides under this kernel: a
     // pass that ran out of pages or of room in a bin is repeated before anything is blended)
-    if (p.totals[kTotFlags] != 0u) return;
-    if (t == 0u) {
-        uint32_t run = 0;
-        for (uint32_t r = 0; r < kBinReplicas; ++r) { s.lists[r] = run; const uint32_t c = *list_cursor(p, b, r); run = run + c < run ? 0xffffffffu : run + c; }
-        s.lists[kBinReplicas] = run;
+    if (p.totals[kTotFlags] != 0u || p.totals[kTotOob] != 0u) return;
+    if (t < 64u) {
+        // the lists' cursors, a lane each, and their running sum across the lanes (one thread walking the sixteen: a tenth of the
+        // workgroup's life went by before its first barrier)
+        static_assert(kBinReplicas <= 64u, "a lane per list");
+        unsigned long long incl = t < kBinReplicas ? *list_cursor(p, b, t) : 0u;
+        const unsigned long long mine = incl;
+#pragma unroll
+        for (int o = 1; o < (int)kBinReplicas; o <<= 1) { const unsigned long long up = __shfl_up(incl, o); if ((int)t >= o) incl += up; }
+        const unsigned long long cap = 0xffffffffull;
+        if (t < kBinReplicas) s.lists[t] = (uint32_t)(incl - mine > cap ? cap : incl - mine);
+        if (t == kBinReplicas - 1u) s.lists[kBinReplicas] = (uint32_t)(incl > cap ? cap : incl);
     }
     __syncthreads();
     const uint32_t n = s.lists[kBinReplicas];        // (places handed out: some may be empty)
     if (n == 0u || n > kBinCap) return;              // (bins of more places: crowd_*_kernel)
+    TH_STAMP(0);
     // place f of the bin's lists walked one after the other
     auto place = [&](uint32_t f) {
         uint32_t r = 0;
@@ -1007,12 +1172,14 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
         auto lt_of = [&](uint32_t q) { return (lts[q >> 2] >> ((q & 3u) * 8u)) & 0xffu; };
         s.cnt[t] = 0u;
         __syncthreads();
+        TH_STAMP(1);
 #pragma unroll
         for (uint32_t q = 0; q < kPer; ++q) if (have >> q & 1u) atomicAdd(&s.cnt[lt_of(q)], 1u);
         __syncthreads();
         const uint32_t mine = s.cnt[t];
         const uint32_t longest = bin_scan_counts(s);
         crowded = longest > kRankMaxRun;
+        TH_STAMP(2);
         if (!crowded) {
             s.cnt[t] = 0u;
             __syncthreads();
@@ -1021,33 +1188,84 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
             for (uint32_t q = 0; q < kPer; ++q)
                 if (have >> q & 1u) { const uint32_t lt = lt_of(q); sid[s.first[lt] + atomicAdd(&s.cnt[lt], 1u)] = id[q]; }
             __syncthreads();
+            TH_STAMP(3);
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
                 if (have >> q & 1u) {
                     const uint32_t lt = lt_of(q), r0 = s.first[lt], r1 = s.first[lt + 1u];
                     uint32_t rank = 0;                  // (< kRankMaxRun = 256: a byte)
-                    for (uint32_t j = r0; j < r1; ++j) rank += sid[j] < id[q] ? 1u : 0u;
+                    // (four stream indices a trip, one 16-byte LDS read from the aligned word at or below the run's start: a trip per
+                    // index waited for its own read; what a read holds of the neighbouring runs is masked out)
+                    const uint4 *sid4 = reinterpret_cast<const uint4 *>(sid);
+                    for (uint32_t j = r0 & ~3u; j < r1; j += 4u) {
+                        const uint4 k4 = sid4[j >> 2];
+                        rank += (j >= r0 && k4.x < id[q] ? 1u : 0u) + (j + 1u >= r0 && j + 1u < r1 && k4.y < id[q] ? 1u : 0u) +
+                                (j + 2u >= r0 && j + 2u < r1 && k4.z < id[q] ? 1u : 0u) + (j + 3u >= r0 && j + 3u < r1 && k4.w < id[q] ? 1u : 0u);
+                    }
                     ranks[q >> 2] |= rank << ((q & 3u) * 8u);
                 }
             __syncthreads();                            // (every stream index has been read: the words now take the places)
+            TH_STAMP(4);
+            if constexpr (WIN) {
+                // The varyings come to the runs, not the runs' threads to the varyings.  A texel's thread fetching its run's
+                // varyings itself reads 16 or 32 bytes from wherever each fragment happened to be placed: 64 lanes, 64 cache lines
+                // per load instruction, every line fetched again by the three other texels whose fragments share it - the
+                // texture path served one line a cycle and a run of six fragments took 45 000 cycles, 37 % of the workgroup's
+                // life (profiles/r6_c_blend_stamps.txt).  Instead the thread that HOLDS fragment f (its place in registers since
+                // the keys were read: consecutive threads, consecutive places - a wave's loads are whole lines) fetches its
+                // varyings and drops them at the fragment's position in blend order, a window of positions at a time in the
+                // words the stream indices no longer need; the texels' threads then walk their runs in LDS.
+                constexpr uint32_t kPerFrag = MODE == 2 ? 2u : 1u, kWin = (3u * kCrowdCap / 4u) / kPerFrag;      // float4s the pool holds: 1536
+                float4 *win = reinterpret_cast<float4 *>(s.pool);
+                const uint32_t total = s.first[kBinTexels], r0 = s.first[t], r1 = r0 + mine;
+                // (a fragment's position: its texel's first + its rank - read again per window rather than kept: sixteen more registers)
+                auto pos_of = [&](uint32_t q) { return (have >> q & 1u) ? s.first[lt_of(q)] + ((ranks[q >> 2] >> ((q & 3u) * 8u)) & 0xffu) : 0xffffffffu; };
+                for (uint32_t w0 = 0; w0 < total; w0 += kWin) {
+                    // (two fragments' varyings in flight per thread and trip; named values, not arrays: indexed under the window's
+                    // condition the arrays went to scratch memory)
+#pragma unroll
+                    for (uint32_t q0 = 0; q0 < kPer; q0 += 2u) {
+                        const uint32_t rel_a = pos_of(q0) - w0, rel_b = pos_of(q0 + 1u) - w0;
+                        const bool in_a = rel_a < kWin, in_b = rel_b < kWin;
+                        float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, b0 = a0, b1 = a0;
+                        if (in_a) fetch_colors<MODE>(p, (size_t)place(q0 * 256u + t), a0, a1);
+                        if (in_b) fetch_colors<MODE>(p, (size_t)place((q0 + 1u) * 256u + t), b0, b1);
+                        if (in_a) { win[rel_a * kPerFrag] = a0; if constexpr (MODE == 2) win[rel_a * kPerFrag + 1u] = a1; }
+                        if (in_b) { win[rel_b * kPerFrag] = b0; if constexpr (MODE == 2) win[rel_b * kPerFrag + 1u] = b1; }
+                    }
+                    __syncthreads();
+                    const uint32_t lo = r0 > w0 ? r0 : w0, hi = r1 < w0 + kWin ? r1 : w0 + kWin;
+                    for (uint32_t j = lo; j < hi; ++j) {
+                        const float4 a = win[(j - w0) * kPerFrag], b = MODE == 2 ? win[(j - w0) * kPerFrag + 1u] : a;
+                        apply_colors<MODE>(d, a, b);
+                    }
+                    __syncthreads();
+                }
+                touched = mine != 0u;
+                TH_STAMP(5);
+            } else {
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
                 if (have >> q & 1u) osrc[s.first[lt_of(q)] + ((ranks[q >> 2] >> ((q & 3u) * 8u)) & 0xffu)] = at[q];
             __syncthreads();
+            TH_STAMP(5);
             const uint32_t r0 = s.first[t];
             auto src_at = [&](uint32_t base) { return [osrc, base](uint32_t j) { return osrc[base + j]; }; };
-            if (mine && mine <= kOwnRun) { touched = true; bin_blend_own<MODE>(p, 0u, mine, d, src_at(r0)); }
-            if (longest > kOwnRun)
-                for (uint32_t lt = 0; lt < kBinTexels; ++lt) {
-                    const uint32_t l = s.first[lt + 1u] - s.first[lt];
-                    if (l <= kOwnRun) continue;
-                    if (t == lt) touched = true;
-                    bin_blend_long<MODE>(s, p, 0u, l, lt, d, src_at(s.first[lt]));
-                }
+            // (WIN = false here is the experiment's other arm: twice the varyings in flight per thread)
+            if (mine && mine <= kOwnRun) { touched = true; bin_blend_own<MODE, decltype(src_at(r0)), (MODE == 2 ? 4u : 8u) * (VAR >= 1 ? 2u : 1u), VAR == 2>(p, 0u, mine, d, src_at(r0)); }
+            }
+#ifdef TH_BLEND_STAMPS
+            TH_STAMP(6);                                 // (thread 0's own run)
+            __syncthreads();
+            TH_STAMP(7);                                 // (... and the wait for the workgroup's longest)
+            if (threadIdx.x == 0u) { atomicAdd(&g_blend_stamps[12], 1ull); atomicAdd(&g_blend_stamps[13], (unsigned long long)n); atomicAdd(&g_blend_stamps[14], (unsigned long long)longest); }
+#endif
+            static_assert(kRankMaxRun <= kOwnRun, "a bin whose runs are ranked by counting has no run its texel's thread does not blend alone");
         }
     }
     if (crowded) { bin_crowded<MODE>(s, p, keys, place, n, d, touched); __syncthreads(); }
     if (inside && touched) d.store(p, texel);
+    TH_STAMP(8);
     // the pages the bin's lists grew by are forgotten for the next pass
     for (uint32_t r = 0; r < kBinReplicas; ++r) if (s.lists[r + 1u] - s.lists[r] > kBinPage) pages_forget(p, b * kBinReplicas + r, s.lists[r + 1u] - s.lists[r], t, 256u);
 }
@@ -1817,10 +2035,28 @@ __global__ __launch_bounds__(256) void owner_insert_kernel(const DepositParams p
 
 }  // namespace
 
-void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, hipStream_t s)
+// A band's first and last row of both state buffers gathered into texel order, f32 (what the neighbouring bands' lines read
+// when the vertex lookup of the texture drifts across rows): through the source tables when the band is held in a slot order.
+__global__ __launch_bounds__(256) void bins_edge_rows_kernel(const DepositParams p, float4 *rows)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= 2u * p.W) return;
+    const uint32_t col = i < p.W ? i : i - p.W, row = i < p.W ? 0u : p.rows - 1u;
+    size_t at = dep_slot_of(p, (int)row, (int)col);
+    if (at == ~(size_t)0) { *p.oob = 1u; at = 0; }
+    float4 *out = rows + (i < p.W ? 0u : 2u * (size_t)p.W) + col;
+    out[0] = dep_state(p, p.cur, at);
+    out[p.W] = dep_state(p, p.prev, at);
+}
+void launch_bins_edge_rows(const DepositParams &p, float4 *rows, hipStream_t s)
+{
+    hipLaunchKernelGGL(bins_edge_rows_kernel, dim3((2u * p.W + 255u) / 256u), dim3(256), 0, s, p, rows);
+}
+
+void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *src_slots, hipStream_t s)
 {
     const uint32_t blocks = (p.W * p.rows + 255u) / 256u;
-    hipLaunchKernelGGL(bins_block_flags_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p, flags);
+    hipLaunchKernelGGL(bins_block_flags_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, p, flags, src_slots);
     hipLaunchKernelGGL(bins_block_list_kernel, dim3(1), dim3(1024), 0, s, (const uint8_t *)flags, blocks, list, count);
 }
 
@@ -1829,14 +2065,16 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     const uint32_t blocks = p.draw_nblocks;
     // the pass's totals, the two lists' counters and the bins' cursors start from zero: one launch (three memsets are three
     // launches with their gaps, between a step and a draw that wait for each other)
-    hipLaunchKernelGGL(bins_zero_kernel, dim3(128), dim3(256), 0, s, p.totals, kTotWords, p.list_n, 2u * kDepLists * kDepListStride, p.bin_cursor, kBinReplicas * p.bin_stride);
+    hipLaunchKernelGGL(bins_zero_kernel, dim3(128), dim3(256), 0, s, p.totals, kTotWords, p.list_n, (uint32_t)kListKinds * kDepLists * kDepListStride, p.bin_cursor, kBinReplicas * p.bin_stride);
     // (one short workgroup per listed block of 256 slots - exactly one: the kernel has no loop over blocks, see there.  Measured
     // and not kept in round 3, profiles/r3_b_fused_pass_experiments.txt: a resident grid of 4 / 8 / 16 workgroups per CU walking
     // the blocks; workgroups of 64 or 128 slots; register CAPS for 5, 6 or 8 waves per SIMD instead of 4 - spills; what got it to
     // six in round 5 was fewer registers needed, not fewer allowed: profiles/r5_h_emit_taken_apart.txt)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
-    hipLaunchKernelGGL((bins_fused_kernel<256u, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 6u), dim3(256), 0, s, p);
+    if (!p.packed && !p.src.row_index) hipLaunchKernelGGL((bins_fused_kernel<256u, true, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((bins_fused_kernel<256u, true, false>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_listed_kernel, dim3(3u * kDepLists * 6u), dim3(256), 0, s, p);
+    if (p.src.row_index) hipLaunchKernelGGL(bins_span_kernel, dim3(kDepLists * 32u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }
@@ -1933,10 +2171,25 @@ void launch_bins_blend_crowd(const DepositParams &p, hipStream_t s)
 // it covers the read-back of the pass's totals (the kernel returns at once when the pass raised a flag)
 void launch_bins_blend(const DepositParams &p, hipStream_t s)
 {
-    if (p.mode == 0) hipLaunchKernelGGL(bins_blend_kernel<0>, dim3(p.nbins), dim3(256), 0, s, p);
-    else if (p.mode == 1) hipLaunchKernelGGL(bins_blend_kernel<1>, dim3(p.nbins), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(bins_blend_kernel<2>, dim3(p.nbins), dim3(256), 0, s, p);
+    static const int var = getenv("TH_EXP_BLEND") ? atoi(getenv("TH_EXP_BLEND")) : 0;        // EXPERIMENT (r6)
+#define TH_GO(M) do { if (var == 3) hipLaunchKernelGGL((bins_blend_kernel<M, 3>), dim3(p.nbins), dim3(256), 0, s, p); \
+                      else if (var == 2) hipLaunchKernelGGL((bins_blend_kernel<M, 2>), dim3(p.nbins), dim3(256), 0, s, p); \
+                      else if (var == 1) hipLaunchKernelGGL((bins_blend_kernel<M, 1>), dim3(p.nbins), dim3(256), 0, s, p); \
+                      else hipLaunchKernelGGL((bins_blend_kernel<M, 0>), dim3(p.nbins), dim3(256), 0, s, p); } while (0)
+    if (p.mode == 0) TH_GO(0);
+    else if (p.mode == 1) TH_GO(1);
+    else TH_GO(2);
+#undef TH_GO
 }
 size_t crowd_words_per_bin() { return 7u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list, the giants' list, the giants' windows (2)
 
 }  // namespace th
+
+#ifdef TH_BLEND_STAMPS
+extern "C" int th_debug_blend_stamps(unsigned long long *out)       // (diagnostic builds: read and clear)
+{
+    const unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(th::g_blend_stamps), sizeof zero) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(th::g_blend_stamps), zero, sizeof zero) != hipSuccess;
+}
+#endif

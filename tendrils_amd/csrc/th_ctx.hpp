@@ -153,6 +153,13 @@ struct th_context {
     void *pinned = nullptr;                    // (pinned, kPinnedBytes) small read-backs: a pageable hipMemcpyAsync costs ~0.15 ms per call
     int lines_local = -1;                // every vertex of every line reads the line's own particle (line_rows)
     uint32_t *d_row_draws = nullptr;     // bit per global row: the row's lines can draw (line_rows)
+    // ... and when not (lines_local == 0): the rows / columns whose texels some OTHER line's vertex reads, and - per slot order -
+    // where those texels lie (th::LineSources; th_bins.hip: bins_block_flags_kernel)
+    uint16_t *src_row_index = nullptr, *src_col_index = nullptr;
+    uint32_t src_nrows = 0, src_ncols = 0;
+    bool rows_cross_bands = false;       // some line of this band looks a row of a neighbouring band up (halo rows needed)
+    uint32_t *src_slots = nullptr;       // (allocated with draw_blocks; valid for draw_blocks_order / _stamp)
+    float4 *edge_rows = nullptr;         // th_draw_sharded through the bins: this band's edge rows gathered into texel order (4 x W)
     int draw_pipeline = TH_DRAW_AUTO;    // th_draw_pipeline
     th_draw_info last_draw{};            // th_draw_query
     long long draws = 0;                          // (`draws` counts frames: the passes drawn at one total_steps share a count ...

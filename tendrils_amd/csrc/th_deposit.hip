@@ -560,14 +560,14 @@ int deposit_grid(uint32_t n)
 
 uint32_t deposit_scan_words(uint32_t W, uint32_t rows) { return ((rows + kColRows - 1) / kColRows) * W + W; }
 
-// words of the slow / long line lists: counters, then 2 * kDepLists segments of *cap entries
+// words of the slow / long / spanning line lists: counters, then kListKinds * kDepLists segments of *cap entries
 size_t deposit_list_words(uint32_t W, uint32_t rows, uint32_t *cap)
 {
     const uint32_t groups = ((W + 255u) >> 8) * rows;
     *cap = ((groups + kDepLists - 1u) / kDepLists) * 256u;
-    return (size_t)2 * kDepLists * kDepListStride + (size_t)2 * kDepLists * *cap;
+    return (size_t)kListKinds * kDepLists * kDepListStride + (size_t)kListKinds * kDepLists * *cap;
 }
-size_t deposit_list_counter_bytes() { return (size_t)2 * kDepLists * kDepListStride * sizeof(uint32_t); }
+size_t deposit_list_counter_bytes() { return (size_t)kListKinds * kDepLists * kDepListStride * sizeof(uint32_t); }
 
 void launch_deposit_count(const DepositParams &p, hipStream_t s)
 {

@@ -55,7 +55,7 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
 bool binned_shards(const th_context *c)
 {
     const int policy = c->draw_pipeline != TH_DRAW_AUTO ? c->draw_pipeline : c->opt.draw;
-    if (policy == 0 || c->lines_local != 1 || c->packed) return false;
+    if (policy == 0 || (c->lines_local != 1 && c->lines_local != 0)) return false;      // (2: lookups off the line's own texel that no table holds)
     if (c->fw > th::kBinsMaxExtent || c->fh > th::kBinsMaxExtent) return false;
     if (drawn_line_width(c, TH_PASS_FLOW) > 2.0f || drawn_line_width(c, TH_PASS_VIEW) > 2.0f) return false;
     if (policy == 1 || c->opt.bucket == 1) return true;
@@ -84,10 +84,11 @@ th_status deposit_prepare(th_context *c, const th_deposit_uniforms *u, th::Depos
     if (want_bins && c->draw_frame_step != c->total_steps) { ++c->draws; c->draw_frame_step = c->total_steps; c->frame_bins = -1; }
     bool use_bins = want_bins && (c->frame_bins >= 0 && c->draw_pipeline == TH_DRAW_AUTO ? c->frame_bins == 1 : draw_uses_bins(c));
     if (use_bins) {
-        // the binned pipeline reads every vertex of a line from the line's own slot: shapes whose vertex lookup lands on
-        // another particle (line_rows) keep to the stream-ordered pipeline in texel order
+        // the binned pipeline reads a line's vertices from the line's own slot - or, for the shapes whose vertex lookup lands on
+        // another particle, through the table of where those particles lie in the slot order (line_rows, th::LineSources); the
+        // few shapes with more such rows / columns than the table holds keep to the stream-ordered pipeline in texel order
         if (th_status s = line_rows(c)) return s;
-        if (c->lines_local != 1) use_bins = false;
+        if (c->lines_local != 1 && c->lines_local != 0) use_bins = false;
         else if (any_sorted(c)) { if (th_status s = align_slot_orders(c)) return s; }
     }
     if (bins) *bins = use_bins;
@@ -119,12 +120,10 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         c->dep_lines = lines;
     }
     p = th::DepositParams{};
-    {   // a packed ring is read through f32 views (what the stored texels decode to)
-        float4 *cur = nullptr, *prev = nullptr;
-        if (th_status s = unpacked_view(c, c->ring[0], 0, &cur)) return s;
-        if (th_status s = unpacked_view(c, c->ring[1], 1, &prev)) return s;
-        p.cur = cur; p.prev = prev;
-    }
+    // a packed ring is read in place, texel by texel, as what the stored texels decode to (dep_state: no f32 copy of the ring
+    // per draw - two passes over 10.7 GB at config 5's size)
+    p.cur = c->ring[0]; p.prev = c->ring[1];
+    p.packed = c->packed ? 1u : 0u;
     p.flow = c->flow;
     p.W = (uint32_t)c->cfg.width; p.H = (uint32_t)c->cfg.global_height;
     p.row0 = (uint32_t)c->cfg.row0; p.rows = (uint32_t)c->cfg.height;
@@ -139,12 +138,15 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
     p.list_n = c->dep_lists; p.list_cap = c->dep_list_cap;
     {
         uint32_t cap = 0;
-        p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)2 * 64 * cap);
+        p.lists = c->dep_lists + (th::deposit_list_words((uint32_t)c->cfg.width, (uint32_t)c->cfg.height, &cap) - (size_t)3 * 64 * cap);      // (three kinds of list, 64 segments each: th_raster.hpp)
     }
     p.halo_lo = c->halo_lo; p.halo_hi = c->halo_hi;
     if (!use_bins) TH_HIP(hipMemsetAsync(c->dep_total, 0, th::kTotWords * sizeof(uint32_t), c->stream));      // (bins: launch_bins_fused)
     if (th_status s = line_rows(c)) return s;
     p.row_draws = c->d_row_draws;
+    if (c->lines_local == 0) {          // (the tables; `slot` stays null in texel order: a texel's slot is its index)
+        p.src.row_index = c->src_row_index; p.src.col_index = c->src_col_index; p.src.nrows = c->src_nrows; p.src.ncols = c->src_ncols;
+    }
     if (use_bins) {
         const int o = order_of(c, c->ring[0]);
         p.perm = o >= 0 ? c->orders[(size_t)o].perm : nullptr;
@@ -172,7 +174,8 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
         // the blocks of slots with something to draw: listed once per slot order (one read-back per re-sort)
         const unsigned long long stamp = o >= 0 ? c->orders[(size_t)o].stamp : 0ull;
         // what the step that wrote these two buffers saw of their lines (th_step.hip): only for exactly this pair, order and view
-        if (c->opt.skip_unseen && c->seen.bytes && c->seen.cur == c->ring[0] && c->seen.prev == c->ring[1] && p.cur == c->ring[0] && p.prev == c->ring[1] &&
+        // (... and only where a line's two ends ARE the slot's own particle, now and a step ago: lines_local)
+        if (c->opt.skip_unseen && c->lines_local == 1 && c->seen.bytes && c->seen.cur == c->ring[0] && c->seen.prev == c->ring[1] && p.cur == c->ring[0] && p.prev == c->ring[1] &&
             c->seen.order == o && c->seen.stamp == stamp && c->seen.view_x == p.view_x && c->seen.view_y == p.view_y && c->seen.fw == c->fw && c->seen.fh == c->fh &&
             drawn_line_width(c, TH_PASS_FLOW) <= 2.0f && drawn_line_width(c, TH_PASS_VIEW) <= 2.0f)
             p.block_seen = reinterpret_cast<const uint32_t *>(c->seen.bytes);
@@ -181,13 +184,16 @@ static th_status prepare_pass(th_context *c, const th_deposit_uniforms *u, th::D
             if (!c->draw_blocks) {
                 TH_HIP(hipMalloc((void **)&c->draw_blocks, (blocks + 1) * sizeof(uint32_t)));
                 TH_HIP(hipMalloc((void **)&c->draw_block_flags, blocks));
+                if (c->lines_local == 0)
+                    TH_HIP(hipMalloc((void **)&c->src_slots, ((size_t)c->src_nrows * c->cfg.width + (size_t)c->src_ncols * c->cfg.height + 1) * sizeof(uint32_t)));
             }
-            th::launch_bins_block_list(p, c->draw_block_flags, c->draw_blocks + 1, c->draw_blocks, c->stream);
+            th::launch_bins_block_list(p, c->draw_block_flags, c->draw_blocks + 1, c->draw_blocks, o >= 0 ? c->src_slots : nullptr, c->stream);
             TH_HIP(hipGetLastError());
             if (th_status s = read_back(c, &c->draw_nblocks, c->draw_blocks, sizeof(uint32_t))) return s;
             c->draw_blocks_order = o; c->draw_blocks_stamp = stamp;
         }
         p.draw_blocks = c->draw_blocks + 1; p.draw_nblocks = c->draw_nblocks;
+        if (c->lines_local == 0 && o >= 0) p.src.slot = c->src_slots;
     }
     return TH_OK;
 }
@@ -511,6 +517,10 @@ th_status bins_pass_emit(th_context *c, th::DepositParams &p, bool blend_early)
         if (blend_early) th::launch_bins_blend(p, c->stream);
         if (th_status s = bins_totals(c, p)) return s;
         const uint32_t flags = host[th::kTotFlags];
+        if (host[th::kTotOob]) {          // (a store nobody will blend: wiped by the next pass)
+            c->bins_dirty = true;
+            return fail(TH_ERR_UNSUPPORTED, "a line of this row band looks up a particle row outside the band (rows %d..%d of %d) and no halo row was supplied (th_deposit_set_halo)", c->cfg.row0, c->cfg.row0 + c->cfg.height, c->cfg.global_height);
+        }
         if (flags == 0) { c->bins_dirty = true; return TH_OK; }        // (until bins_pass_finish has sent the blends after it)
         // nothing has been blended yet: the store is wiped, and the pass is repeated with a larger pool - or, when a bin
         // outgrew its chunk table or a line its reservation, left to the stream-ordered pipeline

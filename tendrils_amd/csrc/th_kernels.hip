@@ -241,6 +241,12 @@ TH_D void stats_take(StatsPartial *slot, const float4 &v, float limit, bool firs
     }
 }
 
+// a wave that met no particle (beyond the last slot of its share) leaves an empty partial: no memset in front of the launch
+TH_D void stats_none(StatsPartial *slot, bool first)
+{
+    if (__ballot(!first) == 0ull && __lane_id() == 0u) *slot = StatsPartial{0ull, 0ull, 0ull, 0.0, 0.0};
+}
+
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED, bool STATS>
 __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 {
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
         store_stream(&p.out[idx], st);
         if constexpr (STATS) { stats_take(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], st, p.u.speedLimit, first); first = false; }
     }
-    // (a wave that met no particle leaves the zeros launch_logic_fused's memset put in its partial)
+    if constexpr (STATS) stats_none(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], first);
 }
 
 // Packed ring (TH_STATE_F16): the same fusion on 8-B texels.  The storage quantisation is part of every step
@@ -340,6 +346,7 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
         // (the statistics of a packed ring are those of what its texels decode to - what th_stats reads through its f32 view)
         if constexpr (STATS) { stats_take(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], unpack_state(w), p.u.speedLimit, first); first = false; }
     }
+    if constexpr (STATS) stats_none(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], first);
 }
 
 // Launch shape of the fused passes: one 256-slot workgroup per 256 particles (no persistent grid).  A fused pass
@@ -1360,7 +1367,9 @@ __global__ __launch_bounds__(256) void stats_fold_kernel(const StatsPartial *par
     }
 }
 
-// 256 partials -> 1, per workgroup (the first level of launch_stats_fold)
+// 256 partials -> 1, per workgroup (the first level of launch_stats_fold).  (Round 6 folded in ONE launch - every workgroup its
+// 256, the one that finishes last the rest, a counter deciding which: at C3 the counter's 1024 device-scope adds on one word, served
+// one after the other, made the fold 29 us instead of 11; at a band of 2 M particles 10.1 against 9.0.  Two short launches it is.)
 __global__ __launch_bounds__(256) void stats_fold_parts_kernel(const StatsPartial *part, uint32_t nparts, StatsPartial *out)
 {
     __shared__ StatsPartial sh[4];

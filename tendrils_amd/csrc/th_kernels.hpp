@@ -123,8 +123,21 @@ constexpr uint32_t kTexelMask = 0xffffffu;
 
 constexpr float kMaxLineWidth = 64.0f;      // th_line_width_range's upper end (TH_MAX_LINE_WIDTH): dep_param's 32-bit arithmetic holds up to it
 
+// Shapes whose vertex lookup lands on ANOTHER particle (th_order.hip: line_rows - a few rows / columns of W >= 8192, of heights
+// such as 100, 1080, 3000): where that particle lies when the state is held in a slot order.  A source texel lies in a source
+// ROW (the row the lookup of some other row lands on) or in a source COLUMN; `slot` holds their slots - row_index[row] * W +
+// col, then nrows * W + col_index[col] * rows + (row - row0) - filled once per slot order (bins_block_flags_kernel).
+struct LineSources {
+    const uint16_t *row_index;   // per LOCAL row: its place among the source rows, 0xffff: not one
+    const uint16_t *col_index;   // per column
+    const uint32_t *slot;        // nullptr: texel order (the slot of a texel is its index), or every vertex reads its line's own particle
+    uint32_t nrows, ncols;
+};
+
 struct DepositParams {
-    const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order
+    const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order (a packed ring: uint2 texels behind the same pointers)
+    uint32_t packed;             // cur / prev hold the packed 8-byte form (TH_STATE_F16): read through dep_state (th_raster.hpp)
+    LineSources src;
     float4 *flow;
     uint32_t W, H;               // particle texture shape (H = the WHOLE texture's height)
     uint32_t row0, rows;         // the rows held by cur/prev (a row-band shard; row0 = 0, rows = H otherwise)
@@ -264,7 +277,8 @@ constexpr int32_t kBinsMaxExtent = 4096;           // fragment keys hold 12 bits
 // totals[]: device words of one pass
 enum { kTotFragments = 0, kTotOob = 1, kTotFlags = 2, kTotLarge = 3, kTotGiant = 4, kTotLong = 5, kTotPool = 6, kTotCrowdKeys = 7, kTotWindows = 8, kTotWords = 12 };
 enum { kBinsPoolExhausted = 1u, kBinsBoundBroken = 2u, kBinsBinFull = 4u, kBinsWaitBroken = 8u };      // (8: a page nobody published - page_of)
-void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, hipStream_t stream);   // list: a word per block of 256 slots
+void launch_bins_block_list(const DepositParams &p, uint8_t *flags, uint32_t *list, uint32_t *count, uint32_t *src_slots, hipStream_t stream);   // list: a word per block of 256 slots; src_slots: LineSources::slot to fill (or nullptr)
+void launch_bins_edge_rows(const DepositParams &p, float4 *rows, hipStream_t stream);   // a band's first and last row of cur and of prev, f32, in texel order: [first cur | first prev | last cur | last prev]
 void launch_bins_fused(const DepositParams &p, hipStream_t stream);                   // rasterise + emit every line's fragments into its bins; then the large-bin plan
 void launch_bins_owner_counts(const DepositParams &p, const OwnerParams &o, hipStream_t stream);
 void launch_bins_owner_extract(const DepositParams &p, const OwnerParams &o, hipStream_t stream);

@@ -50,16 +50,28 @@ bool sorting_possible(const th_context *c)
 // shader turns them back into a texel and a buffer with fp32 arithmetic (src/state/state-at-frame.glsl:12-22): vertex
 // 2m of line m reads `previous` in the lower rows and `current` in the upper ones, vertex 2m+1 `current` - so the lines
 // of the upper half (both vertices the same texel of the same buffer) have no length; and for some shapes (W >= 8192;
-// heights such as 100, 1080, 3000) the lookup of a few rows / columns lands one texel beside the line's own.
+// heights such as 100, 1080, 3000) the lookup of a few rows / columns lands one texel beside the line's own: those texels'
+// rows and columns are tabled (th::LineSources), so that a draw over a slot order finds them (th_bins.hip).
 // Same operations as dep_fetch (th_raster.hpp).  Bit m of the table: row m can draw.
 th_status line_rows(th_context *c)
 {
     if (c->d_row_draws) return TH_OK;
-    const int W = c->cfg.width, H = c->cfg.global_height;
+    const int W = c->cfg.width, H = c->cfg.global_height, row0 = c->cfg.row0, rows = c->cfg.height;
     const double inv_x = 1.0 / (double)((W > 2 ? W : 2) - 1), inv_y = 1.0 / (double)((2 * H > 2 ? 2 * H : 2) - 1);
     auto nearest = [](float u, int n) { const float f = floorf(u * (float)n); return !(f > 0.0f) ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f); };
-    bool local = true;
-    for (int i = 0; i < W && local; ++i) local = nearest((float)((double)i * inv_x), W) == i;
+    // what the lookups of OTHER lines land on: source columns (of every row) and source rows (of this band); a band's own first
+    // and last row too when rows are looked up across rows anywhere in the texture - the neighbouring bands' lines may want them
+    std::vector<uint16_t> col_index((size_t)W, 0xffffu), row_index((size_t)rows, 0xffffu);
+    uint32_t ncols = 0, nrows = 0;
+    bool local = true, rows_drift = false, cross = false;
+    for (int i = 0; i < W; ++i) {
+        const int col = nearest((float)((double)i * inv_x), W);
+        if (col != i) { local = false; if (col_index[(size_t)col] == 0xffffu) { col_index[(size_t)col] = (uint16_t)(ncols < 0xffffu ? ncols : 0xfffeu); ++ncols; } }
+    }
+    auto source_row = [&](int g) {
+        if (g < row0 || g >= row0 + rows) return;
+        if (row_index[(size_t)(g - row0)] == 0xffffu) { row_index[(size_t)(g - row0)] = (uint16_t)(nrows < 0xffffu ? nrows : 0xfffeu); ++nrows; }
+    };
     std::vector<uint32_t> bits(((size_t)H + 31) / 32, 0u);
     for (int m = 0; m < H; ++m) {
         int row[2];
@@ -68,13 +80,26 @@ th_status line_rows(th_context *c)
             const float uvy = (float)((double)(2 * m + v) * inv_y), near_index = uvy * (float)H, fl = floorf(near_index);
             cur[v] = near_index - fl > 0.25f;
             row[v] = nearest(fl / (float)H, H);
-            local = local && row[v] == m;
+            if (row[v] != m) {
+                local = false; rows_drift = true;
+                if (m >= row0 && m < row0 + rows) { source_row(row[v]); if (row[v] < row0 || row[v] >= row0 + rows) cross = true; }
+            }
         }
         if (!(row[0] == row[1] && cur[0] == cur[1])) bits[(size_t)m >> 5] |= 1u << (m & 31);
     }
+    if (rows_drift && rows != H) { source_row(row0); source_row(row0 + rows - 1); }
     TH_HIP(hipMalloc((void **)&c->d_row_draws, bits.size() * sizeof(uint32_t)));
     TH_HIP(hipMemcpy(c->d_row_draws, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    c->lines_local = local ? 1 : 0;
+    c->src_nrows = c->src_ncols = 0; c->rows_cross_bands = false;
+    if (!local && nrows < 0xfffeu && ncols < 0xfffeu && (size_t)nrows * (size_t)W + (size_t)ncols * (size_t)rows < ((size_t)1 << 31)) {
+        TH_HIP(hipMalloc((void **)&c->src_row_index, (size_t)rows * sizeof(uint16_t)));
+        TH_HIP(hipMalloc((void **)&c->src_col_index, (size_t)W * sizeof(uint16_t)));
+        TH_HIP(hipMemcpy(c->src_row_index, row_index.data(), (size_t)rows * sizeof(uint16_t), hipMemcpyHostToDevice));
+        TH_HIP(hipMemcpy(c->src_col_index, col_index.data(), (size_t)W * sizeof(uint16_t), hipMemcpyHostToDevice));
+        c->src_nrows = nrows; c->src_ncols = ncols; c->rows_cross_bands = rows_drift && rows != H;
+        (void)cross;                       // (whether THIS band looks across its edge: every band of such a texture exchanges its edge rows)
+        c->lines_local = 0;
+    } else c->lines_local = local ? 1 : 2;   // 2: lookups beside the line's own texel, and too many to table - such shapes draw in texel order
     return TH_OK;
 }
 

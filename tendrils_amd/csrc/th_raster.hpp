@@ -5,9 +5,27 @@
 // per-line records and slow / long line lists, and the two blend targets.  Semantics as pinned in th_deposit.hip.
 #pragma once
 #include "th_kernels.hpp"
+#include "th_logic.hpp"
 #include "th_math.hpp"
 
 namespace th {
+
+// texel `at` of a state buffer of the pass: f32 texels, or what a packed ring's 8-byte texel decodes to (the lines are made of that)
+TH_D float4 dep_state(const DepositParams &p, const float4 *buf, size_t at)
+{
+    if (p.packed) return unpack_state(reinterpret_cast<const uint2 *>(buf)[at]);
+    return buf[at];
+}
+// where texel (row, col) of this context's rows lies in cur / prev: its index in texel order, or - a slot order, and a texel some
+// other line's vertex reads - what LineSources tables (a texel it does not table: nowhere, ~0)
+TH_D size_t dep_slot_of(const DepositParams &p, int row, int col)
+{
+    if (!p.src.slot) return (size_t)row * p.W + (size_t)col;
+    const uint32_t ri = p.src.row_index[row], ci = p.src.col_index[col];
+    if (ri != 0xffffu) return p.src.slot[(size_t)ri * p.W + (size_t)col];
+    if (ci != 0xffffu) return p.src.slot[(size_t)p.src.nrows * p.W + (size_t)ci * p.rows + (size_t)row];
+    return ~(size_t)0;
+}
 
 struct DepositVertex {
     bool live;
@@ -89,6 +107,9 @@ TH_D void dep_vertex_colors(const DepositParams &p, float4 t, DepositVertex &v)
 // handed over as a pointer to a two-element array they lived in scratch memory - 64 bytes written and read back per line of a
 // pass over sixteen million, a quarter of what the binned pass's first kernel wrote)
 struct OwnTexels { bool have = false; float4 cur{}, prev{}; };
+// PLAIN: f32 texels, and a texel's place in cur / prev is its index or the line's own slot - no packed ring, no table of where
+// other lines' particles lie (the binned pass's kernel for the shapes of the frame loop it was tuned on: nothing it does not need)
+template <bool PLAIN = false>
 TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uint32_t own_row, size_t own_at, const OwnTexels own = OwnTexels{}, bool colors = true)
 {
     const int W = (int)p.W, H = (int)p.H;
@@ -102,20 +123,22 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uin
     const int col = dep_nearest(uvx, W);
     // (one unconditional load from a selected address: a load under a branch is awaited at the join, and the second
     // vertex's load would only go out after the first had come back)
-    size_t at = (size_t)(row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1)) * W + col;
     const bool self = row == (int)own_row && col == (int)i;
-    if (self) at = own_at;
-    const float4 *from = tex + at;
-    if (!(row >= 0 && row < (int)p.rows)) {
-        if (row == -1 && p.halo_lo) from = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
-        else if (row == (int)p.rows && p.halo_hi) from = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
+    const bool inside = row >= 0 && row < (int)p.rows;
+    const int row_in = row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1);
+    size_t at = self ? own_at : (PLAIN ? (size_t)row_in * W + col : dep_slot_of(p, row_in, col));
+    if (!PLAIN && at == ~(size_t)0) { at = own_at; if (inside) *p.oob = 1u; }        // (a texel the tables should hold and do not: the pass is refused)
+    const float4 *halo = nullptr;                                // (the neighbouring bands' edge rows: always f32, in texel order)
+    if (!inside) {
+        if (row == -1 && p.halo_lo) halo = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
+        else if (row == (int)p.rows && p.halo_hi) halo = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
         else *p.oob = 1u;
     }
     float4 t;
     if (own.have && self) {
         const bool c = offset > 0.25f;
         t = make_float4(c ? own.cur.x : own.prev.x, c ? own.cur.y : own.prev.y, c ? own.cur.z : own.prev.z, c ? own.cur.w : own.prev.w);
-    } else t = *from;
+    } else t = halo ? *halo : (PLAIN ? tex[at] : dep_state(p, tex, at));
     DepositVertex v;
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
@@ -158,13 +181,14 @@ template <typename Words>
 struct PolygonY { Words &w; TH_D int operator[](int k) const { return w.i(36 + k); } };
 
 // everything about line `id` (stream index = i*H + m) that does not depend on the texel, except the polygon
+template <bool PLAIN = false>
 TH_D void dep_setup(const DepositParams &p, uint32_t i, uint32_t m, DepositLine &L, size_t own_at, const OwnTexels own = OwnTexels{}, bool colors = true)
 {
     L.draws = false;
     L.short32 = false;
     L.n = 0;
-    L.a = dep_fetch(p, i, 2u * m, m - p.row0, own_at, own, colors);
-    L.b = dep_fetch(p, i, 2u * m + 1u, m - p.row0, own_at, own, colors);
+    L.a = dep_fetch<PLAIN>(p, i, 2u * m, m - p.row0, own_at, own, colors);
+    L.b = dep_fetch<PLAIN>(p, i, 2u * m + 1u, m - p.row0, own_at, own, colors);
     if (!L.a.live || !L.b.live) return;                                  // see the header: inert vertex = no line
     const float fw = (float)p.fw, fh = (float)p.fh;
     const float dx = (0.5f * fw) * (L.b.px - L.a.px), dy = (0.5f * fh) * (L.b.py - L.a.py);
@@ -219,6 +243,18 @@ TH_D int dep_hexagon(const DepositParams &p, const DepositLine &L, float (&cx)[6
         out0 = out0 && !i0; out1 = out1 && !i1; out2 = out2 && !i2; out3 = out3 && !i3;
     }
     return inside ? kHexInside : ((out0 || out1 || out2 || out3) ? kHexOutside : kHexClip);
+}
+
+// does the part of the hexagon inside the view span more than kSpanTexels rows or columns of the target?  (a wave's work then,
+// not a lane's: th_bins.hip bins_span_lines)
+constexpr float kSpanTexels = 24.0f;
+TH_D bool dep_hexagon_spans(const DepositParams &p, const float (&cx)[6], const float (&cy)[6])
+{
+    float x0 = cx[0], x1 = cx[0], y0 = cy[0], y1 = cy[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) { x0 = __builtin_fminf(x0, cx[k]); x1 = __builtin_fmaxf(x1, cx[k]); y0 = __builtin_fminf(y0, cy[k]); y1 = __builtin_fmaxf(y1, cy[k]); }
+    x0 = __builtin_fmaxf(x0, -1.0f); x1 = __builtin_fminf(x1, 1.0f); y0 = __builtin_fmaxf(y0, -1.0f); y1 = __builtin_fminf(y1, 1.0f);
+    return (x1 - x0) * (0.5f * (float)p.fw) > kSpanTexels || (y1 - y0) * (0.5f * (float)p.fh) > kSpanTexels;
 }
 
 // the hexagon snapped to the 1/16-texel grid: the polygon of a line that needs no clipping
@@ -560,7 +596,7 @@ TH_D void dep_list_work(const DepositParams &p, uint32_t which, Work work, uint3
         work(e < n, e < n ? list[e] : 0u, seg);
     }
 }
-enum { kListSlow = 0, kListLong = 1 };
+enum { kListSlow = 0, kListLong = 1, kListSpan = 2, kListKinds = 3 };      // (kListSpan: the binned pipeline's lines that span many rows or columns - th_bins.hip)
 
 TH_D void dep_blend_rgba(float4 &d, float4 c) { const float sa = c.w, da = 1.0f - sa; d.x = c.x * sa + d.x * da; d.y = c.y * sa + d.y * da; d.z = c.z * sa + d.z * da; d.w = c.w * sa + d.w * da; }
 

@@ -504,6 +504,8 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
         auto fixed = [&]() -> th_status {
             if (!c->x_counts) TH_HIP(hipMalloc((void **)&c->x_counts, 97 * sizeof(unsigned long long)));
             if (world > 1 && !c->x_halo) TH_HIP(hipMalloc((void **)&c->x_halo, (size_t)4 * W * sizeof(float4)));
+            if (th_status s = line_rows(c)) return s;
+            if (world > 1 && c->rows_cross_bands && !c->edge_rows) TH_HIP(hipMalloc((void **)&c->edge_rows, (size_t)4 * W * sizeof(float4)));
             return ru ? view_storage(c) : TH_OK;
         };
         if (th_status s = agree_status(c, fixed(), "allocating the exchange's buffers")) return s;
@@ -512,9 +514,29 @@ th_status th_draw_sharded(th_context *c, const th_deposit_uniforms *du, const th
     // the neighbouring bands' edge rows of both state buffers (the fp32 row lookup of the vertex stream can land one row
     // beside a line's own row for some texture heights): my first row to the rank below, my last row to the rank above.
     // A packed ring sends the rows of its f32 views - what the stored texels decode to, what the lines are made of.
-    // (a job that draws through the bins needs none of it: there every vertex of every line is the line's own particle)
+    // A job that draws through the bins keeps its slot order: where every vertex of every line is the line's own particle it
+    // needs none of this; where the row lookup drifts (rows_cross_bands: a property of the texture's shape, the same on every
+    // rank) a band's two edge rows are picked out of the slot order (th::LineSources) into texel order, f32, and sent from there.
+    if (th_status s = line_rows(c)) return s;
     const bool bins = binned_shards(c);
     c->halo_lo = c->halo_hi = nullptr;
+    if (world > 1 && bins && c->rows_cross_bands) {
+        th::DepositParams p;
+        th_status mine = injected(c, 1);
+        if (mine == TH_OK) mine = deposit_prepare_bins(c, du, p);
+        if (mine == TH_OK) { th::launch_bins_edge_rows(p, c->edge_rows, c->stream); if (hipGetLastError() != hipSuccess) mine = fail(TH_ERR_HIP, "the edge rows' gather could not be launched"); }
+        if (th_status s = agree_status(c, mine, "gathering its edge rows")) return s;
+        std::vector<size_t> sc((size_t)world, 0), so((size_t)world, 0), rc((size_t)world, 0), ro((size_t)world, 0);
+        // to rank - 1: my first row of cur and of prev (its `hi`); to rank + 1: my last rows (its `lo`); two rows of W texels each
+        if (rank > 0) { sc[(size_t)rank - 1] = 2; so[(size_t)rank - 1] = 0; rc[(size_t)rank - 1] = 2; ro[(size_t)rank - 1] = 0; }
+        if (rank + 1 < world) { sc[(size_t)rank + 1] = 2; so[(size_t)rank + 1] = 2; rc[(size_t)rank + 1] = 2; ro[(size_t)rank + 1] = 2; }
+        if (c->transport->alltoallv(c->comm, c->edge_rows, sc.data(), so.data(), c->x_halo, rc.data(), ro.data(), (size_t)W * sizeof(float4), world, c->stream))
+            return fail(TH_ERR_UNSUPPORTED, "%s", th::comm_error());
+        const uint64_t rows_moved = 2ull * ((rank > 0 ? 1u : 0u) + (rank + 1 < world ? 1u : 0u)) * (uint64_t)W * sizeof(float4);
+        c->last_draw.sent_bytes += rows_moved; c->last_draw.received_bytes += rows_moved;
+        c->halo_lo = rank > 0 ? c->x_halo : nullptr;
+        c->halo_hi = rank + 1 < world ? c->x_halo + (size_t)2 * W : nullptr;
+    }
     if (world > 1 && !bins) {
         th_status mine = c->packed ? injected(c, 1) : TH_OK;
         if (mine == TH_OK) mine = ensure_identity(c);

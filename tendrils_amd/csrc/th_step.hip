@@ -265,9 +265,11 @@ static th_status enqueue_step(th_context *c, const StepPlan &plan, int32_t targe
     // touch the view (LogicParams::seen); the draw that follows skips the blocks of 256 slots of which none may (44 % of the
     // bench's particles live outside the view, and the tile order keeps them together).  Hidden for sure = both ends beyond one
     // edge by more than 2 texels: more than a line of width <= 2 reaches (its diamonds: one texel) and its snapping moves.
+    // Never inside a stream capture (th_step_n's graphs: time_dev set): the bytes would be allocated on a capturing thread, the
+    // captured launch would keep writing them at every replay, and `seen` would describe a launch that has not run.
     bool seeing = false;
     const float vx = p.u.viewSize[0], vy = p.u.viewSize[1];
-    if (c->opt.skip_unseen && target == TH_TARGET_RING && !c->packed && !plan.generic && (gather || !use_sorted) && rt == out &&
+    if (c->opt.skip_unseen && !time_dev && target == TH_TARGET_RING && !c->packed && !plan.generic && (gather || !use_sorted) && rt == out &&
         c->total_steps - c->last_binned_draw <= 2ll * c->opt.resort_steps && vx > 0.0f && vy > 0.0f && std::isfinite(vx) && std::isfinite(vy)) {
         if (!c->seen.bytes) {
             const size_t bytes = ((c->texels() + 63) / 64 + 7) & ~(size_t)3;
@@ -419,10 +421,10 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
                         TH_HIP(hipStreamSynchronize(c->stream));
                         (void)hipFree(c->fused_parts); c->fused_parts = nullptr; c->fused_parts_cap = 0;
                         TH_HIP(hipMalloc((void **)&c->fused_parts, (size_t)need * sizeof(th::StatsPartial)));
+                        // (no memset, here or in front of a launch: every wave writes its partial - an empty one where it met no particle)
                         c->fused_parts_cap = need;
                     }
                     p.stats_part = c->fused_parts;
-                    TH_HIP(hipMemsetAsync(c->fused_parts, 0, (size_t)parts * sizeof(th::StatsPartial), c->stream));     // (waves beyond the last slot store nothing)
                     c->fused_stats.nparts = parts; c->fused_stats.limit = p.u.speedLimit;
                 }
                 hipEvent_t k0 = nullptr, k1 = nullptr;
@@ -501,6 +503,9 @@ th_status th_step_n(th_context *c, const th_logic_uniforms *u, double time0, dou
         c->ring.pop_back();
         c->ring.insert(c->ring.begin(), last);
     }
+    // the replay wrote the buffers the capture's resolve_target() calls named - at capture time only: what is remembered of
+    // their content (a step's `seen` bytes, a gathered copy, a re-sort's copy) ends here, as it does behind a plain step
+    for (float4 *r : c->ring) state_written(c, r);
     c->steps_since_sort += n; c->total_steps += n;
     // times_host must stay untouched until the copy has run; a later replay of this entry waits here
     TH_HIP(hipEventRecord(hit->copied, c->stream));

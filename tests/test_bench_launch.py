@@ -21,7 +21,7 @@ def test_self_launch_two_ranks_dry_run(oracle):
     assert line["rccl"]["world"] == 2 and line["rccl"]["nranks_seen"] == 2.0
     assert line["rccl"]["reductions_per_timed_repetition"] == 2          # 6 steps in launches of 4: one full, one partial
     assert line["repetitions"]["n"] == 3 and line["repetitions"]["min"] <= line["ms_per_step"] <= line["repetitions"]["max"]
-    assert line["counters"]["particles"] == 2 * 48 * 48
+    assert line["counters"]["particles"] == 2 * 48 * 48 and line["barrier"].startswith("shared-memory epoch barrier")
     assert line["value"] > 0 and line["unit"] == "particle-steps/s"
     # the legs a scaling sweep of the driver's command carries beside the headline: config 5 (strong scaling, packed ring) and
     # the frame loop of a row-band job with the draw's exchange inside

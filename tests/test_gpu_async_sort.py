@@ -199,3 +199,88 @@ def test_draw_skips_what_the_step_saw_leave_the_view_and_nothing_else(oracle, wh
         assert bits_equal(t.particles.read(0), cur).all()
     assert (a.read_view() == b.read_view()).all()
     a.dispose(); b.dispose()
+
+
+@pytest.mark.parametrize("first", ["seen step before the replay", "replay captured right after a draw"])
+def test_a_replayed_graph_ends_what_a_step_saw(oracle, first):
+    """th_step_n without fusion replays a captured graph; the ring comes back to the arrangement a seeing step left (n a
+    multiple of the ring's size) with OTHER content: the bytes that step wrote must not survive the replay, and the captured
+    launches themselves never see (no allocation on a capturing thread, no bytes written at every replay).  Rows of particles
+    that start outside the view and fly into it: in texel order a block of 256 slots is a row, hidden as a whole at first."""
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    n, view = 256, (96, 54)
+    st = np.zeros((n, n, 4), np.float32)
+    rng = np.random.default_rng(77)
+    rows = np.linspace(-2.5, 2.5, n, dtype=np.float32)[:, None]           # y by row: the outer rows lie far outside the view
+    st[..., 0] = rng.uniform(-0.9, 0.9, (n, n))
+    st[..., 1] = rows * (view[1] / view[0])
+    st[..., 2] = rng.uniform(-.002, .002, (n, n))
+    st[..., 3] = -np.sign(rows) * 0.1                                     # towards the view, at the speed limit below
+    limit = 0.05                                                          # (four rows of particles per step)
+
+    def build(skip):
+        t = ta.Tendrils(View(*view))
+        t.resize()
+        t.setup(n)
+        t.state["speedLimit"] = limit
+        t.particles.option("bucket", 0)
+        t.particles.option("fuse", 0)
+        t.particles.option("skip_unseen", 1 if skip else 0)
+        t.particles.draw_pipeline("bins")
+        t.particles.upload_texels(st)
+        t.timer.time = 3000.0
+        return t
+    a, b = build(True), build(False)
+    size = (1.0, view[0] / view[1])
+    cur, prev, flow, time, dt = st.copy(), st.copy(), np.zeros((view[1], view[0], 4), np.float32), 3000.0, 1000.0 / 60.0
+
+    uniforms = dict(oracle.DEFAULT_STATE, speedLimit=limit)
+    hidden_once = np.zeros(n, bool)
+
+    def ref_step():
+        nonlocal cur, prev, time
+        time += dt
+        u = oracle.logic_uniforms(n, n, time, dt, view_size=size, **uniforms)
+        prev, cur = cur, oracle.logic_step(u, cur, flow)
+
+    def ref_draw():
+        nonlocal flow
+        flow, count = oracle.flow_deposit(cur, prev, flow, time, view_size=size, speedLimit=limit)
+        return count
+
+    def rows_outside():                    # rows (= blocks of 256 slots) whose lines all end beyond the view by more than the step's margin
+        y = np.minimum(np.abs(cur[..., 1]), np.abs(prev[..., 1])) * size[1]
+        return (y > 1.0 + 4.0 / view[1] + 0.02).all(axis=1)
+
+    script = ["step", "draw", "step", "step_n 2", "draw", "step_n 4", "draw", "step", "draw"]
+    if first == "replay captured right after a draw":
+        script = ["step", "draw", "step_n 2", "draw", "step", "step_n 2", "draw"]
+    counts = []
+    for op in script:
+        if op == "step":
+            ref_step()
+            hidden_once |= rows_outside()
+            for t in (a, b):
+                t.timer.tick()
+                t.step()
+        elif op.startswith("step_n"):
+            k = int(op.split()[1])
+            for _ in range(k):
+                ref_step()
+            for t in (a, b):
+                t.step_n(k)
+        else:
+            count = ref_draw()
+            counts.append(count)
+            for t in (a, b):
+                t.draw()
+                assert t.fragments == count, (op, len(counts))
+    assert min(counts) > 1000
+    inside_now = (np.abs(cur[..., 1]) * size[1] < 1.0).any(axis=1)
+    assert (hidden_once & inside_now).sum() >= 8                           # rows a step saw hidden as a whole drew lines later on
+    for t in (a, b):
+        assert bits_equal(t.flow.read(), flow).all()
+        assert bits_equal(t.particles.read(0), cur).all() and bits_equal(t.particles.read(1), prev).all()
+    assert (a.read_view() == b.read_view()).all()
+    a.dispose(); b.dispose()

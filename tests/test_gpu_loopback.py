@@ -172,6 +172,50 @@ def test_draw_sharded_through_the_bins_equals_unsharded(n, view, world, spread, 
         t.dispose()
 
 
+@pytest.mark.parametrize("n,world,fmt,sorted_slots", [(100, 3, "f32", True), (100, 4, "f32", False), (100, 3, "f16", True), (128, 3, "f16", True),
+                                                      (128, 2, "f16", False)])
+def test_sharded_bins_over_drifting_rows_and_packed_rings(n, world, fmt, sorted_slots):
+    """Round 6: the sharded draw() goes through the bins for the shapes whose vertex lookup lands beside a line's own texel -
+    n = 100: rows 53 and 59 read the row above, and with bands of 34 / 33 / 33 (or 25) rows some of those lookups cross into
+    the neighbouring band: every band picks its edge rows out of its slot order (th::LineSources) and sends them on - and for
+    packed rings, read in place.  Bands stepping over tile-sorted slots, three frames, every rank bit for bit the unsharded
+    draw (which takes the same pipeline over its own slots)."""
+    from tendrils_amd import sharding
+    view = (48, 27)                                # (a band of 33 x 100 particles steps over sorted slots: twice the target's texels)
+    cur, prev, base = inputs(n, view, 13 * n + world)
+    one = make(n, view, cur, prev, base, None, fmt)
+    if fmt == "f16":                               # what the packed texels decode to is what everybody starts from
+        cur, prev = one.particles.read(0), one.particles.read(1)
+    shards = world_of(n, view, world, cur, prev, base, fmt, pipeline="bins")
+    one.particles.draw_pipeline("bins")
+    everybody = [one] + shards
+    for t in everybody:
+        t.particles.option("bucket", 1 if sorted_slots else 0)
+        t.particles.option("resort_steps", 2)
+        t.state["noiseWeight"] = 0.0005
+    for frame in range(3):
+        for t in everybody:
+            t.timer.tick()
+            t.step()
+        one.draw()
+        frags, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+        assert err == [None] * world, err
+        assert sum(frags) == one.fragments > 1000
+        want_flow, want_view = one.flow.read(), one.read_view()
+        for t in shards:
+            assert last_pipeline(t) == 1                       # TH_DRAW_BINS
+            assert bits_equal(t.flow.read(), want_flow).all()
+            assert (t.read_view() == want_view).all()
+    if sorted_slots:
+        info = __import__("tendrils_amd")._capi.SlotOrderInfo()
+        __import__("tendrils_amd")._capi.call("th_slot_order", shards[0].particles._ctx, C.byref(info))
+        assert info.sorted_buffers == 2
+    whole = np.concatenate([t.particles.read(0) for t in shards])
+    assert bits_equal(whole, one.particles.read(0)).all()
+    for t in everybody:
+        t.dispose()
+
+
 @pytest.mark.parametrize("how", ["flow pass only", "two widths"])
 def test_sharded_bins_pass_by_pass(how):
     """Tendrils.draw() of band contexts (the library's exchange, through the bins) when the passes do not share one
