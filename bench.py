@@ -303,11 +303,16 @@ def main():
 
     if cfg["scaling"] == "strong":
         # what a launch group costs beside its kernel: the part of a strong-scaling point that does not shrink with the band
-        from benchlib.legs import fixed_costs
+        from benchlib.legs import fixed_costs, short_frame_loop
         try:
             line["fixed_costs"] = fixed_costs(job)
         except Exception as e:            # noqa: BLE001
             line["fixed_costs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.config in ("c4", "c5") and not args.no_frame_loop:      # (a run of the configuration itself: its frame loop beside its headline)
+            try:
+                line["frame_loop"] = short_frame_loop(job, frames=12, reupload=args.config == "c4")
+            except Exception as e:        # noqa: BLE001
+                line["frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # (the side legs must not cost the line: whatever goes wrong in them is reported in their place, and one that never comes
     # back - a collective some rank does not reach - ends the job with the line as it stands: benchlib/sidelegs.py)

@@ -33,7 +33,6 @@
 // the restatement's, bit for bit, whatever the slot order and whatever the atomics did.
 #include "th_kernels.hpp"
 #include "th_raster.hpp"
-#include <cstdlib>
 
 namespace th {
 namespace {
@@ -288,11 +287,12 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
     __syncthreads();
 
     OwnTexels own;                                      // (both ends of the line, before anything else)
-    if (can) { own.have = true; own.cur = PLAIN ? p.cur[s] : dep_state(p, p.cur, s); own.prev = PLAIN ? p.prev[s] : dep_state(p, p.prev, s); }
+    if constexpr (PLAIN) { if (can) { own.have = true; own.cur = p.cur[s]; own.prev = p.prev[s]; } }
+    else if (can) { own.have = true; own.cur = dep_state(p, p.cur, s); own.prev = dep_state(p, p.prev, s); }
     DepositLine L;
     L.draws = false;
     LineRecord r{};
-    bool slow = false, spans = false;
+    bool slow = false;
     uint32_t dealt = 0;                                 // rows of this line handed to the wave's lanes
     if (can) {
         dep_setup<PLAIN>(p, col, p.row0 + row, L, s, own, false);          // (the varyings: once the line is known to cover a texel)
@@ -317,14 +317,6 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
                     } else dep_raster_small_hexagon2(p, PX, PY, ymin, ymax, [&](int x, int y) { rec_add(r, x, y); });
                 } else slow = true;
             } else if (where == kHexClip) slow = true;
-        }
-        // a slow line that SPANS the view - tens, hundreds of rows or columns - is a wave's work, not a lane's (bins_span_lines); asked
-        // of the few slow lines alone, their corners made again: not an instruction on the other lines' path
-        if (slow) {
-            float ax[6], ay[6];
-            dep_hexagon(p, L, ax, ay);
-            spans = dep_hexagon_spans(p, ax, ay);
-            slow = !spans;
         }
     }
     if constexpr (DEAL) {
@@ -379,7 +371,6 @@ __global__ __launch_bounds__(BS, 6) void bins_fused_kernel(const DepositParams p
     if (q.c1) took1 = resv_take(t, q.b1, q.c1);
     dep_list_append(p, kListSlow, block, slow, s);
     dep_list_append(p, kListLong, block, lengthy, s);
-    dep_list_append(p, kListSpan, block, spans, s);
     __syncthreads();
     // the block's share of every bin it met: one atomic each on the cursor of the block's list of that bin; the
     // pages that start inside it are taken from the pool
@@ -446,16 +437,23 @@ TH_D void bins_slow_lines(const DepositParams &p, uint32_t block, uint32_t block
     LdsWords<256> words{polygons + threadIdx.x};          // (the clipped polygon: indexed at run time - in LDS, not in scratch memory)
     dep_list_work(p, kListSlow, [&](bool have, uint32_t s, uint32_t seg) {
         const uint32_t rep = seg & (kBinReplicas - 1u);
+        // a slow line that SPANS the view - tens, hundreds of rows or columns - is a wave's work, not a lane's: passed on to
+        // bins_span_kernel (asked here, of the few slow lines, not on the other sixteen million lines' path)
+        bool spans = false;
+        DepositLine L;
+        uint32_t id = 0;
         if (have) {
             uint32_t col, row;
             slot_particle(p, s, col, row);
-            DepositLine L;
             dep_setup(p, col, p.row0 + row, L, s);
-            const uint32_t id = col * p.H + p.row0 + row;
+            id = col * p.H + p.row0 + row;
+            if (L.draws) { float cx[6], cy[6]; dep_hexagon(p, L, cx, cy); spans = dep_hexagon_spans(p, cx, cy); }
+        }
+        dep_list_append(p, kListSpan, seg, spans, s);
+        if (have && !spans)
             dep_raster_line(p, L, [&](int x, int y) {
                 bins_put(p, L, id, place_single(p, bin_of(p, (uint32_t)x, (uint32_t)y), rep), x, y);
             }, words);
-        }
     }, block, blocks);
 }
 
@@ -628,17 +626,16 @@ TH_D void bins_span_lines(const DepositParams &p, uint32_t block, uint32_t block
     }
 }
 
-// the three lists in one launch, a third of the grid each: small grids that wait on their loads and atomics, side by side
+// both lists in one launch, half of the grid each: two small grids that wait on their loads and atomics, side by side
 __global__ __launch_bounds__(256) void bins_listed_kernel(const DepositParams p)
 {
     __shared__ float polygons[48 * 256];                  // (48 KB: three workgroups per CU - the grid is that large)
-    const uint32_t third = gridDim.x / 3u;
-    if (blockIdx.x < third) bins_long_lines(p, blockIdx.x, third);
-    else if (blockIdx.x < 2u * third) bins_slow_lines(p, blockIdx.x - third, third, polygons);
-    else if (!p.src.row_index) bins_span_lines(p, blockIdx.x - 2u * third, third, polygons);
+    const uint32_t half = gridDim.x >> 1;
+    if (blockIdx.x < half) bins_long_lines(p, blockIdx.x, half);
+    else bins_slow_lines(p, blockIdx.x - half, half, polygons);
 }
-// ... where there are tens of thousands of spanning lines for sure - the shapes whose vertex lookup drifts - a launch of their own:
-// 2 KB of LDS instead of 48, every wave slot of the chip (the third of bins_listed_kernel's grid: 1.6 ms at 8192 x 8192 particles)
+// ... and behind it the spanning lines the slow list's pass found (none on an ordinary frame: the workgroups read a zero and
+// leave - a launch of ~3 us in the draw's chain, where classifying every line in the emit cost that kernel 3 %: 473 -> 487 us)
 __global__ __launch_bounds__(256) void bins_span_kernel(const DepositParams p)
 {
     __shared__ float scratch[4 * 128];
@@ -695,17 +692,10 @@ struct BinTexel {
     }
 };
 
-template <int MODE, bool NT = false>
+template <int MODE>
 TH_D void fetch_colors(const DepositParams &p, size_t frag, float4 &c0, float4 &c1)
 {
-    if constexpr (NT) {             // (read once: streamed past the caches' replacement)
-        typedef float v4 __attribute__((ext_vector_type(4)));
-        const v4 *src = reinterpret_cast<const v4 *>(p.colors);
-        if constexpr (MODE == 2) {
-            const v4 a = __builtin_nontemporal_load(src + 2u * frag), b = __builtin_nontemporal_load(src + 2u * frag + 1u);
-            c0 = make_float4(a.x, a.y, a.z, a.w); c1 = make_float4(b.x, b.y, b.z, b.w);
-        } else { const v4 a = __builtin_nontemporal_load(src + frag); c0 = make_float4(a.x, a.y, a.z, a.w); c1 = c0; }
-    } else if constexpr (MODE == 2) { c0 = p.colors[2u * frag]; c1 = p.colors[2u * frag + 1u]; }
+    if constexpr (MODE == 2) { c0 = p.colors[2u * frag]; c1 = p.colors[2u * frag + 1u]; }
     else { c0 = p.colors[frag]; c1 = c0; }
 }
 template <int MODE>
@@ -767,7 +757,7 @@ TH_D uint32_t bin_scan_counts(BinShared<MODE> &s)
 
 // a texel's run blended by its own thread: `len` fragments whose positions src_at(0..len-1) gives in blend order; the
 // varyings are fetched eight ahead of the dependent blends
-template <int MODE, typename SrcAt, uint32_t AHEAD = (MODE == 2 ? 4u : 8u), bool NT = false>
+template <int MODE, typename SrcAt, uint32_t AHEAD = (MODE == 2 ? 4u : 8u)>
 TH_D void bin_blend_own(const DepositParams &p, uint32_t begin, uint32_t len, BinTexel<MODE> &d, SrcAt src_at)
 {
     constexpr uint32_t kAhead = AHEAD;
@@ -777,7 +767,7 @@ TH_D void bin_blend_own(const DepositParams &p, uint32_t begin, uint32_t len, Bi
 #pragma unroll
         for (uint32_t q = 0; q < kAhead; ++q) src[q] = src_at(j0 + q < len ? j0 + q : len - 1u);
 #pragma unroll
-        for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE, NT>(p, (size_t)begin + src[q], c0[q], c1[q]);
+        for (uint32_t q = 0; q < kAhead; ++q) fetch_colors<MODE>(p, (size_t)begin + src[q], c0[q], c1[q]);
 #pragma unroll
         for (uint32_t q = 0; q < kAhead; ++q) if (j0 + q < len) apply_colors<MODE>(d, c0[q], c1[q]);
     }
@@ -1103,10 +1093,9 @@ __device__ unsigned long long g_blend_stamps[16];
 #define TH_STAMP_BEGIN() do {} while (0)
 #endif
 
-template <int MODE, int VAR>           // EXPERIMENT (r6): VAR 0 round 5's blend, 1 twice the varyings in flight, 2 ... streamed past the caches, 3 windows in LDS
+template <int MODE>
 __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(const DepositParams p)
 {
-    constexpr bool WIN = VAR == 3;
     __shared__ BinShared<MODE> s;
     const uint32_t b = blockIdx.x, t = threadIdx.x;
     TH_STAMP_BEGIN();
@@ -1158,10 +1147,13 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
         uint32_t id[kPer], lts[kPer / 4u] = {}, ranks[kPer / 4u] = {}, have = 0u;
         {
             unsigned long long k[kPer];
+            // (only the rounds the bin's places fill - seven of the sixteen on an ordinary first frame: a round beyond them made
+            // its places up - fifteen comparisons against the lists' starts each - and loaded the last place's key again)
+            const uint32_t rounds = (n + 255u) >> 8;
 #pragma unroll
-            for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; at[q] = place(f < n ? f : n - 1u); }
+            for (uint32_t q = 0; q < kPer; ++q) { const uint32_t f = q * 256u + t; at[q] = q < rounds ? place(f < n ? f : n - 1u) : 0u; }
 #pragma unroll
-            for (uint32_t q = 0; q < kPer; ++q) k[q] = keys[at[q]];
+            for (uint32_t q = 0; q < kPer; ++q) k[q] = q < rounds ? keys[at[q]] : kEmptyKey;
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q) {
                 id[q] = (uint32_t)k[q];
@@ -1194,56 +1186,13 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
                 if (have >> q & 1u) {
                     const uint32_t lt = lt_of(q), r0 = s.first[lt], r1 = s.first[lt + 1u];
                     uint32_t rank = 0;                  // (< kRankMaxRun = 256: a byte)
-                    // (four stream indices a trip, one 16-byte LDS read from the aligned word at or below the run's start: a trip per
-                    // index waited for its own read; what a read holds of the neighbouring runs is masked out)
-                    const uint4 *sid4 = reinterpret_cast<const uint4 *>(sid);
-                    for (uint32_t j = r0 & ~3u; j < r1; j += 4u) {
-                        const uint4 k4 = sid4[j >> 2];
-                        rank += (j >= r0 && k4.x < id[q] ? 1u : 0u) + (j + 1u >= r0 && j + 1u < r1 && k4.y < id[q] ? 1u : 0u) +
-                                (j + 2u >= r0 && j + 2u < r1 && k4.z < id[q] ? 1u : 0u) + (j + 3u >= r0 && j + 3u < r1 && k4.w < id[q] ? 1u : 0u);
-                    }
+                    // (four indices a trip from one 16-byte LDS read, the neighbours' masked out - what the crowded bins' sort gained
+                    // from - was 50 us SLOWER here: runs of six, most of a read thrown away; profiles/r6_d_blend_experiments.txt)
+                    for (uint32_t j = r0; j < r1; ++j) rank += sid[j] < id[q] ? 1u : 0u;
                     ranks[q >> 2] |= rank << ((q & 3u) * 8u);
                 }
             __syncthreads();                            // (every stream index has been read: the words now take the places)
             TH_STAMP(4);
-            if constexpr (WIN) {
-                // The varyings come to the runs, not the runs' threads to the varyings.  A texel's thread fetching its run's
-                // varyings itself reads 16 or 32 bytes from wherever each fragment happened to be placed: 64 lanes, 64 cache lines
-                // per load instruction, every line fetched again by the three other texels whose fragments share it - the
-                // texture path served one line a cycle and a run of six fragments took 45 000 cycles, 37 % of the workgroup's
-                // life (profiles/r6_c_blend_stamps.txt).  Instead the thread that HOLDS fragment f (its place in registers since
-                // the keys were read: consecutive threads, consecutive places - a wave's loads are whole lines) fetches its
-                // varyings and drops them at the fragment's position in blend order, a window of positions at a time in the
-                // words the stream indices no longer need; the texels' threads then walk their runs in LDS.
-                constexpr uint32_t kPerFrag = MODE == 2 ? 2u : 1u, kWin = (3u * kCrowdCap / 4u) / kPerFrag;      // float4s the pool holds: 1536
-                float4 *win = reinterpret_cast<float4 *>(s.pool);
-                const uint32_t total = s.first[kBinTexels], r0 = s.first[t], r1 = r0 + mine;
-                // (a fragment's position: its texel's first + its rank - read again per window rather than kept: sixteen more registers)
-                auto pos_of = [&](uint32_t q) { return (have >> q & 1u) ? s.first[lt_of(q)] + ((ranks[q >> 2] >> ((q & 3u) * 8u)) & 0xffu) : 0xffffffffu; };
-                for (uint32_t w0 = 0; w0 < total; w0 += kWin) {
-                    // (two fragments' varyings in flight per thread and trip; named values, not arrays: indexed under the window's
-                    // condition the arrays went to scratch memory)
-#pragma unroll
-                    for (uint32_t q0 = 0; q0 < kPer; q0 += 2u) {
-                        const uint32_t rel_a = pos_of(q0) - w0, rel_b = pos_of(q0 + 1u) - w0;
-                        const bool in_a = rel_a < kWin, in_b = rel_b < kWin;
-                        float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, b0 = a0, b1 = a0;
-                        if (in_a) fetch_colors<MODE>(p, (size_t)place(q0 * 256u + t), a0, a1);
-                        if (in_b) fetch_colors<MODE>(p, (size_t)place((q0 + 1u) * 256u + t), b0, b1);
-                        if (in_a) { win[rel_a * kPerFrag] = a0; if constexpr (MODE == 2) win[rel_a * kPerFrag + 1u] = a1; }
-                        if (in_b) { win[rel_b * kPerFrag] = b0; if constexpr (MODE == 2) win[rel_b * kPerFrag + 1u] = b1; }
-                    }
-                    __syncthreads();
-                    const uint32_t lo = r0 > w0 ? r0 : w0, hi = r1 < w0 + kWin ? r1 : w0 + kWin;
-                    for (uint32_t j = lo; j < hi; ++j) {
-                        const float4 a = win[(j - w0) * kPerFrag], b = MODE == 2 ? win[(j - w0) * kPerFrag + 1u] : a;
-                        apply_colors<MODE>(d, a, b);
-                    }
-                    __syncthreads();
-                }
-                touched = mine != 0u;
-                TH_STAMP(5);
-            } else {
 #pragma unroll
             for (uint32_t q = 0; q < kPer; ++q)
                 if (have >> q & 1u) osrc[s.first[lt_of(q)] + ((ranks[q >> 2] >> ((q & 3u) * 8u)) & 0xffu)] = at[q];
@@ -1251,9 +1200,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? 4 : 5) void bins_blend_kernel(cons
             TH_STAMP(5);
             const uint32_t r0 = s.first[t];
             auto src_at = [&](uint32_t base) { return [osrc, base](uint32_t j) { return osrc[base + j]; }; };
-            // (WIN = false here is the experiment's other arm: twice the varyings in flight per thread)
-            if (mine && mine <= kOwnRun) { touched = true; bin_blend_own<MODE, decltype(src_at(r0)), (MODE == 2 ? 4u : 8u) * (VAR >= 1 ? 2u : 1u), VAR == 2>(p, 0u, mine, d, src_at(r0)); }
-            }
+            // (eight fragments' varyings in flight per thread with both targets, sixteen with one: what the kernel's 122 / 96 registers
+            // hold anyway - its peak is where the keys are read; profiles/r6_d_blend_experiments.txt)
+            if (mine && mine <= kOwnRun) { touched = true; bin_blend_own<MODE, decltype(src_at(r0)), (MODE == 2 ? 8u : 16u)>(p, 0u, mine, d, src_at(r0)); }
 #ifdef TH_BLEND_STAMPS
             TH_STAMP(6);                                 // (thread 0's own run)
             __syncthreads();
@@ -2073,8 +2022,8 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     // (DEAL: the rows of a wave's lines dealt evenly to its lanes; every lane walking its own line's rows was 0.65 against 0.58 ms)
     if (!p.packed && !p.src.row_index) hipLaunchKernelGGL((bins_fused_kernel<256u, true, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((bins_fused_kernel<256u, true, false>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_listed_kernel, dim3(3u * kDepLists * 6u), dim3(256), 0, s, p);
-    if (p.src.row_index) hipLaunchKernelGGL(bins_span_kernel, dim3(kDepLists * 32u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 6u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bins_span_kernel, dim3(kDepLists * (p.src.row_index ? 32u : 4u)), dim3(256), 0, s, p);      // (drifting lookups: tens of thousands of them)
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }
@@ -2171,15 +2120,9 @@ void launch_bins_blend_crowd(const DepositParams &p, hipStream_t s)
 // it covers the read-back of the pass's totals (the kernel returns at once when the pass raised a flag)
 void launch_bins_blend(const DepositParams &p, hipStream_t s)
 {
-    static const int var = getenv("TH_EXP_BLEND") ? atoi(getenv("TH_EXP_BLEND")) : 0;        // EXPERIMENT (r6)
-#define TH_GO(M) do { if (var == 3) hipLaunchKernelGGL((bins_blend_kernel<M, 3>), dim3(p.nbins), dim3(256), 0, s, p); \
-                      else if (var == 2) hipLaunchKernelGGL((bins_blend_kernel<M, 2>), dim3(p.nbins), dim3(256), 0, s, p); \
-                      else if (var == 1) hipLaunchKernelGGL((bins_blend_kernel<M, 1>), dim3(p.nbins), dim3(256), 0, s, p); \
-                      else hipLaunchKernelGGL((bins_blend_kernel<M, 0>), dim3(p.nbins), dim3(256), 0, s, p); } while (0)
-    if (p.mode == 0) TH_GO(0);
-    else if (p.mode == 1) TH_GO(1);
-    else TH_GO(2);
-#undef TH_GO
+    if (p.mode == 0) hipLaunchKernelGGL(bins_blend_kernel<0>, dim3(p.nbins), dim3(256), 0, s, p);
+    else if (p.mode == 1) hipLaunchKernelGGL(bins_blend_kernel<1>, dim3(p.nbins), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(bins_blend_kernel<2>, dim3(p.nbins), dim3(256), 0, s, p);
 }
 size_t crowd_words_per_bin() { return 7u * kBinTexels + 1u; }       // counts, cursors, starts (+ 1), the long list, the giants' list, the giants' windows (2)
 

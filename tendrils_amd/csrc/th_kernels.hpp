@@ -136,8 +136,6 @@ struct LineSources {
 
 struct DepositParams {
     const float4 *cur, *prev;    // buffers[0], buffers[1] in texel order (a packed ring: uint2 texels behind the same pointers)
-    uint32_t packed;             // cur / prev hold the packed 8-byte form (TH_STATE_F16): read through dep_state (th_raster.hpp)
-    LineSources src;
     float4 *flow;
     uint32_t W, H;               // particle texture shape (H = the WHOLE texture's height)
     uint32_t row0, rows;         // the rows held by cur/prev (a row-band shard; row0 = 0, rows = H otherwise)
@@ -191,6 +189,11 @@ struct DepositParams {
     unsigned long long *crowd_parted;              // the giants' keys parted by the leading bits of their stream indices (same positions as crowd_keys)
     uint32_t *crowd_giant_win;                     // per entry of crowd_giant: first window, windows (first = ~0: left to crowd_blend_kernel)
     uint32_t *crowd_windows, crowd_windows_cap;    // per window: entry of crowd_giant, first key inside the run, keys
+    // (round 6's fields at the END: in front, they moved every other field's place in the kernel arguments, and the emit - 106
+    // SGPRs, some of them spilled into VGPR lanes - came out of the compiler scheduled otherwise and 4 % slower, instruction for
+    // instruction the same kernel: profiles/r6_d_blend_experiments.txt)
+    uint32_t packed;             // cur / prev hold the packed 8-byte form (TH_STATE_F16): read through dep_state (th_raster.hpp)
+    LineSources src;
 };
 
 // row-band shards drawing with the binned pipeline (th_bins.hip "the bins travel to the ranks that own them")

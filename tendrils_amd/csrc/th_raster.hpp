@@ -124,21 +124,37 @@ TH_D DepositVertex dep_fetch(const DepositParams &p, uint32_t i, uint32_t j, uin
     // (one unconditional load from a selected address: a load under a branch is awaited at the join, and the second
     // vertex's load would only go out after the first had come back)
     const bool self = row == (int)own_row && col == (int)i;
-    const bool inside = row >= 0 && row < (int)p.rows;
-    const int row_in = row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1);
-    size_t at = self ? own_at : (PLAIN ? (size_t)row_in * W + col : dep_slot_of(p, row_in, col));
-    if (!PLAIN && at == ~(size_t)0) { at = own_at; if (inside) *p.oob = 1u; }        // (a texel the tables should hold and do not: the pass is refused)
-    const float4 *halo = nullptr;                                // (the neighbouring bands' edge rows: always f32, in texel order)
-    if (!inside) {
-        if (row == -1 && p.halo_lo) halo = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
-        else if (row == (int)p.rows && p.halo_hi) halo = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
-        else *p.oob = 1u;
-    }
     float4 t;
-    if (own.have && self) {
-        const bool c = offset > 0.25f;
-        t = make_float4(c ? own.cur.x : own.prev.x, c ? own.cur.y : own.prev.y, c ? own.cur.z : own.prev.z, c ? own.cur.w : own.prev.w);
-    } else t = halo ? *halo : (PLAIN ? tex[at] : dep_state(p, tex, at));
+    if constexpr (PLAIN) {
+        // (one unconditional load from a selected address: a load under a branch is awaited at the join, and the second
+        // vertex's load would only go out after the first had come back)
+        size_t at = (size_t)(row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1)) * W + col;
+        if (self) at = own_at;
+        const float4 *from = tex + at;
+        if (!(row >= 0 && row < (int)p.rows)) {
+            if (row == -1 && p.halo_lo) from = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
+            else if (row == (int)p.rows && p.halo_hi) from = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
+            else *p.oob = 1u;
+        }
+        if (own.have && self) {
+            const bool c = offset > 0.25f;
+            t = make_float4(c ? own.cur.x : own.prev.x, c ? own.cur.y : own.prev.y, c ? own.cur.z : own.prev.z, c ? own.cur.w : own.prev.w);
+        } else t = *from;
+    } else {
+        const bool inside = row >= 0 && row < (int)p.rows;
+        size_t at = self ? own_at : dep_slot_of(p, row < 0 ? 0 : (row < (int)p.rows ? row : (int)p.rows - 1), col);
+        if (at == ~(size_t)0) { at = own_at; if (inside) *p.oob = 1u; }        // (a texel the tables should hold and do not: the pass is refused)
+        const float4 *halo = nullptr;                            // (the neighbouring bands' edge rows: always f32, in texel order)
+        if (!inside) {
+            if (row == -1 && p.halo_lo) halo = p.halo_lo + (offset > 0.25f ? 0 : W) + col;
+            else if (row == (int)p.rows && p.halo_hi) halo = p.halo_hi + (offset > 0.25f ? 0 : W) + col;
+            else *p.oob = 1u;
+        }
+        if (own.have && self) {
+            const bool c = offset > 0.25f;
+            t = make_float4(c ? own.cur.x : own.prev.x, c ? own.cur.y : own.prev.y, c ? own.cur.z : own.prev.z, c ? own.cur.w : own.prev.w);
+        } else t = halo ? *halo : dep_state(p, tex, at);
+    }
     DepositVertex v;
     v.live = (t.x != kInert) || (t.y != kInert);
     v.px = t.x * p.view_x;
