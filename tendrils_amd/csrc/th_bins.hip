@@ -1084,7 +1084,7 @@ TH_D void bin_crowded(BinShared<MODE> &s, const DepositParams &p, const unsigned
 }
 
 #ifdef TH_BLEND_STAMPS
-// (diagnostic builds only - tools/gpu_r6_blend_stamps.sh: where a bin's workgroup spends its life, cycles per phase summed over the launch)
+// (diagnostic builds only - tools/build_variant_libs.sh, tools/gpu_ab_prev.sh: where a bin's workgroup spends its life, cycles per phase summed over the launch)
 __device__ unsigned long long g_blend_stamps[16];
 #define TH_STAMP(k) do { if (threadIdx.x == 0u) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_blend_stamps[k], now_ - last_); last_ = now_; } } while (0)
 #define TH_STAMP_BEGIN() unsigned long long last_ = __builtin_readcyclecounter()

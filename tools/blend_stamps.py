@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a bin's workgroup of bins_blend_kernel spends its life: a diagnostic build of th_bins.hip (-DTH_BLEND_STAMPS:
-cycle stamps at the kernel's barriers, summed over the launch; tools/gpu_r6_blend_stamps.sh builds it into tools/bin/ and runs
+cycle stamps at the kernel's barriers, summed over the launch; tools/build_variant_libs.sh builds it into tools/bin/, tools/gpu_ab_prev.sh runs
 this with TH_LIB pointing there) under the C3 frame loop.  Prints cycles per phase per workgroup and their shares.
 
     TH_LIB=tools/bin/libtendrils_hip_stamps.so python3 tools/blend_stamps.py [frames] [settle frames]
