@@ -599,25 +599,30 @@ TH_D void bins_span_lines(const DepositParams &p, uint32_t block, uint32_t block
                 for (uint32_t step = 32u; step > 0u; step >>= 1) if (starts[j + step] <= (have ? f : 0u)) j += step;
                 const int x = __shfl(left, (int)j) + (int)((have ? f : 0u) - starts[j]), yy = base + (int)j;
                 const uint32_t b = have ? bin_of(p, (uint32_t)x, (uint32_t)yy) : kNoPlace;
-                // one reservation per bin the 64 fragments meet (a line passes from bin to bin: a handful)
-                uint32_t v = 0;
+                // one reservation per bin the 64 fragments meet (a line passes from bin to bin: a handful) - the lanes are grouped by
+                // bin first (ballots only), then every group's first lane moves its bin's cursor: the groups' atomics go out TOGETHER,
+                // one round trip to the memory side per 64 fragments instead of one per bin met
+                uint32_t leader = lane, rank = 0, cnt = 0;
                 unsigned long long left_over = __ballot(have);
                 while (left_over) {
-                    const int leader = __builtin_ctzll(left_over);
-                    const uint32_t lb = (uint32_t)__shfl((int)b, leader);
+                    const int first_lane = __builtin_ctzll(left_over);
+                    const uint32_t lb = (uint32_t)__shfl((int)b, first_lane);
                     const unsigned long long same = __ballot(have && b == lb) & left_over;
-                    const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
-                    uint32_t first = 0;
-                    if ((int)lane == leader) {
-                        first = atomicAdd(list_cursor(p, lb, rep), cnt);
-                        if (first + cnt < first) { bins_flag(p, kBinsBinFull); first = 0xffffffffu - cnt; }
-                        else if (((first + cnt - 1u) >> kPageShift) != (first >> kPageShift) || (first & (kBinPage - 1u)) == 0u)
-                            pages_open(p, lb * kBinReplicas + rep, first, cnt);
+                    if (same >> lane & 1ull) {
+                        leader = (uint32_t)first_lane;
+                        rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+                        cnt = (uint32_t)__builtin_popcountll(same);
                     }
-                    first = (uint32_t)__shfl((int)first, leader);
-                    if (same >> lane & 1ull) v = first + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
                     left_over &= ~same;
                 }
+                uint32_t first = 0;
+                if (have && leader == lane) {
+                    first = atomicAdd(list_cursor(p, b, rep), cnt);
+                    if (first + cnt < first) { bins_flag(p, kBinsBinFull); first = 0xffffffffu - cnt; }
+                    else if (((first + cnt - 1u) >> kPageShift) != (first >> kPageShift) || (first & (kBinPage - 1u)) == 0u)
+                        pages_open(p, b * kBinReplicas + rep, first, cnt);
+                }
+                const uint32_t v = (uint32_t)__shfl((int)first, (int)leader) + rank;
                 if (have) bins_put(p, L, id, place_of<true>(p, b * kBinReplicas + rep, v), x, yy);       // (a list that overflowed: no place, the pass is repeated)
             }
             wave_sync_lds();                             // (the starts are the next 64 rows' now)

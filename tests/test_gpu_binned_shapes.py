@@ -64,14 +64,16 @@ def lookups_drift(n):
     return sorted(set(rows)), cols
 
 
-@pytest.mark.parametrize("n,slots", [(100, "sorted"), (100, "texel"), (1080, "sorted")])
+@pytest.mark.parametrize("n,slots", [(100, "sorted"), (100, "texel"), (1080, "sorted"), (3000, "sorted")])
 def test_frame_loop_over_drifting_rows_bins_equal_restatement_and_stream(oracle, n, slots):
-    """heights 100 and 1080: rows whose vertices read the row beside them.  A loop of tick(); step(); draw() through the bins -
+    """heights 100, 1080 and 3000 (2, 22, 177 rows whose vertices read the row beside them).  A loop of tick(); step(); draw() through the bins -
     over tile-sorted slots re-sorted every 3 steps, and in texel order - against the restatement (n = 100) and the
     stream-ordered pipeline, every frame's fragments and the last frame's targets and particles bit for bit."""
     rows, cols = lookups_drift(n)
     assert rows and not cols                                   # (what this size is here for)
-    view, frames = ((96, 54) if n > 128 else (64, 36)), 7     # (sorted slots need twice as many particles as target texels)
+    view, frames = ((96, 54) if n > 128 else (64, 36)), (7 if n < 2000 else 4)     # (sorted slots need twice as many particles as target texels)
+    if n >= 2000:
+        view = (480, 270)
     st = state(n, view, 100 + n)
     a = make(n, view, "bins", bucket=1 if slots == "sorted" else 0)
     b = make(n, view, "stream", bucket=0)
