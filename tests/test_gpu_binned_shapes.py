@@ -169,3 +169,43 @@ def test_packed_ring_draws_through_the_bins_in_place(oracle, n, slots):
     assert bits_equal(a.flow.read(), b.flow.read()).all() and (a.read_view() == b.read_view()).all() and a.read_view().any()
     assert bits_equal(a.particles.read(0), b.particles.read(0)).all()
     a.dispose(); b.dispose()
+
+
+def test_spanning_lines_through_a_pool_that_runs_dry_and_lists_that_outgrow_their_pages(oracle, monkeypatch):
+    """100 x 100 particles: rows 53 and 59 join unrelated particles - lines across the whole 64 x 36 target, a wave each
+    (bins_span_lines).  With a page pool of 4 pages and lists of ONE page at first (two bins of 8000 fragments) the emitting pass runs out of both while those
+    lines reserve their places a bin's worth at a time: repeated with a larger pool / a wider table before anything is blended -
+    the restatement's result, and the same again on the next draw."""
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    monkeypatch.setenv("TH_BINS_POOL", "4")
+    monkeypatch.setenv("TH_BINS_PAGES", "1")
+    n, view = 100, (64, 36)
+    rng = np.random.default_rng(5)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-0.1, 0.1, (n, n, 2)) * [1.0, view[1] / view[0]]            # a crowded middle: lists of many pages
+    prev[53:61, :, :2] = rng.uniform(-0.95, 0.95, (8, n, 2)) * [1.0, view[1] / view[0]]      # the drifting rows' particles all over the view
+    prev[..., 2:] = rng.uniform(-.01, .01, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.15, .15, (n, n, 2)).astype(np.float32)                     # (lines of up to ten texels)
+    base = np.zeros((view[1], view[0], 4), np.float32)
+    size = (1.0, view[0] / view[1])
+    want, frags = oracle.flow_deposit(cur, prev, base, 2500.0, view_size=size)
+    again, frags2 = oracle.flow_deposit(cur, prev, want, 2500.0, view_size=size)
+    t = ta.Tendrils(View(*view))
+    t.resize()
+    t.setup(n)
+    assert t.particles.option("bins_pool") == 4 and t.particles.option("bins_pages") == 1
+    t.particles.option("bucket", 1)
+    t.particles.draw_pipeline("bins")
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.flow.set_pixels(base)
+    t.timer.time = 2500.0
+    t.renderView = False
+    t.draw()
+    assert t.fragments == frags > 15_000 and pipeline_of(t) == 1
+    assert bits_equal(t.flow.read(), want).all()
+    t.draw()
+    assert t.fragments == frags2 and bits_equal(t.flow.read(), again).all()
+    t.dispose()
