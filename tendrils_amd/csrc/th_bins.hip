@@ -19,7 +19,9 @@
 //      workgroup whose reservation crosses into a new page takes that page from the pool and publishes it.  Every place
 //      handed out is written (a pass that ran out of pages is flagged and repeated before anything reads it).
 //      bins_listed_kernel: the few lines that cross the view's edge (clipped) and the lines of more fragments than a record
-//      holds, one place at a time.
+//      holds, one place at a time.  bins_span_kernel: the lines that SPAN the view - the drifting rows / columns of some shapes
+//      join unrelated particles (th_order.hip: line_rows; th::LineSources is how their vertices are found in a slot order) - a
+//      wave each: rows to lanes, texels dealt evenly, one cursor atomic per bin a batch of 64 fragments meets.
 //   2. bins_plan_kernel / crowd_plan_kernel: the bins of more than kBinCap places ("large").
 //   3. bins_blend_kernel: one workgroup per bin of up to kBinCap places: its fragments grouped by texel (LDS counting sort), every
 //      texel's run ordered by the stream index of its line (short runs: rank by counting; long ones: bitonic sort) and
