@@ -16,7 +16,8 @@ JSON line and exits with the child's status.  Under a launcher (WORLD_SIZE set) 
 Timed region: W warm-up steps, then an untimed clock pre-roll (>= 50 ms of the same launches,
 disclosed as `preroll_ms`: a GPU that has idled for a few ms runs its first launches ~10 %
 slower, profiles/r2_a_*), then `--reps` (5) repetitions of: barrier + synchronize, EXACTLY K steps,
-barrier + synchronize; max over ranks per repetition; `value` / `ms_per_step` are the MEDIAN repetition
+barrier + synchronize (the barrier: the ranks of one node meeting in shared memory - benchlib/job.py NodeBarrier; `barrier` in the
+line says which); max over ranks per repetition; `value` / `ms_per_step` are the MEDIAN repetition
 (`repetitions` carries all of them and their spread).  Every timed repetition contains the path's
 collective: after every fused launch the statistics pass and - world > 1 - the library's own RCCL
 all-reduce of the counter block (th_stats_allreduce, on the context's stream); `rccl` reports the ranks
