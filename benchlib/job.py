@@ -38,26 +38,38 @@ class NodeBarrier:
     def __init__(self, dist, rank, world):
         self.dist, self.rank, self.world, self.epoch, self.slots, self.shm = dist, rank, world, 0, None, None
         self.kind = "torch.distributed barrier"
+        # (every rank takes every collective below whatever failed on it: a rank that skipped one would leave the others inside it)
+        slots, ok, name = None, 1, [None]
         try:
             from multiprocessing import resource_tracker, shared_memory
-            name = [None]
-            if rank == 0:
-                self.shm = shared_memory.SharedMemory(create=True, size=64 * world)
-                name[0] = self.shm.name
-            dist.broadcast_object_list(name, src=0)
-            if rank != 0:
-                self.shm = shared_memory.SharedMemory(name=name[0])
-                try:                       # (the creator unlinks it; an attaching process's tracker must not)
-                    resource_tracker.unregister(self.shm._name, "shared_memory")
-                except Exception:          # noqa: BLE001
-                    pass
-            slots = np.ndarray((world, 8), dtype=np.int64, buffer=self.shm.buf)
-            if rank == 0:
-                slots[:] = 0
-            dist.barrier()
-            ok = 1
         except Exception:                  # noqa: BLE001
             ok = 0
+        if rank == 0 and ok:
+            try:                           # (a fresh segment is zero-filled: epoch 0 everywhere)
+                self.shm = shared_memory.SharedMemory(create=True, size=64 * world)
+                name[0] = self.shm.name
+            except Exception:              # noqa: BLE001
+                name[0] = None
+        try:
+            dist.broadcast_object_list(name, src=0)
+        except Exception:                  # noqa: BLE001
+            name[0] = None
+        if name[0] is None:
+            ok = 0
+        if ok:
+            try:
+                import os
+                if os.environ.get("TH_BENCH_TEST_NOSHM") == str(rank):      # (tests: this rank cannot have the segment)
+                    raise OSError("TH_BENCH_TEST_NOSHM")
+                if rank != 0:
+                    self.shm = shared_memory.SharedMemory(name=name[0])
+                    try:                   # (the creator unlinks it; an attaching process's tracker must not)
+                        resource_tracker.unregister(self.shm._name, "shared_memory")
+                    except Exception:      # noqa: BLE001
+                        pass
+                slots = np.ndarray((world, 8), dtype=np.int64, buffer=self.shm.buf)
+            except Exception:              # noqa: BLE001
+                ok = 0
         try:                               # every rank or none
             import torch
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -70,6 +82,8 @@ class NodeBarrier:
             self.kind = "shared-memory epoch barrier (the ranks of one node)"
             import atexit
             atexit.register(self.close)
+        else:
+            self.close()
 
     def __call__(self):
         if self.slots is None:

@@ -37,6 +37,18 @@ def test_self_launch_two_ranks_dry_run(oracle):
     assert fls["sent_bytes_per_draw"] > 0 and fls["received_bytes_per_draw"] > 0 and fls["fragments_per_draw_all_ranks"] > 100
 
 
+def test_a_rank_without_shared_memory_sends_every_rank_to_the_torch_barrier(oracle):
+    """the bracket's barrier is the ranks meeting in shared memory - every rank or none: one that cannot attach the segment takes
+    all of them to torch.distributed's barrier, and nobody is left inside a collective the others skipped"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TH_BENCH_TEST_NOSHM="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "4", "--warmup", "1",
+                        "--reps", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert line["barrier"] == "torch.distributed barrier" and line["value"] > 0 and line["legs_failed"] == []
+
+
 def test_child_failure_is_the_parents_status():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--config", "nope"],
