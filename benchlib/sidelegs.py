@@ -126,7 +126,7 @@ class comm_deadline:
     def __init__(self, rank, argv, bench):
         self.rank, self.argv, self.bench = rank, list(argv), bench
         self.seconds = float(os.environ.get("TH_BENCH_COMM_TIMEOUT", "180"))
-        self.timer = None
+        self.timer, self.lock, self.over = None, threading.Lock(), False
 
     def __enter__(self):
         self.timer = threading.Timer(max(min(self.seconds, remaining() - 60.0), 1.0), self._fresh_child)
@@ -135,10 +135,16 @@ class comm_deadline:
         return self
 
     def __exit__(self, *exc):
-        self.timer.cancel()
+        with self.lock:                   # (a deadline that has just passed holds it: this thread stops here and the process ends)
+            self.over = True
+            self.timer.cancel()
         return False
 
     def _fresh_child(self):
+        self.lock.acquire()               # (never released: the body must not go on beside the child)
+        if self.over:
+            self.lock.release()
+            return
         why = "the library's communicator had not come up on every rank within %.0f s" % self.seconds
         if self.rank == 0:
             print("[bench] %s: the bench starts again as a child process with --no-library-comm" % why, file=sys.stderr, flush=True)
