@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void logic_fused_kernel(const LogicParams p)
 // (a step reads what the previous one stored), so each intermediate state goes through pack -> unpack in
 // registers: bit-identical to nsteps logic_packed_kernel launches.
 template <bool FAST, bool NOISE, bool TARGET, bool POW2, bool BUCKETED, bool STATS>
-__global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicParams p)
+__global__ __launch_bounds__(256, 5) void logic_fused_packed_kernel(const LogicParams p)
 {
     __shared__ float4 smem[NOISE ? kHashVec + kLutSize : 1];
     const float4 *lut = smem + (NOISE ? kHashVec : 0);
@@ -336,15 +336,21 @@ __global__ __launch_bounds__(256) void logic_fused_packed_kernel(const LogicPara
             nxt = __builtin_nontemporal_load(&in[idx + stride]);
             if constexpr (BUCKETED) npid = __builtin_nontemporal_load(&p.perm[idx + stride]);
         }
+        // (between two fused steps the state is what the ring WOULD hold of it - quantize_state = unpack of pack - in registers as
+        // floats; the words are made once, for the two states that leave)
+        float4 st = unpack_state(w);
         for (uint32_t k = 0; k < p.nsteps; ++k) {
-            wprev = w;
-            w = pack_state(integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, unpack_state(w), pid, p.times[k], &tabs));
+            // (the state before the last step leaves as words at once: carried through the loop as four more floats the kernel
+            // had 101 VGPRs - four waves per SIMD instead of five)
+            if (k + 1u == p.nsteps && k) wprev = pack_state(st);
+            st = quantize_state(integrate<FAST, NOISE, TARGET, POW2, false, kFusedPermTable>(p, lut, st, pid, p.times[k], &tabs));
         }
+        if (p.nsteps) w = pack_state(st);                         // (one step: wprev stays the word that came in, whatever it decodes to)
         v2u a = {wprev.x, wprev.y}, b = {w.x, w.y};
         __builtin_nontemporal_store(a, &out_prev[idx]);
         __builtin_nontemporal_store(b, &out[idx]);
         // (the statistics of a packed ring are those of what its texels decode to - what th_stats reads through its f32 view)
-        if constexpr (STATS) { stats_take(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], unpack_state(w), p.u.speedLimit, first); first = false; }
+        if constexpr (STATS) { stats_take(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], st, p.u.speedLimit, first); first = false; }
     }
     if constexpr (STATS) stats_none(&p.stats_part[blockIdx.x * 4u + (threadIdx.x >> 6)], first);
 }

@@ -66,6 +66,22 @@ TH_D uint2 pack_state(float4 s)
     __builtin_memcpy(&ux, &hx, 2); __builtin_memcpy(&uy, &hy, 2);
     return make_uint2(px, (unsigned)ux | ((unsigned)uy << 16));
 }
+// unpack_state(pack_state(s)) without the 8 bytes in between: what a packed ring holds of a state, as the next fused step reads it.
+// The quantised position is an integer-valued float in [-32767, 32767]: the stored short converts back to exactly that float, and
+// never to the sentinel -32768; the velocity goes through fp16 and back; inert and NaN positions come back as unpack_state gives
+// them.  (Sixteen instructions fewer per fused step than the words packed, stored in registers and unpacked: round 6.)
+TH_D float4 quantize_state(float4 s)
+{
+    float4 r;
+    r.z = (float)(_Float16)s.z; r.w = (float)(_Float16)s.w;
+    if (!(s.x != kInert || s.y != kInert)) { r.x = kInert; r.y = kInert; }
+    else if (s.x != s.x || s.y != s.y) { r.x = __builtin_nanf(""); r.y = __builtin_nanf(""); }
+    else {
+        r.x = __builtin_rintf(__builtin_amdgcn_fmed3f(s.x * 16384.0f, -32767.0f, 32767.0f)) * 6.103515625e-05f;
+        r.y = __builtin_rintf(__builtin_amdgcn_fmed3f(s.y * 16384.0f, -32767.0f, 32767.0f)) * 6.103515625e-05f;
+    }
+    return r;
+}
 // ---------------------------------------------------------------------------
 // Reference-order evaluation of one texel: any input, any uniform set.  Used
 // for lanes outside the fast path's proven domain and by the generic kernel.
