@@ -2,10 +2,10 @@
 # ISA of one kernel (default: the exact fused integrator) and an instruction histogram of its step loop
 set -u
 GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-K=${1:-_ZN2th18logic_fused_kernelILb0ELb1ELb0ELb1ELb0EEEvNS_11LogicParamsE}
+K=${1:-_ZN2th18logic_fused_kernelILb0ELb1ELb0ELb1ELb1ELb1EEEvNS_11LogicParamsE}
 cd "$(dirname "$0")/../tendrils_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I../../include -S --cuda-device-only -o /tmp/th_kernels.s th_kernels.hip 2>/dev/null
-awk -v k="$K:" '$1==k{f=1} f{print} f&&/s_endpgm/{exit}' /tmp/th_kernels.s > /tmp/kernel.s
+awk -v k="$K:" '$1==k{f=1} f{print} f&&/^\.Lfunc_end/{exit}' /tmp/th_kernels.s > /tmp/kernel.s
 grep -A30 "^\s*.amdhsa_kernel $K" /tmp/th_kernels.s | grep -E "next_free_vgpr|next_free_sgpr|private_segment_fixed" 
 # inner loop = the deepest-nesting block range (Depth=2 header to its backedge)
 hdr=$(grep -n "Inner Loop Header: Depth=2" /tmp/kernel.s | head -1 | cut -d: -f1)
