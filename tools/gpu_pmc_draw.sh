@@ -3,7 +3,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-x}; PIPE=${2:-bins}
-OUT=$ROOT/gpurun_out/r3/pmc_$TAG
+OUT=$ROOT/gpurun_out/pmc_$TAG
 BENCH_ARGS=${BENCH_ARGS:-12}; GROUPS_WANTED=${PMC_GROUPS:-sq1 sq2 tcc mem mem2}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

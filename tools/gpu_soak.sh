@@ -2,7 +2,7 @@
 # long runs: frame loop (both passes), single steps, fused steps - counters must stay sane, nothing may fail
 set -u
 GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-mkdir -p gpurun_out/r2
+
 echo "=== 1500 frames step + draw (both passes)"; timeout 300 python tools/deposit_bench.py 1500 --both 2>&1 | tail -1
 echo "=== 1500 frames, all in view"; timeout 300 python tools/deposit_bench.py 1500 --both --in-view 2>&1 | tail -1
 echo "=== 4096 single steps"; PROBE_STEPS=4096 timeout 300 python tools/step_probe.py 2>&1 | grep "single step" | tail -1

@@ -25,7 +25,7 @@ ball = spawnBall(None, dict(uniforms=dict(radius=0.3, speed=0.005)))
 print("spawn-ball      best %.3f ms mean %.3f" % timed(lambda: ball.spawn(t)))
 fs = PixelSpawner(None, dict(shader=flow_sample_frag(), buffer=t.flow))
 print("flow best-sample best %.3f ms mean %.3f" % timed(lambda: fs.spawn(t)))
-ds = PixelSpawner(None, dict(shader=data_sample_frag(), buffer=t.particles))
+ds = PixelSpawner(None, dict(shader=data_sample_frag(), buffer=t.particles.buffers[0]))      # (src/demo.main.js:433-441: a ring buffer as the data texture)
 try:
     print("data best-sample best %.3f ms mean %.3f" % timed(lambda: ds.spawn(t)))
 except Exception as e:
