@@ -216,6 +216,48 @@ def test_sharded_bins_over_drifting_rows_and_packed_rings(n, world, fmt, sorted_
         t.dispose()
 
 
+@pytest.mark.parametrize("bands,pipeline,fmt", [([(0, 53), (53, 47)], "bins", "f32"), ([(0, 53), (53, 6), (59, 41)], "bins", "f32"),
+                                                ([(0, 53), (53, 6), (59, 41)], "stream", "f32"), ([(0, 53), (53, 47)], "bins", "f16")])
+def test_a_drifting_row_at_the_edge_of_its_band_reads_the_neighbours_last_row(bands, pipeline, fmt):
+    """100 x 100 particles: the vertices of rows 53 and 59 read the row ABOVE.  With bands that begin exactly there the row a line
+    reads is the LAST row of the rank below: it arrives as a halo row - through the bins picked out of that rank's slot order
+    (bins_edge_rows_kernel over th::LineSources), through the stream-ordered pass straight from texel order - and the lines of a
+    band's first row are made of another rank's particles.  (Balanced bands of 34 / 33 / 33 rows keep both lookups inside band 1:
+    the other tests exchange edge rows nobody reads.)"""
+    from tendrils_amd import sharding
+    n, view, world = 100, (16, 9), len(bands)
+    cur, prev, base = inputs(n, view, 1234 + world)
+    one = make(n, view, cur, prev, base, None, fmt)
+    if fmt == "f16":
+        cur, prev = one.particles.read(0), one.particles.read(1)
+    ident = sharding.loopback_id()
+    shards = [make(n, view, cur, prev, base, band, fmt) for band in bands]
+    _, err = in_threads(world, lambda r: sharding.comm_join(shards[r].particles._ctx, ident, r, world))
+    assert err == [None] * world, err
+    everybody = [one] + shards
+    for t in everybody:
+        t.particles.draw_pipeline(pipeline)
+        t.particles.option("bucket", 1 if pipeline == "bins" else 0)
+        t.particles.option("resort_steps", 2)
+        t.state["noiseWeight"] = 0.0005
+    for frame in range(3):
+        for t in everybody:
+            t.timer.tick()
+            t.step()
+        one.draw()
+        frags, err = in_threads(world, lambda r: sharding.draw_sharded_native(shards[r], view=True))
+        assert err == [None] * world, err
+        assert sum(frags) == one.fragments > 500
+        want_flow, want_view = one.flow.read(), one.read_view()
+        for t in shards:
+            assert last_pipeline(t) == (1 if pipeline == "bins" else 0)
+            assert bits_equal(t.flow.read(), want_flow).all()
+            assert (t.read_view() == want_view).all()
+    # (the lines in question do draw: without the halo rows the emit refuses the pass - "looks up a particle row outside the band")
+    for t in everybody:
+        t.dispose()
+
+
 @pytest.mark.parametrize("how", ["flow pass only", "two widths"])
 def test_sharded_bins_pass_by_pass(how):
     """Tendrils.draw() of band contexts (the library's exchange, through the bins) when the passes do not share one
