@@ -122,6 +122,36 @@ def test_export_lines_matches_oracle(oracle):
     assert bits_equal(got, want).all()
 
 
+def test_export_lines_of_a_packed_ring_are_those_of_what_it_decodes_to(oracle):
+    """TH_STATE_F16: the trail export reads the ring in place (dep_state) - the lines of the decoded texels, bit for bit, with and
+    without the view pass's colours; n = 100: rows whose vertices are other particles."""
+    import tendrils_amd as ta
+    from tendrils_amd.tendrils import View
+    n, view = 100, (96, 54)
+    rng = np.random.default_rng(16)
+    prev = np.zeros((n, n, 4), np.float32)
+    prev[..., :2] = rng.uniform(-1.2, 1.2, (n, n, 2))
+    prev[..., 2:] = rng.uniform(-.012, .012, (n, n, 2))
+    cur = prev.copy()
+    cur[..., :2] += rng.uniform(-.05, .05, (n, n, 2)).astype(np.float32)
+    cur[rng.random((n, n)) < 0.1] = [-1e6, -1e6, 0, 0]
+    opts = ta.defaults()
+    opts.update(stateFormat=ta._capi.TH_STATE_F16)
+    t = ta.Tendrils(View(*view), opts)
+    t.resize()
+    t.setup(n)
+    t.particles.upload_texels(cur, 0)
+    t.particles.upload_texels(prev, 1)
+    t.timer.time = 321.0
+    got = t.export_lines()
+    cur16, prev16 = t.particles.read(0), t.particles.read(1)        # what the ring decodes to
+    t.dispose()
+    assert not bits_equal(cur16, cur).all()
+    want = oracle.export_lines(cur16, prev16, 321.0, view_size=(1.0, 96 / 54))
+    assert got.shape == want.shape and 3000 < len(got) < n * n
+    assert bits_equal(got, want).all()
+
+
 def test_closed_loop_against_reference_frames():
     """The reference's own K = 6 frames of step() + draw() against the GPU frame loop (tolerances of
     tests/test_deposit_oracle.py:loop_close; the first frame is bit-exact)."""
