@@ -537,11 +537,20 @@ TH_D void bins_span_lines(const DepositParams &p, uint32_t block, uint32_t block
     float *words = scratch + wave * 128u;                // per wave: the clipped polygon (48 words), then 64 row starts
     uint32_t *starts = reinterpret_cast<uint32_t *>(words + 48);
     LdsWords<1> w{words};                                // (every lane of the wave computes the same polygon into the same words)
-    const uint32_t seg = block & (kDepLists - 1u), part = block / kDepLists, parts = blocks / kDepLists;
+    const uint32_t seg = block & (kDepLists - 1u);
     const uint32_t n = p.list_n[(kListSpan * kDepLists + seg) * kDepListStride];
     const uint32_t *list = p.lists + ((size_t)kListSpan * kDepLists + seg) * p.list_cap;
     const uint32_t rep = seg & (kBinReplicas - 1u);
-    for (uint32_t e = part * 4u + wave; e < n; e += parts * 4u) {
+    // the segment's lines are TAKEN, one at a time, by whichever wave of the segment's workgroups is free (the word beside the
+    // segment's counter, zero when the pass starts): a line is a few dozen fragments or a few thousand, and dealt out in turn the
+    // launch lasted as long as the wave with the longest lines (bins_span_kernel 803 -> us at 8192 x 8192 particles)
+    uint32_t *next = &p.list_n[(kListSpan * kDepLists + seg) * kDepListStride + 1u];
+    (void)blocks;
+    for (;;) {
+        uint32_t e = 0;
+        if (lane == 0u) e = atomicAdd(next, 1u);
+        e = (uint32_t)__shfl((int)e, 0);
+        if (e >= n) break;
         const uint32_t s = list[e];
         uint32_t col, row;
         slot_particle(p, s, col, row);
@@ -581,7 +590,14 @@ TH_D void bins_span_lines(const DepositParams &p, uint32_t block, uint32_t block
                     const int X1 = swap ? Xb : Xa, Y1 = swap ? Yb : Ya, X2 = swap ? Xa : Xb, Y2 = swap ? Ya : Yb;
                     if (y < ((Y1 + 15) >> 4) || y >= ((Y2 + 15) >> 4)) continue;
                     const long long DX = X2 - X1, DY = Y2 - Y1;
-                    long long x = dep_ceil_div(DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, 16 * DY);
+                    // ceil(num / den), den > 0, |num| < 2^53: the quotient estimated in fp64 (within one of the floor), the remainder
+                    // decides - dep_ceil_div's integer, without a 64-bit integer division per edge and row (software: hundreds of
+                    // dependent instructions, most of this kernel's arithmetic)
+                    const long long num = DX * (((long long)y << 4) - Y1) + (long long)X1 * DY, den = 16 * DY;
+                    long long q = (long long)__builtin_floor((double)num / (double)den), rem = num - q * den;
+                    if (rem < 0) { --q; rem += den; }
+                    if (rem >= den) { ++q; rem -= den; }
+                    long long x = rem > 0 ? q + 1 : q;
                     x = x < 0 ? 0 : (x > p.fw ? p.fw : x);
                     if (swap) right = (int)x; else left = (int)x;
                 }
@@ -2030,7 +2046,7 @@ void launch_bins_fused(const DepositParams &p, hipStream_t s)
     if (!p.packed && !p.src.row_index) hipLaunchKernelGGL((bins_fused_kernel<256u, true, true>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((bins_fused_kernel<256u, true, false>), dim3(blocks ? blocks : 1u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bins_listed_kernel, dim3(2u * kDepLists * 6u), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bins_span_kernel, dim3(kDepLists * (p.src.row_index ? 32u : 4u)), dim3(256), 0, s, p);      // (drifting lookups: tens of thousands of them)
+    hipLaunchKernelGGL(bins_span_kernel, dim3(kDepLists * (p.src.row_index ? 32u : 4u)), dim3(256), 0, s, p);      // (drifting lookups: tens of thousands of them; the lines are taken from a queue)
     hipLaunchKernelGGL(bins_plan_kernel, dim3((p.nbins + 255u) / 256u), dim3(256), 0, s, p);
     hipLaunchKernelGGL(crowd_plan_kernel, dim3(1), dim3(1024), 0, s, p);
 }
